@@ -1,0 +1,154 @@
+"""The oracle (oracle/*.py, our fp32 CPU restatement) against outputs of the
+REFERENCE ITSELF captured in tests/golden/*.npz by oracle/gen_golden.py.
+CPU only; runs in seconds."""
+import pytest
+import torch
+
+from ming_univision_amd import configuration as C
+from ming_univision_amd.synth import synth_state_dict
+from oracle import bailing_ref, mingtok_ref, rf_ref
+from tests.util import checksum, llm_sd, load_golden, mingtok_sd, rel_err
+
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def mt():
+    g = load_golden("mingtok_tiny")
+    sd = mingtok_sd(g["config"], g["seed"])
+    assert abs(checksum(sd) - g["checksum"]) < 1e-6 * g["checksum"], "synthetic-weight RNG drifted"
+    return g, sd
+
+
+def test_mingtok_encoder_tokens(mt):
+    g, sd = mt
+    assert rel_err(mingtok_ref.encoder_prepare_tokens(g["img"], sd), g["enc_tokens"]) < TOL
+    # 128x128 input on a 64x64-trained pos-embed: bicubic interpolation with the +0.1 kludge
+    assert rel_err(mingtok_ref.encoder_prepare_tokens(g["img2"], sd), g["enc_tokens2"]) < TOL
+
+
+def test_mingtok_encoder_block(mt):
+    g, sd = mt
+    y = mingtok_ref.block(g["enc_tokens"], sd, "low_level_encoder.blocks.0.0", 2)
+    assert rel_err(y, g["enc_block0"]) < TOL
+
+
+def test_mingtok_forward(mt):
+    g, sd = mt
+    assert rel_err(mingtok_ref.encoder_forward(g["img"], sd), g["latent_raw"]) < TOL
+    out = mingtok_ref.mingtok_forward(g["img"], sd)
+    assert rel_err(out["latent"], g["latent"]) < TOL
+    assert rel_err(out["x_norm_patchtokens"], g["sem"]) < TOL
+    out2 = mingtok_ref.mingtok_forward(g["img2"], sd)
+    assert rel_err(out2["latent"], g["latent2"]) < TOL
+    assert rel_err(out2["x_norm_patchtokens"], g["sem2"]) < TOL
+
+
+def test_mingtok_pixel_decoder(mt):
+    g, sd = mt
+    assert rel_err(mingtok_ref.sem_to_pix(g["sem"], sd) if False else
+                   torch.nn.functional.linear(g["sem"], sd["sem_to_pix.weight"], sd["sem_to_pix.bias"]),
+                   g["sem_to_pix"]) < TOL
+    assert rel_err(mingtok_ref.pixel_decoder_forward(g["sem"], sd), g["recon"]) < TOL
+    assert rel_err(mingtok_ref.mingtok_forward_enc_dec(g["img2"], sd), g["recon2"]) < TOL
+
+
+def test_mingtok_cached_decode(mt):
+    g, sd = mt
+    caches = mingtok_ref.semdec_new_cache(sd)
+    outs = []
+    for i in range(g["dec_latent_norm"].shape[1]):
+        outs.append(mingtok_ref.mingtok_feature_decoder_step(g["dec_latent_norm"][:, i:i + 1], sd, caches))
+    assert rel_err(torch.cat(outs, 1), g["dec_steps"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["rf_tiny", "rf_tiny16"])
+def test_rf_head(name):
+    g = load_golden(name)
+    sd_full = synth_state_dict(C.rf_param_shapes(64, 2, 64, 32, 4), g["seed"])
+    sd = {k[len("diffloss."):]: v for k, v in sd_full.items()}
+    assert abs(checksum(sd) - g["checksum"]) < 1e-6 * g["checksum"]
+    assert rel_err(rf_ref.time_embed(torch.tensor([1000.0, 937.5, 62.5]), sd), g["temb"]) < TOL
+    assert rel_err(rf_ref.net_forward(g["x"], g["t"], g["z"], sd), g["v"]) < TOL
+    n = g["noise"]
+    s3 = rf_ref.sample(g["z"], n[0:1], sd, steps=g["steps"])
+    assert rel_err(s3, g["sample3"]) < TOL
+    s2 = rf_ref.sample(g["z"][:2], n[1:2], sd, steps=g["steps"], temperature=g["sample2_temperature"])
+    assert rel_err(s2, g["sample2"]) < TOL
+    s1 = rf_ref.sample(g["z"][:1], n[2:3], sd, steps=g["steps"], text_cfg=1.0, image_cfg=1.0)
+    assert rel_err(s1, g["sample1"]) < TOL
+
+
+@pytest.fixture(scope="module")
+def llm():
+    g = load_golden("llm_tiny")
+    sd = llm_sd(g["config"], g["rf_config"], g["seed"])
+    assert abs(checksum(sd) - g["checksum"]) < 1e-6 * g["checksum"]
+    cfg = bailing_ref.LLMConfig(**{k: v for k, v in g["config"].items()
+                                   if k in bailing_ref.LLMConfig.__dataclass_fields__})
+    return g, sd, cfg
+
+
+def test_llm_pieces(llm):
+    g, sd, cfg = llm
+    xn = bailing_ref.rmsnorm(g["emb"], sd["model.layers.0.input_layernorm.weight"], cfg.rms_norm_eps)
+    assert rel_err(xn, g["x_norm"]) < TOL
+    x2 = g["moe_in"].reshape(-1, cfg.hidden_size)
+    ti, tw, _ = bailing_ref.gate(x2, sd["model.layers.0.mlp.gate.weight"], cfg)
+    assert torch.equal(ti, g["gate_idx"]) and rel_err(tw, g["gate_w"]) < TOL
+    ti, tw, _ = bailing_ref.gate(x2, sd["model.layers.0.mlp.image_gate.weight"], cfg)
+    assert torch.equal(ti, g["igate_idx"]) and rel_err(tw, g["igate_w"]) < TOL
+    y, (idx, _) = bailing_ref.moe_block(g["moe_in"], sd, "model.layers.0.mlp", cfg, g["moe_image_mask"].bool())
+    assert torch.equal(idx, g["moe_topk_idx"])
+    assert rel_err(y, g["moe_out"]) < TOL
+
+
+def test_llm_prefill_and_cfg_decode(llm):
+    g, sd, cfg = llm
+    kvs = bailing_ref.new_kv(cfg)
+    T = g["emb"].shape[1]
+    h = bailing_ref.model_forward(g["emb"], sd, cfg, torch.ones(1, T, dtype=torch.long), None, kvs,
+                                  g["image_mask"].bool())
+    assert rel_err(h, g["hidden"]) < TOL
+    assert rel_err(kvs[0]["k"], g["k0"]) < TOL and rel_err(kvs[1]["v"], g["v1"]) < TOL
+    assert rel_err(bailing_ref.lm_logits(h[:, -1:], sd), g["logits"]) < TOL
+    rows = 3
+    for kv in kvs:
+        kv["k"], kv["v"] = kv["k"].repeat(rows, 1, 1, 1), kv["v"].repeat(rows, 1, 1, 1)
+    am = g["dec_mask0"].clone()
+    for s in range(g["dec_in"].shape[0]):
+        pos = (am.cumsum(-1) - 1)[:, -1:]
+        hd = bailing_ref.model_forward(g["dec_in"][s], sd, cfg, am, pos, kvs)
+        assert rel_err(hd, g["dec_hidden"][s]) < TOL, s
+        am = torch.cat([am, torch.ones(rows, 1, dtype=torch.long)], 1)
+    assert rel_err(rf_ref.vis_head(hd[:, -1], sd), g["vis_z"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["rows3", "rows2"])
+def test_generate_image(tag):
+    g = load_golden("genimg_tiny")
+    sd = llm_sd(g["llm_config"], g["rf_config"], g["seed"])
+    tsd = mingtok_sd(g["mingtok_config"], g["seed"])
+    lsd = synth_state_dict(C.linear_proj_param_shapes(128, 256, 2), g["seed"])
+    assert abs(checksum(sd) + checksum(tsd) - g["checksum"]) < 1e-6 * g["checksum"]
+    cfg = bailing_ref.LLMConfig(**{k: v for k, v in g["llm_config"].items()
+                                   if k in bailing_ref.LLMConfig.__dataclass_fields__})
+    T = g["ids"].shape[1]
+    kvs = bailing_ref.new_kv(cfg)
+    emb = sd["model.word_embeddings.weight"][g["ids"]]
+    bailing_ref.model_forward(emb, sd, cfg, torch.ones(1, T, dtype=torch.long), None, kvs)
+    start = sd["model.word_embeddings.weight"][torch.tensor([[cfg.image_start_token]])]
+    caches = mingtok_ref.semdec_new_cache(tsd)
+    out = bailing_ref.generate_image(
+        start, kvs, g["mask"], g["uncond"], g[tag + "_tuncond"], sd, cfg, g["noises"],
+        latent_to_sem=lambda lat: mingtok_ref.mingtok_feature_decoder_step(lat, tsd, caches),
+        linear_proj=lambda s: bailing_ref.linear_proj(s, lsd),
+        sem_to_pix=lambda s: mingtok_ref.pixel_decoder_forward(s, tsd),
+        steps=int(g["rf_config"]["num_sampling_steps"]))
+    assert out["image"].shape == g[tag + "_image"].shape
+    assert rel_err(out["image"], g[tag + "_image"]) < 1e-4
+    assert rel_err(out["last_hidden"], g[tag + "_last_hidden"]) < 1e-4
+    assert torch.equal(out["attention_mask"], g[tag + "_mask_out"])
+    assert kvs[0]["k"].shape[2] == g[tag + "_cache_len"]
+    assert rel_err(kvs[0]["k"], g[tag + "_k0"]) < 1e-4
+    assert rel_err(bailing_ref.lm_logits(out["last_hidden"][0:1], sd), g[tag + "_logits"]) < 1e-4
