@@ -1,0 +1,277 @@
+/*
+ * mingnative.h — C ABI of libmingnative.so: the MI355X (gfx950) native hot path of
+ * Ming-UniVision (MingTok-Vision tokenizer -> Bailing-MoE next-token forward ->
+ * rectified-flow SwiGLU head -> MingTok decode).
+ *
+ * The reference has no FFI: the path is PyTorch module calls that dispatch into
+ * third-party GPU kernels (cuBLAS/cuDNN/flash-attn).  Every entry
+ * point below replaces one of those call sites; the reference file:line is cited
+ * per function (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - All pointers are DEVICE pointers unless the name ends in _host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - Launchers never allocate, never synchronise, never throw: they enqueue work
+ *     on `stream` and return 0, or a negative MN_E* code (see mn_last_error()).
+ *   - Weights are bf16 (uint16_t bit patterns) in the reference's nn.Linear layout
+ *     [out_features, in_features] row-major unless stated.  Small-row ("decode")
+ *     activations are fp32; batched (MFMA) activations are bf16 with fp32 accumulate.
+ */
+#ifndef MINGNATIVE_H
+#define MINGNATIVE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MN_VERSION 100 /* 0.1.0 */
+
+enum {
+  MN_OK = 0,
+  MN_EINVAL = -1,   /* bad argument (shape / alignment / enum) */
+  MN_ELAUNCH = -2,  /* hip launch failure, see mn_last_error() */
+  MN_ENOSPACE = -3  /* workspace too small */
+};
+
+int mn_version(void);
+const char* mn_last_error(void);
+/* Number of compute units of the current device (host query, cached). */
+int mn_num_cus(void);
+
+/* ------------------------------------------------------------------------------------------
+ * 1. Skinny GEMM (M <= 8 rows): out = epilogue( prologue(x) @ W^T + bias )
+ *    Weight-streaming, HBM-bound.  Replaces every nn.Linear call with <= 8 rows on the
+ *    decode path: modeling_bailing_moe.py:760,824 (query_key_value / dense), :483-484
+ *    (expert / shared-expert MLPs), :1551 (lm_head), :1571-1574 (vis_head);
+ *    diff_loss_rf_swiglu.py:27-34,194-198,263-266,282-286,324-326 (RF head);
+ *    mingtok layers/attention.py:49-51, layers/swiglu_ffn.py:27-28 (semantic-decoder decode step);
+ *    modeling_bailingmm.py:111-115 (linear_proj).
+ * ------------------------------------------------------------------------------------------ */
+enum mn_prologue {
+  MN_PRO_NONE = 0,
+  MN_PRO_SILU = 1,      /* x' = silu(x) */
+  MN_PRO_ADD_SILU = 2,  /* x' = silu(x + pro_a)          (adaLN input SiLU(t_emb + c), diff_loss_rf_swiglu.py:263-266,376) */
+  MN_PRO_RMSNORM = 3,   /* x' = x * rsqrt(mean(x^2)+eps) * ln_g   (BailingMoeRMSNorm, modeling_bailing_moe.py:131-136) */
+  MN_PRO_LN = 4,        /* x' = LayerNorm(x; ln_g, ln_b, eps)     (nn.LayerNorm eps=1e-6) */
+  MN_PRO_LN_MOD = 5     /* x' = LayerNorm(x; ln_g?, ln_b?, eps) * (1 + pro_b) + pro_a   (modulate, diff_loss_rf_swiglu.py:184-185,270,290) */
+};
+enum mn_epilogue {
+  MN_EPI_NONE = 0,
+  MN_EPI_SILU = 1,
+  MN_EPI_GELU = 2,        /* exact erf GELU (nn.GELU default) */
+  MN_EPI_SWIGLU = 3,      /* out[n] = silu(y[n]) * y[n + N]; W and bias hold 2N rows (chunk(2), swiglu_ffn.py:30-34) */
+  MN_EPI_RESID = 4,       /* out = res + y */
+  MN_EPI_RESID_GATE = 5   /* out = res + gate * y   (ResBlock, diff_loss_rf_swiglu.py:272) */
+};
+
+typedef struct mn_skinny_args {
+  const float* x;      int64_t ldx;    /* [M, K] fp32 (per batch entry) */
+  const uint16_t* w;   int64_t ldw;    /* bf16 [N or 2N, K]; row stride ldw elements */
+  const uint16_t* bias;                /* bf16 [N or 2N] or NULL */
+  float* out;          int64_t ldo;    /* [M, N] fp32 */
+  int32_t M, N, K;                     /* 1 <= M <= 8; K % 8 == 0 (K is per segment when nseg > 1) */
+  int32_t prologue, epilogue;
+  const float* pro_a;  int64_t ld_pro_a; /* ADD_SILU: addend [K] (ld 0) or [M,K]; LN_MOD: shift [M,K] */
+  const float* pro_b;  int64_t ld_pro_b; /* LN_MOD: scale [M,K] */
+  const uint16_t* ln_g; const uint16_t* ln_b; /* bf16 [K] norm gain / bias (NULL = none) */
+  float eps;
+  const float* res;    int64_t ldres;  /* RESID / RESID_GATE */
+  const float* gate;   int64_t ldgate; /* RESID_GATE */
+  /* Batching over independent problems that differ in weights (MoE experts):
+   * entry b uses W + w_index[b]*w_batch_stride (w_index NULL -> b), x + (b / x_batch_div)*x_batch_stride,
+   * out + b*out_batch_stride, res + b*res_batch_stride.  batch <= 0 means 1. */
+  int32_t batch; const int32_t* w_index; int64_t w_batch_stride;
+  int64_t x_batch_stride; int32_t x_batch_div; int64_t out_batch_stride; int64_t res_batch_stride;
+  /* K-segments (MoE down-projection summed over the experts of one token):
+   * y = sum_s seg_scale[b*nseg+s] * x[:, s*K:(s+1)*K] @ W[seg_index[b*nseg+s]]^T ; nseg <= 0 means 1. */
+  int32_t nseg; const int32_t* seg_index; const float* seg_scale; int64_t seg_w_stride;
+} mn_skinny_args;
+
+int mn_skinny_gemm(const mn_skinny_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 2. MoE router: RMSNorm + gate GEMV + fp32 softmax + top-k + renormalise, with the
+ *    image-gate override on rows flagged by image_mask.
+ *    Replaces BailingMoeGate.forward (modeling_bailing_moe.py:505-520) and the multi-gate blend
+ *    of BailingMoeSparseMoeBlock.forward (:565-592).  num_experts <= 64, top_k <= 8.
+ *      x [M,H] fp32 (pre-norm residual stream), norm_w bf16 [H]
+ *      gate_w / image_gate_w bf16 [E,H]; image_mask uint8 [M] or NULL
+ *      -> x_norm [M,H] fp32 (the normalised rows, input of the experts)
+ *         topk_idx int32 [M, n_slot], topk_w fp32 [M, n_slot] where
+ *         n_slot = top_k + n_shared_slots; the trailing shared slots are filled with
+ *         (E + j, 1.0) so that shared experts ride the same grouped GEMV.
+ * ------------------------------------------------------------------------------------------ */
+int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w, float eps,
+                  const uint16_t* gate_w, const uint16_t* image_gate_w, const uint8_t* image_mask,
+                  int M, int H, int E, int top_k, int norm_topk_prob, int n_shared_slots,
+                  float* x_norm, int32_t* topk_idx, float* topk_w, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 3. RoPE + KV-cache append, and masked GQA / MHA decode attention.
+ *    Replaces apply_rotary_pos_emb + DynamicCache.update + the eager/flash attention of
+ *    BailingMoeAttention.forward (modeling_bailing_moe.py:428-461, 768-812) and, with
+ *    rope = 0, CausalAttention.forward + cache (mingtok layers/attention.py:138-163).
+ *
+ *    KV cache layout: fp32 [n_seq][2 (k,v)][n_kv_heads][t_max][head_dim].
+ *    qkv [M, (n_q + 2 n_kv) * hd] fp32, heads ordered q.., k.., v.. (qkv.split, :762-764); the ViT
+ *    layout [3][n_heads][hd] (attention.py:140) is the same ordering with n_q == n_kv.
+ *    row_seq[m]: cache sequence of row m; row_slot[m]: cache slot to write; row_pos[m]: rotary
+ *    position (cumsum(mask)-1, :1905).  cos/sin tables fp32 [n_pos, hd/2].
+ *    q_out [M, n_q*hd] fp32 receives rotated (and scaled by q_scale) queries.
+ * ------------------------------------------------------------------------------------------ */
+int mn_rope_kv_append(const float* qkv, int64_t ldqkv, int M, int n_q, int n_kv, int hd,
+                      int rope, const float* cos_tab, const float* sin_tab,
+                      const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_pos,
+                      float q_scale, float* q_out, float* kv_cache, int64_t t_max, void* stream);
+
+/*    out[m] = softmax(q[m] . K[seq]^T + mask) V[seq] over keys j < row_len[m] with
+ *    key_mask[m*ld_mask + j] != 0 (key_mask NULL = all ones; a row with every key masked is undefined).
+ *    q is pre-scaled.  out [M, n_q*hd] fp32.  The key range is split over workgroups
+ *    (flash-decoding); workspace holds the per-split partials. */
+size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t t_max);
+int mn_attn_decode(const float* q, int M, int n_q, int n_kv, int hd, const float* kv_cache, int64_t t_max,
+                   const int32_t* row_seq, const int32_t* row_len, const uint8_t* key_mask, int64_t ld_mask,
+                   float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 4. Batched (MFMA) path: bf16 GEMM with fused epilogues, LayerNorm, flash attention hd=64.
+ *    Replaces nn.Linear / nn.LayerNorm / flash_attn_func in the MingTok ViT blocks
+ *    (layers/block.py:80-105, layers/attention.py:78-108,213-239, layers/mlp.py:34-40,
+ *    layers/swiglu_ffn.py:30-34) and the step-invariant adaLN GEMM of the RF head.
+ * ------------------------------------------------------------------------------------------ */
+enum mn_gemm_epilogue {
+  MN_GEMM_BF16 = 0,        /* C bf16 = A W^T + bias */
+  MN_GEMM_BF16_GELU = 1,   /* C bf16 = gelu(A W^T + bias) */
+  MN_GEMM_F32 = 2,         /* C fp32 = A W^T + bias */
+  MN_GEMM_F32_RESID = 3    /* C fp32 += A W^T + bias   (residual stream accumulate) */
+};
+/* A bf16 [M,K] (lda), W bf16 [N,K] (ldw), bias bf16 [N] or NULL, C [M,N] (ldc). K % 32 == 0. */
+int mn_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias,
+                 void* C, int64_t ldc, int M, int N, int K, int epilogue, void* stream);
+
+/* y bf16 [M,D] = LayerNorm(x fp32 [M,D]; g,b bf16, eps) ; optional GELU afterwards (encoder out layer,
+ * vision_transformer.py:173-178). */
+int mn_layernorm_bf16(const float* x, int64_t ldx, const uint16_t* g, const uint16_t* b, float eps,
+                      uint16_t* y, int64_t ldy, int M, int D, int gelu, void* stream);
+
+/* h bf16 [M,H] = silu(x12[:, :H]) * x12[:, H:]   (x12 bf16 [M,2H]) */
+int mn_swiglu_bf16(const uint16_t* x12, int64_t ldx, uint16_t* h, int64_t ldh, int M, int H, void* stream);
+
+/* Flash attention, head_dim 64, bf16 in/out, fp32 softmax.
+ * qkv bf16 [B, T, 3, n_heads, 64] (the reshape of attention.py:83,98); out bf16 [B, T, n_heads*64].
+ * causal: 0 = bidirectional (Attention / MemEffAttention), 1 = causal (MemEffCausalAttention). */
+int mn_attn_prefill_hd64(const uint16_t* qkv, uint16_t* out, int B, int T, int n_heads, int causal, void* stream);
+
+/* Small fp32 elementwise helpers of the ViT glue (all [M, D] row-major contiguous):
+ *   mn_add_bcast_f32    out[i] = a[i] + b[i % period]     (+pos-embed, vision_transformer.py:222)
+ *   mn_group_mean_add   out[m,c] = y[m,c] + mean_g x[m, c*G + g], G = D/C   (encoder out shortcut, :174)
+ *   mn_repeat_add       out[m,n] = y[m,n] + s[m, n / (D/C)] * scale + shift   (decoder in shortcut, :375-379)
+ *   mn_clamp_f32        x = clamp(x, lo, hi) in place            (modeling_mingtok.py:194) */
+int mn_add_bcast_f32(const float* a, const float* b, float* out, int64_t n, int64_t period, void* stream);
+int mn_group_mean_add(const float* y, const float* x, float* out, int M, int D, int Cout, void* stream);
+int mn_repeat_add(const float* y, const float* s, float* out, int M, int D, int Cin, float scale, float shift, void* stream);
+int mn_clamp_f32(float* x, int64_t n, float lo, float hi, void* stream);
+
+/* fp32 <-> bf16 conversion and hi/lo split helpers (elementwise, n elements). */
+int mn_f32_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
+int mn_bf16_to_f32(const uint16_t* x, float* y, int64_t n, void* stream);
+/* hi = bf16(x), lo = bf16(x - hi): lets an fp32 activation go through the bf16 MFMA twice at fp32-class accuracy */
+int mn_f32_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 5. Composite device-side sequences (one C call = many launches, no host sync).
+ *    See the struct comments; Python builds these tables once at load time.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Rectified-flow head (RectifiedFlowLoss.sample, diff_loss_rf_swiglu.py:103-181, called from
+ * forward_for_image_generation_inner, modeling_bailing_moe.py:1659-1670). */
+typedef struct mn_rf_head {
+  int32_t w, depth, hidden, z_dim, target, steps, llm_hidden;
+  /* vis_head = Linear(llm_hidden->z) + LayerNorm(z) */
+  const uint16_t *vis_w, *vis_b, *vis_ln_g, *vis_ln_b;
+  const uint16_t *cond_w, *cond_b;        /* cond_embed [w, z] */
+  const uint16_t *in_w, *in_b;            /* input_proj [w, target] */
+  const float* temb;                      /* [steps, w] fp32: time_embed(t_s * 1000), precomputed at load */
+  /* all adaLN projections stacked: rows [depth*3w + 2w, w] = blocks' (shift,scale,gate) then final (shift,scale) */
+  const uint16_t *ada_w, *ada_b;
+  const uint16_t* const* ln_g;  const uint16_t* const* ln_b;   /* [depth] in_ln */
+  const uint16_t* const* w12;   const uint16_t* const* b12;    /* [depth] [2*hidden, w] */
+  const uint16_t* const* w3;    const uint16_t* const* b3;     /* [depth] [w, hidden] */
+  const uint16_t *fin_w, *fin_b;          /* final_layer.linear [target, w] */
+} mn_rf_head;
+
+/* hidden [rows, llm_hidden] fp32 (last hidden state of the LLM step), noise [target] fp32.
+ * rows = 1 (no CFG), 2 ([cond, uncond]) or 3 ([cond, uncond, text_uncond]).
+ * latent_out [target] fp32 (all CFG rows carry the same latent).  Workspace: mn_rf_workspace_bytes. */
+size_t mn_rf_workspace_bytes(const mn_rf_head* h, int rows);
+int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld_hidden, int rows, const float* noise,
+                 float temperature, float text_cfg, float image_cfg, float* latent_out,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* Bailing-MoE decoder stack, decode-style step for M <= 8 rows
+ * (BailingMoeModel.forward, modeling_bailing_moe.py:1391-1540, with q_len rows per sequence). */
+typedef struct mn_llm {
+  int32_t hidden, n_layers, n_q, n_kv, head_dim, n_experts, top_k, n_shared_slots, moe_inter;
+  int32_t norm_topk_prob;
+  float rms_eps;
+  const uint16_t* const* ln1;        /* [L] input_layernorm [H] */
+  const uint16_t* const* wqkv;       /* [L] [(nq+2nkv)*hd, H] */
+  const uint16_t* const* wdense;     /* [L] [H, nq*hd] */
+  const uint16_t* const* ln2;        /* [L] post_attention_layernorm */
+  const uint16_t* const* gate;       /* [L] [E, H] */
+  const uint16_t* const* image_gate; /* [L] [E, H] or NULL entries */
+  const uint16_t* const* w_gate_up;  /* [L] [E + n_shared_slots, 2*I, H]: rows 0..I-1 gate_proj, I..2I-1 up_proj */
+  const uint16_t* const* w_down;     /* [L] [E + n_shared_slots, H, I] */
+  const uint16_t* final_norm;        /* [H] */
+  const float *cos_tab, *sin_tab;    /* [n_pos, hd/2] */
+  int32_t n_pos;
+} mn_llm;
+
+size_t mn_llm_workspace_bytes(const mn_llm* m, int rows, int64_t t_max);
+/* x [M,H] fp32 in (embeddings; row stride ldx, ldx == 0 broadcasts one row to all M rows)
+ * -> hidden_out [M,H] fp32 (after the final RMSNorm).
+ * kv_cache: fp32 [n_layers][n_seq][2][n_kv][t_max][hd]; per-row int32 device arrays as in
+ * mn_rope_kv_append / mn_attn_decode (row_len = row_slot + 1 is computed by the caller). */
+int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int M, const uint8_t* image_mask,
+                const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len,
+                const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
+                float* hidden_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* a[i] += delta, b[i] += delta, c[i] += delta for i < M (any pointer may be NULL): advances the
+ * device-resident row_slot / row_pos / row_len arrays between autoregressive steps without a host round trip. */
+int mn_rows_advance(int32_t* a, int32_t* b, int32_t* c, int M, int delta, void* stream);
+
+/* MingTok semantic decoder, cached causal decode step for M <= 8 rows of ONE sequence each
+ * (MingTok.forward_feature_decoder, modeling_mingtok.py:165-174 -> TransformerDecoder.forward_features,
+ * vision_transformer.py:382-451) followed by linear_proj (modeling_bailingmm.py:111-115). */
+typedef struct mn_semdec {
+  int32_t dim, depth, n_heads, hidden, in_dim, proj_dim, proj_depth;
+  float mean, scale;
+  const uint16_t *in_w, *in_b;
+  const uint16_t* const* ln1_g; const uint16_t* const* ln1_b;
+  const uint16_t* const* wqkv;  const uint16_t* const* bqkv;
+  const uint16_t* const* wproj; const uint16_t* const* bproj;
+  const uint16_t* const* ln2_g; const uint16_t* const* ln2_b;
+  const uint16_t* const* w12;   const uint16_t* const* b12;
+  const uint16_t* const* w3;    const uint16_t* const* b3;
+  const uint16_t *norm_g, *norm_b;
+  const uint16_t* const* proj_w; const uint16_t* const* proj_b;  /* [proj_depth] linear_proj layers */
+} mn_semdec;
+
+size_t mn_semdec_workspace_bytes(const mn_semdec* s, int rows, int64_t t_max);
+/* latent_norm [M, in_dim] fp32 (normalised latent from the RF head) -> sem_out [M, dim] fp32 (x_norm),
+ * embed_out [M, proj_dim] fp32 (linear_proj(sem)), either may be NULL.
+ * kv_cache fp32 [depth][n_seq][2][n_heads][t_max][64]. */
+int mn_semdec_step(const mn_semdec* s, const float* latent_norm, int M,
+                   const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_len,
+                   float* kv_cache, int n_seq, int64_t t_max, float* sem_out, float* embed_out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINGNATIVE_H */

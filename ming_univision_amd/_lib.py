@@ -1,0 +1,158 @@
+"""ctypes binding of libmingnative.so (the C ABI declared in include/mingnative.h).
+
+The library is the product: there is NO fallback.  If the shared object is missing
+or cannot be loaded, `lib()` raises and every operator of this package fails loudly.
+Build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C ming_univision_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmingnative.so")
+
+c_bf16_p = C.c_void_p
+c_f32_p = C.c_void_p
+c_i32_p = C.c_void_p
+c_u8_p = C.c_void_p
+
+
+class SkinnyArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64),
+        ("w", C.c_void_p), ("ldw", C.c_int64),
+        ("bias", C.c_void_p),
+        ("out", C.c_void_p), ("ldo", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("prologue", C.c_int32), ("epilogue", C.c_int32),
+        ("pro_a", C.c_void_p), ("ld_pro_a", C.c_int64),
+        ("pro_b", C.c_void_p), ("ld_pro_b", C.c_int64),
+        ("ln_g", C.c_void_p), ("ln_b", C.c_void_p),
+        ("eps", C.c_float),
+        ("res", C.c_void_p), ("ldres", C.c_int64),
+        ("gate", C.c_void_p), ("ldgate", C.c_int64),
+        ("batch", C.c_int32), ("w_index", C.c_void_p), ("w_batch_stride", C.c_int64),
+        ("x_batch_stride", C.c_int64), ("x_batch_div", C.c_int32), ("out_batch_stride", C.c_int64),
+        ("res_batch_stride", C.c_int64),
+        ("nseg", C.c_int32), ("seg_index", C.c_void_p), ("seg_scale", C.c_void_p), ("seg_w_stride", C.c_int64),
+    ]
+
+
+PP = C.POINTER(C.c_void_p)
+
+
+class RfHead(C.Structure):
+    _fields_ = [
+        ("w", C.c_int32), ("depth", C.c_int32), ("hidden", C.c_int32), ("z_dim", C.c_int32),
+        ("target", C.c_int32), ("steps", C.c_int32), ("llm_hidden", C.c_int32),
+        ("vis_w", C.c_void_p), ("vis_b", C.c_void_p), ("vis_ln_g", C.c_void_p), ("vis_ln_b", C.c_void_p),
+        ("cond_w", C.c_void_p), ("cond_b", C.c_void_p),
+        ("in_w", C.c_void_p), ("in_b", C.c_void_p),
+        ("temb", C.c_void_p),
+        ("ada_w", C.c_void_p), ("ada_b", C.c_void_p),
+        ("ln_g", PP), ("ln_b", PP), ("w12", PP), ("b12", PP), ("w3", PP), ("b3", PP),
+        ("fin_w", C.c_void_p), ("fin_b", C.c_void_p),
+    ]
+
+
+class Llm(C.Structure):
+    _fields_ = [
+        ("hidden", C.c_int32), ("n_layers", C.c_int32), ("n_q", C.c_int32), ("n_kv", C.c_int32),
+        ("head_dim", C.c_int32), ("n_experts", C.c_int32), ("top_k", C.c_int32), ("n_shared_slots", C.c_int32),
+        ("moe_inter", C.c_int32), ("norm_topk_prob", C.c_int32),
+        ("rms_eps", C.c_float),
+        ("ln1", PP), ("wqkv", PP), ("wdense", PP), ("ln2", PP), ("gate", PP), ("image_gate", PP),
+        ("w_gate_up", PP), ("w_down", PP),
+        ("final_norm", C.c_void_p),
+        ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p),
+        ("n_pos", C.c_int32),
+    ]
+
+
+class SemDec(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int32), ("depth", C.c_int32), ("n_heads", C.c_int32), ("hidden", C.c_int32),
+        ("in_dim", C.c_int32), ("proj_dim", C.c_int32), ("proj_depth", C.c_int32),
+        ("mean", C.c_float), ("scale", C.c_float),
+        ("in_w", C.c_void_p), ("in_b", C.c_void_p),
+        ("ln1_g", PP), ("ln1_b", PP), ("wqkv", PP), ("bqkv", PP), ("wproj", PP), ("bproj", PP),
+        ("ln2_g", PP), ("ln2_b", PP), ("w12", PP), ("b12", PP), ("w3", PP), ("b3", PP),
+        ("norm_g", C.c_void_p), ("norm_b", C.c_void_p),
+        ("proj_w", PP), ("proj_b", PP),
+    ]
+
+
+_lib = None
+
+# every symbol include/mingnative.h declares: (name, restype, argtypes)
+_i, _i64, _f, _p, _sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+SYMBOLS = {
+    "mn_version": (_i, []),
+    "mn_last_error": (C.c_char_p, []),
+    "mn_num_cus": (_i, []),
+    "mn_skinny_gemm": (_i, [C.POINTER(SkinnyArgs), _p]),
+    "mn_moe_router": (_i, [_p, _i64, _p, _f, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "mn_rope_kv_append": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _i64, _p]),
+    "mn_attn_decode_workspace_bytes": (_sz, [_i, _i, _i, _i64]),
+    "mn_attn_decode": (_i, [_p, _i, _i, _i, _i, _p, _i64, _p, _p, _p, _i64, _p, _p, _sz, _p]),
+    "mn_gemm_bf16": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _i, _i, _i, _i, _p]),
+    "mn_layernorm_bf16": (_i, [_p, _i64, _p, _p, _f, _p, _i64, _i, _i, _i, _p]),
+    "mn_swiglu_bf16": (_i, [_p, _i64, _p, _i64, _i, _i, _p]),
+    "mn_attn_prefill_hd64": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "mn_f32_to_bf16": (_i, [_p, _p, _i64, _p]),
+    "mn_bf16_to_f32": (_i, [_p, _p, _i64, _p]),
+    "mn_f32_split_bf16": (_i, [_p, _p, _p, _i64, _p]),
+    "mn_rf_workspace_bytes": (_sz, [C.POINTER(RfHead), _i]),
+    "mn_rf_sample": (_i, [C.POINTER(RfHead), _p, _i64, _i, _p, _f, _f, _f, _p, _p, _sz, _p]),
+    "mn_llm_workspace_bytes": (_sz, [C.POINTER(Llm), _i, _i64]),
+    "mn_llm_step": (_i, [C.POINTER(Llm), _p, _i64, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _i, _i64, _p, _p, _sz, _p]),
+    "mn_rows_advance": (_i, [_p, _p, _p, _i, _i, _p]),
+    "mn_add_bcast_f32": (_i, [_p, _p, _p, _i64, _i64, _p]),
+    "mn_group_mean_add": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "mn_repeat_add": (_i, [_p, _p, _p, _i, _i, _i, _f, _f, _p]),
+    "mn_clamp_f32": (_i, [_p, _i64, _f, _f, _p]),
+    "mn_semdec_workspace_bytes": (_sz, [C.POINTER(SemDec), _i, _i64]),
+    "mn_semdec_step": (_i, [C.POINTER(SemDec), _p, _i, _p, _p, _p, _p, _i, _i64, _p, _p, _p, _sz, _p]),
+}
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `make -C {_HERE}/csrc` "
+            "(or __graft_entry__.build()). There is no CPU/PyTorch fallback.")
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(handle, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if handle.mn_version() < 100:
+        raise RuntimeError("libmingnative.so is too old")
+    _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().mn_last_error().decode(errors="replace")
+        raise RuntimeError(f"libmingnative {what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, or None."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    """A ctypes array of device pointers (host-side table the composite structs point to)."""
+    arr = (C.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+    return arr
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,280 @@
+"""Host-side mirror of the Bailing-MoE decoder stack and its image-generation loop.
+
+Mirrors BailingMoeModel.forward (modeling_bailing_moe.py:1391-1540), the lm_head
+(:1604-1620) and BailingMoeForCausalLM.generate_image (:1844-1965) for the hot-path
+configuration (rope_scaling=None -> Legacy rotary, first_k_dense_replace=0).
+All arithmetic runs in libmingnative; this module owns HBM residency:
+
+  * weights: bf16, reference names; the 64 routed experts and the shared expert of a layer
+    are re-packed ONCE at load into two grouped tensors
+        w_gate_up [E + S, 2I, H]  (rows 0..I-1 gate_proj, I..2I-1 up_proj)
+        w_down    [E + S, H, I]
+    where the shared expert (intermediate S*I) is split into S pseudo-experts E..E+S-1 that
+    every token selects with weight 1 (their partial down-projections add up to the shared
+    expert's output), so routed and shared experts ride the same two grouped launches.
+  * KV cache: one preallocated fp32 arena [L, n_seq, 2, n_kv, t_max, hd] instead of the
+    reference's torch.cat per layer per step (DynamicCache.update, :789).
+  * per-row bookkeeping (cache slot, rotary position, length, key mask) lives in device
+    int32/uint8 arrays that the kernels read, so the AR loop never syncs with the host.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+from ._lib import Llm, check, current_stream, lib, ptr, ptr_array
+from .configuration import BailingMoeConfig
+
+
+def rope_tables(head_dim, base, n_pos, device):
+    """cos/sin [n_pos, hd/2] fp32 — BailingMoeRotaryEmbeddingLegacy (modeling_bailing_moe.py:213-237);
+    a load-time table (emb = cat(freqs, freqs) so only the first half is stored)."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2).float() / head_dim))
+    t = torch.arange(n_pos, dtype=torch.float32)
+    freqs = torch.outer(t, inv_freq)
+    return freqs.cos().to(device).contiguous(), freqs.sin().to(device).contiguous()
+
+
+def pack_experts(sd, prefix, cfg):
+    """-> (w_gate_up [E+S, 2I, H], w_down [E+S, H, I]) bf16, from reference-named per-expert weights."""
+    E, S, I, H = cfg.num_experts, cfg.num_shared_experts or 0, cfg.moe_intermediate_size, cfg.hidden_size
+    any_w = sd[f"{prefix}.experts.0.gate_proj.weight"]
+    gu = torch.empty(E + S, 2 * I, H, dtype=torch.bfloat16, device=any_w.device)
+    dn = torch.empty(E + S, H, I, dtype=torch.bfloat16, device=any_w.device)
+    for e in range(E):
+        gu[e, :I] = sd[f"{prefix}.experts.{e}.gate_proj.weight"]
+        gu[e, I:] = sd[f"{prefix}.experts.{e}.up_proj.weight"]
+        dn[e] = sd[f"{prefix}.experts.{e}.down_proj.weight"]
+    for s in range(S):
+        gu[E + s, :I] = sd[f"{prefix}.shared_experts.gate_proj.weight"][s * I:(s + 1) * I]
+        gu[E + s, I:] = sd[f"{prefix}.shared_experts.up_proj.weight"][s * I:(s + 1) * I]
+        dn[E + s] = sd[f"{prefix}.shared_experts.down_proj.weight"][:, s * I:(s + 1) * I]
+    return gu, dn
+
+
+class BailingMoeDecoder:
+    """Weights + KV arena + C-ABI pointer table of the decoder stack."""
+
+    def __init__(self, cfg: BailingMoeConfig, layers, final_norm, word_embeddings=None, lm_head=None,
+                 t_max=2048, n_seq=3, n_pos=None):
+        """layers: list of dicts with bf16 CUDA tensors: ln1, wqkv, wdense, ln2, gate, image_gate (or None),
+        w_gate_up, w_down (see pack_experts).  Use `from_state_dict` / `synthetic` to build them."""
+        assert cfg.rope_scaling is None, "hot path uses the Legacy rotary (SURVEY.md item 3)"
+        assert cfg.first_k_dense_replace == 0 and not cfg.use_qkv_bias and not cfg.use_bias
+        self.cfg = cfg
+        self.layers = layers
+        self.final_norm = final_norm
+        self.word_embeddings = word_embeddings
+        self.lm_head = lm_head
+        dev = final_norm.device
+        self.device = dev
+        self.t_max, self.n_seq = t_max, n_seq
+        L, nkv, hd = cfg.num_hidden_layers, cfg.num_key_value_heads, cfg.head_dim
+        self.kv_cache = torch.zeros(L, n_seq, 2, nkv, t_max, hd, dtype=torch.float32, device=dev)
+        self.cos, self.sin = rope_tables(hd, cfg.rope_theta, n_pos or t_max, dev)
+        self.n_shared = cfg.num_shared_experts or 0
+        keys = ("ln1", "wqkv", "wdense", "ln2", "gate", "image_gate", "w_gate_up", "w_down")
+        self._arrays = {k: ptr_array([ly.get(k) for ly in layers]) for k in keys}
+        s = Llm()
+        s.hidden, s.n_layers, s.n_q, s.n_kv, s.head_dim = cfg.hidden_size, L, cfg.num_attention_heads, nkv, hd
+        s.n_experts, s.top_k, s.n_shared_slots = cfg.num_experts, cfg.num_experts_per_tok, self.n_shared
+        s.moe_inter, s.norm_topk_prob, s.rms_eps = cfg.moe_intermediate_size, int(cfg.norm_topk_prob), cfg.rms_norm_eps
+        for k in keys:
+            setattr(s, k, C.cast(self._arrays[k], _lib.PP))
+        if not cfg.multi_gate:
+            s.image_gate = None
+        s.final_norm = ptr(final_norm)
+        s.cos_tab, s.sin_tab, s.n_pos = ptr(self.cos), ptr(self.sin), self.cos.shape[0]
+        self.struct = s
+        self._ws = {}
+
+    # ---- construction -------------------------------------------------------------------
+    @classmethod
+    def from_state_dict(cls, cfg, sd, prefix="model.", **kw):
+        """sd: reference-named bf16 CUDA tensors of BailingMoeForCausalLM (`model.layers.{i}.…`)."""
+        layers = []
+        for li in range(cfg.num_hidden_layers):
+            p = f"{prefix}layers.{li}"
+            gu, dn = pack_experts(sd, p + ".mlp", cfg)
+            layers.append(dict(
+                ln1=sd[p + ".input_layernorm.weight"], wqkv=sd[p + ".attention.query_key_value.weight"],
+                wdense=sd[p + ".attention.dense.weight"], ln2=sd[p + ".post_attention_layernorm.weight"],
+                gate=sd[p + ".mlp.gate.weight"],
+                image_gate=sd.get(p + ".mlp.image_gate.weight") if cfg.multi_gate else None,
+                w_gate_up=gu, w_down=dn))
+        root = prefix[:-len("model.")] if prefix.endswith("model.") else ""
+        return cls(cfg, layers, sd[prefix + "norm.weight"], sd.get(prefix + "word_embeddings.weight"),
+                   sd.get(root + "lm_head.weight"), **kw)
+
+    @classmethod
+    def synthetic(cls, cfg, device, seed=0, with_vocab=True, **kw):
+        """Random-init weights of the exact architecture, generated layer by layer on `device`
+        straight into the packed layout (no 2x peak), keyed by the reference parameter names."""
+        from .configuration import llm_layer_param_shapes
+        from .synth import synth_tensor
+        layers = []
+        for li in range(cfg.num_hidden_layers):
+            shapes = llm_layer_param_shapes(cfg, li)
+            sd = {k: synth_tensor(k, v, seed, device, torch.bfloat16) for k, v in shapes.items()}
+            p = f"model.layers.{li}"
+            gu, dn = pack_experts(sd, p + ".mlp", cfg)
+            layers.append(dict(
+                ln1=sd[p + ".input_layernorm.weight"], wqkv=sd[p + ".attention.query_key_value.weight"],
+                wdense=sd[p + ".attention.dense.weight"], ln2=sd[p + ".post_attention_layernorm.weight"],
+                gate=sd[p + ".mlp.gate.weight"],
+                image_gate=sd.get(p + ".mlp.image_gate.weight") if cfg.multi_gate else None,
+                w_gate_up=gu, w_down=dn))
+            del sd
+        H, V = cfg.hidden_size, cfg.vocab_size
+        fn = synth_tensor("model.norm.weight", (H,), seed, device, torch.bfloat16)
+        emb = lm = None
+        if with_vocab:
+            emb = synth_tensor("model.word_embeddings.weight", (V, H), seed, device, torch.bfloat16)
+            lm = synth_tensor("lm_head.weight", (V, H), seed, device, torch.bfloat16)
+        return cls(cfg, layers, fn, emb, lm, **kw)
+
+    def weight_bytes_active(self, distinct_experts_per_layer):
+        cfg = self.cfg
+        H, I = cfg.hidden_size, cfg.moe_intermediate_size
+        attn = (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim * H + H * cfg.num_attention_heads * cfg.head_dim
+        per_expert = 3 * I * H
+        return 2 * cfg.num_hidden_layers * (attn + cfg.num_experts * H + (distinct_experts_per_layer + self.n_shared) * per_expert)
+
+    # ---- stepping -------------------------------------------------------------------------
+    def _workspace(self, rows):
+        if rows not in self._ws:
+            n = lib().mn_llm_workspace_bytes(C.byref(self.struct), rows, self.t_max)
+            self._ws[rows] = torch.empty(n, dtype=torch.uint8, device=self.device)
+        return self._ws[rows]
+
+    def step(self, x, row_seq, row_slot, row_pos, row_len, key_mask=None, image_mask=None, out=None, rows=None):
+        """One pass of the 28-layer stack over M <= 8 rows.
+        x fp32 [M,H] (or [1,H] with rows=M to broadcast); int32 device arrays per row; key_mask uint8 [M, >=len].
+        Returns the post-final-norm hidden states [M,H] fp32."""
+        M = rows or x.shape[0]
+        ldx = 0 if (rows is not None and x.shape[0] == 1) else x.stride(0)
+        assert x.dtype == torch.float32 and x.is_cuda and x.stride(-1) == 1
+        for t in (row_seq, row_slot, row_pos, row_len):
+            assert t.dtype == torch.int32 and t.is_cuda and t.numel() >= M
+        if key_mask is not None:
+            assert key_mask.dtype == torch.uint8 and key_mask.shape[0] >= M
+        if out is None:
+            out = torch.empty(M, self.cfg.hidden_size, dtype=torch.float32, device=self.device)
+        ws = self._workspace(M)
+        check(lib().mn_llm_step(C.byref(self.struct), ptr(x), ldx, M, ptr(image_mask), ptr(row_seq), ptr(row_slot),
+                                ptr(row_pos), ptr(row_len), ptr(key_mask),
+                                0 if key_mask is None else key_mask.stride(0), ptr(self.kv_cache), self.n_seq,
+                                self.t_max, ptr(out), ptr(ws), ws.numel(), current_stream()), "mn_llm_step")
+        return out
+
+    def prefill(self, embeds, seq=0, past=0, image_mask=None, chunk=8):
+        """Causal prefill of ONE sequence by chunks of <= 8 rows through the decode kernels
+        (each row m of a chunk attends cache[0 : past + m + 1]).  embeds fp32 [T,H].
+        Returns the hidden states [T,H]."""
+        T = embeds.shape[0]
+        assert past + T <= self.t_max
+        outs = []
+        for c0 in range(0, T, chunk):
+            m = min(chunk, T - c0)
+            slot = torch.arange(past + c0, past + c0 + m, dtype=torch.int32, device=self.device)
+            seqs = torch.full((m,), seq, dtype=torch.int32, device=self.device)
+            im = None if image_mask is None else image_mask[c0:c0 + m].to(torch.uint8).contiguous()
+            outs.append(self.step(embeds[c0:c0 + m].contiguous(), seqs, slot, slot, slot + 1, None, im))
+        return torch.cat(outs, 0)
+
+    def logits(self, hidden):
+        """lm_head -> fp32 logits (compute_logit, :1604-1620, norm_head=False)."""
+        outs = [ops.skinny_gemm(hidden[i:i + 8].contiguous(), self.lm_head) for i in range(0, hidden.shape[0], 8)]
+        return torch.cat(outs, 0)
+
+    def embed(self, ids):
+        """word_embeddings lookup -> fp32 rows (gather = memory plumbing)."""
+        return ops.bf16_to_f32(self.word_embeddings[ids.reshape(-1)])
+
+
+def build_cfg_rows(attention_mask, uncond_attention_mask, text_uncond_attention_mask):
+    """CFG row construction of generate_image (modeling_bailing_moe.py:1867-1889) — host integer logic.
+    Masks are [1, T*] integer tensors (CPU or GPU); returns the stacked [rows, T] mask."""
+    assert attention_mask.shape[0] == 1
+    am = attention_mask
+    if uncond_attention_mask is not None:
+        n_c, n_u = am.shape[1], uncond_attention_mask.shape[1]
+        if n_u < n_c:
+            uncond_attention_mask = torch.cat((uncond_attention_mask, am[:, n_u:]), dim=1)
+        am = torch.cat((am, uncond_attention_mask), dim=0)
+    if text_uncond_attention_mask is not None and int(text_uncond_attention_mask.sum()) > 0:
+        n_c, n_u = am.shape[1], text_uncond_attention_mask.shape[1]
+        if n_u < n_c:
+            text_uncond_attention_mask = torch.cat((text_uncond_attention_mask, am[0:1, n_u:]), dim=1)
+        if int((text_uncond_attention_mask == uncond_attention_mask).sum()) != uncond_attention_mask.numel():
+            am = torch.cat((am, text_uncond_attention_mask), dim=0)
+    return am
+
+
+class ImageGenState:
+    """Device-resident bookkeeping of one generate_image call."""
+
+    def __init__(self, dec: BailingMoeDecoder, am_rows, past_len):
+        dev = dec.device
+        rows, L = am_rows.shape
+        assert L == past_len + 1 and rows <= dec.n_seq
+        self.rows = rows
+        km = torch.ones(rows, dec.t_max, dtype=torch.uint8, device=dev)   # generated tokens are always attended
+        km[:, :L] = am_rows.to(dev).to(torch.uint8)
+        self.key_mask = km
+        pos = (am_rows.long().cumsum(-1) - 1)[:, -1]                       # :1905-1907
+        self.row_pos = pos.to(torch.int32).to(dev).contiguous()
+        self.row_slot = torch.full((rows,), past_len, dtype=torch.int32, device=dev)
+        self.row_len = torch.full((rows,), past_len + 1, dtype=torch.int32, device=dev)
+        self.row_seq = torch.arange(rows, dtype=torch.int32, device=dev)
+
+    def advance(self):
+        check(lib().mn_rows_advance(ptr(self.row_slot), ptr(self.row_pos), ptr(self.row_len), self.rows, 1,
+                                    current_stream()), "mn_rows_advance")
+
+
+def generate_image(dec: BailingMoeDecoder, rf, tok, start_embed, past_len, attention_mask, uncond_attention_mask,
+                   text_uncond_attention_mask, noises, temperature=1.0, text_cfg=3.0, image_cfg=1.1,
+                   decode_pixels=True, skip_last_sample=True):
+    """BailingMoeForCausalLM.generate_image (modeling_bailing_moe.py:1844-1965) on the HIP path.
+
+    dec: decoder whose sequence 0 already holds `past_len` cached tokens.  rf: RectifiedFlowHead.
+    tok: MingTok (semantic decoder + linear_proj step, pixel decoder).  start_embed fp32 [1,H]: the
+    `<image>` token embedding.  noises fp32 [n_tokens(+1), latent_dim]: the noise RectifiedFlowLoss.sample
+    would draw per iteration (torch.randn, diff_loss_rf_swiglu.py:117-122), supplied by the caller.
+    CFG scales: the reference always runs 3.0 / 1.1 (its kwargs are swallowed); the
+    façade passes those.  Differences from the reference that do not change results: CFG rows that
+    are bit-identical (semantic decoder, linear_proj, pixel decoder) are computed once; the sampler
+    output of the 257th iteration (discarded at :1936) is not computed when skip_last_sample.
+    Returns dict(image [1,3,R,R] fp32 | None, latents [n,32], sem [n,D], last_hidden [rows,H], attention_mask).
+    """
+    cfg = dec.cfg
+    am = build_cfg_rows(attention_mask, uncond_attention_mask, text_uncond_attention_mask).cpu()
+    rows = am.shape[0]
+    n_tok = cfg.num_image_tokens_for_gen
+    assert past_len + n_tok + 1 <= dec.t_max
+    if rows > 1:   # replicate the prompt KV to the CFG rows (:1891-1902) — device memcpy
+        for r in range(1, rows):
+            dec.kv_cache[:, r, :, :, :past_len].copy_(dec.kv_cache[:, 0, :, :, :past_len])
+    st = ImageGenState(dec, am, past_len)
+    dev = dec.device
+    D = tok.feature_dim
+    latents = torch.empty(n_tok, rf.target, dtype=torch.float32, device=dev)
+    sems = torch.empty(n_tok, D, dtype=torch.float32, device=dev)
+    embed = torch.empty(1, cfg.hidden_size, dtype=torch.float32, device=dev)
+    hidden = torch.empty(rows, cfg.hidden_size, dtype=torch.float32, device=dev)
+    sem_state = tok.new_decode_state(n_seq=1, t_max=n_tok)
+    x = start_embed
+    for ti in range(n_tok + 1):
+        dec.step(x, st.row_seq, st.row_slot, st.row_pos, st.row_len, st.key_mask, None, out=hidden, rows=rows)
+        if ti < n_tok:
+            rf.sample(hidden, noises[ti], temperature, text_cfg, image_cfg, out=latents[ti])
+            tok.decode_step(latents[ti:ti + 1], sem_state, sem_out=sems[ti:ti + 1], embed_out=embed)
+            x = embed
+            st.advance()
+        elif not skip_last_sample:
+            rf.sample(hidden, noises[ti], temperature, text_cfg, image_cfg)
+    image = tok.forward_pixel_decoder(sems.unsqueeze(0)) if decode_pixels else None
+    am_out = torch.cat((am, torch.ones(rows, n_tok, dtype=am.dtype)), dim=-1)
+    return dict(image=image, latents=latents, sem=sems, last_hidden=hidden, attention_mask=am_out,
+                cache_len=past_len + n_tok + 1)

@@ -1,0 +1,460 @@
+// batch_ops.hip — batched (many-row) operators on the bf16 MFMA path (gfx950):
+//   mn_gemm_bf16          C = A W^T (+bias, GELU, fp32 residual accumulate), 128x128x64 tiles,
+//                         v_mfma_f32_16x16x32_bf16, register-staged double-buffered LDS with an
+//                         XOR swizzle on the 16-byte slots (conflict-free ds_read_b128 fragments)
+//   mn_attn_prefill_hd64  flash attention, head_dim 64, S^T = K Q^T / O^T = V^T P^T formulation so
+//                         that the softmax probabilities never leave registers
+//   mn_layernorm_bf16, mn_swiglu_bf16, fp32<->bf16 converters
+#include "common.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// ===========================================================================================
+// GEMM
+// ===========================================================================================
+namespace {
+constexpr int BM = 128, BN = 128, BK = 64;
+
+// LDS tile: [128 rows][64 k] bf16 = 128 B per row = 8 slots of 16 B; slot index XOR (row & 7).
+__device__ __forceinline__ int tile_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                        const bf16_t* __restrict__ W, int64_t ldw,
+                                                        const bf16_t* __restrict__ bias, void* __restrict__ Cv,
+                                                        int64_t ldc, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) char lds[2][2][BM * BK * 2];  // [buf][A|W]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware tile order: consecutive tiles of one XCD share the A row panel
+  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int nt = tiles_n * tiles_m;
+  int bid = blockIdx.x;
+  {
+    const int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+  // global -> register staging: each thread moves 4 slots of A and 4 slots of W per k-tile
+  // thread t: row = t/8 + 32*i, slot = t%8
+  const int ld_row = tid >> 3, ld_slot = tid & 7;
+  u32x4 ra[4], rw[4];
+  auto gload = [&](int kt) {
+    const int k = kt * BK + ld_slot * 8;
+    const bool kok = k < K;  // K % 8 == 0 so a slot is all-in or all-out
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = ld_row + 32 * i;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      ra[i] = (kok && (m0 + r) < M) ? *reinterpret_cast<const u32x4*>(A + (int64_t)(m0 + r) * lda + k) : z;
+      rw[i] = (kok && (n0 + r) < N) ? *reinterpret_cast<const u32x4*>(W + (int64_t)(n0 + r) * ldw + k) : z;
+    }
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = ld_row + 32 * i;
+      *reinterpret_cast<u32x4*>(&lds[buf][0][tile_off(r, ld_slot)]) = ra[i];
+      *reinterpret_cast<u32x4*>(&lds[buf][1][tile_off(r, ld_slot)]) = rw[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (K + BK - 1) / BK;
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8*>(&lds[cur][0][tile_off(wm + i * 16 + fr, kk * 4 + fq)]);
+        bf[i] = *reinterpret_cast<const bf16x8*>(&lds[cur][1][tile_off(wn + i * 16 + fr, kk * 4 + fq)]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) swrite(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue. C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wn + j * 16 + fr;
+    if (n >= N) continue;
+    const float bv = bias ? bf16_to_f32(bias[n]) : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + i * 16 + fq * 4 + r;
+        if (m >= M) continue;
+        float v = acc[i][j][r] + bv;
+        if (EPI == MN_GEMM_BF16) {
+          reinterpret_cast<bf16_t*>(Cv)[(int64_t)m * ldc + n] = f32_to_bf16(v);
+        } else if (EPI == MN_GEMM_BF16_GELU) {
+          reinterpret_cast<bf16_t*>(Cv)[(int64_t)m * ldc + n] = f32_to_bf16(gelu_erf_f(v));
+        } else if (EPI == MN_GEMM_F32) {
+          reinterpret_cast<float*>(Cv)[(int64_t)m * ldc + n] = v;
+        } else {
+          reinterpret_cast<float*>(Cv)[(int64_t)m * ldc + n] += v;
+        }
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int mn_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias,
+                            void* C, int64_t ldc, int M, int N, int K, int epilogue, void* stream) {
+  MN_CHECK_ARG(A && W && C, "mn_gemm_bf16: null pointer");
+  MN_CHECK_ARG(M >= 1 && N >= 1 && K >= 8 && (K % 8) == 0, "mn_gemm_bf16: bad M=%d N=%d K=%d (K %% 8 == 0)", M, N, K);
+  MN_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0,
+               "mn_gemm_bf16: A/W rows must be 16-byte aligned");
+  const int tiles = (int)(mn_cdiv(M, BM) * mn_cdiv(N, BN));
+  hipStream_t st = mn_stream(stream);
+  switch (epilogue) {
+    case MN_GEMM_BF16:
+      hipLaunchKernelGGL(gemm_bf16_kernel<MN_GEMM_BF16>, dim3(tiles), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K);
+      break;
+    case MN_GEMM_BF16_GELU:
+      hipLaunchKernelGGL(gemm_bf16_kernel<MN_GEMM_BF16_GELU>, dim3(tiles), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K);
+      break;
+    case MN_GEMM_F32:
+      hipLaunchKernelGGL(gemm_bf16_kernel<MN_GEMM_F32>, dim3(tiles), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K);
+      break;
+    case MN_GEMM_F32_RESID:
+      hipLaunchKernelGGL(gemm_bf16_kernel<MN_GEMM_F32_RESID>, dim3(tiles), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K);
+      break;
+    default:
+      mn_set_error("mn_gemm_bf16: bad epilogue %d", epilogue);
+      return MN_EINVAL;
+  }
+  MN_CHECK_LAUNCH("mn_gemm_bf16");
+  return MN_OK;
+}
+
+// ===========================================================================================
+// LayerNorm fp32 -> bf16 (one wave per row), SwiGLU, converters
+// ===========================================================================================
+__global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __restrict__ x, int64_t ldx,
+                                                             const bf16_t* __restrict__ g, const bf16_t* __restrict__ b,
+                                                             float eps, bf16_t* __restrict__ y, int64_t ldy, int M, int D,
+                                                             int gelu) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (int64_t)row * ldx;
+  float s = 0.f;
+  for (int k = lane * 4; k < D; k += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
+    s += v.x + v.y + v.z + v.w;
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float ss = 0.f;
+  for (int k = lane * 4; k < D; k += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
+    const float a = v.x - mean, b2 = v.y - mean, c = v.z - mean, d = v.w - mean;
+    ss += a * a + b2 * b2 + c * c + d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+  for (int k = lane * 4; k < D; k += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float t = (o[i] - mean) * rstd;
+      if (g) t *= bf16_to_f32(g[k + i]);
+      if (b) t += bf16_to_f32(b[k + i]);
+      if (gelu) t = gelu_erf_f(t);
+      o[i] = t;
+    }
+    u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+    *reinterpret_cast<u32x2*>(y + (int64_t)row * ldy + k) = pk;
+  }
+}
+
+extern "C" int mn_layernorm_bf16(const float* x, int64_t ldx, const uint16_t* g, const uint16_t* b, float eps,
+                                 uint16_t* y, int64_t ldy, int M, int D, int gelu, void* stream) {
+  MN_CHECK_ARG(x && y && M >= 1 && D >= 4 && (D % 4) == 0 && (ldx % 4) == 0 && (ldy % 4) == 0, "mn_layernorm_bf16: bad args");
+  hipLaunchKernelGGL(layernorm_bf16_kernel, dim3(mn_cdiv(M, 4)), dim3(256), 0, mn_stream(stream), x, ldx, g, b, eps, y,
+                     ldy, M, D, gelu);
+  MN_CHECK_LAUNCH("mn_layernorm_bf16");
+  return MN_OK;
+}
+
+__global__ void swiglu_bf16_kernel(const bf16_t* __restrict__ x12, int64_t ldx, bf16_t* __restrict__ h, int64_t ldh,
+                                   int M, int H) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over M * H/8
+  const int per = H / 8;
+  if (i >= (int64_t)M * per) return;
+  const int m = (int)(i / per), c = (int)(i % per) * 8;
+  const u32x4 a = *reinterpret_cast<const u32x4*>(x12 + (int64_t)m * ldx + c);
+  const u32x4 b = *reinterpret_cast<const u32x4*>(x12 + (int64_t)m * ldx + H + c);
+  u32x4 o;
+  o.x = pack_bf16x2(silu_f(bf16lo_to_f32(a.x)) * bf16lo_to_f32(b.x), silu_f(bf16hi_to_f32(a.x)) * bf16hi_to_f32(b.x));
+  o.y = pack_bf16x2(silu_f(bf16lo_to_f32(a.y)) * bf16lo_to_f32(b.y), silu_f(bf16hi_to_f32(a.y)) * bf16hi_to_f32(b.y));
+  o.z = pack_bf16x2(silu_f(bf16lo_to_f32(a.z)) * bf16lo_to_f32(b.z), silu_f(bf16hi_to_f32(a.z)) * bf16hi_to_f32(b.z));
+  o.w = pack_bf16x2(silu_f(bf16lo_to_f32(a.w)) * bf16lo_to_f32(b.w), silu_f(bf16hi_to_f32(a.w)) * bf16hi_to_f32(b.w));
+  *reinterpret_cast<u32x4*>(h + (int64_t)m * ldh + c) = o;
+}
+
+extern "C" int mn_swiglu_bf16(const uint16_t* x12, int64_t ldx, uint16_t* h, int64_t ldh, int M, int H, void* stream) {
+  MN_CHECK_ARG(x12 && h && M >= 1 && H >= 8 && (H % 8) == 0 && (ldx % 8) == 0 && (ldh % 8) == 0, "mn_swiglu_bf16: bad args");
+  const int64_t n = (int64_t)M * (H / 8);
+  hipLaunchKernelGGL(swiglu_bf16_kernel, dim3(mn_cdiv(n, 256)), dim3(256), 0, mn_stream(stream), x12, ldx, h, ldh, M, H);
+  MN_CHECK_LAUNCH("mn_swiglu_bf16");
+  return MN_OK;
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = f32_to_bf16(x[i]);
+}
+__global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = bf16_to_f32(x[i]);
+}
+__global__ void f32_split_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
+                                      int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    const bf16_t h = f32_to_bf16(v);
+    hi[i] = h;
+    lo[i] = f32_to_bf16(v - bf16_to_f32(h));
+  }
+}
+__global__ void add_bcast_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o,
+                                 int64_t n, int64_t period) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    o[i] = a[i] + b[i % period];
+}
+__global__ void group_mean_add_kernel(const float* __restrict__ y, const float* __restrict__ x, float* __restrict__ o,
+                                      int M, int D, int Cout) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * Cout) return;
+  const int m = (int)(i / Cout), c = (int)(i % Cout), G = D / Cout;
+  float s = 0.f;
+  for (int g = 0; g < G; ++g) s += x[(int64_t)m * D + c * G + g];
+  o[i] = y[i] + s / (float)G;
+}
+__global__ void repeat_add_kernel(const float* __restrict__ y, const float* __restrict__ sc, float* __restrict__ o,
+                                  int M, int D, int Cin, float scale, float shift) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * D) return;
+  const int m = (int)(i / D), n = (int)(i % D);
+  o[i] = y[i] + sc[(int64_t)m * Cin + n / (D / Cin)] * scale + shift;
+}
+__global__ void clamp_kernel(float* __restrict__ x, int64_t n, float lo, float hi) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = fminf(fmaxf(x[i], lo), hi);
+}
+static inline int ew_blocks(int64_t n) { int64_t b = mn_cdiv(n, 256); return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
+
+extern "C" int mn_add_bcast_f32(const float* a, const float* b, float* out, int64_t n, int64_t period, void* stream) {
+  MN_CHECK_ARG(a && b && out && n > 0 && period > 0, "mn_add_bcast_f32: bad args");
+  hipLaunchKernelGGL(add_bcast_kernel, dim3(ew_blocks(n)), dim3(256), 0, mn_stream(stream), a, b, out, n, period);
+  MN_CHECK_LAUNCH("mn_add_bcast_f32");
+  return MN_OK;
+}
+extern "C" int mn_group_mean_add(const float* y, const float* x, float* out, int M, int D, int Cout, void* stream) {
+  MN_CHECK_ARG(y && x && out && M > 0 && Cout > 0 && D % Cout == 0, "mn_group_mean_add: bad args");
+  hipLaunchKernelGGL(group_mean_add_kernel, dim3(mn_cdiv((int64_t)M * Cout, 256)), dim3(256), 0, mn_stream(stream), y, x,
+                     out, M, D, Cout);
+  MN_CHECK_LAUNCH("mn_group_mean_add");
+  return MN_OK;
+}
+extern "C" int mn_repeat_add(const float* y, const float* s, float* out, int M, int D, int Cin, float scale, float shift,
+                             void* stream) {
+  MN_CHECK_ARG(y && s && out && M > 0 && Cin > 0 && D % Cin == 0, "mn_repeat_add: bad args");
+  hipLaunchKernelGGL(repeat_add_kernel, dim3(mn_cdiv((int64_t)M * D, 256)), dim3(256), 0, mn_stream(stream), y, s, out, M,
+                     D, Cin, scale, shift);
+  MN_CHECK_LAUNCH("mn_repeat_add");
+  return MN_OK;
+}
+extern "C" int mn_clamp_f32(float* x, int64_t n, float lo, float hi, void* stream) {
+  MN_CHECK_ARG(x && n > 0, "mn_clamp_f32: bad args");
+  hipLaunchKernelGGL(clamp_kernel, dim3(ew_blocks(n)), dim3(256), 0, mn_stream(stream), x, n, lo, hi);
+  MN_CHECK_LAUNCH("mn_clamp_f32");
+  return MN_OK;
+}
+
+extern "C" int mn_f32_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream) {
+  MN_CHECK_ARG(x && y && n >= 0, "mn_f32_to_bf16: bad args");
+  if (n == 0) return MN_OK;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(ew_blocks(n)), dim3(256), 0, mn_stream(stream), x, y, n);
+  MN_CHECK_LAUNCH("mn_f32_to_bf16");
+  return MN_OK;
+}
+extern "C" int mn_bf16_to_f32(const uint16_t* x, float* y, int64_t n, void* stream) {
+  MN_CHECK_ARG(x && y && n >= 0, "mn_bf16_to_f32: bad args");
+  if (n == 0) return MN_OK;
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(ew_blocks(n)), dim3(256), 0, mn_stream(stream), x, y, n);
+  MN_CHECK_LAUNCH("mn_bf16_to_f32");
+  return MN_OK;
+}
+extern "C" int mn_f32_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, void* stream) {
+  MN_CHECK_ARG(x && hi && lo && n >= 0, "mn_f32_split_bf16: bad args");
+  if (n == 0) return MN_OK;
+  hipLaunchKernelGGL(f32_split_bf16_kernel, dim3(ew_blocks(n)), dim3(256), 0, mn_stream(stream), x, hi, lo, n);
+  MN_CHECK_LAUNCH("mn_f32_split_bf16");
+  return MN_OK;
+}
+
+// ===========================================================================================
+// Flash attention, head_dim 64.  Block = (b, head, 64-query tile); wave = 16 queries.
+//
+// Per 32-key tile, with q = lane & 15 (a query COLUMN) and g = lane >> 4:
+//   S^T[key, q] = sum_d K[key, d] Q[q, d]      A = K fragment (16 keys x 32 d, 16 B per lane straight
+//                                              from global), B = Q fragment (registers, loaded once)
+//     -> accumulator reg r of sub-tile t holds key t*16 + g*4 + r for query q.
+//   online softmax per query: max/sum over 8 registers + xor-16 / xor-32 shuffles.
+//   O^T[d, q] += sum_key V[key, d] P[q, key]   B = P^T built in registers: MFMA k-slot (g, i) is
+//     DEFINED as key (i < 4 ? g*4 + i : 16 + g*4 + i - 4), which is exactly what the lane already holds;
+//     A = V^T fragment read from an LDS image Vt[d][key] with the same slot map.
+// ===========================================================================================
+namespace {
+constexpr int KT = 32;
+
+__global__ __launch_bounds__(256) void attn_prefill_hd64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                int B, int T, int nh, int causal) {
+  __shared__ __attribute__((aligned(16))) bf16_t vt[64][KT + 8];  // V^T tile, +8 pad (row = 80 B)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int64_t row_stride = (int64_t)3 * nh * 64;
+  const bf16_t* base = qkv + (int64_t)b * T * row_stride;
+  const bf16_t* Qp = base + (int64_t)h * 64;
+  const bf16_t* Kp = base + (int64_t)(nh + h) * 64;
+  const bf16_t* Vp = base + (int64_t)(2 * nh + h) * 64;
+  const int ql = lane & 15, g = lane >> 4;
+  const int q_idx = qt * 64 + wave * 16 + ql;
+  const int q_ld = min(q_idx, T - 1);
+  // Q fragments (B operand): Q[q][d = kk*32 + g*8 .. +8], pre-scaled by 64^-0.5 = 0.125 (exact in bf16)
+  bf16x8 qf[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(Qp + (int64_t)q_ld * row_stride + kk * 32 + g * 8);
+    u32x4 sc;
+    sc.x = pack_bf16x2(bf16lo_to_f32(raw.x) * 0.125f, bf16hi_to_f32(raw.x) * 0.125f);
+    sc.y = pack_bf16x2(bf16lo_to_f32(raw.y) * 0.125f, bf16hi_to_f32(raw.y) * 0.125f);
+    sc.z = pack_bf16x2(bf16lo_to_f32(raw.z) * 0.125f, bf16hi_to_f32(raw.z) * 0.125f);
+    sc.w = pack_bf16x2(bf16lo_to_f32(raw.w) * 0.125f, bf16hi_to_f32(raw.w) * 0.125f);
+    qf[kk] = __builtin_bit_cast(bf16x8, sc);
+  }
+  f32x4 o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int q_hi = min(T, qt * 64 + 64) - 1;          // last query row of this block
+  const int k_end = causal ? (q_hi + 1) : T;          // keys needed by the block
+  const int ntile = (k_end + KT - 1) / KT;
+  for (int kt = 0; kt < ntile; ++kt) {
+    const int k0 = kt * KT;
+    __syncthreads();  // previous tile's V^T fully consumed
+    {  // stage V^T: thread -> key = tid/8 (0..31), d-chunk = tid%8 (8 d each)
+      const int key = tid >> 3, dc = tid & 7;
+      const int kr = min(k0 + key, T - 1);
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(Vp + (int64_t)kr * row_stride + dc * 8);
+      const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vt[dc * 8 + 2 * i][key] = (bf16_t)(wv[i] & 0xffffu);
+        vt[dc * 8 + 2 * i + 1][key] = (bf16_t)(wv[i] >> 16);
+      }
+    }
+    // S^T: two 16-key sub-tiles
+    f32x4 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int kr = min(k0 + t * 16 + ql, T - 1);  // A row = key (lane & 15)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kp + (int64_t)kr * row_stride + kk * 32 + g * 8);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
+      }
+    }
+    // mask + online softmax (per query column q = lane & 15)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + t * 16 + g * 4 + r;
+        const bool ok = key < T && (!causal || key <= q_idx);
+        s[t][r] = ok ? s[t][r] : -INFINITY;
+        mx = fmaxf(mx, s[t][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
+    float psum = 0.f;
+    float p[8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = (m_new == -INFINITY) ? 0.f : __expf(s[t][r] - m_new);
+        p[t * 4 + r] = e;
+        psum += e;
+      }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] *= alpha;
+    u32x4 pk = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
+    const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+    __syncthreads();  // V^T tile visible
+    // O^T += V^T P^T : A row = d (lane & 15) + 16*dt, k-slots (g, i) as defined above
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const bf16_t* vr = &vt[dt * 16 + ql][0];
+      const u32x2 lo = *reinterpret_cast<const u32x2*>(vr + g * 4);
+      const u32x2 hi = *reinterpret_cast<const u32x2*>(vr + 16 + g * 4);
+      u32x4 vv = {lo.x, lo.y, hi.x, hi.y};
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
+    }
+  }
+  if (q_idx < T) {
+    const float inv = 1.0f / l_run;
+    bf16_t* op = out + ((int64_t)b * T + q_idx) * (nh * 64) + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      u32x2 pk = {pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
+      *reinterpret_cast<u32x2*>(op + dt * 16 + g * 4) = pk;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int mn_attn_prefill_hd64(const uint16_t* qkv, uint16_t* out, int B, int T, int n_heads, int causal,
+                                    void* stream) {
+  MN_CHECK_ARG(qkv && out && B >= 1 && T >= 1 && n_heads >= 1, "mn_attn_prefill_hd64: bad args");
+  hipLaunchKernelGGL(attn_prefill_hd64_kernel, dim3(mn_cdiv(T, 64), n_heads, B), dim3(256), 0, mn_stream(stream), qkv,
+                     out, B, T, n_heads, causal);
+  MN_CHECK_LAUNCH("mn_attn_prefill_hd64");
+  return MN_OK;
+}

@@ -1,0 +1,293 @@
+// decode_ops.hip — small-row (decode) operators around the skinny GEMM (gfx950):
+//   mn_moe_router       RMSNorm + gate GEMV + softmax + top-k (+ image-gate override)
+//   mn_rope_kv_append   neox-style rotary on q/k, append k/v to the fp32 KV cache
+//   mn_attn_decode      masked GQA/MHA attention of <= 8 query rows against the cache
+//                       (split over the key range = flash-decoding, then a combine pass)
+// All of these are HBM/latency-bound index-and-reduce work: coalesced loads, wave shuffles,
+// no MFMA.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// -------------------------------------------------------------------------------------------
+// MoE router. One 256-thread block per row.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void moe_router_kernel(
+    const float* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ norm_w, float eps,
+    const bf16_t* __restrict__ gate_w, const bf16_t* __restrict__ image_gate_w,
+    const uint8_t* __restrict__ image_mask, int H, int E, int top_k, int norm_topk_prob, int n_shared,
+    float* __restrict__ x_norm, int32_t* __restrict__ topk_idx, float* __restrict__ topk_w) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* xn = sm;            // [H]
+  float* logits = sm + H;    // [64]
+  float* red = logits + 64;  // [8]
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xr = x + (int64_t)m * ldx;
+  float ss = 0.f;
+  for (int k = tid; k < H; k += 256) { float v = xr[k]; xn[k] = v; ss += v * v; }
+  ss = block_sum(ss, red);
+  const float rstd = rsqrtf(ss / (float)H + eps);
+  for (int k = tid; k < H; k += 256) {
+    float v = xn[k] * rstd * bf16_to_f32(norm_w[k]);
+    xn[k] = v;
+    x_norm[(int64_t)m * H + k] = v;
+  }
+  __syncthreads();
+  const bf16_t* gw = (image_mask && image_gate_w && image_mask[m]) ? image_gate_w : gate_w;
+  for (int e = wave; e < E; e += 4) {
+    const bf16_t* wr = gw + (int64_t)e * H;
+    float acc = 0.f;
+    for (int k = lane * 8; k < H; k += 512) {
+      const u32x4 w = *reinterpret_cast<const u32x4*>(wr + k);
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xn + k);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(xn + k + 4);
+      acc = fmaf(bf16lo_to_f32(w.x), a.x, acc); acc = fmaf(bf16hi_to_f32(w.x), a.y, acc);
+      acc = fmaf(bf16lo_to_f32(w.y), a.z, acc); acc = fmaf(bf16hi_to_f32(w.y), a.w, acc);
+      acc = fmaf(bf16lo_to_f32(w.z), b.x, acc); acc = fmaf(bf16hi_to_f32(w.z), b.y, acc);
+      acc = fmaf(bf16lo_to_f32(w.w), b.z, acc); acc = fmaf(bf16hi_to_f32(w.w), b.w, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) logits[e] = acc;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // softmax over E (fp32) then iterative arg-max; ties -> lowest expert index
+    float s = lane < E ? logits[lane] : -INFINITY;
+    const float mx = wave_max(s);
+    float p = lane < E ? __expf(s - mx) : 0.f;
+    const float denom = wave_sum(p);
+    p = p / denom;
+    float cur = lane < E ? p : -1.f;
+    float wsum = 0.f;
+    float myw = 0.f;
+    int myidx = 0;
+    const int n_slot = top_k + n_shared;
+    for (int k = 0; k < top_k; ++k) {
+      const float best = wave_max(cur);
+      const unsigned long long ball = __ballot(cur == best);
+      const int sel = __ffsll((long long)ball) - 1;
+      if (lane == k) { myw = best; myidx = sel; }
+      if (lane == sel) cur = -1.f;
+      wsum += best;
+    }
+    if (lane < top_k) {
+      topk_idx[(int64_t)m * n_slot + lane] = myidx;
+      topk_w[(int64_t)m * n_slot + lane] = (norm_topk_prob && top_k > 1) ? myw / wsum : myw;
+    } else if (lane < n_slot) {
+      topk_idx[(int64_t)m * n_slot + lane] = E + (lane - top_k);
+      topk_w[(int64_t)m * n_slot + lane] = 1.0f;
+    }
+  }
+}
+
+extern "C" int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w, float eps,
+                             const uint16_t* gate_w, const uint16_t* image_gate_w, const uint8_t* image_mask,
+                             int M, int H, int E, int top_k, int norm_topk_prob, int n_shared_slots,
+                             float* x_norm, int32_t* topk_idx, float* topk_w, void* stream) {
+  MN_CHECK_ARG(M >= 1 && H >= 8 && (H % 8) == 0, "mn_moe_router: bad M=%d H=%d", M, H);
+  MN_CHECK_ARG(E >= 1 && E <= 64 && top_k >= 1 && top_k <= E && top_k + n_shared_slots <= 64,
+               "mn_moe_router: bad E=%d top_k=%d", E, top_k);
+  MN_CHECK_ARG(x && norm_w && gate_w && x_norm && topk_idx && topk_w, "mn_moe_router: null pointer");
+  const size_t lds = (size_t)(H + 64 + 16) * sizeof(float);
+  hipLaunchKernelGGL(moe_router_kernel, dim3(M), dim3(256), lds, mn_stream(stream), x, ldx, norm_w, eps, gate_w,
+                     image_gate_w, image_mask, H, E, top_k, norm_topk_prob, n_shared_slots, x_norm, topk_idx, topk_w);
+  MN_CHECK_LAUNCH("mn_moe_router");
+  return MN_OK;
+}
+
+// -------------------------------------------------------------------------------------------
+// RoPE + KV append. grid (M, n_q + 2*n_kv), block hd/2 threads.
+// -------------------------------------------------------------------------------------------
+__global__ void rope_kv_append_kernel(const float* __restrict__ qkv, int64_t ldqkv, int n_q, int n_kv, int hd,
+                                      int rope, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+                                      const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_slot,
+                                      const int32_t* __restrict__ row_pos, float q_scale, float* __restrict__ q_out,
+                                      float* __restrict__ kv_cache, int64_t t_max) {
+  const int m = blockIdx.x, h = blockIdx.y, i = threadIdx.x, half = hd >> 1;
+  const float* src = qkv + (int64_t)m * ldqkv + (int64_t)h * hd;
+  float x1 = src[i], x2 = src[i + half];
+  const bool is_q = h < n_q, is_k = !is_q && h < n_q + n_kv;
+  if (rope && (is_q || is_k)) {
+    const int pos = row_pos[m];
+    const float c = cos_tab[(int64_t)pos * half + i], s = sin_tab[(int64_t)pos * half + i];
+    const float o1 = x1 * c - x2 * s, o2 = x2 * c + x1 * s;
+    x1 = o1; x2 = o2;
+  }
+  if (is_q) {
+    float* dst = q_out + (int64_t)m * n_q * hd + (int64_t)h * hd;
+    dst[i] = x1 * q_scale;
+    dst[i + half] = x2 * q_scale;
+  } else {
+    const int kvh = is_k ? h - n_q : h - n_q - n_kv;
+    const int64_t seq = row_seq[m], slot = row_slot[m];
+    float* dst = kv_cache + (((seq * 2 + (is_k ? 0 : 1)) * n_kv + kvh) * t_max + slot) * hd;
+    dst[i] = x1;
+    dst[i + half] = x2;
+  }
+}
+
+extern "C" int mn_rope_kv_append(const float* qkv, int64_t ldqkv, int M, int n_q, int n_kv, int hd, int rope,
+                                 const float* cos_tab, const float* sin_tab, const int32_t* row_seq,
+                                 const int32_t* row_slot, const int32_t* row_pos, float q_scale, float* q_out,
+                                 float* kv_cache, int64_t t_max, void* stream) {
+  MN_CHECK_ARG(M >= 1 && n_q >= 1 && n_kv >= 1 && (hd == 64 || hd == 128), "mn_rope_kv_append: bad shape");
+  MN_CHECK_ARG(qkv && row_seq && row_slot && q_out && kv_cache, "mn_rope_kv_append: null pointer");
+  MN_CHECK_ARG(!rope || (cos_tab && sin_tab && row_pos), "mn_rope_kv_append: rope needs tables and positions");
+  hipLaunchKernelGGL(rope_kv_append_kernel, dim3(M, n_q + 2 * n_kv), dim3(hd / 2), 0, mn_stream(stream), qkv, ldqkv,
+                     n_q, n_kv, hd, rope, cos_tab, sin_tab, row_seq, row_slot, row_pos, q_scale, q_out, kv_cache,
+                     t_max);
+  MN_CHECK_LAUNCH("mn_rope_kv_append");
+  return MN_OK;
+}
+
+// -------------------------------------------------------------------------------------------
+// Decode attention, split over keys. One wave per (row, q head, split); 4 waves per block
+// cover 4 consecutive q heads (= one GQA group when n_q/n_kv == 4, so K/V lines are shared in L1).
+// partial layout: [M][n_q][S][HD + 2]  (acc[HD], m, l)
+// -------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_split_kernel(
+    const float* __restrict__ q, int n_q, int n_kv, const float* __restrict__ kv_cache, int64_t t_max,
+    const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_len, const uint8_t* __restrict__ key_mask,
+    int64_t ld_mask, int S, int chunk_cap, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x, s = blockIdx.z;
+  const int h_raw = blockIdx.y * 4 + wave;
+  const bool active = h_raw < n_q;          // inactive waves shadow the last head, store nothing
+  const int h = active ? h_raw : n_q - 1;
+  float* sc = sm + wave * chunk_cap;
+  const int len = row_len[m];
+  int chunk = (len + S - 1) / S;
+  chunk = (chunk + 3) & ~3;
+  const int j0 = s * chunk, j1 = min(len, j0 + chunk);
+  const int kvh = h / (n_q / n_kv);
+  const int64_t seq = row_seq[m];
+  const float* Kb = kv_cache + ((seq * 2 + 0) * n_kv + kvh) * t_max * HD;
+  const float* Vb = kv_cache + ((seq * 2 + 1) * n_kv + kvh) * t_max * HD;
+  const float* qr = q + ((int64_t)m * n_q + h) * HD;
+  const uint8_t* mk = key_mask ? key_mask + (int64_t)m * ld_mask : nullptr;
+  float* out = partial + (((int64_t)m * n_q + h) * S + s) * (HD + 2);
+
+  // ---- scores: 16 lanes per key, 4 keys per wave-iteration
+  constexpr int PER = HD / 16;  // floats per lane (8 for 128, 4 for 64)
+  const int sub = lane & 15, kq = lane >> 4;
+  float qv[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) qv[i] = qr[sub * PER + i];
+  float mx = -INFINITY;
+  for (int j = j0 + kq; j < j0 + chunk; j += 4) {
+    float d = 0.f;
+    const bool ok = j < j1;
+    if (ok) {
+      const float* kr = Kb + (int64_t)j * HD + sub * PER;
+#pragma unroll
+      for (int i = 0; i < PER; i += 4) {
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(kr + i);
+        d = fmaf(kv.x, qv[i], d); d = fmaf(kv.y, qv[i + 1], d); d = fmaf(kv.z, qv[i + 2], d); d = fmaf(kv.w, qv[i + 3], d);
+      }
+    }
+    d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 1, 64);
+    const bool keep = ok && (!mk || mk[j] != 0);
+    const float sv = keep ? d : -INFINITY;
+    if (sub == 0 && (j - j0) < chunk_cap) sc[j - j0] = sv;
+    mx = fmaxf(mx, sv);
+  }
+  mx = wave_max(mx);
+  // ---- softmax numerators
+  __syncthreads();
+  float l = 0.f;
+  const int n = max(0, j1 - j0);
+  for (int j = lane; j < n; j += 64) {
+    const float p = (mx == -INFINITY) ? 0.f : __expf(sc[j] - mx);
+    sc[j] = p;
+    l += p;
+  }
+  l = wave_sum(l);
+  __syncthreads();
+  // ---- PV: lane owns HD/64 dims
+  constexpr int DPL = HD / 64;  // 2 or 1
+  float acc[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) acc[i] = 0.f;
+  const float* vr = Vb + (int64_t)j0 * HD + lane * DPL;
+  int j = 0;
+  for (; j + 4 <= n; j += 4) {
+    float v[4][DPL];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < DPL; ++i) v[u][i] = vr[(int64_t)(j + u) * HD + i];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float p = sc[j + u];
+#pragma unroll
+      for (int i = 0; i < DPL; ++i) acc[i] = fmaf(p, v[u][i], acc[i]);
+    }
+  }
+  for (; j < n; ++j) {
+    const float p = sc[j];
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) acc[i] = fmaf(p, vr[(int64_t)j * HD + i], acc[i]);
+  }
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) out[lane * DPL + i] = acc[i];
+    if (lane == 0) { out[HD] = mx; out[HD + 1] = l; }
+  }
+}
+
+template <int HD>
+__global__ void attn_decode_combine_kernel(const float* __restrict__ partial, int n_q, int S, float* __restrict__ out) {
+  const int m = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
+  const float* p = partial + (((int64_t)m * n_q + h) * S) * (HD + 2);
+  float mx = -INFINITY;
+  for (int s = 0; s < S; ++s) mx = fmaxf(mx, p[s * (HD + 2) + HD]);
+  float l = 0.f, acc = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float ms = p[s * (HD + 2) + HD];
+    const float f = (ms == -INFINITY) ? 0.f : __expf(ms - mx);
+    l = fmaf(f, p[s * (HD + 2) + HD + 1], l);
+    acc = fmaf(f, p[s * (HD + 2) + d], acc);
+  }
+  out[((int64_t)m * n_q + h) * HD + d] = acc / l;
+}
+
+extern "C" size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t t_max) {
+  int S = (int)mn_cdiv(t_max, 96);
+  if (S > 32) S = 32;
+  if (S < 1) S = 1;
+  return (size_t)M * n_q * S * (hd + 2) * sizeof(float);
+}
+
+extern "C" int mn_attn_decode(const float* q, int M, int n_q, int n_kv, int hd, const float* kv_cache,
+                                 int64_t t_max, const int32_t* row_seq, const int32_t* row_len,
+                                 const uint8_t* key_mask, int64_t ld_mask, float* out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  MN_CHECK_ARG(M >= 1 && n_q >= 1 && n_kv >= 1 && n_q % n_kv == 0 && (hd == 64 || hd == 128), "mn_attn_decode: bad shape");
+  MN_CHECK_ARG(q && kv_cache && row_seq && row_len && out && workspace, "mn_attn_decode: null pointer");
+  int S = (int)mn_cdiv(t_max, 96);
+  if (S > 32) S = 32;
+  if (S < 1) S = 1;
+  const size_t need = (size_t)M * n_q * S * (hd + 2) * sizeof(float);
+  if (workspace_bytes < need) { mn_set_error("mn_attn_decode: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
+  int chunk_cap = (int)mn_cdiv(t_max, S);
+  chunk_cap = (chunk_cap + 3) & ~3;
+  const size_t lds = (size_t)4 * chunk_cap * sizeof(float);
+  float* partial = reinterpret_cast<float*>(workspace);
+  dim3 grid(M, (n_q + 3) / 4, S);
+  hipStream_t st = mn_stream(stream);
+  if (hd == 128) {
+    hipLaunchKernelGGL(attn_decode_split_kernel<128>, grid, dim3(256), lds, st, q, n_q, n_kv, kv_cache, t_max, row_seq,
+                       row_len, key_mask, ld_mask, S, chunk_cap, partial);
+    hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(M, n_q), dim3(128), 0, st, partial, n_q, S, out);
+  } else {
+    hipLaunchKernelGGL(attn_decode_split_kernel<64>, grid, dim3(256), lds, st, q, n_q, n_kv, kv_cache, t_max, row_seq,
+                       row_len, key_mask, ld_mask, S, chunk_cap, partial);
+    hipLaunchKernelGGL(attn_decode_combine_kernel<64>, dim3(M, n_q), dim3(64), 0, st, partial, n_q, S, out);
+  }
+  MN_CHECK_LAUNCH("mn_attn_decode");
+  return MN_OK;
+}

@@ -1,0 +1,386 @@
+// engine.hip — composite device-side sequences of the decode path (gfx950).
+//
+// One C call enqueues every launch of: the rectified-flow sampler for one visual token
+// (mn_rf_sample), one Bailing-MoE decoder-stack step (mn_llm_step) and one cached
+// MingTok semantic-decoder step + linear_proj (mn_semdec_step).  Nothing here touches
+// the host after enqueueing: positions, lengths, expert indices all live in device memory,
+// so a whole visual token can be captured into a hipGraph by the caller.
+#include <string.h>
+
+#include "common.h"
+
+extern "C" size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t t_max);
+
+namespace {
+
+struct Carver {  // carve 256-byte aligned pieces out of a caller-provided workspace
+  char* base;
+  size_t off, cap;
+  bool dry;
+  Carver(void* p, size_t n, bool d = false) : base((char*)p), off(0), cap(n), dry(d) {}
+  template <typename T>
+  T* take(size_t count) {
+    size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    T* r = dry ? nullptr : reinterpret_cast<T*>(base + off);
+    off += bytes;
+    return r;
+  }
+  bool ok() const { return dry || off <= cap; }
+};
+
+// ---------------- small fp32 row kernels ----------------
+__global__ __launch_bounds__(256) void rmsnorm_f32_kernel(const float* __restrict__ x, int64_t ldx,
+                                                          const bf16_t* __restrict__ g, float eps,
+                                                          float* __restrict__ y, int64_t ldy, int D) {
+  __shared__ float red[8];
+  const int m = blockIdx.x;
+  const float* xr = x + (int64_t)m * ldx;
+  float ss = 0.f;
+  for (int k = threadIdx.x; k < D; k += 256) { float v = xr[k]; ss += v * v; }
+  ss = block_sum(ss, red);
+  const float rstd = rsqrtf(ss / (float)D + eps);
+  for (int k = threadIdx.x; k < D; k += 256) y[(int64_t)m * ldy + k] = xr[k] * rstd * bf16_to_f32(g[k]);
+}
+
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ x, int64_t ldx,
+                                                            const bf16_t* __restrict__ g, const bf16_t* __restrict__ b,
+                                                            float eps, float* __restrict__ y, int64_t ldy, int D) {
+  __shared__ float red[8];
+  const int m = blockIdx.x;
+  const float* xr = x + (int64_t)m * ldx;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < D; k += 256) s += xr[k];
+  const float mean = block_sum(s, red) / (float)D;
+  float ss = 0.f;
+  for (int k = threadIdx.x; k < D; k += 256) { float d = xr[k] - mean; ss += d * d; }
+  ss = block_sum(ss, red);
+  const float rstd = rsqrtf(ss / (float)D + eps);
+  for (int k = threadIdx.x; k < D; k += 256) {
+    float v = (xr[k] - mean) * rstd;
+    if (g) v *= bf16_to_f32(g[k]);
+    if (b) v += bf16_to_f32(b[k]);
+    y[(int64_t)m * ldy + k] = v;
+  }
+}
+
+__global__ void rf_init_x_kernel(const float* __restrict__ noise, float temperature, float* __restrict__ x, int rows,
+                                 int target) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows * target) x[i] = noise[i % target] * temperature;
+}
+
+// CFG combine + Euler step (diff_loss_rf_swiglu.py:144-179): v rows = [cond, uncond, text_uncond]
+__global__ void rf_euler_kernel(const float* __restrict__ v, float* __restrict__ x, int rows, int target,
+                                float text_cfg, float image_cfg, float step) {
+  const int i = threadIdx.x;
+  if (i >= target) return;
+  float vg;
+  if (rows == 3) {
+    const float vc = v[i], vu = v[target + i], vtu = v[2 * target + i];
+    vg = vu + image_cfg * (vtu - vu) + text_cfg * (vc - vtu);
+  } else if (rows == 2) {
+    const float vc = v[i], vu = v[target + i];
+    vg = vu + text_cfg * (vc - vu);
+  } else {
+    vg = v[i];
+  }
+  for (int r = 0; r < rows; ++r) x[r * target + i] += vg * step;
+}
+
+// semantic decoder input: de-normalise, Linear(in_dim -> D) + channel-repeat shortcut
+// (modeling_mingtok.py:168; vision_transformer.py:373-380)
+__global__ void semdec_in_kernel(const float* __restrict__ latent, int in_dim, float scale, float mean,
+                                 const bf16_t* __restrict__ w, const bf16_t* __restrict__ b, float* __restrict__ out,
+                                 int D) {
+  const int m = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= D) return;
+  const float* lr = latent + (int64_t)m * in_dim;
+  float acc = bf16_to_f32(b[n]);
+  for (int k = 0; k < in_dim; ++k) acc = fmaf(bf16_to_f32(w[(int64_t)n * in_dim + k]), lr[k] * scale + mean, acc);
+  acc += lr[n / (D / in_dim)] * scale + mean;
+  out[(int64_t)m * D + n] = acc;
+}
+
+__global__ void copy_f32_kernel(const float* __restrict__ a, float* __restrict__ b, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[i] = a[i];
+}
+
+// rows copy with a source row stride (ldx == 0 broadcasts one row to all M rows)
+__global__ void copy_rows_f32_kernel(const float* __restrict__ a, int64_t lda, float* __restrict__ b, int M, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (int64_t)M * D) b[i] = a[(i / D) * lda + (i % D)];
+}
+
+__global__ void rows_advance_kernel(int32_t* a, int32_t* b, int32_t* c, int M, int delta) {
+  const int i = threadIdx.x;
+  if (i < M) {
+    if (a) a[i] += delta;
+    if (b) b[i] += delta;
+    if (c) c[i] += delta;
+  }
+}
+
+mn_skinny_args sk(const float* x, int64_t ldx, const bf16_t* w, int64_t ldw, const bf16_t* bias, float* out,
+                  int64_t ldo, int M, int N, int K) {
+  mn_skinny_args a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.ldx = ldx; a.w = w; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo;
+  a.M = M; a.N = N; a.K = K;
+  return a;
+}
+
+#define MN_TRY(expr)            \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != MN_OK) return rc__; \
+  } while (0)
+
+}  // namespace
+
+// ===========================================================================================
+// Rectified-flow head
+// ===========================================================================================
+static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, float** z, float** c, float** ada,
+                       float** hh, float** hid, float** v, float** x) {
+  Carver cv(ws, cap, ws == nullptr);
+  const int A = h->depth * 3 * h->w + 2 * h->w;
+  *z = cv.take<float>((size_t)rows * h->z_dim);
+  *c = cv.take<float>((size_t)rows * h->w);
+  *ada = cv.take<float>((size_t)rows * A);
+  *hh = cv.take<float>((size_t)rows * h->w);
+  *hid = cv.take<float>((size_t)rows * h->hidden);
+  *v = cv.take<float>((size_t)rows * h->target);
+  *x = cv.take<float>((size_t)rows * h->target);
+  return cv.off;
+}
+
+extern "C" size_t mn_rf_workspace_bytes(const mn_rf_head* h, int rows) {
+  float *a, *b, *c, *d, *e, *f, *g;
+  return rf_carve(h, rows, nullptr, 0, &a, &b, &c, &d, &e, &f, &g);
+}
+
+extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld_hidden, int rows, const float* noise,
+                            float temperature, float text_cfg, float image_cfg, float* latent_out, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  MN_CHECK_ARG(h && hidden && noise && latent_out && workspace, "mn_rf_sample: null pointer");
+  MN_CHECK_ARG(rows >= 1 && rows <= 3, "mn_rf_sample: rows=%d (1..3)", rows);
+  MN_CHECK_ARG(h->target <= 256, "mn_rf_sample: target too large");
+  float *z, *c, *ada, *hh, *hid, *v, *x;
+  const size_t need = rf_carve(h, rows, workspace, workspace_bytes, &z, &c, &ada, &hh, &hid, &v, &x);
+  if (need > workspace_bytes) { mn_set_error("mn_rf_sample: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
+  hipStream_t st = mn_stream(stream);
+  const int w = h->w, A = h->depth * 3 * w + 2 * w, T = h->target;
+
+  // z = vis_head Linear(hidden); c = cond_embed(LayerNorm(z))  (modeling_bailing_moe.py:1571-1574,1659; diff_loss:374)
+  {
+    mn_skinny_args a = sk(hidden, ld_hidden, h->vis_w, h->llm_hidden, h->vis_b, z, h->z_dim, rows, h->z_dim, h->llm_hidden);
+    MN_TRY(mn_skinny_gemm(&a, stream));
+    a = sk(z, h->z_dim, h->cond_w, h->z_dim, h->cond_b, c, w, rows, w, h->z_dim);
+    a.prologue = MN_PRO_LN; a.ln_g = h->vis_ln_g; a.ln_b = h->vis_ln_b; a.eps = 1e-6f;
+    MN_TRY(mn_skinny_gemm(&a, stream));
+  }
+  hipLaunchKernelGGL(rf_init_x_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, noise, temperature, x, rows, T);
+  const float step = 1.0f / (float)h->steps;
+  for (int s = 0; s < h->steps; ++s) {
+    // all adaLN projections of this step: Linear(SiLU(t_emb[s] + c))  (diff_loss:263-266,283-286,376)
+    mn_skinny_args a = sk(c, w, h->ada_w, w, h->ada_b, ada, A, rows, A, w);
+    a.prologue = MN_PRO_ADD_SILU; a.pro_a = h->temb + (int64_t)s * w; a.ld_pro_a = 0;
+    MN_TRY(mn_skinny_gemm(&a, stream));
+    // h = input_proj(x)  (diff_loss:371)
+    a = sk(x, T, h->in_w, T, h->in_b, hh, w, rows, w, T);
+    MN_TRY(mn_skinny_gemm(&a, stream));
+    for (int b = 0; b < h->depth; ++b) {
+      const float* mod = ada + (int64_t)b * 3 * w;
+      a = sk(hh, w, h->w12[b], w, h->b12[b], hid, h->hidden, rows, h->hidden, w);
+      a.prologue = MN_PRO_LN_MOD; a.ln_g = h->ln_g[b]; a.ln_b = h->ln_b[b]; a.eps = 1e-6f;
+      a.pro_a = mod; a.ld_pro_a = A; a.pro_b = mod + w; a.ld_pro_b = A;
+      a.epilogue = MN_EPI_SWIGLU;
+      MN_TRY(mn_skinny_gemm(&a, stream));
+      a = sk(hid, h->hidden, h->w3[b], h->hidden, h->b3[b], hh, w, rows, w, h->hidden);
+      a.epilogue = MN_EPI_RESID_GATE; a.res = hh; a.ldres = w; a.gate = mod + 2 * w; a.ldgate = A;
+      MN_TRY(mn_skinny_gemm(&a, stream));
+    }
+    const float* modf = ada + (int64_t)h->depth * 3 * w;
+    a = sk(hh, w, h->fin_w, w, h->fin_b, v, T, rows, T, w);
+    a.prologue = MN_PRO_LN_MOD; a.eps = 1e-6f; a.pro_a = modf; a.ld_pro_a = A; a.pro_b = modf + w; a.ld_pro_b = A;
+    MN_TRY(mn_skinny_gemm(&a, stream));
+    hipLaunchKernelGGL(rf_euler_kernel, dim3(1), dim3(256), 0, st, v, x, rows, T, text_cfg, image_cfg, step);
+  }
+  hipLaunchKernelGGL(copy_f32_kernel, dim3(1), dim3(256), 0, st, x, latent_out, (int64_t)T);
+  MN_CHECK_LAUNCH("mn_rf_sample");
+  return MN_OK;
+}
+
+// ===========================================================================================
+// Bailing-MoE decoder stack step
+// ===========================================================================================
+struct LlmWs {
+  float *h, *qkv, *q, *attn, *xn, *tw, *hmid;
+  int32_t* ti;
+  void* attn_ws;
+  size_t attn_ws_bytes;
+};
+
+static size_t llm_carve(const mn_llm* m, int rows, int64_t t_max, void* ws, size_t cap, LlmWs* o) {
+  Carver cv(ws, cap, ws == nullptr);
+  const int n_slot = m->top_k + m->n_shared_slots;
+  const int qkv_dim = (m->n_q + 2 * m->n_kv) * m->head_dim;
+  o->h = cv.take<float>((size_t)rows * m->hidden);
+  o->qkv = cv.take<float>((size_t)rows * qkv_dim);
+  o->q = cv.take<float>((size_t)rows * m->n_q * m->head_dim);
+  o->attn = cv.take<float>((size_t)rows * m->n_q * m->head_dim);
+  o->xn = cv.take<float>((size_t)rows * m->hidden);
+  o->tw = cv.take<float>((size_t)rows * n_slot);
+  o->ti = cv.take<int32_t>((size_t)rows * n_slot);
+  o->hmid = cv.take<float>((size_t)rows * n_slot * m->moe_inter);
+  o->attn_ws_bytes = mn_attn_decode_workspace_bytes(rows, m->n_q, m->head_dim, t_max);
+  o->attn_ws = cv.take<char>(o->attn_ws_bytes);
+  return cv.off;
+}
+
+extern "C" size_t mn_llm_workspace_bytes(const mn_llm* m, int rows, int64_t t_max) {
+  LlmWs w;
+  return llm_carve(m, rows, t_max, nullptr, 0, &w);
+}
+
+extern "C" int mn_rows_advance(int32_t* a, int32_t* b, int32_t* c, int M, int delta, void* stream) {
+  MN_CHECK_ARG(M >= 1 && M <= 64, "mn_rows_advance: M=%d", M);
+  hipLaunchKernelGGL(rows_advance_kernel, dim3(1), dim3(64), 0, mn_stream(stream), a, b, c, M, delta);
+  MN_CHECK_LAUNCH("mn_rows_advance");
+  return MN_OK;
+}
+
+extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int M, const uint8_t* image_mask, const int32_t* row_seq,
+                           const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len,
+                           const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
+                           float* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
+  MN_CHECK_ARG(m && x && row_seq && row_slot && row_pos && row_len && kv_cache && hidden_out && workspace,
+               "mn_llm_step: null pointer");
+  MN_CHECK_ARG(M >= 1 && M <= 8, "mn_llm_step: M=%d (1..8)", M);
+  LlmWs w;
+  const size_t need = llm_carve(m, M, t_max, workspace, workspace_bytes, &w);
+  if (need > workspace_bytes) { mn_set_error("mn_llm_step: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
+  hipStream_t st = mn_stream(stream);
+  const int H = m->hidden, hd = m->head_dim, nq = m->n_q, nkv = m->n_kv, I = m->moe_inter;
+  const int qkv_dim = (nq + 2 * nkv) * hd, n_slot = m->top_k + m->n_shared_slots;
+  const int64_t layer_kv = (int64_t)n_seq * 2 * nkv * t_max * hd;
+  const float q_scale = 1.0f / sqrtf((float)hd);
+  hipLaunchKernelGGL(copy_rows_f32_kernel, dim3(mn_cdiv((int64_t)M * H, 256)), dim3(256), 0, st, x, ldx, w.h, M, H);
+  for (int l = 0; l < m->n_layers; ++l) {
+    float* kv_l = kv_cache + (int64_t)l * layer_kv;
+    // attention: RMSNorm -> QKV -> RoPE/KV append -> masked GQA -> dense + residual  (:1204-1215, :743-829)
+    mn_skinny_args a = sk(w.h, H, m->wqkv[l], H, nullptr, w.qkv, qkv_dim, M, qkv_dim, H);
+    a.prologue = MN_PRO_RMSNORM; a.ln_g = m->ln1[l]; a.eps = m->rms_eps;
+    MN_TRY(mn_skinny_gemm(&a, stream));
+    MN_TRY(mn_rope_kv_append(w.qkv, qkv_dim, M, nq, nkv, hd, 1, m->cos_tab, m->sin_tab, row_seq, row_slot, row_pos,
+                             q_scale, w.q, kv_l, t_max, stream));
+    MN_TRY(mn_attn_decode(w.q, M, nq, nkv, hd, kv_l, t_max, row_seq, row_len, key_mask, ld_mask, w.attn, w.attn_ws,
+                          w.attn_ws_bytes, stream));
+    a = sk(w.attn, nq * hd, m->wdense[l], nq * hd, nullptr, w.h, H, M, H, nq * hd);
+    a.epilogue = MN_EPI_RESID; a.res = w.h; a.ldres = H;
+    MN_TRY(mn_skinny_gemm(&a, stream));
+    // MoE: RMSNorm + router -> grouped expert gate/up (SwiGLU) -> grouped down + weighted sum + residual (:1218-1225, :556-639)
+    MN_TRY(mn_moe_router(w.h, H, m->ln2[l], m->rms_eps, m->gate[l], m->image_gate ? m->image_gate[l] : nullptr,
+                         image_mask, M, H, m->n_experts, m->top_k, m->norm_topk_prob, m->n_shared_slots, w.xn, w.ti,
+                         w.tw, stream));
+    a = sk(w.xn, H, m->w_gate_up[l], H, nullptr, w.hmid, I, 1, I, H);
+    a.epilogue = MN_EPI_SWIGLU;
+    a.batch = M * n_slot; a.w_index = w.ti; a.w_batch_stride = (int64_t)2 * I * H;
+    a.x_batch_stride = H; a.x_batch_div = n_slot; a.out_batch_stride = I;
+    MN_TRY(mn_skinny_gemm(&a, stream));
+    a = sk(w.hmid, (int64_t)n_slot * I, m->w_down[l], I, nullptr, w.h, H, 1, H, I);
+    a.epilogue = MN_EPI_RESID; a.res = w.h; a.ldres = H; a.res_batch_stride = H;
+    a.batch = M; a.w_index = nullptr; a.w_batch_stride = 0;
+    a.x_batch_stride = (int64_t)n_slot * I; a.x_batch_div = 1; a.out_batch_stride = H;
+    a.nseg = n_slot; a.seg_index = w.ti; a.seg_scale = w.tw; a.seg_w_stride = (int64_t)H * I;
+    MN_TRY(mn_skinny_gemm(&a, stream));
+  }
+  hipLaunchKernelGGL(rmsnorm_f32_kernel, dim3(M), dim3(256), 0, st, w.h, (int64_t)H, m->final_norm, m->rms_eps,
+                     hidden_out, (int64_t)H, H);
+  MN_CHECK_LAUNCH("mn_llm_step");
+  return MN_OK;
+}
+
+// ===========================================================================================
+// MingTok semantic decoder: cached causal decode step + linear_proj
+// ===========================================================================================
+struct SemWs {
+  float *h, *qkv, *q, *attn, *hid, *sem, *p0;
+  void* attn_ws;
+  size_t attn_ws_bytes;
+};
+
+static size_t sem_carve(const mn_semdec* s, int rows, int64_t t_max, void* ws, size_t cap, SemWs* o) {
+  Carver cv(ws, cap, ws == nullptr);
+  o->h = cv.take<float>((size_t)rows * s->dim);
+  o->qkv = cv.take<float>((size_t)rows * 3 * s->dim);
+  o->q = cv.take<float>((size_t)rows * s->dim);
+  o->attn = cv.take<float>((size_t)rows * s->dim);
+  o->hid = cv.take<float>((size_t)rows * s->hidden);
+  o->sem = cv.take<float>((size_t)rows * s->dim);
+  o->p0 = cv.take<float>((size_t)rows * s->proj_dim * 2);
+  o->attn_ws_bytes = mn_attn_decode_workspace_bytes(rows, s->n_heads, 64, t_max);
+  o->attn_ws = cv.take<char>(o->attn_ws_bytes);
+  return cv.off;
+}
+
+extern "C" size_t mn_semdec_workspace_bytes(const mn_semdec* s, int rows, int64_t t_max) {
+  SemWs w;
+  return sem_carve(s, rows, t_max, nullptr, 0, &w);
+}
+
+extern "C" int mn_semdec_step(const mn_semdec* s, const float* latent_norm, int M, const int32_t* row_seq,
+                              const int32_t* row_slot, const int32_t* row_len, float* kv_cache, int n_seq,
+                              int64_t t_max, float* sem_out, float* embed_out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  MN_CHECK_ARG(s && latent_norm && row_seq && row_slot && row_len && kv_cache && workspace, "mn_semdec_step: null pointer");
+  MN_CHECK_ARG(M >= 1 && M <= 8 && s->dim == s->n_heads * 64 && s->dim % s->in_dim == 0, "mn_semdec_step: bad shape");
+  MN_CHECK_ARG(!embed_out || (s->proj_depth >= 1 && s->proj_depth <= 2), "mn_semdec_step: proj_depth must be 1 or 2");
+  SemWs w;
+  const size_t need = sem_carve(s, M, t_max, workspace, workspace_bytes, &w);
+  if (need > workspace_bytes) { mn_set_error("mn_semdec_step: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
+  hipStream_t st = mn_stream(stream);
+  const int D = s->dim, nh = s->n_heads;
+  const int64_t layer_kv = (int64_t)n_seq * 2 * nh * t_max * 64;
+  hipLaunchKernelGGL(semdec_in_kernel, dim3(mn_cdiv(D, 256), M), dim3(256), 0, st, latent_norm, s->in_dim, s->scale,
+                     s->mean, s->in_w, s->in_b, w.h, D);
+  for (int l = 0; l < s->depth; ++l) {
+    float* kv_l = kv_cache + (int64_t)l * layer_kv;
+    mn_skinny_args a = sk(w.h, D, s->wqkv[l], D, s->bqkv[l], w.qkv, 3 * D, M, 3 * D, D);
+    a.prologue = MN_PRO_LN; a.ln_g = s->ln1_g[l]; a.ln_b = s->ln1_b[l]; a.eps = 1e-6f;
+    MN_TRY(mn_skinny_gemm(&a, stream));
+    MN_TRY(mn_rope_kv_append(w.qkv, 3 * D, M, nh, nh, 64, 0, nullptr, nullptr, row_seq, row_slot, nullptr, 0.125f,
+                             w.q, kv_l, t_max, stream));
+    MN_TRY(mn_attn_decode(w.q, M, nh, nh, 64, kv_l, t_max, row_seq, row_len, nullptr, 0, w.attn, w.attn_ws,
+                          w.attn_ws_bytes, stream));
+    a = sk(w.attn, D, s->wproj[l], D, s->bproj[l], w.h, D, M, D, D);
+    a.epilogue = MN_EPI_RESID; a.res = w.h; a.ldres = D;
+    MN_TRY(mn_skinny_gemm(&a, stream));
+    a = sk(w.h, D, s->w12[l], D, s->b12[l], w.hid, s->hidden, M, s->hidden, D);
+    a.prologue = MN_PRO_LN; a.ln_g = s->ln2_g[l]; a.ln_b = s->ln2_b[l]; a.eps = 1e-6f;
+    a.epilogue = MN_EPI_SWIGLU;
+    MN_TRY(mn_skinny_gemm(&a, stream));
+    a = sk(w.hid, s->hidden, s->w3[l], s->hidden, s->b3[l], w.h, D, M, D, s->hidden);
+    a.epilogue = MN_EPI_RESID; a.res = w.h; a.ldres = D;
+    MN_TRY(mn_skinny_gemm(&a, stream));
+  }
+  float* sem = sem_out ? sem_out : w.sem;
+  hipLaunchKernelGGL(layernorm_f32_kernel, dim3(M), dim3(256), 0, st, w.h, (int64_t)D, s->norm_g, s->norm_b, 1e-6f, sem,
+                     (int64_t)D, D);
+  if (embed_out) {
+    // linear_proj = Linear [GELU Linear]  (modeling_bailingmm.py:111-115)
+    if (s->proj_depth == 1) {
+      mn_skinny_args a = sk(sem, D, s->proj_w[0], D, s->proj_b[0], embed_out, s->proj_dim, M, s->proj_dim, D);
+      MN_TRY(mn_skinny_gemm(&a, stream));
+    } else {
+      mn_skinny_args a = sk(sem, D, s->proj_w[0], D, s->proj_b[0], w.p0, s->proj_dim, M, s->proj_dim, D);
+      a.epilogue = MN_EPI_GELU;
+      MN_TRY(mn_skinny_gemm(&a, stream));
+      a = sk(w.p0, s->proj_dim, s->proj_w[1], s->proj_dim, s->proj_b[1], embed_out, s->proj_dim, M, s->proj_dim, s->proj_dim);
+      MN_TRY(mn_skinny_gemm(&a, stream));
+    }
+  }
+  MN_CHECK_LAUNCH("mn_semdec_step");
+  return MN_OK;
+}

@@ -1,0 +1,328 @@
+// skinny_gemm.hip — weight-streaming GEMM for M <= 8 activation rows (gfx950).
+//
+//   out[m, n] = epilogue( sum_k prologue(x)[m, k] * W[n, k] + bias[n] )
+//
+// Roofline: HBM. Every weight byte is read exactly once per launch (non-temporal 16-byte loads,
+// one wave covers 1 KiB of one weight row per instruction), activations are tiny and live in LDS
+// as fp32 (so the result is fp32-accurate against the fp32 oracle; only the weights are bf16).
+//
+// Work decomposition: a block stages prologue(x) into LDS once (fused RMSNorm / LayerNorm /
+// adaLN-modulate / SiLU), then its waves walk "row groups" of R consecutive output rows in a
+// grid-stride loop.  Within a row group each lane owns 8 consecutive k of every 512-wide chunk,
+// accumulates R x M partial sums in registers and the wave reduces them with xor shuffles.
+// The LDS image of x is permuted so that the two ds_read_b128 per (row, chunk) are
+// lane-contiguous (conflict-free): position c*512 + j*256 + lane*4 + i holds x[c*512 + lane*8 + j*4 + i].
+#include "common.h"
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct KArgs {  // device copy of mn_skinny_args (plain data)
+  mn_skinny_args a;
+  int32_t nchunk;   // chunks of 512 k per segment
+  int32_t nseg;
+  int32_t batch;
+};
+
+__device__ __forceinline__ int perm_k(int k) {
+  return (k & ~511) | (((k >> 2) & 1) << 8) | (((k >> 3) & 63) << 2) | (k & 3);
+}
+
+// Stage prologue(x) for this block's batch entry into LDS. xs layout: [M][nseg][nchunk*512] permuted.
+template <int M, int NT>
+__device__ void stage_x(const KArgs& ka, float* xs, float* red, int b) {
+  const mn_skinny_args& a = ka.a;
+  const int K = a.K, Kp = ka.nchunk << 9, nseg = ka.nseg;
+  const int tid = threadIdx.x;
+  const float* xb = a.x + (int64_t)(b / (a.x_batch_div > 0 ? a.x_batch_div : 1)) * a.x_batch_stride;
+  const int Ktot = K * nseg;  // contiguous per row in global memory
+  const int pro = a.prologue;
+
+  if (pro == MN_PRO_NONE || pro == MN_PRO_SILU || pro == MN_PRO_ADD_SILU) {
+    for (int m = 0; m < M; ++m) {
+      const float* xr = xb + (int64_t)m * a.ldx;
+      for (int s = 0; s < nseg; ++s) {
+        const float sc = a.seg_scale ? a.seg_scale[(int64_t)b * nseg + s] : 1.0f;
+        float* dst = xs + ((int64_t)m * nseg + s) * Kp;
+        for (int k = tid; k < Kp; k += NT) {
+          float v = 0.f;
+          if (k < K) {
+            v = xr[s * K + k];
+            if (pro == MN_PRO_ADD_SILU) v += a.pro_a[(int64_t)m * a.ld_pro_a + k];
+            if (pro != MN_PRO_NONE) v = silu_f(v);
+            v *= sc;
+          }
+          dst[perm_k(k)] = v;
+        }
+      }
+    }
+    return;
+  }
+  // Normalising prologues (nseg == 1): two-pass statistics from LDS-resident raw rows.
+  for (int m = 0; m < M; ++m) {
+    const float* xr = xb + (int64_t)m * a.ldx;
+    float* dst = xs + (int64_t)m * Kp;
+    float s = 0.f;
+    for (int k = tid; k < Kp; k += NT) {
+      float v = (k < K) ? xr[k] : 0.f;
+      dst[perm_k(k)] = v;
+      s += v;
+    }
+    float mean = 0.f, rstd;
+    if (pro == MN_PRO_RMSNORM) {
+      float ss = 0.f;
+      for (int k = tid; k < K; k += NT) { float v = dst[perm_k(k)]; ss += v * v; }
+      ss = block_sum(ss, red);
+      rstd = rsqrtf(ss / (float)K + a.eps);
+    } else {
+      mean = block_sum(s, red) / (float)K;
+      float ss = 0.f;
+      for (int k = tid; k < K; k += NT) { float d = dst[perm_k(k)] - mean; ss += d * d; }
+      ss = block_sum(ss, red);
+      rstd = rsqrtf(ss / (float)K + a.eps);
+    }
+    for (int k = tid; k < K; k += NT) {
+      const int p = perm_k(k);
+      float v = (dst[p] - mean) * rstd;
+      if (a.ln_g) v *= bf16_to_f32(a.ln_g[k]);
+      if (a.ln_b && pro != MN_PRO_RMSNORM) v += bf16_to_f32(a.ln_b[k]);
+      if (pro == MN_PRO_LN_MOD)
+        v = v * (1.0f + a.pro_b[(int64_t)m * a.ld_pro_b + k]) + a.pro_a[(int64_t)m * a.ld_pro_a + k];
+      dst[p] = v;
+    }
+  }
+}
+
+template <int M>
+__device__ __forceinline__ void fma_chunk(const u32x4 w, const float* xrow0, int64_t xstride, float (&acc)[M]) {
+  const float w0 = bf16lo_to_f32(w.x), w1 = bf16hi_to_f32(w.x), w2 = bf16lo_to_f32(w.y), w3 = bf16hi_to_f32(w.y);
+  const float w4 = bf16lo_to_f32(w.z), w5 = bf16hi_to_f32(w.z), w6 = bf16lo_to_f32(w.w), w7 = bf16hi_to_f32(w.w);
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const f32x4 xa = *reinterpret_cast<const f32x4*>(xrow0 + m * xstride);
+    const f32x4 xb = *reinterpret_cast<const f32x4*>(xrow0 + m * xstride + 256);
+    float t = acc[m];
+    t = fmaf(w0, xa.x, t); t = fmaf(w1, xa.y, t); t = fmaf(w2, xa.z, t); t = fmaf(w3, xa.w, t);
+    t = fmaf(w4, xb.x, t); t = fmaf(w5, xb.y, t); t = fmaf(w6, xb.z, t); t = fmaf(w7, xb.w, t);
+    acc[m] = t;
+  }
+}
+
+// SW: number of weight row sets per output row (2 for SWIGLU, else 1).
+template <int M, int R, int SW, int NT>
+__global__ __launch_bounds__(NT) void skinny_kernel(const KArgs ka) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const mn_skinny_args& a = ka.a;
+  const int nchunk = ka.nchunk, Kp = nchunk << 9, nseg = ka.nseg, K = a.K, N = a.N;
+  float* xs = smem;
+  float* red = smem + (int64_t)M * nseg * Kp;
+  const int b = blockIdx.y;
+  stage_x<M, NT>(ka, xs, red, b);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwaves = gridDim.x * (NT / 64);
+  const int ngroups = (N + R - 1) / R;
+  const int64_t xstride = (int64_t)nseg * Kp;  // LDS row stride (floats)
+  const int wsel = a.w_index ? a.w_index[b] : b;
+  const bf16_t* wbase = a.w + (int64_t)wsel * a.w_batch_stride;
+  const int lane_k = lane * 8;
+
+  for (int g = blockIdx.x * (NT / 64) + wave; g < ngroups; g += nwaves) {
+    const int n0 = g * R;
+    float acc[SW][R][M];
+#pragma unroll
+    for (int s = 0; s < SW; ++s)
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[s][r][m] = 0.f;
+
+    for (int sg = 0; sg < nseg; ++sg) {
+      const bf16_t* wseg = wbase + (a.seg_index ? (int64_t)a.seg_index[(int64_t)b * nseg + sg] * a.seg_w_stride : 0);
+      const bf16_t* wrow[SW][R];
+#pragma unroll
+      for (int s = 0; s < SW; ++s)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int n = min(n0 + r, N - 1) + s * N;
+          wrow[s][r] = wseg + (int64_t)n * a.ldw + lane_k;
+        }
+      const float* xsg = xs + (int64_t)sg * Kp + lane * 4;
+      int c = 0;
+      // main loop: two chunks (2 x SW x R 16-byte loads) in flight per lane
+      for (; c + 2 <= nchunk && (c + 2) * 512 <= K; c += 2) {
+        u32x4 w0[SW][R], w1[SW][R];
+#pragma unroll
+        for (int s = 0; s < SW; ++s)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            w0[s][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[s][r] + c * 512));
+            w1[s][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[s][r] + c * 512 + 512));
+          }
+#pragma unroll
+        for (int s = 0; s < SW; ++s)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            fma_chunk<M>(w0[s][r], xsg + c * 512, xstride, acc[s][r]);
+            fma_chunk<M>(w1[s][r], xsg + c * 512 + 512, xstride, acc[s][r]);
+          }
+      }
+      for (; c < nchunk; ++c) {  // tail chunks (possibly partial)
+        const bool valid = (c * 512 + lane_k) < K;
+#pragma unroll
+        for (int s = 0; s < SW; ++s)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            u32x4 w = {0u, 0u, 0u, 0u};
+            if (valid) w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[s][r] + c * 512));
+            fma_chunk<M>(w, xsg + c * 512, xstride, acc[s][r]);
+          }
+      }
+    }
+
+    // wave reduction; afterwards every lane holds every sum
+#pragma unroll
+    for (int s = 0; s < SW; ++s)
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[s][r][m] = wave_sum(acc[s][r][m]);
+
+    // epilogue: lane (r*M + m) stores element (m, n0 + r)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        if (lane == r * M + m) {
+          const int n = n0 + r;
+          if (n < N) {
+            float y = acc[0][r][m];
+            if (a.bias) y += bf16_to_f32(a.bias[n]);
+            float* o = a.out + (int64_t)b * a.out_batch_stride + (int64_t)m * a.ldo + n;
+            switch (a.epilogue) {
+              case MN_EPI_SILU: y = silu_f(y); break;
+              case MN_EPI_GELU: y = gelu_erf_f(y); break;
+              case MN_EPI_SWIGLU: {
+                float y2 = acc[SW - 1][r][m];
+                if (a.bias) y2 += bf16_to_f32(a.bias[n + N]);
+                y = silu_f(y) * y2;
+              } break;
+              case MN_EPI_RESID:
+                y += a.res[(int64_t)b * a.res_batch_stride + (int64_t)m * a.ldres + n];
+                break;
+              case MN_EPI_RESID_GATE:
+                y = a.res[(int64_t)b * a.res_batch_stride + (int64_t)m * a.ldres + n] +
+                    a.gate[(int64_t)m * a.ldgate + n] * y;
+                break;
+              default: break;
+            }
+            *o = y;
+          }
+        }
+      }
+  }
+}
+
+// Dynamic LDS above 64 KiB needs an explicit opt-in, once per kernel.
+template <int M, int R, int SW, int NT>
+void launch_one(const KArgs& ka, dim3 grid, size_t lds, hipStream_t st) {
+  static bool opted = false;
+  if (!opted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_kernel<M, R, SW, NT>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    opted = true;
+  }
+  hipLaunchKernelGGL((skinny_kernel<M, R, SW, NT>), grid, dim3(NT), lds, st, ka);
+}
+
+template <int M, int R, int SW>
+int launch_nt(const KArgs& ka, int nt, dim3 grid, size_t lds, hipStream_t st) {
+  if (nt == 256) launch_one<M, R, SW, 256>(ka, grid, lds, st);
+  else if (nt == 512) launch_one<M, R, SW, 512>(ka, grid, lds, st);
+  else launch_one<M, R, SW, 1024>(ka, grid, lds, st);
+  return 0;
+}
+
+template <int M>
+int launch_m(const KArgs& ka, int R, int sw, int nt, dim3 grid, size_t lds, hipStream_t st) {
+  if (sw == 2) {
+    if (R >= 2) return launch_nt<M, 2, 2>(ka, nt, grid, lds, st);
+    return launch_nt<M, 1, 2>(ka, nt, grid, lds, st);
+  }
+  if (R >= 4) return launch_nt<M, 4, 1>(ka, nt, grid, lds, st);
+  if (R >= 2) return launch_nt<M, 2, 1>(ka, nt, grid, lds, st);
+  return launch_nt<M, 1, 1>(ka, nt, grid, lds, st);
+}
+
+}  // namespace
+
+extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
+  MN_CHECK_ARG(args != nullptr, "mn_skinny_gemm: null args");
+  KArgs ka;
+  ka.a = *args;
+  mn_skinny_args& a = ka.a;
+  MN_CHECK_ARG(a.M >= 1 && a.M <= 8, "mn_skinny_gemm: M=%d out of range [1,8]", a.M);
+  MN_CHECK_ARG(a.N >= 1 && a.K >= 8 && (a.K % 8) == 0, "mn_skinny_gemm: bad N=%d K=%d (K %% 8 must be 0)", a.N, a.K);
+  MN_CHECK_ARG((a.ldw % 8) == 0, "mn_skinny_gemm: ldw=%lld must be a multiple of 8", (long long)a.ldw);
+  MN_CHECK_ARG(a.x && a.w && a.out, "mn_skinny_gemm: null pointer");
+  MN_CHECK_ARG(a.prologue >= 0 && a.prologue <= MN_PRO_LN_MOD, "mn_skinny_gemm: bad prologue %d", a.prologue);
+  MN_CHECK_ARG(a.epilogue >= 0 && a.epilogue <= MN_EPI_RESID_GATE, "mn_skinny_gemm: bad epilogue %d", a.epilogue);
+  ka.nseg = a.nseg > 0 ? a.nseg : 1;
+  ka.batch = a.batch > 0 ? a.batch : 1;
+  MN_CHECK_ARG(ka.nseg == 1 || a.prologue <= MN_PRO_ADD_SILU, "mn_skinny_gemm: normalising prologue with segments");
+  MN_CHECK_ARG(a.prologue != MN_PRO_ADD_SILU || a.pro_a, "mn_skinny_gemm: ADD_SILU needs pro_a");
+  MN_CHECK_ARG(a.prologue != MN_PRO_LN_MOD || (a.pro_a && a.pro_b), "mn_skinny_gemm: LN_MOD needs shift/scale");
+  MN_CHECK_ARG(a.prologue != MN_PRO_RMSNORM || a.ln_g, "mn_skinny_gemm: RMSNORM needs ln_g");
+  MN_CHECK_ARG((a.epilogue != MN_EPI_RESID && a.epilogue != MN_EPI_RESID_GATE) || a.res, "mn_skinny_gemm: RESID needs res");
+  MN_CHECK_ARG(a.epilogue != MN_EPI_RESID_GATE || a.gate, "mn_skinny_gemm: RESID_GATE needs gate");
+  MN_CHECK_ARG((((uintptr_t)a.w) & 15) == 0 && ((a.w_batch_stride | a.seg_w_stride) % 8) == 0,
+               "mn_skinny_gemm: weights must be 16-byte aligned");
+  ka.nchunk = (a.K + 511) / 512;
+  const int64_t Kp = (int64_t)ka.nchunk * 512;
+  const size_t lds = ((size_t)a.M * ka.nseg * Kp + 32) * sizeof(float);
+  MN_CHECK_ARG(lds <= 160 * 1024, "mn_skinny_gemm: M*K too large for LDS (%zu bytes); split M", lds);
+
+  const int sw = a.epilogue == MN_EPI_SWIGLU ? 2 : 1;
+  // Occupancy plan: blocks per CU limited by LDS; 16+ waves per CU wanted.
+  const int cus = mn_num_cus();
+  int bpc = (int)((160 * 1024) / lds);
+  int nt;
+  if (bpc >= 4) { nt = 256; bpc = bpc > 8 ? 8 : bpc; }
+  else if (bpc >= 2) { nt = 512; }
+  else { nt = 1024; bpc = 1; }
+  const int waves_per_block = nt / 64;
+  // rows per wave: keep >= ~2 row groups per resident wave when N is large, else favour parallelism
+  const int64_t resident_waves = (int64_t)cus * bpc * waves_per_block / ka.batch + 1;
+  int R = 1;
+  if (sw == 1) {
+    if ((int64_t)a.N >= 8 * resident_waves) R = 4;
+    else if ((int64_t)a.N >= 4 * resident_waves) R = 2;
+  } else {
+    if ((int64_t)a.N >= 4 * resident_waves) R = 2;
+  }
+  if (R * a.M > 64) R = 64 / a.M;
+  if (sw == 2 && R > 2) R = 2;
+  if (R == 3) R = 2;
+  const int ngroups = (a.N + R - 1) / R;
+  int64_t gx = mn_cdiv(ngroups, waves_per_block);
+  const int64_t cap = mn_cdiv((int64_t)cus * bpc, ka.batch);
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  dim3 grid((unsigned)gx, (unsigned)ka.batch);
+  hipStream_t st = mn_stream(stream);
+  switch (a.M) {
+    case 1: launch_m<1>(ka, R, sw, nt, grid, lds, st); break;
+    case 2: launch_m<2>(ka, R, sw, nt, grid, lds, st); break;
+    case 3: launch_m<3>(ka, R, sw, nt, grid, lds, st); break;
+    case 4: launch_m<4>(ka, R, sw, nt, grid, lds, st); break;
+    case 5: launch_m<5>(ka, R, sw, nt, grid, lds, st); break;
+    case 6: launch_m<6>(ka, R, sw, nt, grid, lds, st); break;
+    case 7: launch_m<7>(ka, R, sw, nt, grid, lds, st); break;
+    default: launch_m<8>(ka, R, sw, nt, grid, lds, st); break;
+  }
+  MN_CHECK_LAUNCH("mn_skinny_gemm");
+  return MN_OK;
+}

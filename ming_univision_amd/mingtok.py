@@ -1,0 +1,254 @@
+"""Host-side mirror of MingTok-Vision (mingtok/modeling_mingtok.py:97-207).
+
+Public surface kept from the reference: `MingTok(config)`, `.forward(x)`, `.forward_enc_dec(x)`,
+`.forward_feature_decoder(h, past_key_values)`, `.forward_feature_decoder_wo_cache(h)`,
+`.forward_pixel_decoder(x)`, `.latent_dim`, `.feature_dim`, `.patch_size`.
+
+Two execution regimes, both entirely in libmingnative:
+  * batched (encode, semantic-decoder prefill, pixel decoder): bf16 MFMA GEMMs with fp32
+    accumulate and an fp32 residual stream, flash attention hd=64;
+  * cached decode of the causal semantic decoder (<= 8 rows): weight-streaming skinny GEMMs with
+    fp32 activations (mn_semdec_step), fused with linear_proj for the LLM's next input embedding.
+torch is used for memory, views and the load-time pos-embed interpolation table only.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, ops
+from ._lib import SemDec, check, current_stream, lib, ptr, ptr_array
+from .configuration import MingTokConfig, mingtok_param_shapes, swiglu_hidden
+
+
+class SemDecodeState:
+    """KV arena + device row bookkeeping of a cached semantic-decoder decode (replaces DynamicCache)."""
+
+    def __init__(self, depth, n_heads, n_seq, t_max, device):
+        self.kv = torch.zeros(depth, n_seq, 2, n_heads, t_max, 64, dtype=torch.float32, device=device)
+        self.n_seq, self.t_max = n_seq, t_max
+        self.row_seq = torch.arange(n_seq, dtype=torch.int32, device=device)
+        self.row_slot = torch.zeros(n_seq, dtype=torch.int32, device=device)
+        self.row_len = torch.ones(n_seq, dtype=torch.int32, device=device)
+        self.length = 0
+
+    def get_seq_length(self):
+        return self.length
+
+
+class MingTok:
+    config_class = MingTokConfig
+
+    def __init__(self, config: MingTokConfig, state_dict=None, device="cuda", seed=0, linear_proj=None):
+        """state_dict: reference-named tensors (any float dtype; stored as bf16 in HBM); None -> synthetic.
+        linear_proj: optional list of (weight, bias) bf16 CUDA tensors (modeling_bailingmm.py:111-115)
+        fused behind the decode step."""
+        self.config = config
+        enc, sem, pix = config.low_level_encoder, config.semantic_decoder, config.pixel_decoder
+        self.latent_dim = enc.get("out_dim", 32)
+        self.feature_dim = sem.get("embed_dim", 1024)
+        self.patch_size = enc.get("patch_size", 32)
+        self.pix_patch = pix.get("patch_size", 16)
+        self.sem_patch = sem.get("patch_size", 16)
+        self.scaling_factor, self.mean = config.scaling_factor, config.mean
+        self.device = torch.device(device)
+        shapes = mingtok_param_shapes(config)
+        if state_dict is None:
+            from .synth import synth_tensor
+            self.sd = {k: synth_tensor(k, s, seed, self.device, torch.bfloat16) for k, s in shapes.items()}
+        else:
+            missing = [k for k in shapes if k not in state_dict]
+            if missing:
+                raise KeyError(f"MingTok state dict is missing {missing[:5]}…")
+            self.sd = {k: state_dict[k].to(self.device, torch.bfloat16).contiguous() for k in shapes}
+        self.enc_depth, self.sem_depth, self.pix_depth = enc.get("depth", 24), sem.get("decoder_depth", 1), pix.get("decoder_depth", 1)
+        self.enc_dim, self.pix_dim = enc.get("embed_dim", 1024), pix.get("embed_dim", 1024)
+        self._pos_cache = {}
+        self._semdec_struct = None
+        self.linear_proj = linear_proj
+        self._ws = {}
+
+    # ---- helpers ---------------------------------------------------------------------------
+    def _w(self, k):
+        return self.sd[k]
+
+    def _block(self, x, prefix, D, B, T, causal):
+        """Block.forward / CausalBlock.forward (layers/block.py:80-105, 301-327) on the fp32 residual x [B*T, D]."""
+        nh = D // 64
+        xn = ops.layernorm_bf16(x, self._w(prefix + ".norm1.weight"), self._w(prefix + ".norm1.bias"))
+        qkv = ops.gemm_bf16(xn, self._w(prefix + ".attn.qkv.weight"), self._w(prefix + ".attn.qkv.bias"))
+        att = ops.attn_prefill_hd64(qkv, B, T, nh, causal)
+        ops.gemm_bf16(att, self._w(prefix + ".attn.proj.weight"), self._w(prefix + ".attn.proj.bias"), "f32_resid", out=x)
+        xn = ops.layernorm_bf16(x, self._w(prefix + ".norm2.weight"), self._w(prefix + ".norm2.bias"))
+        if (prefix + ".mlp.w12.weight") in self.sd:
+            h12 = ops.gemm_bf16(xn, self._w(prefix + ".mlp.w12.weight"), self._w(prefix + ".mlp.w12.bias"))
+            h = ops.swiglu_bf16(h12)
+            ops.gemm_bf16(h, self._w(prefix + ".mlp.w3.weight"), self._w(prefix + ".mlp.w3.bias"), "f32_resid", out=x)
+        else:
+            h = ops.gemm_bf16(xn, self._w(prefix + ".mlp.fc1.weight"), self._w(prefix + ".mlp.fc1.bias"), "bf16_gelu")
+            ops.gemm_bf16(h, self._w(prefix + ".mlp.fc2.weight"), self._w(prefix + ".mlp.fc2.bias"), "f32_resid", out=x)
+        return x
+
+    def _pos_embed(self, npatch, w, h):
+        """interpolate_pos_encoding (vision_transformer.py:183-215) — cached per resolution (load-time table)."""
+        key = (npatch, w, h)
+        if key in self._pos_cache:
+            return self._pos_cache[key]
+        pe = self._w("low_level_encoder.pos_embed").float()
+        N = pe.shape[1] - 1
+        if not (npatch == N and w == h):
+            P, dim = self.patch_size, pe.shape[-1]
+            w0, h0 = w // P, h // P
+            M = int(math.sqrt(N))
+            sx, sy = float(w0 + 0.1) / M, float(h0 + 0.1) / M
+            patch = F.interpolate(pe[:, :-1].reshape(1, M, M, dim).permute(0, 3, 1, 2), mode="bicubic",
+                                  antialias=False, scale_factor=(sx, sy))
+            assert (w0, h0) == patch.shape[-2:]
+            pe = torch.cat((patch.permute(0, 2, 3, 1).reshape(1, -1, dim), pe[:, -1:]), dim=1)
+        pe = pe.reshape(-1, pe.shape[-1]).contiguous()
+        self._pos_cache[key] = pe
+        return pe
+
+    # ---- encoder ---------------------------------------------------------------------------
+    def encode(self, x):
+        """low_level_encoder(x) -> RAW latent fp32 [B, N+1, latent_dim] (vision_transformer.py:225-233)."""
+        B, _, W, H = x.shape
+        P, D = self.patch_size, self.enc_dim
+        gh, gw = W // P, H // P
+        N = gh * gw
+        # im2col (view/permute only): conv k=s=P == GEMM over (c, ph, pw)  (patch_embed.py:76-78)
+        cols = x.to(self.device, torch.float32).reshape(B, 3, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B * N, 3 * P * P)
+        cols = ops.f32_to_bf16(cols.contiguous())
+        wpe = self._w("low_level_encoder.patch_embed.proj.weight").reshape(D, 3 * P * P)
+        tok = ops.gemm_bf16(cols, wpe, self._w("low_level_encoder.patch_embed.proj.bias"), "f32")
+        cls = ops.bf16_to_f32(self._w("low_level_encoder.cls_token").reshape(1, D))
+        xt = torch.cat((tok.reshape(B, N, D), cls.reshape(1, 1, D).expand(B, 1, D)), dim=1).contiguous()  # cls LAST (:221)
+        T = N + 1
+        pe = self._pos_embed(N, W, H)
+        xf = xt.reshape(B * T, D)
+        check(lib().mn_add_bcast_f32(ptr(xf), ptr(pe), ptr(xf), xf.numel(), pe.numel(), current_stream()), "mn_add_bcast_f32")
+        for i in range(self.enc_depth):
+            self._block(xf, f"low_level_encoder.blocks.0.{i}", D, B, T, causal=False)
+        # forward_out_layer (:173-178)
+        xn = ops.layernorm_bf16(xf, self._w("low_level_encoder.out_norm.weight"), self._w("low_level_encoder.out_norm.bias"), gelu=True)
+        y = ops.gemm_bf16(xn, self._w("low_level_encoder.out_proj.weight"), self._w("low_level_encoder.out_proj.bias"), "f32")
+        out = torch.empty_like(y)
+        check(lib().mn_group_mean_add(ptr(y), ptr(xf), ptr(out), B * T, D, self.latent_dim, current_stream()), "mn_group_mean_add")
+        return out.reshape(B, T, self.latent_dim)
+
+    # ---- semantic decoder, full causal pass -----------------------------------------------
+    def _semantic_decoder_full(self, latent_raw):
+        """forward_features without cache (vision_transformer.py:382-451): [B,T,in] RAW latent -> x_norm bf16->fp32 [B,T,D]."""
+        B, T, Cin = latent_raw.shape
+        D = self.feature_dim
+        lat = latent_raw.reshape(B * T, Cin).contiguous()
+        y = ops.gemm_bf16(ops.f32_to_bf16(lat), self._w("semantic_decoder.in_proj.weight"),
+                          self._w("semantic_decoder.in_proj.bias"), "f32")
+        x = torch.empty_like(y)
+        check(lib().mn_repeat_add(ptr(y), ptr(lat), ptr(x), B * T, D, Cin, 1.0, 0.0, current_stream()), "mn_repeat_add")
+        for i in range(self.sem_depth):
+            self._block(x, f"semantic_decoder.blocks.0.{i}", D, B, T, causal=True)
+        xn = ops.layernorm_bf16(x, self._w("semantic_decoder.norm.weight"), self._w("semantic_decoder.norm.bias"))
+        return ops.bf16_to_f32(xn).reshape(B, T, D)
+
+    def forward(self, x):
+        """MingTok.forward (modeling_mingtok.py:156-163)."""
+        latent = self.encode(x)
+        x_norm = self._semantic_decoder_full(latent)
+        return {"x_norm_patchtokens": x_norm[:, :-1], "latent": (latent - self.mean) / self.scaling_factor}
+
+    __call__ = forward
+
+    def forward_feature_decoder_wo_cache(self, hidden_states):
+        """(modeling_mingtok.py:176-177): RAW latent in, dict out."""
+        x_norm = self._semantic_decoder_full(hidden_states.to(self.device, torch.float32))
+        return {"x_norm_patchtokens": x_norm[:, :-1] if x_norm.shape[1] > 1 else x_norm, "x_norm": x_norm}
+
+    # ---- pixel decoder ----------------------------------------------------------------------
+    def forward_pixel_decoder(self, sem):
+        """MingTok.forward_pixel_decoder (modeling_mingtok.py:179-196): sem [B,N,Dsem] -> image [B,3,R,R] fp32 in [-1,1]."""
+        B, N, Ds = sem.shape
+        r = self.sem_patch // self.pix_patch
+        Dp = self.pix_dim
+        s = ops.f32_to_bf16(sem.to(self.device, torch.float32).reshape(B * N, Ds).contiguous())
+        y = ops.gemm_bf16(s, self._w("sem_to_pix.weight"), self._w("sem_to_pix.bias"), "f32")
+        h = w = int(math.sqrt(N))
+        # rearrange "b (h w) (x y c) -> b (h x w y) c" (view/permute only)
+        x = y.reshape(B, h, w, r, r, Dp).permute(0, 1, 3, 2, 4, 5).reshape(B * h * r * w * r, Dp).contiguous()
+        T = N * r * r
+        for i in range(self.pix_depth):
+            self._block(x, f"pixel_decoder.blocks.0.{i}", Dp, B, T, causal=False)
+        xn = ops.layernorm_bf16(x, self._w("pixel_decoder.norm.weight"), self._w("pixel_decoder.norm.bias"))
+        o = ops.gemm_bf16(xn, self._w("pixel_decoder.head.weight"), self._w("pixel_decoder.head.bias"), "f32")
+        p = self.pix_patch
+        hh = ww = int(math.sqrt(T))
+        # unpatchify (vision_transformer.py:515-527): 'nhwpqc->nchpwq' (view/permute only)
+        img = o.reshape(B, hh, ww, p, p, 3).permute(0, 5, 1, 3, 2, 4).reshape(B, 3, hh * p, ww * p).contiguous()
+        check(lib().mn_clamp_f32(ptr(img), img.numel(), -1.0, 1.0, current_stream()), "mn_clamp_f32")
+        return img
+
+    def forward_enc_dec(self, x):
+        """MingTok.forward_enc_dec (modeling_mingtok.py:150-153)."""
+        return self.forward_pixel_decoder(self.forward(x)["x_norm_patchtokens"])
+
+    # ---- cached decode -----------------------------------------------------------------------
+    def _semdec(self):
+        if self._semdec_struct is not None:
+            return self._semdec_struct
+        D, L = self.feature_dim, self.sem_depth
+        b = [f"semantic_decoder.blocks.0.{i}" for i in range(L)]
+        names = dict(ln1_g=".norm1.weight", ln1_b=".norm1.bias", wqkv=".attn.qkv.weight", bqkv=".attn.qkv.bias",
+                     wproj=".attn.proj.weight", bproj=".attn.proj.bias", ln2_g=".norm2.weight", ln2_b=".norm2.bias",
+                     w12=".mlp.w12.weight", b12=".mlp.w12.bias", w3=".mlp.w3.weight", b3=".mlp.w3.bias")
+        self._sem_arrays = {k: ptr_array([self._w(p + sfx) for p in b]) for k, sfx in names.items()}
+        s = SemDec()
+        s.dim, s.depth, s.n_heads, s.hidden = D, L, D // 64, swiglu_hidden(D)
+        s.in_dim = self.latent_dim
+        s.mean, s.scale = self.mean, self.scaling_factor
+        s.in_w, s.in_b = ptr(self._w("semantic_decoder.in_proj.weight")), ptr(self._w("semantic_decoder.in_proj.bias"))
+        for k, arr in self._sem_arrays.items():
+            setattr(s, k, C.cast(arr, _lib.PP))
+        s.norm_g, s.norm_b = ptr(self._w("semantic_decoder.norm.weight")), ptr(self._w("semantic_decoder.norm.bias"))
+        if self.linear_proj:
+            self._proj_arrays = (ptr_array([w for w, _ in self.linear_proj]), ptr_array([b_ for _, b_ in self.linear_proj]))
+            s.proj_w, s.proj_b = C.cast(self._proj_arrays[0], _lib.PP), C.cast(self._proj_arrays[1], _lib.PP)
+            s.proj_dim, s.proj_depth = self.linear_proj[0][0].shape[0], len(self.linear_proj)
+        else:
+            s.proj_dim, s.proj_depth = 8, 0
+        self._semdec_struct = s
+        return s
+
+    def new_decode_state(self, n_seq=1, t_max=256):
+        return SemDecodeState(self.sem_depth, self.feature_dim // 64, n_seq, t_max, self.device)
+
+    def decode_step(self, latent_norm, state: SemDecodeState, sem_out=None, embed_out=None):
+        """One cached causal step for state.n_seq rows. latent_norm fp32 [rows, latent_dim] (normalised).
+        Writes x_norm rows to sem_out [rows, D] and linear_proj(x_norm) to embed_out [rows, H] (if given)."""
+        s = self._semdec()
+        M = latent_norm.shape[0]
+        assert M == state.n_seq and state.length < state.t_max
+        assert latent_norm.dtype == torch.float32 and latent_norm.is_cuda and latent_norm.is_contiguous()
+        if sem_out is None:
+            sem_out = torch.empty(M, self.feature_dim, dtype=torch.float32, device=self.device)
+        key = (M, state.t_max)
+        if key not in self._ws:
+            n = lib().mn_semdec_workspace_bytes(C.byref(s), M, state.t_max)
+            self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.device)
+        ws = self._ws[key]
+        check(lib().mn_semdec_step(C.byref(s), ptr(latent_norm), M, ptr(state.row_seq), ptr(state.row_slot),
+                                   ptr(state.row_len), ptr(state.kv), state.n_seq, state.t_max, ptr(sem_out),
+                                   ptr(embed_out), ptr(ws), ws.numel(), current_stream()), "mn_semdec_step")
+        check(lib().mn_rows_advance(ptr(state.row_slot), ptr(state.row_len), None, M, 1, current_stream()), "mn_rows_advance")
+        state.length += 1
+        return sem_out
+
+    def forward_feature_decoder(self, hidden_states, past_key_values=None):
+        """MingTok.forward_feature_decoder (modeling_mingtok.py:165-174): normalised latent [rows,1,32] in,
+        dict(x_norm_patchtokens [rows,1,D], past_key_values) out."""
+        rows = hidden_states.shape[0]
+        if past_key_values is None:
+            past_key_values = self.new_decode_state(n_seq=rows)
+        lat = hidden_states.to(self.device, torch.float32).reshape(rows, self.latent_dim).contiguous()
+        sem = self.decode_step(lat, past_key_values)
+        return {"x_norm_patchtokens": sem.reshape(rows, 1, -1), "past_key_values": past_key_values}

@@ -1,0 +1,198 @@
+"""Tensor-level wrappers of the primitive C-ABI operators (torch tensors in, torch tensors out).
+
+PyTorch is plumbing here: it owns device memory and the stream; all arithmetic
+runs in libmingnative.so.  Every wrapper validates dtype/device and raises on
+any error code — nothing silently falls back to torch math.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import SkinnyArgs, check, current_stream, lib, ptr
+
+PRO = dict(none=0, silu=1, add_silu=2, rmsnorm=3, ln=4, ln_mod=5)
+EPI = dict(none=0, silu=1, gelu=2, swiglu=3, resid=4, resid_gate=5)
+GEMM_EPI = dict(bf16=0, bf16_gelu=1, f32=2, f32_resid=3)
+
+
+def _req(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a CUDA/HIP tensor (no CPU fallback exists)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def as_bf16_bits(t):
+    """bf16 tensor -> same storage (the ABI takes uint16 bit patterns)."""
+    return t
+
+
+def skinny_gemm(x, w, bias=None, *, prologue="none", epilogue="none", out=None, pro_a=None, pro_b=None,
+                ln_g=None, ln_b=None, eps=1e-6, res=None, gate=None, n_out=None):
+    """out[M,N] = epilogue(prologue(x)[M,K] @ w[N(,2N),K]^T + bias).  x fp32, w/bias/ln bf16."""
+    _req(x, torch.float32, "x"); _req(w, torch.bfloat16, "w"); _req(bias, torch.bfloat16, "bias")
+    _req(ln_g, torch.bfloat16, "ln_g"); _req(ln_b, torch.bfloat16, "ln_b")
+    _req(pro_a, torch.float32, "pro_a"); _req(pro_b, torch.float32, "pro_b")
+    _req(res, torch.float32, "res"); _req(gate, torch.float32, "gate")
+    M, K = x.shape
+    N = w.shape[0] // 2 if epilogue == "swiglu" else w.shape[0]
+    if n_out is not None:
+        N = n_out
+    assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    a = SkinnyArgs()
+    a.x, a.ldx = ptr(x), x.stride(0)
+    a.w, a.ldw = ptr(w), w.stride(0)
+    a.bias = ptr(bias)
+    a.out, a.ldo = ptr(out), out.stride(0)
+    a.M, a.N, a.K = M, N, K
+    a.prologue, a.epilogue = PRO[prologue], EPI[epilogue]
+    if pro_a is not None:
+        a.pro_a, a.ld_pro_a = ptr(pro_a), (0 if pro_a.dim() == 1 else pro_a.stride(0))
+    if pro_b is not None:
+        a.pro_b, a.ld_pro_b = ptr(pro_b), (0 if pro_b.dim() == 1 else pro_b.stride(0))
+    a.ln_g, a.ln_b, a.eps = ptr(ln_g), ptr(ln_b), eps
+    if res is not None:
+        a.res, a.ldres = ptr(res), res.stride(0)
+    if gate is not None:
+        a.gate, a.ldgate = ptr(gate), gate.stride(0)
+    check(lib().mn_skinny_gemm(C.byref(a), current_stream()), "mn_skinny_gemm")
+    return out
+
+
+def moe_router(x, norm_w, eps, gate_w, image_gate_w, image_mask, top_k, norm_topk_prob=True, n_shared_slots=0):
+    _req(x, torch.float32, "x"); _req(norm_w, torch.bfloat16, "norm_w"); _req(gate_w, torch.bfloat16, "gate_w")
+    _req(image_gate_w, torch.bfloat16, "image_gate_w"); _req(image_mask, torch.uint8, "image_mask")
+    M, H = x.shape
+    E = gate_w.shape[0]
+    n_slot = top_k + n_shared_slots
+    xn = torch.empty(M, H, dtype=torch.float32, device=x.device)
+    idx = torch.empty(M, n_slot, dtype=torch.int32, device=x.device)
+    w = torch.empty(M, n_slot, dtype=torch.float32, device=x.device)
+    check(lib().mn_moe_router(ptr(x), x.stride(0), ptr(norm_w), eps, ptr(gate_w), ptr(image_gate_w), ptr(image_mask),
+                              M, H, E, top_k, int(norm_topk_prob), n_shared_slots, ptr(xn), ptr(idx), ptr(w),
+                              current_stream()), "mn_moe_router")
+    return xn, idx, w
+
+
+def moe_experts(xn, idx, w, w_gate_up, w_down, res):
+    """Grouped expert MLPs of one MoE layer for M rows: returns res + sum_slot w * down(silu(gate x) * up x).
+    w_gate_up bf16 [E', 2I, H], w_down bf16 [E', H, I]; idx/w [M, n_slot] from moe_router."""
+    M, H = xn.shape
+    n_slot = idx.shape[1]
+    I = w_down.shape[2]
+    hmid = torch.empty(M * n_slot, I, dtype=torch.float32, device=xn.device)
+    a = SkinnyArgs()
+    a.x, a.ldx, a.w, a.ldw, a.out, a.ldo = ptr(xn), H, ptr(w_gate_up), H, ptr(hmid), I
+    a.M, a.N, a.K = 1, I, H
+    a.epilogue = EPI["swiglu"]
+    a.batch, a.w_index, a.w_batch_stride = M * n_slot, ptr(idx), 2 * I * H
+    a.x_batch_stride, a.x_batch_div, a.out_batch_stride = H, n_slot, I
+    check(lib().mn_skinny_gemm(C.byref(a), current_stream()), "mn_skinny_gemm(moe gate_up)")
+    out = torch.empty(M, H, dtype=torch.float32, device=xn.device)
+    b = SkinnyArgs()
+    b.x, b.ldx, b.w, b.ldw, b.out, b.ldo = ptr(hmid), n_slot * I, ptr(w_down), I, ptr(out), H
+    b.M, b.N, b.K = 1, H, I
+    b.epilogue = EPI["resid"]
+    b.res, b.ldres, b.res_batch_stride = ptr(res), res.stride(0), res.stride(0)
+    b.batch, b.x_batch_stride, b.x_batch_div, b.out_batch_stride = M, n_slot * I, 1, H
+    b.nseg, b.seg_index, b.seg_scale, b.seg_w_stride = n_slot, ptr(idx), ptr(w), H * I
+    check(lib().mn_skinny_gemm(C.byref(b), current_stream()), "mn_skinny_gemm(moe down)")
+    return out
+
+
+def rope_kv_append(qkv, n_q, n_kv, hd, kv_cache, row_seq, row_slot, row_pos=None, cos=None, sin=None, q_scale=1.0):
+    """kv_cache fp32 [n_seq, 2, n_kv, t_max, hd].  Returns q_out [M, n_q*hd]."""
+    _req(qkv, torch.float32, "qkv"); _req(kv_cache, torch.float32, "kv_cache")
+    M = qkv.shape[0]
+    t_max = kv_cache.shape[3]
+    q = torch.empty(M, n_q * hd, dtype=torch.float32, device=qkv.device)
+    rope = int(cos is not None)
+    check(lib().mn_rope_kv_append(ptr(qkv), qkv.stride(0), M, n_q, n_kv, hd, rope, ptr(cos), ptr(sin), ptr(row_seq),
+                                  ptr(row_slot), ptr(row_pos), q_scale, ptr(q), ptr(kv_cache), t_max,
+                                  current_stream()), "mn_rope_kv_append")
+    return q
+
+
+def attn_decode(q, n_q, n_kv, hd, kv_cache, row_seq, row_len, key_mask=None):
+    _req(q, torch.float32, "q"); _req(key_mask, torch.uint8, "key_mask")
+    M = q.shape[0]
+    t_max = kv_cache.shape[3]
+    nbytes = lib().mn_attn_decode_workspace_bytes(M, n_q, hd, t_max)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+    out = torch.empty(M, n_q * hd, dtype=torch.float32, device=q.device)
+    check(lib().mn_attn_decode(ptr(q), M, n_q, n_kv, hd, ptr(kv_cache), t_max, ptr(row_seq), ptr(row_len),
+                               ptr(key_mask), 0 if key_mask is None else key_mask.stride(0), ptr(out), ptr(ws), nbytes,
+                               current_stream()), "mn_attn_decode")
+    return out
+
+
+def gemm_bf16(a, w, bias=None, epilogue="bf16", out=None):
+    """a bf16 [M,K], w bf16 [N,K] -> bf16 or fp32 [M,N] (f32_resid accumulates into `out`)."""
+    _req(a, torch.bfloat16, "a"); _req(w, torch.bfloat16, "w"); _req(bias, torch.bfloat16, "bias")
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        assert epilogue != "f32_resid"
+        out = torch.empty(M, N, dtype=torch.bfloat16 if epilogue.startswith("bf16") else torch.float32, device=a.device)
+    _req(out, torch.bfloat16 if epilogue.startswith("bf16") else torch.float32, "out")
+    check(lib().mn_gemm_bf16(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(out), out.stride(0), M, N, K,
+                             GEMM_EPI[epilogue], current_stream()), "mn_gemm_bf16")
+    return out
+
+
+def layernorm_bf16(x, g, b, eps=1e-6, gelu=False):
+    _req(x, torch.float32, "x"); _req(g, torch.bfloat16, "g"); _req(b, torch.bfloat16, "b")
+    M, D = x.shape
+    y = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    check(lib().mn_layernorm_bf16(ptr(x), x.stride(0), ptr(g), ptr(b), eps, ptr(y), D, M, D, int(gelu),
+                                  current_stream()), "mn_layernorm_bf16")
+    return y
+
+
+def swiglu_bf16(x12):
+    _req(x12, torch.bfloat16, "x12")
+    M, H2 = x12.shape
+    h = torch.empty(M, H2 // 2, dtype=torch.bfloat16, device=x12.device)
+    check(lib().mn_swiglu_bf16(ptr(x12), x12.stride(0), ptr(h), H2 // 2, M, H2 // 2, current_stream()), "mn_swiglu_bf16")
+    return h
+
+
+def attn_prefill_hd64(qkv, B, T, n_heads, causal):
+    """qkv bf16 [B*T, 3*n_heads*64] -> bf16 [B*T, n_heads*64]."""
+    _req(qkv, torch.bfloat16, "qkv")
+    assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * n_heads * 64)
+    out = torch.empty(B * T, n_heads * 64, dtype=torch.bfloat16, device=qkv.device)
+    check(lib().mn_attn_prefill_hd64(ptr(qkv), ptr(out), B, T, n_heads, int(causal), current_stream()),
+          "mn_attn_prefill_hd64")
+    return out
+
+
+def f32_to_bf16(x):
+    _req(x, torch.float32, "x")
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib().mn_f32_to_bf16(ptr(x), ptr(y), x.numel(), current_stream()), "mn_f32_to_bf16")
+    return y
+
+
+def bf16_to_f32(x):
+    _req(x, torch.bfloat16, "x")
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib().mn_bf16_to_f32(ptr(x), ptr(y), x.numel(), current_stream()), "mn_bf16_to_f32")
+    return y
+
+
+def f32_split_bf16(x):
+    _req(x, torch.float32, "x")
+    x = x.contiguous()
+    hi = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib().mn_f32_split_bf16(ptr(x), ptr(hi), ptr(lo), x.numel(), current_stream()), "mn_f32_split_bf16")
+    return hi, lo

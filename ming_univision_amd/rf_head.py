@@ -1,0 +1,107 @@
+"""Host-side mirror of the rectified-flow continuous-token head.
+
+Mirrors `vis_head` + `RectifiedFlowLoss` as set up by
+BailingMoeForCausalLM.setup_vishead_diffloss (modeling_bailing_moe.py:1559-1584) and
+sampled in forward_for_image_generation_inner (:1659-1670) /
+RectifiedFlowLoss.sample (diff_loss_rf_swiglu.py:103-181).  All arithmetic runs in
+libmingnative (mn_rf_sample); this class only owns the bf16 weights in HBM,
+re-packs them once at load and builds the pointer table the C ABI takes.
+
+Load-time re-packing (results unchanged):
+  * the 12 blocks' adaLN projections and the final layer's are stacked into one
+    [depth*3w + 2w, w] matrix so a step's modulations are ONE weight-streaming launch;
+  * time_embed(t_s * 1000) only ever sees the `steps` fixed times of the Euler grid, so the
+    [steps, w] table is computed once (with the same kernels) instead of per token.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib, ops
+from ._lib import RfHead, check, current_stream, lib, ptr, ptr_array
+from .configuration import DEFAULT_VISHEAD_DIFFLOSS, swiglu_hidden
+
+
+class RectifiedFlowHead:
+    def __init__(self, sd, llm_hidden, vishead_diffloss_config=None, latent_dim=32, prefix=""):
+        """sd: {reference parameter name: bf16 CUDA tensor} holding `vis_head.*` and `diffloss.net.*`."""
+        cfg = {**DEFAULT_VISHEAD_DIFFLOSS, **(vishead_diffloss_config or {})}
+        assert cfg["vis_head_arch"] == "linear2-norm"          # modeling_bailing_moe.py:1568
+        assert cfg["gen_method"].startswith("flow_matching_swiglu-")
+        self.w = int(cfg["diffloss_w"])
+        self.depth = int(cfg["diffloss_d"])
+        self.steps = int(cfg["num_sampling_steps"])
+        self.hidden = swiglu_hidden(self.w, int(cfg["gen_method"].split("-")[1]))
+        self.target = latent_dim
+        self.llm_hidden = llm_hidden
+        g = lambda k: sd[prefix + k]
+        n = "diffloss.net."
+        self.t = dict(
+            vis_w=g("vis_head.0.weight"), vis_b=g("vis_head.0.bias"),
+            vis_ln_g=g("vis_head.1.weight"), vis_ln_b=g("vis_head.1.bias"),
+            cond_w=g(n + "cond_embed.weight"), cond_b=g(n + "cond_embed.bias"),
+            in_w=g(n + "input_proj.weight"), in_b=g(n + "input_proj.bias"),
+            fin_w=g(n + "final_layer.linear.weight"), fin_b=g(n + "final_layer.linear.bias"),
+        )
+        blocks = [n + f"res_blocks.{i}." for i in range(self.depth)]
+        self.t["ada_w"] = torch.cat([g(b + "adaLN_modulation.1.weight") for b in blocks]
+                                    + [g(n + "final_layer.adaLN_modulation.1.weight")], 0).contiguous()
+        self.t["ada_b"] = torch.cat([g(b + "adaLN_modulation.1.bias") for b in blocks]
+                                    + [g(n + "final_layer.adaLN_modulation.1.bias")], 0).contiguous()
+        self.lists = dict(
+            ln_g=[g(b + "in_ln.weight") for b in blocks], ln_b=[g(b + "in_ln.bias") for b in blocks],
+            w12=[g(b + "mlp.w12.weight") for b in blocks], b12=[g(b + "mlp.w12.bias") for b in blocks],
+            w3=[g(b + "mlp.w3.weight") for b in blocks], b3=[g(b + "mlp.w3.bias") for b in blocks],
+        )
+        for v in list(self.t.values()) + sum(self.lists.values(), []):
+            assert v.is_cuda and v.dtype == torch.bfloat16 and v.is_contiguous()
+        dev = self.t["vis_w"].device
+        # time-embedding table for t_s = linspace(1, 0, steps+1)[:-1] (diff_loss_rf_swiglu.py:135, 372-373)
+        ts = torch.linspace(1.0, 0.0, self.steps + 1)[:-1] * 1000.0
+        half = 128
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(0, half, dtype=torch.float32) / half)
+        args = ts[:, None].float() * freqs[None]
+        femb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(dev)
+        temb = []
+        for i in range(0, self.steps, 8):
+            h = ops.skinny_gemm(femb[i:i + 8].contiguous(), g(n + "time_embed.mlp.0.weight"),
+                                g(n + "time_embed.mlp.0.bias"), epilogue="silu")
+            temb.append(ops.skinny_gemm(h, g(n + "time_embed.mlp.2.weight"), g(n + "time_embed.mlp.2.bias")))
+        self.t["temb"] = torch.cat(temb, 0).contiguous()
+        self._arrays = {k: ptr_array(v) for k, v in self.lists.items()}
+        s = RfHead()
+        s.w, s.depth, s.hidden, s.z_dim, s.target, s.steps, s.llm_hidden = (
+            self.w, self.depth, self.hidden, self.w, self.target, self.steps, llm_hidden)
+        for k in ("vis_w", "vis_b", "vis_ln_g", "vis_ln_b", "cond_w", "cond_b", "in_w", "in_b", "temb", "ada_w",
+                  "ada_b", "fin_w", "fin_b"):
+            setattr(s, k, ptr(self.t[k]))
+        for k, arr in self._arrays.items():
+            setattr(s, k, C.cast(arr, _lib.PP))
+        self.struct = s
+        self._ws = {}
+
+    def weight_bytes_per_step(self):
+        """bf16 bytes one Euler step must stream from HBM."""
+        per_block = (2 * self.hidden * self.w + self.w * self.hidden) * 2
+        return self.depth * per_block + self.t["ada_w"].numel() * 2
+
+    def _workspace(self, rows, device):
+        if rows not in self._ws:
+            n = lib().mn_rf_workspace_bytes(C.byref(self.struct), rows)
+            self._ws[rows] = torch.empty(n, dtype=torch.uint8, device=device)
+        return self._ws[rows]
+
+    def sample(self, hidden, noise, temperature=1.0, text_cfg=3.0, image_cfg=1.1, out=None):
+        """hidden [rows, llm_hidden] fp32 (last hidden state of each CFG row), noise [target] fp32.
+        Returns the sampled latent [target] fp32 (identical for every CFG row)."""
+        rows = hidden.shape[0]
+        assert hidden.dtype == torch.float32 and hidden.is_cuda and hidden.stride(1) == 1
+        assert noise.dtype == torch.float32 and noise.numel() == self.target
+        ws = self._workspace(rows, hidden.device)
+        if out is None:
+            out = torch.empty(self.target, dtype=torch.float32, device=hidden.device)
+        check(lib().mn_rf_sample(C.byref(self.struct), ptr(hidden), hidden.stride(0), rows, ptr(noise),
+                                 float(temperature), float(text_cfg), float(image_cfg), ptr(out), ptr(ws), ws.numel(),
+                                 current_stream()), "mn_rf_sample")
+        return out

@@ -1,0 +1,206 @@
+"""GPU parity of every primitive C-ABI operator against a plain fp32 PyTorch statement of the
+same op (computed on CPU in float64/float32 from the SAME bf16-rounded weights).
+Tolerance: 1e-3 relative (north_star) unless a kernel's output type is bf16 (1 ulp = 2^-8)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from ming_univision_amd import ops as o
+    o.lib()
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def bw(*shape, seed=0, scale=1.0):
+    """bf16 weight on GPU + its exact fp32 value on CPU"""
+    w = rnd(*shape, seed=seed, scale=scale).to(torch.bfloat16)
+    return w.cuda(), w.float()
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 64, 32), (2, 3072, 3072), (3, 1000, 1408), (4, 37, 344), (8, 515, 2048),
+                                   (2, 3072, 8192), (5, 129, 8192), (7, 9, 520)])
+def test_skinny_plain_bias(ops, M, N, K):
+    x = rnd(M, K, seed=1)
+    w, wf = bw(N, K, seed=2, scale=K ** -0.5)
+    b, bf = bw(N, seed=3)
+    y = ops.skinny_gemm(x.cuda(), w, b)
+    assert rel(y, x.double() @ wf.double().T + bf.double()) < 1e-5
+    for epi, fn in (("silu", F.silu), ("gelu", F.gelu)):
+        y = ops.skinny_gemm(x.cuda(), w, b, epilogue=epi)
+        assert rel(y, fn(x.double() @ wf.double().T + bf.double())) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(2, 8192, 3072), (3, 344, 128), (1, 1408, 2048), (8, 100, 1024)])
+def test_skinny_swiglu(ops, M, N, K):
+    x = rnd(M, K, seed=4)
+    w, wf = bw(2 * N, K, seed=5, scale=K ** -0.5)
+    b, bf = bw(2 * N, seed=6)
+    y = ops.skinny_gemm(x.cuda(), w, b, epilogue="swiglu")
+    ref = x.double() @ wf.double().T + bf.double()
+    assert rel(y, F.silu(ref[:, :N]) * ref[:, N:]) < 1e-5
+
+
+def test_skinny_prologues_and_resid(ops):
+    M, N, K = 3, 777, 3072
+    x = rnd(M, K, seed=7) * 2 + 0.3
+    w, wf = bw(N, K, seed=8, scale=K ** -0.5)
+    b, bf = bw(N, seed=9)
+    g, gf = bw(K, seed=10); g2 = (gf * 0.1 + 1).to(torch.bfloat16); g, gf = g2.cuda(), g2.float()
+    be, bef = bw(K, seed=11, scale=0.1)
+    shift, scale, res, gate = rnd(M, K, seed=12), rnd(M, K, seed=13), rnd(M, N, seed=14), rnd(M, N, seed=15)
+    xd, wd = x.double(), wf.double()
+    lin = lambda h: h @ wd.T + bf.double()
+    y = ops.skinny_gemm(x.cuda(), w, b, prologue="silu")
+    assert rel(y, lin(F.silu(xd))) < 1e-5
+    y = ops.skinny_gemm(x.cuda(), w, b, prologue="add_silu", pro_a=shift[0].contiguous().cuda())
+    assert rel(y, lin(F.silu(xd + shift[0].double()))) < 1e-5
+    y = ops.skinny_gemm(x.cuda(), w, b, prologue="rmsnorm", ln_g=g, eps=1e-5)
+    rms = xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-5) * gf.double()
+    assert rel(y, lin(rms)) < 1e-5
+    ln = F.layer_norm(xd, (K,), gf.double(), bef.double(), 1e-6)
+    y = ops.skinny_gemm(x.cuda(), w, b, prologue="ln", ln_g=g, ln_b=be, eps=1e-6)
+    assert rel(y, lin(ln)) < 1e-5
+    y = ops.skinny_gemm(x.cuda(), w, b, prologue="ln_mod", ln_g=g, ln_b=be, eps=1e-6, pro_a=shift.cuda(), pro_b=scale.cuda())
+    assert rel(y, lin(ln * (1 + scale.double()) + shift.double())) < 1e-5
+    y = ops.skinny_gemm(x.cuda(), w, b, prologue="ln_mod", eps=1e-6, pro_a=shift.cuda(), pro_b=scale.cuda())
+    assert rel(y, lin(F.layer_norm(xd, (K,), None, None, 1e-6) * (1 + scale.double()) + shift.double())) < 1e-5
+    y = ops.skinny_gemm(x.cuda(), w, b, epilogue="resid", res=res.cuda())
+    assert rel(y, res.double() + lin(xd)) < 1e-5
+    r = res.cuda().clone()
+    ops.skinny_gemm(x.cuda(), w, b, epilogue="resid_gate", res=r, gate=gate.cuda(), out=r)   # in place
+    assert rel(r, res.double() + gate.double() * lin(xd)) < 1e-5
+
+
+def test_router_and_experts(ops):
+    M, H, E, k, I, S = 5, 256, 8, 3, 64, 2
+    x = rnd(M, H, seed=20)
+    nw, nwf = bw(H, seed=21); nw2 = (nwf * 0.1 + 1).to(torch.bfloat16); nw, nwf = nw2.cuda(), nw2.float()
+    gw, gwf = bw(E, H, seed=22, scale=0.3)
+    iw, iwf = bw(E, H, seed=23, scale=0.3)
+    mask = torch.tensor([1, 0, 1, 0, 0], dtype=torch.uint8)
+    xn, idx, w = ops.moe_router(x.cuda(), nw, 1e-5, gw, iw, mask.cuda(), k, True, S)
+    xr = (x.double() * torch.rsqrt(x.double().pow(2).mean(-1, keepdim=True) + 1e-5) * nwf.double())
+    assert rel(xn, xr) < 1e-5
+    for m in range(M):
+        gsel = iwf if mask[m] else gwf
+        p = (xr[m] @ gsel.double().T).softmax(-1)
+        tw, ti = torch.topk(p, k)
+        assert ti.tolist() == idx[m, :k].cpu().tolist()
+        assert rel(w[m, :k], tw / tw.sum()) < 1e-5
+        assert idx[m, k:].cpu().tolist() == [E, E + 1] and w[m, k:].cpu().tolist() == [1.0, 1.0]
+    gu, guf = bw(E + S, 2 * I, H, seed=24, scale=H ** -0.5)
+    dn, dnf = bw(E + S, H, I, seed=25, scale=I ** -0.5)
+    res = rnd(M, H, seed=26)
+    y = ops.moe_experts(xn, idx, w, gu, dn, res.cuda())
+    ref = res.double().clone()
+    for m in range(M):
+        for s in range(k + S):
+            e, ww = int(idx[m, s]), float(w[m, s])
+            h = guf[e].double() @ xr[m]
+            ref[m] += ww * (dnf[e].double() @ (F.silu(h[:I]) * h[I:]))
+    assert rel(y, ref) < 1e-5
+
+
+@pytest.mark.parametrize("hd,nq,nkv,rope", [(128, 16, 4, True), (64, 16, 16, False), (128, 4, 2, True)])
+def test_rope_kv_attn_decode(ops, hd, nq, nkv, rope):
+    n_seq, t_max, M = 3, 300, 3
+    kv = rnd(n_seq, 2, nkv, t_max, hd, seed=30)
+    kvd = kv.cuda()
+    qkv = rnd(M, (nq + 2 * nkv) * hd, seed=31)
+    lens = torch.tensor([200, 157, 1], dtype=torch.int32)
+    slot = lens - 1
+    pos = torch.tensor([120, 99, 0], dtype=torch.int32)
+    seqs = torch.tensor([0, 1, 2], dtype=torch.int32)
+    mask = (torch.rand(M, t_max, generator=torch.Generator().manual_seed(32)) > 0.3).to(torch.uint8)
+    for m in range(M):
+        mask[m, slot[m]] = 1
+    from oracle.bailing_ref import rope_cos_sin, rotate_half
+    cos, sin = rope_cos_sin(hd, 600000.0, 256)
+    half = hd // 2
+    qs = 1.0 / math.sqrt(hd)
+    q = ops.rope_kv_append(qkv.cuda(), nq, nkv, hd, kvd, seqs.cuda(), slot.cuda(), pos.cuda() if rope else None,
+                           cos[:, :half].contiguous().cuda() if rope else None,
+                           sin[:, :half].contiguous().cuda() if rope else None, qs)
+    out = ops.attn_decode(q, nq, nkv, hd, kvd, seqs.cuda(), lens.cuda(), mask.cuda())
+    x = qkv.double().view(M, nq + 2 * nkv, hd)
+    for m in range(M):
+        qq, kk, vv = x[m, :nq], x[m, nq:nq + nkv], x[m, nq + nkv:]
+        if rope:
+            c, s = cos[pos[m]].double(), sin[pos[m]].double()
+            qq = qq * c + rotate_half(qq) * s
+            kk = kk * c + rotate_half(kk) * s
+        assert rel(q[m].view(nq, hd), qq * qs) < 1e-5
+        L = int(lens[m])
+        K = kv[m, 0, :, :L].double().clone(); V = kv[m, 1, :, :L].double().clone()
+        K[:, L - 1], V[:, L - 1] = kk, vv
+        assert rel(kvd[m, 0, :, L - 1], kk) < 1e-6 and rel(kvd[m, 1, :, L - 1], vv) < 1e-6
+        rep = nq // nkv
+        for h in range(nq):
+            sc = (K[h // rep] @ (qq[h] * qs))
+            sc = sc.masked_fill(mask[m, :L] == 0, float("-inf")).softmax(-1)
+            assert rel(out[m].view(nq, hd)[h], sc @ V[h // rep]) < 1e-5, (m, h)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 344), (4160, 2304, 768), (96, 1000, 3072), (70, 32, 32)])
+def test_gemm_bf16(ops, M, N, K):
+    a = rnd(M, K, seed=40).to(torch.bfloat16)
+    w, wf = bw(N, K, seed=41, scale=K ** -0.5)
+    b, bf = bw(N, seed=42)
+    ref = a.double() @ wf.double().T + bf.double()
+    y = ops.gemm_bf16(a.cuda(), w, b, "f32")
+    assert rel(y, ref) < 1e-5
+    y = ops.gemm_bf16(a.cuda(), w, b, "bf16")
+    assert rel(y, ref) < 2 ** -8
+    y = ops.gemm_bf16(a.cuda(), w, b, "bf16_gelu")
+    assert rel(y, F.gelu(ref)) < 2 ** -8
+    acc = rnd(M, N, seed=43)
+    accd = acc.cuda()
+    ops.gemm_bf16(a.cuda(), w, b, "f32_resid", out=accd)
+    assert rel(accd, acc.double() + ref) < 1e-5
+
+
+def test_layernorm_swiglu_convert(ops):
+    x = rnd(37, 768, seed=50) * 3 + 1
+    g, gf = bw(768, seed=51); be, bef = bw(768, seed=52)
+    ref = F.layer_norm(x.double(), (768,), gf.double(), bef.double(), 1e-6)
+    assert rel(ops.layernorm_bf16(x.cuda(), g, be), ref) < 2 ** -8
+    assert rel(ops.layernorm_bf16(x.cuda(), g, be, gelu=True), F.gelu(ref)) < 2 ** -8
+    x12 = rnd(9, 688, seed=53).to(torch.bfloat16)
+    assert rel(ops.swiglu_bf16(x12.cuda()), F.silu(x12[:, :344].double()) * x12[:, 344:].double()) < 2 ** -8
+    v = rnd(1000, seed=54)
+    assert torch.equal(ops.f32_to_bf16(v.cuda()).cpu(), v.to(torch.bfloat16))
+    hi, lo = ops.f32_split_bf16(v.cuda())
+    assert rel(hi.float() + lo.float(), v) < 2 ** -15
+
+
+@pytest.mark.parametrize("B,T,nh,causal", [(2, 65, 2, False), (1, 257, 12, False), (2, 5, 2, True), (1, 300, 16, True),
+                                           (1, 1024, 16, False)])
+def test_attn_prefill_hd64(ops, B, T, nh, causal):
+    qkv = rnd(B * T, 3 * nh * 64, seed=60).to(torch.bfloat16)
+    out = ops.attn_prefill_hd64(qkv.cuda(), B, T, nh, causal)
+    x = qkv.double().view(B, T, 3, nh, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = x[0] * 0.125, x[1], x[2]
+    att = q @ k.transpose(-1, -2)
+    if causal:
+        att = att.masked_fill(torch.triu(torch.ones(T, T, dtype=torch.bool), 1), float("-inf"))
+    ref = (att.softmax(-1) @ v).transpose(1, 2).reshape(B * T, nh * 64)
+    # P is rounded to bf16 before P.V (as flash-attn does) and the output is bf16
+    assert rel(out, ref) < 3 * 2 ** -8

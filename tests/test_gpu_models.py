@@ -1,0 +1,177 @@
+"""GPU parity of the composite path (RF sampler, Bailing-MoE stack, MingTok, generate_image)
+against the golden vectors captured from the REFERENCE (tests/golden, via oracle/gen_golden.py)
+and against the CPU oracle on the same seeded inputs.  Everything goes through the C ABI."""
+import pytest
+import torch
+
+from ming_univision_amd import configuration as C
+from ming_univision_amd.synth import synth_state_dict
+from tests.util import llm_sd, load_golden, mingtok_sd, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3          # north_star tolerance: relative, fp32-activation decode path
+TOL_BF16 = 3e-2     # batched MFMA path keeps bf16 activations (like the reference's autocast path)
+
+
+def to_dev(sd):
+    return {k: v.to("cuda", torch.bfloat16).contiguous() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("name", ["rf_tiny", "rf_tiny16"])
+def test_rf_sample_vs_reference(name):
+    from ming_univision_amd.rf_head import RectifiedFlowHead
+    from oracle import rf_ref
+    g = load_golden(name)
+    rf_cfg = dict(diffloss_w=64, diffloss_d=2, num_sampling_steps=str(g["steps"]), gen_method="flow_matching_swiglu-4")
+    shapes = C.rf_param_shapes(64, 2, 64, 32, 4)
+    shapes.update({"vis_head.0.weight": (64, 48), "vis_head.0.bias": (64,), "vis_head.1.weight": (64,), "vis_head.1.bias": (64,)})
+    sd = synth_state_dict(shapes, g["seed"])
+    head = RectifiedFlowHead(to_dev(sd), 48, rf_cfg)
+    rf_sd = {k[len("diffloss."):]: v for k, v in sd.items() if k.startswith("diffloss.")}
+    # time-embedding table
+    ts = torch.linspace(1.0, 0.0, g["steps"] + 1)[:-1] * 1000
+    assert rel_err(head.t["temb"], rf_ref.time_embed(ts, rf_sd)) < 1e-5
+    # the golden z is the vis_head OUTPUT; drive the full entry point with a hidden state whose
+    # vis_head output we get from the oracle, and separately check against the reference samples
+    hid = torch.randn(3, 48, generator=torch.Generator().manual_seed(5))
+    for rows, temp in ((3, 1.0), (2, 0.9), (1, 1.0)):
+        z = rf_ref.vis_head(hid[:rows], sd)
+        tc, ic = (3.0, 1.1) if rows > 1 else (1.0, 1.0)
+        ref = rf_ref.sample(z, g["noise"][0:1], rf_sd, steps=g["steps"], temperature=temp, text_cfg=tc, image_cfg=ic)
+        out = head.sample(hid[:rows].cuda(), g["noise"][0].cuda(), temp, tc, ic)
+        assert rel_err(out, ref[0]) < TOL, (rows, rel_err(out, ref[0]))
+
+
+def test_rf_sample_golden_z():
+    """Feed the reference's own z (golden) through an identity vis_head: W = I, LN affine = (1, 0) cannot
+    reproduce z exactly (LayerNorm is not invertible), so instead pin the net: one Euler step from the
+    golden (x, t, z) must reproduce the reference's velocity."""
+    from ming_univision_amd import ops
+    from oracle import rf_ref
+    g = load_golden("rf_tiny")
+    sd = synth_state_dict(C.rf_param_shapes(64, 2, 64, 32, 4), g["seed"])
+    rf_sd = {k[len("diffloss."):]: v for k, v in sd.items()}
+    d = to_dev(rf_sd)
+    x, t, z = g["x"], g["t"], g["z"]
+    temb = rf_ref.time_embed(t * 1000, rf_sd)
+    c = ops.skinny_gemm(z.cuda(), d["net.cond_embed.weight"], d["net.cond_embed.bias"])
+    h = ops.skinny_gemm(x.cuda(), d["net.input_proj.weight"], d["net.input_proj.bias"])
+    for i in range(2):
+        p = f"net.res_blocks.{i}."
+        ada = ops.skinny_gemm(c, d[p + "adaLN_modulation.1.weight"], d[p + "adaLN_modulation.1.bias"],
+                              prologue="add_silu", pro_a=temb.cuda())
+        hid = ops.skinny_gemm(h, d[p + "mlp.w12.weight"], d[p + "mlp.w12.bias"], prologue="ln_mod", epilogue="swiglu",
+                              ln_g=d[p + "in_ln.weight"], ln_b=d[p + "in_ln.bias"], eps=1e-6,
+                              pro_a=ada[:, :64], pro_b=ada[:, 64:128])
+        h = ops.skinny_gemm(hid, d[p + "mlp.w3.weight"], d[p + "mlp.w3.bias"], epilogue="resid_gate", res=h, gate=ada[:, 128:])
+    ada = ops.skinny_gemm(c, d["net.final_layer.adaLN_modulation.1.weight"], d["net.final_layer.adaLN_modulation.1.bias"],
+                          prologue="add_silu", pro_a=temb.cuda())
+    v = ops.skinny_gemm(h, d["net.final_layer.linear.weight"], d["net.final_layer.linear.bias"], prologue="ln_mod",
+                        eps=1e-6, pro_a=ada[:, :64], pro_b=ada[:, 64:])
+    assert rel_err(v, g["v"]) < TOL
+
+
+@pytest.fixture(scope="module")
+def llm():
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder
+    g = load_golden("llm_tiny")
+    sd = llm_sd(g["config"], g["rf_config"], g["seed"])
+    cfg = C.BailingMoeConfig(**g["config"])
+    dec = BailingMoeDecoder.from_state_dict(cfg, to_dev(sd), t_max=64, n_seq=3)
+    return g, sd, cfg, dec
+
+
+def test_llm_prefill_and_cfg_decode_vs_reference(llm):
+    g, sd, cfg, dec = llm
+    T = g["emb"].shape[1]
+    h = dec.prefill(g["emb"][0].cuda(), seq=0, past=0, image_mask=g["image_mask"][0], chunk=5)
+    assert rel_err(h, g["hidden"][0]) < TOL
+    # cache layout [L, seq, 2, kv, t, hd] vs reference [B, kv, T, hd]
+    assert rel_err(dec.kv_cache[0, 0, 0, :, :T], g["k0"][0]) < TOL
+    assert rel_err(dec.kv_cache[1, 0, 1, :, :T], g["v1"][0]) < TOL
+    assert rel_err(dec.logits(h[-1:]), g["logits"][0]) < TOL
+    rows = 3
+    for r in range(1, rows):
+        dec.kv_cache[:, r, :, :, :T].copy_(dec.kv_cache[:, 0, :, :, :T])
+    from ming_univision_amd.bailing_moe import ImageGenState
+    st = ImageGenState(dec, g["dec_mask0"], T)
+    for s in range(g["dec_in"].shape[0]):
+        hd = dec.step(g["dec_in"][s][:, 0].cuda().contiguous(), st.row_seq, st.row_slot, st.row_pos, st.row_len, st.key_mask)
+        assert rel_err(hd, g["dec_hidden"][s][:, 0]) < TOL, s
+        st.advance()
+    from ming_univision_amd import ops
+    d = to_dev({k: v for k, v in sd.items() if k.startswith("vis_head")})
+    z = ops.skinny_gemm(hd, d["vis_head.0.weight"], d["vis_head.0.bias"])
+    import torch.nn.functional as F
+    zr = F.layer_norm(z.cpu(), (z.shape[1],), sd["vis_head.1.weight"], sd["vis_head.1.bias"], 1e-6)
+    assert rel_err(zr, g["vis_z"]) < TOL
+
+
+@pytest.fixture(scope="module")
+def mt():
+    from ming_univision_amd.mingtok import MingTok
+    g = load_golden("mingtok_tiny")
+    sd = mingtok_sd(g["config"], g["seed"])
+    tok = MingTok(C.MingTokConfig(**g["config"]), state_dict=sd)
+    return g, sd, tok
+
+
+def psnr(a, b):
+    mse = float(((a.double().cpu() - b.double().cpu()) ** 2).mean())
+    return 10 * torch.log10(torch.tensor(4.0 / max(mse, 1e-20))).item()
+
+
+def test_mingtok_batched_vs_reference(mt):
+    g, sd, tok = mt
+    out = tok.forward(g["img"].cuda())
+    assert rel_err(out["latent"], g["latent"]) < TOL_BF16
+    assert rel_err(out["x_norm_patchtokens"], g["sem"]) < TOL_BF16
+    out2 = tok.forward(g["img2"].cuda())            # interpolated pos-embed path
+    assert rel_err(out2["latent"], g["latent2"]) < TOL_BF16
+    assert rel_err(out2["x_norm_patchtokens"], g["sem2"]) < TOL_BF16
+    rec = tok.forward_pixel_decoder(g["sem"].cuda())
+    assert rec.shape == g["recon"].shape and psnr(rec, g["recon"]) > 40.0
+    rec2 = tok.forward_enc_dec(g["img2"].cuda())
+    assert psnr(rec2, g["recon2"]) > 35.0
+    assert float(rec2.max()) <= 1.0 and float(rec2.min()) >= -1.0
+
+
+def test_mingtok_cached_decode_vs_reference(mt):
+    g, sd, tok = mt
+    st = None
+    outs = []
+    for i in range(g["dec_latent_norm"].shape[1]):
+        r = tok.forward_feature_decoder(g["dec_latent_norm"][:, i:i + 1], past_key_values=st)
+        st = r["past_key_values"]
+        outs.append(r["x_norm_patchtokens"].clone())
+    assert rel_err(torch.cat(outs, 1), g["dec_steps"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["rows3", "rows2"])
+def test_generate_image_vs_reference(tag):
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder, generate_image
+    from ming_univision_amd.mingtok import MingTok
+    from ming_univision_amd.rf_head import RectifiedFlowHead
+    g = load_golden("genimg_tiny")
+    sd = llm_sd(g["llm_config"], g["rf_config"], g["seed"])
+    dsd = to_dev(sd)
+    cfg = C.BailingMoeConfig(**g["llm_config"])
+    dec = BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=32, n_seq=3)
+    rf = RectifiedFlowHead(dsd, cfg.hidden_size, g["rf_config"])
+    lsd = to_dev(synth_state_dict(C.linear_proj_param_shapes(128, 256, 2), g["seed"]))
+    tok = MingTok(C.MingTokConfig(**g["mingtok_config"]), state_dict=mingtok_sd(g["mingtok_config"], g["seed"]),
+                  linear_proj=[(lsd["linear_proj.0.weight"], lsd["linear_proj.0.bias"]),
+                               (lsd["linear_proj.2.weight"], lsd["linear_proj.2.bias"])])
+    T = g["ids"].shape[1]
+    dec.prefill(dec.embed(g["ids"][0].cuda()), seq=0, past=0)
+    start = dec.embed(torch.tensor([cfg.image_start_token]).cuda())
+    out = generate_image(dec, rf, tok, start, T, g["mask"], g["uncond"], g[tag + "_tuncond"], g["noises"].cuda(),
+                         skip_last_sample=(tag == "rows2"))
+    assert torch.equal(out["attention_mask"], g[tag + "_mask_out"])
+    assert out["cache_len"] == g[tag + "_cache_len"]
+    assert rel_err(out["last_hidden"], g[tag + "_last_hidden"][:, 0]) < TOL
+    assert rel_err(dec.kv_cache[0, 0, 0, :, :out["cache_len"]], g[tag + "_k0"][0]) < TOL
+    assert rel_err(dec.logits(out["last_hidden"][0:1]), g[tag + "_logits"][0]) < TOL
+    assert out["image"].shape[1:] == g[tag + "_image"].shape[1:]
+    assert psnr(out["image"][0], g[tag + "_image"][0]) > 40.0   # pixel decoder runs on the bf16 MFMA path
