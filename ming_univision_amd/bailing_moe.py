@@ -157,7 +157,9 @@ class BailingMoeDecoder:
         for t in (row_seq, row_slot, row_pos, row_len):
             assert t.dtype == torch.int32 and t.is_cuda and t.numel() >= M
         if key_mask is not None:
-            assert key_mask.dtype == torch.uint8 and key_mask.shape[0] >= M
+            assert key_mask.dtype == torch.uint8 and key_mask.is_cuda and key_mask.shape[0] >= M
+        if image_mask is not None:
+            assert image_mask.dtype == torch.uint8 and image_mask.is_cuda and image_mask.numel() >= M
         if out is None:
             out = torch.empty(M, self.cfg.hidden_size, dtype=torch.float32, device=self.device)
         ws = self._workspace(M)
@@ -178,7 +180,7 @@ class BailingMoeDecoder:
             m = min(chunk, T - c0)
             slot = torch.arange(past + c0, past + c0 + m, dtype=torch.int32, device=self.device)
             seqs = torch.full((m,), seq, dtype=torch.int32, device=self.device)
-            im = None if image_mask is None else image_mask[c0:c0 + m].to(torch.uint8).contiguous()
+            im = None if image_mask is None else image_mask[c0:c0 + m].to(self.device, torch.uint8).contiguous()
             outs.append(self.step(embeds[c0:c0 + m].contiguous(), seqs, slot, slot, slot + 1, None, im))
         return torch.cat(outs, 0)
 

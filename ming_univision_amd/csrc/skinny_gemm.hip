@@ -283,7 +283,24 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   ka.nchunk = (a.K + 511) / 512;
   const int64_t Kp = (int64_t)ka.nchunk * 512;
   const size_t lds = ((size_t)a.M * ka.nseg * Kp + 32) * sizeof(float);
-  MN_CHECK_ARG(lds <= 160 * 1024, "mn_skinny_gemm: M*K too large for LDS (%zu bytes); split M", lds);
+  if (lds > 160 * 1024) {
+    // x does not fit the 160 KiB LDS: run the rows in slices (weights are re-streamed per slice)
+    const int mc = (int)((160 * 1024 / sizeof(float) - 32) / ((size_t)ka.nseg * Kp));
+    MN_CHECK_ARG(mc >= 1, "mn_skinny_gemm: K=%d x nseg=%d too large for LDS", a.K, ka.nseg);
+    for (int m0 = 0; m0 < a.M; m0 += mc) {
+      mn_skinny_args s = *args;
+      s.M = (a.M - m0) < mc ? (a.M - m0) : mc;
+      s.x = a.x + (int64_t)m0 * a.ldx;
+      s.out = a.out + (int64_t)m0 * a.ldo;
+      if (a.res) s.res = a.res + (int64_t)m0 * a.ldres;
+      if (a.gate) s.gate = a.gate + (int64_t)m0 * a.ldgate;
+      if (a.pro_a) s.pro_a = a.pro_a + (int64_t)m0 * a.ld_pro_a;
+      if (a.pro_b) s.pro_b = a.pro_b + (int64_t)m0 * a.ld_pro_b;
+      const int rc = mn_skinny_gemm(&s, stream);
+      if (rc != MN_OK) return rc;
+    }
+    return MN_OK;
+  }
 
   const int sw = a.epilogue == MN_EPI_SWIGLU ? 2 : 1;
   // Occupancy plan: blocks per CU limited by LDS; 16+ waves per CU wanted.
