@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py — visual tokens/s of Ming-UniVision-16B-A3B text->512^2 image generation on MI355X.
+
+Workload (BASELINE.json configs[3], the configuration the metric is quoted on; fits one GPU):
+  random-init weights of the exact 16B-A3B architecture (bf16, 16.8 B params + 1.29 B RF head +
+  0.70 B MingTok), a 40-token text prompt, forced `<image>`, 2 CFG rows (text->image), 256 visual
+  tokens: per token one 28-layer MoE step over the CFG rows, the 16-step rectified-flow SwiGLU
+  sampler, one cached semantic-decoder step + linear_proj; then the 24-layer pixel decoder.
+  A "step" = one full image (prompt prefill + 257 LLM steps + 256 samplers + pixel decode).
+
+One process per GPU (independent prompts per rank = replicas, no data-path collective: the path
+is a strictly sequential AR chain per image).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tokens", type=int, default=256, help="visual tokens per image (256 = 512^2)")
+    ap.add_argument("--prompt-len", type=int, default=40)
+    ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only; INVALID as a result)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", type=int, default=None, help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+def build_models(args, device, seed):
+    from ming_univision_amd import configuration as C
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder
+    from ming_univision_amd.mingtok import MingTok
+    from ming_univision_amd.rf_head import RectifiedFlowHead
+    from ming_univision_amd.synth import synth_tensor
+    if args.tiny:
+        cfg = C.BailingMoeConfig(vocab_size=512, hidden_size=256, num_hidden_layers=2, num_attention_heads=4,
+                                 num_key_value_heads=2, head_dim=128, use_bias=False, rope_theta=600000.0, num_experts=8,
+                                 num_shared_experts=2, num_experts_per_tok=3, moe_intermediate_size=64, multi_gate=True,
+                                 num_image_tokens_for_gen=args.tokens, image_start_token=500)
+        rf_cfg = dict(diffloss_w=64, diffloss_d=2, num_sampling_steps="4", gen_method="flow_matching_swiglu-4")
+        tcfg = C.MingTokConfig(
+            low_level_encoder=dict(img_size=64, patch_size=32, depth=2, embed_dim=128, ffn_layer="swiglufused", out_dim=32),
+            semantic_decoder=dict(in_dim=32, patch_size=32, embed_dim=128, decoder_depth=2, ffn_layer="swiglufused"),
+            pixel_decoder=dict(patch_size=16, decoder_depth=2, embed_dim=128))
+    else:
+        cfg = C.BailingMoeConfig.ming_univision_16b_a3b()
+        cfg.num_image_tokens_for_gen = args.tokens
+        if args.layers:
+            cfg.num_hidden_layers = args.layers
+        rf_cfg = dict(C.DEFAULT_VISHEAD_DIFFLOSS)
+        tcfg = C.MingTokConfig()
+    t_max = args.prompt_len + args.tokens + 8
+    dec = BailingMoeDecoder.synthetic(cfg, device, seed=seed, t_max=t_max, n_seq=2)
+    full = C.llm_param_shapes(cfg, rf_cfg, 32)
+    rf_sd = {k: synth_tensor(k, s, seed, device, torch.bfloat16) for k, s in full.items()
+             if k.startswith("vis_head") or k.startswith("diffloss")}
+    rf = RectifiedFlowHead(rf_sd, cfg.hidden_size, rf_cfg)
+    D = tcfg.semantic_decoder["embed_dim"]
+    lp = {k: synth_tensor(k, s, seed, device, torch.bfloat16)
+          for k, s in C.linear_proj_param_shapes(D, cfg.hidden_size, 2).items()}
+    tok = MingTok(tcfg, device=device, seed=seed,
+                  linear_proj=[(lp["linear_proj.0.weight"], lp["linear_proj.0.bias"]),
+                               (lp["linear_proj.2.weight"], lp["linear_proj.2.bias"])])
+    return cfg, dec, rf, tok
+
+
+def one_image(cfg, dec, rf, tok, prompt_ids, noises):
+    """prefill -> forced <image> -> generate_image (2 CFG rows) -> pixel decode."""
+    from ming_univision_amd.bailing_moe import generate_image
+    T = prompt_ids.numel()
+    dec.prefill(dec.embed(prompt_ids), seq=0, past=0)
+    start = dec.embed(torch.tensor([cfg.image_start_token], device=prompt_ids.device))
+    am = torch.ones(1, T + 1, dtype=torch.long)
+    unc = torch.ones(1, T + 1, dtype=torch.long)
+    unc[0, 2:T - 2] = 0                     # uncond row: the user's text span is masked out
+    return generate_image(dec, rf, tok, start, T, am, unc, unc.clone(), noises)
+
+
+def dominant_kernel_roofline(rf, rows, iters=48):
+    """Average duration of the dominant kernel — the RF head's w12 weight-streaming launch
+    (skinny GEMM, N = 2 x hidden, K = w, fused LN-modulate prologue + SwiGLU epilogue) — timed with
+    HIP events on the stream it is launched on, cycling through the real per-block weights."""
+    from ming_univision_amd import ops
+    dev = rf.t["vis_w"].device
+    w, hid = rf.w, rf.hidden
+    x = torch.randn(rows, w, device=dev)
+    sh, sc = torch.randn(rows, w, device=dev) * 0.1, torch.randn(rows, w, device=dev) * 0.1
+    out = torch.empty(rows, hid, device=dev)
+
+    def launch(b):
+        ops.skinny_gemm(x, rf.lists["w12"][b], rf.lists["b12"][b], prologue="ln_mod", epilogue="swiglu", out=out,
+                        ln_g=rf.lists["ln_g"][b], ln_b=rf.lists["ln_b"][b], eps=1e-6, pro_a=sh, pro_b=sc)
+    for b in range(rf.depth):
+        launch(b)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for i in range(iters):
+        launch(i % rf.depth)
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / iters
+    nbytes = 2 * hid * w * 2          # algorithmic bytes: the bf16 weight matrix, read once
+    return dict(kernel="skinny_kernel<rows,R,SWIGLU>(RF w12: N=2x%d, K=%d)" % (hid, w), us=us, bytes=nbytes,
+                gbs=nbytes / us * 1e-3)
+
+
+def cpu_baseline(args, rows=2):
+    """The oracle (CPU restatement, fp32 PyTorch) on a bounded sample of the same workload:
+    one visual token = RF sampler (full size, `rows` CFG rows) + 28 x one full-shape MoE decoder layer
+    (decode step against a prompt-length cache) + one semantic-decoder step.  ~10-30 s of CPU work."""
+    from ming_univision_amd import configuration as C
+    from oracle import bailing_ref, mingtok_ref, rf_ref
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    g = torch.Generator().manual_seed(0)
+
+    def fill(shapes):
+        return {k: (torch.rand(s, generator=g) - 0.5) * (2.0 / max(1, s[-1]) ** 0.5) if len(s) > 1
+                else torch.ones(s) for k, s in shapes.items()}
+    cfgC = C.BailingMoeConfig.ming_univision_16b_a3b()
+    rf_shapes = {k: s for k, s in C.llm_param_shapes(cfgC, dict(C.DEFAULT_VISHEAD_DIFFLOSS), 32).items()
+                 if k.startswith("vis_head") or k.startswith("diffloss")}
+    sd = fill(rf_shapes)
+    rf_sd = {k[len("diffloss."):]: v for k, v in sd.items() if k.startswith("diffloss.")}
+    hid = torch.randn(rows, cfgC.hidden_size, generator=g)
+    noise = torch.randn(1, 32, generator=g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        z = rf_ref.vis_head(hid, sd)
+        rf_ref.sample(z, noise, rf_sd, steps=16)
+        t_rf = time.perf_counter() - t0
+    del sd, rf_sd
+    ocfg = bailing_ref.LLMConfig(num_hidden_layers=1)
+    lsd = fill(C.llm_layer_param_shapes(cfgC, 0))
+    T = args.prompt_len + 128
+    kv = [dict(k=torch.randn(rows, 4, T, 128, generator=g), v=torch.randn(rows, 4, T, 128, generator=g))]
+    x = torch.randn(rows, 1, cfgC.hidden_size, generator=g)
+    am = torch.ones(rows, T + 1, dtype=torch.long)
+    pos = torch.full((rows, 1), T, dtype=torch.long)
+    with torch.no_grad():
+        m4 = bailing_ref.build_4d_mask(am, 1, T)
+        bailing_ref.decoder_layer(x, lsd, 0, ocfg, m4, pos, dict(kv[0]))      # warm
+        t0 = time.perf_counter()
+        bailing_ref.decoder_layer(x, lsd, 0, ocfg, m4, pos, dict(kv[0]))
+        t_layer = time.perf_counter() - t0
+    del lsd
+    tcfg = C.MingTokConfig()
+    msd = fill({k: s for k, s in C.mingtok_param_shapes(tcfg).items() if k.startswith("semantic_decoder")})
+    caches = mingtok_ref.semdec_new_cache(msd)
+    with torch.no_grad():
+        for _ in range(2):
+            t0 = time.perf_counter()
+            mingtok_ref.semdec_forward(torch.randn(1, 1, 32, generator=g), msd, kv_caches=caches)
+            t_sem = time.perf_counter() - t0
+    per_tok = t_rf + cfgC.num_hidden_layers * t_layer + t_sem
+    return dict(value=1.0 / per_tok, unit="visual_tokens/s", cores=cores, kind="port",
+                sample=("1 visual token at full 16B-A3B shapes, fp32 oracle: RF sampler rows=%d %.2fs + 28 x one MoE "
+                        "decoder layer (decode step, %d-token cache) %.3fs + semantic-decoder step %.3fs; pixel decoder "
+                        "and prompt prefill not included (favours the CPU)" % (rows, t_rf, T, t_layer, t_sem)))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        dist = None
+
+    cfg, dec, rf, tok = build_models(args, device, seed=0)
+    g = torch.Generator(device=device).manual_seed(1000 + rank)
+    prompt = torch.randint(0, min(cfg.vocab_size, 100000), (args.prompt_len,), generator=g, device=device)
+    noises = torch.randn(args.tokens + 1, 32, generator=g, device=device)
+    rows = 2
+
+    for _ in range(args.warmup):
+        one_image(cfg, dec, rf, tok, prompt, noises)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(args.steps):
+        out = one_image(cfg, dec, rf, tok, prompt, noises)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    finite = bool(torch.isfinite(out["image"]).all()) and bool(torch.isfinite(out["latents"]).all())
+
+    if rank == 0:
+        dom = dominant_kernel_roofline(rf, rows)
+        total_tokens = args.tokens * args.steps * world
+        res = {
+            "metric": "visual tokens/sec (16B-A3B 512^2 gen)", "value": total_tokens / dt, "unit": "visual_tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Ming-UniVision-16B-A3B text->image 512^2 (BASELINE configs[3]): %d-token prompt, "
+                                   "2 CFG rows, %d visual tokens/image, RF head w=%d d=%d steps=%d, MingTok pixel decode; "
+                                   "random-init bf16 weights" % (args.prompt_len, args.tokens, rf.w, rf.depth, rf.steps),
+                       "images_per_step_per_gpu": 1, "parallelism": "replicas x%d" % world, "tiny": bool(args.tiny)},
+            "roofline": {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": None, "kernel": dom["kernel"],
+                         "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"]},
+            "outputs_finite": finite,
+        }
+        # whole-token HBM accounting: bytes that must cross HBM per visual token / measured time per token
+        tok_bytes = rf.steps * rf.weight_bytes_per_step() + dec.weight_bytes_active(6 * rows) + 0.61e9
+        res["token_level"] = {"algorithmic_GB_per_token": tok_bytes / 1e9,
+                              "achieved_GBs": tok_bytes / (dt / (args.tokens * args.steps)) / 1e9}
+        if not args.no_cpu_baseline and not args.tiny:
+            try:
+                res["cpu_baseline"] = cpu_baseline(args, rows)
+            except Exception as ex:  # the baseline must never kill the bench line
+                res["cpu_baseline"] = {"value": None, "unit": "visual_tokens/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (ex,)}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,10 +24,31 @@ struct KArgs {  // device copy of mn_skinny_args (plain data)
   int32_t nchunk;   // chunks of 512 k per segment
   int32_t nseg;
   int32_t batch;
+  int32_t inv_nchunk;  // ceil(65536 / nchunk): ct / nchunk == (ct * inv_nchunk) >> 16 for ct < 4096
 };
 
 __device__ __forceinline__ int perm_k(int k) {
   return (k & ~511) | (((k >> 2) & 1) << 8) | (((k >> 3) & 63) << 2) | (k & 3);
+}
+
+// Block-wide sums of M per-thread values (one barrier pair for all rows).
+template <int M, int NT>
+__device__ __forceinline__ void block_sum_multi(float (&v)[M], float* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int m = 0; m < M; ++m) v[m] = wave_sum(v[m]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) red[wave * M + m] = v[m];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    float t = 0.f;
+    for (int i = 0; i < NT / 64; ++i) t += red[i * M + m];
+    v[m] = t;
+  }
 }
 
 // Stage prologue(x) for this block's batch entry into LDS. xs layout: [M][nseg][nchunk*512] permuted.
@@ -37,60 +58,71 @@ __device__ void stage_x(const KArgs& ka, float* xs, float* red, int b) {
   const int K = a.K, Kp = ka.nchunk << 9, nseg = ka.nseg;
   const int tid = threadIdx.x;
   const float* xb = a.x + (int64_t)(b / (a.x_batch_div > 0 ? a.x_batch_div : 1)) * a.x_batch_stride;
-  const int Ktot = K * nseg;  // contiguous per row in global memory
   const int pro = a.prologue;
 
   if (pro == MN_PRO_NONE || pro == MN_PRO_SILU || pro == MN_PRO_ADD_SILU) {
-    for (int m = 0; m < M; ++m) {
-      const float* xr = xb + (int64_t)m * a.ldx;
-      for (int s = 0; s < nseg; ++s) {
-        const float sc = a.seg_scale ? a.seg_scale[(int64_t)b * nseg + s] : 1.0f;
-        float* dst = xs + ((int64_t)m * nseg + s) * Kp;
-        for (int k = tid; k < Kp; k += NT) {
+    for (int s = 0; s < nseg; ++s) {
+      const float sc = a.seg_scale ? a.seg_scale[(int64_t)b * nseg + s] : 1.0f;
+      for (int k = tid; k < Kp; k += NT) {
+        const int p = perm_k(k);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
           float v = 0.f;
           if (k < K) {
-            v = xr[s * K + k];
+            v = xb[(int64_t)m * a.ldx + s * K + k];
             if (pro == MN_PRO_ADD_SILU) v += a.pro_a[(int64_t)m * a.ld_pro_a + k];
             if (pro != MN_PRO_NONE) v = silu_f(v);
             v *= sc;
           }
-          dst[perm_k(k)] = v;
+          xs[((int64_t)m * nseg + s) * Kp + p] = v;
         }
       }
     }
     return;
   }
-  // Normalising prologues (nseg == 1): two-pass statistics from LDS-resident raw rows.
-  for (int m = 0; m < M; ++m) {
-    const float* xr = xb + (int64_t)m * a.ldx;
-    float* dst = xs + (int64_t)m * Kp;
-    float s = 0.f;
-    for (int k = tid; k < Kp; k += NT) {
-      float v = (k < K) ? xr[k] : 0.f;
-      dst[perm_k(k)] = v;
-      s += v;
+  // Normalising prologues (nseg == 1): statistics of all M rows together, from the LDS-resident raw rows.
+  float s1[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) s1[m] = 0.f;
+  for (int k = tid; k < Kp; k += NT) {
+    const int p = perm_k(k);
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const float v = (k < K) ? xb[(int64_t)m * a.ldx + k] : 0.f;
+      xs[(int64_t)m * Kp + p] = v;
+      s1[m] += v;
     }
-    float mean = 0.f, rstd;
-    if (pro == MN_PRO_RMSNORM) {
-      float ss = 0.f;
-      for (int k = tid; k < K; k += NT) { float v = dst[perm_k(k)]; ss += v * v; }
-      ss = block_sum(ss, red);
-      rstd = rsqrtf(ss / (float)K + a.eps);
-    } else {
-      mean = block_sum(s, red) / (float)K;
-      float ss = 0.f;
-      for (int k = tid; k < K; k += NT) { float d = dst[perm_k(k)] - mean; ss += d * d; }
-      ss = block_sum(ss, red);
-      rstd = rsqrtf(ss / (float)K + a.eps);
-    }
-    for (int k = tid; k < K; k += NT) {
-      const int p = perm_k(k);
-      float v = (dst[p] - mean) * rstd;
-      if (a.ln_g) v *= bf16_to_f32(a.ln_g[k]);
-      if (a.ln_b && pro != MN_PRO_RMSNORM) v += bf16_to_f32(a.ln_b[k]);
+  }
+  float mean[M], rstd[M];
+  if (pro == MN_PRO_RMSNORM) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) mean[m] = 0.f;
+  } else {
+    block_sum_multi<M, NT>(s1, red);
+#pragma unroll
+    for (int m = 0; m < M; ++m) mean[m] = s1[m] / (float)K;
+  }
+  float s2[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) s2[m] = 0.f;
+  for (int k = tid; k < K; k += NT) {
+    const int p = perm_k(k);
+#pragma unroll
+    for (int m = 0; m < M; ++m) { const float d = xs[(int64_t)m * Kp + p] - mean[m]; s2[m] += d * d; }
+  }
+  block_sum_multi<M, NT>(s2, red);
+#pragma unroll
+  for (int m = 0; m < M; ++m) rstd[m] = rsqrtf(s2[m] / (float)K + a.eps);
+  for (int k = tid; k < K; k += NT) {
+    const int p = perm_k(k);
+    const float g = a.ln_g ? bf16_to_f32(a.ln_g[k]) : 1.0f;
+    const float be = (a.ln_b && pro != MN_PRO_RMSNORM) ? bf16_to_f32(a.ln_b[k]) : 0.0f;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      float v = (xs[(int64_t)m * Kp + p] - mean[m]) * rstd[m] * g + be;
       if (pro == MN_PRO_LN_MOD)
         v = v * (1.0f + a.pro_b[(int64_t)m * a.ld_pro_b + k]) + a.pro_a[(int64_t)m * a.ld_pro_a + k];
-      dst[p] = v;
+      xs[(int64_t)m * Kp + p] = v;
     }
   }
 }
@@ -110,27 +142,74 @@ __device__ __forceinline__ void fma_chunk(const u32x4 w, const float* xrow0, int
   }
 }
 
+// 16-byte weight loads kept in flight per lane per (row, swiglu half). The 512-thread plan runs one
+// block per CU (2 waves per SIMD, so each wave may use up to 256 VGPRs) and keeps a deeper ring.
+template <int NT> struct RingDepth { static constexpr int value = 4; };
+
 // SW: number of weight row sets per output row (2 for SWIGLU, else 1).
+//
+// Per wave the weight stream is software-pipelined through a RING-deep register ring: the first
+// RING chunks of the wave's first row group are requested BEFORE the block stages x (so the HBM
+// latency of the first weights overlaps the prologue), and the first RING chunks of the next row
+// group are requested before the current group's cross-lane reduction and epilogue.
 template <int M, int R, int SW, int NT>
 __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs ka) {
+  constexpr int RING = RingDepth<NT>::value;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const mn_skinny_args& a = ka.a;
   const int nchunk = ka.nchunk, Kp = nchunk << 9, nseg = ka.nseg, K = a.K, N = a.N;
   float* xs = smem;
   float* red = smem + (int64_t)M * nseg * Kp;
   const int b = blockIdx.y;
-  stage_x<M, NT>(ka, xs, red, b);
-  __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwaves = gridDim.x * (NT / 64);
   const int ngroups = (N + R - 1) / R;
+  const int nct = nseg * nchunk;               // chunks per row (all segments)
   const int64_t xstride = (int64_t)nseg * Kp;  // LDS row stride (floats)
   const int wsel = a.w_index ? a.w_index[b] : b;
-  const bf16_t* wbase = a.w + (int64_t)wsel * a.w_batch_stride;
-  const int lane_k = lane * 8;
+  const int32_t* segi = a.seg_index ? a.seg_index + (int64_t)b * nseg : nullptr;
 
-  for (int g = blockIdx.x * (NT / 64) + wave; g < ngroups; g += nwaves) {
+  // per-segment weight offsets live one per lane (lane sg holds segment sg's offset); a uniform
+  // readlane fetches them without touching memory in the issue path
+  int64_t my_segoff = 0;
+  if (segi && lane < nseg) my_segoff = (int64_t)segi[lane] * a.seg_w_stride;
+  const int seg_lo = (int)(my_segoff & 0xffffffff), seg_hi = (int)(my_segoff >> 32);
+  const int kmax = K - 8;
+
+  u32x4 ring[RING][SW][R];
+  // Branch-free request of chunk ct of row group g.  Lanes past the end of a row (partial last chunk)
+  // and rows past N re-read valid in-bounds data; the matching x entries in LDS are zero / unused.
+  auto issue = [&](int g, int ct, u32x4 (&dst)[SW][R]) {
+    int c = ct;
+    int64_t so = 0;
+    if (nseg > 1) {
+      const int sg = (ct * ka.inv_nchunk) >> 16;
+      c = ct - sg * nchunk;
+      so = ((int64_t)__builtin_amdgcn_readlane(seg_hi, sg) << 32) | (uint32_t)__builtin_amdgcn_readlane(seg_lo, sg);
+    }
+    const bf16_t* wp = a.w + (int64_t)wsel * a.w_batch_stride + so + min(c * 512 + lane * 8, kmax);
+#pragma unroll
+    for (int s = 0; s < SW; ++s)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int n = min(g * R + r, N - 1) + s * N;
+        dst[s][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (int64_t)n * a.ldw));
+      }
+  };
+  auto issue_head = [&](int g) {
+#pragma unroll
+    for (int d = 0; d < RING; ++d)
+      if (d < nct) issue(g, d, ring[d]);
+  };
+
+  int g = blockIdx.x * (NT / 64) + wave;
+  if (g < ngroups) issue_head(g);
+  stage_x<M, NT>(ka, xs, red, b);
+  __syncthreads();
+
+  const float* xl = xs + lane * 4;
+  for (; g < ngroups; g += nwaves) {
     const int n0 = g * R;
     float acc[SW][R][M];
 #pragma unroll
@@ -140,48 +219,35 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs ka) {
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[s][r][m] = 0.f;
 
-    for (int sg = 0; sg < nseg; ++sg) {
-      const bf16_t* wseg = wbase + (a.seg_index ? (int64_t)a.seg_index[(int64_t)b * nseg + sg] * a.seg_w_stride : 0);
-      const bf16_t* wrow[SW][R];
+    auto consume = [&](int ct, const u32x4 (&src)[SW][R]) {
+      const float* xp = xl + (int64_t)ct * 512;   // LDS image is [M][nseg * nchunk * 512]
 #pragma unroll
       for (int s = 0; s < SW; ++s)
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int n = min(n0 + r, N - 1) + s * N;
-          wrow[s][r] = wseg + (int64_t)n * a.ldw + lane_k;
-        }
-      const float* xsg = xs + (int64_t)sg * Kp + lane * 4;
-      int c = 0;
-      // main loop: two chunks (2 x SW x R 16-byte loads) in flight per lane
-      for (; c + 2 <= nchunk && (c + 2) * 512 <= K; c += 2) {
-        u32x4 w0[SW][R], w1[SW][R];
+        for (int r = 0; r < R; ++r) fma_chunk<M>(src[s][r], xp, xstride, acc[s][r]);
+    };
+    int c0 = 0;
+    // steady state: every slot is consumed and immediately refilled RING chunks ahead (no branches)
+    for (; c0 + 2 * RING <= nct; c0 += RING) {
 #pragma unroll
-        for (int s = 0; s < SW; ++s)
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            w0[s][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[s][r] + c * 512));
-            w1[s][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[s][r] + c * 512 + 512));
-          }
-#pragma unroll
-        for (int s = 0; s < SW; ++s)
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            fma_chunk<M>(w0[s][r], xsg + c * 512, xstride, acc[s][r]);
-            fma_chunk<M>(w1[s][r], xsg + c * 512 + 512, xstride, acc[s][r]);
-          }
-      }
-      for (; c < nchunk; ++c) {  // tail chunks (possibly partial)
-        const bool valid = (c * 512 + lane_k) < K;
-#pragma unroll
-        for (int s = 0; s < SW; ++s)
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            u32x4 w = {0u, 0u, 0u, 0u};
-            if (valid) w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[s][r] + c * 512));
-            fma_chunk<M>(w, xsg + c * 512, xstride, acc[s][r]);
-          }
+      for (int d = 0; d < RING; ++d) {
+        consume(c0 + d, ring[d]);
+        issue(g, c0 + d + RING, ring[d]);
       }
     }
+    // drain: at most 2*RING - 1 chunks left, of which the first RING are already in the ring
+#pragma unroll
+    for (int d = 0; d < RING; ++d) {
+      if (c0 + d < nct) {
+        consume(c0 + d, ring[d]);
+        if (c0 + d + RING < nct) issue(g, c0 + d + RING, ring[d]);
+      }
+    }
+    c0 += RING;
+#pragma unroll
+    for (int d = 0; d < RING; ++d)
+      if (c0 + d < nct) consume(c0 + d, ring[d]);
+    if (g + nwaves < ngroups) issue_head(g + nwaves);   // next group's head overlaps the reduction below
 
     // wave reduction; afterwards every lane holds every sum
 #pragma unroll
@@ -241,8 +307,7 @@ void launch_one(const KArgs& ka, dim3 grid, size_t lds, hipStream_t st) {
 template <int M, int R, int SW>
 int launch_nt(const KArgs& ka, int nt, dim3 grid, size_t lds, hipStream_t st) {
   if (nt == 256) launch_one<M, R, SW, 256>(ka, grid, lds, st);
-  else if (nt == 512) launch_one<M, R, SW, 512>(ka, grid, lds, st);
-  else launch_one<M, R, SW, 1024>(ka, grid, lds, st);
+  else launch_one<M, R, SW, 512>(ka, grid, lds, st);
   return 0;
 }
 
@@ -258,6 +323,10 @@ int launch_m(const KArgs& ka, int R, int sw, int nt, dim3 grid, size_t lds, hipS
 }
 
 }  // namespace
+
+// Tuning overrides for micro-benchmarks (0 = heuristic). Not part of the stable ABI.
+static struct { int R, nt, bpc; } g_tune = {0, 0, 0};
+extern "C" void mn_skinny_tune(int R, int nt, int bpc) { g_tune.R = R; g_tune.nt = nt; g_tune.bpc = bpc; }
 
 extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   MN_CHECK_ARG(args != nullptr, "mn_skinny_gemm: null args");
@@ -281,6 +350,8 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   MN_CHECK_ARG((((uintptr_t)a.w) & 15) == 0 && ((a.w_batch_stride | a.seg_w_stride) % 8) == 0,
                "mn_skinny_gemm: weights must be 16-byte aligned");
   ka.nchunk = (a.K + 511) / 512;
+  ka.inv_nchunk = (65536 + ka.nchunk - 1) / ka.nchunk;
+  MN_CHECK_ARG((int64_t)ka.nseg * ka.nchunk < 4096 && ka.nseg <= 64, "mn_skinny_gemm: too many K chunks / segments");
   const int64_t Kp = (int64_t)ka.nchunk * 512;
   const size_t lds = ((size_t)a.M * ka.nseg * Kp + 32) * sizeof(float);
   if (lds > 160 * 1024) {
@@ -303,16 +374,28 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   }
 
   const int sw = a.epilogue == MN_EPI_SWIGLU ? 2 : 1;
-  // Occupancy plan: blocks per CU limited by LDS; 16+ waves per CU wanted.
+  // Occupancy plan: ~16 waves per CU (each keeps RING x SW x R KiB of weights in flight), blocks per CU
+  // limited by the LDS image of x; a wave should own >= 2 row groups where N allows so that the
+  // per-block prologue is amortised and the next group's loads overlap the current reduction.
   const int cus = mn_num_cus();
-  int bpc = (int)((160 * 1024) / lds);
-  int nt;
-  if (bpc >= 4) { nt = 256; bpc = bpc > 8 ? 8 : bpc; }
-  else if (bpc >= 2) { nt = 512; }
-  else { nt = 1024; bpc = 1; }
+  // Plan A (default): one 512-thread block per CU — the per-block prologue (x staging, LayerNorm
+  // statistics, modulation) is paid once per CU and hidden behind an 8-deep weight ring.
+  // Plan B: 256-thread blocks, up to 4 per CU, when there are too few row groups to feed plan A.
+  int bpc = 1, nt = 512;
+  {
+    const int64_t groups_r1 = (int64_t)a.N * ka.batch;
+    const int max_bpc = (int)((160 * 1024) / lds);
+    if (groups_r1 < (int64_t)cus * 8 && max_bpc >= 2) { nt = 256; bpc = max_bpc > 4 ? 4 : max_bpc; }
+  }
+  if (g_tune.nt == 256 || g_tune.nt == 512) {
+    nt = g_tune.nt;
+    bpc = g_tune.bpc > 0 ? g_tune.bpc : 1;
+    const int max_bpc = (int)((160 * 1024) / lds);
+    if (bpc > max_bpc) bpc = max_bpc;
+    if (bpc * nt > 2048) bpc = 2048 / nt;
+  }
   const int waves_per_block = nt / 64;
-  // rows per wave: keep >= ~2 row groups per resident wave when N is large, else favour parallelism
-  const int64_t resident_waves = (int64_t)cus * bpc * waves_per_block / ka.batch + 1;
+  const int64_t resident_waves = mn_cdiv((int64_t)cus * bpc * waves_per_block, ka.batch);
   int R = 1;
   if (sw == 1) {
     if ((int64_t)a.N >= 8 * resident_waves) R = 4;
@@ -320,6 +403,7 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   } else {
     if ((int64_t)a.N >= 4 * resident_waves) R = 2;
   }
+  if (g_tune.R > 0) R = g_tune.R;
   if (R * a.M > 64) R = 64 / a.M;
   if (sw == 2 && R > 2) R = 2;
   if (R == 3) R = 2;
