@@ -123,7 +123,9 @@ def cpu_baseline(args, rows=2):
     (decode step against a prompt-length cache) + one semantic-decoder step.  ~10-30 s of CPU work."""
     from ming_univision_amd import configuration as C
     from oracle import bailing_ref, mingtok_ref, rf_ref
-    torch.set_num_threads(os.cpu_count() or 1)
+    # GEMV-sized fp32 work does not scale past a few tens of threads (256 threads made the RF sampler
+    # 100x slower than 8 threads in a first run); use what the reference's CPU path would sensibly get.
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     cores = torch.get_num_threads()
     g = torch.Generator().manual_seed(0)
 

@@ -97,7 +97,7 @@ int mn_skinny_gemm(const mn_skinny_args* args, void* stream);
  * 2. MoE router: RMSNorm + gate GEMV + fp32 softmax + top-k + renormalise, with the
  *    image-gate override on rows flagged by image_mask.
  *    Replaces BailingMoeGate.forward (modeling_bailing_moe.py:505-520) and the multi-gate blend
- *    of BailingMoeSparseMoeBlock.forward (:565-592).  num_experts <= 64, top_k <= 8.
+ *    of BailingMoeSparseMoeBlock.forward (:565-592).  M <= 8, num_experts <= 64.
  *      x [M,H] fp32 (pre-norm residual stream), norm_w bf16 [H]
  *      gate_w / image_gate_w bf16 [E,H]; image_mask uint8 [M] or NULL
  *      -> x_norm [M,H] fp32 (the normalised rows, input of the experts)
@@ -108,7 +108,8 @@ int mn_skinny_gemm(const mn_skinny_args* args, void* stream);
 int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w, float eps,
                   const uint16_t* gate_w, const uint16_t* image_gate_w, const uint8_t* image_mask,
                   int M, int H, int E, int top_k, int norm_topk_prob, int n_shared_slots,
-                  float* x_norm, int32_t* topk_idx, float* topk_w, void* stream);
+                  float* x_norm, int32_t* topk_idx, float* topk_w, float* logits_ws /* [2*M*E] scratch */,
+                  void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 3. RoPE + KV-cache append, and masked GQA / MHA decode attention.

@@ -91,7 +91,7 @@ SYMBOLS = {
     "mn_last_error": (C.c_char_p, []),
     "mn_num_cus": (_i, []),
     "mn_skinny_gemm": (_i, [C.POINTER(SkinnyArgs), _p]),
-    "mn_moe_router": (_i, [_p, _i64, _p, _f, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "mn_moe_router": (_i, [_p, _i64, _p, _f, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "mn_rope_kv_append": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _i64, _p]),
     "mn_attn_decode_workspace_bytes": (_sz, [_i, _i, _i, _i64]),
     "mn_attn_decode": (_i, [_p, _i, _i, _i, _i, _p, _i64, _p, _p, _p, _i64, _p, _p, _sz, _p]),

@@ -17,17 +17,18 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // GEMM
 // ===========================================================================================
 namespace {
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BN = 128, BK = 64;  // BM is a template parameter (64 for skinny-M problems, else 128)
 
 // LDS tile: [128 rows][64 k] bf16 = 128 B per row = 8 slots of 16 B; slot index XOR (row & 7).
 __device__ __forceinline__ int tile_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
 
-template <int EPI>
+template <int EPI, int BM>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                         const bf16_t* __restrict__ W, int64_t ldw,
                                                         const bf16_t* __restrict__ bias, void* __restrict__ Cv,
                                                         int64_t ldc, int M, int N, int K) {
-  __shared__ __attribute__((aligned(16))) char lds[2][2][BM * BK * 2];  // [buf][A|W]
+  constexpr int MI = BM / 32;   // 16-row MFMA tiles per wave along M (wave grid is 2 x 2)
+  __shared__ __attribute__((aligned(16))) char lds[2][2][128 * BK * 2];  // [buf][A|W]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware tile order: consecutive tiles of one XCD share the A row panel
   const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   }
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * 64;
 
   // global -> register staging: each thread moves 4 slots of A and 4 slots of W per k-tile
   // thread t: row = t/8 + 32*i, slot = t%8
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     for (int i = 0; i < 4; ++i) {
       const int r = ld_row + 32 * i;
       const u32x4 z = {0u, 0u, 0u, 0u};
-      ra[i] = (kok && (m0 + r) < M) ? *reinterpret_cast<const u32x4*>(A + (int64_t)(m0 + r) * lda + k) : z;
+      if (i < MI) ra[i] = (kok && (m0 + r) < M) ? *reinterpret_cast<const u32x4*>(A + (int64_t)(m0 + r) * lda + k) : z;
       rw[i] = (kok && (n0 + r) < N) ? *reinterpret_cast<const u32x4*>(W + (int64_t)(n0 + r) * ldw + k) : z;
     }
   };
@@ -60,14 +61,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = ld_row + 32 * i;
-      *reinterpret_cast<u32x4*>(&lds[buf][0][tile_off(r, ld_slot)]) = ra[i];
+      if (i < MI) *reinterpret_cast<u32x4*>(&lds[buf][0][tile_off(r, ld_slot)]) = ra[i];
       *reinterpret_cast<u32x4*>(&lds[buf][1][tile_off(r, ld_slot)]) = rw[i];
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -81,14 +82,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[4], bf[4];
+      bf16x8 af[MI], bf[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8*>(&lds[cur][0][tile_off(wm + i * 16 + fr, kk * 4 + fq)]);
+        if (i < MI) af[i] = *reinterpret_cast<const bf16x8*>(&lds[cur][0][tile_off(wm + i * 16 + fr, kk * 4 + fq)]);
         bf[i] = *reinterpret_cast<const bf16x8*>(&lds[cur][1][tile_off(wn + i * 16 + fr, kk * 4 + fq)]);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     if (n >= N) continue;
     const float bv = bias ? bf16_to_f32(bias[n]) : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm + i * 16 + fq * 4 + r;
@@ -131,25 +132,26 @@ extern "C" int mn_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
   MN_CHECK_ARG(M >= 1 && N >= 1 && K >= 8 && (K % 8) == 0, "mn_gemm_bf16: bad M=%d N=%d K=%d (K %% 8 == 0)", M, N, K);
   MN_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0,
                "mn_gemm_bf16: A/W rows must be 16-byte aligned");
-  const int tiles = (int)(mn_cdiv(M, BM) * mn_cdiv(N, BN));
   hipStream_t st = mn_stream(stream);
+  const int bm = (M <= 64) ? 64 : 128;
+  const int tiles = (int)(mn_cdiv(M, bm) * mn_cdiv(N, BN));
+#define MN_GEMM_LAUNCH(E)                                                                                          \
+  do {                                                                                                             \
+    if (bm == 64)                                                                                                  \
+      hipLaunchKernelGGL((gemm_bf16_kernel<E, 64>), dim3(tiles), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K);  \
+    else                                                                                                           \
+      hipLaunchKernelGGL((gemm_bf16_kernel<E, 128>), dim3(tiles), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K); \
+  } while (0)
   switch (epilogue) {
-    case MN_GEMM_BF16:
-      hipLaunchKernelGGL(gemm_bf16_kernel<MN_GEMM_BF16>, dim3(tiles), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K);
-      break;
-    case MN_GEMM_BF16_GELU:
-      hipLaunchKernelGGL(gemm_bf16_kernel<MN_GEMM_BF16_GELU>, dim3(tiles), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K);
-      break;
-    case MN_GEMM_F32:
-      hipLaunchKernelGGL(gemm_bf16_kernel<MN_GEMM_F32>, dim3(tiles), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K);
-      break;
-    case MN_GEMM_F32_RESID:
-      hipLaunchKernelGGL(gemm_bf16_kernel<MN_GEMM_F32_RESID>, dim3(tiles), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K);
-      break;
+    case MN_GEMM_BF16: MN_GEMM_LAUNCH(MN_GEMM_BF16); break;
+    case MN_GEMM_BF16_GELU: MN_GEMM_LAUNCH(MN_GEMM_BF16_GELU); break;
+    case MN_GEMM_F32: MN_GEMM_LAUNCH(MN_GEMM_F32); break;
+    case MN_GEMM_F32_RESID: MN_GEMM_LAUNCH(MN_GEMM_F32_RESID); break;
     default:
       mn_set_error("mn_gemm_bf16: bad epilogue %d", epilogue);
       return MN_EINVAL;
   }
+#undef MN_GEMM_LAUNCH
   MN_CHECK_LAUNCH("mn_gemm_bf16");
   return MN_OK;
 }

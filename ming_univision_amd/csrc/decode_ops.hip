@@ -5,6 +5,8 @@
 //                       (split over the key range = flash-decoding, then a combine pass)
 // All of these are HBM/latency-bound index-and-reduce work: coalesced loads, wave shuffles,
 // no MFMA.
+#include <string.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -12,49 +14,27 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // -------------------------------------------------------------------------------------------
-// MoE router. One 256-thread block per row.
+// MoE router = gate logits (skinny GEMV with a fused RMSNorm prologue, all CUs) + this kernel:
+// one 256-thread block per row writes the normalised row (input of the experts) and wave 0 does
+// the fp32 softmax + iterative arg-max top-k + renormalisation.
 // -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void moe_router_kernel(
+__global__ __launch_bounds__(256) void moe_topk_kernel(
     const float* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ norm_w, float eps,
-    const bf16_t* __restrict__ gate_w, const bf16_t* __restrict__ image_gate_w,
+    const float* __restrict__ logits_text, const float* __restrict__ logits_image,
     const uint8_t* __restrict__ image_mask, int H, int E, int top_k, int norm_topk_prob, int n_shared,
     float* __restrict__ x_norm, int32_t* __restrict__ topk_idx, float* __restrict__ topk_w) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* xn = sm;            // [H]
-  float* logits = sm + H;    // [64]
-  float* red = logits + 64;  // [8]
+  __shared__ float red[8];
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* xr = x + (int64_t)m * ldx;
   float ss = 0.f;
-  for (int k = tid; k < H; k += 256) { float v = xr[k]; xn[k] = v; ss += v * v; }
+  for (int k = tid; k < H; k += 256) { float v = xr[k]; ss += v * v; }
   ss = block_sum(ss, red);
   const float rstd = rsqrtf(ss / (float)H + eps);
-  for (int k = tid; k < H; k += 256) {
-    float v = xn[k] * rstd * bf16_to_f32(norm_w[k]);
-    xn[k] = v;
-    x_norm[(int64_t)m * H + k] = v;
-  }
-  __syncthreads();
-  const bf16_t* gw = (image_mask && image_gate_w && image_mask[m]) ? image_gate_w : gate_w;
-  for (int e = wave; e < E; e += 4) {
-    const bf16_t* wr = gw + (int64_t)e * H;
-    float acc = 0.f;
-    for (int k = lane * 8; k < H; k += 512) {
-      const u32x4 w = *reinterpret_cast<const u32x4*>(wr + k);
-      const f32x4 a = *reinterpret_cast<const f32x4*>(xn + k);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(xn + k + 4);
-      acc = fmaf(bf16lo_to_f32(w.x), a.x, acc); acc = fmaf(bf16hi_to_f32(w.x), a.y, acc);
-      acc = fmaf(bf16lo_to_f32(w.y), a.z, acc); acc = fmaf(bf16hi_to_f32(w.y), a.w, acc);
-      acc = fmaf(bf16lo_to_f32(w.z), b.x, acc); acc = fmaf(bf16hi_to_f32(w.z), b.y, acc);
-      acc = fmaf(bf16lo_to_f32(w.w), b.z, acc); acc = fmaf(bf16hi_to_f32(w.w), b.w, acc);
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) logits[e] = acc;
-  }
-  __syncthreads();
+  for (int k = tid; k < H; k += 256) x_norm[(int64_t)m * H + k] = xr[k] * rstd * bf16_to_f32(norm_w[k]);
   if (wave == 0) {
+    const float* lg = (image_mask && logits_image && image_mask[m]) ? logits_image : logits_text;
     // softmax over E (fp32) then iterative arg-max; ties -> lowest expert index
-    float s = lane < E ? logits[lane] : -INFINITY;
+    float s = lane < E ? lg[(int64_t)m * E + lane] : -INFINITY;
     const float mx = wave_max(s);
     float p = lane < E ? __expf(s - mx) : 0.f;
     const float denom = wave_sum(p);
@@ -85,14 +65,25 @@ __global__ __launch_bounds__(256) void moe_router_kernel(
 extern "C" int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w, float eps,
                              const uint16_t* gate_w, const uint16_t* image_gate_w, const uint8_t* image_mask,
                              int M, int H, int E, int top_k, int norm_topk_prob, int n_shared_slots,
-                             float* x_norm, int32_t* topk_idx, float* topk_w, void* stream) {
-  MN_CHECK_ARG(M >= 1 && H >= 8 && (H % 8) == 0, "mn_moe_router: bad M=%d H=%d", M, H);
+                             float* x_norm, int32_t* topk_idx, float* topk_w, float* logits_ws, void* stream) {
+  MN_CHECK_ARG(M >= 1 && M <= 8 && H >= 8 && (H % 8) == 0, "mn_moe_router: bad M=%d H=%d", M, H);
   MN_CHECK_ARG(E >= 1 && E <= 64 && top_k >= 1 && top_k <= E && top_k + n_shared_slots <= 64,
                "mn_moe_router: bad E=%d top_k=%d", E, top_k);
-  MN_CHECK_ARG(x && norm_w && gate_w && x_norm && topk_idx && topk_w, "mn_moe_router: null pointer");
-  const size_t lds = (size_t)(H + 64 + 16) * sizeof(float);
-  hipLaunchKernelGGL(moe_router_kernel, dim3(M), dim3(256), lds, mn_stream(stream), x, ldx, norm_w, eps, gate_w,
-                     image_gate_w, image_mask, H, E, top_k, norm_topk_prob, n_shared_slots, x_norm, topk_idx, topk_w);
+  MN_CHECK_ARG(x && norm_w && gate_w && x_norm && topk_idx && topk_w && logits_ws, "mn_moe_router: null pointer");
+  const bool both = image_mask && image_gate_w;
+  for (int gsel = 0; gsel < (both ? 2 : 1); ++gsel) {
+    mn_skinny_args a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.ldx = ldx; a.w = gsel ? image_gate_w : gate_w; a.ldw = H;
+    a.out = logits_ws + (int64_t)gsel * M * E; a.ldo = E;
+    a.M = M; a.N = E; a.K = H;
+    a.prologue = MN_PRO_RMSNORM; a.ln_g = norm_w; a.eps = eps;
+    const int rc = mn_skinny_gemm(&a, stream);
+    if (rc != MN_OK) return rc;
+  }
+  hipLaunchKernelGGL(moe_topk_kernel, dim3(M), dim3(256), 0, mn_stream(stream), x, ldx, norm_w, eps, logits_ws,
+                     both ? logits_ws + (int64_t)M * E : nullptr, image_mask, H, E, top_k, norm_topk_prob,
+                     n_shared_slots, x_norm, topk_idx, topk_w);
   MN_CHECK_LAUNCH("mn_moe_router");
   return MN_OK;
 }

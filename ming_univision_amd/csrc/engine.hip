@@ -69,6 +69,26 @@ __global__ void rf_init_x_kernel(const float* __restrict__ noise, float temperat
   if (i < rows * target) x[i] = noise[i % target] * temperature;
 }
 
+// Y[s*rows + r, k] = silu(temb[s, k] + c[r, k]) split into bf16 hi (rows 0..SR-1) and lo (rows SR..2SR-1):
+// the input of every adaLN projection of every Euler step (diff_loss_rf_swiglu.py:263-266, 376).
+__global__ void rf_build_y_kernel(const float* __restrict__ temb, const float* __restrict__ c, bf16_t* __restrict__ y,
+                                  int steps, int rows, int w) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t SR = (int64_t)steps * rows;
+  if (i >= SR * w) return;
+  const int k = (int)(i % w), sr = (int)(i / w), s = sr / rows, r = sr % rows;
+  const float v = silu_f(temb[(int64_t)s * w + k] + c[(int64_t)r * w + k]);
+  const bf16_t hi = f32_to_bf16(v);
+  y[i] = hi;
+  y[SR * w + i] = f32_to_bf16(v - bf16_to_f32(hi));
+}
+
+// ada[i, n] = C[i, n] + C[SR + i, n] + bias[n]  (hi + lo halves of the split-bf16 GEMM), in place
+__global__ void rf_ada_combine_kernel(float* __restrict__ C, const bf16_t* __restrict__ bias, int64_t SR, int64_t A) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < SR * A; i += (int64_t)gridDim.x * blockDim.x)
+    C[i] = C[i] + C[SR * A + i] + bf16_to_f32(bias[i % A]);
+}
+
 // CFG combine + Euler step (diff_loss_rf_swiglu.py:144-179): v rows = [cond, uncond, text_uncond]
 __global__ void rf_euler_kernel(const float* __restrict__ v, float* __restrict__ x, int rows, int target,
                                 float text_cfg, float image_cfg, float step) {
@@ -142,12 +162,13 @@ mn_skinny_args sk(const float* x, int64_t ldx, const bf16_t* w, int64_t ldw, con
 // Rectified-flow head
 // ===========================================================================================
 static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, float** z, float** c, float** ada,
-                       float** hh, float** hid, float** v, float** x) {
+                       float** hh, float** hid, float** v, float** x, bf16_t** y) {
   Carver cv(ws, cap, ws == nullptr);
   const int A = h->depth * 3 * h->w + 2 * h->w;
   *z = cv.take<float>((size_t)rows * h->z_dim);
   *c = cv.take<float>((size_t)rows * h->w);
-  *ada = cv.take<float>((size_t)rows * A);
+  *ada = cv.take<float>((size_t)2 * h->steps * rows * A);   // [hi | lo] GEMM output, combined in place
+  *y = cv.take<bf16_t>((size_t)2 * h->steps * rows * h->w);
   *hh = cv.take<float>((size_t)rows * h->w);
   *hid = cv.take<float>((size_t)rows * h->hidden);
   *v = cv.take<float>((size_t)rows * h->target);
@@ -157,7 +178,8 @@ static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, floa
 
 extern "C" size_t mn_rf_workspace_bytes(const mn_rf_head* h, int rows) {
   float *a, *b, *c, *d, *e, *f, *g;
-  return rf_carve(h, rows, nullptr, 0, &a, &b, &c, &d, &e, &f, &g);
+  bf16_t* y;
+  return rf_carve(h, rows, nullptr, 0, &a, &b, &c, &d, &e, &f, &g, &y);
 }
 
 extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld_hidden, int rows, const float* noise,
@@ -167,7 +189,8 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   MN_CHECK_ARG(rows >= 1 && rows <= 3, "mn_rf_sample: rows=%d (1..3)", rows);
   MN_CHECK_ARG(h->target <= 256, "mn_rf_sample: target too large");
   float *z, *c, *ada, *hh, *hid, *v, *x;
-  const size_t need = rf_carve(h, rows, workspace, workspace_bytes, &z, &c, &ada, &hh, &hid, &v, &x);
+  bf16_t* y;
+  const size_t need = rf_carve(h, rows, workspace, workspace_bytes, &z, &c, &ada, &hh, &hid, &v, &x, &y);
   if (need > workspace_bytes) { mn_set_error("mn_rf_sample: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
   hipStream_t st = mn_stream(stream);
   const int w = h->w, A = h->depth * 3 * w + 2 * w, T = h->target;
@@ -181,14 +204,20 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
     MN_TRY(mn_skinny_gemm(&a, stream));
   }
   hipLaunchKernelGGL(rf_init_x_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, noise, temperature, x, rows, T);
+  // The adaLN inputs SiLU(t_emb[s] + c) do not depend on the ODE state, so the modulations of ALL
+  // Euler steps are one [2*steps*rows, w] x [w, depth*3w+2w] MFMA GEMM that reads the 0.7 GB of adaLN
+  // weights once per token instead of once per step (activations split into bf16 hi+lo so that the
+  // products stay fp32-accurate).   Linear(SiLU(t_emb[s] + c))  (diff_loss:263-266,283-286,376)
+  const int64_t SR = (int64_t)h->steps * rows;
+  hipLaunchKernelGGL(rf_build_y_kernel, dim3(mn_cdiv(SR * w, 256)), dim3(256), 0, st, h->temb, c, y, h->steps, rows, w);
+  MN_TRY(mn_gemm_bf16(y, w, h->ada_w, w, nullptr, ada, A, (int)(2 * SR), A, w, MN_GEMM_F32, stream));
+  hipLaunchKernelGGL(rf_ada_combine_kernel, dim3(2048), dim3(256), 0, st, ada, h->ada_b, SR, (int64_t)A);
   const float step = 1.0f / (float)h->steps;
+  const float* ada_all = ada;
   for (int s = 0; s < h->steps; ++s) {
-    // all adaLN projections of this step: Linear(SiLU(t_emb[s] + c))  (diff_loss:263-266,283-286,376)
-    mn_skinny_args a = sk(c, w, h->ada_w, w, h->ada_b, ada, A, rows, A, w);
-    a.prologue = MN_PRO_ADD_SILU; a.pro_a = h->temb + (int64_t)s * w; a.ld_pro_a = 0;
-    MN_TRY(mn_skinny_gemm(&a, stream));
+    const float* ada = ada_all + (int64_t)s * rows * A;
     // h = input_proj(x)  (diff_loss:371)
-    a = sk(x, T, h->in_w, T, h->in_b, hh, w, rows, w, T);
+    mn_skinny_args a = sk(x, T, h->in_w, T, h->in_b, hh, w, rows, w, T);
     MN_TRY(mn_skinny_gemm(&a, stream));
     for (int b = 0; b < h->depth; ++b) {
       const float* mod = ada + (int64_t)b * 3 * w;
@@ -216,7 +245,7 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
 // Bailing-MoE decoder stack step
 // ===========================================================================================
 struct LlmWs {
-  float *h, *qkv, *q, *attn, *xn, *tw, *hmid;
+  float *h, *qkv, *q, *attn, *xn, *tw, *hmid, *logits;
   int32_t* ti;
   void* attn_ws;
   size_t attn_ws_bytes;
@@ -234,6 +263,7 @@ static size_t llm_carve(const mn_llm* m, int rows, int64_t t_max, void* ws, size
   o->tw = cv.take<float>((size_t)rows * n_slot);
   o->ti = cv.take<int32_t>((size_t)rows * n_slot);
   o->hmid = cv.take<float>((size_t)rows * n_slot * m->moe_inter);
+  o->logits = cv.take<float>((size_t)2 * rows * m->n_experts);
   o->attn_ws_bytes = mn_attn_decode_workspace_bytes(rows, m->n_q, m->head_dim, t_max);
   o->attn_ws = cv.take<char>(o->attn_ws_bytes);
   return cv.off;
@@ -283,7 +313,7 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int M, 
     // MoE: RMSNorm + router -> grouped expert gate/up (SwiGLU) -> grouped down + weighted sum + residual (:1218-1225, :556-639)
     MN_TRY(mn_moe_router(w.h, H, m->ln2[l], m->rms_eps, m->gate[l], m->image_gate ? m->image_gate[l] : nullptr,
                          image_mask, M, H, m->n_experts, m->top_k, m->norm_topk_prob, m->n_shared_slots, w.xn, w.ti,
-                         w.tw, stream));
+                         w.tw, w.logits, stream));
     a = sk(w.xn, H, m->w_gate_up[l], H, nullptr, w.hmid, I, 1, I, H);
     a.epilogue = MN_EPI_SWIGLU;
     a.batch = M * n_slot; a.w_index = w.ti; a.w_batch_stride = (int64_t)2 * I * H;

@@ -73,8 +73,9 @@ def moe_router(x, norm_w, eps, gate_w, image_gate_w, image_mask, top_k, norm_top
     xn = torch.empty(M, H, dtype=torch.float32, device=x.device)
     idx = torch.empty(M, n_slot, dtype=torch.int32, device=x.device)
     w = torch.empty(M, n_slot, dtype=torch.float32, device=x.device)
+    lws = torch.empty(2 * M * E, dtype=torch.float32, device=x.device)
     check(lib().mn_moe_router(ptr(x), x.stride(0), ptr(norm_w), eps, ptr(gate_w), ptr(image_gate_w), ptr(image_mask),
-                              M, H, E, top_k, int(norm_topk_prob), n_shared_slots, ptr(xn), ptr(idx), ptr(w),
+                              M, H, E, top_k, int(norm_topk_prob), n_shared_slots, ptr(xn), ptr(idx), ptr(w), ptr(lws),
                               current_stream()), "mn_moe_router")
     return xn, idx, w
 
