@@ -176,44 +176,24 @@ def cpu_baseline(args, rows=2):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    from ming_univision_amd.dist_util import ReplicaGroup
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
-    else:
-        dist = None
+    grp = ReplicaGroup(backend="nccl", device=device)   # "nccl" is RCCL on ROCm
+    world, rank = grp.world, grp.rank
 
     cfg, dec, rf, tok = build_models(args, device, seed=0)
-    g = torch.Generator(device=device).manual_seed(1000 + rank)
+    g = torch.Generator(device=device).manual_seed(grp.seed(1000))     # independent prompt / noise per replica
     prompt = torch.randint(0, min(cfg.vocab_size, 100000), (args.prompt_len,), generator=g, device=device)
     noises = torch.randn(args.tokens + 1, 32, generator=g, device=device)
     rows = 2
 
     for _ in range(args.warmup):
         one_image(cfg, dec, rf, tok, prompt, noises)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    out = None
-    for _ in range(args.steps):
-        out = one_image(cfg, dec, rf, tok, prompt, noises)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, out = grp.timed(lambda: one_image(cfg, dec, rf, tok, prompt, noises), args.steps)
     finite = bool(torch.isfinite(out["image"]).all()) and bool(torch.isfinite(out["latents"]).all())
 
     if rank == 0:
@@ -243,9 +223,7 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "visual_tokens/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (ex,)}
         print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

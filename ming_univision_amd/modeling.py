@@ -1,0 +1,186 @@
+"""MingUniVisionForConditionalGeneration — host-side mirror of mingunivision/modeling_bailingmm.py:85-307.
+
+Owns MingTok (`vision`), the Bailing-MoE decoder (`model`), `linear_proj` and the RF head, wires them the
+way the reference does (latent_to_sem_func / linear_proj / sem_to_pix_func, :261-263) and keeps the
+multi-round state (KV cache + three attention masks, :124-127, 273-299).  The reference delegates
+decoding to HF `GenerationMixin.generate`; only greedy decoding with the `<image>` trigger and EOS is
+needed on the hot path (generation_config: do_sample=false), so this class runs its own
+greedy loop on top of the C-ABI step functions.
+"""
+import os
+
+import torch
+
+from . import ops
+from .bailing_moe import BailingMoeDecoder, generate_image
+from .configuration import MingUniVisionConfig, linear_proj_param_shapes, llm_param_shapes
+from .mingtok import MingTok
+from .rf_head import RectifiedFlowHead
+
+
+def tensor_to_pil(image_tensor):
+    """modeling_bailing_moe.py:84-90 — [1,3,H,W] in [-1,1] -> PIL."""
+    from PIL import Image
+    x = (image_tensor[0].float().cpu() * 0.5 + 0.5).clamp(0, 1)
+    arr = (x * 255.0).round().to(torch.uint8).permute(1, 2, 0).numpy()
+    return Image.fromarray(arr)
+
+
+class MingUniVisionForConditionalGeneration:
+    config_class = MingUniVisionConfig
+
+    def __init__(self, config: MingUniVisionConfig, state_dict=None, device="cuda", seed=0, t_max=4096):
+        """state_dict: reference-named tensors (`vision.*`, `model.model.*`, `model.lm_head.*`, `model.vis_head.*`,
+        `model.diffloss.*`, `linear_proj.*`); None -> deterministic synthetic weights (synth.py)."""
+        assert config.llm_config is not None
+        assert config.vishead_diffloss_config is not None          # modeling_bailingmm.py:118
+        self.config = config
+        self.device = torch.device(device)
+        cfg = config.llm_config
+        from .synth import synth_tensor
+        from .configuration import MingTokConfig
+        tcfg = config.mingtok_config or MingTokConfig()
+
+        def bf(t):
+            return t.to(self.device, torch.bfloat16).contiguous()
+        D = tcfg.semantic_decoder.get("embed_dim", 1024)
+        lp_shapes = linear_proj_param_shapes(D, cfg.hidden_size, config.mlp_depth)
+        if state_dict is None:
+            lp = {k: synth_tensor(k, s, seed, self.device, torch.bfloat16) for k, s in lp_shapes.items()}
+            tok_sd = None
+        else:
+            lp = {k: bf(state_dict[k]) for k in lp_shapes}
+            tok_sd = {k[len("vision."):]: v for k, v in state_dict.items() if k.startswith("vision.")}
+        self.linear_proj = [(lp[f"linear_proj.{2 * i}.weight"], lp[f"linear_proj.{2 * i}.bias"])
+                            for i in range(config.mlp_depth)]
+        self.vision = MingTok(tcfg, state_dict=tok_sd, device=self.device, seed=seed, linear_proj=self.linear_proj)
+        if state_dict is None:
+            self.model = BailingMoeDecoder.synthetic(cfg, self.device, seed=seed, t_max=t_max, n_seq=3)
+            shapes = llm_param_shapes(cfg, config.vishead_diffloss_config, self.vision.latent_dim)
+            rf_sd = {k: synth_tensor(k, s, seed, self.device, torch.bfloat16) for k, s in shapes.items()
+                     if k.startswith("vis_head") or k.startswith("diffloss")}
+        else:
+            llm_sd = {k[len("model."):]: bf(v) for k, v in state_dict.items() if k.startswith("model.")}
+            self.model = BailingMoeDecoder.from_state_dict(cfg, llm_sd, t_max=t_max, n_seq=3)
+            rf_sd = {k: v for k, v in llm_sd.items() if k.startswith("vis_head") or k.startswith("diffloss")}
+        self.rf = RectifiedFlowHead(rf_sd, cfg.hidden_size, config.vishead_diffloss_config, self.vision.latent_dim)
+        self.tokenizer = None
+        self.noise_generator = torch.Generator(device=self.device)
+        self.noise_generator.manual_seed(seed)
+        self.reset_inner_state()
+
+    # ---- state -----------------------------------------------------------------------------------
+    def reset_inner_state(self):
+        """modeling_bailingmm.py:303-307"""
+        self.past_len = 0
+        self.past_attention_mask = None
+        self.past_text_uncond_attention_mask = None
+        self.past_uncond_attention_mask = None
+
+    # ---- vision ----------------------------------------------------------------------------------
+    def extract_image_feature(self, pixel_values, grid_thw=None):
+        """MingTok.forward -> x_norm_patchtokens -> linear_proj (modeling_bailingmm.py:131-138) -> [B*N, H] fp32."""
+        feat = self.vision.forward(pixel_values)["x_norm_patchtokens"]
+        x = ops.f32_to_bf16(feat.reshape(-1, feat.shape[-1]).contiguous())
+        n = len(self.linear_proj)
+        for i, (w, b) in enumerate(self.linear_proj):
+            last = i == n - 1
+            x = ops.gemm_bf16(x, w, b, "f32" if last else "bf16_gelu")
+        return x
+
+    def prompt_wrap_vision(self, input_ids, inputs_embeds, vision_embeds, image_token_id=None):
+        """masked_scatter of image features at `<imagePatch>` positions (modeling_bailingmm.py:152-177)."""
+        if vision_embeds is None or input_ids is None:
+            return inputs_embeds
+        patch = image_token_id if image_token_id is not None else self.config.llm_config.image_patch_token
+        sel = (input_ids.reshape(-1) == patch)
+        n_tok, n_feat = int(sel.sum()), vision_embeds.reshape(-1, vision_embeds.shape[-1]).shape[0]
+        if n_tok != n_feat:
+            raise ValueError(f"Image features and image tokens do not match: tokens: {n_tok}, features {n_feat}")
+        out = inputs_embeds.clone()
+        out[sel.to(out.device)] = vision_embeds.reshape(n_feat, -1).to(out.dtype)
+        return out, sel
+
+    # ---- generation --------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, uncond_attention_mask=None, text_uncond_attention_mask=None,
+                 pixel_values=None, image_grid_thw=None, past_key_values=None, output_image_prefix="output",
+                 image_gen_temperature=1.0, image_gen_text_cfg=3.0, image_gen_image_cfg=1.1, max_new_tokens=512,
+                 use_cache=True, forced_first_token=None, **generate_kwargs):
+        """Greedy decode with the `<image>` trigger (modeling_bailingmm.py:206-301; modeling_bailing_moe.py:1769-1796).
+        Returns the LongTensor `sequences` [1, T_in + n_new] like HF generate.  `forced_first_token` (extension
+        used by benchmarks/tests with random weights) overrides the first generated id."""
+        cfg = self.config.llm_config
+        dev = self.device
+        assert input_ids.shape[0] == 1, "the reference path is batch-size 1 (modeling_bailing_moe.py:1865)"
+        input_ids = input_ids.to(dev)
+        T = input_ids.shape[1]
+        attention_mask = torch.ones(1, T, dtype=torch.long) if attention_mask is None else attention_mask.cpu()
+        unc = attention_mask.clone() if uncond_attention_mask is None else uncond_attention_mask.cpu()
+        tunc = attention_mask.clone() if text_uncond_attention_mask is None else text_uncond_attention_mask.cpu()
+        if self.past_attention_mask is not None:                         # :231-234
+            attention_mask = torch.cat((self.past_attention_mask, attention_mask), dim=1)
+            unc = torch.cat((self.past_uncond_attention_mask, unc), dim=1)
+            tunc = torch.cat((self.past_text_uncond_attention_mask, tunc), dim=1)
+        prompt_mask_len = attention_mask.shape[1]
+        ids = input_ids.clip(0, cfg.vocab_size - 1)
+        embeds = self.model.embed(ids[0])
+        image_mask = None
+        if pixel_values is not None and T > 1:
+            feats = self.extract_image_feature(pixel_values.to(dev), image_grid_thw)
+            embeds, image_mask = self.prompt_wrap_vision(ids, embeds, feats)
+        past = self.past_len
+        hidden = self.model.prefill(embeds, seq=0, past=past, image_mask=image_mask)[-1:]
+        cache_len = past + T
+        am = attention_mask
+        new_ids = []
+        n_img = 0
+        one = torch.ones(1, 1, dtype=am.dtype)
+        for step in range(max_new_tokens):
+            logits = self.model.logits(hidden)
+            tok = int(torch.argmax(logits[0]).item())
+            if step == 0 and forced_first_token is not None:
+                tok = int(forced_first_token)
+            new_ids.append(tok)
+            if tok == cfg.eos_token_id:
+                break
+            if step == max_new_tokens - 1:
+                break
+            if am.shape[1] < cache_len:                                  # pad the mask over generated image tokens
+                am = torch.cat((am, torch.ones(1, cache_len - am.shape[1], dtype=am.dtype)), dim=1)
+            x = self.model.embed(torch.tensor([tok], device=dev))
+            if tok == cfg.image_start_token:
+                n_tok = cfg.num_image_tokens_for_gen
+                noises = torch.randn(n_tok + 1, self.vision.latent_dim, generator=self.noise_generator, device=dev)
+                # NB: the reference swallows the caller's CFG scales and always runs 3.0 / 1.1
+                out = generate_image(self.model, self.rf, self.vision, x, cache_len, torch.cat((am, one), 1), unc, tunc,
+                                     noises, temperature=image_gen_temperature, text_cfg=3.0, image_cfg=1.1)
+                cache_len = out["cache_len"]
+                hidden = out["last_hidden"][0:1]
+                pil = tensor_to_pil(out["image"])
+                for i in range(100):                                     # modeling_bailing_moe.py:1788-1796
+                    name = f"{output_image_prefix}.png" if i == 0 else f"{output_image_prefix}_{i}.png"
+                    if not os.path.exists(name):
+                        print(f"Saving to {name}")
+                        pil.save(name)
+                        break
+                n_img += 1
+                self.last_image = out["image"]
+            else:
+                slot = torch.tensor([cache_len], dtype=torch.int32, device=dev)
+                seq0 = torch.zeros(1, dtype=torch.int32, device=dev)
+                hidden = self.model.step(x, seq0, slot, slot, slot + 1)
+                cache_len += 1
+        # state for the next round (:273-299)
+        self.past_len = cache_len
+        pad1 = torch.ones(1, cache_len - prompt_mask_len, dtype=attention_mask.dtype)
+        pad0 = torch.zeros(1, cache_len - prompt_mask_len, dtype=attention_mask.dtype)
+        if os.environ.get("PAST_MODE", "DROP") == "KEEP":
+            self.past_attention_mask = torch.cat((attention_mask, pad1), dim=1)
+            self.past_text_uncond_attention_mask = torch.cat((tunc, pad1), dim=1)
+            self.past_uncond_attention_mask = torch.cat((unc, pad0), dim=1)
+        else:
+            self.past_attention_mask = torch.cat((attention_mask, pad1), dim=1)
+            self.past_text_uncond_attention_mask = torch.cat((attention_mask, pad1), dim=1)
+            self.past_uncond_attention_mask = torch.cat((attention_mask, pad0), dim=1)
+        return torch.cat((input_ids.cpu(), torch.tensor([new_ids], dtype=input_ids.dtype)), dim=1)

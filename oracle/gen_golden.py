@@ -299,6 +299,63 @@ def gen_genimg():
          ids=ids, noises=noises, mask=am, uncond=uncond, checksum=checksum(m) + checksum(tok), **res)
 
 
+class _FakeTok:
+    """Deterministic stand-in tokenizer used to drive the REFERENCE BailingMMProcessor methods
+    (the real tokenizer.json is not shipped): same contract as ming_univision_amd.processing.SpecialTokenTokenizer."""
+
+    def __init__(self):
+        from ming_univision_amd.processing import SpecialTokenTokenizer
+        self._t = SpecialTokenTokenizer()
+        self.chat_template = None
+        self.init_kwargs = {}
+
+    def __call__(self, text, **kw):
+        return self._t(text)
+
+    def encode(self, text, add_special_tokens=False):
+        return self._t.encode(text)
+
+    def convert_tokens_to_ids(self, t):
+        return self._t.convert_tokens_to_ids(t)
+
+
+def gen_processor():
+    """Reference BailingMMProcessor.apply_chat_template / _expand_image_tokens / tokenize
+    (processing_bailingmm.py:282-464) driven with a stand-in tokenizer."""
+    import types
+    import processing_bailingmm as pb
+    fake = types.SimpleNamespace(tokenizer=_FakeTok())
+    fake._find_all_subsequences = lambda seq, sub: pb.BailingMMProcessor._find_all_subsequences(fake, seq, sub)
+    fake.apply_system_template = lambda text: pb.USER_PREFIX
+    convs = {
+        "t2i": [{"role": "HUMAN", "content": [{"type": "text", "text": "Please draw a red cube."}]}],
+        "edit": [{"role": "HUMAN", "content": [{"type": "image", "image": "a.png"}, {"type": "text", "text": "make it blue"}]}],
+        "multi": [{"role": "HUMAN", "content": [{"type": "text", "text": "hi"}]},
+                  {"role": "ASSISTANT", "content": [{"type": "text", "text": "hello there"}]},
+                  {"role": "HUMAN", "content": [{"type": "image", "image": "b.png"}, {"type": "text", "text": "what is this?"}]}],
+    }
+    out = {}
+    for name, conv in convs.items():
+        text = pb.BailingMMProcessor.apply_chat_template(fake, conv, add_generation_prompt=True)
+        n_img = text.count("<IMAGE>")
+        if n_img:
+            grid = torch.tensor([[1, 4, 4]] * n_img)
+            text = pb.BailingMMProcessor._expand_image_tokens(fake, [text], grid)[0]
+        enc = pb.BailingMMProcessor.tokenize(fake, [text])
+        out[name] = dict(text=text, input_ids=enc["input_ids"][0].tolist(),
+                         uncond=enc["uncond_attention_mask"][0].tolist(),
+                         text_uncond=enc["text_uncond_attention_mask"][0].tolist())
+    # an incomplete dialogue (no ASSISTANT tag after the last HUMAN tag)
+    text = pb.USER_PREFIX + "<image><imagePatch><imagePatch></image>\ndescribe"
+    enc = pb.BailingMMProcessor.tokenize(fake, [text])
+    out["no_assistant"] = dict(text=text, input_ids=enc["input_ids"][0].tolist(),
+                               uncond=enc["uncond_attention_mask"][0].tolist(),
+                               text_uncond=enc["text_uncond_attention_mask"][0].tolist())
+    with open(os.path.join(GOLDEN, "processor.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote", os.path.join(GOLDEN, "processor.json"))
+
+
 def main():
     ref_shim.install()
     os.makedirs(GOLDEN, exist_ok=True)
@@ -307,6 +364,7 @@ def main():
     gen_rf()
     gen_llm()
     gen_genimg()
+    gen_processor()
 
 
 if __name__ == "__main__":

@@ -93,6 +93,10 @@ def install():
             setattr(tvt, nm, type(nm, (), {"__init__": lambda self, *a, **k: None}))
         tv.transforms = tvt
         tvt.functional = tvf
+        tv.io = _stub_module("torchvision.io")
+        tv.__version__ = "0.0-stub"
+    if "torchaudio" not in sys.modules:
+        _stub_module("torchaudio")
 
     for p in (REFERENCE_ROOT, os.path.join(REFERENCE_ROOT, "mingunivision")):
         if p not in sys.path:

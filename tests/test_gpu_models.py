@@ -175,3 +175,51 @@ def test_generate_image_vs_reference(tag):
     assert rel_err(dec.logits(out["last_hidden"][0:1]), g[tag + "_logits"][0]) < TOL
     assert out["image"].shape[1:] == g[tag + "_image"].shape[1:]
     assert psnr(out["image"][0], g[tag + "_image"][0]) > 40.0   # pixel decoder runs on the bf16 MFMA path
+
+
+def test_facade_generate_text_and_image(tmp_path):
+    """MingUniVisionInfer / MingUniVisionForConditionalGeneration.generate on a tiny synthetic model:
+    greedy text tokens must equal the CPU oracle's greedy tokens; a forced `<image>` must produce an image
+    file and leave the multi-round state (cache length, masks) as the reference does (KV +257-style bookkeeping)."""
+    from ming_univision_amd.infer import MingUniVisionInfer
+    from oracle import bailing_ref
+    g = load_golden("genimg_tiny")
+    llm_cfg = dict(g["llm_config"]); llm_cfg["eos_token_id"] = 1
+    cfg = C.MingUniVisionConfig(mlp_depth=2, llm_config=llm_cfg, vishead_diffloss_config=g["rf_config"],
+                                mingtok_config=g["mingtok_config"])
+    # reference-named checkpoint (CPU-synthesised so that the oracle sees the very same weights)
+    sd = llm_sd(g["llm_config"], g["rf_config"], g["seed"])
+    ckpt = {"model." + k: v for k, v in sd.items()}
+    ckpt.update({"vision." + k: v for k, v in mingtok_sd(g["mingtok_config"], g["seed"]).items()})
+    ckpt.update(synth_state_dict(C.linear_proj_param_shapes(128, 256, 2), g["seed"]))
+    from ming_univision_amd.modeling import MingUniVisionForConditionalGeneration
+    infer = MingUniVisionInfer.__new__(MingUniVisionInfer)
+    infer.model = MingUniVisionForConditionalGeneration(cfg, state_dict=ckpt, seed=g["seed"], t_max=64)
+    model = infer.model
+    ids = g["ids"]
+    seqs = model.generate(input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=6)
+    new = seqs[0, ids.shape[1]:].tolist()
+    # oracle greedy decode with the same weights
+    ocfg = bailing_ref.LLMConfig(**{k: v for k, v in g["llm_config"].items() if k in bailing_ref.LLMConfig.__dataclass_fields__})
+    kvs = bailing_ref.new_kv(ocfg)
+    h = bailing_ref.model_forward(sd["model.word_embeddings.weight"][ids], sd, ocfg, None, None, kvs)
+    ref = []
+    for _ in range(len(new)):
+        t = int(bailing_ref.lm_logits(h[:, -1:], sd).argmax())
+        ref.append(t)
+        h = bailing_ref.model_forward(sd["model.word_embeddings.weight"][torch.tensor([[t]])], sd, ocfg, None, None, kvs)
+    assert new == ref, (new, ref)
+    model.reset_inner_state()
+    prefix = str(tmp_path / "img")
+    seqs = model.generate(input_ids=ids, attention_mask=torch.ones_like(ids), uncond_attention_mask=g["uncond"][:, :-1],
+                          text_uncond_attention_mask=g["rows3_tuncond"][:, :-1], max_new_tokens=3,
+                          forced_first_token=llm_cfg["image_start_token"], output_image_prefix=prefix)
+    import os
+    assert os.path.exists(prefix + ".png")
+    n_tok = llm_cfg["num_image_tokens_for_gen"]
+    assert model.past_len == ids.shape[1] + 1 + n_tok + 1           # prompt + <image> + n image tokens + 1 text token
+    assert model.past_attention_mask.shape[1] == model.past_len and int(model.past_uncond_attention_mask[0, -1]) == 0
+    assert model.last_image.shape == (1, 3, 64, 64)
+    # second round re-uses the cache (multi-round state)
+    seqs2 = model.generate(input_ids=ids[:, :4], attention_mask=torch.ones(1, 4, dtype=torch.long), max_new_tokens=2)
+    assert seqs2.shape[1] == 6 and model.past_len > ids.shape[1] + n_tok
