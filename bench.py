@@ -213,7 +213,9 @@ def main():
             "outputs_finite": finite,
         }
         # whole-token HBM accounting: bytes that must cross HBM per visual token / measured time per token
-        tok_bytes = rf.steps * rf.weight_bytes_per_step() + dec.weight_bytes_active(6 * rows) + 0.61e9
+        ada_bytes = rf.t["ada_w"].numel() * 2          # read once per token (all steps in one GEMM)
+        tok_bytes = (rf.steps * (rf.weight_bytes_per_step() - ada_bytes) + ada_bytes
+                     + dec.weight_bytes_active(6 * rows) + 0.61e9)
         res["token_level"] = {"algorithmic_GB_per_token": tok_bytes / 1e9,
                               "achieved_GBs": tok_bytes / (dt / (args.tokens * args.steps)) / 1e9}
         if not args.no_cpu_baseline and not args.tiny:
