@@ -247,7 +247,7 @@ __global__ void attn_decode_combine_kernel(const float* __restrict__ partial, in
 }
 
 extern "C" size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t t_max) {
-  int S = (int)mn_cdiv(t_max, 96);
+  int S = (int)mn_cdiv(t_max, 32);
   if (S > 32) S = 32;
   if (S < 1) S = 1;
   return (size_t)M * n_q * S * (hd + 2) * sizeof(float);
@@ -259,7 +259,7 @@ extern "C" int mn_attn_decode(const float* q, int M, int n_q, int n_kv, int hd, 
                                  size_t workspace_bytes, void* stream) {
   MN_CHECK_ARG(M >= 1 && n_q >= 1 && n_kv >= 1 && n_q % n_kv == 0 && (hd == 64 || hd == 128), "mn_attn_decode: bad shape");
   MN_CHECK_ARG(q && kv_cache && row_seq && row_len && out && workspace, "mn_attn_decode: null pointer");
-  int S = (int)mn_cdiv(t_max, 96);
+  int S = (int)mn_cdiv(t_max, 32);
   if (S > 32) S = 32;
   if (S < 1) S = 1;
   const size_t need = (size_t)M * n_q * S * (hd + 2) * sizeof(float);

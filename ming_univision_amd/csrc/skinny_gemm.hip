@@ -307,6 +307,7 @@ void launch_one(const KArgs& ka, dim3 grid, size_t lds, hipStream_t st) {
 template <int M, int R, int SW>
 int launch_nt(const KArgs& ka, int nt, dim3 grid, size_t lds, hipStream_t st) {
   if (nt == 256) launch_one<M, R, SW, 256>(ka, grid, lds, st);
+  else if (nt == 768) launch_one<M, R, SW, 768>(ka, grid, lds, st);
   else launch_one<M, R, SW, 512>(ka, grid, lds, st);
   return 0;
 }
@@ -354,9 +355,11 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   MN_CHECK_ARG((int64_t)ka.nseg * ka.nchunk < 4096 && ka.nseg <= 64, "mn_skinny_gemm: too many K chunks / segments");
   const int64_t Kp = (int64_t)ka.nchunk * 512;
   const size_t lds = ((size_t)a.M * ka.nseg * Kp + 32) * sizeof(float);
-  if (lds > 160 * 1024) {
-    // x does not fit the 160 KiB LDS: run the rows in slices (weights are re-streamed per slice)
-    const int mc = (int)((160 * 1024 / sizeof(float) - 32) / ((size_t)ka.nseg * Kp));
+  if (lds > 160 * 1024 || (a.M > 4 && a.M < 8)) {
+    // x does not fit the 160 KiB LDS (or M has no dedicated instantiation: 5..7 run as 4 + rest):
+    // run the rows in slices (weights are re-streamed per slice)
+    int mc = (int)((160 * 1024 / sizeof(float) - 32) / ((size_t)ka.nseg * Kp));
+    if (a.M > 4 && a.M < 8 && mc > 4) mc = 4;
     MN_CHECK_ARG(mc >= 1, "mn_skinny_gemm: K=%d x nseg=%d too large for LDS", a.K, ka.nseg);
     for (int m0 = 0; m0 < a.M; m0 += mc) {
       mn_skinny_args s = *args;
@@ -387,7 +390,13 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
     const int max_bpc = (int)((160 * 1024) / lds);
     if (groups_r1 < (int64_t)cus * 8 && max_bpc >= 2) { nt = 256; bpc = max_bpc > 4 ? 4 : max_bpc; }
   }
-  if (g_tune.nt == 256 || g_tune.nt == 512) {
+  if (nt == 512 && g_tune.nt == 0) {
+    // 12 waves per CU balance better than 8 when the row groups per CU are a multiple of 12 but not of 8
+    // (e.g. N = 3072 on 256 CUs: 12 groups per CU)
+    const int64_t per_cu = mn_cdiv((int64_t)a.N * ka.batch, cus);
+    if (per_cu % 12 == 0 && per_cu % 8 != 0) nt = 768;
+  }
+  if (g_tune.nt == 256 || g_tune.nt == 512 || g_tune.nt == 768) {
     nt = g_tune.nt;
     bpc = g_tune.bpc > 0 ? g_tune.bpc : 1;
     const int max_bpc = (int)((160 * 1024) / lds);
@@ -401,7 +410,7 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
     if ((int64_t)a.N >= 8 * resident_waves) R = 4;
     else if ((int64_t)a.N >= 4 * resident_waves) R = 2;
   } else {
-    if ((int64_t)a.N >= 4 * resident_waves) R = 2;
+    if ((int64_t)a.N >= 16 * resident_waves) R = 2;   // SwiGLU already keeps 2 rows per group in flight
   }
   if (g_tune.R > 0) R = g_tune.R;
   if (R * a.M > 64) R = 64 / a.M;
@@ -419,9 +428,6 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
     case 2: launch_m<2>(ka, R, sw, nt, grid, lds, st); break;
     case 3: launch_m<3>(ka, R, sw, nt, grid, lds, st); break;
     case 4: launch_m<4>(ka, R, sw, nt, grid, lds, st); break;
-    case 5: launch_m<5>(ka, R, sw, nt, grid, lds, st); break;
-    case 6: launch_m<6>(ka, R, sw, nt, grid, lds, st); break;
-    case 7: launch_m<7>(ka, R, sw, nt, grid, lds, st); break;
     default: launch_m<8>(ka, R, sw, nt, grid, lds, st); break;
   }
   MN_CHECK_LAUNCH("mn_skinny_gemm");

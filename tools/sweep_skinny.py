@@ -29,7 +29,7 @@ def run(M, N, K, epi, pro, iters=24, nbuf=6):
         e.record(); torch.cuda.synchronize()
         return s.elapsed_time(e) * 1e3 / iters
     res = []
-    for nt in (256, 512, 1024):
+    for nt in (256, 512, 768):
         for bpc in (1, 2, 4, 8):
             if nt * bpc > 2048: continue
             for R in (1, 2, 4):
@@ -49,5 +49,5 @@ def run(M, N, K, epi, pro, iters=24, nbuf=6):
 for M in (1, 2, 3):
     run(M, 8192, 3072, "swiglu", "ln_mod")
     run(M, 3072, 8192, "resid_gate", "none")
-    run(M, 3072, 2048, "none", "rmsnorm")
-    run(M, 2048, 2048, "none", "none")
+    run(M, 2736, 1024, "swiglu", "none")
+    run(M, 1024, 2736, "none", "none")
