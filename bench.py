@@ -113,7 +113,11 @@ def dominant_kernel_roofline(rf, rows, iters=48):
     torch.cuda.synchronize()
     us = s.elapsed_time(e) * 1e3 / iters
     nbytes = 2 * hid * w * 2          # algorithmic bytes: the bf16 weight matrix, read once
-    return dict(kernel="skinny_kernel<rows,R,SWIGLU>(RF w12: N=2x%d, K=%d)" % (hid, w), us=us, bytes=nbytes,
+    traffic = None                    # HBM bytes per launch from the committed PMC pass (same kernel, same shape)
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")
+    if os.path.exists(pmc) and hid == 8192 and w == 3072 and rows == 2:
+        traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+    return dict(traffic=traffic, kernel="skinny_kernel<rows,R,SWIGLU>(RF w12: N=2x%d, K=%d)" % (hid, w), us=us, bytes=nbytes,
                 gbs=nbytes / us * 1e-3)
 
 
@@ -208,7 +212,7 @@ def main():
                                    "random-init bf16 weights" % (args.prompt_len, args.tokens, rf.w, rf.depth, rf.steps),
                        "images_per_step_per_gpu": 1, "parallelism": "replicas x%d" % world, "tiny": bool(args.tiny)},
             "roofline": {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": None, "kernel": dom["kernel"],
+                         "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": dom["traffic"], "kernel": dom["kernel"],
                          "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"]},
             "outputs_finite": finite,
         }

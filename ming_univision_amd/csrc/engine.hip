@@ -10,6 +10,17 @@
 #include "common.h"
 
 extern "C" size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t t_max);
+extern "C" int mn_rf_blocks_persistent(int rows, int w, int hidden, int depth, int A, const uint16_t* const* w12,
+                                       const uint16_t* const* b12, const uint16_t* const* w3,
+                                       const uint16_t* const* b3, const uint16_t* const* ln_g,
+                                       const uint16_t* const* ln_b, const float* ada, float* h, float* hid,
+                                       unsigned* bar, void* stream);
+// 1: all residual blocks of an Euler step run as ONE persistent launch (rf_persistent.hip); 0 (default): two
+// launches per block.  Measured on MI355X (round 1): the persistent form is correct but SLOWER (52.6 vs 71.6
+// tok/s) because a 256-workgroup counter barrier costs more than a launch boundary and the 4-deep register
+// ring only covers ~2.5 us of it; kept for the next round (LDS-DMA ring, XCD-hierarchical barrier).
+static int g_rf_persistent = 0;
+extern "C" void mn_rf_set_persistent(int on) { g_rf_persistent = on; }
 
 namespace {
 
@@ -162,13 +173,14 @@ mn_skinny_args sk(const float* x, int64_t ldx, const bf16_t* w, int64_t ldw, con
 // Rectified-flow head
 // ===========================================================================================
 static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, float** z, float** c, float** ada,
-                       float** hh, float** hid, float** v, float** x, bf16_t** y) {
+                       float** hh, float** hid, float** v, float** x, bf16_t** y, unsigned** bar) {
   Carver cv(ws, cap, ws == nullptr);
   const int A = h->depth * 3 * h->w + 2 * h->w;
   *z = cv.take<float>((size_t)rows * h->z_dim);
   *c = cv.take<float>((size_t)rows * h->w);
   *ada = cv.take<float>((size_t)2 * h->steps * rows * A);   // [hi | lo] GEMM output, combined in place
   *y = cv.take<bf16_t>((size_t)2 * h->steps * rows * h->w);
+  *bar = cv.take<unsigned>(64);
   *hh = cv.take<float>((size_t)rows * h->w);
   *hid = cv.take<float>((size_t)rows * h->hidden);
   *v = cv.take<float>((size_t)rows * h->target);
@@ -179,7 +191,8 @@ static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, floa
 extern "C" size_t mn_rf_workspace_bytes(const mn_rf_head* h, int rows) {
   float *a, *b, *c, *d, *e, *f, *g;
   bf16_t* y;
-  return rf_carve(h, rows, nullptr, 0, &a, &b, &c, &d, &e, &f, &g, &y);
+  unsigned* bar;
+  return rf_carve(h, rows, nullptr, 0, &a, &b, &c, &d, &e, &f, &g, &y, &bar);
 }
 
 extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld_hidden, int rows, const float* noise,
@@ -190,7 +203,8 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   MN_CHECK_ARG(h->target <= 256, "mn_rf_sample: target too large");
   float *z, *c, *ada, *hh, *hid, *v, *x;
   bf16_t* y;
-  const size_t need = rf_carve(h, rows, workspace, workspace_bytes, &z, &c, &ada, &hh, &hid, &v, &x, &y);
+  unsigned* bar;
+  const size_t need = rf_carve(h, rows, workspace, workspace_bytes, &z, &c, &ada, &hh, &hid, &v, &x, &y, &bar);
   if (need > workspace_bytes) { mn_set_error("mn_rf_sample: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
   hipStream_t st = mn_stream(stream);
   const int w = h->w, A = h->depth * 3 * w + 2 * w, T = h->target;
@@ -219,7 +233,12 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
     // h = input_proj(x)  (diff_loss:371)
     mn_skinny_args a = sk(x, T, h->in_w, T, h->in_b, hh, w, rows, w, T);
     MN_TRY(mn_skinny_gemm(&a, stream));
-    for (int b = 0; b < h->depth; ++b) {
+    const bool persistent = g_rf_persistent && h->depth <= 16 && rows <= 4 && (size_t)rows * h->hidden * 4 <= 150 * 1024;
+    if (persistent) {
+      MN_TRY(mn_rf_blocks_persistent(rows, w, h->hidden, h->depth, A, h->w12, h->b12, h->w3, h->b3, h->ln_g, h->ln_b, ada,
+                                     hh, hid, bar, stream));
+    }
+    for (int b = 0; b < (persistent ? 0 : h->depth); ++b) {
       const float* mod = ada + (int64_t)b * 3 * w;
       a = sk(hh, w, h->w12[b], w, h->b12[b], hid, h->hidden, rows, h->hidden, w);
       a.prologue = MN_PRO_LN_MOD; a.ln_g = h->ln_g[b]; a.ln_b = h->ln_b[b]; a.eps = 1e-6f;

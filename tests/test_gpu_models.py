@@ -223,3 +223,30 @@ def test_facade_generate_text_and_image(tmp_path):
     # second round re-uses the cache (multi-round state)
     seqs2 = model.generate(input_ids=ids[:, :4], attention_mask=torch.ones(1, 4, dtype=torch.long), max_new_tokens=2)
     assert seqs2.shape[1] == 6 and model.past_len > ids.shape[1] + n_tok
+
+
+def test_rf_persistent_matches_per_launch_path():
+    """The persistent RF-block kernel (grid barriers, cross-phase prefetch) must give the same latents as the
+    two-launches-per-block path, at the full head size and for 1/2/3 CFG rows; the barrier error word stays 0."""
+    import ctypes
+    from ming_univision_amd._lib import lib
+    from ming_univision_amd.rf_head import RectifiedFlowHead
+    from ming_univision_amd.synth import synth_tensor
+    L = lib()
+    L.mn_rf_set_persistent.argtypes = [ctypes.c_int]
+    L.mn_rf_set_persistent.restype = None
+    rf_cfg = dict(diffloss_w=1024, diffloss_d=3, num_sampling_steps="4", gen_method="flow_matching_swiglu-4")
+    shapes = C.rf_param_shapes(1024, 3, 1024, 32, 4)
+    shapes.update({"vis_head.0.weight": (1024, 256), "vis_head.0.bias": (1024,), "vis_head.1.weight": (1024,), "vis_head.1.bias": (1024,)})
+    sd = {k: synth_tensor(k, s, 3, "cuda", torch.bfloat16) for k, s in shapes.items()}
+    head = RectifiedFlowHead(sd, 256, rf_cfg)
+    hid = torch.randn(3, 256, device="cuda")
+    noise = torch.randn(32, device="cuda")
+    for rows in (1, 2, 3):
+        L.mn_rf_set_persistent(0)
+        ref = head.sample(hid[:rows].contiguous(), noise).clone()
+        L.mn_rf_set_persistent(1)
+        for _ in range(3):
+            out = head.sample(hid[:rows].contiguous(), noise)
+            assert rel_err(out, ref) < 1e-5, rows
+    torch.cuda.synchronize()
