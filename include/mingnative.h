@@ -89,15 +89,21 @@ typedef struct mn_skinny_args {
   /* K-segments (MoE down-projection summed over the experts of one token):
    * y = sum_s seg_scale[b*nseg+s] * x[:, s*K:(s+1)*K] @ W[seg_index[b*nseg+s]]^T ; nseg <= 0 means 1. */
   int32_t nseg; const int32_t* seg_index; const float* seg_scale; int64_t seg_w_stride;
+  /* Scratch for 9 <= M <= 16 (batched generation): such launches run as prologue -> split-K bf16-MFMA GEMM on
+   * hi/lo-split activations -> reduce+epilogue, and need mn_skinny_workspace_bytes(M, N, K, epilogue) bytes.
+   * Unused (may be NULL) for M <= 8. */
+  void* ws; size_t ws_bytes;
 } mn_skinny_args;
 
+/* 1 <= M <= 16 (batch / nseg forms: M <= 8). */
 int mn_skinny_gemm(const mn_skinny_args* args, void* stream);
+size_t mn_skinny_workspace_bytes(int M, int N, int K, int epilogue);
 
 /* ------------------------------------------------------------------------------------------
  * 2. MoE router: RMSNorm + gate GEMV + fp32 softmax + top-k + renormalise, with the
  *    image-gate override on rows flagged by image_mask.
  *    Replaces BailingMoeGate.forward (modeling_bailing_moe.py:505-520) and the multi-gate blend
- *    of BailingMoeSparseMoeBlock.forward (:565-592).  M <= 8, num_experts <= 64.
+ *    of BailingMoeSparseMoeBlock.forward (:565-592).  M <= 64, num_experts <= 64.
  *      x [M,H] fp32 (pre-norm residual stream), norm_w bf16 [H]
  *      gate_w / image_gate_w bf16 [E,H]; image_mask uint8 [M] or NULL
  *      -> x_norm [M,H] fp32 (the normalised rows, input of the experts)
@@ -154,6 +160,11 @@ enum mn_gemm_epilogue {
 int mn_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias,
                  void* C, int64_t ldc, int M, int N, int K, int epilogue, void* stream);
 
+/* Split-K form for few-row weight-streaming problems: slice z of the K range writes partials[z][M][N] (fp32);
+ * returns the number of slices used (>= 1) or a negative error. */
+int mn_gemm_bf16_splitk(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, float* partials,
+                        int M, int N, int K, int ksplit, void* stream);
+
 /* y bf16 [M,D] = LayerNorm(x fp32 [M,D]; g,b bf16, eps) ; optional GELU afterwards (encoder out layer,
  * vision_transformer.py:173-178). */
 int mn_layernorm_bf16(const float* x, int64_t ldx, const uint16_t* g, const uint16_t* b, float eps,
@@ -205,15 +216,16 @@ typedef struct mn_rf_head {
   const uint16_t *fin_w, *fin_b;          /* final_layer.linear [target, w] */
 } mn_rf_head;
 
-/* hidden [rows, llm_hidden] fp32 (last hidden state of the LLM step), noise [target] fp32.
- * rows = 1 (no CFG), 2 ([cond, uncond]) or 3 ([cond, uncond, text_uncond]).
- * latent_out [target] fp32 (all CFG rows carry the same latent).  Workspace: mn_rf_workspace_bytes. */
+/* hidden [rows, llm_hidden] fp32 (last hidden states of the LLM step), rows = n_images x R image-major with
+ * R = 1 (no CFG), 2 ([cond, uncond]) or 3 ([cond, uncond, text_uncond]) rows per image; rows <= 16.
+ * noise [n_images, target] fp32; latent_out [n_images, target] fp32 (all CFG rows of an image carry the same
+ * latent).  n_images = 1 is the reference's batch-size-1 call.  Workspace: mn_rf_workspace_bytes(h, rows). */
 size_t mn_rf_workspace_bytes(const mn_rf_head* h, int rows);
-int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld_hidden, int rows, const float* noise,
-                 float temperature, float text_cfg, float image_cfg, float* latent_out,
+int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld_hidden, int rows, int n_images,
+                 const float* noise, float temperature, float text_cfg, float image_cfg, float* latent_out,
                  void* workspace, size_t workspace_bytes, void* stream);
 
-/* Bailing-MoE decoder stack, decode-style step for M <= 8 rows
+/* Bailing-MoE decoder stack, decode-style step for M <= 16 rows
  * (BailingMoeModel.forward, modeling_bailing_moe.py:1391-1540, with q_len rows per sequence). */
 typedef struct mn_llm {
   int32_t hidden, n_layers, n_q, n_kv, head_dim, n_experts, top_k, n_shared_slots, moe_inter;
@@ -233,11 +245,12 @@ typedef struct mn_llm {
 } mn_llm;
 
 size_t mn_llm_workspace_bytes(const mn_llm* m, int rows, int64_t t_max);
-/* x [M,H] fp32 in (embeddings; row stride ldx, ldx == 0 broadcasts one row to all M rows)
+/* x fp32 in (embeddings): row m is read from x + (m / x_row_div) * ldx (ldx == 0 broadcasts one row to all M
+ * rows; x_row_div = R shares one embedding between the R CFG rows of an image)
  * -> hidden_out [M,H] fp32 (after the final RMSNorm).
  * kv_cache: fp32 [n_layers][n_seq][2][n_kv][t_max][hd]; per-row int32 device arrays as in
  * mn_rope_kv_append / mn_attn_decode (row_len = row_slot + 1 is computed by the caller). */
-int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int M, const uint8_t* image_mask,
+int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int M, const uint8_t* image_mask,
                 const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len,
                 const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
                 float* hidden_out, void* workspace, size_t workspace_bytes, void* stream);

@@ -35,6 +35,7 @@ class SkinnyArgs(C.Structure):
         ("x_batch_stride", C.c_int64), ("x_batch_div", C.c_int32), ("out_batch_stride", C.c_int64),
         ("res_batch_stride", C.c_int64),
         ("nseg", C.c_int32), ("seg_index", C.c_void_p), ("seg_scale", C.c_void_p), ("seg_w_stride", C.c_int64),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
     ]
 
 
@@ -91,6 +92,8 @@ SYMBOLS = {
     "mn_last_error": (C.c_char_p, []),
     "mn_num_cus": (_i, []),
     "mn_skinny_gemm": (_i, [C.POINTER(SkinnyArgs), _p]),
+    "mn_skinny_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "mn_gemm_bf16_splitk": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _i, _i, _p]),
     "mn_moe_router": (_i, [_p, _i64, _p, _f, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "mn_rope_kv_append": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _i64, _p]),
     "mn_attn_decode_workspace_bytes": (_sz, [_i, _i, _i, _i64]),
@@ -103,9 +106,9 @@ SYMBOLS = {
     "mn_bf16_to_f32": (_i, [_p, _p, _i64, _p]),
     "mn_f32_split_bf16": (_i, [_p, _p, _p, _i64, _p]),
     "mn_rf_workspace_bytes": (_sz, [C.POINTER(RfHead), _i]),
-    "mn_rf_sample": (_i, [C.POINTER(RfHead), _p, _i64, _i, _p, _f, _f, _f, _p, _p, _sz, _p]),
+    "mn_rf_sample": (_i, [C.POINTER(RfHead), _p, _i64, _i, _i, _p, _f, _f, _f, _p, _p, _sz, _p]),
     "mn_llm_workspace_bytes": (_sz, [C.POINTER(Llm), _i, _i64]),
-    "mn_llm_step": (_i, [C.POINTER(Llm), _p, _i64, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _i, _i64, _p, _p, _sz, _p]),
+    "mn_llm_step": (_i, [C.POINTER(Llm), _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _i, _i64, _p, _p, _sz, _p]),
     "mn_rows_advance": (_i, [_p, _p, _p, _i, _i, _p]),
     "mn_add_bcast_f32": (_i, [_p, _p, _p, _i64, _i64, _p]),
     "mn_group_mean_add": (_i, [_p, _p, _p, _i, _i, _i, _p]),

@@ -147,12 +147,15 @@ class BailingMoeDecoder:
             self._ws[rows] = torch.empty(n, dtype=torch.uint8, device=self.device)
         return self._ws[rows]
 
-    def step(self, x, row_seq, row_slot, row_pos, row_len, key_mask=None, image_mask=None, out=None, rows=None):
-        """One pass of the 28-layer stack over M <= 8 rows.
-        x fp32 [M,H] (or [1,H] with rows=M to broadcast); int32 device arrays per row; key_mask uint8 [M, >=len].
+    def step(self, x, row_seq, row_slot, row_pos, row_len, key_mask=None, image_mask=None, out=None, rows=None,
+             x_row_div=1):
+        """One pass of the 28-layer stack over M <= 16 rows.
+        x fp32 [M,H]; or [1,H] with rows=M to broadcast; or [M / x_row_div, H] with rows=M when the x_row_div CFG
+        rows of an image share one embedding.  int32 device arrays per row; key_mask uint8 [M, >=len].
         Returns the post-final-norm hidden states [M,H] fp32."""
         M = rows or x.shape[0]
         ldx = 0 if (rows is not None and x.shape[0] == 1) else x.stride(0)
+        assert x.shape[0] in (1, M, M // x_row_div)
         assert x.dtype == torch.float32 and x.is_cuda and x.stride(-1) == 1
         for t in (row_seq, row_slot, row_pos, row_len):
             assert t.dtype == torch.int32 and t.is_cuda and t.numel() >= M
@@ -163,7 +166,7 @@ class BailingMoeDecoder:
         if out is None:
             out = torch.empty(M, self.cfg.hidden_size, dtype=torch.float32, device=self.device)
         ws = self._workspace(M)
-        check(lib().mn_llm_step(C.byref(self.struct), ptr(x), ldx, M, ptr(image_mask), ptr(row_seq), ptr(row_slot),
+        check(lib().mn_llm_step(C.byref(self.struct), ptr(x), ldx, x_row_div, M, ptr(image_mask), ptr(row_seq), ptr(row_slot),
                                 ptr(row_pos), ptr(row_len), ptr(key_mask),
                                 0 if key_mask is None else key_mask.stride(0), ptr(self.kv_cache), self.n_seq,
                                 self.t_max, ptr(out), ptr(ws), ws.numel(), current_stream()), "mn_llm_step")
@@ -214,69 +217,99 @@ def build_cfg_rows(attention_mask, uncond_attention_mask, text_uncond_attention_
 
 
 class ImageGenState:
-    """Device-resident bookkeeping of one generate_image call."""
+    """Device-resident bookkeeping of one (possibly batched) generate_image call.
+    Rows are image-major: row r belongs to image r // rpi and is its (r % rpi)-th CFG row; the KV sequence
+    of row r is `seq_base + r`."""
 
-    def __init__(self, dec: BailingMoeDecoder, am_rows, past_len):
+    def __init__(self, dec: BailingMoeDecoder, am_rows_list, past_lens, seq_base=0):
         dev = dec.device
-        rows, L = am_rows.shape
-        assert L == past_len + 1 and rows <= dec.n_seq
-        self.rows = rows
-        km = torch.ones(rows, dec.t_max, dtype=torch.uint8, device=dev)   # generated tokens are always attended
-        km[:, :L] = am_rows.to(dev).to(torch.uint8)
-        self.key_mask = km
-        pos = (am_rows.long().cumsum(-1) - 1)[:, -1]                       # :1905-1907
-        self.row_pos = pos.to(torch.int32).to(dev).contiguous()
-        self.row_slot = torch.full((rows,), past_len, dtype=torch.int32, device=dev)
-        self.row_len = torch.full((rows,), past_len + 1, dtype=torch.int32, device=dev)
-        self.row_seq = torch.arange(rows, dtype=torch.int32, device=dev)
+        rpi = am_rows_list[0].shape[0]
+        B = len(am_rows_list)
+        rows = B * rpi
+        assert seq_base + rows <= dec.n_seq, f"KV arena holds {dec.n_seq} sequences, need {seq_base + rows}"
+        self.rows, self.rpi, self.n_images = rows, rpi, B
+        km = torch.ones(rows, dec.t_max, dtype=torch.uint8)               # generated tokens are always attended
+        pos, slot = [], []
+        for i, (am, past) in enumerate(zip(am_rows_list, past_lens)):
+            assert am.shape == (rpi, past + 1)
+            km[i * rpi:(i + 1) * rpi, :past + 1] = am.to(torch.uint8)
+            pos.append((am.long().cumsum(-1) - 1)[:, -1])                   # modeling_bailing_moe.py:1905-1907
+            slot.append(torch.full((rpi,), past, dtype=torch.long))
+        self.key_mask = km.to(dev)
+        self.row_pos = torch.cat(pos).to(torch.int32).to(dev).contiguous()
+        self.row_slot = torch.cat(slot).to(torch.int32).to(dev).contiguous()
+        self.row_len = (self.row_slot + 1).contiguous()
+        self.row_seq = (torch.arange(rows, dtype=torch.int32) + seq_base).to(dev)
 
     def advance(self):
         check(lib().mn_rows_advance(ptr(self.row_slot), ptr(self.row_pos), ptr(self.row_len), self.rows, 1,
                                     current_stream()), "mn_rows_advance")
 
 
-def generate_image(dec: BailingMoeDecoder, rf, tok, start_embed, past_len, attention_mask, uncond_attention_mask,
-                   text_uncond_attention_mask, noises, temperature=1.0, text_cfg=3.0, image_cfg=1.1,
-                   decode_pixels=True, skip_last_sample=True):
-    """BailingMoeForCausalLM.generate_image (modeling_bailing_moe.py:1844-1965) on the HIP path.
+def generate_images(dec: BailingMoeDecoder, rf, tok, start_embed, past_lens, attention_masks, uncond_attention_masks,
+                    text_uncond_attention_masks, noises, temperature=1.0, text_cfg=3.0, image_cfg=1.1,
+                    decode_pixels=True, skip_last_sample=True):
+    """BailingMoeForCausalLM.generate_image (modeling_bailing_moe.py:1844-1965) for B >= 1 independent images
+    advancing in lock-step (B = 1 is the reference's call; B > 1 amortises every weight byte over B images).
 
-    dec: decoder whose sequence 0 already holds `past_len` cached tokens.  rf: RectifiedFlowHead.
-    tok: MingTok (semantic decoder + linear_proj step, pixel decoder).  start_embed fp32 [1,H]: the
-    `<image>` token embedding.  noises fp32 [n_tokens(+1), latent_dim]: the noise RectifiedFlowLoss.sample
-    would draw per iteration (torch.randn, diff_loss_rf_swiglu.py:117-122), supplied by the caller.
-    CFG scales: the reference always runs 3.0 / 1.1 (its kwargs are swallowed); the
-    façade passes those.  Differences from the reference that do not change results: CFG rows that
-    are bit-identical (semantic decoder, linear_proj, pixel decoder) are computed once; the sampler
-    output of the 257th iteration (discarded at :1936) is not computed when skip_last_sample.
-    Returns dict(image [1,3,R,R] fp32 | None, latents [n,32], sem [n,D], last_hidden [rows,H], attention_mask).
+    dec: decoder whose KV sequence i*R already holds image i's `past_lens[i]` prompt tokens (R = CFG rows per
+    image, equal for all images of the batch).  start_embed fp32 [1,H]: the `<image>` token embedding.
+    The three mask arguments are lists of [1, T*] tensors (one per image).  noises fp32 [B, n_tokens(+1), latent]:
+    the noise RectifiedFlowLoss.sample would draw per iteration (torch.randn, diff_loss_rf_swiglu.py:117-122).
+    CFG scales: the reference always runs 3.0 / 1.1 (its kwargs are swallowed).  Differences from
+    the reference that do not change results: CFG rows that are bit-identical (semantic decoder, linear_proj,
+    pixel decoder) are computed once per image; the sampler output of the 257th iteration (discarded at :1936)
+    is not computed when skip_last_sample.
+    Returns dict(image [B,3,R,R] | None, latents [B,n,32], sem [B,n,D], last_hidden [B*R,H], attention_mask list).
     """
     cfg = dec.cfg
-    am = build_cfg_rows(attention_mask, uncond_attention_mask, text_uncond_attention_mask).cpu()
-    rows = am.shape[0]
+    B = len(attention_masks)
+    ams = [build_cfg_rows(a, u, t).cpu() for a, u, t in zip(attention_masks, uncond_attention_masks, text_uncond_attention_masks)]
+    rpi = ams[0].shape[0]
+    assert all(a.shape[0] == rpi for a in ams), "all images of a batch must have the same number of CFG rows"
+    rows = B * rpi
     n_tok = cfg.num_image_tokens_for_gen
-    assert past_len + n_tok + 1 <= dec.t_max
-    if rows > 1:   # replicate the prompt KV to the CFG rows (:1891-1902) — device memcpy
-        for r in range(1, rows):
-            dec.kv_cache[:, r, :, :, :past_len].copy_(dec.kv_cache[:, 0, :, :, :past_len])
-    st = ImageGenState(dec, am, past_len)
+    assert max(past_lens) + n_tok + 1 <= dec.t_max and rows <= 16
+    if rpi > 1:   # replicate each prompt's KV to its CFG rows (:1891-1902) — device memcpy
+        for i, past in enumerate(past_lens):
+            for r in range(1, rpi):
+                dec.kv_cache[:, i * rpi + r, :, :, :past].copy_(dec.kv_cache[:, i * rpi, :, :, :past])
+    st = ImageGenState(dec, ams, past_lens)
     dev = dec.device
     D = tok.feature_dim
-    latents = torch.empty(n_tok, rf.target, dtype=torch.float32, device=dev)
-    sems = torch.empty(n_tok, D, dtype=torch.float32, device=dev)
-    embed = torch.empty(1, cfg.hidden_size, dtype=torch.float32, device=dev)
+    latents = torch.empty(n_tok, B, rf.target, dtype=torch.float32, device=dev)
+    sems = torch.empty(n_tok, B, D, dtype=torch.float32, device=dev)
+    embed = torch.empty(B, cfg.hidden_size, dtype=torch.float32, device=dev)
     hidden = torch.empty(rows, cfg.hidden_size, dtype=torch.float32, device=dev)
-    sem_state = tok.new_decode_state(n_seq=1, t_max=n_tok)
-    x = start_embed
+    noises = noises.reshape(B, -1, rf.target)
+    noise_t = noises.transpose(0, 1).contiguous()                    # [n+1, B, latent]
+    sem_state = tok.new_decode_state(n_seq=B, t_max=n_tok)
     for ti in range(n_tok + 1):
-        dec.step(x, st.row_seq, st.row_slot, st.row_pos, st.row_len, st.key_mask, None, out=hidden, rows=rows)
+        if ti == 0:
+            dec.step(start_embed, st.row_seq, st.row_slot, st.row_pos, st.row_len, st.key_mask, None, out=hidden, rows=rows)
+        else:
+            dec.step(embed, st.row_seq, st.row_slot, st.row_pos, st.row_len, st.key_mask, None, out=hidden, rows=rows,
+                     x_row_div=rpi)
         if ti < n_tok:
-            rf.sample(hidden, noises[ti], temperature, text_cfg, image_cfg, out=latents[ti])
-            tok.decode_step(latents[ti:ti + 1], sem_state, sem_out=sems[ti:ti + 1], embed_out=embed)
-            x = embed
+            rf.sample(hidden, noise_t[ti], temperature, text_cfg, image_cfg, out=latents[ti], n_images=B)
+            tok.decode_step(latents[ti], sem_state, sem_out=sems[ti], embed_out=embed)
             st.advance()
         elif not skip_last_sample:
-            rf.sample(hidden, noises[ti], temperature, text_cfg, image_cfg)
-    image = tok.forward_pixel_decoder(sems.unsqueeze(0)) if decode_pixels else None
-    am_out = torch.cat((am, torch.ones(rows, n_tok, dtype=am.dtype)), dim=-1)
-    return dict(image=image, latents=latents, sem=sems, last_hidden=hidden, attention_mask=am_out,
-                cache_len=past_len + n_tok + 1)
+            rf.sample(hidden, noise_t[ti], temperature, text_cfg, image_cfg, n_images=B)
+    sem_b = sems.transpose(0, 1).contiguous()
+    image = tok.forward_pixel_decoder(sem_b) if decode_pixels else None
+    am_out = [torch.cat((a, torch.ones(rpi, n_tok, dtype=a.dtype)), dim=-1) for a in ams]
+    return dict(image=image, latents=latents.transpose(0, 1), sem=sem_b, last_hidden=hidden, attention_mask=am_out,
+                cache_len=[p + n_tok + 1 for p in past_lens])
+
+
+def generate_image(dec: BailingMoeDecoder, rf, tok, start_embed, past_len, attention_mask, uncond_attention_mask,
+                   text_uncond_attention_mask, noises, **kw):
+    """Batch-size-1 form (the reference's): see generate_images."""
+    out = generate_images(dec, rf, tok, start_embed, [past_len], [attention_mask], [uncond_attention_mask],
+                          [text_uncond_attention_mask], noises.unsqueeze(0), **kw)
+    out["latents"] = out["latents"][0]
+    out["sem"] = out["sem"][0]
+    out["attention_mask"] = out["attention_mask"][0]
+    out["cache_len"] = out["cache_len"][0]
+    return out

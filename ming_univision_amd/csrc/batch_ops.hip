@@ -25,10 +25,15 @@ __device__ __forceinline__ int tile_off(int row, int slot) { return row * 128 + 
 template <int EPI, int BM>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                         const bf16_t* __restrict__ W, int64_t ldw,
-                                                        const bf16_t* __restrict__ bias, void* __restrict__ Cv,
-                                                        int64_t ldc, int M, int N, int K) {
+                                                        const bf16_t* __restrict__ bias, void* __restrict__ Cv0,
+                                                        int64_t ldc, int M, int N, int K, int Kc, int64_t c_zstride) {
   constexpr int MI = BM / 32;   // 16-row MFMA tiles per wave along M (wave grid is 2 x 2)
-  __shared__ __attribute__((aligned(16))) char lds[2][2][128 * BK * 2];  // [buf][A|W]
+  constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
+  __shared__ __attribute__((aligned(16))) char lds_raw[2][A_BYTES + W_BYTES];  // [buf][A | W]
+  // split-K: blockIdx.y owns k in [kbeg, kend) and writes its own fp32 partial slab (F32 epilogue only)
+  const int kbeg = blockIdx.y * Kc, kend = min(K, kbeg + Kc);
+  void* Cv = (EPI == MN_GEMM_F32 || EPI == MN_GEMM_F32_RESID)
+                 ? (void*)(reinterpret_cast<float*>(Cv0) + (int64_t)blockIdx.y * c_zstride) : Cv0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware tile order: consecutive tiles of one XCD share the A row panel
   const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
@@ -47,8 +52,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   const int ld_row = tid >> 3, ld_slot = tid & 7;
   u32x4 ra[4], rw[4];
   auto gload = [&](int kt) {
-    const int k = kt * BK + ld_slot * 8;
-    const bool kok = k < K;  // K % 8 == 0 so a slot is all-in or all-out
+    const int k = kbeg + kt * BK + ld_slot * 8;
+    const bool kok = k < kend;  // K % 8 == 0 so a slot is all-in or all-out
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = ld_row + 32 * i;
@@ -61,8 +66,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = ld_row + 32 * i;
-      if (i < MI) *reinterpret_cast<u32x4*>(&lds[buf][0][tile_off(r, ld_slot)]) = ra[i];
-      *reinterpret_cast<u32x4*>(&lds[buf][1][tile_off(r, ld_slot)]) = rw[i];
+      if (i < MI) *reinterpret_cast<u32x4*>(&lds_raw[buf][tile_off(r, ld_slot)]) = ra[i];
+      *reinterpret_cast<u32x4*>(&lds_raw[buf][A_BYTES + tile_off(r, ld_slot)]) = rw[i];
     }
   };
 
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (K + BK - 1) / BK;
+  const int nk = (kend - kbeg + BK - 1) / BK;
   gload(0);
   swrite(0);
   __syncthreads();
@@ -85,8 +90,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
       bf16x8 af[MI], bf[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (i < MI) af[i] = *reinterpret_cast<const bf16x8*>(&lds[cur][0][tile_off(wm + i * 16 + fr, kk * 4 + fq)]);
-        bf[i] = *reinterpret_cast<const bf16x8*>(&lds[cur][1][tile_off(wn + i * 16 + fr, kk * 4 + fq)]);
+        if (i < MI) af[i] = *reinterpret_cast<const bf16x8*>(&lds_raw[cur][tile_off(wm + i * 16 + fr, kk * 4 + fq)]);
+        bf[i] = *reinterpret_cast<const bf16x8*>(&lds_raw[cur][A_BYTES + tile_off(wn + i * 16 + fr, kk * 4 + fq)]);
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -126,21 +131,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 }
 }  // namespace
 
-extern "C" int mn_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias,
-                            void* C, int64_t ldc, int M, int N, int K, int epilogue, void* stream) {
-  MN_CHECK_ARG(A && W && C, "mn_gemm_bf16: null pointer");
-  MN_CHECK_ARG(M >= 1 && N >= 1 && K >= 8 && (K % 8) == 0, "mn_gemm_bf16: bad M=%d N=%d K=%d (K %% 8 == 0)", M, N, K);
-  MN_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0,
-               "mn_gemm_bf16: A/W rows must be 16-byte aligned");
-  hipStream_t st = mn_stream(stream);
-  const int bm = (M <= 64) ? 64 : 128;
+static int gemm_launch(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias, void* C,
+                       int64_t ldc, int M, int N, int K, int epilogue, int ksplit, int64_t c_zstride, hipStream_t st) {
+  const int bm = (M <= 32) ? 32 : (M <= 64) ? 64 : 128;
   const int tiles = (int)(mn_cdiv(M, bm) * mn_cdiv(N, BN));
-#define MN_GEMM_LAUNCH(E)                                                                                          \
-  do {                                                                                                             \
-    if (bm == 64)                                                                                                  \
-      hipLaunchKernelGGL((gemm_bf16_kernel<E, 64>), dim3(tiles), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K);  \
-    else                                                                                                           \
-      hipLaunchKernelGGL((gemm_bf16_kernel<E, 128>), dim3(tiles), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K); \
+  int Kc = K;
+  if (ksplit > 1) Kc = (int)(mn_cdiv(mn_cdiv(K, ksplit), BK) * BK);
+  const int nz = (int)mn_cdiv(K, Kc);
+  dim3 grid(tiles, nz);
+#define MN_GEMM_LAUNCH(E)                                                                                              \
+  do {                                                                                                                 \
+    if (bm == 32)                                                                                                      \
+      hipLaunchKernelGGL((gemm_bf16_kernel<E, 32>), grid, dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, Kc, c_zstride);  \
+    else if (bm == 64)                                                                                                 \
+      hipLaunchKernelGGL((gemm_bf16_kernel<E, 64>), grid, dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, Kc, c_zstride);  \
+    else                                                                                                               \
+      hipLaunchKernelGGL((gemm_bf16_kernel<E, 128>), grid, dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, Kc, c_zstride); \
   } while (0)
   switch (epilogue) {
     case MN_GEMM_BF16: MN_GEMM_LAUNCH(MN_GEMM_BF16); break;
@@ -152,8 +158,35 @@ extern "C" int mn_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
       return MN_EINVAL;
   }
 #undef MN_GEMM_LAUNCH
+  return nz;
+}
+
+extern "C" int mn_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias,
+                            void* C, int64_t ldc, int M, int N, int K, int epilogue, void* stream) {
+  MN_CHECK_ARG(A && W && C, "mn_gemm_bf16: null pointer");
+  MN_CHECK_ARG(M >= 1 && N >= 1 && K >= 8 && (K % 8) == 0, "mn_gemm_bf16: bad M=%d N=%d K=%d (K %% 8 == 0)", M, N, K);
+  MN_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0,
+               "mn_gemm_bf16: A/W rows must be 16-byte aligned");
+  const int rc = gemm_launch(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, 1, 0, mn_stream(stream));
+  if (rc < 0) return rc;
   MN_CHECK_LAUNCH("mn_gemm_bf16");
   return MN_OK;
+}
+
+// Split-K form for weight-streaming problems with few rows (M <= 64): the K range is cut into `ksplit`
+// slices (rounded to 64), slice z writes the fp32 partial product to partials[z][M][N] (ldc = N).  Returns
+// the number of slices actually used (>= 1) or a negative error; the caller reduces the slabs.
+extern "C" int mn_gemm_bf16_splitk(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, float* partials,
+                                   int M, int N, int K, int ksplit, void* stream) {
+  MN_CHECK_ARG(A && W && partials, "mn_gemm_bf16_splitk: null pointer");
+  MN_CHECK_ARG(M >= 1 && N >= 1 && K >= 8 && (K % 8) == 0 && ksplit >= 1, "mn_gemm_bf16_splitk: bad shape");
+  MN_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0,
+               "mn_gemm_bf16_splitk: A/W rows must be 16-byte aligned");
+  const int nz = gemm_launch(A, lda, W, ldw, nullptr, partials, N, M, N, K, MN_GEMM_F32, ksplit, (int64_t)M * N,
+                             mn_stream(stream));
+  if (nz < 0) return nz;
+  MN_CHECK_LAUNCH("mn_gemm_bf16_splitk");
+  return nz;
 }
 
 // ===========================================================================================

@@ -5,7 +5,11 @@
 // MingTok semantic-decoder step + linear_proj (mn_semdec_step).  Nothing here touches
 // the host after enqueueing: positions, lengths, expert indices all live in device memory,
 // so a whole visual token can be captured into a hipGraph by the caller.
+#include <stdlib.h>
 #include <string.h>
+
+#include <array>
+#include <initializer_list>
 
 #include "common.h"
 
@@ -74,10 +78,11 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restr
   }
 }
 
+// x[r] = noise[image(r)] * temperature; rows are image-major: image = r / rows_per_image
 __global__ void rf_init_x_kernel(const float* __restrict__ noise, float temperature, float* __restrict__ x, int rows,
-                                 int target) {
+                                 int target, int rpi) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < rows * target) x[i] = noise[i % target] * temperature;
+  if (i < rows * target) x[i] = noise[(i / target / rpi) * target + i % target] * temperature;
 }
 
 // Y[s*rows + r, k] = silu(temb[s, k] + c[r, k]) split into bf16 hi (rows 0..SR-1) and lo (rows SR..2SR-1):
@@ -101,10 +106,13 @@ __global__ void rf_ada_combine_kernel(float* __restrict__ C, const bf16_t* __res
 }
 
 // CFG combine + Euler step (diff_loss_rf_swiglu.py:144-179): v rows = [cond, uncond, text_uncond]
-__global__ void rf_euler_kernel(const float* __restrict__ v, float* __restrict__ x, int rows, int target,
+// one block per image; `rows` = CFG rows of ONE image
+__global__ void rf_euler_kernel(const float* __restrict__ v0, float* __restrict__ x0, int rows, int target,
                                 float text_cfg, float image_cfg, float step) {
   const int i = threadIdx.x;
   if (i >= target) return;
+  const float* v = v0 + (int64_t)blockIdx.x * rows * target;
+  float* x = x0 + (int64_t)blockIdx.x * rows * target;
   float vg;
   if (rows == 3) {
     const float vc = v[i], vu = v[target + i], vtu = v[2 * target + i];
@@ -137,10 +145,17 @@ __global__ void copy_f32_kernel(const float* __restrict__ a, float* __restrict__
   if (i < n) b[i] = a[i];
 }
 
-// rows copy with a source row stride (ldx == 0 broadcasts one row to all M rows)
-__global__ void copy_rows_f32_kernel(const float* __restrict__ a, int64_t lda, float* __restrict__ b, int M, int D) {
+// latent_out[img] = x[img * rpi] (every CFG row of an image carries the same latent)
+__global__ void rf_gather_latent_kernel(const float* __restrict__ x, float* __restrict__ out, int n_images, int rpi, int target) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_images * target) out[i] = x[(int64_t)(i / target) * rpi * target + i % target];
+}
+
+// rows copy: b[m] = a[(m / row_div) * lda]  (lda == 0 broadcasts one row; row_div > 1 shares one source row
+// between the CFG rows of an image)
+__global__ void copy_rows_f32_kernel(const float* __restrict__ a, int64_t lda, int row_div, float* __restrict__ b, int M, int D) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (int64_t)M * D) b[i] = a[(i / D) * lda + (i % D)];
+  if (i < (int64_t)M * D) b[i] = a[((i / D) / row_div) * lda + (i % D)];
 }
 
 __global__ void rows_advance_kernel(int32_t* a, int32_t* b, int32_t* c, int M, int delta) {
@@ -152,13 +167,36 @@ __global__ void rows_advance_kernel(int32_t* a, int32_t* b, int32_t* c, int M, i
   }
 }
 
+// scratch for the M > 8 route of mn_skinny_gemm; set by the running composite (single-threaded host code)
+thread_local void* t_sk_ws = nullptr;
+thread_local size_t t_sk_ws_bytes = 0;
+
 mn_skinny_args sk(const float* x, int64_t ldx, const bf16_t* w, int64_t ldw, const bf16_t* bias, float* out,
                   int64_t ldo, int M, int N, int K) {
   mn_skinny_args a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.ldx = ldx; a.w = w; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo;
   a.M = M; a.N = N; a.K = K;
+  a.ws = t_sk_ws; a.ws_bytes = t_sk_ws_bytes;
   return a;
+}
+
+size_t sk_ws_need(int M, std::initializer_list<std::array<int, 3>> shapes) {   // {N, K, epilogue}
+  size_t mx = 0;
+  for (auto& s : shapes) {
+    const size_t b = mn_skinny_workspace_bytes(M, s[0], s[1], s[2]);
+    if (b > mx) mx = b;
+  }
+  return mx;
+}
+
+// MN_DEBUG_SYNC=1: synchronise after every sub-launch and report which one faulted (debug aid only)
+static inline void dbg_sync(const char* what, hipStream_t st) {
+  static int on = -1;
+  if (on < 0) on = getenv("MN_DEBUG_SYNC") ? 1 : 0;
+  if (!on) return;
+  hipError_t e = hipStreamSynchronize(st);
+  fprintf(stderr, "[mn] %s: %s\n", what, hipGetErrorString(e));
 }
 
 #define MN_TRY(expr)            \
@@ -173,7 +211,8 @@ mn_skinny_args sk(const float* x, int64_t ldx, const bf16_t* w, int64_t ldw, con
 // Rectified-flow head
 // ===========================================================================================
 static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, float** z, float** c, float** ada,
-                       float** hh, float** hid, float** v, float** x, bf16_t** y, unsigned** bar) {
+                       float** hh, float** hid, float** v, float** x, bf16_t** y, unsigned** bar, char** skws,
+                       size_t* skws_bytes) {
   Carver cv(ws, cap, ws == nullptr);
   const int A = h->depth * 3 * h->w + 2 * h->w;
   *z = cv.take<float>((size_t)rows * h->z_dim);
@@ -185,6 +224,9 @@ static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, floa
   *hid = cv.take<float>((size_t)rows * h->hidden);
   *v = cv.take<float>((size_t)rows * h->target);
   *x = cv.take<float>((size_t)rows * h->target);
+  *skws_bytes = sk_ws_need(rows, {{h->z_dim, h->llm_hidden, 0}, {h->w, h->z_dim, 0}, {h->hidden, h->w, MN_EPI_SWIGLU},
+                                   {h->w, h->hidden, 0}, {h->target, h->w, 0}, {h->w, h->target, 0}});
+  *skws = cv.take<char>(*skws_bytes);
   return cv.off;
 }
 
@@ -192,19 +234,26 @@ extern "C" size_t mn_rf_workspace_bytes(const mn_rf_head* h, int rows) {
   float *a, *b, *c, *d, *e, *f, *g;
   bf16_t* y;
   unsigned* bar;
-  return rf_carve(h, rows, nullptr, 0, &a, &b, &c, &d, &e, &f, &g, &y, &bar);
+  char* sw;
+  size_t swb;
+  return rf_carve(h, rows, nullptr, 0, &a, &b, &c, &d, &e, &f, &g, &y, &bar, &sw, &swb);
 }
 
-extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld_hidden, int rows, const float* noise,
-                            float temperature, float text_cfg, float image_cfg, float* latent_out, void* workspace,
-                            size_t workspace_bytes, void* stream) {
+extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld_hidden, int rows, int n_images,
+                            const float* noise, float temperature, float text_cfg, float image_cfg,
+                            float* latent_out, void* workspace, size_t workspace_bytes, void* stream) {
   MN_CHECK_ARG(h && hidden && noise && latent_out && workspace, "mn_rf_sample: null pointer");
-  MN_CHECK_ARG(rows >= 1 && rows <= 3, "mn_rf_sample: rows=%d (1..3)", rows);
+  MN_CHECK_ARG(n_images >= 1 && rows >= n_images && rows % n_images == 0 && rows / n_images <= 3 && rows <= 16,
+               "mn_rf_sample: rows=%d n_images=%d (1..3 CFG rows per image, <= 16 rows)", rows, n_images);
   MN_CHECK_ARG(h->target <= 256, "mn_rf_sample: target too large");
+  const int rpi = rows / n_images;
   float *z, *c, *ada, *hh, *hid, *v, *x;
   bf16_t* y;
   unsigned* bar;
-  const size_t need = rf_carve(h, rows, workspace, workspace_bytes, &z, &c, &ada, &hh, &hid, &v, &x, &y, &bar);
+  char* skws;
+  size_t skws_bytes;
+  const size_t need = rf_carve(h, rows, workspace, workspace_bytes, &z, &c, &ada, &hh, &hid, &v, &x, &y, &bar, &skws, &skws_bytes);
+  t_sk_ws = skws; t_sk_ws_bytes = skws_bytes;
   if (need > workspace_bytes) { mn_set_error("mn_rf_sample: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
   hipStream_t st = mn_stream(stream);
   const int w = h->w, A = h->depth * 3 * w + 2 * w, T = h->target;
@@ -213,11 +262,13 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   {
     mn_skinny_args a = sk(hidden, ld_hidden, h->vis_w, h->llm_hidden, h->vis_b, z, h->z_dim, rows, h->z_dim, h->llm_hidden);
     MN_TRY(mn_skinny_gemm(&a, stream));
+    dbg_sync("rf vis_head", st);
     a = sk(z, h->z_dim, h->cond_w, h->z_dim, h->cond_b, c, w, rows, w, h->z_dim);
     a.prologue = MN_PRO_LN; a.ln_g = h->vis_ln_g; a.ln_b = h->vis_ln_b; a.eps = 1e-6f;
     MN_TRY(mn_skinny_gemm(&a, stream));
+    dbg_sync("rf cond_embed", st);
   }
-  hipLaunchKernelGGL(rf_init_x_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, noise, temperature, x, rows, T);
+  hipLaunchKernelGGL(rf_init_x_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, noise, temperature, x, rows, T, rpi);
   // The adaLN inputs SiLU(t_emb[s] + c) do not depend on the ODE state, so the modulations of ALL
   // Euler steps are one [2*steps*rows, w] x [w, depth*3w+2w] MFMA GEMM that reads the 0.7 GB of adaLN
   // weights once per token instead of once per step (activations split into bf16 hi+lo so that the
@@ -225,7 +276,9 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   const int64_t SR = (int64_t)h->steps * rows;
   hipLaunchKernelGGL(rf_build_y_kernel, dim3(mn_cdiv(SR * w, 256)), dim3(256), 0, st, h->temb, c, y, h->steps, rows, w);
   MN_TRY(mn_gemm_bf16(y, w, h->ada_w, w, nullptr, ada, A, (int)(2 * SR), A, w, MN_GEMM_F32, stream));
+  dbg_sync("rf ada gemm", st);
   hipLaunchKernelGGL(rf_ada_combine_kernel, dim3(2048), dim3(256), 0, st, ada, h->ada_b, SR, (int64_t)A);
+  dbg_sync("rf ada combine", st);
   const float step = 1.0f / (float)h->steps;
   const float* ada_all = ada;
   for (int s = 0; s < h->steps; ++s) {
@@ -233,6 +286,7 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
     // h = input_proj(x)  (diff_loss:371)
     mn_skinny_args a = sk(x, T, h->in_w, T, h->in_b, hh, w, rows, w, T);
     MN_TRY(mn_skinny_gemm(&a, stream));
+    dbg_sync("rf input_proj", st);
     const bool persistent = g_rf_persistent && h->depth <= 16 && rows <= 4 && (size_t)rows * h->hidden * 4 <= 150 * 1024;
     if (persistent) {
       MN_TRY(mn_rf_blocks_persistent(rows, w, h->hidden, h->depth, A, h->w12, h->b12, h->w3, h->b3, h->ln_g, h->ln_b, ada,
@@ -245,17 +299,20 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
       a.pro_a = mod; a.ld_pro_a = A; a.pro_b = mod + w; a.ld_pro_b = A;
       a.epilogue = MN_EPI_SWIGLU;
       MN_TRY(mn_skinny_gemm(&a, stream));
+      dbg_sync("rf w12", st);
       a = sk(hid, h->hidden, h->w3[b], h->hidden, h->b3[b], hh, w, rows, w, h->hidden);
       a.epilogue = MN_EPI_RESID_GATE; a.res = hh; a.ldres = w; a.gate = mod + 2 * w; a.ldgate = A;
       MN_TRY(mn_skinny_gemm(&a, stream));
+      dbg_sync("rf w3", st);
     }
     const float* modf = ada + (int64_t)h->depth * 3 * w;
     a = sk(hh, w, h->fin_w, w, h->fin_b, v, T, rows, T, w);
     a.prologue = MN_PRO_LN_MOD; a.eps = 1e-6f; a.pro_a = modf; a.ld_pro_a = A; a.pro_b = modf + w; a.ld_pro_b = A;
     MN_TRY(mn_skinny_gemm(&a, stream));
-    hipLaunchKernelGGL(rf_euler_kernel, dim3(1), dim3(256), 0, st, v, x, rows, T, text_cfg, image_cfg, step);
+    dbg_sync("rf final", st);
+    hipLaunchKernelGGL(rf_euler_kernel, dim3(n_images), dim3(256), 0, st, v, x, rpi, T, text_cfg, image_cfg, step);
   }
-  hipLaunchKernelGGL(copy_f32_kernel, dim3(1), dim3(256), 0, st, x, latent_out, (int64_t)T);
+  hipLaunchKernelGGL(rf_gather_latent_kernel, dim3(mn_cdiv(n_images * T, 256)), dim3(256), 0, st, x, latent_out, n_images, rpi, T);
   MN_CHECK_LAUNCH("mn_rf_sample");
   return MN_OK;
 }
@@ -268,6 +325,8 @@ struct LlmWs {
   int32_t* ti;
   void* attn_ws;
   size_t attn_ws_bytes;
+  char* sk_ws;
+  size_t sk_ws_bytes;
 };
 
 static size_t llm_carve(const mn_llm* m, int rows, int64_t t_max, void* ws, size_t cap, LlmWs* o) {
@@ -285,6 +344,8 @@ static size_t llm_carve(const mn_llm* m, int rows, int64_t t_max, void* ws, size
   o->logits = cv.take<float>((size_t)2 * rows * m->n_experts);
   o->attn_ws_bytes = mn_attn_decode_workspace_bytes(rows, m->n_q, m->head_dim, t_max);
   o->attn_ws = cv.take<char>(o->attn_ws_bytes);
+  o->sk_ws_bytes = sk_ws_need(rows, {{qkv_dim, m->hidden, 0}, {m->hidden, m->n_q * m->head_dim, 0}});
+  o->sk_ws = cv.take<char>(o->sk_ws_bytes);
   return cv.off;
 }
 
@@ -300,13 +361,13 @@ extern "C" int mn_rows_advance(int32_t* a, int32_t* b, int32_t* c, int M, int de
   return MN_OK;
 }
 
-extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int M, const uint8_t* image_mask, const int32_t* row_seq,
+extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int M, const uint8_t* image_mask, const int32_t* row_seq,
                            const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len,
                            const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
                            float* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
   MN_CHECK_ARG(m && x && row_seq && row_slot && row_pos && row_len && kv_cache && hidden_out && workspace,
                "mn_llm_step: null pointer");
-  MN_CHECK_ARG(M >= 1 && M <= 8, "mn_llm_step: M=%d (1..8)", M);
+  MN_CHECK_ARG(M >= 1 && M <= 16 && x_row_div >= 1, "mn_llm_step: M=%d (1..16)", M);
   LlmWs w;
   const size_t need = llm_carve(m, M, t_max, workspace, workspace_bytes, &w);
   if (need > workspace_bytes) { mn_set_error("mn_llm_step: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
@@ -315,7 +376,8 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int M, 
   const int qkv_dim = (nq + 2 * nkv) * hd, n_slot = m->top_k + m->n_shared_slots;
   const int64_t layer_kv = (int64_t)n_seq * 2 * nkv * t_max * hd;
   const float q_scale = 1.0f / sqrtf((float)hd);
-  hipLaunchKernelGGL(copy_rows_f32_kernel, dim3(mn_cdiv((int64_t)M * H, 256)), dim3(256), 0, st, x, ldx, w.h, M, H);
+  t_sk_ws = w.sk_ws; t_sk_ws_bytes = w.sk_ws_bytes;
+  hipLaunchKernelGGL(copy_rows_f32_kernel, dim3(mn_cdiv((int64_t)M * H, 256)), dim3(256), 0, st, x, ldx, x_row_div, w.h, M, H);
   for (int l = 0; l < m->n_layers; ++l) {
     float* kv_l = kv_cache + (int64_t)l * layer_kv;
     // attention: RMSNorm -> QKV -> RoPE/KV append -> masked GQA -> dense + residual  (:1204-1215, :743-829)
@@ -385,6 +447,7 @@ extern "C" int mn_semdec_step(const mn_semdec* s, const float* latent_norm, int 
                               size_t workspace_bytes, void* stream) {
   MN_CHECK_ARG(s && latent_norm && row_seq && row_slot && row_len && kv_cache && workspace, "mn_semdec_step: null pointer");
   MN_CHECK_ARG(M >= 1 && M <= 8 && s->dim == s->n_heads * 64 && s->dim % s->in_dim == 0, "mn_semdec_step: bad shape");
+  t_sk_ws = nullptr; t_sk_ws_bytes = 0;
   MN_CHECK_ARG(!embed_out || (s->proj_depth >= 1 && s->proj_depth <= 2), "mn_semdec_step: proj_depth must be 1 or 2");
   SemWs w;
   const size_t need = sem_carve(s, M, t_max, workspace, workspace_bytes, &w);

@@ -12,6 +12,8 @@
 // accumulates R x M partial sums in registers and the wave reduces them with xor shuffles.
 // The LDS image of x is permuted so that the two ds_read_b128 per (row, chunk) are
 // lane-contiguous (conflict-free): position c*512 + j*256 + lane*4 + i holds x[c*512 + lane*8 + j*4 + i].
+#include <stdlib.h>
+
 #include "skinny_device.h"
 
 namespace {
@@ -199,6 +201,123 @@ int launch_m(const KArgs& ka, int R, int sw, int nt, dim3 grid, size_t lds, hipS
 
 }  // namespace
 
+// ===========================================================================================
+// 9 <= M <= 16 rows (batched generation): weights are still read once, but the fp32 FMA path would be
+// VALU-bound, so the product runs on the matrix cores:
+//   prologue kernel : x' = prologue(x) in fp32, split into bf16 hi + lo rows  -> Y[2M, K]
+//   mn_gemm_bf16_splitk : partials[z][2M][Ntot] = Y[:, kz] W[:, kz]^T          (bf16 MFMA, fp32 accumulate)
+//   epilogue kernel : out = epilogue( sum_z (hi + lo) + bias )
+// hi + lo keeps the products fp32-accurate (x' = hi + lo to 2^-17 relative).
+// ===========================================================================================
+extern "C" int mn_gemm_bf16_splitk(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, float* partials,
+                                   int M, int N, int K, int ksplit, void* stream);
+
+namespace {
+
+__global__ __launch_bounds__(1024) void medium_prologue_kernel(const mn_skinny_args a, bf16_t* __restrict__ Y) {
+  __shared__ float red[32];
+  const int m = blockIdx.x, tid = threadIdx.x, K = a.K, M = a.M;
+  const float* xr = a.x + (int64_t)m * a.ldx;
+  const int pro = a.prologue;
+  float mean = 0.f, rstd = 1.f;
+  if (pro >= MN_PRO_RMSNORM) {
+    if (pro != MN_PRO_RMSNORM) {
+      float s = 0.f;
+      for (int k = tid; k < K; k += 1024) s += xr[k];
+      mean = block_sum(s, red) / (float)K;
+    }
+    float ss = 0.f;
+    for (int k = tid; k < K; k += 1024) { const float d = xr[k] - mean; ss += d * d; }
+    ss = block_sum(ss, red);
+    rstd = rsqrtf(ss / (float)K + a.eps);
+  }
+  for (int k = tid; k < K; k += 1024) {
+    float v = xr[k];
+    if (pro == MN_PRO_ADD_SILU) v += a.pro_a[(int64_t)m * a.ld_pro_a + k];
+    if (pro == MN_PRO_SILU || pro == MN_PRO_ADD_SILU) v = silu_f(v);
+    if (pro >= MN_PRO_RMSNORM) {
+      v = (v - mean) * rstd;
+      if (a.ln_g) v *= bf16_to_f32(a.ln_g[k]);
+      if (a.ln_b && pro != MN_PRO_RMSNORM) v += bf16_to_f32(a.ln_b[k]);
+      if (pro == MN_PRO_LN_MOD) v = v * (1.0f + a.pro_b[(int64_t)m * a.ld_pro_b + k]) + a.pro_a[(int64_t)m * a.ld_pro_a + k];
+    }
+    const bf16_t hi = f32_to_bf16(v);
+    Y[(int64_t)m * K + k] = hi;
+    Y[(int64_t)(M + m) * K + k] = f32_to_bf16(v - bf16_to_f32(hi));
+  }
+}
+
+__global__ __launch_bounds__(256) void medium_epilogue_kernel(const mn_skinny_args a, const float* __restrict__ P, int nz,
+                                                              int Ntot) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int M = a.M, N = a.N;
+  if (i >= (int64_t)M * N) return;
+  const int m = (int)(i / N), n = (int)(i % N);
+  const int64_t slab = (int64_t)2 * M * Ntot;
+  auto gather = [&](int col) {
+    float s = 0.f;
+    for (int z = 0; z < nz; ++z) s += P[z * slab + (int64_t)m * Ntot + col] + P[z * slab + (int64_t)(M + m) * Ntot + col];
+    return s;
+  };
+  float y = gather(n);
+  if (a.bias) y += bf16_to_f32(a.bias[n]);
+  switch (a.epilogue) {
+    case MN_EPI_SILU: y = silu_f(y); break;
+    case MN_EPI_GELU: y = gelu_erf_f(y); break;
+    case MN_EPI_SWIGLU: {
+      float y2 = gather(n + N);
+      if (a.bias) y2 += bf16_to_f32(a.bias[n + N]);
+      y = silu_f(y) * y2;
+    } break;
+    case MN_EPI_RESID: y += a.res[(int64_t)m * a.ldres + n]; break;
+    case MN_EPI_RESID_GATE: y = a.res[(int64_t)m * a.ldres + n] + a.gate[(int64_t)m * a.ldgate + n] * y; break;
+    default: break;
+  }
+  a.out[(int64_t)m * a.ldo + n] = y;
+}
+
+int medium_ksplit(int Ntot, int K) {
+  const int tiles = (Ntot + 127) / 128;
+  int s = (1024 + tiles - 1) / tiles;          // ~4 workgroups per CU
+  const int smax = K / 128 > 0 ? K / 128 : 1;  // at least two 64-wide k-steps per slice
+  if (s > smax) s = smax;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : s;
+}
+
+}  // namespace
+
+extern "C" size_t mn_skinny_workspace_bytes(int M, int N, int K, int epilogue) {
+  if (M <= 8) return 0;
+  const int Ntot = epilogue == MN_EPI_SWIGLU ? 2 * N : N;
+  const size_t y = ((size_t)2 * M * K * sizeof(bf16_t) + 255) & ~(size_t)255;
+  return y + (size_t)medium_ksplit(Ntot, K) * 2 * M * Ntot * sizeof(float) + 256;
+}
+
+static int skinny_medium(const mn_skinny_args& a, void* stream) {
+  MN_CHECK_ARG(a.M <= 16, "mn_skinny_gemm: M=%d out of range [1,16]", a.M);
+  MN_CHECK_ARG((a.batch <= 1) && (a.nseg <= 1), "mn_skinny_gemm: batch/nseg forms need M <= 8");
+  MN_CHECK_ARG(a.ldw == a.K, "mn_skinny_gemm: M > 8 needs densely packed weights (ldw == K)");
+  const int Ntot = a.epilogue == MN_EPI_SWIGLU ? 2 * a.N : a.N;
+  const size_t need = mn_skinny_workspace_bytes(a.M, a.N, a.K, a.epilogue);
+  if (!a.ws || a.ws_bytes < need) { mn_set_error("mn_skinny_gemm: M=%d needs %zu workspace bytes", a.M, need); return MN_ENOSPACE; }
+  bf16_t* Y = reinterpret_cast<bf16_t*>(a.ws);
+  float* P = reinterpret_cast<float*>(reinterpret_cast<char*>(a.ws) + (((size_t)2 * a.M * a.K * sizeof(bf16_t) + 255) & ~(size_t)255));
+  hipStream_t st = mn_stream(stream);
+  const bool dbg = getenv("MN_DEBUG_SYNC") != nullptr;
+  if (dbg) fprintf(stderr, "[mn] medium M=%d N=%d K=%d pro=%d epi=%d ws=%p bytes=%zu need=%zu x=%p ldx=%lld\n", a.M, a.N, a.K,
+                   a.prologue, a.epilogue, a.ws, a.ws_bytes, need, (const void*)a.x, (long long)a.ldx);
+  hipLaunchKernelGGL(medium_prologue_kernel, dim3(a.M), dim3(1024), 0, st, a, Y);
+  if (dbg) fprintf(stderr, "[mn]  prologue: %s\n", hipGetErrorString(hipStreamSynchronize(st)));
+  const int nz = mn_gemm_bf16_splitk(Y, a.K, a.w, a.K, P, 2 * a.M, Ntot, a.K, medium_ksplit(Ntot, a.K), stream);
+  if (nz < 0) return nz;
+  if (dbg) fprintf(stderr, "[mn]  gemm nz=%d: %s\n", nz, hipGetErrorString(hipStreamSynchronize(st)));
+  hipLaunchKernelGGL(medium_epilogue_kernel, dim3((unsigned)mn_cdiv((int64_t)a.M * a.N, 256)), dim3(256), 0, st, a, P, nz, Ntot);
+  if (dbg) fprintf(stderr, "[mn]  epilogue: %s\n", hipGetErrorString(hipStreamSynchronize(st)));
+  MN_CHECK_LAUNCH("mn_skinny_gemm(medium)");
+  return MN_OK;
+}
+
 // Tuning overrides for micro-benchmarks (0 = heuristic). Not part of the stable ABI.
 static struct { int R, nt, bpc; } g_tune = {0, 0, 0};
 extern "C" void mn_skinny_tune(int R, int nt, int bpc) { g_tune.R = R; g_tune.nt = nt; g_tune.bpc = bpc; }
@@ -208,7 +327,7 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   KArgs ka;
   ka.a = *args;
   mn_skinny_args& a = ka.a;
-  MN_CHECK_ARG(a.M >= 1 && a.M <= 8, "mn_skinny_gemm: M=%d out of range [1,8]", a.M);
+  MN_CHECK_ARG(a.M >= 1 && a.M <= 16, "mn_skinny_gemm: M=%d out of range [1,16]", a.M);
   MN_CHECK_ARG(a.N >= 1 && a.K >= 8 && (a.K % 8) == 0, "mn_skinny_gemm: bad N=%d K=%d (K %% 8 must be 0)", a.N, a.K);
   MN_CHECK_ARG((a.ldw % 8) == 0, "mn_skinny_gemm: ldw=%lld must be a multiple of 8", (long long)a.ldw);
   MN_CHECK_ARG(a.x && a.w && a.out, "mn_skinny_gemm: null pointer");
@@ -216,6 +335,7 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   MN_CHECK_ARG(a.epilogue >= 0 && a.epilogue <= MN_EPI_RESID_GATE, "mn_skinny_gemm: bad epilogue %d", a.epilogue);
   ka.nseg = a.nseg > 0 ? a.nseg : 1;
   ka.batch = a.batch > 0 ? a.batch : 1;
+  if (a.M > 8) return skinny_medium(a, stream);
   MN_CHECK_ARG(ka.nseg == 1 || a.prologue <= MN_PRO_ADD_SILU, "mn_skinny_gemm: normalising prologue with segments");
   MN_CHECK_ARG(a.prologue != MN_PRO_ADD_SILU || a.pro_a, "mn_skinny_gemm: ADD_SILU needs pro_a");
   MN_CHECK_ARG(a.prologue != MN_PRO_LN_MOD || (a.pro_a && a.pro_b), "mn_skinny_gemm: LN_MOD needs shift/scale");

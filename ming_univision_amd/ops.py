@@ -60,6 +60,11 @@ def skinny_gemm(x, w, bias=None, *, prologue="none", epilogue="none", out=None, 
         a.res, a.ldres = ptr(res), res.stride(0)
     if gate is not None:
         a.gate, a.ldgate = ptr(gate), gate.stride(0)
+    ws = None
+    if M > 8:
+        nb = lib().mn_skinny_workspace_bytes(M, N, K, a.epilogue)
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        a.ws, a.ws_bytes = ptr(ws), nb
     check(lib().mn_skinny_gemm(C.byref(a), current_stream()), "mn_skinny_gemm")
     return out
 

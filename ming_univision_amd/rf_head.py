@@ -92,16 +92,19 @@ class RectifiedFlowHead:
             self._ws[rows] = torch.empty(n, dtype=torch.uint8, device=device)
         return self._ws[rows]
 
-    def sample(self, hidden, noise, temperature=1.0, text_cfg=3.0, image_cfg=1.1, out=None):
-        """hidden [rows, llm_hidden] fp32 (last hidden state of each CFG row), noise [target] fp32.
-        Returns the sampled latent [target] fp32 (identical for every CFG row)."""
+    def sample(self, hidden, noise, temperature=1.0, text_cfg=3.0, image_cfg=1.1, out=None, n_images=1):
+        """hidden [rows, llm_hidden] fp32: last hidden state of each CFG row, image-major (rows = n_images x R).
+        noise [n_images, target] (or [target] for one image) fp32.  Returns the sampled latents
+        [n_images, target] ([target] when called with a 1-D noise) — identical for every CFG row of an image."""
         rows = hidden.shape[0]
         assert hidden.dtype == torch.float32 and hidden.is_cuda and hidden.stride(1) == 1
-        assert noise.dtype == torch.float32 and noise.numel() == self.target
+        assert noise.dtype == torch.float32 and noise.is_cuda and noise.is_contiguous()
+        assert noise.numel() == n_images * self.target and rows % n_images == 0
         ws = self._workspace(rows, hidden.device)
         if out is None:
-            out = torch.empty(self.target, dtype=torch.float32, device=hidden.device)
-        check(lib().mn_rf_sample(C.byref(self.struct), ptr(hidden), hidden.stride(0), rows, ptr(noise),
+            out = torch.empty(noise.shape, dtype=torch.float32, device=hidden.device)
+        assert out.is_contiguous() and out.numel() == n_images * self.target
+        check(lib().mn_rf_sample(C.byref(self.struct), ptr(hidden), hidden.stride(0), rows, n_images, ptr(noise),
                                  float(temperature), float(text_cfg), float(image_cfg), ptr(out), ptr(ws), ws.numel(),
                                  current_stream()), "mn_rf_sample")
         return out

@@ -204,3 +204,42 @@ def test_attn_prefill_hd64(ops, B, T, nh, causal):
     ref = (att.softmax(-1) @ v).transpose(1, 2).reshape(B * T, nh * 64)
     # P is rounded to bf16 before P.V (as flash-attn does) and the output is bf16
     assert rel(out, ref) < 3 * 2 ** -8
+
+
+@pytest.mark.parametrize("M,N,K,epi,pro", [(9, 515, 2048, "none", "rmsnorm"), (16, 8192, 3072, "swiglu", "ln_mod"),
+                                           (12, 3072, 8192, "resid_gate", "none"), (16, 32, 3072, "none", "ln_mod"),
+                                           (10, 1000, 32, "silu", "none"), (16, 3072, 2048, "resid", "add_silu")])
+def test_skinny_medium_rows(ops, M, N, K, epi, pro):
+    """9..16 rows take the split-bf16 MFMA route (prologue -> split-K GEMM -> reduce+epilogue)."""
+    x = rnd(M, K, seed=70) * 1.5 + 0.2
+    rows = 2 * N if epi == "swiglu" else N
+    w, wf = bw(rows, K, seed=71, scale=K ** -0.5)
+    b, bf = bw(rows, seed=72)
+    g, gf = bw(K, seed=73); g2 = (gf * 0.1 + 1).to(torch.bfloat16); g, gf = g2.cuda(), g2.float()
+    be, bef = bw(K, seed=74, scale=0.1)
+    sh, sc = rnd(M, K, seed=75), rnd(M, K, seed=76)
+    res, gate = rnd(M, N, seed=77), rnd(M, N, seed=78)
+    xd = x.double()
+    kw = {}
+    if pro == "rmsnorm":
+        xp = xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-5) * gf.double(); kw = dict(prologue=pro, ln_g=g, eps=1e-5)
+    elif pro == "ln_mod":
+        xp = F.layer_norm(xd, (K,), gf.double(), bef.double(), 1e-6) * (1 + sc.double()) + sh.double()
+        kw = dict(prologue=pro, ln_g=g, ln_b=be, eps=1e-6, pro_a=sh.cuda(), pro_b=sc.cuda())
+    elif pro == "add_silu":
+        xp = F.silu(xd + sh[0].double()); kw = dict(prologue=pro, pro_a=sh[0].contiguous().cuda())
+    else:
+        xp = xd
+    y = xp @ wf.double().T + bf.double()
+    if epi == "swiglu":
+        ref = F.silu(y[:, :N]) * y[:, N:]
+    elif epi == "silu":
+        ref = F.silu(y)
+    elif epi == "resid":
+        ref = res.double() + y; kw["res"] = res.cuda()
+    elif epi == "resid_gate":
+        ref = res.double() + gate.double() * y; kw.update(res=res.cuda(), gate=gate.cuda())
+    else:
+        ref = y
+    out = ops.skinny_gemm(x.cuda(), w, b, epilogue=epi, **kw)
+    assert rel(out, ref) < 2e-5     # hi+lo bf16 split: 2^-17 relative per activation

@@ -95,7 +95,7 @@ def test_llm_prefill_and_cfg_decode_vs_reference(llm):
     for r in range(1, rows):
         dec.kv_cache[:, r, :, :, :T].copy_(dec.kv_cache[:, 0, :, :, :T])
     from ming_univision_amd.bailing_moe import ImageGenState
-    st = ImageGenState(dec, g["dec_mask0"], T)
+    st = ImageGenState(dec, [g["dec_mask0"]], [T])
     for s in range(g["dec_in"].shape[0]):
         hd = dec.step(g["dec_in"][s][:, 0].cuda().contiguous(), st.row_seq, st.row_slot, st.row_pos, st.row_len, st.key_mask)
         assert rel_err(hd, g["dec_hidden"][s][:, 0]) < TOL, s
@@ -250,3 +250,52 @@ def test_rf_persistent_matches_per_launch_path():
             out = head.sample(hid[:rows].contiguous(), noise)
             assert rel_err(out, ref) < 1e-5, rows
     torch.cuda.synchronize()
+
+
+def test_batched_generation_matches_single_image():
+    """generate_images with B images in lock-step (rows = B x CFG rows through the M<=16 kernels, incl. the
+    MFMA route for > 8 rows) must reproduce each image's batch-size-1 result."""
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder, generate_image, generate_images
+    from ming_univision_amd.mingtok import MingTok
+    from ming_univision_amd.rf_head import RectifiedFlowHead
+    g = load_golden("genimg_tiny")
+    sd = llm_sd(g["llm_config"], g["rf_config"], g["seed"])
+    dsd = to_dev(sd)
+    cfg = C.BailingMoeConfig(**g["llm_config"])
+    B, R = 4, 3                                   # 12 rows -> exercises the > 8-row route
+    dec = BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=32, n_seq=B * R)
+    rf = RectifiedFlowHead(dsd, cfg.hidden_size, g["rf_config"])
+    lsd = to_dev(synth_state_dict(C.linear_proj_param_shapes(128, 256, 2), g["seed"]))
+    tok = MingTok(C.MingTokConfig(**g["mingtok_config"]), state_dict=mingtok_sd(g["mingtok_config"], g["seed"]),
+                  linear_proj=[(lsd["linear_proj.0.weight"], lsd["linear_proj.0.bias"]),
+                               (lsd["linear_proj.2.weight"], lsd["linear_proj.2.bias"])])
+    gen = torch.Generator().manual_seed(3)
+    T = g["ids"].shape[1]
+    prompts = [g["ids"][0]] + [torch.randint(0, 400, (T - i,), generator=gen) for i in range(1, B)]   # ragged lengths
+    noises = torch.randn(B, cfg.num_image_tokens_for_gen + 1, 32, generator=gen)
+    noises[0] = g["noises"]
+    start = dec.embed(torch.tensor([cfg.image_start_token]).cuda())
+
+    def masks(n):
+        am = torch.ones(1, n + 1, dtype=torch.long)
+        un = am.clone(); un[0, 2:n - 2] = 0
+        tu = am.clone(); tu[0, 2:4] = 0
+        return am, un, tu
+    singles = []
+    for i in range(B):
+        dec.prefill(dec.embed(prompts[i].cuda()), seq=0, past=0)
+        am, un, tu = (g["mask"], g["uncond"], g["rows3_tuncond"]) if i == 0 else masks(prompts[i].numel())
+        singles.append(generate_image(dec, rf, tok, start, prompts[i].numel(), am, un, tu, noises[i].cuda()))
+        singles[-1] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in singles[-1].items()}
+    ams, uns, tus = [], [], []
+    for i in range(B):
+        dec.prefill(dec.embed(prompts[i].cuda()), seq=i * R, past=0)
+        am, un, tu = (g["mask"], g["uncond"], g["rows3_tuncond"]) if i == 0 else masks(prompts[i].numel())
+        ams.append(am); uns.append(un); tus.append(tu)
+    out = generate_images(dec, rf, tok, start, [p.numel() for p in prompts], ams, uns, tus, noises.cuda())
+    assert out["image"].shape[0] == B
+    for i in range(B):
+        assert rel_err(out["latents"][i], singles[i]["latents"]) < TOL, i
+        assert rel_err(out["last_hidden"][i * R:(i + 1) * R], singles[i]["last_hidden"]) < TOL, i
+        assert psnr(out["image"][i], singles[i]["image"][0]) > 45.0, i
+    assert rel_err(out["last_hidden"][:R], g["rows3_last_hidden"][:, 0]) < TOL      # image 0 is the reference's case
