@@ -32,6 +32,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tokens", type=int, default=256, help="visual tokens per image (256 = 512^2)")
     ap.add_argument("--prompt-len", type=int, default=40)
+    ap.add_argument("--images", type=int, default=1,
+                    help="images generated in lock-step per GPU (1 = the reference's batch-size-1 call; up to 8)")
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only; INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", type=int, default=None, help=argparse.SUPPRESS)
@@ -62,7 +64,7 @@ def build_models(args, device, seed):
         rf_cfg = dict(C.DEFAULT_VISHEAD_DIFFLOSS)
         tcfg = C.MingTokConfig()
     t_max = args.prompt_len + args.tokens + 8
-    dec = BailingMoeDecoder.synthetic(cfg, device, seed=seed, t_max=t_max, n_seq=2)
+    dec = BailingMoeDecoder.synthetic(cfg, device, seed=seed, t_max=t_max, n_seq=2 * args.images)
     full = C.llm_param_shapes(cfg, rf_cfg, 32)
     rf_sd = {k: synth_tensor(k, s, seed, device, torch.bfloat16) for k, s in full.items()
              if k.startswith("vis_head") or k.startswith("diffloss")}
@@ -76,16 +78,18 @@ def build_models(args, device, seed):
     return cfg, dec, rf, tok
 
 
-def one_image(cfg, dec, rf, tok, prompt_ids, noises):
-    """prefill -> forced <image> -> generate_image (2 CFG rows) -> pixel decode."""
-    from ming_univision_amd.bailing_moe import generate_image
-    T = prompt_ids.numel()
-    dec.prefill(dec.embed(prompt_ids), seq=0, past=0)
-    start = dec.embed(torch.tensor([cfg.image_start_token], device=prompt_ids.device))
+def one_image(cfg, dec, rf, tok, prompts, noises):
+    """prefill -> forced <image> -> generate_images (2 CFG rows per image) -> pixel decode.
+    prompts [B, T] ids, noises [B, n+1, 32]; B images advance in lock-step (B = 1: the reference's call)."""
+    from ming_univision_amd.bailing_moe import generate_images
+    B, T = prompts.shape
+    for i in range(B):
+        dec.prefill(dec.embed(prompts[i]), seq=2 * i, past=0)
+    start = dec.embed(torch.tensor([cfg.image_start_token], device=prompts.device))
     am = torch.ones(1, T + 1, dtype=torch.long)
     unc = torch.ones(1, T + 1, dtype=torch.long)
     unc[0, 2:T - 2] = 0                     # uncond row: the user's text span is masked out
-    return generate_image(dec, rf, tok, start, T, am, unc, unc.clone(), noises)
+    return generate_images(dec, rf, tok, start, [T] * B, [am] * B, [unc] * B, [unc.clone()] * B, noises)
 
 
 def dominant_kernel_roofline(rf, rows, iters=48):
@@ -191,8 +195,8 @@ def main():
 
     cfg, dec, rf, tok = build_models(args, device, seed=0)
     g = torch.Generator(device=device).manual_seed(grp.seed(1000))     # independent prompt / noise per replica
-    prompt = torch.randint(0, min(cfg.vocab_size, 100000), (args.prompt_len,), generator=g, device=device)
-    noises = torch.randn(args.tokens + 1, 32, generator=g, device=device)
+    prompt = torch.randint(0, min(cfg.vocab_size, 100000), (args.images, args.prompt_len), generator=g, device=device)
+    noises = torch.randn(args.images, args.tokens + 1, 32, generator=g, device=device)
     rows = 2
 
     for _ in range(args.warmup):
@@ -202,7 +206,7 @@ def main():
 
     if rank == 0:
         dom = dominant_kernel_roofline(rf, rows)
-        total_tokens = args.tokens * args.steps * world
+        total_tokens = args.tokens * args.steps * world * args.images
         res = {
             "metric": "visual tokens/sec (16B-A3B 512^2 gen)", "value": total_tokens / dt, "unit": "visual_tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -210,7 +214,7 @@ def main():
             "config": {"workload": "Ming-UniVision-16B-A3B text->image 512^2 (BASELINE configs[3]): %d-token prompt, "
                                    "2 CFG rows, %d visual tokens/image, RF head w=%d d=%d steps=%d, MingTok pixel decode; "
                                    "random-init bf16 weights" % (args.prompt_len, args.tokens, rf.w, rf.depth, rf.steps),
-                       "images_per_step_per_gpu": 1, "parallelism": "replicas x%d" % world, "tiny": bool(args.tiny)},
+                       "images_per_step_per_gpu": args.images, "parallelism": "replicas x%d" % world, "tiny": bool(args.tiny)},
             "roofline": {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": dom["traffic"], "kernel": dom["kernel"],
                          "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"]},
@@ -220,7 +224,7 @@ def main():
         ada_bytes = rf.t["ada_w"].numel() * 2          # read once per token (all steps in one GEMM)
         tok_bytes = (rf.steps * (rf.weight_bytes_per_step() - ada_bytes) + ada_bytes
                      + dec.weight_bytes_active(6 * rows) + 0.61e9)
-        res["token_level"] = {"algorithmic_GB_per_token": tok_bytes / 1e9,
+        res["token_level"] = {"algorithmic_GB_per_lockstep_token": tok_bytes / 1e9,
                               "achieved_GBs": tok_bytes / (dt / (args.tokens * args.steps)) / 1e9}
         if not args.no_cpu_baseline and not args.tiny:
             try:

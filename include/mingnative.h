@@ -89,9 +89,9 @@ typedef struct mn_skinny_args {
   /* K-segments (MoE down-projection summed over the experts of one token):
    * y = sum_s seg_scale[b*nseg+s] * x[:, s*K:(s+1)*K] @ W[seg_index[b*nseg+s]]^T ; nseg <= 0 means 1. */
   int32_t nseg; const int32_t* seg_index; const float* seg_scale; int64_t seg_w_stride;
-  /* Scratch for 9 <= M <= 16 (batched generation): such launches run as prologue -> split-K bf16-MFMA GEMM on
-   * hi/lo-split activations -> reduce+epilogue, and need mn_skinny_workspace_bytes(M, N, K, epilogue) bytes.
-   * Unused (may be NULL) for M <= 8. */
+  /* Scratch for the matrix-core route (M >= 5, batched generation): such launches run as prologue (activations
+   * split into bf16 hi + lo) -> weight-streaming MFMA kernel over K slices -> reduce + epilogue, and need
+   * mn_skinny_workspace_bytes(M, N, K, epilogue) bytes.  May be NULL for M <= 8 (fp32-FMA kernel is used). */
   void* ws; size_t ws_bytes;
 } mn_skinny_args;
 

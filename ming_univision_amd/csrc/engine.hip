@@ -420,6 +420,8 @@ struct SemWs {
   float *h, *qkv, *q, *attn, *hid, *sem, *p0;
   void* attn_ws;
   size_t attn_ws_bytes;
+  char* sk_ws;
+  size_t sk_ws_bytes;
 };
 
 static size_t sem_carve(const mn_semdec* s, int rows, int64_t t_max, void* ws, size_t cap, SemWs* o) {
@@ -433,6 +435,9 @@ static size_t sem_carve(const mn_semdec* s, int rows, int64_t t_max, void* ws, s
   o->p0 = cv.take<float>((size_t)rows * s->proj_dim * 2);
   o->attn_ws_bytes = mn_attn_decode_workspace_bytes(rows, s->n_heads, 64, t_max);
   o->attn_ws = cv.take<char>(o->attn_ws_bytes);
+  o->sk_ws_bytes = sk_ws_need(rows, {{3 * s->dim, s->dim, 0}, {s->dim, s->dim, 0}, {s->hidden, s->dim, MN_EPI_SWIGLU},
+                                      {s->dim, s->hidden, 0}, {s->proj_dim, s->dim, 0}, {s->proj_dim, s->proj_dim, 0}});
+  o->sk_ws = cv.take<char>(o->sk_ws_bytes);
   return cv.off;
 }
 
@@ -447,7 +452,7 @@ extern "C" int mn_semdec_step(const mn_semdec* s, const float* latent_norm, int 
                               size_t workspace_bytes, void* stream) {
   MN_CHECK_ARG(s && latent_norm && row_seq && row_slot && row_len && kv_cache && workspace, "mn_semdec_step: null pointer");
   MN_CHECK_ARG(M >= 1 && M <= 8 && s->dim == s->n_heads * 64 && s->dim % s->in_dim == 0, "mn_semdec_step: bad shape");
-  t_sk_ws = nullptr; t_sk_ws_bytes = 0;
+
   MN_CHECK_ARG(!embed_out || (s->proj_depth >= 1 && s->proj_depth <= 2), "mn_semdec_step: proj_depth must be 1 or 2");
   SemWs w;
   const size_t need = sem_carve(s, M, t_max, workspace, workspace_bytes, &w);
@@ -455,6 +460,7 @@ extern "C" int mn_semdec_step(const mn_semdec* s, const float* latent_norm, int 
   hipStream_t st = mn_stream(stream);
   const int D = s->dim, nh = s->n_heads;
   const int64_t layer_kv = (int64_t)n_seq * 2 * nh * t_max * 64;
+  t_sk_ws = w.sk_ws; t_sk_ws_bytes = w.sk_ws_bytes;
   hipLaunchKernelGGL(semdec_in_kernel, dim3(mn_cdiv(D, 256), M), dim3(256), 0, st, latent_norm, s->in_dim, s->scale,
                      s->mean, s->in_w, s->in_b, w.h, D);
   for (int l = 0; l < s->depth; ++l) {

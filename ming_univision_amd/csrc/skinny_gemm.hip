@@ -202,15 +202,15 @@ int launch_m(const KArgs& ka, int R, int sw, int nt, dim3 grid, size_t lds, hipS
 }  // namespace
 
 // ===========================================================================================
-// 9 <= M <= 16 rows (batched generation): weights are still read once, but the fp32 FMA path would be
+// 5 <= M <= 16 rows (batched generation): weights are still read once, but the fp32 FMA path would be
 // VALU-bound, so the product runs on the matrix cores:
 //   prologue kernel : x' = prologue(x) in fp32, split into bf16 hi + lo rows  -> Y[2M, K]
-//   mn_gemm_bf16_splitk : partials[z][2M][Ntot] = Y[:, kz] W[:, kz]^T          (bf16 MFMA, fp32 accumulate)
-//   epilogue kernel : out = epilogue( sum_z (hi + lo) + bias )
+//   stream_mfma_kernel : partials[z][M][Ntot] = (Y_hi + Y_lo)[:, kz] W[:, kz]^T   (stream_mfma.hip)
+//   epilogue kernel : out = epilogue( sum_z partials + bias )
 // hi + lo keeps the products fp32-accurate (x' = hi + lo to 2^-17 relative).
 // ===========================================================================================
-extern "C" int mn_gemm_bf16_splitk(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, float* partials,
-                                   int M, int N, int K, int ksplit, void* stream);
+extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream);
+extern "C" int mn_stream_mfma_slices(int K);
 
 namespace {
 
@@ -253,10 +253,10 @@ __global__ __launch_bounds__(256) void medium_epilogue_kernel(const mn_skinny_ar
   const int M = a.M, N = a.N;
   if (i >= (int64_t)M * N) return;
   const int m = (int)(i / N), n = (int)(i % N);
-  const int64_t slab = (int64_t)2 * M * Ntot;
+  const int64_t slab = (int64_t)M * Ntot;
   auto gather = [&](int col) {
     float s = 0.f;
-    for (int z = 0; z < nz; ++z) s += P[z * slab + (int64_t)m * Ntot + col] + P[z * slab + (int64_t)(M + m) * Ntot + col];
+    for (int z = 0; z < nz; ++z) s += P[z * slab + (int64_t)m * Ntot + col];
     return s;
   };
   float y = gather(n);
@@ -287,11 +287,15 @@ int medium_ksplit(int Ntot, int K) {
 
 }  // namespace
 
+// Rows at or above this count take the MFMA route (measured on MI355X: the fp32-FMA kernel wins up to 4 rows,
+// RF w12 37.6 us at M = 4 vs ~36 us for the MFMA route at any M <= 16).
+constexpr int MEDIUM_MIN_M = 5;
+
 extern "C" size_t mn_skinny_workspace_bytes(int M, int N, int K, int epilogue) {
-  if (M <= 8) return 0;
+  if (M < MEDIUM_MIN_M) return 0;
   const int Ntot = epilogue == MN_EPI_SWIGLU ? 2 * N : N;
   const size_t y = ((size_t)2 * M * K * sizeof(bf16_t) + 255) & ~(size_t)255;
-  return y + (size_t)medium_ksplit(Ntot, K) * 2 * M * Ntot * sizeof(float) + 256;
+  return y + (size_t)mn_stream_mfma_slices(K) * M * Ntot * sizeof(float) + 256;
 }
 
 static int skinny_medium(const mn_skinny_args& a, void* stream) {
@@ -309,7 +313,7 @@ static int skinny_medium(const mn_skinny_args& a, void* stream) {
                    a.prologue, a.epilogue, a.ws, a.ws_bytes, need, (const void*)a.x, (long long)a.ldx);
   hipLaunchKernelGGL(medium_prologue_kernel, dim3(a.M), dim3(1024), 0, st, a, Y);
   if (dbg) fprintf(stderr, "[mn]  prologue: %s\n", hipGetErrorString(hipStreamSynchronize(st)));
-  const int nz = mn_gemm_bf16_splitk(Y, a.K, a.w, a.K, P, 2 * a.M, Ntot, a.K, medium_ksplit(Ntot, a.K), stream);
+  const int nz = mn_stream_mfma(Y, a.w, P, a.M, Ntot, a.K, stream);
   if (nz < 0) return nz;
   if (dbg) fprintf(stderr, "[mn]  gemm nz=%d: %s\n", nz, hipGetErrorString(hipStreamSynchronize(st)));
   hipLaunchKernelGGL(medium_epilogue_kernel, dim3((unsigned)mn_cdiv((int64_t)a.M * a.N, 256)), dim3(256), 0, st, a, P, nz, Ntot);
@@ -335,7 +339,8 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   MN_CHECK_ARG(a.epilogue >= 0 && a.epilogue <= MN_EPI_RESID_GATE, "mn_skinny_gemm: bad epilogue %d", a.epilogue);
   ka.nseg = a.nseg > 0 ? a.nseg : 1;
   ka.batch = a.batch > 0 ? a.batch : 1;
-  if (a.M > 8) return skinny_medium(a, stream);
+  if (a.M >= MEDIUM_MIN_M && ka.batch == 1 && ka.nseg == 1 && a.ldw == a.K && a.ws != nullptr) return skinny_medium(a, stream);
+  MN_CHECK_ARG(a.M <= 8, "mn_skinny_gemm: M=%d > 8 needs the workspace route (ws, dense weights, no batch/nseg)", a.M);
   MN_CHECK_ARG(ka.nseg == 1 || a.prologue <= MN_PRO_ADD_SILU, "mn_skinny_gemm: normalising prologue with segments");
   MN_CHECK_ARG(a.prologue != MN_PRO_ADD_SILU || a.pro_a, "mn_skinny_gemm: ADD_SILU needs pro_a");
   MN_CHECK_ARG(a.prologue != MN_PRO_LN_MOD || (a.pro_a && a.pro_b), "mn_skinny_gemm: LN_MOD needs shift/scale");

@@ -31,7 +31,7 @@ def as_bf16_bits(t):
 
 
 def skinny_gemm(x, w, bias=None, *, prologue="none", epilogue="none", out=None, pro_a=None, pro_b=None,
-                ln_g=None, ln_b=None, eps=1e-6, res=None, gate=None, n_out=None):
+                ln_g=None, ln_b=None, eps=1e-6, res=None, gate=None, n_out=None, use_mfma_route=True):
     """out[M,N] = epilogue(prologue(x)[M,K] @ w[N(,2N),K]^T + bias).  x fp32, w/bias/ln bf16."""
     _req(x, torch.float32, "x"); _req(w, torch.bfloat16, "w"); _req(bias, torch.bfloat16, "bias")
     _req(ln_g, torch.bfloat16, "ln_g"); _req(ln_b, torch.bfloat16, "ln_b")
@@ -61,8 +61,8 @@ def skinny_gemm(x, w, bias=None, *, prologue="none", epilogue="none", out=None, 
     if gate is not None:
         a.gate, a.ldgate = ptr(gate), gate.stride(0)
     ws = None
-    if M > 8:
-        nb = lib().mn_skinny_workspace_bytes(M, N, K, a.epilogue)
+    nb = lib().mn_skinny_workspace_bytes(M, N, K, a.epilogue)
+    if nb > 0 and (M > 8 or use_mfma_route):
         ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
         a.ws, a.ws_bytes = ptr(ws), nb
     check(lib().mn_skinny_gemm(C.byref(a), current_stream()), "mn_skinny_gemm")
