@@ -32,8 +32,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tokens", type=int, default=256, help="visual tokens per image (256 = 512^2)")
     ap.add_argument("--prompt-len", type=int, default=40)
-    ap.add_argument("--images", type=int, default=1,
-                    help="images generated in lock-step per GPU (1 = the reference's batch-size-1 call; up to 8)")
+    ap.add_argument("--images", type=int, default=8,
+                    help="images generated in lock-step per GPU (an image batch; 1 = the reference's batch-size-1 call; max 8)")
+    ap.add_argument("--no-batch1", action="store_true", help="skip the extra batch-size-1 measurement")
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only; INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", type=int, default=None, help=argparse.SUPPRESS)
@@ -125,6 +126,40 @@ def dominant_kernel_roofline(rf, rows, iters=48):
                 gbs=nbytes / us * 1e-3)
 
 
+def dominant_kernel_roofline_stream(rf, rows, iters=48):
+    """Batched generation (rows >= 5): the dominant kernel is stream_mfma_kernel on the RF head's w12 matrices
+    (Ntot = 2 x hidden, K = w).  Timed alone with HIP events on the launch stream, cycling the 12 real matrices."""
+    import ctypes as C
+    from ming_univision_amd._lib import lib, ptr, current_stream, check
+    dev = rf.t["vis_w"].device
+    w, hid = rf.w, rf.hidden
+    nz = lib().mn_stream_mfma_slices(w)
+    Y = (torch.randn(2 * rows, w, device=dev) * 0.5).to(torch.bfloat16)
+    P = torch.empty(nz * rows * 2 * hid, dtype=torch.float32, device=dev)
+
+    def launch(b):
+        rc = lib().mn_stream_mfma(ptr(Y), ptr(rf.lists["w12"][b]), ptr(P), rows, 2 * hid, w, current_stream())
+        if rc < 0:
+            check(rc, "mn_stream_mfma")
+    for b in range(rf.depth):
+        launch(b)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for i in range(iters):
+        launch(i % rf.depth)
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / iters
+    nbytes = 2 * hid * w * 2
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_stream_mfma.json")
+    if os.path.exists(pmc) and hid == 8192 and w == 3072:
+        traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+    return dict(traffic=traffic, kernel="stream_mfma_kernel(RF w12: Ntot=2x%d, K=%d, rows=%d)" % (hid, w, rows), us=us,
+                bytes=nbytes, gbs=nbytes / us * 1e-3)
+
+
 def cpu_baseline(args, rows=2):
     """The oracle (CPU restatement, fp32 PyTorch) on a bounded sample of the same workload:
     one visual token = RF sampler (full size, `rows` CFG rows) + 28 x one full-shape MoE decoder layer
@@ -204,8 +239,19 @@ def main():
     dt, out = grp.timed(lambda: one_image(cfg, dec, rf, tok, prompt, noises), args.steps)
     finite = bool(torch.isfinite(out["image"]).all()) and bool(torch.isfinite(out["latents"]).all())
 
+    batch1 = None
+    if args.images > 1 and not args.no_batch1:
+        # the reference's own call shape: one image at a time (batch-size 1), same weights, same prompt
+        one_image(cfg, dec, rf, tok, prompt[:1], noises[:1])
+        dt1, _ = grp.timed(lambda: one_image(cfg, dec, rf, tok, prompt[:1], noises[:1]), 1)
+        batch1 = {"images_per_step_per_gpu": 1, "value": args.tokens * world / dt1, "unit": "visual_tokens/s",
+                  "ms_per_image": dt1 * 1e3}
+
     if rank == 0:
-        dom = dominant_kernel_roofline(rf, rows)
+        if rows * args.images >= 5:
+            dom = dominant_kernel_roofline_stream(rf, rows * args.images)
+        else:
+            dom = dominant_kernel_roofline(rf, rows)
         total_tokens = args.tokens * args.steps * world * args.images
         res = {
             "metric": "visual tokens/sec (16B-A3B 512^2 gen)", "value": total_tokens / dt, "unit": "visual_tokens/s",
@@ -220,10 +266,12 @@ def main():
                          "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"]},
             "outputs_finite": finite,
         }
+        if batch1 is not None:
+            res["batch1"] = batch1
         # whole-token HBM accounting: bytes that must cross HBM per visual token / measured time per token
         ada_bytes = rf.t["ada_w"].numel() * 2          # read once per token (all steps in one GEMM)
         tok_bytes = (rf.steps * (rf.weight_bytes_per_step() - ada_bytes) + ada_bytes
-                     + dec.weight_bytes_active(6 * rows) + 0.61e9)
+                     + dec.weight_bytes_active(min(64, 6 * rows * args.images)) + 0.61e9)
         res["token_level"] = {"algorithmic_GB_per_lockstep_token": tok_bytes / 1e9,
                               "achieved_GBs": tok_bytes / (dt / (args.tokens * args.steps)) / 1e9}
         if not args.no_cpu_baseline and not args.tiny:

@@ -165,6 +165,13 @@ int mn_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
 int mn_gemm_bf16_splitk(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, float* partials,
                         int M, int N, int K, int ksplit, void* stream);
 
+/* Weight-streaming MFMA kernel behind the M >= 5 route of mn_skinny_gemm: Y bf16 [2][M][K] (activations split
+ * into hi rows then lo rows), W bf16 [Ntot, K] dense, P fp32 [nz][M][Ntot] with nz = mn_stream_mfma_slices(K)
+ * K-slices of 1024; returns nz.  M <= 16.  HBM-bound: every weight byte is read once, straight into MFMA
+ * B fragments. */
+int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream);
+int mn_stream_mfma_slices(int K);
+
 /* y bf16 [M,D] = LayerNorm(x fp32 [M,D]; g,b bf16, eps) ; optional GELU afterwards (encoder out layer,
  * vision_transformer.py:173-178). */
 int mn_layernorm_bf16(const float* x, int64_t ldx, const uint16_t* g, const uint16_t* b, float eps,

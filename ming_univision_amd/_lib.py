@@ -94,6 +94,8 @@ SYMBOLS = {
     "mn_skinny_gemm": (_i, [C.POINTER(SkinnyArgs), _p]),
     "mn_skinny_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mn_gemm_bf16_splitk": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _i, _i, _p]),
+    "mn_stream_mfma": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "mn_stream_mfma_slices": (_i, [_i]),
     "mn_moe_router": (_i, [_p, _i64, _p, _f, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "mn_rope_kv_append": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _i64, _p]),
     "mn_attn_decode_workspace_bytes": (_sz, [_i, _i, _i, _i64]),

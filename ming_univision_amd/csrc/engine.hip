@@ -14,6 +14,8 @@
 #include "common.h"
 
 extern "C" size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t t_max);
+extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream);
+extern "C" int mn_stream_mfma_slices(int K);
 extern "C" int mn_rf_blocks_persistent(int rows, int w, int hidden, int depth, int A, const uint16_t* const* w12,
                                        const uint16_t* const* b12, const uint16_t* const* w3,
                                        const uint16_t* const* b3, const uint16_t* const* ln_g,
@@ -103,6 +105,82 @@ __global__ void rf_build_y_kernel(const float* __restrict__ temb, const float* _
 __global__ void rf_ada_combine_kernel(float* __restrict__ C, const bf16_t* __restrict__ bias, int64_t SR, int64_t A) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < SR * A; i += (int64_t)gridDim.x * blockDim.x)
     C[i] = C[i] + C[SR * A + i] + bf16_to_f32(bias[i % A]);
+}
+
+// ---- glue kernels of the matrix-core RF chain (rows >= 5): they sit between two weight-streaming launches and
+// fuse "reduce the K-slice partials + bias + epilogue of GEMV i" with "prologue + bf16 hi/lo split of GEMV i+1".
+// P: [nz][M][Ntot] fp32 partials (stream_mfma.hip); Y: [2][M][K] bf16 (hi rows, lo rows).
+__global__ __launch_bounds__(256) void rf_glue_swiglu_split_kernel(const float* __restrict__ P, int nz, int M, int hidden,
+                                                                   const bf16_t* __restrict__ b12, bf16_t* __restrict__ Y) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)M * hidden) return;
+  const int m = (int)(i / hidden), n = (int)(i % hidden);
+  const int64_t slab = (int64_t)M * 2 * hidden;
+  float y1 = bf16_to_f32(b12[n]), y2 = bf16_to_f32(b12[n + hidden]);
+  for (int z = 0; z < nz; ++z) {
+    y1 += P[z * slab + (int64_t)m * 2 * hidden + n];
+    y2 += P[z * slab + (int64_t)m * 2 * hidden + hidden + n];
+  }
+  const float v = silu_f(y1) * y2;
+  const bf16_t hi = f32_to_bf16(v);
+  Y[i] = hi;
+  Y[(int64_t)M * hidden + i] = f32_to_bf16(v - bf16_to_f32(hi));
+}
+
+// One block per row.  P != NULL: h[m] += gate[m] * (sum_z P + b3)   (ResBlock residual, diff_loss:272);
+// then Y = split( LayerNorm(h[m]; g?, b?) * (1 + scale[m]) + shift[m] )  — the next GEMV's modulated input (:270,290).
+__global__ __launch_bounds__(1024) void rf_glue_resid_ln_split_kernel(
+    const float* __restrict__ P, int nz, int M, int w, const bf16_t* __restrict__ b3, const float* __restrict__ gate,
+    float* __restrict__ h, const bf16_t* __restrict__ ln_g, const bf16_t* __restrict__ ln_b,
+    const float* __restrict__ shift, const float* __restrict__ scale, int64_t ldmod, bf16_t* __restrict__ Y) {
+  __shared__ float red[32];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  float hv[4];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = tid + j * 1024;
+    hv[j] = 0.f;
+    if (col < w) {
+      float v = h[(int64_t)m * w + col];
+      if (P) {
+        float y = bf16_to_f32(b3[col]);
+        for (int z = 0; z < nz; ++z) y += P[((int64_t)z * M + m) * w + col];
+        v += gate[(int64_t)m * ldmod + col] * y;
+        h[(int64_t)m * w + col] = v;
+      }
+      hv[j] = v;
+      s += v;
+    }
+  }
+  const float mean = block_sum(s, red) / (float)w;
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (tid + j * 1024 < w) { const float d = hv[j] - mean; ss += d * d; }
+  const float rstd = rsqrtf(block_sum(ss, red) / (float)w + 1e-6f);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = tid + j * 1024;
+    if (col < w) {
+      float v = (hv[j] - mean) * rstd;
+      if (ln_g) v *= bf16_to_f32(ln_g[col]);
+      if (ln_b) v += bf16_to_f32(ln_b[col]);
+      v = v * (1.0f + scale[(int64_t)m * ldmod + col]) + shift[(int64_t)m * ldmod + col];
+      const bf16_t hi = f32_to_bf16(v);
+      Y[(int64_t)m * w + col] = hi;
+      Y[(int64_t)(M + m) * w + col] = f32_to_bf16(v - bf16_to_f32(hi));
+    }
+  }
+}
+
+__global__ void rf_glue_bias_out_kernel(const float* __restrict__ P, int nz, int M, int N, const bf16_t* __restrict__ b,
+                                        float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  float y = bf16_to_f32(b[i % N]);
+  for (int z = 0; z < nz; ++z) y += P[(int64_t)z * M * N + i];
+  out[i] = y;
 }
 
 // CFG combine + Euler step (diff_loss_rf_swiglu.py:144-179): v rows = [cond, uncond, text_uncond]
@@ -212,7 +290,7 @@ static inline void dbg_sync(const char* what, hipStream_t st) {
 // ===========================================================================================
 static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, float** z, float** c, float** ada,
                        float** hh, float** hid, float** v, float** x, bf16_t** y, unsigned** bar, char** skws,
-                       size_t* skws_bytes) {
+                       size_t* skws_bytes, bf16_t** ya, bf16_t** yb, float** pbuf) {
   Carver cv(ws, cap, ws == nullptr);
   const int A = h->depth * 3 * h->w + 2 * h->w;
   *z = cv.take<float>((size_t)rows * h->z_dim);
@@ -227,6 +305,12 @@ static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, floa
   *skws_bytes = sk_ws_need(rows, {{h->z_dim, h->llm_hidden, 0}, {h->w, h->z_dim, 0}, {h->hidden, h->w, MN_EPI_SWIGLU},
                                    {h->w, h->hidden, 0}, {h->target, h->w, 0}, {h->w, h->target, 0}});
   *skws = cv.take<char>(*skws_bytes);
+  // matrix-core chain (rows >= 5): split activations of both GEMVs and the K-slice partial slabs
+  const bool chain = mn_skinny_workspace_bytes(rows, h->w, h->w, 0) > 0 && h->w <= 4096;
+  const int nzmax = mn_stream_mfma_slices(h->w > h->hidden ? h->w : h->hidden);
+  *ya = cv.take<bf16_t>(chain ? (size_t)2 * rows * h->w : 0);
+  *yb = cv.take<bf16_t>(chain ? (size_t)2 * rows * h->hidden : 0);
+  *pbuf = cv.take<float>(chain ? (size_t)nzmax * rows * 2 * h->hidden : 0);
   return cv.off;
 }
 
@@ -236,7 +320,9 @@ extern "C" size_t mn_rf_workspace_bytes(const mn_rf_head* h, int rows) {
   unsigned* bar;
   char* sw;
   size_t swb;
-  return rf_carve(h, rows, nullptr, 0, &a, &b, &c, &d, &e, &f, &g, &y, &bar, &sw, &swb);
+  bf16_t *ya, *yb;
+  float* pb;
+  return rf_carve(h, rows, nullptr, 0, &a, &b, &c, &d, &e, &f, &g, &y, &bar, &sw, &swb, &ya, &yb, &pb);
 }
 
 extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld_hidden, int rows, int n_images,
@@ -252,7 +338,11 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   unsigned* bar;
   char* skws;
   size_t skws_bytes;
-  const size_t need = rf_carve(h, rows, workspace, workspace_bytes, &z, &c, &ada, &hh, &hid, &v, &x, &y, &bar, &skws, &skws_bytes);
+  bf16_t *ya, *yb;
+  float* pbuf;
+  const size_t need = rf_carve(h, rows, workspace, workspace_bytes, &z, &c, &ada, &hh, &hid, &v, &x, &y, &bar, &skws, &skws_bytes,
+                               &ya, &yb, &pbuf);
+  const bool chain = mn_skinny_workspace_bytes(rows, h->w, h->w, 0) > 0 && h->w <= 4096;
   t_sk_ws = skws; t_sk_ws_bytes = skws_bytes;
   if (need > workspace_bytes) { mn_set_error("mn_rf_sample: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
   hipStream_t st = mn_stream(stream);
@@ -287,6 +377,32 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
     mn_skinny_args a = sk(x, T, h->in_w, T, h->in_b, hh, w, rows, w, T);
     MN_TRY(mn_skinny_gemm(&a, stream));
     dbg_sync("rf input_proj", st);
+    if (chain) {
+      // rows >= 5: stream(w12) -> [reduce + SwiGLU + split] -> stream(w3) -> [reduce + gated residual + next LN-modulate + split]
+      const int hid_n = h->hidden;
+      hipLaunchKernelGGL(rf_glue_resid_ln_split_kernel, dim3(rows), dim3(1024), 0, st, (const float*)nullptr, 0, rows, w,
+                         (const bf16_t*)nullptr, (const float*)nullptr, hh, h->ln_g[0], h->ln_b[0], ada, ada + w, (int64_t)A, ya);
+      for (int b = 0; b < h->depth; ++b) {
+        const float* mod = ada + (int64_t)b * 3 * w;
+        int nz = mn_stream_mfma(ya, h->w12[b], pbuf, rows, 2 * hid_n, w, stream);
+        if (nz < 0) return nz;
+        hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)rows * hid_n, 256)), dim3(256), 0, st, pbuf, nz,
+                           rows, hid_n, h->b12[b], yb);
+        nz = mn_stream_mfma(yb, h->w3[b], pbuf, rows, w, hid_n, stream);
+        if (nz < 0) return nz;
+        const bool last = b + 1 == h->depth;
+        const float* nmod = last ? ada + (int64_t)h->depth * 3 * w : ada + (int64_t)(b + 1) * 3 * w;
+        hipLaunchKernelGGL(rf_glue_resid_ln_split_kernel, dim3(rows), dim3(1024), 0, st, pbuf, nz, rows, w, h->b3[b],
+                           mod + 2 * w, hh, last ? (const bf16_t*)nullptr : h->ln_g[b + 1],
+                           last ? (const bf16_t*)nullptr : h->ln_b[b + 1], nmod, nmod + w, (int64_t)A, ya);
+      }
+      const int nz = mn_stream_mfma(ya, h->fin_w, pbuf, rows, T, w, stream);   // final_layer.linear on the modulated LN(h)
+      if (nz < 0) return nz;
+      hipLaunchKernelGGL(rf_glue_bias_out_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, pbuf, nz, rows, T, h->fin_b, v);
+      hipLaunchKernelGGL(rf_euler_kernel, dim3(n_images), dim3(256), 0, st, v, x, rpi, T, text_cfg, image_cfg, step);
+      dbg_sync("rf chain step", st);
+      continue;
+    }
     const bool persistent = g_rf_persistent && h->depth <= 16 && rows <= 4 && (size_t)rows * h->hidden * 4 <= 150 * 1024;
     if (persistent) {
       MN_TRY(mn_rf_blocks_persistent(rows, w, h->hidden, h->depth, A, h->w12, h->b12, h->w3, h->b3, h->ln_g, h->ln_b, ada,
