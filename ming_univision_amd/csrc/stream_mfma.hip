@@ -122,7 +122,87 @@ __global__ __launch_bounds__(SNT) void stream_mfma_kernel(const bf16_t* __restri
   }
 }
 
+
+// ---- variant 2: weights staged through a wave-private LDS tile with fully coalesced global loads ----
+// The direct B-fragment load above touches 16 rows x 64 B per instruction (two instructions per 128-B line);
+// here a wave loads its 16-row x 256-k chunk as 8 instructions of 8 rows x 128 B (whole lines, like the
+// fp32 skinny kernel), parks it in its own 8 KiB of LDS (XOR-swizzled 16-byte slots, wave-private so no
+// workgroup barrier is involved) and reads MFMA fragments back with ds_read_b128.  One chunk (8 KiB per
+// wave) is in flight in registers while the previous one is multiplied.
+constexpr int WCH = 256;                       // k per chunk
+__device__ __forceinline__ int wslot(int row, int slot) { return row * (WCH * 2) + (((slot) ^ (row & 15)) << 4); }
+
+__global__ __launch_bounds__(SNT) void stream_mfma_lds_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ W,
+                                                              float* __restrict__ P, int M, int Ntot, int K) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t xs_raw[];      // [2][16][SROW] x image, then 8 x 8 KiB weight tiles
+  bf16_t (*xs)[16][SROW] = reinterpret_cast<bf16_t (*)[16][SROW]>(xs_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* wbuf = reinterpret_cast<char*>(xs_raw) + (size_t)2 * 16 * SROW * sizeof(bf16_t) + (size_t)wave * 16 * WCH * 2;
+  const int z = blockIdx.y;
+  const int k0 = z * SKS, klen = min(SKS, K - k0);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int r8 = lane >> 3, c8 = lane & 7;
+  const int ntiles = (Ntot + 15) >> 4;
+  const int nch = (klen + WCH - 1) / WCH;
+  const int twaves = gridDim.x * (SNT / 64);
+  u32x4 ring[8];
+  // instruction i: rows (i & 1) * 8 + r8, 16-byte slot (i >> 1) * 8 + c8 of the chunk
+  auto issue = [&](int t, int ch) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = (i & 1) * 8 + r8;
+      const int n = min(t * 16 + row, Ntot - 1);
+      const int k = min(ch * WCH + ((i >> 1) * 8 + c8) * 8, klen - 8);
+      ring[i] = *reinterpret_cast<const u32x4*>(W + (int64_t)n * K + k0 + k);
+    }
+  };
+  int t = blockIdx.x * (SNT / 64) + wave;
+  if (t < ntiles) issue(t, 0);
+  for (int i = tid; i < 2 * 16 * (SKS / 8); i += SNT) {
+    const int slot = i % (SKS / 8), m = (i / (SKS / 8)) % 16, h = i / (16 * (SKS / 8));
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (m < M && slot * 8 < klen) v = *reinterpret_cast<const u32x4*>(Y + ((int64_t)h * M + m) * K + k0 + slot * 8);
+    *reinterpret_cast<u32x4*>(&xs[h][m][slot * 8]) = v;
+  }
+  const bf16_t* xh = &xs[0][fr][fq * 8];
+  const bf16_t* xl = &xs[1][fr][fq * 8];
+  __syncthreads();
+  for (; t < ntiles; t += twaves) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < nch; ++ch) {
+      // park the landed chunk in LDS ...
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<u32x4*>(wbuf + wslot((i & 1) * 8 + r8, (i >> 1) * 8 + c8)) = ring[i];
+      // ... request the next one (next chunk of this tile, or the first chunk of the wave's next tile) ...
+      if (ch + 1 < nch) issue(t, ch + 1);
+      else if (t + twaves < ntiles) issue(t + twaves, 0);
+      // ... and multiply this one: 8 MFMA steps of 32 k (columns >= klen of x are zero in LDS)
+#pragma unroll
+      for (int sstep = 0; sstep < 8; ++sstep) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wbuf + wslot(fr, sstep * 4 + fq));
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xh + ch * WCH + sstep * 32);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(xl + ch * WCH + sstep * 32);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w, acc, 0, 0, 0);
+      }
+    }
+    const int nn = t * 16 + fr;
+    if (nn < Ntot) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = fq * 4 + r;
+        if (m < M) P[((int64_t)z * M + m) * Ntot + nn] = acc[r];
+      }
+    }
+  }
+}
+
 }  // namespace
+
+// Tuning knobs for in-process A/B (not part of the stable ABI): mode 0 = direct fragment loads, 1 = LDS-staged.
+static int g_mode = -1, g_nt = -1, g_cap = -1;
+extern "C" void mn_stream_tune(int mode, int nt, int cap) { g_mode = mode; g_nt = nt; g_cap = cap; }
 
 // Internal: returns the number of K slices written (partials [nz][M][Ntot]).
 extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream) {
@@ -132,9 +212,8 @@ extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, in
   const int cus = mn_num_cus();
   // 2 workgroups (66 KiB LDS each) per CU; every wave should get >= 1 tile
   int gx = (int)mn_cdiv(ntiles, SNT / 64);
-  static int cap_x = -1, use_nt = -1;
-  if (cap_x < 0) { const char* e = getenv("MN_STREAM_CAP"); cap_x = e ? atoi(e) : 4; }
-  if (use_nt < 0) { const char* e = getenv("MN_STREAM_NT"); use_nt = e ? atoi(e) : 0; }
+  const int cap_x = g_cap > 0 ? g_cap : 4;
+  const int use_nt = g_nt >= 0 ? g_nt : 0;
   const int cap = (int)mn_cdiv((int64_t)cap_x * cus, nz * 2);   // cap_x / 2 workgroups per CU
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
@@ -143,6 +222,22 @@ extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, in
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     opted = true;
+  }
+  const int mode = g_mode >= 0 ? g_mode : 1;   // default: LDS-staged coalesced loads (12.9 vs 14.1 us on RF w3, equal on w12)
+  if (mode == 1) {   // LDS-staged, fully coalesced weight loads; one workgroup per CU
+    static bool opted2 = false;
+    if (!opted2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      opted2 = true;
+    }
+    int gx2 = (int)mn_cdiv(ntiles, SNT / 64);
+    const int cap2 = (int)mn_cdiv(cus, nz);
+    if (gx2 > cap2) gx2 = cap2;
+    if (gx2 < 1) gx2 = 1;
+    const size_t lds2 = (size_t)2 * 16 * SROW * sizeof(bf16_t) + (size_t)(SNT / 64) * 16 * WCH * 2;
+    hipLaunchKernelGGL(stream_mfma_lds_kernel, dim3(gx2, nz), dim3(SNT), lds2, mn_stream(stream), Y, W, P, M, Ntot, K);
+    MN_CHECK_LAUNCH("mn_stream_mfma");
+    return nz;
   }
   const size_t lds = (size_t)2 * 16 * SROW * sizeof(bf16_t);
   if (use_nt)
