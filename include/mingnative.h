@@ -165,6 +165,39 @@ int mn_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
 int mn_gemm_bf16_splitk(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, float* partials,
                         int M, int N, int K, int ksplit, void* stream);
 
+/* ---- many-token (prefill) operators of the Bailing-MoE decoder, bf16 MFMA path -------------------------------
+ * Replace, for q_len > 16: BailingMoeRMSNorm (modeling_bailing_moe.py:131-136), apply_rotary_pos_emb +
+ * DynamicCache.update (:428-461, :789), the flash-attn varlen prefill (:946-1007), BailingMoeGate (:505-520) and
+ * moe_infer's argsort / per-expert loop / un-permute / weighted sum (:608-639). */
+int mn_rmsnorm_bf16(const float* x, int64_t ldx, const uint16_t* g, float eps, uint16_t* y, int64_t ldy, int M, int D,
+                    void* stream);
+/* qkv fp32 [T, (n_q + 2 n_kv) hd]; token t gets rotary position pos[t] and cache slot slot0 + t of ONE sequence:
+ * kv_seq fp32 [2][n_kv][t_max][hd].  q_out bf16 [T, n_q, hd] (rotated, scaled). */
+int mn_rope_kv_prefill(const float* qkv, int64_t ldqkv, int T, int n_q, int n_kv, int hd, const float* cos_tab,
+                       const float* sin_tab, const int32_t* pos, int slot0, float q_scale, uint16_t* q_out,
+                       float* kv_seq, int64_t t_max, void* stream);
+/* Flash attention, head_dim 128, GQA: query i of the T new tokens attends keys j <= past + i with
+ * key_mask[j] != 0 (NULL = all).  Keys/values come from the fp32 arena of the sequence.  out bf16 [T, n_q*128]. */
+int mn_attn_prefill_gqa_hd128(const uint16_t* q, const float* kv_seq, int64_t t_max, int n_q, int n_kv, int past, int T,
+                              const uint8_t* key_mask, uint16_t* out, void* stream);
+/* top-k routing from precomputed gate logits [T, E] (image-gate logits chosen where image_mask is set). */
+int mn_moe_topk_logits(const float* logits_text, const float* logits_image, const uint8_t* image_mask, int T, int E,
+                       int top_k, int norm_topk_prob, int n_shared_slots, int32_t* topk_idx, float* topk_w, void* stream);
+/* Expert-sort of the (token, pick) pairs: counts[g], offsets[g+1], perm[sorted pos] = token,
+ * slot_of[token * n_slot + pick] = sorted pos.  T * n_slot <= 65536, n_groups <= 128.  All device arrays. */
+int mn_moe_sort(const int32_t* topk_idx, int T, int n_slot, int n_groups, int32_t* counts, int32_t* offsets,
+                int32_t* perm, int32_t* slot_of, void* stream);
+int mn_gather_rows_bf16(const uint16_t* x, int64_t ldx, const int32_t* perm, uint16_t* y, int64_t ldy, int n_rows, int D,
+                        void* stream);
+/* h[t] += sum_j w[t, j] * y[slot_of[t, j]]  (fp32) */
+int mn_moe_combine(const float* y, int64_t ldy, const int32_t* slot_of, const float* w, int n_slot, float* h, int64_t ldh,
+                   int T, int D, void* stream);
+/* Grouped GEMM over experts: rows [off[g], off[g] + cnt[g]) of A / C use W + g * w_gstride.  off / cnt are device
+ * arrays (from mn_moe_sort); m_max >= every cnt[g].  epilogue: MN_GEMM_BF16 or MN_GEMM_F32, no bias. */
+int mn_gemm_bf16_grouped(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int64_t w_gstride,
+                         const int32_t* off, const int32_t* cnt, int n_groups, void* C, int64_t ldc, int m_max, int N,
+                         int K, int epilogue, void* stream);
+
 /* Weight-streaming MFMA kernel behind the M >= 5 route of mn_skinny_gemm: Y bf16 [2][M][K] (activations split
  * into hi rows then lo rows), W bf16 [Ntot, K] dense, P fp32 [nz][M][Ntot] with nz = mn_stream_mfma_slices(K)
  * K-slices of 1024; returns nz.  M <= 16.  HBM-bound: every weight byte is read once, straight into MFMA

@@ -187,6 +187,77 @@ class BailingMoeDecoder:
             outs.append(self.step(embeds[c0:c0 + m].contiguous(), seqs, slot, slot, slot + 1, None, im))
         return torch.cat(outs, 0)
 
+    def prefill_mfma(self, embeds, seq=0, past=0, image_mask=None, positions=None, key_mask=None):
+        """Causal prefill of ONE sequence for long prompts on the bf16 MFMA path: per layer
+        RMSNorm -> QKV GEMM -> RoPE + KV append -> GQA flash attention (hd 128) -> dense GEMM (+residual) ->
+        RMSNorm -> gate GEMM -> top-k -> expert sort -> grouped gate/up GEMM -> SwiGLU -> grouped down GEMM ->
+        weighted combine (+residual).  fp32 residual stream, bf16 GEMM operands (like the reference's autocast
+        path); the KV arena stays fp32.  embeds fp32 [T,H].  Returns the final-norm hidden state of the LAST
+        token [1,H] fp32 (what the next-token logits need)."""
+        import math
+        cfg, L_ = self.cfg, lib()
+        T, H = embeds.shape
+        assert past + T <= self.t_max and cfg.head_dim == 128
+        dev = self.device
+        nq, nkv, hd, I = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.moe_intermediate_size
+        E, k, S = cfg.num_experts, cfg.num_experts_per_tok, self.n_shared
+        n_slot, G = k + S, E + S
+        st = current_stream()
+        h = embeds.to(torch.float32).contiguous().clone()
+        pos = (torch.arange(past, past + T, dtype=torch.int32, device=dev) if positions is None
+               else positions.to(dev, torch.int32).contiguous())
+        im = None if image_mask is None else image_mask.to(dev, torch.uint8).contiguous()
+        km = None if key_mask is None else key_mask.to(dev, torch.uint8).contiguous()
+        bf = torch.bfloat16
+        xn = torch.empty(T, H, dtype=bf, device=dev)
+        qkv = torch.empty(T, (nq + 2 * nkv) * hd, dtype=torch.float32, device=dev)
+        qb = torch.empty(T, nq * hd, dtype=bf, device=dev)
+        att = torch.empty(T, nq * hd, dtype=bf, device=dev)
+        lg = torch.empty(2, T, E, dtype=torch.float32, device=dev)
+        ti = torch.empty(T, n_slot, dtype=torch.int32, device=dev)
+        tw = torch.empty(T, n_slot, dtype=torch.float32, device=dev)
+        cnt = torch.empty(G, dtype=torch.int32, device=dev)
+        off = torch.empty(G + 1, dtype=torch.int32, device=dev)
+        perm = torch.empty(T * n_slot, dtype=torch.int32, device=dev)
+        slot_of = torch.empty(T * n_slot, dtype=torch.int32, device=dev)
+        xg = torch.empty(T * n_slot, H, dtype=bf, device=dev)
+        gu = torch.empty(T * n_slot, 2 * I, dtype=bf, device=dev)
+        hm = torch.empty(T * n_slot, I, dtype=bf, device=dev)
+        yg = torch.empty(T * n_slot, H, dtype=torch.float32, device=dev)
+        for li, ly in enumerate(self.layers):
+            kv_seq = self.kv_cache[li, seq]
+            check(L_.mn_rmsnorm_bf16(ptr(h), H, ptr(ly["ln1"]), cfg.rms_norm_eps, ptr(xn), H, T, H, st), "mn_rmsnorm_bf16")
+            ops.gemm_bf16(xn, ly["wqkv"], None, "f32", out=qkv)
+            check(L_.mn_rope_kv_prefill(ptr(qkv), qkv.stride(0), T, nq, nkv, hd, ptr(self.cos), ptr(self.sin), ptr(pos), past,
+                                        1.0 / math.sqrt(hd), ptr(qb), ptr(kv_seq), self.t_max, st), "mn_rope_kv_prefill")
+            check(L_.mn_attn_prefill_gqa_hd128(ptr(qb), ptr(kv_seq), self.t_max, nq, nkv, past, T, ptr(km), ptr(att), st),
+                  "mn_attn_prefill_gqa_hd128")
+            ops.gemm_bf16(att, ly["wdense"], None, "f32_resid", out=h)
+            check(L_.mn_rmsnorm_bf16(ptr(h), H, ptr(ly["ln2"]), cfg.rms_norm_eps, ptr(xn), H, T, H, st), "mn_rmsnorm_bf16")
+            ops.gemm_bf16(xn, ly["gate"], None, "f32", out=lg[0])
+            use_img = im is not None and ly.get("image_gate") is not None
+            if use_img:
+                ops.gemm_bf16(xn, ly["image_gate"], None, "f32", out=lg[1])
+            check(L_.mn_moe_topk_logits(ptr(lg[0]), ptr(lg[1]) if use_img else None, ptr(im) if use_img else None, T, E, k,
+                                        int(cfg.norm_topk_prob), S, ptr(ti), ptr(tw), st), "mn_moe_topk_logits")
+            check(L_.mn_moe_sort(ptr(ti), T, n_slot, G, ptr(cnt), ptr(off), ptr(perm), ptr(slot_of), st), "mn_moe_sort")
+            check(L_.mn_gather_rows_bf16(ptr(xn), H, ptr(perm), ptr(xg), H, T * n_slot, H, st), "mn_gather_rows_bf16")
+            check(L_.mn_gemm_bf16_grouped(ptr(xg), H, ptr(ly["w_gate_up"]), H, 2 * I * H, ptr(off), ptr(cnt), G, ptr(gu), 2 * I,
+                                          T, 2 * I, H, ops.GEMM_EPI["bf16"], st), "mn_gemm_bf16_grouped(gate_up)")
+            check(L_.mn_swiglu_bf16(ptr(gu), 2 * I, ptr(hm), I, T * n_slot, I, st), "mn_swiglu_bf16")
+            check(L_.mn_gemm_bf16_grouped(ptr(hm), I, ptr(ly["w_down"]), I, H * I, ptr(off), ptr(cnt), G, ptr(yg), H, T, H, I,
+                                          ops.GEMM_EPI["f32"], st), "mn_gemm_bf16_grouped(down)")
+            check(L_.mn_moe_combine(ptr(yg), H, ptr(slot_of), ptr(tw), n_slot, ptr(h), H, T, H, st), "mn_moe_combine")
+        return self._final_norm_rows(h[T - 1:T].contiguous())
+
+    def _final_norm_rows(self, x):
+        """model.norm on the prefill path (modeling_bailing_moe.py:1521): bf16 output like the rest of that path."""
+        H = x.shape[1]
+        y16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        check(lib().mn_rmsnorm_bf16(ptr(x), H, ptr(self.final_norm), self.cfg.rms_norm_eps, ptr(y16), H, x.shape[0], H,
+                                    current_stream()), "mn_rmsnorm_bf16")
+        return ops.bf16_to_f32(y16)
+
     def logits(self, hidden):
         """lm_head -> fp32 logits (compute_logit, :1604-1620, norm_head=False)."""
         outs = [ops.skinny_gemm(hidden[i:i + 8].contiguous(), self.lm_head) for i in range(0, hidden.shape[0], 8)]

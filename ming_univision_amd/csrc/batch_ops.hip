@@ -22,18 +22,36 @@ constexpr int BN = 128, BK = 64;  // BM is a template parameter (64 for skinny-M
 // LDS tile: [128 rows][64 k] bf16 = 128 B per row = 8 slots of 16 B; slot index XOR (row & 7).
 __device__ __forceinline__ int tile_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
 
-template <int EPI, int BM>
+// Grouped form (MoE experts): blockIdx.y = group g works on rows [g_off[g], g_off[g] + g_cnt[g]) of A / C with
+// the weights W + g * w_gstride; M is then the upper bound used to size the grid (tiles beyond g_cnt exit).
+struct GemmGroups {
+  const int32_t* off;
+  const int32_t* cnt;
+  int64_t w_gstride;
+};
+
+template <int EPI, int BM, bool GROUPED = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                         const bf16_t* __restrict__ W, int64_t ldw,
                                                         const bf16_t* __restrict__ bias, void* __restrict__ Cv0,
-                                                        int64_t ldc, int M, int N, int K, int Kc, int64_t c_zstride) {
+                                                        int64_t ldc, int M, int N, int K, int Kc, int64_t c_zstride,
+                                                        GemmGroups grp = GemmGroups{nullptr, nullptr, 0}) {
   constexpr int MI = BM / 32;   // 16-row MFMA tiles per wave along M (wave grid is 2 x 2)
   constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
   __shared__ __attribute__((aligned(16))) char lds_raw[2][A_BYTES + W_BYTES];  // [buf][A | W]
   // split-K: blockIdx.y owns k in [kbeg, kend) and writes its own fp32 partial slab (F32 epilogue only)
-  const int kbeg = blockIdx.y * Kc, kend = min(K, kbeg + Kc);
-  void* Cv = (EPI == MN_GEMM_F32 || EPI == MN_GEMM_F32_RESID)
+  const int kbeg = GROUPED ? 0 : blockIdx.y * Kc, kend = GROUPED ? K : min(K, kbeg + Kc);
+  void* Cv = (!GROUPED && (EPI == MN_GEMM_F32 || EPI == MN_GEMM_F32_RESID))
                  ? (void*)(reinterpret_cast<float*>(Cv0) + (int64_t)blockIdx.y * c_zstride) : Cv0;
+  if (GROUPED) {
+    const int g = blockIdx.y;
+    const int row0 = grp.off[g];
+    M = grp.cnt[g];
+    A += (int64_t)row0 * lda;
+    W += (int64_t)g * grp.w_gstride;
+    Cv = (EPI == MN_GEMM_F32 || EPI == MN_GEMM_F32_RESID) ? (void*)(reinterpret_cast<float*>(Cv0) + (int64_t)row0 * ldc)
+                                                           : (void*)(reinterpret_cast<bf16_t*>(Cv0) + (int64_t)row0 * ldc);
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware tile order: consecutive tiles of one XCD share the A row panel
   const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
@@ -45,6 +63,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   }
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
+  if (GROUPED && m0 >= M) return;   // this group has fewer rows than the grid's upper bound (uniform per block)
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * 64;
 
   // global -> register staging: each thread moves 4 slots of A and 4 slots of W per k-tile
@@ -170,6 +189,30 @@ extern "C" int mn_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
   const int rc = gemm_launch(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, 1, 0, mn_stream(stream));
   if (rc < 0) return rc;
   MN_CHECK_LAUNCH("mn_gemm_bf16");
+  return MN_OK;
+}
+
+// Grouped GEMM over `n_groups` experts: C[off_g : off_g + cnt_g] = A[off_g : off_g + cnt_g] W_g^T with W_g = W + g * w_gstride.
+// off / cnt are DEVICE arrays (written by mn_moe_sort, no host sync); m_max bounds every cnt_g (e.g. the token count).
+extern "C" int mn_gemm_bf16_grouped(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int64_t w_gstride,
+                                    const int32_t* off, const int32_t* cnt, int n_groups, void* C, int64_t ldc, int m_max,
+                                    int N, int K, int epilogue, void* stream) {
+  MN_CHECK_ARG(A && W && C && off && cnt && n_groups >= 1 && m_max >= 1 && N >= 1 && K >= 8 && (K % 8) == 0,
+               "mn_gemm_bf16_grouped: bad args");
+  MN_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0 && (w_gstride % 8) == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0,
+               "mn_gemm_bf16_grouped: alignment");
+  MN_CHECK_ARG(epilogue == MN_GEMM_BF16 || epilogue == MN_GEMM_F32, "mn_gemm_bf16_grouped: epilogue must be BF16 or F32");
+  const int tiles = (int)(mn_cdiv(m_max, 128) * mn_cdiv(N, BN));
+  dim3 grid(tiles, n_groups);
+  GemmGroups g{off, cnt, w_gstride};
+  hipStream_t st = mn_stream(stream);
+  if (epilogue == MN_GEMM_BF16)
+    hipLaunchKernelGGL((gemm_bf16_kernel<MN_GEMM_BF16, 128, true>), grid, dim3(256), 0, st, A, lda, W, ldw,
+                       (const bf16_t*)nullptr, C, ldc, m_max, N, K, K, (int64_t)0, g);
+  else
+    hipLaunchKernelGGL((gemm_bf16_kernel<MN_GEMM_F32, 128, true>), grid, dim3(256), 0, st, A, lda, W, ldw,
+                       (const bf16_t*)nullptr, C, ldc, m_max, N, K, K, (int64_t)0, g);
+  MN_CHECK_LAUNCH("mn_gemm_bf16_grouped");
   return MN_OK;
 }
 

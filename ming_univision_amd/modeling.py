@@ -65,6 +65,7 @@ class MingUniVisionForConditionalGeneration:
             rf_sd = {k: v for k, v in llm_sd.items() if k.startswith("vis_head") or k.startswith("diffloss")}
         self.rf = RectifiedFlowHead(rf_sd, cfg.hidden_size, config.vishead_diffloss_config, self.vision.latent_dim)
         self.tokenizer = None
+        self.mfma_prefill_threshold = 64   # prompts longer than this prefill on the MFMA path
         self.noise_generator = torch.Generator(device=self.device)
         self.noise_generator.manual_seed(seed)
         self.reset_inner_state()
@@ -130,7 +131,11 @@ class MingUniVisionForConditionalGeneration:
             feats = self.extract_image_feature(pixel_values.to(dev), image_grid_thw)
             embeds, image_mask = self.prompt_wrap_vision(ids, embeds, feats)
         past = self.past_len
-        hidden = self.model.prefill(embeds, seq=0, past=past, image_mask=image_mask)[-1:]
+        if T > self.mfma_prefill_threshold and self.config.llm_config.head_dim == 128:
+            # long prompts (image understanding: 256-1024 image tokens): bf16 MFMA prefill with grouped-GEMM MoE
+            hidden = self.model.prefill_mfma(embeds, seq=0, past=past, image_mask=image_mask)
+        else:
+            hidden = self.model.prefill(embeds, seq=0, past=past, image_mask=image_mask)[-1:]
         cache_len = past + T
         am = attention_mask
         new_ids = []

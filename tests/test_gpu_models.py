@@ -299,3 +299,24 @@ def test_batched_generation_matches_single_image():
         assert rel_err(out["last_hidden"][i * R:(i + 1) * R], singles[i]["last_hidden"]) < TOL, i
         assert psnr(out["image"][i], singles[i]["image"][0]) > 45.0, i
     assert rel_err(out["last_hidden"][:R], g["rows3_last_hidden"][:, 0]) < TOL      # image 0 is the reference's case
+
+
+def test_prefill_mfma_vs_chunked_fp32_and_reference(llm):
+    """Long-prompt prefill on the bf16 MFMA path (grouped-GEMM MoE, GQA flash attention) against the exact
+    chunked fp32 prefill and the reference's golden hidden state; then a decode step on top of its KV cache."""
+    g, sd, cfg, dec = llm
+    T = g["emb"].shape[1]
+    emb = g["emb"][0].cuda()
+    h_ref = dec.prefill(emb, seq=0, past=0, image_mask=g["image_mask"][0], chunk=8)
+    kv_ref = dec.kv_cache[:, 0, :, :, :T].clone()
+    dec.kv_cache.zero_()
+    h = dec.prefill_mfma(emb, seq=0, past=0, image_mask=g["image_mask"][0])
+    assert rel_err(h, g["hidden"][0, -1:]) < TOL_BF16
+    assert rel_err(h, h_ref[-1:]) < TOL_BF16
+    assert rel_err(dec.kv_cache[:, 0, :, :, :T], kv_ref) < TOL_BF16
+    # two-segment prefill (past > 0) must agree with the one-shot prefill
+    dec.kv_cache.zero_()
+    dec.prefill_mfma(emb[:7], seq=1, past=0, image_mask=g["image_mask"][0][:7])
+    h2 = dec.prefill_mfma(emb[7:], seq=1, past=7, image_mask=g["image_mask"][0][7:])
+    assert rel_err(h2, h) < TOL_BF16
+    assert rel_err(dec.kv_cache[:, 1, :, :, :T], kv_ref) < TOL_BF16
