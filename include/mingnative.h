@@ -115,6 +115,7 @@ int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w, float eps
                   const uint16_t* gate_w, const uint16_t* image_gate_w, const uint8_t* image_mask,
                   int M, int H, int E, int top_k, int norm_topk_prob, int n_shared_slots,
                   float* x_norm, int32_t* topk_idx, float* topk_w, float* logits_ws /* [2*M*E] scratch */,
+                  void* ws, size_t ws_bytes /* optional: mn_skinny_workspace_bytes(M, E, H, 0) enables the MFMA route */,
                   void* stream);
 
 /* ------------------------------------------------------------------------------------------

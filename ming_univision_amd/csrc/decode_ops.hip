@@ -65,20 +65,25 @@ __global__ __launch_bounds__(256) void moe_topk_kernel(
 extern "C" int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w, float eps,
                              const uint16_t* gate_w, const uint16_t* image_gate_w, const uint8_t* image_mask,
                              int M, int H, int E, int top_k, int norm_topk_prob, int n_shared_slots,
-                             float* x_norm, int32_t* topk_idx, float* topk_w, float* logits_ws, void* stream) {
+                             float* x_norm, int32_t* topk_idx, float* topk_w, float* logits_ws, void* ws, size_t ws_bytes,
+                             void* stream) {
   MN_CHECK_ARG(M >= 1 && M <= 64 && H >= 8 && (H % 8) == 0, "mn_moe_router: bad M=%d H=%d", M, H);
   MN_CHECK_ARG(E >= 1 && E <= 64 && top_k >= 1 && top_k <= E && top_k + n_shared_slots <= 64,
                "mn_moe_router: bad E=%d top_k=%d", E, top_k);
   MN_CHECK_ARG(x && norm_w && gate_w && x_norm && topk_idx && topk_w && logits_ws, "mn_moe_router: null pointer");
   const bool both = image_mask && image_gate_w;
+  // >= 5 rows with scratch: one launch on the matrix-core route; otherwise the fp32 path, 8 rows at a time
+  const bool mfma = M <= 16 && ws != nullptr && ws_bytes >= mn_skinny_workspace_bytes(M, E, H, 0) && mn_skinny_workspace_bytes(M, E, H, 0) > 0;
+  const int mstep = mfma ? M : 8;
   for (int gsel = 0; gsel < (both ? 2 : 1); ++gsel)
-    for (int m0 = 0; m0 < M; m0 += 8) {   // the gate is tiny: rows go through the fp32 path 8 at a time
+    for (int m0 = 0; m0 < M; m0 += mstep) {
       mn_skinny_args a;
       memset(&a, 0, sizeof(a));
       a.x = x + (int64_t)m0 * ldx; a.ldx = ldx; a.w = gsel ? image_gate_w : gate_w; a.ldw = H;
       a.out = logits_ws + (int64_t)gsel * M * E + (int64_t)m0 * E; a.ldo = E;
-      a.M = (M - m0) < 8 ? (M - m0) : 8; a.N = E; a.K = H;
+      a.M = (M - m0) < mstep ? (M - m0) : mstep; a.N = E; a.K = H;
       a.prologue = MN_PRO_RMSNORM; a.ln_g = norm_w; a.eps = eps;
+      if (mfma) { a.ws = ws; a.ws_bytes = ws_bytes; }
       const int rc = mn_skinny_gemm(&a, stream);
       if (rc != MN_OK) return rc;
     }

@@ -134,43 +134,54 @@ __global__ __launch_bounds__(1024) void rf_glue_resid_ln_split_kernel(
     float* __restrict__ h, const bf16_t* __restrict__ ln_g, const bf16_t* __restrict__ ln_b,
     const float* __restrict__ shift, const float* __restrict__ scale, int64_t ldmod, bf16_t* __restrict__ Y) {
   __shared__ float red[32];
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
   const int m = blockIdx.x, tid = threadIdx.x;
-  float hv[4];
+  const int col = tid * 4;                       // w <= 4096, w % 4 == 0: one float4 of columns per thread
+  const bool act = col < w;
+  f4 hv = {0.f, 0.f, 0.f, 0.f};
   float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int col = tid + j * 1024;
-    hv[j] = 0.f;
-    if (col < w) {
-      float v = h[(int64_t)m * w + col];
-      if (P) {
-        float y = bf16_to_f32(b3[col]);
-        for (int z = 0; z < nz; ++z) y += P[((int64_t)z * M + m) * w + col];
-        v += gate[(int64_t)m * ldmod + col] * y;
-        h[(int64_t)m * w + col] = v;
+  if (act) {
+    hv = *reinterpret_cast<const f4*>(h + (int64_t)m * w + col);
+    if (P) {
+      f4 y = {bf16_to_f32(b3[col]), bf16_to_f32(b3[col + 1]), bf16_to_f32(b3[col + 2]), bf16_to_f32(b3[col + 3])};
+      const float* pp = P + (int64_t)m * w + col;
+      const int64_t slab = (int64_t)M * w;
+      int z = 0;
+      for (; z + 4 <= nz; z += 4) {              // independent 16-byte loads, 4 in flight
+        const f4 a = *reinterpret_cast<const f4*>(pp + (z + 0) * slab), b = *reinterpret_cast<const f4*>(pp + (z + 1) * slab);
+        const f4 c = *reinterpret_cast<const f4*>(pp + (z + 2) * slab), d = *reinterpret_cast<const f4*>(pp + (z + 3) * slab);
+        y += (a + b) + (c + d);
       }
-      hv[j] = v;
-      s += v;
+      for (; z < nz; ++z) y += *reinterpret_cast<const f4*>(pp + z * slab);
+      const f4 g = *reinterpret_cast<const f4*>(gate + (int64_t)m * ldmod + col);
+      hv += g * y;
+      *reinterpret_cast<f4*>(h + (int64_t)m * w + col) = hv;
     }
+    s = (hv.x + hv.y) + (hv.z + hv.w);
   }
   const float mean = block_sum(s, red) / (float)w;
   float ss = 0.f;
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (tid + j * 1024 < w) { const float d = hv[j] - mean; ss += d * d; }
+  if (act) { const f4 d = hv - mean; ss = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w; }
   const float rstd = rsqrtf(block_sum(ss, red) / (float)w + 1e-6f);
+  if (act) {
+    const f4 sc = *reinterpret_cast<const f4*>(scale + (int64_t)m * ldmod + col);
+    const f4 sh = *reinterpret_cast<const f4*>(shift + (int64_t)m * ldmod + col);
+    float v[4] = {(hv.x - mean) * rstd, (hv.y - mean) * rstd, (hv.z - mean) * rstd, (hv.w - mean) * rstd};
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+    bf16_t hi[4], lo[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int col = tid + j * 1024;
-    if (col < w) {
-      float v = (hv[j] - mean) * rstd;
-      if (ln_g) v *= bf16_to_f32(ln_g[col]);
-      if (ln_b) v += bf16_to_f32(ln_b[col]);
-      v = v * (1.0f + scale[(int64_t)m * ldmod + col]) + shift[(int64_t)m * ldmod + col];
-      const bf16_t hi = f32_to_bf16(v);
-      Y[(int64_t)m * w + col] = hi;
-      Y[(int64_t)(M + m) * w + col] = f32_to_bf16(v - bf16_to_f32(hi));
+    for (int j = 0; j < 4; ++j) {
+      if (ln_g) v[j] *= bf16_to_f32(ln_g[col + j]);
+      if (ln_b) v[j] += bf16_to_f32(ln_b[col + j]);
+      v[j] = v[j] * (1.0f + scv[j]) + shv[j];
+      hi[j] = f32_to_bf16(v[j]);
+      lo[j] = f32_to_bf16(v[j] - bf16_to_f32(hi[j]));
     }
+    u2 ph = {(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
+    u2 pl = {(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
+    *reinterpret_cast<u2*>(Y + (int64_t)m * w + col) = ph;
+    *reinterpret_cast<u2*>(Y + (int64_t)(M + m) * w + col) = pl;
   }
 }
 
@@ -306,7 +317,7 @@ static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, floa
                                    {h->w, h->hidden, 0}, {h->target, h->w, 0}, {h->w, h->target, 0}});
   *skws = cv.take<char>(*skws_bytes);
   // matrix-core chain (rows >= 5): split activations of both GEMVs and the K-slice partial slabs
-  const bool chain = mn_skinny_workspace_bytes(rows, h->w, h->w, 0) > 0 && h->w <= 4096;
+  const bool chain = mn_skinny_workspace_bytes(rows, h->w, h->w, 0) > 0 && h->w <= 4096 && (h->w % 4) == 0 && (A % 4) == 0;
   const int nzmax = mn_stream_mfma_slices(h->w > h->hidden ? h->w : h->hidden);
   *ya = cv.take<bf16_t>(chain ? (size_t)2 * rows * h->w : 0);
   *yb = cv.take<bf16_t>(chain ? (size_t)2 * rows * h->hidden : 0);
@@ -342,7 +353,7 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   float* pbuf;
   const size_t need = rf_carve(h, rows, workspace, workspace_bytes, &z, &c, &ada, &hh, &hid, &v, &x, &y, &bar, &skws, &skws_bytes,
                                &ya, &yb, &pbuf);
-  const bool chain = mn_skinny_workspace_bytes(rows, h->w, h->w, 0) > 0 && h->w <= 4096;
+  const bool chain = mn_skinny_workspace_bytes(rows, h->w, h->w, 0) > 0 && h->w <= 4096 && (h->w % 4) == 0;
   t_sk_ws = skws; t_sk_ws_bytes = skws_bytes;
   if (need > workspace_bytes) { mn_set_error("mn_rf_sample: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
   hipStream_t st = mn_stream(stream);
@@ -460,7 +471,7 @@ static size_t llm_carve(const mn_llm* m, int rows, int64_t t_max, void* ws, size
   o->logits = cv.take<float>((size_t)2 * rows * m->n_experts);
   o->attn_ws_bytes = mn_attn_decode_workspace_bytes(rows, m->n_q, m->head_dim, t_max);
   o->attn_ws = cv.take<char>(o->attn_ws_bytes);
-  o->sk_ws_bytes = sk_ws_need(rows, {{qkv_dim, m->hidden, 0}, {m->hidden, m->n_q * m->head_dim, 0}});
+  o->sk_ws_bytes = sk_ws_need(rows, {{qkv_dim, m->hidden, 0}, {m->hidden, m->n_q * m->head_dim, 0}, {m->n_experts, m->hidden, 0}});
   o->sk_ws = cv.take<char>(o->sk_ws_bytes);
   return cv.off;
 }
@@ -510,7 +521,7 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
     // MoE: RMSNorm + router -> grouped expert gate/up (SwiGLU) -> grouped down + weighted sum + residual (:1218-1225, :556-639)
     MN_TRY(mn_moe_router(w.h, H, m->ln2[l], m->rms_eps, m->gate[l], m->image_gate ? m->image_gate[l] : nullptr,
                          image_mask, M, H, m->n_experts, m->top_k, m->norm_topk_prob, m->n_shared_slots, w.xn, w.ti,
-                         w.tw, w.logits, stream));
+                         w.tw, w.logits, w.sk_ws, w.sk_ws_bytes, stream));
     a = sk(w.xn, H, m->w_gate_up[l], H, nullptr, w.hmid, I, 1, I, H);
     a.epilogue = MN_EPI_SWIGLU;
     a.batch = M * n_slot; a.w_index = w.ti; a.w_batch_stride = (int64_t)2 * I * H;

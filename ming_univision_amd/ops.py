@@ -81,7 +81,7 @@ def moe_router(x, norm_w, eps, gate_w, image_gate_w, image_mask, top_k, norm_top
     lws = torch.empty(2 * M * E, dtype=torch.float32, device=x.device)
     check(lib().mn_moe_router(ptr(x), x.stride(0), ptr(norm_w), eps, ptr(gate_w), ptr(image_gate_w), ptr(image_mask),
                               M, H, E, top_k, int(norm_topk_prob), n_shared_slots, ptr(xn), ptr(idx), ptr(w), ptr(lws),
-                              current_stream()), "mn_moe_router")
+                              None, 0, current_stream()), "mn_moe_router")
     return xn, idx, w
 
 
