@@ -133,7 +133,7 @@ def dominant_kernel_roofline_stream(rf, rows, iters=48):
     from ming_univision_amd._lib import lib, ptr, current_stream, check
     dev = rf.t["vis_w"].device
     w, hid = rf.w, rf.hidden
-    nz = lib().mn_stream_mfma_slices(w)
+    nz = lib().mn_stream_mfma_slices(rows, 2 * hid, w)
     Y = (torch.randn(2 * rows, w, device=dev) * 0.5).to(torch.bfloat16)
     P = torch.empty(nz * rows * 2 * hid, dtype=torch.float32, device=dev)
 

@@ -200,11 +200,21 @@ int mn_gemm_bf16_grouped(const uint16_t* A, int64_t lda, const uint16_t* W, int6
                          int K, int epilogue, void* stream);
 
 /* Weight-streaming MFMA kernel behind the M >= 5 route of mn_skinny_gemm: Y bf16 [2][M][K] (activations split
- * into hi rows then lo rows), W bf16 [Ntot, K] dense, P fp32 [nz][M][Ntot] with nz = mn_stream_mfma_slices(K)
- * K-slices of 1024; returns nz.  M <= 16.  HBM-bound: every weight byte is read once, straight into MFMA
- * B fragments. */
+ * into hi rows then lo rows), W bf16 [Ntot, K] dense, P fp32 [nz][M][Ntot] K-slice partials with
+ * nz = mn_stream_mfma_slices(M, Ntot, K) (the launch plan picks slices of 256..1024 k so that every wave of the
+ * chip gets the same number of 16-row weight tiles); returns nz.  M <= 32.  HBM-bound: every weight byte is read
+ * once. */
 int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream);
-int mn_stream_mfma_slices(int K);
+int mn_stream_mfma_slices(int M, int Ntot, int K);
+/* Grouped form (MoE experts; replaces the per-token expert loop of modeling_bailing_moe.py:605-639 for 5..32
+ * rows): group g of G multiplies the x rows xrows[off[g] .. off[g+1]) (identity rows when xrows == NULL) by
+ * W + g * w_stride and writes rows off[g].. of P [nz][p_rows][Ntot]; Y holds y_rows hi rows then y_rows lo rows;
+ * no group may exceed max_rows (<= 32) rows.  off / xrows are device arrays.  Every distinct expert is streamed
+ * once for all the rows routed to it.  Returns nz = mn_stream_mfma_grouped_slices(G, max_rows, Ntot, K). */
+int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P, int p_rows,
+                           const int32_t* off, const int32_t* xrows, int G, int max_rows, int Ntot, int K,
+                           void* stream);
+int mn_stream_mfma_grouped_slices(int G, int max_rows, int Ntot, int K);
 
 /* y bf16 [M,D] = LayerNorm(x fp32 [M,D]; g,b bf16, eps) ; optional GELU afterwards (encoder out layer,
  * vision_transformer.py:173-178). */

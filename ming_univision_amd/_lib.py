@@ -103,7 +103,9 @@ SYMBOLS = {
     "mn_gather_rows_bf16": (_i, [_p, _i64, _p, _p, _i64, _i, _i, _p]),
     "mn_moe_combine": (_i, [_p, _i64, _p, _p, _i, _p, _i64, _i, _i, _p]),
     "mn_gemm_bf16_grouped": (_i, [_p, _i64, _p, _i64, _i64, _p, _p, _i, _p, _i64, _i, _i, _i, _i, _p]),
-    "mn_stream_mfma_slices": (_i, [_i]),
+    "mn_stream_mfma_slices": (_i, [_i, _i, _i]),
+    "mn_stream_mfma_grouped": (_i, [_p, _i, _p, _i64, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "mn_stream_mfma_grouped_slices": (_i, [_i, _i, _i, _i]),
     "mn_moe_router": (_i, [_p, _i64, _p, _f, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "mn_rope_kv_append": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _i64, _p]),
     "mn_attn_decode_workspace_bytes": (_sz, [_i, _i, _i, _i64]),

@@ -15,7 +15,11 @@
 
 extern "C" size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t t_max);
 extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream);
-extern "C" int mn_stream_mfma_slices(int K);
+extern "C" int mn_stream_mfma_slices(int M, int Ntot, int K);
+extern "C" int mn_stream_mfma_grouped_slices(int G, int max_rows, int Ntot, int K);
+extern "C" int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P,
+                                      int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows,
+                                      int Ntot, int K, void* stream);
 extern "C" int mn_rf_blocks_persistent(int rows, int w, int hidden, int depth, int A, const uint16_t* const* w12,
                                        const uint16_t* const* b12, const uint16_t* const* w3,
                                        const uint16_t* const* b3, const uint16_t* const* ln_g,
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void rf_glue_swiglu_split_kernel(const float* 
   if (i >= (int64_t)M * hidden) return;
   const int m = (int)(i / hidden), n = (int)(i % hidden);
   const int64_t slab = (int64_t)M * 2 * hidden;
-  float y1 = bf16_to_f32(b12[n]), y2 = bf16_to_f32(b12[n + hidden]);
+  float y1 = b12 ? bf16_to_f32(b12[n]) : 0.f, y2 = b12 ? bf16_to_f32(b12[n + hidden]) : 0.f;
   for (int z = 0; z < nz; ++z) {
     y1 += P[z * slab + (int64_t)m * 2 * hidden + n];
     y2 += P[z * slab + (int64_t)m * 2 * hidden + hidden + n];
@@ -318,10 +322,13 @@ static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, floa
   *skws = cv.take<char>(*skws_bytes);
   // matrix-core chain (rows >= 5): split activations of both GEMVs and the K-slice partial slabs
   const bool chain = mn_skinny_workspace_bytes(rows, h->w, h->w, 0) > 0 && h->w <= 4096 && (h->w % 4) == 0 && (A % 4) == 0;
-  const int nzmax = mn_stream_mfma_slices(h->w > h->hidden ? h->w : h->hidden);
+  const size_t p12 = (size_t)mn_stream_mfma_slices(rows, 2 * h->hidden, h->w) * 2 * h->hidden;
+  const size_t p3 = (size_t)mn_stream_mfma_slices(rows, h->w, h->hidden) * h->w;
+  const size_t pf = (size_t)mn_stream_mfma_slices(rows, h->target, h->w) * h->target;
+  const size_t pmax = p12 > p3 ? (p12 > pf ? p12 : pf) : (p3 > pf ? p3 : pf);
   *ya = cv.take<bf16_t>(chain ? (size_t)2 * rows * h->w : 0);
   *yb = cv.take<bf16_t>(chain ? (size_t)2 * rows * h->hidden : 0);
-  *pbuf = cv.take<float>(chain ? (size_t)nzmax * rows * 2 * h->hidden : 0);
+  *pbuf = cv.take<float>(chain ? pmax * rows : 0);
   return cv.off;
 }
 
@@ -447,9 +454,92 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
 // ===========================================================================================
 // Bailing-MoE decoder stack step
 // ===========================================================================================
+// ---- grouped expert path (rows >= 5): every distinct expert's weights are streamed once on the matrix cores ----
+// Block 0 sorts the (row, slot) pairs by expert — off[g] .. off[g+1] are the sorted positions of group g, a pair's
+// rank inside its group is its pair index order, so the layout is deterministic; blocks 1..M split row m-1 of the
+// normalised activations into bf16 hi / lo halves for the MFMA kernel.
+__global__ __launch_bounds__(256) void moe_group_split_kernel(const int32_t* __restrict__ topk_idx, int M, int n_slot, int G,
+                                                              int32_t* __restrict__ off, int32_t* __restrict__ xrows,
+                                                              int32_t* __restrict__ pair_pos, const float* __restrict__ xn,
+                                                              int H, bf16_t* __restrict__ Y) {
+  __shared__ int32_t s_idx[1024];
+  __shared__ int32_t s_off[257];
+  const int tid = threadIdx.x;
+  if (blockIdx.x > 0) {
+    const int m = blockIdx.x - 1;
+    for (int k = tid; k < H; k += 256) {
+      const float v = xn[(int64_t)m * H + k];
+      const bf16_t hi = f32_to_bf16(v);
+      Y[(int64_t)m * H + k] = hi;
+      Y[(int64_t)(M + m) * H + k] = f32_to_bf16(v - bf16_to_f32(hi));
+    }
+    return;
+  }
+  const int P = M * n_slot;                         // <= 1024 pairs, G <= 256 groups (checked by the caller)
+  for (int p = tid; p < P; p += 256) s_idx[p] = topk_idx[p];
+  for (int g = tid; g <= G; g += 256) s_off[g] = 0;
+  __syncthreads();
+  for (int p = tid; p < P; p += 256) atomicAdd(&s_off[s_idx[p] + 1], 1);
+  __syncthreads();
+  if (tid == 0) for (int g = 0; g < G; ++g) s_off[g + 1] += s_off[g];
+  __syncthreads();
+  for (int g = tid; g <= G; g += 256) off[g] = s_off[g];
+  for (int p = tid; p < P; p += 256) {
+    const int e = s_idx[p];
+    int rank = 0;
+    for (int q = 0; q < p; ++q) rank += (s_idx[q] == e);
+    const int pos = s_off[e] + rank;
+    xrows[pos] = p / n_slot;
+    pair_pos[p] = pos;
+  }
+}
+
+// h[m, n] += sum_s w[m, s] * sum_z P[z][pos(m, s)][n]   (weighted sum of the routed + shared experts, residual add)
+__global__ __launch_bounds__(256) void moe_combine_resid_kernel(const float* __restrict__ P, int nz, int64_t slab, int M, int H,
+                                                                int n_slot, const int32_t* __restrict__ pair_pos,
+                                                                const float* __restrict__ tw, float* __restrict__ h) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)M * H) return;
+  const int m = (int)(i / H), n = (int)(i % H);
+  float acc = 0.f;
+  for (int s = 0; s < n_slot; ++s) {
+    const float* pp = P + (int64_t)pair_pos[m * n_slot + s] * H + n;
+    float y = 0.f;
+    for (int z = 0; z < nz; ++z) y += pp[z * slab];
+    acc += tw[m * n_slot + s] * y;
+  }
+  h[i] += acc;
+}
+
+struct MoeWs {
+  int32_t *off, *xrows, *pair_pos;
+  bf16_t *y1, *y2;
+  float *p1, *p2;
+};
+
+static size_t moe_carve(Carver& cv, int rows, int H, int I, int G, int n_slot, MoeWs* o) {
+  const size_t P = (size_t)rows * n_slot;
+  const size_t before = cv.off;
+  o->off = cv.take<int32_t>((size_t)G + 1);
+  o->xrows = cv.take<int32_t>(P);
+  o->pair_pos = cv.take<int32_t>(P);
+  o->y1 = cv.take<bf16_t>((size_t)2 * rows * H);
+  o->y2 = cv.take<bf16_t>(2 * P * I);
+  o->p1 = cv.take<float>((size_t)mn_stream_mfma_grouped_slices(G, rows, 2 * I, H) * P * 2 * I);
+  o->p2 = cv.take<float>((size_t)mn_stream_mfma_grouped_slices(G, rows, H, I) * P * H);
+  return cv.off - before;
+}
+
+constexpr int MOE_MFMA_MIN_ROWS = 5;
+static bool moe_mfma_ok(const mn_llm* m, int rows) {
+  return rows >= MOE_MFMA_MIN_ROWS && rows * (m->top_k + m->n_shared_slots) <= 1024 &&
+         m->n_experts + m->n_shared_slots <= 256 && (m->hidden % 8) == 0 && (m->moe_inter % 8) == 0;
+}
+
 struct LlmWs {
   float *h, *qkv, *q, *attn, *xn, *tw, *hmid, *logits;
   int32_t* ti;
+  MoeWs moe;
   void* attn_ws;
   size_t attn_ws_bytes;
   char* sk_ws;
@@ -473,6 +563,7 @@ static size_t llm_carve(const mn_llm* m, int rows, int64_t t_max, void* ws, size
   o->attn_ws = cv.take<char>(o->attn_ws_bytes);
   o->sk_ws_bytes = sk_ws_need(rows, {{qkv_dim, m->hidden, 0}, {m->hidden, m->n_q * m->head_dim, 0}, {m->n_experts, m->hidden, 0}});
   o->sk_ws = cv.take<char>(o->sk_ws_bytes);
+  if (moe_mfma_ok(m, rows)) moe_carve(cv, rows, m->hidden, m->moe_inter, m->n_experts + m->n_shared_slots, n_slot, &o->moe);
   return cv.off;
 }
 
@@ -494,7 +585,7 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
                            float* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
   MN_CHECK_ARG(m && x && row_seq && row_slot && row_pos && row_len && kv_cache && hidden_out && workspace,
                "mn_llm_step: null pointer");
-  MN_CHECK_ARG(M >= 1 && M <= 16 && x_row_div >= 1, "mn_llm_step: M=%d (1..16)", M);
+  MN_CHECK_ARG(M >= 1 && M <= 32 && x_row_div >= 1, "mn_llm_step: M=%d (1..32)", M);
   LlmWs w;
   const size_t need = llm_carve(m, M, t_max, workspace, workspace_bytes, &w);
   if (need > workspace_bytes) { mn_set_error("mn_llm_step: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
@@ -522,6 +613,21 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
     MN_TRY(mn_moe_router(w.h, H, m->ln2[l], m->rms_eps, m->gate[l], m->image_gate ? m->image_gate[l] : nullptr,
                          image_mask, M, H, m->n_experts, m->top_k, m->norm_topk_prob, m->n_shared_slots, w.xn, w.ti,
                          w.tw, w.logits, w.sk_ws, w.sk_ws_bytes, stream));
+    if (moe_mfma_ok(m, M)) {
+      const int G = m->n_experts + m->n_shared_slots, P = M * n_slot;
+      hipLaunchKernelGGL(moe_group_split_kernel, dim3(M + 1), dim3(256), 0, st, w.ti, M, n_slot, G, w.moe.off, w.moe.xrows,
+                         w.moe.pair_pos, w.xn, H, w.moe.y1);
+      int nz = mn_stream_mfma_grouped(w.moe.y1, M, m->w_gate_up[l], (int64_t)2 * I * H, w.moe.p1, P, w.moe.off, w.moe.xrows,
+                                      G, M, 2 * I, H, stream);
+      if (nz < 0) return nz;
+      hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)P * I, 256)), dim3(256), 0, st, w.moe.p1, nz, P, I,
+                         (const bf16_t*)nullptr, w.moe.y2);
+      nz = mn_stream_mfma_grouped(w.moe.y2, P, m->w_down[l], (int64_t)H * I, w.moe.p2, P, w.moe.off, nullptr, G, M, H, I, stream);
+      if (nz < 0) return nz;
+      hipLaunchKernelGGL(moe_combine_resid_kernel, dim3(mn_cdiv((int64_t)M * H, 256)), dim3(256), 0, st, w.moe.p2, nz,
+                         (int64_t)P * H, M, H, n_slot, w.moe.pair_pos, w.tw, w.h);
+      continue;
+    }
     a = sk(w.xn, H, m->w_gate_up[l], H, nullptr, w.hmid, I, 1, I, H);
     a.epilogue = MN_EPI_SWIGLU;
     a.batch = M * n_slot; a.w_index = w.ti; a.w_batch_stride = (int64_t)2 * I * H;

@@ -210,7 +210,7 @@ int launch_m(const KArgs& ka, int R, int sw, int nt, dim3 grid, size_t lds, hipS
 // hi + lo keeps the products fp32-accurate (x' = hi + lo to 2^-17 relative).
 // ===========================================================================================
 extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream);
-extern "C" int mn_stream_mfma_slices(int K);
+extern "C" int mn_stream_mfma_slices(int M, int Ntot, int K);
 
 namespace {
 
@@ -295,11 +295,11 @@ extern "C" size_t mn_skinny_workspace_bytes(int M, int N, int K, int epilogue) {
   if (M < MEDIUM_MIN_M) return 0;
   const int Ntot = epilogue == MN_EPI_SWIGLU ? 2 * N : N;
   const size_t y = ((size_t)2 * M * K * sizeof(bf16_t) + 255) & ~(size_t)255;
-  return y + (size_t)mn_stream_mfma_slices(K) * M * Ntot * sizeof(float) + 256;
+  return y + (size_t)mn_stream_mfma_slices(M, Ntot, K) * M * Ntot * sizeof(float) + 256;
 }
 
 static int skinny_medium(const mn_skinny_args& a, void* stream) {
-  MN_CHECK_ARG(a.M <= 16, "mn_skinny_gemm: M=%d out of range [1,16]", a.M);
+  MN_CHECK_ARG(a.M <= 32, "mn_skinny_gemm: M=%d out of range [1,32]", a.M);
   MN_CHECK_ARG((a.batch <= 1) && (a.nseg <= 1), "mn_skinny_gemm: batch/nseg forms need M <= 8");
   MN_CHECK_ARG(a.ldw == a.K, "mn_skinny_gemm: M > 8 needs densely packed weights (ldw == K)");
   const int Ntot = a.epilogue == MN_EPI_SWIGLU ? 2 * a.N : a.N;
@@ -331,7 +331,7 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   KArgs ka;
   ka.a = *args;
   mn_skinny_args& a = ka.a;
-  MN_CHECK_ARG(a.M >= 1 && a.M <= 16, "mn_skinny_gemm: M=%d out of range [1,16]", a.M);
+  MN_CHECK_ARG(a.M >= 1 && a.M <= 32, "mn_skinny_gemm: M=%d out of range [1,32]", a.M);
   MN_CHECK_ARG(a.N >= 1 && a.K >= 8 && (a.K % 8) == 0, "mn_skinny_gemm: bad N=%d K=%d (K %% 8 must be 0)", a.N, a.K);
   MN_CHECK_ARG((a.ldw % 8) == 0, "mn_skinny_gemm: ldw=%lld must be a multiple of 8", (long long)a.ldw);
   MN_CHECK_ARG(a.x && a.w && a.out, "mn_skinny_gemm: null pointer");

@@ -1,21 +1,24 @@
-// stream_mfma.hip — weight-streaming GEMM for 3..16 activation rows on the matrix cores (gfx950).
+// stream_mfma.hip — weight-streaming GEMM for 5..32 activation rows on the matrix cores (gfx950).
 //
-//   partial[z][m][n] = sum_{k in slice z} (x_hi[m,k] + x_lo[m,k]) * W[n,k]
+//   partial[z][row][n] = sum_{k in slice z} (x_hi[xrow,k] + x_lo[xrow,k]) * W_g[n,k]
 //
 // Same roofline as the fp32 skinny kernel (HBM: every weight byte is read once), but the multiply runs
-// on v_mfma_f32_16x16x32_bf16 so that up to 16 rows cost the same as one.  The activations arrive
-// pre-split into bf16 hi + lo halves (x = hi + lo to 2^-17, so products stay fp32-accurate); a
-// workgroup copies its K-slice of both halves into LDS once and every wave then streams weight rows
-// STRAIGHT from HBM into MFMA B-fragments — a weight element is used exactly once per workgroup, so
-// staging it through LDS would be pure overhead:
+// on v_mfma_f32_16x16x32_bf16 so that up to 32 rows cost the same as one.  The activations arrive
+// pre-split into bf16 hi + lo halves (x = hi + lo to 2^-17, so products stay fp32-accurate).
 //
-//   B fragment (W):  lane l holds W[n0 + (l & 15)][k + (l >> 4) * 8 .. +8]   one 16-byte nt load
-//   A fragment (x):  lane l holds x[m = l & 15][k + (l >> 4) * 8 .. +8]      ds_read_b128 (hi) + (lo)
-//   D:               lane l, reg r holds out[m = (l >> 4) * 4 + r][n0 + (l & 15)]
+// A workgroup owns one K-slice (`ks` = 1..4 chunks of 256 k) of one weight matrix: it copies that slice of both
+// x halves into LDS once, and each of its waves then streams 16-row weight tiles:
+//   * a wave loads its 16-row x 256-k chunk as 8 instructions of 8 rows x 128 B (whole cache lines), parks
+//     it in its own 8 KiB of LDS (XOR-swizzled 16-byte slots; wave-private, so no workgroup barrier is
+//     involved) and reads MFMA B fragments back with ds_read_b128; the next chunk is in flight in registers
+//     while this one is multiplied (deeper rings measured slower: 25.9 / 26.8 / 27.9 / 30.6 us at depth 1-4;
+//     B fragments loaded straight from HBM, 16 rows x 64 B per instruction, also slower: 14.2 vs 12.9 us on RF w3);
+//   * A fragments (x): lane l holds x[m = l & 15][k + (l >> 4) * 8 .. +8], ds_read_b128 of hi and of lo;
+//   * D: lane l, reg r holds out[m = (l >> 4) * 4 + r][n0 + (l & 15)].
+// K-slice partials are reduced (with bias / activation / residual epilogues) by the caller's next kernel.
 //
-// A wave owns a tile of 16 output rows for the workgroup's K-slice (KS = 1024: 32 MFMA steps, a
-// 4-deep ring of 8 loads each keeps 32 KiB per wave in flight at 8 waves per CU), then moves on to its next tile.
-// Slices are reduced (with bias / activation / residual epilogues) by medium_epilogue_kernel.
+// Grouped form (MoE experts): blockIdx.z selects a weight matrix and a list of x rows (off[g]..off[g+1]),
+// so every distinct expert is streamed once for all the rows routed to it; empty groups exit at once.
 #include <stdlib.h>
 
 #include "common.h"
@@ -26,127 +29,49 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int SKS = 1024;            // K-slice per workgroup
-constexpr int SROW = SKS + 8;        // LDS row stride in bf16 elements (+16 B: conflict-free b128 fragment reads)
-constexpr int SNT = 512;             // 8 waves
+constexpr int WCH = 256;             // k per chunk
+constexpr int MAX_KCH = 4;           // K-slice <= 1024
+constexpr size_t LDS_CAP = 160 * 1024;
 
-// Y: [2][M][K] bf16 (hi rows then lo rows, row stride K).  P: [nz][M][Ntot] fp32.
-template <bool NTLOAD>
-__device__ __forceinline__ u32x4 ldw(const bf16_t* p) {
-  if (NTLOAD) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-  return *reinterpret_cast<const u32x4*>(p);
-}
-
-template <bool NTLOAD>
-__global__ __launch_bounds__(SNT) void stream_mfma_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ W,
-                                                          float* __restrict__ P, int M, int Ntot, int K) {
-  extern __shared__ __attribute__((aligned(16))) bf16_t xs_raw[];      // [2][16][SROW] = 66 KiB
-  bf16_t (*xs)[16][SROW] = reinterpret_cast<bf16_t (*)[16][SROW]>(xs_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int z = blockIdx.y;
-  const int k0 = z * SKS, klen = min(SKS, K - k0);          // K % 8 == 0; klen % 8 == 0
-  const int fr = lane & 15, fq = lane >> 4;
-  const int ntiles = (Ntot + 15) >> 4;
-  const int nsteps = (klen + 31) >> 5;                       // MFMA steps of 32 k
-  const int twaves = gridDim.x * (SNT / 64);
-  const int kcl = klen - 8 - fq * 8;                         // last valid 8-element offset for this lane group
-  u32x4 ring[8];
-  auto head = [&](int t) {                                   // request the first 8 weight fragments of tile t
-    const int n = min(t * 16 + fr, Ntot - 1);
-    const bf16_t* wp = W + (int64_t)n * K + k0 + fq * 8;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) ring[d] = ldw<NTLOAD>(wp + min(d * 32, kcl));
-  };
-  int t = blockIdx.x * (SNT / 64) + wave;
-  if (t < ntiles) head(t);                                   // weights first: their HBM latency overlaps the x staging
-  // ---- stage this slice of x (rows >= M are zero so that unused MFMA rows contribute nothing)
-  for (int i = tid; i < 2 * 16 * (SKS / 8); i += SNT) {
-    const int slot = i % (SKS / 8), m = (i / (SKS / 8)) % 16, h = i / (16 * (SKS / 8));
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (m < M && slot * 8 < klen) v = *reinterpret_cast<const u32x4*>(Y + ((int64_t)h * M + m) * K + k0 + slot * 8);
-    *reinterpret_cast<u32x4*>(&xs[h][m][slot * 8]) = v;
-  }
-  const bf16_t* xh = &xs[0][fr][fq * 8];
-  const bf16_t* xl = &xs[1][fr][fq * 8];
-  __syncthreads();
-  for (; t < ntiles; t += twaves) {
-    const int n = min(t * 16 + fr, Ntot - 1);
-    const bf16_t* wp = W + (int64_t)n * K + k0 + fq * 8;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int s = 0;
-    for (; s + 16 <= nsteps; s += 8) {
-#pragma unroll
-      for (int d = 0; d < 8; ++d) {
-        const bf16x8 w = __builtin_bit_cast(bf16x8, ring[d]);
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xh + (s + d) * 32);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(xl + (s + d) * 32);
-        ring[d] = ldw<NTLOAD>(wp + min((s + d + 8) * 32, kcl));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w, acc, 0, 0, 0);
-      }
-    }
-    // drain (steps beyond nsteps multiply the zero-padded x tail or re-read clamped in-bounds weights
-    // against x columns >= klen, which are zero in LDS)
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      if (s + d < nsteps) {
-        const bf16x8 w = __builtin_bit_cast(bf16x8, ring[d]);
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xh + (s + d) * 32);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(xl + (s + d) * 32);
-        if (s + d + 8 < nsteps) ring[d] = ldw<NTLOAD>(wp + min((s + d + 8) * 32, kcl));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w, acc, 0, 0, 0);
-      }
-    }
-    s += 8;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      if (s + d < nsteps) {
-        const bf16x8 w = __builtin_bit_cast(bf16x8, ring[d]);
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xh + (s + d) * 32);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(xl + (s + d) * 32);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w, acc, 0, 0, 0);
-      }
-    }
-    if (t + twaves < ntiles) head(t + twaves);               // next tile's head overlaps the stores below
-    // D layout: row m = fq*4 + r, col n = t*16 + fr
-    const int nn = t * 16 + fr;
-    if (nn < Ntot) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = fq * 4 + r;
-        if (m < M) P[((int64_t)z * M + m) * Ntot + nn] = acc[r];
-      }
-    }
-  }
-}
-
-
-// ---- variant 2: weights staged through a wave-private LDS tile with fully coalesced global loads ----
-// The direct B-fragment load above touches 16 rows x 64 B per instruction (two instructions per 128-B line);
-// here a wave loads its 16-row x 256-k chunk as 8 instructions of 8 rows x 128 B (whole lines, like the
-// fp32 skinny kernel), parks it in its own 8 KiB of LDS (XOR-swizzled 16-byte slots, wave-private so no
-// workgroup barrier is involved) and reads MFMA fragments back with ds_read_b128.  One chunk (8 KiB per
-// wave) is in flight in registers while the previous one is multiplied.
-constexpr int WCH = 256;                       // k per chunk
 __device__ __forceinline__ int wslot(int row, int slot) { return row * (WCH * 2) + (((slot) ^ (row & 15)) << 4); }
 
-__global__ __launch_bounds__(SNT) void stream_mfma_lds_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ W,
-                                                              float* __restrict__ P, int M, int Ntot, int K) {
-  extern __shared__ __attribute__((aligned(16))) bf16_t xs_raw[];      // [2][16][SROW] x image, then 8 x 8 KiB weight tiles
-  bf16_t (*xs)[16][SROW] = reinterpret_cast<bf16_t (*)[16][SROW]>(xs_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  char* wbuf = reinterpret_cast<char*>(xs_raw) + (size_t)2 * 16 * SROW * sizeof(bf16_t) + (size_t)wave * 16 * WCH * 2;
+struct StreamGroups {
+  const int32_t* off;      // [G + 1] offsets into the sorted row list; nullptr = one dense group of M rows
+  const int32_t* xrows;    // [total] x row of each sorted row; nullptr = identity (off[g] + r)
+  int64_t w_stride;        // elements between consecutive groups' weight matrices
+};
+
+// Y: bf16, hi rows at Y, lo rows at Y + y_lo (row stride K).  P: [nz][p_rows][Ntot] fp32, p_slab = p_rows * Ntot.
+template <int MT>
+__global__ __launch_bounds__(1024) void stream_mfma_lds_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
+                                                               const bf16_t* __restrict__ W, float* __restrict__ P,
+                                                               int64_t p_slab, int M, int Ntot, int K, int ks,
+                                                               StreamGroups g) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t xs_raw[];      // [2][16*MT][ks + 8] x image, then nw x 8 KiB weight tiles
+  int row0 = 0, nrows = M;
+  if (g.off) {
+    row0 = g.off[blockIdx.z];
+    nrows = g.off[blockIdx.z + 1] - row0;
+    if (nrows <= 0) return;
+    W += (int64_t)blockIdx.z * g.w_stride;
+  }
+  constexpr int XR = 16 * MT;
+  const int srow = ks + 8;                                              // +16 B: conflict-free b128 fragment reads
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  char* wbuf = reinterpret_cast<char*>(xs_raw) + (size_t)2 * XR * srow * sizeof(bf16_t) + (size_t)wave * 16 * WCH * 2;
   const int z = blockIdx.y;
-  const int k0 = z * SKS, klen = min(SKS, K - k0);
+  const int k0 = z * ks, klen = min(ks, K - k0);
   const int fr = lane & 15, fq = lane >> 4;
   const int r8 = lane >> 3, c8 = lane & 7;
   const int ntiles = (Ntot + 15) >> 4;
   const int nch = (klen + WCH - 1) / WCH;
-  const int twaves = gridDim.x * (SNT / 64);
-  u32x4 ring[8];
-  // instruction i: rows (i & 1) * 8 + r8, 16-byte slot (i >> 1) * 8 + c8 of the chunk
+  const int twaves = gridDim.x * nw;
+  const int t0 = blockIdx.x * nw + wave;
+  const int mytiles = t0 < ntiles ? (ntiles - t0 + twaves - 1) / twaves : 0;
+  const int total = mytiles * nch;                  // chunks this wave streams, tile-major
+  u32x4 ring[8];                                    // one chunk (8 KiB per wave) in flight in registers
+  // instruction i of a chunk: rows (i & 1) * 8 + r8, 16-byte slot (i >> 1) * 8 + c8 — whole 128-byte lines
   auto issue = [&](int t, int ch) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -156,96 +81,157 @@ __global__ __launch_bounds__(SNT) void stream_mfma_lds_kernel(const bf16_t* __re
       ring[i] = *reinterpret_cast<const u32x4*>(W + (int64_t)n * K + k0 + k);
     }
   };
-  int t = blockIdx.x * (SNT / 64) + wave;
-  if (t < ntiles) issue(t, 0);
-  for (int i = tid; i < 2 * 16 * (SKS / 8); i += SNT) {
-    const int slot = i % (SKS / 8), m = (i / (SKS / 8)) % 16, h = i / (16 * (SKS / 8));
+  if (total > 0) issue(t0, 0);                      // weights first: their HBM latency overlaps the x staging
+  // ---- stage this slice of x (rows >= nrows are zero so that unused MFMA rows contribute nothing)
+  const int slots = ks >> 3;
+  const int mtn = (nrows + 15) >> 4;                // 16-row tiles of x actually populated
+  const int xr_used = mtn * 16;
+  for (int i = tid; i < 2 * xr_used * slots; i += blockDim.x) {
+    const int slot = i % slots, m = (i / slots) % xr_used, h = i / (xr_used * slots);
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (m < M && slot * 8 < klen) v = *reinterpret_cast<const u32x4*>(Y + ((int64_t)h * M + m) * K + k0 + slot * 8);
-    *reinterpret_cast<u32x4*>(&xs[h][m][slot * 8]) = v;
+    if (m < nrows && slot * 8 < klen) {
+      const int xr = g.xrows ? g.xrows[row0 + m] : row0 + m;
+      v = *reinterpret_cast<const u32x4*>(Y + h * y_lo + (int64_t)xr * K + k0 + slot * 8);
+    }
+    *reinterpret_cast<u32x4*>(xs_raw + (size_t)(h * XR + m) * srow + slot * 8) = v;
   }
-  const bf16_t* xh = &xs[0][fr][fq * 8];
-  const bf16_t* xl = &xs[1][fr][fq * 8];
+  const bf16_t* xh = xs_raw + (size_t)fr * srow + fq * 8;
+  const bf16_t* xl = xs_raw + (size_t)(XR + fr) * srow + fq * 8;
   __syncthreads();
-  for (; t < ntiles; t += twaves) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int ch = 0; ch < nch; ++ch) {
-      // park the landed chunk in LDS ...
+  f32x4 acc[MT];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        *reinterpret_cast<u32x4*>(wbuf + wslot((i & 1) * 8 + r8, (i >> 1) * 8 + c8)) = ring[i];
-      // ... request the next one (next chunk of this tile, or the first chunk of the wave's next tile) ...
-      if (ch + 1 < nch) issue(t, ch + 1);
-      else if (t + twaves < ntiles) issue(t + twaves, 0);
-      // ... and multiply this one: 8 MFMA steps of 32 k (columns >= klen of x are zero in LDS)
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int t = t0, ch = 0;
+  for (int q = 0; q < total; ++q) {
+    // park the landed chunk in the wave's LDS tile ...
 #pragma unroll
-      for (int sstep = 0; sstep < 8; ++sstep) {
-        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wbuf + wslot(fr, sstep * 4 + fq));
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xh + ch * WCH + sstep * 32);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(xl + ch * WCH + sstep * 32);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w, acc, 0, 0, 0);
+    for (int i = 0; i < 8; ++i)
+      *reinterpret_cast<u32x4*>(wbuf + wslot((i & 1) * 8 + r8, (i >> 1) * 8 + c8)) = ring[i];
+    // ... request the next one (next chunk of this tile, or the first chunk of the wave's next tile) ...
+    if (q + 1 < total) { if (ch + 1 < nch) issue(t, ch + 1); else issue(t + twaves, 0); }
+    // ... and multiply: 8 MFMA steps of 32 k (columns >= klen of x are zero in LDS)
+#pragma unroll
+    for (int sstep = 0; sstep < 8; ++sstep) {
+      const bf16x8 w = *reinterpret_cast<const bf16x8*>(wbuf + wslot(fr, sstep * 4 + fq));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (mt < mtn) {
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xh + (size_t)mt * 16 * srow + ch * WCH + sstep * 32);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(xl + (size_t)mt * 16 * srow + ch * WCH + sstep * 32);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w, acc[mt], 0, 0, 0);
+        }
       }
     }
-    const int nn = t * 16 + fr;
-    if (nn < Ntot) {
+    if (++ch == nch) {                              // tile done: D layout row m = fq*4 + r, col n = t*16 + fr
+      const int nn = t * 16 + fr;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = fq * 4 + r;
-        if (m < M) P[((int64_t)z * M + m) * Ntot + nn] = acc[r];
+      for (int mt = 0; mt < MT; ++mt) {
+        if (nn < Ntot) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = mt * 16 + fq * 4 + r;
+            if (m < nrows) P[(int64_t)z * p_slab + (int64_t)(row0 + m) * Ntot + nn] = acc[mt][r];
+          }
+        }
+        acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      ch = 0;
+      t += twaves;
     }
   }
+}
+
+struct StreamPlan { int ks, nw, gx, nz; size_t lds; };
+
+// Tuning knobs for in-process A/B (not part of the stable ABI): force the slice length (in 256-k chunks) and the
+// waves per workgroup.
+int g_kch = 0, g_nw = 0;
+
+// Launch shape for one [Ntot, K] matrix that has `slots` CUs to itself (dense: the whole chip; grouped: the chip's
+// share of one group).  One workgroup per CU (LDS-bound); the cost is the bytes a CU moves: weight chunks of its
+// waves + its x image + its share of the partial slabs (written here, read back by the reducing kernel).
+// E.g. RF w12 (1024 tiles x 12 chunks) runs as 4 slices of 768 x 64 workgroups x 8 waves = exactly 2 tiles per wave,
+// RF w3 (192 tiles x 32 chunks) as 16 slices of 512 x 16 workgroups x 12 waves = exactly 1 tile per wave.
+StreamPlan stream_plan(int mt, int Ntot, int K, int slots) {
+  const int ntiles = (Ntot + 15) / 16;
+  StreamPlan best{};
+  double best_cost = 1e30;
+  for (int kch = 1; kch <= MAX_KCH; ++kch) {
+    if (g_kch > 0 && kch != g_kch) continue;
+    const int ks = kch * WCH, nz = (K + ks - 1) / ks;
+    for (int nw = 8; nw <= 16; nw += 4) {
+      if (g_nw > 0 && nw != g_nw) continue;
+      const size_t lds = (size_t)2 * 16 * mt * (ks + 8) * sizeof(bf16_t) + (size_t)nw * 16 * WCH * 2;
+      if (lds > LDS_CAP) continue;
+      int gx = (int)mn_cdiv(ntiles, nw);
+      const int gxmax = slots / nz > 0 ? slots / nz : 1;
+      if (gx > gxmax) gx = gxmax;
+      const int tiles_w = (int)mn_cdiv(ntiles, (int64_t)gx * nw);
+      const double cost = (double)nw * tiles_w * kch * 8192.0 + kch * 16384.0 * mt +
+                          (double)nz * 16 * mt * Ntot * 8.0 / slots + (nz > slots ? 1e12 : 0.0);
+      if (cost < best_cost) { best_cost = cost; best = StreamPlan{ks, nw, gx, nz, lds}; }
+    }
+  }
+  return best;
+}
+
+template <int MT>
+void stream_launch(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab,
+                   int M, int Ntot, int K, const StreamGroups& g, hipStream_t st) {
+  static bool opted = false;
+  if (!opted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_lds_kernel<MT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP);
+    opted = true;
+  }
+  hipLaunchKernelGGL(stream_mfma_lds_kernel<MT>, dim3(pl.gx, pl.nz, G), dim3(pl.nw * 64), pl.lds, st, Y, y_lo, W, P, p_slab,
+                     M, Ntot, K, pl.ks, g);
+}
+
+// CUs one group of a grouped launch can count on: ~4 workgroups per CU over the groups expected to be active
+int group_slots(int G) {
+  const int s = (int)mn_cdiv((int64_t)4 * mn_num_cus(), G);
+  return s < 1 ? 1 : s;
 }
 
 }  // namespace
 
-// Tuning knobs for in-process A/B (not part of the stable ABI): mode 0 = direct fragment loads, 1 = LDS-staged.
-static int g_mode = -1, g_nt = -1, g_cap = -1;
-extern "C" void mn_stream_tune(int mode, int nt, int cap) { g_mode = mode; g_nt = nt; g_cap = cap; }
+extern "C" void mn_stream_tune_plan(int kch, int nw) { g_kch = kch; g_nw = nw; }
 
-// Internal: returns the number of K slices written (partials [nz][M][Ntot]).
-extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream) {
-  MN_CHECK_ARG(Y && W && P && M >= 1 && M <= 16 && Ntot >= 1 && K >= 8 && (K % 8) == 0, "mn_stream_mfma: bad args");
-  const int nz = (K + SKS - 1) / SKS;
-  const int ntiles = (Ntot + 15) / 16;
-  const int cus = mn_num_cus();
-  // 2 workgroups (66 KiB LDS each) per CU; every wave should get >= 1 tile
-  int gx = (int)mn_cdiv(ntiles, SNT / 64);
-  const int cap_x = g_cap > 0 ? g_cap : 4;
-  const int use_nt = g_nt >= 0 ? g_nt : 0;
-  const int cap = (int)mn_cdiv((int64_t)cap_x * cus, nz * 2);   // cap_x / 2 workgroups per CU
-  if (gx > cap) gx = cap;
-  if (gx < 1) gx = 1;
-  static bool opted = false;
-  if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    opted = true;
-  }
-  const int mode = g_mode >= 0 ? g_mode : 1;   // default: LDS-staged coalesced loads (12.9 vs 14.1 us on RF w3, equal on w12)
-  if (mode == 1) {   // LDS-staged, fully coalesced weight loads; one workgroup per CU
-    static bool opted2 = false;
-    if (!opted2) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      opted2 = true;
-    }
-    int gx2 = (int)mn_cdiv(ntiles, SNT / 64);
-    const int cap2 = (int)mn_cdiv(cus, nz);
-    if (gx2 > cap2) gx2 = cap2;
-    if (gx2 < 1) gx2 = 1;
-    const size_t lds2 = (size_t)2 * 16 * SROW * sizeof(bf16_t) + (size_t)(SNT / 64) * 16 * WCH * 2;
-    hipLaunchKernelGGL(stream_mfma_lds_kernel, dim3(gx2, nz), dim3(SNT), lds2, mn_stream(stream), Y, W, P, M, Ntot, K);
-    MN_CHECK_LAUNCH("mn_stream_mfma");
-    return nz;
-  }
-  const size_t lds = (size_t)2 * 16 * SROW * sizeof(bf16_t);
-  if (use_nt)
-    hipLaunchKernelGGL(stream_mfma_kernel<true>, dim3(gx, nz), dim3(SNT), lds, mn_stream(stream), Y, W, P, M, Ntot, K);
-  else
-    hipLaunchKernelGGL(stream_mfma_kernel<false>, dim3(gx, nz), dim3(SNT), lds, mn_stream(stream), Y, W, P, M, Ntot, K);
-  MN_CHECK_LAUNCH("mn_stream_mfma");
-  return nz;
+extern "C" int mn_stream_mfma_slices(int M, int Ntot, int K) {
+  return stream_plan(M > 16 ? 2 : 1, Ntot, K, mn_num_cus()).nz;
 }
 
-extern "C" int mn_stream_mfma_slices(int K) { return (K + SKS - 1) / SKS; }
+// Dense: Y [2][M][K] bf16 (hi rows then lo rows), W [Ntot][K], P [nz][M][Ntot].  Returns nz (< 0: error).
+extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream) {
+  MN_CHECK_ARG(Y && W && P && M >= 1 && M <= 32 && Ntot >= 1 && K >= 8 && (K % 8) == 0, "mn_stream_mfma: bad args");
+  const int mt = M > 16 ? 2 : 1;
+  const StreamPlan pl = stream_plan(mt, Ntot, K, mn_num_cus());
+  const StreamGroups g{nullptr, nullptr, 0};
+  if (mt == 1) stream_launch<1>(pl, 1, Y, (int64_t)M * K, W, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
+  else stream_launch<2>(pl, 1, Y, (int64_t)M * K, W, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
+  MN_CHECK_LAUNCH("mn_stream_mfma");
+  return pl.nz;
+}
+
+extern "C" int mn_stream_mfma_grouped_slices(int G, int max_rows, int Ntot, int K) {
+  return stream_plan(max_rows > 16 ? 2 : 1, Ntot, K, group_slots(G)).nz;
+}
+
+// Grouped: group g (of G) multiplies the x rows xrows[off[g] .. off[g+1]) (identity when xrows == NULL) by
+// W + g * w_stride and writes partial rows off[g].. of P [nz][p_rows][Ntot].  Y holds y_rows hi rows then y_rows lo
+// rows.  No group may have more than max_rows (<= 32) rows.  off / xrows live in device memory.
+extern "C" int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P,
+                                      int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows,
+                                      int Ntot, int K, void* stream) {
+  MN_CHECK_ARG(Y && W && P && off && G >= 1 && max_rows >= 1 && max_rows <= 32 && Ntot >= 1 && K >= 8 && (K % 8) == 0,
+               "mn_stream_mfma_grouped: bad args");
+  const int mt = max_rows > 16 ? 2 : 1;
+  const StreamPlan pl = stream_plan(mt, Ntot, K, group_slots(G));
+  const StreamGroups g{off, xrows, w_stride};
+  if (mt == 1) stream_launch<1>(pl, G, Y, (int64_t)y_rows * K, W, P, (int64_t)p_rows * Ntot, 0, Ntot, K, g, mn_stream(stream));
+  else stream_launch<2>(pl, G, Y, (int64_t)y_rows * K, W, P, (int64_t)p_rows * Ntot, 0, Ntot, K, g, mn_stream(stream));
+  MN_CHECK_LAUNCH("mn_stream_mfma_grouped");
+  return pl.nz;
+}

@@ -4,16 +4,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ming_univision_amd._lib import lib, ptr, current_stream
 L = lib()
-L.mn_stream_tune.argtypes = [ctypes.c_int] * 3; L.mn_stream_tune.restype = None
+L.mn_stream_tune_plan.argtypes = [ctypes.c_int] * 2; L.mn_stream_tune_plan.restype = None
 M = 16
 def bench(N2, K, variants, rounds=6, iters=24):
     ws = [torch.randn(N2, K, device="cuda").to(torch.bfloat16) for _ in range(6)]
     Y = torch.randn(2 * M, K, device="cuda").to(torch.bfloat16)
-    P = torch.empty(L.mn_stream_mfma_slices(K) * M * N2, device="cuda")
+    P = torch.empty(64 * M * N2, device="cuda")
     res = {v: [] for v in variants}
     for r in range(rounds):
         for v in variants:
-            L.mn_stream_tune(*v)
+            L.mn_stream_tune_plan(v[1], v[2])
             for i in range(3): L.mn_stream_mfma(ptr(Y), ptr(ws[i % 6]), ptr(P), M, N2, K, current_stream())
             torch.cuda.synchronize()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -22,8 +22,10 @@ def bench(N2, K, variants, rounds=6, iters=24):
             e.record(); torch.cuda.synchronize()
             res[v].append(s.elapsed_time(e) * 1e3 / iters)
     for v in variants:
-        t = sorted(res[v]); print(f"N={N2} K={K} mode={v[0]} nt={v[1]} cap={v[2]}: median {t[len(t)//2]:.1f} us  min {t[0]:.1f}  ({N2*K*2/t[len(t)//2]/1e3:.0f} GB/s)", flush=True)
-V = [(0, 0, 4), (0, 1, 4), (0, 0, 2), (0, 0, 8), (1, 0, 4)]
+        t = sorted(res[v]); print(f"N={N2} K={K} kch={v[1]} nw={v[2]}: median {t[len(t)//2]:.1f} us  min {t[0]:.1f}  ({N2*K*2/t[len(t)//2]/1e3:.0f} GB/s)", flush=True)
+V = [(1, 0, 0)] + [(1, k, n) for k in (1, 2, 3, 4) for n in (8, 12, 16)]
 bench(16384, 3072, V)
 bench(3072, 8192, V)
 bench(3072, 2048, V)
+bench(2048, 2048, V)
+bench(4096, 1024, V)
