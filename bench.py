@@ -32,8 +32,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tokens", type=int, default=256, help="visual tokens per image (256 = 512^2)")
     ap.add_argument("--prompt-len", type=int, default=40)
-    ap.add_argument("--images", type=int, default=8,
-                    help="images generated in lock-step per GPU (an image batch; 1 = the reference's batch-size-1 call; max 8)")
+    ap.add_argument("--images", type=int, default=16,
+                    help="images generated in lock-step per GPU (an image batch; 1 = the reference's batch-size-1 call; max 16 = 32 CFG rows)")
     ap.add_argument("--no-batch1", action="store_true", help="skip the extra batch-size-1 measurement")
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only; INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

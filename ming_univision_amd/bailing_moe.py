@@ -149,7 +149,7 @@ class BailingMoeDecoder:
 
     def step(self, x, row_seq, row_slot, row_pos, row_len, key_mask=None, image_mask=None, out=None, rows=None,
              x_row_div=1):
-        """One pass of the 28-layer stack over M <= 16 rows.
+        """One pass of the 28-layer stack over M <= 32 rows.
         x fp32 [M,H]; or [1,H] with rows=M to broadcast; or [M / x_row_div, H] with rows=M when the x_row_div CFG
         rows of an image share one embedding.  int32 device arrays per row; key_mask uint8 [M, >=len].
         Returns the post-final-norm hidden states [M,H] fp32."""
@@ -287,6 +287,9 @@ def build_cfg_rows(attention_mask, uncond_attention_mask, text_uncond_attention_
     return am
 
 
+MAX_ROWS = 32   # rows of one lock-step pass (two 16-row MFMA tiles)
+
+
 class ImageGenState:
     """Device-resident bookkeeping of one (possibly batched) generate_image call.
     Rows are image-major: row r belongs to image r // rpi and is its (r % rpi)-th CFG row; the KV sequence
@@ -340,7 +343,7 @@ def generate_images(dec: BailingMoeDecoder, rf, tok, start_embed, past_lens, att
     assert all(a.shape[0] == rpi for a in ams), "all images of a batch must have the same number of CFG rows"
     rows = B * rpi
     n_tok = cfg.num_image_tokens_for_gen
-    assert max(past_lens) + n_tok + 1 <= dec.t_max and rows <= 16
+    assert max(past_lens) + n_tok + 1 <= dec.t_max and rows <= MAX_ROWS
     if rpi > 1:   # replicate each prompt's KV to its CFG rows (:1891-1902) — device memcpy
         for i, past in enumerate(past_lens):
             for r in range(1, rpi):

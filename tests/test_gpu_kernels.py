@@ -208,9 +208,12 @@ def test_attn_prefill_hd64(ops, B, T, nh, causal):
 
 @pytest.mark.parametrize("M,N,K,epi,pro", [(9, 515, 2048, "none", "rmsnorm"), (16, 8192, 3072, "swiglu", "ln_mod"),
                                            (12, 3072, 8192, "resid_gate", "none"), (16, 32, 3072, "none", "ln_mod"),
-                                           (10, 1000, 32, "silu", "none"), (16, 3072, 2048, "resid", "add_silu")])
+                                           (10, 1000, 32, "silu", "none"), (16, 3072, 2048, "resid", "add_silu"),
+                                           (32, 8192, 3072, "swiglu", "ln_mod"), (24, 3072, 2048, "resid", "rmsnorm"),
+                                           (17, 100, 1408, "none", "none"), (31, 3072, 8192, "resid_gate", "none")])
 def test_skinny_medium_rows(ops, M, N, K, epi, pro):
-    """9..16 rows take the split-bf16 MFMA route (prologue -> split-K GEMM -> reduce+epilogue)."""
+    """5..32 rows take the split-bf16 MFMA route (prologue -> K-sliced streaming GEMM -> reduce+epilogue);
+    > 16 rows use two 16-row MFMA tiles per weight tile."""
     x = rnd(M, K, seed=70) * 1.5 + 0.2
     rows = 2 * N if epi == "swiglu" else N
     w, wf = bw(rows, K, seed=71, scale=K ** -0.5)
@@ -243,3 +246,40 @@ def test_skinny_medium_rows(ops, M, N, K, epi, pro):
         ref = y
     out = ops.skinny_gemm(x.cuda(), w, b, epilogue=epi, **kw)
     assert rel(out, ref) < 2e-5     # hi+lo bf16 split: 2^-17 relative per activation
+
+
+@pytest.mark.parametrize("G,max_rows,N,K,gather", [(10, 16, 2816, 2048, True), (7, 32, 2048, 1408, False),
+                                                   (3, 5, 100, 264, True)])
+def test_stream_mfma_grouped(ops, G, max_rows, N, K, gather):
+    """Grouped weight-streaming kernel (MoE experts): ragged groups incl. empty ones, gathered or contiguous x rows,
+    K not a multiple of the 256-k chunk; partial slabs summed here in float64."""
+    import ctypes as C
+    from ming_univision_amd._lib import lib, ptr, current_stream, check
+    g = torch.Generator().manual_seed(5)
+    cnt = torch.randint(0, max_rows + 1, (G,), generator=g)
+    cnt[1] = 0
+    cnt[G - 1] = max_rows
+    off = torch.zeros(G + 1, dtype=torch.int32)
+    off[1:] = cnt.cumsum(0)
+    total = int(off[-1])
+    n_x = 9 if gather else total
+    xrows = torch.randint(0, n_x, (total,), generator=g, dtype=torch.int32) if gather else None
+    x = rnd(n_x, K, seed=90)
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    Y = torch.cat([hi, lo], 0).contiguous().cuda()
+    w, wf = bw(G, N, K, seed=91, scale=K ** -0.5)
+    nz = lib().mn_stream_mfma_grouped_slices(G, max_rows, N, K)
+    P = torch.full((nz, total, N), float("nan"), device="cuda")
+    offd = off.cuda()
+    xr = xrows.cuda() if gather else None
+    rc = lib().mn_stream_mfma_grouped(ptr(Y), n_x, ptr(w), N * K, ptr(P), total, ptr(offd), ptr(xr), G, max_rows, N, K,
+                                      current_stream())
+    assert rc == nz, rc
+    out = P.double().sum(0).cpu()
+    xe = (hi.double() + lo.double())
+    for gi in range(G):
+        for r in range(int(off[gi]), int(off[gi + 1])):
+            src = int(xrows[r]) if gather else r
+            ref = wf[gi].double() @ xe[src]
+            assert rel(out[r], ref) < 1e-5, (gi, r)

@@ -252,9 +252,10 @@ def test_rf_persistent_matches_per_launch_path():
     torch.cuda.synchronize()
 
 
-def test_batched_generation_matches_single_image():
-    """generate_images with B images in lock-step (rows = B x CFG rows through the M<=16 kernels, incl. the
-    MFMA route for > 8 rows) must reproduce each image's batch-size-1 result."""
+@pytest.mark.parametrize("B", [4, 10])
+def test_batched_generation_matches_single_image(B):
+    """generate_images with B images in lock-step (rows = B x CFG rows: 12 rows = one MFMA row tile, 30 rows =
+    two; grouped-expert MoE path) must reproduce each image's batch-size-1 result."""
     from ming_univision_amd.bailing_moe import BailingMoeDecoder, generate_image, generate_images
     from ming_univision_amd.mingtok import MingTok
     from ming_univision_amd.rf_head import RectifiedFlowHead
@@ -262,7 +263,7 @@ def test_batched_generation_matches_single_image():
     sd = llm_sd(g["llm_config"], g["rf_config"], g["seed"])
     dsd = to_dev(sd)
     cfg = C.BailingMoeConfig(**g["llm_config"])
-    B, R = 4, 3                                   # 12 rows -> exercises the > 8-row route
+    R = 3
     dec = BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=32, n_seq=B * R)
     rf = RectifiedFlowHead(dsd, cfg.hidden_size, g["rf_config"])
     lsd = to_dev(synth_state_dict(C.linear_proj_param_shapes(128, 256, 2), g["seed"]))
@@ -271,7 +272,7 @@ def test_batched_generation_matches_single_image():
                                (lsd["linear_proj.2.weight"], lsd["linear_proj.2.bias"])])
     gen = torch.Generator().manual_seed(3)
     T = g["ids"].shape[1]
-    prompts = [g["ids"][0]] + [torch.randint(0, 400, (T - i,), generator=gen) for i in range(1, B)]   # ragged lengths
+    prompts = [g["ids"][0]] + [torch.randint(0, 400, (T - i % 4,), generator=gen) for i in range(1, B)]   # ragged lengths
     noises = torch.randn(B, cfg.num_image_tokens_for_gen + 1, 32, generator=gen)
     noises[0] = g["noises"]
     start = dec.embed(torch.tensor([cfg.image_start_token]).cuda())
