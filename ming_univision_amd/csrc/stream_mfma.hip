@@ -34,6 +34,8 @@ constexpr int MAX_KCH = 4;           // K-slice <= 1024
 constexpr size_t LDS_CAP = 160 * 1024;
 
 __device__ __forceinline__ int wslot(int row, int slot) { return row * (WCH * 2) + (((slot) ^ (row & 15)) << 4); }
+// x image: element offset of 16-byte slot `slot` of row `row` (row stride = ks elements, a multiple of 256)
+__device__ __forceinline__ int xslot(int row, int srow, int slot) { return row * srow + ((slot ^ (row & 15)) << 3); }
 
 struct StreamGroups {
   const int32_t* off;      // [G + 1] offsets into the sorted row list; nullptr = one dense group of M rows
@@ -42,12 +44,12 @@ struct StreamGroups {
 };
 
 // Y: bf16, hi rows at Y, lo rows at Y + y_lo (row stride K).  P: [nz][p_rows][Ntot] fp32, p_slab = p_rows * Ntot.
-template <int MT>
+template <int MT, bool XFIRST, bool NTL>
 __global__ __launch_bounds__(1024) void stream_mfma_lds_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
                                                                const bf16_t* __restrict__ W, float* __restrict__ P,
                                                                int64_t p_slab, int M, int Ntot, int K, int ks,
                                                                StreamGroups g) {
-  extern __shared__ __attribute__((aligned(16))) bf16_t xs_raw[];      // [2][16*MT][ks + 8] x image, then nw x 8 KiB weight tiles
+  extern __shared__ __attribute__((aligned(16))) bf16_t xs_raw[];      // [2][16*MT][ks] x image, then nw x 8 KiB weight tiles
   int row0 = 0, nrows = M;
   if (g.off) {
     row0 = g.off[blockIdx.z];
@@ -56,7 +58,8 @@ __global__ __launch_bounds__(1024) void stream_mfma_lds_kernel(const bf16_t* __r
     W += (int64_t)blockIdx.z * g.w_stride;
   }
   constexpr int XR = 16 * MT;
-  const int srow = ks + 8;                                              // +16 B: conflict-free b128 fragment reads
+  constexpr int XL = 8 * MT;                                            // x loads per thread: 2*XR*(1024/8) / 512 threads at most
+  const int srow = ks;                                                  // 16-byte slots XOR-swizzled by row (xslot)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6;
   char* wbuf = reinterpret_cast<char*>(xs_raw) + (size_t)2 * XR * srow * sizeof(bf16_t) + (size_t)wave * 16 * WCH * 2;
@@ -70,74 +73,104 @@ __global__ __launch_bounds__(1024) void stream_mfma_lds_kernel(const bf16_t* __r
   const int t0 = blockIdx.x * nw + wave;
   const int mytiles = t0 < ntiles ? (ntiles - t0 + twaves - 1) / twaves : 0;
   const int total = mytiles * nch;                  // chunks this wave streams, tile-major
-  u32x4 ring[8];                                    // one chunk (8 KiB per wave) in flight in registers
-  // instruction i of a chunk: rows (i & 1) * 8 + r8, 16-byte slot (i >> 1) * 8 + c8 — whole 128-byte lines
-  auto issue = [&](int t, int ch) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = (i & 1) * 8 + r8;
-      const int n = min(t * 16 + row, Ntot - 1);
-      const int k = min(ch * WCH + ((i >> 1) * 8 + c8) * 8, klen - 8);
-      ring[i] = *reinterpret_cast<const u32x4*>(W + (int64_t)n * K + k0 + k);
-    }
-  };
-  if (total > 0) issue(t0, 0);                      // weights first: their HBM latency overlaps the x staging
-  // ---- stage this slice of x (rows >= nrows are zero so that unused MFMA rows contribute nothing)
+  // ---- this slice of x goes to registers FIRST: loads retire in order, so the x image can be written to LDS
+  // while the (younger) weight loads below are still in flight
   const int slots = ks >> 3;
   const int mtn = (nrows + 15) >> 4;                // 16-row tiles of x actually populated
   const int xr_used = mtn * 16;
-  for (int i = tid; i < 2 * xr_used * slots; i += blockDim.x) {
-    const int slot = i % slots, m = (i / slots) % xr_used, h = i / (xr_used * slots);
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (m < nrows && slot * 8 < klen) {
-      const int xr = g.xrows ? g.xrows[row0 + m] : row0 + m;
-      v = *reinterpret_cast<const u32x4*>(Y + h * y_lo + (int64_t)xr * K + k0 + slot * 8);
+  const int xcount = 2 * xr_used * slots;
+  u32x4 xv[XL];
+  auto load_x = [&]() {
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+      const int i = tid + j * blockDim.x;
+      xv[j] = u32x4{0u, 0u, 0u, 0u};
+      if (i < xcount) {
+        const int slot = i % slots, m = (i / slots) % xr_used, h = i / (xr_used * slots);
+        if (m < nrows && slot * 8 < klen) {           // rows >= nrows stay zero: unused MFMA rows contribute nothing
+          const int xr = g.xrows ? g.xrows[row0 + m] : row0 + m;
+          xv[j] = *reinterpret_cast<const u32x4*>(Y + h * y_lo + (int64_t)xr * K + k0 + slot * 8);
+        }
+      }
     }
-    *reinterpret_cast<u32x4*>(xs_raw + (size_t)(h * XR + m) * srow + slot * 8) = v;
+  };
+  if (XFIRST) load_x();
+  // ---- weight ring: one chunk (8 KiB per wave) in flight in registers
+  constexpr int DEPTH = 1;
+  u32x4 ring[DEPTH][8];
+  int it = t0, ich = 0;                             // issue cursor (tile, chunk), tile-major
+  // instruction i of a chunk: rows (i & 1) * 8 + r8, 16-byte slot (i >> 1) * 8 + c8 — whole 128-byte lines
+  auto issue = [&](u32x4 (&dst)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = (i & 1) * 8 + r8;
+      const int n = min(it * 16 + row, Ntot - 1);
+      const int k = min(ich * WCH + ((i >> 1) * 8 + c8) * 8, klen - 8);
+      if (NTL) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (int64_t)n * K + k0 + k));
+      else dst[i] = *reinterpret_cast<const u32x4*>(W + (int64_t)n * K + k0 + k);
+    }
+    if (++ich == nch) { ich = 0; it += twaves; }
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    if (d < total) issue(ring[d]);
+  if (!XFIRST) load_x();
+#pragma unroll
+  for (int j = 0; j < XL; ++j) {
+    const int i = tid + j * blockDim.x;
+    if (i < xcount) {
+      const int slot = i % slots, m = (i / slots) % xr_used, h = i / (xr_used * slots);
+      *reinterpret_cast<u32x4*>(xs_raw + xslot(h * XR + m, srow, slot)) = xv[j];
+    }
   }
-  const bf16_t* xh = xs_raw + (size_t)fr * srow + fq * 8;
-  const bf16_t* xl = xs_raw + (size_t)(XR + fr) * srow + fq * 8;
   __syncthreads();
   f32x4 acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   int t = t0, ch = 0;
-  for (int q = 0; q < total; ++q) {
-    // park the landed chunk in the wave's LDS tile ...
+  for (int q0 = 0; q0 < total; q0 += DEPTH) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      *reinterpret_cast<u32x4*>(wbuf + wslot((i & 1) * 8 + r8, (i >> 1) * 8 + c8)) = ring[i];
-    // ... request the next one (next chunk of this tile, or the first chunk of the wave's next tile) ...
-    if (q + 1 < total) { if (ch + 1 < nch) issue(t, ch + 1); else issue(t + twaves, 0); }
-    // ... and multiply: 8 MFMA steps of 32 k (columns >= klen of x are zero in LDS)
+    for (int d = 0; d < DEPTH; ++d) {
+      const int q = q0 + d;
+      if (q < total) {
+        // park the landed chunk in the wave's LDS tile ...
 #pragma unroll
-    for (int sstep = 0; sstep < 8; ++sstep) {
-      const bf16x8 w = *reinterpret_cast<const bf16x8*>(wbuf + wslot(fr, sstep * 4 + fq));
+        for (int i = 0; i < 8; ++i)
+          *reinterpret_cast<u32x4*>(wbuf + wslot((i & 1) * 8 + r8, (i >> 1) * 8 + c8)) = ring[d][i];
+        // ... refill its registers with the chunk DEPTH ahead ...
+        if (q + DEPTH < total) issue(ring[d]);
+        // ... and multiply: 8 MFMA steps of 32 k (columns >= klen of x are zero in LDS)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if (mt < mtn) {
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xh + (size_t)mt * 16 * srow + ch * WCH + sstep * 32);
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(xl + (size_t)mt * 16 * srow + ch * WCH + sstep * 32);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w, acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w, acc[mt], 0, 0, 0);
-        }
-      }
-    }
-    if (++ch == nch) {                              // tile done: D layout row m = fq*4 + r, col n = t*16 + fr
-      const int nn = t * 16 + fr;
+        for (int sstep = 0; sstep < 8; ++sstep) {
+          const bf16x8 w = *reinterpret_cast<const bf16x8*>(wbuf + wslot(fr, sstep * 4 + fq));
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if (nn < Ntot) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = mt * 16 + fq * 4 + r;
-            if (m < nrows) P[(int64_t)z * p_slab + (int64_t)(row0 + m) * Ntot + nn] = acc[mt][r];
+          for (int mt = 0; mt < MT; ++mt) {
+            if (mt < mtn) {
+              const int xs4 = ch * (WCH / 8) + sstep * 4 + fq;       // XR % 16 == 0: hi and lo rows swizzle alike
+              const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xs_raw + xslot(mt * 16 + fr, srow, xs4));
+              const bf16x8 al = *reinterpret_cast<const bf16x8*>(xs_raw + xslot(XR + mt * 16 + fr, srow, xs4));
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w, acc[mt], 0, 0, 0);
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w, acc[mt], 0, 0, 0);
+            }
           }
         }
-        acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (++ch == nch) {                          // tile done: D layout row m = fq*4 + r, col n = t*16 + fr
+          const int nn = t * 16 + fr;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            if (nn < Ntot) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int m = mt * 16 + fq * 4 + r;
+                if (m < nrows) P[(int64_t)z * p_slab + (int64_t)(row0 + m) * Ntot + nn] = acc[mt][r];
+              }
+            }
+            acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          ch = 0;
+          t += twaves;
+        }
       }
-      ch = 0;
-      t += twaves;
     }
   }
 }
@@ -162,7 +195,7 @@ StreamPlan stream_plan(int mt, int Ntot, int K, int slots) {
     const int ks = kch * WCH, nz = (K + ks - 1) / ks;
     for (int nw = 8; nw <= 16; nw += 4) {
       if (g_nw > 0 && nw != g_nw) continue;
-      const size_t lds = (size_t)2 * 16 * mt * (ks + 8) * sizeof(bf16_t) + (size_t)nw * 16 * WCH * 2;
+      const size_t lds = (size_t)2 * 16 * mt * ks * sizeof(bf16_t) + (size_t)nw * 16 * WCH * 2;
       if (lds > LDS_CAP) continue;
       int gx = (int)mn_cdiv(ntiles, nw);
       const int gxmax = slots / nz > 0 ? slots / nz : 1;
@@ -176,17 +209,34 @@ StreamPlan stream_plan(int mt, int Ntot, int K, int slots) {
   return best;
 }
 
-template <int MT>
-void stream_launch(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab,
-                   int M, int Ntot, int K, const StreamGroups& g, hipStream_t st) {
+int g_depth = 0;
+
+int g_ntl = 1;   // nontemporal weight loads: 21.7 vs 23.4 us on RF w12 at 16 rows, 28.4 vs 29.4 at 32
+
+template <int MT, bool XFIRST, bool NTL>
+void stream_launch_d(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab,
+                     int M, int Ntot, int K, const StreamGroups& g, hipStream_t st) {
   static bool opted = false;
   if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_lds_kernel<MT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_lds_kernel<MT, XFIRST, NTL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP);
     opted = true;
   }
-  hipLaunchKernelGGL(stream_mfma_lds_kernel<MT>, dim3(pl.gx, pl.nz, G), dim3(pl.nw * 64), pl.lds, st, Y, y_lo, W, P, p_slab,
-                     M, Ntot, K, pl.ks, g);
+  hipLaunchKernelGGL((stream_mfma_lds_kernel<MT, XFIRST, NTL>), dim3(pl.gx, pl.nz, G), dim3(pl.nw * 64), pl.lds, st, Y, y_lo, W, P,
+                     p_slab, M, Ntot, K, pl.ks, g);
+}
+
+template <int MT>
+void stream_launch(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab,
+                   int M, int Ntot, int K, const StreamGroups& g, hipStream_t st) {
+  const bool xfirst = g_depth != 2;
+  if (g_ntl) {
+    if (xfirst) stream_launch_d<MT, true, true>(pl, G, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+    else stream_launch_d<MT, false, true>(pl, G, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+  } else {
+    if (xfirst) stream_launch_d<MT, true, false>(pl, G, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+    else stream_launch_d<MT, false, false>(pl, G, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+  }
 }
 
 // CUs one group of a grouped launch can count on: ~4 workgroups per CU over the groups expected to be active
@@ -198,6 +248,7 @@ int group_slots(int G) {
 }  // namespace
 
 extern "C" void mn_stream_tune_plan(int kch, int nw) { g_kch = kch; g_nw = nw; }
+extern "C" void mn_stream_tune_depth(int depth) { g_depth = depth & 15; g_ntl = depth >> 4; }
 
 extern "C" int mn_stream_mfma_slices(int M, int Ntot, int K) {
   return stream_plan(M > 16 ? 2 : 1, Ntot, K, mn_num_cus()).nz;
