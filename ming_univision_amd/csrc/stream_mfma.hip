@@ -58,7 +58,7 @@ __global__ __launch_bounds__(1024) void stream_mfma_lds_kernel(const bf16_t* __r
     W += (int64_t)blockIdx.z * g.w_stride;
   }
   constexpr int XR = 16 * MT;
-  constexpr int XL = 8 * MT;                                            // x loads per thread: 2*XR*(1024/8) / 512 threads at most
+  constexpr int RPW = (2 * XR + 7) / 8;                                  // x rows (hi and lo) per wave at >= 8 waves
   const int srow = ks;                                                  // 16-byte slots XOR-swizzled by row (xslot)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6;
@@ -78,18 +78,21 @@ __global__ __launch_bounds__(1024) void stream_mfma_lds_kernel(const bf16_t* __r
   const int slots = ks >> 3;
   const int mtn = (nrows + 15) >> 4;                // 16-row tiles of x actually populated
   const int xr_used = mtn * 16;
-  const int xcount = 2 * xr_used * slots;
-  u32x4 xv[XL];
+  // wave w takes rows w, w + nw, ... of the 2 * xr_used hi/lo rows, a lane the 16-byte slots lane and lane + 64
+  // (no integer division: at 768-k slices it cost more than the loads)
+  u32x4 xv[RPW][2];
   auto load_x = [&]() {
 #pragma unroll
-    for (int j = 0; j < XL; ++j) {
-      const int i = tid + j * blockDim.x;
-      xv[j] = u32x4{0u, 0u, 0u, 0u};
-      if (i < xcount) {
-        const int slot = i % slots, m = (i / slots) % xr_used, h = i / (xr_used * slots);
-        if (m < nrows && slot * 8 < klen) {           // rows >= nrows stay zero: unused MFMA rows contribute nothing
+    for (int j = 0; j < RPW; ++j) {
+      const int rr = wave + j * nw;
+      const int h = rr >= xr_used ? 1 : 0, m = rr - h * xr_used;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int slot = lane + u * 64;
+        xv[j][u] = u32x4{0u, 0u, 0u, 0u};
+        if (rr < 2 * xr_used && m < nrows && slot * 8 < klen) {   // rows >= nrows stay zero: unused MFMA rows contribute nothing
           const int xr = g.xrows ? g.xrows[row0 + m] : row0 + m;
-          xv[j] = *reinterpret_cast<const u32x4*>(Y + h * y_lo + (int64_t)xr * K + k0 + slot * 8);
+          xv[j][u] = *reinterpret_cast<const u32x4*>(Y + h * y_lo + (int64_t)xr * K + k0 + slot * 8);
         }
       }
     }
@@ -116,11 +119,13 @@ __global__ __launch_bounds__(1024) void stream_mfma_lds_kernel(const bf16_t* __r
     if (d < total) issue(ring[d]);
   if (!XFIRST) load_x();
 #pragma unroll
-  for (int j = 0; j < XL; ++j) {
-    const int i = tid + j * blockDim.x;
-    if (i < xcount) {
-      const int slot = i % slots, m = (i / slots) % xr_used, h = i / (xr_used * slots);
-      *reinterpret_cast<u32x4*>(xs_raw + xslot(h * XR + m, srow, slot)) = xv[j];
+  for (int j = 0; j < RPW; ++j) {
+    const int rr = wave + j * nw;
+    const int h = rr >= xr_used ? 1 : 0, m = rr - h * xr_used;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int slot = lane + u * 64;
+      if (rr < 2 * xr_used && slot < slots) *reinterpret_cast<u32x4*>(xs_raw + xslot(h * XR + m, srow, slot)) = xv[j][u];
     }
   }
   __syncthreads();
