@@ -32,8 +32,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tokens", type=int, default=256, help="visual tokens per image (256 = 512^2)")
     ap.add_argument("--prompt-len", type=int, default=40)
-    ap.add_argument("--images", type=int, default=16,
-                    help="images generated in lock-step per GPU (an image batch; 1 = the reference's batch-size-1 call; max 16 = 32 CFG rows)")
+    ap.add_argument("--images", type=int, default=48,
+                    help="images generated in lock-step per GPU (an image batch; 1 = the reference's batch-size-1 call; 16 per group = 32 CFG rows)")
+    ap.add_argument("--groups", type=int, default=3,
+                    help="split the image batch into this many lock-step groups on separate HIP streams")
     ap.add_argument("--no-batch1", action="store_true", help="skip the extra batch-size-1 measurement")
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only; INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -79,7 +81,7 @@ def build_models(args, device, seed):
     return cfg, dec, rf, tok
 
 
-def one_image(cfg, dec, rf, tok, prompts, noises):
+def one_image(cfg, dec, rf, tok, prompts, noises, groups=1):
     """prefill -> forced <image> -> generate_images (2 CFG rows per image) -> pixel decode.
     prompts [B, T] ids, noises [B, n+1, 32]; B images advance in lock-step (B = 1: the reference's call)."""
     from ming_univision_amd.bailing_moe import generate_images
@@ -90,7 +92,7 @@ def one_image(cfg, dec, rf, tok, prompts, noises):
     am = torch.ones(1, T + 1, dtype=torch.long)
     unc = torch.ones(1, T + 1, dtype=torch.long)
     unc[0, 2:T - 2] = 0                     # uncond row: the user's text span is masked out
-    return generate_images(dec, rf, tok, start, [T] * B, [am] * B, [unc] * B, [unc.clone()] * B, noises)
+    return generate_images(dec, rf, tok, start, [T] * B, [am] * B, [unc] * B, [unc.clone()] * B, noises, n_groups=groups)
 
 
 def dominant_kernel_roofline(rf, rows, iters=48):
@@ -235,8 +237,8 @@ def main():
     rows = 2
 
     for _ in range(args.warmup):
-        one_image(cfg, dec, rf, tok, prompt, noises)
-    dt, out = grp.timed(lambda: one_image(cfg, dec, rf, tok, prompt, noises), args.steps)
+        one_image(cfg, dec, rf, tok, prompt, noises, args.groups)
+    dt, out = grp.timed(lambda: one_image(cfg, dec, rf, tok, prompt, noises, args.groups), args.steps)
     finite = bool(torch.isfinite(out["image"]).all()) and bool(torch.isfinite(out["latents"]).all())
 
     batch1 = None
@@ -248,8 +250,8 @@ def main():
                   "ms_per_image": dt1 * 1e3}
 
     if rank == 0:
-        if rows * args.images >= 5:
-            dom = dominant_kernel_roofline_stream(rf, rows * args.images)
+        if rows * ((args.images + args.groups - 1) // args.groups) >= 5:
+            dom = dominant_kernel_roofline_stream(rf, rows * ((args.images + args.groups - 1) // args.groups))
         else:
             dom = dominant_kernel_roofline(rf, rows)
         total_tokens = args.tokens * args.steps * world * args.images
@@ -260,7 +262,7 @@ def main():
             "config": {"workload": "Ming-UniVision-16B-A3B text->image 512^2 (BASELINE configs[3]): %d-token prompt, "
                                    "2 CFG rows, %d visual tokens/image, RF head w=%d d=%d steps=%d, MingTok pixel decode; "
                                    "random-init bf16 weights" % (args.prompt_len, args.tokens, rf.w, rf.depth, rf.steps),
-                       "images_per_step_per_gpu": args.images, "parallelism": "replicas x%d" % world, "tiny": bool(args.tiny)},
+                       "images_per_step_per_gpu": args.images, "stream_groups": args.groups, "parallelism": "replicas x%d" % world, "tiny": bool(args.tiny)},
             "roofline": {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": dom["traffic"], "kernel": dom["kernel"],
                          "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"]},

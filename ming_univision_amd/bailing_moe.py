@@ -142,10 +142,11 @@ class BailingMoeDecoder:
 
     # ---- stepping -------------------------------------------------------------------------
     def _workspace(self, rows):
-        if rows not in self._ws:
+        key = (rows, torch.cuda.current_stream().cuda_stream)      # one scratch area per stream: groups overlap
+        if key not in self._ws:
             n = lib().mn_llm_workspace_bytes(C.byref(self.struct), rows, self.t_max)
-            self._ws[rows] = torch.empty(n, dtype=torch.uint8, device=self.device)
-        return self._ws[rows]
+            self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.device)
+        return self._ws[key]
 
     def step(self, x, row_seq, row_slot, row_pos, row_len, key_mask=None, image_mask=None, out=None, rows=None,
              x_row_div=1):
@@ -320,11 +321,60 @@ class ImageGenState:
                                     current_stream()), "mn_rows_advance")
 
 
+_STREAM_POOL = {}
+
+
+def _group_streams(device, n):
+    """n side streams for lock-step groups (created once per device and reused)."""
+    pool = _STREAM_POOL.setdefault(str(device), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
+class _GroupRun:
+    """One lock-step group of images of a generate_images call: its rows, outputs and per-token work."""
+
+    def __init__(self, dec, rf, tok, ams, past_lens, noises, seq_base, start_embed, sampler_kw, skip_last_sample):
+        cfg = dec.cfg
+        self.dec, self.rf, self.tok, self.start_embed = dec, rf, tok, start_embed
+        self.kw, self.skip_last = sampler_kw, skip_last_sample
+        self.B, self.rpi = len(ams), ams[0].shape[0]
+        self.rows = self.B * self.rpi
+        self.n_tok = cfg.num_image_tokens_for_gen
+        dev = dec.device
+        self.st = ImageGenState(dec, ams, past_lens, seq_base=seq_base)
+        self.latents = torch.empty(self.n_tok, self.B, rf.target, dtype=torch.float32, device=dev)
+        self.sems = torch.empty(self.n_tok, self.B, tok.feature_dim, dtype=torch.float32, device=dev)
+        self.embed = torch.empty(self.B, cfg.hidden_size, dtype=torch.float32, device=dev)
+        self.hidden = torch.empty(self.rows, cfg.hidden_size, dtype=torch.float32, device=dev)
+        self.noise_t = noises.reshape(self.B, -1, rf.target).transpose(0, 1).contiguous()     # [n+1, B, latent]
+        self.sem_state = tok.new_decode_state(n_seq=self.B, t_max=self.n_tok)
+
+    def token(self, ti):
+        st, dec, rf = self.st, self.dec, self.rf
+        if ti == 0:
+            dec.step(self.start_embed, st.row_seq, st.row_slot, st.row_pos, st.row_len, st.key_mask, None, out=self.hidden,
+                     rows=self.rows)
+        else:
+            dec.step(self.embed, st.row_seq, st.row_slot, st.row_pos, st.row_len, st.key_mask, None, out=self.hidden,
+                     rows=self.rows, x_row_div=self.rpi)
+        if ti < self.n_tok:
+            rf.sample(self.hidden, self.noise_t[ti], out=self.latents[ti], n_images=self.B, **self.kw)
+            self.tok.decode_step(self.latents[ti], self.sem_state, sem_out=self.sems[ti], embed_out=self.embed)
+            st.advance()
+        elif not self.skip_last:
+            rf.sample(self.hidden, self.noise_t[ti], n_images=self.B, **self.kw)
+
+
 def generate_images(dec: BailingMoeDecoder, rf, tok, start_embed, past_lens, attention_masks, uncond_attention_masks,
                     text_uncond_attention_masks, noises, temperature=1.0, text_cfg=3.0, image_cfg=1.1,
-                    decode_pixels=True, skip_last_sample=True):
+                    decode_pixels=True, skip_last_sample=True, n_groups=1):
     """BailingMoeForCausalLM.generate_image (modeling_bailing_moe.py:1844-1965) for B >= 1 independent images
-    advancing in lock-step (B = 1 is the reference's call; B > 1 amortises every weight byte over B images).
+    (B = 1 is the reference's call).  The images advance in lock-step, so every weight byte streamed from HBM is
+    shared by all rows of a group (<= MAX_ROWS rows); with n_groups > 1 the batch is cut into groups that run on
+    separate HIP streams, so one group's short kernels (norms, attention, reductions) run beside another's
+    weight streaming.
 
     dec: decoder whose KV sequence i*R already holds image i's `past_lens[i]` prompt tokens (R = CFG rows per
     image, equal for all images of the batch).  start_embed fp32 [1,H]: the `<image>` token embedding.
@@ -341,36 +391,34 @@ def generate_images(dec: BailingMoeDecoder, rf, tok, start_embed, past_lens, att
     ams = [build_cfg_rows(a, u, t).cpu() for a, u, t in zip(attention_masks, uncond_attention_masks, text_uncond_attention_masks)]
     rpi = ams[0].shape[0]
     assert all(a.shape[0] == rpi for a in ams), "all images of a batch must have the same number of CFG rows"
-    rows = B * rpi
     n_tok = cfg.num_image_tokens_for_gen
-    assert max(past_lens) + n_tok + 1 <= dec.t_max and rows <= MAX_ROWS
+    assert 1 <= n_groups <= B
+    per = (B + n_groups - 1) // n_groups                     # images per group
+    assert max(past_lens) + n_tok + 1 <= dec.t_max and per * rpi <= MAX_ROWS
     if rpi > 1:   # replicate each prompt's KV to its CFG rows (:1891-1902) — device memcpy
         for i, past in enumerate(past_lens):
             for r in range(1, rpi):
                 dec.kv_cache[:, i * rpi + r, :, :, :past].copy_(dec.kv_cache[:, i * rpi, :, :, :past])
-    st = ImageGenState(dec, ams, past_lens)
-    dev = dec.device
-    D = tok.feature_dim
-    latents = torch.empty(n_tok, B, rf.target, dtype=torch.float32, device=dev)
-    sems = torch.empty(n_tok, B, D, dtype=torch.float32, device=dev)
-    embed = torch.empty(B, cfg.hidden_size, dtype=torch.float32, device=dev)
-    hidden = torch.empty(rows, cfg.hidden_size, dtype=torch.float32, device=dev)
     noises = noises.reshape(B, -1, rf.target)
-    noise_t = noises.transpose(0, 1).contiguous()                    # [n+1, B, latent]
-    sem_state = tok.new_decode_state(n_seq=B, t_max=n_tok)
+    kw = dict(temperature=temperature, text_cfg=text_cfg, image_cfg=image_cfg)
+    main = torch.cuda.current_stream()
+    streams = [main] if n_groups == 1 else _group_streams(dec.device, n_groups)
+    runs = []
+    for g, s in enumerate(streams):
+        lo, hi = g * per, min(B, (g + 1) * per)
+        s.wait_stream(main)
+        with torch.cuda.stream(s):
+            runs.append(_GroupRun(dec, rf, tok, ams[lo:hi], past_lens[lo:hi], noises[lo:hi], lo * rpi, start_embed, kw,
+                                  skip_last_sample))
     for ti in range(n_tok + 1):
-        if ti == 0:
-            dec.step(start_embed, st.row_seq, st.row_slot, st.row_pos, st.row_len, st.key_mask, None, out=hidden, rows=rows)
-        else:
-            dec.step(embed, st.row_seq, st.row_slot, st.row_pos, st.row_len, st.key_mask, None, out=hidden, rows=rows,
-                     x_row_div=rpi)
-        if ti < n_tok:
-            rf.sample(hidden, noise_t[ti], temperature, text_cfg, image_cfg, out=latents[ti], n_images=B)
-            tok.decode_step(latents[ti], sem_state, sem_out=sems[ti], embed_out=embed)
-            st.advance()
-        elif not skip_last_sample:
-            rf.sample(hidden, noise_t[ti], temperature, text_cfg, image_cfg, n_images=B)
-    sem_b = sems.transpose(0, 1).contiguous()
+        for run, s in zip(runs, streams):
+            with torch.cuda.stream(s):
+                run.token(ti)
+    for s in streams:
+        main.wait_stream(s)
+    latents = torch.cat([r.latents for r in runs], dim=1)
+    sem_b = torch.cat([r.sems for r in runs], dim=1).transpose(0, 1).contiguous()
+    hidden = torch.cat([r.hidden for r in runs], dim=0)
     image = tok.forward_pixel_decoder(sem_b) if decode_pixels else None
     am_out = [torch.cat((a, torch.ones(rpi, n_tok, dtype=a.dtype)), dim=-1) for a in ams]
     return dict(image=image, latents=latents.transpose(0, 1), sem=sem_b, last_hidden=hidden, attention_mask=am_out,

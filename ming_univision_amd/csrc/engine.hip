@@ -116,19 +116,43 @@ __global__ void rf_ada_combine_kernel(float* __restrict__ C, const bf16_t* __res
 // P: [nz][M][Ntot] fp32 partials (stream_mfma.hip); Y: [2][M][K] bf16 (hi rows, lo rows).
 __global__ __launch_bounds__(256) void rf_glue_swiglu_split_kernel(const float* __restrict__ P, int nz, int M, int hidden,
                                                                    const bf16_t* __restrict__ b12, bf16_t* __restrict__ Y) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;    // 4 consecutive columns per thread (hidden % 4 == 0)
   if (i >= (int64_t)M * hidden) return;
   const int m = (int)(i / hidden), n = (int)(i % hidden);
   const int64_t slab = (int64_t)M * 2 * hidden;
-  float y1 = b12 ? bf16_to_f32(b12[n]) : 0.f, y2 = b12 ? bf16_to_f32(b12[n + hidden]) : 0.f;
-  for (int z = 0; z < nz; ++z) {
-    y1 += P[z * slab + (int64_t)m * 2 * hidden + n];
-    y2 += P[z * slab + (int64_t)m * 2 * hidden + hidden + n];
+  f4 y1 = {0.f, 0.f, 0.f, 0.f}, y2 = {0.f, 0.f, 0.f, 0.f};
+  if (b12) {
+    y1 = f4{bf16_to_f32(b12[n]), bf16_to_f32(b12[n + 1]), bf16_to_f32(b12[n + 2]), bf16_to_f32(b12[n + 3])};
+    y2 = f4{bf16_to_f32(b12[n + hidden]), bf16_to_f32(b12[n + hidden + 1]), bf16_to_f32(b12[n + hidden + 2]),
+            bf16_to_f32(b12[n + hidden + 3])};
   }
-  const float v = silu_f(y1) * y2;
-  const bf16_t hi = f32_to_bf16(v);
-  Y[i] = hi;
-  Y[(int64_t)M * hidden + i] = f32_to_bf16(v - bf16_to_f32(hi));
+  const float* p1 = P + (int64_t)m * 2 * hidden + n;
+  const float* p2 = p1 + hidden;
+  int z = 0;
+  for (; z + 4 <= nz; z += 4) {                    // 8 independent 16-byte loads in flight
+    const f4 a0 = *reinterpret_cast<const f4*>(p1 + (z + 0) * slab), b0 = *reinterpret_cast<const f4*>(p2 + (z + 0) * slab);
+    const f4 a1 = *reinterpret_cast<const f4*>(p1 + (z + 1) * slab), b1 = *reinterpret_cast<const f4*>(p2 + (z + 1) * slab);
+    const f4 a2 = *reinterpret_cast<const f4*>(p1 + (z + 2) * slab), b2 = *reinterpret_cast<const f4*>(p2 + (z + 2) * slab);
+    const f4 a3 = *reinterpret_cast<const f4*>(p1 + (z + 3) * slab), b3 = *reinterpret_cast<const f4*>(p2 + (z + 3) * slab);
+    y1 += (a0 + a1) + (a2 + a3);
+    y2 += (b0 + b1) + (b2 + b3);
+  }
+  for (; z < nz; ++z) {
+    y1 += *reinterpret_cast<const f4*>(p1 + z * slab);
+    y2 += *reinterpret_cast<const f4*>(p2 + z * slab);
+  }
+  bf16_t hi[4], lo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float v = silu_f(y1[j]) * y2[j];
+    hi[j] = f32_to_bf16(v);
+    lo[j] = f32_to_bf16(v - bf16_to_f32(hi[j]));
+  }
+  *reinterpret_cast<u2*>(Y + i) = u2{(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
+  *reinterpret_cast<u2*>(Y + (int64_t)M * hidden + i) =
+      u2{(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
 }
 
 // One block per row.  P != NULL: h[m] += gate[m] * (sum_z P + b3)   (ResBlock residual, diff_loss:272);
@@ -152,7 +176,13 @@ __global__ __launch_bounds__(1024) void rf_glue_resid_ln_split_kernel(
       const float* pp = P + (int64_t)m * w + col;
       const int64_t slab = (int64_t)M * w;
       int z = 0;
-      for (; z + 4 <= nz; z += 4) {              // independent 16-byte loads, 4 in flight
+      for (; z + 8 <= nz; z += 8) {              // independent 16-byte loads, 8 in flight
+        f4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f4*>(pp + (z + j) * slab);
+        y += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      }
+      for (; z + 4 <= nz; z += 4) {
         const f4 a = *reinterpret_cast<const f4*>(pp + (z + 0) * slab), b = *reinterpret_cast<const f4*>(pp + (z + 1) * slab);
         const f4 c = *reinterpret_cast<const f4*>(pp + (z + 2) * slab), d = *reinterpret_cast<const f4*>(pp + (z + 3) * slab);
         y += (a + b) + (c + d);
@@ -303,6 +333,11 @@ static inline void dbg_sync(const char* what, hipStream_t st) {
 // ===========================================================================================
 // Rectified-flow head
 // ===========================================================================================
+// rows >= 5 run the RF blocks as the matrix-core chain; its glue kernels move 4 columns (16 bytes) per thread
+static bool rf_chain_ok(const mn_rf_head* h, int rows) {
+  return mn_skinny_workspace_bytes(rows, h->w, h->w, 0) > 0 && h->w <= 4096 && (h->w % 4) == 0 && (h->hidden % 4) == 0;
+}
+
 static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, float** z, float** c, float** ada,
                        float** hh, float** hid, float** v, float** x, bf16_t** y, unsigned** bar, char** skws,
                        size_t* skws_bytes, bf16_t** ya, bf16_t** yb, float** pbuf) {
@@ -321,7 +356,7 @@ static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, floa
                                    {h->w, h->hidden, 0}, {h->target, h->w, 0}, {h->w, h->target, 0}});
   *skws = cv.take<char>(*skws_bytes);
   // matrix-core chain (rows >= 5): split activations of both GEMVs and the K-slice partial slabs
-  const bool chain = mn_skinny_workspace_bytes(rows, h->w, h->w, 0) > 0 && h->w <= 4096 && (h->w % 4) == 0 && (A % 4) == 0;
+  const bool chain = rf_chain_ok(h, rows);
   const size_t p12 = (size_t)mn_stream_mfma_slices(rows, 2 * h->hidden, h->w) * 2 * h->hidden;
   const size_t p3 = (size_t)mn_stream_mfma_slices(rows, h->w, h->hidden) * h->w;
   const size_t pf = (size_t)mn_stream_mfma_slices(rows, h->target, h->w) * h->target;
@@ -360,7 +395,7 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   float* pbuf;
   const size_t need = rf_carve(h, rows, workspace, workspace_bytes, &z, &c, &ada, &hh, &hid, &v, &x, &y, &bar, &skws, &skws_bytes,
                                &ya, &yb, &pbuf);
-  const bool chain = mn_skinny_workspace_bytes(rows, h->w, h->w, 0) > 0 && h->w <= 4096 && (h->w % 4) == 0;
+  const bool chain = rf_chain_ok(h, rows);
   t_sk_ws = skws; t_sk_ws_bytes = skws_bytes;
   if (need > workspace_bytes) { mn_set_error("mn_rf_sample: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
   hipStream_t st = mn_stream(stream);
@@ -404,7 +439,7 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
         const float* mod = ada + (int64_t)b * 3 * w;
         int nz = mn_stream_mfma(ya, h->w12[b], pbuf, rows, 2 * hid_n, w, stream);
         if (nz < 0) return nz;
-        hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)rows * hid_n, 256)), dim3(256), 0, st, pbuf, nz,
+        hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)rows * hid_n, 1024)), dim3(256), 0, st, pbuf, nz,
                            rows, hid_n, h->b12[b], yb);
         nz = mn_stream_mfma(yb, h->w3[b], pbuf, rows, w, hid_n, stream);
         if (nz < 0) return nz;
@@ -498,17 +533,24 @@ __global__ __launch_bounds__(256) void moe_group_split_kernel(const int32_t* __r
 __global__ __launch_bounds__(256) void moe_combine_resid_kernel(const float* __restrict__ P, int nz, int64_t slab, int M, int H,
                                                                 int n_slot, const int32_t* __restrict__ pair_pos,
                                                                 const float* __restrict__ tw, float* __restrict__ h) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;    // 4 consecutive columns per thread (H % 4 == 0)
   if (i >= (int64_t)M * H) return;
   const int m = (int)(i / H), n = (int)(i % H);
-  float acc = 0.f;
-  for (int s = 0; s < n_slot; ++s) {
-    const float* pp = P + (int64_t)pair_pos[m * n_slot + s] * H + n;
-    float y = 0.f;
-    for (int z = 0; z < nz; ++z) y += pp[z * slab];
-    acc += tw[m * n_slot + s] * y;
+  f4 acc = *reinterpret_cast<const f4*>(h + i);
+  for (int s = 0; s < n_slot; s += 2) {           // two slots x nz slabs of independent 16-byte loads in flight
+    const bool two = s + 1 < n_slot;
+    const float* pa = P + (int64_t)pair_pos[m * n_slot + s] * H + n;
+    const float* pb = P + (int64_t)pair_pos[m * n_slot + (two ? s + 1 : s)] * H + n;
+    f4 ya = {0.f, 0.f, 0.f, 0.f}, yb = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < nz; ++z) {
+      ya += *reinterpret_cast<const f4*>(pa + z * slab);
+      yb += *reinterpret_cast<const f4*>(pb + z * slab);
+    }
+    acc += tw[m * n_slot + s] * ya;
+    if (two) acc += tw[m * n_slot + s + 1] * yb;
   }
-  h[i] += acc;
+  *reinterpret_cast<f4*>(h + i) = acc;
 }
 
 struct MoeWs {
@@ -533,7 +575,7 @@ static size_t moe_carve(Carver& cv, int rows, int H, int I, int G, int n_slot, M
 constexpr int MOE_MFMA_MIN_ROWS = 5;
 static bool moe_mfma_ok(const mn_llm* m, int rows) {
   return rows >= MOE_MFMA_MIN_ROWS && rows * (m->top_k + m->n_shared_slots) <= 1024 &&
-         m->n_experts + m->n_shared_slots <= 256 && (m->hidden % 8) == 0 && (m->moe_inter % 8) == 0;
+         m->n_experts + m->n_shared_slots <= 256 && (m->hidden % 8) == 0 && (m->moe_inter % 8) == 0;   // % 4: vector glue
 }
 
 struct LlmWs {
@@ -620,11 +662,11 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
       int nz = mn_stream_mfma_grouped(w.moe.y1, M, m->w_gate_up[l], (int64_t)2 * I * H, w.moe.p1, P, w.moe.off, w.moe.xrows,
                                       G, M, 2 * I, H, stream);
       if (nz < 0) return nz;
-      hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)P * I, 256)), dim3(256), 0, st, w.moe.p1, nz, P, I,
+      hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)P * I, 1024)), dim3(256), 0, st, w.moe.p1, nz, P, I,
                          (const bf16_t*)nullptr, w.moe.y2);
       nz = mn_stream_mfma_grouped(w.moe.y2, P, m->w_down[l], (int64_t)H * I, w.moe.p2, P, w.moe.off, nullptr, G, M, H, I, stream);
       if (nz < 0) return nz;
-      hipLaunchKernelGGL(moe_combine_resid_kernel, dim3(mn_cdiv((int64_t)M * H, 256)), dim3(256), 0, st, w.moe.p2, nz,
+      hipLaunchKernelGGL(moe_combine_resid_kernel, dim3(mn_cdiv((int64_t)M * H, 1024)), dim3(256), 0, st, w.moe.p2, nz,
                          (int64_t)P * H, M, H, n_slot, w.moe.pair_pos, w.tw, w.h);
       continue;
     }

@@ -231,7 +231,7 @@ class MingTok:
         assert latent_norm.dtype == torch.float32 and latent_norm.is_cuda and latent_norm.is_contiguous()
         if sem_out is None:
             sem_out = torch.empty(M, self.feature_dim, dtype=torch.float32, device=self.device)
-        key = (M, state.t_max)
+        key = (M, state.t_max, torch.cuda.current_stream().cuda_stream)
         if key not in self._ws:
             n = lib().mn_semdec_workspace_bytes(C.byref(s), M, state.t_max)
             self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.device)

@@ -87,10 +87,11 @@ class RectifiedFlowHead:
         return self.depth * per_block + self.t["ada_w"].numel() * 2
 
     def _workspace(self, rows, device):
-        if rows not in self._ws:
+        key = (rows, torch.cuda.current_stream().cuda_stream)      # one scratch area per stream: groups overlap
+        if key not in self._ws:
             n = lib().mn_rf_workspace_bytes(C.byref(self.struct), rows)
-            self._ws[rows] = torch.empty(n, dtype=torch.uint8, device=device)
-        return self._ws[rows]
+            self._ws[key] = torch.empty(n, dtype=torch.uint8, device=device)
+        return self._ws[key]
 
     def sample(self, hidden, noise, temperature=1.0, text_cfg=3.0, image_cfg=1.1, out=None, n_images=1):
         """hidden [rows, llm_hidden] fp32: last hidden state of each CFG row, image-major (rows = n_images x R).

@@ -252,10 +252,11 @@ def test_rf_persistent_matches_per_launch_path():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("B", [4, 10])
-def test_batched_generation_matches_single_image(B):
+@pytest.mark.parametrize("B,groups", [(4, 1), (10, 1), (6, 3)])
+def test_batched_generation_matches_single_image(B, groups):
     """generate_images with B images in lock-step (rows = B x CFG rows: 12 rows = one MFMA row tile, 30 rows =
-    two; grouped-expert MoE path) must reproduce each image's batch-size-1 result."""
+    two; grouped-expert MoE path; groups > 1: lock-step groups overlapped on separate HIP streams) must reproduce
+    each image's batch-size-1 result."""
     from ming_univision_amd.bailing_moe import BailingMoeDecoder, generate_image, generate_images
     from ming_univision_amd.mingtok import MingTok
     from ming_univision_amd.rf_head import RectifiedFlowHead
@@ -293,7 +294,7 @@ def test_batched_generation_matches_single_image(B):
         dec.prefill(dec.embed(prompts[i].cuda()), seq=i * R, past=0)
         am, un, tu = (g["mask"], g["uncond"], g["rows3_tuncond"]) if i == 0 else masks(prompts[i].numel())
         ams.append(am); uns.append(un); tus.append(tu)
-    out = generate_images(dec, rf, tok, start, [p.numel() for p in prompts], ams, uns, tus, noises.cuda())
+    out = generate_images(dec, rf, tok, start, [p.numel() for p in prompts], ams, uns, tus, noises.cuda(), n_groups=groups)
     assert out["image"].shape[0] == B
     for i in range(B):
         assert rel_err(out["latents"][i], singles[i]["latents"]) < TOL, i
