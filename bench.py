@@ -272,10 +272,12 @@ def main():
             res["batch1"] = batch1
         # whole-token HBM accounting: bytes that must cross HBM per visual token / measured time per token
         ada_bytes = rf.t["ada_w"].numel() * 2          # read once per token (all steps in one GEMM)
+        per_group = (args.images + args.groups - 1) // args.groups
         tok_bytes = (rf.steps * (rf.weight_bytes_per_step() - ada_bytes) + ada_bytes
-                     + dec.weight_bytes_active(min(64, 6 * rows * args.images)) + 0.61e9)
-        res["token_level"] = {"algorithmic_GB_per_lockstep_token": tok_bytes / 1e9,
-                              "achieved_GBs": tok_bytes / (dt / (args.tokens * args.steps)) / 1e9}
+                     + dec.weight_bytes_active(min(64, 6 * rows * per_group)) + 0.61e9)
+        # every group streams the weights once per lock-step token
+        res["token_level"] = {"algorithmic_GB_per_group_token": tok_bytes / 1e9, "groups": args.groups,
+                              "achieved_GBs": args.groups * tok_bytes / (dt / (args.tokens * args.steps)) / 1e9}
         if not args.no_cpu_baseline and not args.tiny:
             try:
                 res["cpu_baseline"] = cpu_baseline(args, rows)

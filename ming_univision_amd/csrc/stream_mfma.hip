@@ -11,7 +11,7 @@
 //   * a wave loads its 16-row x 256-k chunk as 8 instructions of 8 rows x 128 B (whole cache lines), parks
 //     it in its own 8 KiB of LDS (XOR-swizzled 16-byte slots; wave-private, so no workgroup barrier is
 //     involved) and reads MFMA B fragments back with ds_read_b128; the next chunk is in flight in registers
-//     while this one is multiplied (deeper rings measured slower: 25.9 / 26.8 / 27.9 / 30.6 us at depth 1-4;
+//     while this one is multiplied (deeper rings measured no faster;
 //     B fragments loaded straight from HBM, 16 rows x 64 B per instruction, also slower: 14.2 vs 12.9 us on RF w3);
 //   * A fragments (x): lane l holds x[m = l & 15][k + (l >> 4) * 8 .. +8], ds_read_b128 of hi and of lo;
 //   * D: lane l, reg r holds out[m = (l >> 4) * 4 + r][n0 + (l & 15)].
@@ -44,8 +44,8 @@ struct StreamGroups {
 };
 
 // Y: bf16, hi rows at Y, lo rows at Y + y_lo (row stride K).  P: [nz][p_rows][Ntot] fp32, p_slab = p_rows * Ntot.
-template <int MT, bool XFIRST, bool NTL>
-__global__ __launch_bounds__(1024) void stream_mfma_lds_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
+template <int MT, int DEPTH, int MAXT>
+__global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
                                                                const bf16_t* __restrict__ W, float* __restrict__ P,
                                                                int64_t p_slab, int M, int Ntot, int K, int ks,
                                                                StreamGroups g) {
@@ -97,9 +97,8 @@ __global__ __launch_bounds__(1024) void stream_mfma_lds_kernel(const bf16_t* __r
       }
     }
   };
-  if (XFIRST) load_x();
+  load_x();   // before the weights: loads retire in order, so the x image never waits behind a weight chunk
   // ---- weight ring: one chunk (8 KiB per wave) in flight in registers
-  constexpr int DEPTH = 1;
   u32x4 ring[DEPTH][8];
   int it = t0, ich = 0;                             // issue cursor (tile, chunk), tile-major
   // instruction i of a chunk: rows (i & 1) * 8 + r8, 16-byte slot (i >> 1) * 8 + c8 — whole 128-byte lines
@@ -109,15 +108,14 @@ __global__ __launch_bounds__(1024) void stream_mfma_lds_kernel(const bf16_t* __r
       const int row = (i & 1) * 8 + r8;
       const int n = min(it * 16 + row, Ntot - 1);
       const int k = min(ich * WCH + ((i >> 1) * 8 + c8) * 8, klen - 8);
-      if (NTL) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (int64_t)n * K + k0 + k));
-      else dst[i] = *reinterpret_cast<const u32x4*>(W + (int64_t)n * K + k0 + k);
+      // nontemporal: every weight byte is used once (21.7 vs 23.4 us on RF w12 at 16 rows)
+      dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (int64_t)n * K + k0 + k));
     }
     if (++ich == nch) { ich = 0; it += twaves; }
   };
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
     if (d < total) issue(ring[d]);
-  if (!XFIRST) load_x();
 #pragma unroll
   for (int j = 0; j < RPW; ++j) {
     const int rr = wave + j * nw;
@@ -214,34 +212,26 @@ StreamPlan stream_plan(int mt, int Ntot, int K, int slots) {
   return best;
 }
 
-int g_depth = 0;
-
-int g_ntl = 1;   // nontemporal weight loads: 21.7 vs 23.4 us on RF w12 at 16 rows, 28.4 vs 29.4 at 32
-
-template <int MT, bool XFIRST, bool NTL>
+template <int MT, int DEPTH, int MAXT>
 void stream_launch_d(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab,
                      int M, int Ntot, int K, const StreamGroups& g, hipStream_t st) {
   static bool opted = false;
   if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_lds_kernel<MT, XFIRST, NTL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_lds_kernel<MT, DEPTH, MAXT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP);
     opted = true;
   }
-  hipLaunchKernelGGL((stream_mfma_lds_kernel<MT, XFIRST, NTL>), dim3(pl.gx, pl.nz, G), dim3(pl.nw * 64), pl.lds, st, Y, y_lo, W, P,
+  hipLaunchKernelGGL((stream_mfma_lds_kernel<MT, DEPTH, MAXT>), dim3(pl.gx, pl.nz, G), dim3(pl.nw * 64), pl.lds, st, Y, y_lo, W, P,
                      p_slab, M, Ntot, K, pl.ks, g);
 }
 
 template <int MT>
 void stream_launch(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab,
                    int M, int Ntot, int K, const StreamGroups& g, hipStream_t st) {
-  const bool xfirst = g_depth != 2;
-  if (g_ntl) {
-    if (xfirst) stream_launch_d<MT, true, true>(pl, G, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
-    else stream_launch_d<MT, false, true>(pl, G, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
-  } else {
-    if (xfirst) stream_launch_d<MT, true, false>(pl, G, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
-    else stream_launch_d<MT, false, false>(pl, G, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
-  }
+  // 8-wave workgroups compile for 512 threads, larger ones for 1024
+  // (a 2-deep ring measured 2-4 % slower at every shape: 20.4 vs 20.0 us on RF w12 at 16 rows, 24.6 vs 23.8 at 32)
+  if (pl.nw <= 8) stream_launch_d<MT, 1, 512>(pl, G, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+  else stream_launch_d<MT, 1, 1024>(pl, G, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
 }
 
 // CUs one group of a grouped launch can count on: ~4 workgroups per CU over the groups expected to be active
@@ -253,7 +243,6 @@ int group_slots(int G) {
 }  // namespace
 
 extern "C" void mn_stream_tune_plan(int kch, int nw) { g_kch = kch; g_nw = nw; }
-extern "C" void mn_stream_tune_depth(int depth) { g_depth = depth & 15; g_ntl = depth >> 4; }
 
 extern "C" int mn_stream_mfma_slices(int M, int Ntot, int K) {
   return stream_plan(M > 16 ? 2 : 1, Ntot, K, mn_num_cus()).nz;
