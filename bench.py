@@ -121,7 +121,7 @@ def dominant_kernel_roofline(rf, rows, iters=48):
     us = s.elapsed_time(e) * 1e3 / iters
     nbytes = 2 * hid * w * 2          # algorithmic bytes: the bf16 weight matrix, read once
     traffic = None                    # HBM bytes per launch from the committed PMC pass (same kernel, same shape)
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_skinny_w12_rows2.json")
     if os.path.exists(pmc) and hid == 8192 and w == 3072 and rows == 2:
         traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
     return dict(traffic=traffic, kernel="skinny_kernel<rows,R,SWIGLU>(RF w12: N=2x%d, K=%d)" % (hid, w), us=us, bytes=nbytes,
