@@ -95,7 +95,7 @@ typedef struct mn_skinny_args {
   void* ws; size_t ws_bytes;
 } mn_skinny_args;
 
-/* 1 <= M <= 16 (batch / nseg forms: M <= 8). */
+/* 1 <= M <= 32 (batch / nseg forms: M <= 8). */
 int mn_skinny_gemm(const mn_skinny_args* args, void* stream);
 size_t mn_skinny_workspace_bytes(int M, int N, int K, int epilogue);
 
@@ -268,7 +268,7 @@ typedef struct mn_rf_head {
 } mn_rf_head;
 
 /* hidden [rows, llm_hidden] fp32 (last hidden states of the LLM step), rows = n_images x R image-major with
- * R = 1 (no CFG), 2 ([cond, uncond]) or 3 ([cond, uncond, text_uncond]) rows per image; rows <= 16.
+ * R = 1 (no CFG), 2 ([cond, uncond]) or 3 ([cond, uncond, text_uncond]) rows per image; rows <= 32.
  * noise [n_images, target] fp32; latent_out [n_images, target] fp32 (all CFG rows of an image carry the same
  * latent).  n_images = 1 is the reference's batch-size-1 call.  Workspace: mn_rf_workspace_bytes(h, rows). */
 size_t mn_rf_workspace_bytes(const mn_rf_head* h, int rows);
@@ -276,7 +276,7 @@ int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld_hidden, in
                  const float* noise, float temperature, float text_cfg, float image_cfg, float* latent_out,
                  void* workspace, size_t workspace_bytes, void* stream);
 
-/* Bailing-MoE decoder stack, decode-style step for M <= 16 rows
+/* Bailing-MoE decoder stack, decode-style step for M <= 32 rows
  * (BailingMoeModel.forward, modeling_bailing_moe.py:1391-1540, with q_len rows per sequence). */
 typedef struct mn_llm {
   int32_t hidden, n_layers, n_q, n_kv, head_dim, n_experts, top_k, n_shared_slots, moe_inter;
@@ -310,7 +310,7 @@ int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int
  * device-resident row_slot / row_pos / row_len arrays between autoregressive steps without a host round trip. */
 int mn_rows_advance(int32_t* a, int32_t* b, int32_t* c, int M, int delta, void* stream);
 
-/* MingTok semantic decoder, cached causal decode step for M <= 8 rows of ONE sequence each
+/* MingTok semantic decoder, cached causal decode step for M <= 32 rows of ONE sequence each
  * (MingTok.forward_feature_decoder, modeling_mingtok.py:165-174 -> TransformerDecoder.forward_features,
  * vision_transformer.py:382-451) followed by linear_proj (modeling_bailingmm.py:111-115). */
 typedef struct mn_semdec {
