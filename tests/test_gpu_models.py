@@ -225,6 +225,39 @@ def test_facade_generate_text_and_image(tmp_path):
     assert seqs2.shape[1] == 6 and model.past_len > ids.shape[1] + n_tok
 
 
+def test_checkpoint_directory_roundtrip(tmp_path):
+    """MingUniVisionInfer(model_dir): config.json + safetensors shards keyed by the reference's parameter names
+    (vision.*, model.model.layers.*, model.vis_head.*, model.diffloss.*, linear_proj.*) load
+    unchanged and give the same greedy tokens as the state-dict constructor; the chat-level generate() runs."""
+    from safetensors.torch import save_file
+    from ming_univision_amd.infer import MingUniVisionInfer
+    from ming_univision_amd.modeling import MingUniVisionForConditionalGeneration
+    g = load_golden("genimg_tiny")
+    llm_cfg = dict(g["llm_config"]); llm_cfg["eos_token_id"] = 1
+    cfg = C.MingUniVisionConfig(mlp_depth=2, llm_config=llm_cfg, vishead_diffloss_config=g["rf_config"],
+                                mingtok_config=g["mingtok_config"])
+    sd = llm_sd(g["llm_config"], g["rf_config"], g["seed"])
+    ckpt = {"model." + k: v for k, v in sd.items()}
+    ckpt.update({"vision." + k: v for k, v in mingtok_sd(g["mingtok_config"], g["seed"]).items()})
+    ckpt.update(synth_state_dict(C.linear_proj_param_shapes(128, 256, 2), g["seed"]))
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    (d / "config.json").write_text(cfg.to_json_string())
+    keys = sorted(ckpt)
+    half = len(keys) // 2
+    for i, part in enumerate((keys[:half], keys[half:])):                # two shards, bf16 like the published checkpoint
+        save_file({k: ckpt[k].to(torch.bfloat16).contiguous() for k in part}, str(d / f"model-0000{i + 1}-of-00002.safetensors"))
+    infer = MingUniVisionInfer(str(d), t_max=64)
+    direct = MingUniVisionForConditionalGeneration(cfg, state_dict=ckpt, seed=g["seed"], t_max=64)
+    ids = g["ids"]
+    a = infer.model.generate(input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=5)
+    b = direct.generate(input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=5)
+    assert a.tolist() == b.tolist()
+    infer.reset_inner_state()
+    text = infer.generate([{"role": "HUMAN", "content": [{"type": "text", "text": "hi"}]}], max_new_tokens=3)
+    assert isinstance(text, str)
+
+
 def test_rf_persistent_matches_per_launch_path():
     """The persistent RF-block kernel (grid barriers, cross-phase prefetch) must give the same latents as the
     two-launches-per-block path, at the full head size and for 1/2/3 CFG rows; the barrier error word stays 0."""
