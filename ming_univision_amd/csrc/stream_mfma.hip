@@ -11,7 +11,8 @@
 //   * a wave loads its 16-row x 256-k chunk as 8 instructions of 8 rows x 128 B (whole cache lines), parks
 //     it in its own 8 KiB of LDS (XOR-swizzled 16-byte slots; wave-private, so no workgroup barrier is
 //     involved) and reads MFMA B fragments back with ds_read_b128; the next chunk is in flight in registers
-//     while this one is multiplied (deeper rings measured no faster;
+//     while this one is multiplied (deeper rings, parking chunk 0 before the x barrier and nontemporal partial
+//     stores all measured no faster;
 //     B fragments loaded straight from HBM, 16 rows x 64 B per instruction, also slower: 14.2 vs 12.9 us on RF w3);
 //   * A fragments (x): lane l holds x[m = l & 15][k + (l >> 4) * 8 .. +8], ds_read_b128 of hi and of lo;
 //   * D: lane l, reg r holds out[m = (l >> 4) * 4 + r][n0 + (l & 15)].
