@@ -135,6 +135,15 @@ int mn_rope_kv_append(const float* qkv, int64_t ldqkv, int M, int n_q, int n_kv,
                       int rope, const float* cos_tab, const float* sin_tab,
                       const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_pos,
                       float q_scale, float* q_out, float* kv_cache, int64_t t_max, void* stream);
+/*    3D rotary variant (BailingMoe3DRotaryEmbedding :413-425 + apply_multimodal_rotary_pos_emb :463-469, the
+ *    `rope_scaling.type == "3D"` branch at :780-782): row_pos is [3][M] = temporal, height, width positions; rotary
+ *    frequency i (of each half of the head) follows the t stream for i < sec_t, the h stream for the next sec_h, the
+ *    w stream for the rest (mrope_section [16, 24, 24] at hd = 128).  sec_t == 0 is the Legacy rotary above.  With
+ *    equal t/h/w positions the result is bit-identical to Legacy. */
+int mn_rope_kv_append_3d(const float* qkv, int64_t ldqkv, int M, int n_q, int n_kv, int hd,
+                         int rope, const float* cos_tab, const float* sin_tab,
+                         const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_pos, int sec_t, int sec_h,
+                         float q_scale, float* q_out, float* kv_cache, int64_t t_max, void* stream);
 
 /*    out[m] = softmax(q[m] . K[seq]^T + mask) V[seq] over keys j < row_len[m] with
  *    key_mask[m*ld_mask + j] != 0 (key_mask NULL = all ones; a row with every key masked is undefined).
@@ -293,6 +302,7 @@ typedef struct mn_llm {
   const uint16_t* final_norm;        /* [H] */
   const float *cos_tab, *sin_tab;    /* [n_pos, hd/2] */
   int32_t n_pos;
+  int32_t mrope_sec_t, mrope_sec_h;  /* 0, 0: Legacy rotary, row_pos [M]; else 3D rotary sections, row_pos [3][M] (t, h, w) */
 } mn_llm;
 
 size_t mn_llm_workspace_bytes(const mn_llm* m, int rows, int64_t t_max);

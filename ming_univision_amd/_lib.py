@@ -67,6 +67,7 @@ class Llm(C.Structure):
         ("final_norm", C.c_void_p),
         ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p),
         ("n_pos", C.c_int32),
+        ("mrope_sec_t", C.c_int32), ("mrope_sec_h", C.c_int32),
     ]
 
 
@@ -108,6 +109,7 @@ SYMBOLS = {
     "mn_stream_mfma_grouped_slices": (_i, [_i, _i, _i, _i]),
     "mn_moe_router": (_i, [_p, _i64, _p, _f, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "mn_rope_kv_append": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _i64, _p]),
+    "mn_rope_kv_append_3d": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _i64, _p]),
     "mn_attn_decode_workspace_bytes": (_sz, [_i, _i, _i, _i64]),
     "mn_attn_decode": (_i, [_p, _i, _i, _i, _i, _p, _i64, _p, _p, _p, _i64, _p, _p, _sz, _p]),
     "mn_gemm_bf16": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _i, _i, _i, _i, _p]),

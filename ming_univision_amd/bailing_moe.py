@@ -59,7 +59,12 @@ class BailingMoeDecoder:
                  t_max=2048, n_seq=3, n_pos=None):
         """layers: list of dicts with bf16 CUDA tensors: ln1, wqkv, wdense, ln2, gate, image_gate (or None),
         w_gate_up, w_down (see pack_experts).  Use `from_state_dict` / `synthetic` to build them."""
-        assert cfg.rope_scaling is None, "hot path uses the Legacy rotary (SURVEY.md item 3)"
+        rs = cfg.rope_scaling
+        assert rs is None or rs.get("type") == "3D", "Legacy or 3D rotary only (linear / NTK / YaRN are dead code, SURVEY.md a27)"
+        # 3D rotary (:413-425, 463-469): same tables, per-frequency choice among the t / h / w position streams.
+        # Every caller of the reference passes 2-D positions (= equal streams = Legacy, bit-identical); step() also
+        # takes int32 [3, M] positions.
+        self.mrope_section = [16, 24, 24] if rs is not None else None
         assert cfg.first_k_dense_replace == 0 and not cfg.use_qkv_bias and not cfg.use_bias
         self.cfg = cfg
         self.layers = layers
@@ -85,6 +90,9 @@ class BailingMoeDecoder:
             s.image_gate = None
         s.final_norm = ptr(final_norm)
         s.cos_tab, s.sin_tab, s.n_pos = ptr(self.cos), ptr(self.sin), self.cos.shape[0]
+        if self.mrope_section is not None:
+            assert sum(self.mrope_section) == hd // 2
+            s.mrope_sec_t, s.mrope_sec_h = self.mrope_section[0], self.mrope_section[1]
         self.struct = s
         self._ws = {}
 
@@ -160,6 +168,12 @@ class BailingMoeDecoder:
         assert x.dtype == torch.float32 and x.is_cuda and x.stride(-1) == 1
         for t in (row_seq, row_slot, row_pos, row_len):
             assert t.dtype == torch.int32 and t.is_cuda and t.numel() >= M
+        if self.mrope_section is not None:
+            if row_pos.dim() == 1:                       # 2-D ids of the reference's callers: t = h = w
+                row_pos = row_pos[:M].unsqueeze(0).expand(3, M).contiguous()
+            assert row_pos.shape == (3, M) and row_pos.is_contiguous()
+        else:
+            assert row_pos.dim() == 1
         if key_mask is not None:
             assert key_mask.dtype == torch.uint8 and key_mask.is_cuda and key_mask.shape[0] >= M
         if image_mask is not None:

@@ -100,14 +100,17 @@ extern "C" int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w
 __global__ void rope_kv_append_kernel(const float* __restrict__ qkv, int64_t ldqkv, int n_q, int n_kv, int hd,
                                       int rope, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
                                       const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_slot,
-                                      const int32_t* __restrict__ row_pos, float q_scale, float* __restrict__ q_out,
-                                      float* __restrict__ kv_cache, int64_t t_max) {
+                                      const int32_t* __restrict__ row_pos, int M, int sec_t, int sec_h, float q_scale,
+                                      float* __restrict__ q_out, float* __restrict__ kv_cache, int64_t t_max) {
   const int m = blockIdx.x, h = blockIdx.y, i = threadIdx.x, half = hd >> 1;
   const float* src = qkv + (int64_t)m * ldqkv + (int64_t)h * hd;
   float x1 = src[i], x2 = src[i + half];
   const bool is_q = h < n_q, is_k = !is_q && h < n_q + n_kv;
   if (rope && (is_q || is_k)) {
-    const int pos = row_pos[m];
+    // 3D rotary (sec_t > 0): row_pos is [3][M] = t, h, w positions; frequency i of each half follows the t stream for
+    // i < sec_t, the h stream for the next sec_h, the w stream for the rest (apply_multimodal_rotary_pos_emb, :463-469)
+    const int stream = sec_t <= 0 ? 0 : (i < sec_t ? 0 : (i < sec_t + sec_h ? 1 : 2));
+    const int pos = row_pos[stream * M + m];
     const float c = cos_tab[(int64_t)pos * half + i], s = sin_tab[(int64_t)pos * half + i];
     const float o1 = x1 * c - x2 * s, o2 = x2 * c + x1 * s;
     x1 = o1; x2 = o2;
@@ -125,18 +128,27 @@ __global__ void rope_kv_append_kernel(const float* __restrict__ qkv, int64_t ldq
   }
 }
 
+extern "C" int mn_rope_kv_append_3d(const float* qkv, int64_t ldqkv, int M, int n_q, int n_kv, int hd, int rope,
+                                    const float* cos_tab, const float* sin_tab, const int32_t* row_seq,
+                                    const int32_t* row_slot, const int32_t* row_pos, int sec_t, int sec_h, float q_scale,
+                                    float* q_out, float* kv_cache, int64_t t_max, void* stream) {
+  MN_CHECK_ARG(M >= 1 && n_q >= 1 && n_kv >= 1 && (hd == 64 || hd == 128), "mn_rope_kv_append: bad shape");
+  MN_CHECK_ARG(qkv && row_seq && row_slot && q_out && kv_cache, "mn_rope_kv_append: null pointer");
+  MN_CHECK_ARG(!rope || (cos_tab && sin_tab && row_pos), "mn_rope_kv_append: rope needs tables and positions");
+  MN_CHECK_ARG(sec_t >= 0 && sec_h >= 0 && sec_t + sec_h <= hd / 2, "mn_rope_kv_append: bad rotary sections %d/%d", sec_t, sec_h);
+  hipLaunchKernelGGL(rope_kv_append_kernel, dim3(M, n_q + 2 * n_kv), dim3(hd / 2), 0, mn_stream(stream), qkv, ldqkv,
+                     n_q, n_kv, hd, rope, cos_tab, sin_tab, row_seq, row_slot, row_pos, M, sec_t, sec_h, q_scale, q_out,
+                     kv_cache, t_max);
+  MN_CHECK_LAUNCH("mn_rope_kv_append");
+  return MN_OK;
+}
+
 extern "C" int mn_rope_kv_append(const float* qkv, int64_t ldqkv, int M, int n_q, int n_kv, int hd, int rope,
                                  const float* cos_tab, const float* sin_tab, const int32_t* row_seq,
                                  const int32_t* row_slot, const int32_t* row_pos, float q_scale, float* q_out,
                                  float* kv_cache, int64_t t_max, void* stream) {
-  MN_CHECK_ARG(M >= 1 && n_q >= 1 && n_kv >= 1 && (hd == 64 || hd == 128), "mn_rope_kv_append: bad shape");
-  MN_CHECK_ARG(qkv && row_seq && row_slot && q_out && kv_cache, "mn_rope_kv_append: null pointer");
-  MN_CHECK_ARG(!rope || (cos_tab && sin_tab && row_pos), "mn_rope_kv_append: rope needs tables and positions");
-  hipLaunchKernelGGL(rope_kv_append_kernel, dim3(M, n_q + 2 * n_kv), dim3(hd / 2), 0, mn_stream(stream), qkv, ldqkv,
-                     n_q, n_kv, hd, rope, cos_tab, sin_tab, row_seq, row_slot, row_pos, q_scale, q_out, kv_cache,
-                     t_max);
-  MN_CHECK_LAUNCH("mn_rope_kv_append");
-  return MN_OK;
+  return mn_rope_kv_append_3d(qkv, ldqkv, M, n_q, n_kv, hd, rope, cos_tab, sin_tab, row_seq, row_slot, row_pos, 0, 0, q_scale,
+                              q_out, kv_cache, t_max, stream);
 }
 
 // -------------------------------------------------------------------------------------------

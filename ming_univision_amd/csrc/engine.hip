@@ -644,8 +644,8 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
     mn_skinny_args a = sk(w.h, H, m->wqkv[l], H, nullptr, w.qkv, qkv_dim, M, qkv_dim, H);
     a.prologue = MN_PRO_RMSNORM; a.ln_g = m->ln1[l]; a.eps = m->rms_eps;
     MN_TRY(mn_skinny_gemm(&a, stream));
-    MN_TRY(mn_rope_kv_append(w.qkv, qkv_dim, M, nq, nkv, hd, 1, m->cos_tab, m->sin_tab, row_seq, row_slot, row_pos,
-                             q_scale, w.q, kv_l, t_max, stream));
+    MN_TRY(mn_rope_kv_append_3d(w.qkv, qkv_dim, M, nq, nkv, hd, 1, m->cos_tab, m->sin_tab, row_seq, row_slot, row_pos,
+                                m->mrope_sec_t, m->mrope_sec_h, q_scale, w.q, kv_l, t_max, stream));
     MN_TRY(mn_attn_decode(w.q, M, nq, nkv, hd, kv_l, t_max, row_seq, row_len, key_mask, ld_mask, w.attn, w.attn_ws,
                           w.attn_ws_bytes, stream));
     a = sk(w.attn, nq * hd, m->wdense[l], nq * hd, nullptr, w.h, H, M, H, nq * hd);

@@ -111,16 +111,21 @@ def moe_experts(xn, idx, w, w_gate_up, w_down, res):
     return out
 
 
-def rope_kv_append(qkv, n_q, n_kv, hd, kv_cache, row_seq, row_slot, row_pos=None, cos=None, sin=None, q_scale=1.0):
-    """kv_cache fp32 [n_seq, 2, n_kv, t_max, hd].  Returns q_out [M, n_q*hd]."""
+def rope_kv_append(qkv, n_q, n_kv, hd, kv_cache, row_seq, row_slot, row_pos=None, cos=None, sin=None, q_scale=1.0,
+                   mrope_section=None):
+    """kv_cache fp32 [n_seq, 2, n_kv, t_max, hd].  Returns q_out [M, n_q*hd].
+    mrope_section (e.g. [16, 24, 24]): 3D rotary, row_pos is then int32 [3, M] (t, h, w positions)."""
     _req(qkv, torch.float32, "qkv"); _req(kv_cache, torch.float32, "kv_cache")
     M = qkv.shape[0]
     t_max = kv_cache.shape[3]
     q = torch.empty(M, n_q * hd, dtype=torch.float32, device=qkv.device)
     rope = int(cos is not None)
-    check(lib().mn_rope_kv_append(ptr(qkv), qkv.stride(0), M, n_q, n_kv, hd, rope, ptr(cos), ptr(sin), ptr(row_seq),
-                                  ptr(row_slot), ptr(row_pos), q_scale, ptr(q), ptr(kv_cache), t_max,
-                                  current_stream()), "mn_rope_kv_append")
+    sec_t, sec_h = (0, 0) if mrope_section is None else (int(mrope_section[0]), int(mrope_section[1]))
+    if mrope_section is not None:
+        assert row_pos.shape == (3, M) and row_pos.is_contiguous() and sum(mrope_section) == hd // 2
+    check(lib().mn_rope_kv_append_3d(ptr(qkv), qkv.stride(0), M, n_q, n_kv, hd, rope, ptr(cos), ptr(sin), ptr(row_seq),
+                                     ptr(row_slot), ptr(row_pos), sec_t, sec_h, q_scale, ptr(q), ptr(kv_cache), t_max,
+                                     current_stream()), "mn_rope_kv_append")
     return q
 
 

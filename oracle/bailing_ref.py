@@ -70,6 +70,23 @@ def apply_rope(q, k, cos, sin, position_ids):
     return q * cos + rotate_half(q) * sin, k * cos + rotate_half(k) * sin
 
 
+def rope3d_cos_sin(head_dim, base, position_ids3):
+    """BailingMoe3DRotaryEmbedding.forward (:413-425): position_ids3 [3,B,T] (t, h, w) -> cos, sin [3,B,T,hd]."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2).float() / head_dim))
+    freqs = position_ids3.float().unsqueeze(-1) * inv_freq            # [3,B,T,hd/2]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos(), emb.sin()
+
+
+def apply_rope_3d(q, k, cos, sin, mrope_section=(16, 24, 24)):
+    """apply_multimodal_rotary_pos_emb (:463-469): the 2 x 3 sections of the head dim take their angles from the
+    t, h, w streams in turn.  q [B,h,T,hd]; cos/sin [3,B,T,hd]."""
+    sec = list(mrope_section) * 2
+    cos = torch.cat([m[i % 3] for i, m in enumerate(cos.split(sec, dim=-1))], dim=-1).unsqueeze(1)
+    sin = torch.cat([m[i % 3] for i, m in enumerate(sin.split(sec, dim=-1))], dim=-1).unsqueeze(1)
+    return q * cos + rotate_half(q) * sin, k * cos + rotate_half(k) * sin
+
+
 def build_4d_mask(attention_mask, q_len, past_len):
     """Equivalent of transformers-4.52 `_prepare_4d_causal_attention_mask`
     (called at modeling_bailing_moe.py:1466): additive mask [B,1,q,kv], finfo.min
@@ -95,8 +112,12 @@ def attention(x, sd, prefix, cfg, attn_mask4d, position_ids, kv):
     q, k, v = qkv.split([nh, nkv, nkv], dim=-2)
     q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
     past = 0 if kv.get("k") is None else kv["k"].shape[2]
-    cos, sin = rope_cos_sin(hd, cfg.rope_theta, past + T)
-    q, k = apply_rope(q, k, cos, sin, position_ids)
+    if position_ids.dim() == 3:      # rope_scaling.type == "3D" branch (:780-782)
+        cos, sin = rope3d_cos_sin(hd, cfg.rope_theta, position_ids)
+        q, k = apply_rope_3d(q, k, cos, sin)
+    else:
+        cos, sin = rope_cos_sin(hd, cfg.rope_theta, int(position_ids.max()) + 1)
+        q, k = apply_rope(q, k, cos, sin, position_ids)
     if kv.get("k") is not None:
         k = torch.cat([kv["k"], k], dim=2)
         v = torch.cat([kv["v"], v], dim=2)

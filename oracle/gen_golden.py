@@ -250,6 +250,29 @@ def gen_llm():
          dec_in=torch.stack(dec_in), dec_hidden=torch.stack(dec_hidden), vis_z=z)
 
 
+def gen_rope3d():
+    """The 3D rotary branch (rope_scaling.type == "3D"): BailingMoe3DRotaryEmbedding + apply_multimodal_rotary_pos_emb
+    on random q / k with DIFFERENT t / h / w position streams, and with equal streams (== Legacy)."""
+    import modeling_bailing_moe as mbm
+    g = torch.Generator().manual_seed(21)
+    B, T, nq, nkv, hd = 2, 5, 4, 2, 128
+    q = torch.randn(B, nq, T, hd, generator=g)
+    k = torch.randn(B, nkv, T, hd, generator=g)
+    pos3 = torch.stack([torch.randint(0, 40, (B, T), generator=g) for _ in range(3)])      # [3,B,T]
+    rot = mbm.BailingMoe3DRotaryEmbedding(hd, max_position_embeddings=64, base=600000.0)
+    with torch.no_grad():
+        cos, sin = rot(k, position_ids=pos3)
+        q3, k3 = mbm.apply_multimodal_rotary_pos_emb(q, k, cos, sin)
+        same = pos3[:1].expand(3, -1, -1)
+        cos_s, sin_s = rot(k, position_ids=same)
+        qs, ks = mbm.apply_multimodal_rotary_pos_emb(q, k, cos_s, sin_s)
+        legacy = mbm.BailingMoeRotaryEmbeddingLegacy(hd, base=600000.0)
+        cl, sl = legacy(k, seq_len=64)
+        ql, kl = mbm.apply_rotary_pos_emb(q, k, cl, sl, pos3[0])
+    assert torch.equal(qs, ql) and torch.equal(ks, kl)          # SURVEY.md: equal streams are bit-identical to Legacy
+    save("rope3d", q=q, k=k, pos3=pos3, q3=q3, k3=k3, q_same=qs, k_same=ks, base=600000.0)
+
+
 def gen_genimg():
     """End-to-end BailingMoeForCausalLM.generate_image on tiny configs (3-row and 2-row CFG)."""
     import torch.nn as nn
@@ -365,6 +388,7 @@ def main():
     gen_llm()
     gen_genimg()
     gen_processor()
+    gen_rope3d()
 
 
 if __name__ == "__main__":

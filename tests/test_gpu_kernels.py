@@ -283,3 +283,34 @@ def test_stream_mfma_grouped(ops, G, max_rows, N, K, gather):
             src = int(xrows[r]) if gather else r
             ref = wf[gi].double() @ xe[src]
             assert rel(out[r], ref) < 1e-5, (gi, r)
+
+
+def test_rope3d_kv_append(ops):
+    """mn_rope_kv_append_3d against the reference's 3D rotary (golden from BailingMoe3DRotaryEmbedding +
+    apply_multimodal_rotary_pos_emb): distinct t / h / w streams, sections 16/24/24; equal streams == Legacy."""
+    import os
+    import numpy as np
+    from ming_univision_amd.bailing_moe import rope_tables
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rope3d.npz"))
+    q, k, pos3 = torch.from_numpy(z["q"]), torch.from_numpy(z["k"]), torch.from_numpy(z["pos3"])
+    B, nq, T, hd = q.shape
+    nkv = k.shape[1]
+    M = B * T
+    v = rnd(B, nkv, T, hd, seed=5)
+    qkv = torch.cat([q, k, v], dim=1).permute(0, 2, 1, 3).reshape(M, (nq + 2 * nkv) * hd).contiguous()   # rows = (b, t)
+    cos, sin = rope_tables(hd, float(z["base"]), 64, torch.device("cuda"))
+    kv = torch.zeros(B, 2, nkv, T, hd, device="cuda")
+    row_seq = torch.arange(B).repeat_interleave(T).to(torch.int32).cuda()
+    row_slot = torch.arange(T).repeat(B).to(torch.int32).cuda()
+    for name, p3 in (("q3", pos3), ("q_same", pos3[:1].expand(3, -1, -1))):
+        rp = p3.reshape(3, M).to(torch.int32).contiguous().cuda()
+        qo = ops.rope_kv_append(qkv.cuda(), nq, nkv, hd, kv, row_seq, row_slot, rp, cos, sin, q_scale=0.5,
+                                mrope_section=[16, 24, 24])
+        qr = torch.from_numpy(z[name]).permute(0, 2, 1, 3).reshape(M, nq * hd) * 0.5
+        kr = torch.from_numpy(z["k3" if name == "q3" else "k_same"])
+        assert rel(qo, qr) < 1e-6, name
+        assert rel(kv[:, 0], kr) < 1e-6 and rel(kv[:, 1], v) == 0.0, name
+    # Legacy entry point with the t stream alone == equal streams
+    qo = ops.rope_kv_append(qkv.cuda(), nq, nkv, hd, kv, row_seq, row_slot, pos3[0].reshape(M).to(torch.int32).cuda(), cos, sin,
+                            q_scale=0.5)
+    assert rel(qo, torch.from_numpy(z["q_same"]).permute(0, 2, 1, 3).reshape(M, nq * hd) * 0.5) < 1e-6

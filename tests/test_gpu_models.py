@@ -108,6 +108,37 @@ def test_llm_prefill_and_cfg_decode_vs_reference(llm):
     assert rel_err(zr, g["vis_z"]) < TOL
 
 
+def test_llm_step_3d_rotary_vs_oracle():
+    """rope_scaling {"type": "3D"} (the shipped config.json): decode steps with DIFFERENT t / h / w positions against
+    the oracle (whose 3D rotary is pinned to the reference's functions by tests/golden/rope3d.npz); with the 1-D
+    positions every reference caller passes, the 3D model equals the Legacy model."""
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder
+    from oracle import bailing_ref
+    g = load_golden("llm_tiny")
+    sd = llm_sd(g["config"], g["rf_config"], g["seed"])
+    cfg3 = C.BailingMoeConfig(**{**g["config"], "rope_scaling": {"type": "3D", "factor": None}})
+    dec = BailingMoeDecoder.from_state_dict(cfg3, to_dev(sd), t_max=16, n_seq=2)
+    ocfg = bailing_ref.LLMConfig(**{k: v for k, v in g["config"].items() if k in bailing_ref.LLMConfig.__dataclass_fields__})
+    kvs = bailing_ref.new_kv(ocfg)
+    gen = torch.Generator().manual_seed(9)
+    rows = 2
+    seq = torch.arange(rows, dtype=torch.int32).cuda()
+    for step in range(4):
+        x = torch.randn(rows, 1, cfg3.hidden_size, generator=gen)
+        pos3 = torch.randint(0, 12, (3, rows, 1), generator=gen)
+        am = torch.ones(rows, step + 1, dtype=torch.long)
+        ref = bailing_ref.model_forward(x, sd, ocfg, am, pos3, kvs)
+        slot = torch.full((rows,), step, dtype=torch.int32).cuda()
+        out = dec.step(x[:, 0].cuda().contiguous(), seq, slot, pos3[:, :, 0].to(torch.int32).contiguous().cuda(), slot + 1)
+        assert rel_err(out, ref[:, 0]) < TOL, step
+    legacy = BailingMoeDecoder.from_state_dict(C.BailingMoeConfig(**g["config"]), to_dev(sd), t_max=16, n_seq=2)
+    x = torch.randn(rows, cfg3.hidden_size, generator=gen).cuda()
+    slot = torch.zeros(rows, dtype=torch.int32).cuda()
+    pos = torch.tensor([3, 7], dtype=torch.int32).cuda()
+    dec.kv_cache.zero_()
+    assert torch.equal(dec.step(x, seq, slot, pos, slot + 1), legacy.step(x, seq, slot, pos, slot + 1))
+
+
 @pytest.fixture(scope="module")
 def mt():
     from ming_univision_amd.mingtok import MingTok

@@ -152,3 +152,18 @@ def test_generate_image(tag):
     assert kvs[0]["k"].shape[2] == g[tag + "_cache_len"]
     assert rel_err(kvs[0]["k"], g[tag + "_k0"]) < 1e-4
     assert rel_err(bailing_ref.lm_logits(out["last_hidden"][0:1], sd), g[tag + "_logits"]) < 1e-4
+
+
+def test_rope3d_matches_reference():
+    """3D rotary branch (rope_scaling.type == "3D", modeling_bailing_moe.py:413-425, 463-469): the restatement against
+    the reference's own functions, with distinct t / h / w position streams and with equal streams (== Legacy)."""
+    g = load_golden("rope3d")
+    cos, sin = bailing_ref.rope3d_cos_sin(128, g["base"], g["pos3"])
+    q3, k3 = bailing_ref.apply_rope_3d(g["q"], g["k"], cos, sin)
+    assert rel_err(q3, g["q3"]) < 1e-6 and rel_err(k3, g["k3"]) < 1e-6
+    same = g["pos3"][:1].expand(3, -1, -1)
+    cos, sin = bailing_ref.rope3d_cos_sin(128, g["base"], same)
+    qs, ks = bailing_ref.apply_rope_3d(g["q"], g["k"], cos, sin)
+    cl, sl = bailing_ref.rope_cos_sin(128, g["base"], 64)
+    ql, kl = bailing_ref.apply_rope(g["q"], g["k"], cl, sl, g["pos3"][0])
+    assert rel_err(qs, g["q_same"]) < 1e-6 and rel_err(ql, g["q_same"]) < 1e-6 and rel_err(kl, g["k_same"]) < 1e-6
