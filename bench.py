@@ -40,7 +40,9 @@ def parse():
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only; INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", type=int, default=None, help=argparse.SUPPRESS)
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.groups = max(1, min(args.groups, args.images))
+    return args
 
 
 def build_models(args, device, seed):
