@@ -1,0 +1,254 @@
+// stream_kloop.hip — weight-streaming MFMA GEMM for 5..64 activation rows, K-loop form (gfx950).
+//
+//   partial[z][row][n] = sum_{k in K-range z} (x_hi[xrow,k] + x_lo[xrow,k]) * W_g[n,k]
+//
+// Same contract as stream_mfma.hip (bf16 hi+lo activations, fp32 K-range partials, optional expert groups), different
+// decomposition: a workgroup of 8 waves owns 8 weight tiles (16 rows each) over a LONG K-range and walks it in chunks
+// of 128 k.  The x chunk of all rows is double-buffered in LDS and refilled from a register ring while the previous
+// chunk is multiplied, so
+//   * x never has to fit in LDS as a whole (64 rows x 4 B x K would not): the x image costs 8 KiB x MT per buffer;
+//   * the x fetch is pipelined along K instead of being a start-up bubble in front of the weight stream;
+//   * K-ranges are long, so few (often 1-2) partial slabs are written.
+// Each wave streams its own 16 x 128 weight chunks (4 instructions of 4 rows x 256 B, nontemporal) through a D-deep
+// register ring into a wave-private swizzled 4 KiB LDS tile; one workgroup barrier per chunk orders the x buffers.
+//
+// STATUS (round 1): parity-green (tools/ab_kloop.py: <= 7e-7 against float64 on dense shapes) but NOT on the product
+// path.  Measured on MI355X: on par with the K-slice kernel at 32 rows (RF w12 23.0-24.9 vs 24.1 us, w3 15.1 vs 14.9);
+// at 64 rows RF w12 takes 39.8 us (2.5 TB/s) — no longer HBM-bound: with one weight tile per wave every 4 KiB weight
+// chunk costs 32 KiB of x fragment reads from LDS.  The 64-row regime needs two weight tiles per wave (or the 32x32x16
+// MFMA) to halve that traffic; that is next round's work, and this file is its starting point.  Entry points are
+// internal (not declared in mingnative.h).
+#include "common.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int CK = 128;              // k per chunk
+constexpr int KW = 8;                // waves (= weight tiles) per workgroup
+constexpr int ROWB = CK * 2;         // bytes per LDS row of a chunk (16 slots of 16 B)
+
+struct KGroups {
+  const int32_t* off;      // [G + 1] offsets into the sorted row list; nullptr = one dense group of M rows
+  const int32_t* xrows;    // [total] x row of each sorted row; nullptr = identity (off[g] + r)
+  int64_t w_stride;        // elements between consecutive groups' weight matrices
+};
+
+// byte offset of 16-byte slot `slot` (0..15) of chunk row `row`: XOR swizzle makes the b128 fragment reads
+// (16 rows x 4 slots per lane group) conflict-free
+__device__ __forceinline__ int cslot(int row, int slot) { return row * ROWB + ((slot ^ (row & 15)) << 4); }
+
+template <int MT, int D>
+__global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
+                                                               const bf16_t* __restrict__ W, float* __restrict__ P,
+                                                               int64_t p_slab, int M, int Ntot, int K, int nz, KGroups g) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];          // x: [2 bufs][2 x 16MT rows][256 B]; w: [KW][16][256 B]
+  constexpr int XR = 16 * MT;                                         // x rows per half (hi / lo)
+  constexpr int XB = 2 * XR * ROWB;                                   // bytes per x buffer
+  int row0 = 0, nrows = M;
+  if (g.off) {
+    row0 = g.off[blockIdx.z];
+    nrows = g.off[blockIdx.z + 1] - row0;
+    if (nrows <= 0) return;
+    W += (int64_t)blockIdx.z * g.w_stride;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  char* wt = lds + 2 * XB + wave * 16 * ROWB;
+  // K-range of this workgroup: chunks [c0, c0 + nc), balanced over the nz ranges
+  const int nch = (K + CK - 1) / CK;
+  const int z = blockIdx.y, base = nch / nz, rem = nch % nz;
+  const int c0 = z * base + min(z, rem), nc = base + (z < rem ? 1 : 0);
+  const int ntiles = (Ntot + 15) >> 4;
+  const int t = blockIdx.x * KW + wave;
+  const bool active = t < ntiles;                                     // idle waves still help with x and the barriers
+  const int mtn = (nrows + 15) >> 4;                                  // 16-row x tiles actually populated
+
+  // ---- x pieces of this thread: piece p = tid + j * 512 -> row p >> 4 (hi rows, then lo rows), slot p & 15
+  const bf16_t* xp[MT];
+  int xo[MT];                                                         // LDS byte offset inside a buffer, -1 = nothing to write
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int p = tid + j * (KW * 64);
+    const int rr = p >> 4, slot = p & 15;
+    const int h = rr >= XR ? 1 : 0, m = rr - h * XR;
+    xo[j] = m < mtn * 16 ? cslot(h * XR + m, slot) : -1;
+    xp[j] = nullptr;
+    if (m < nrows) {
+      const int xr = g.xrows ? g.xrows[row0 + m] : row0 + m;
+      xp[j] = Y + h * y_lo + (int64_t)xr * K + slot * 8;
+    }
+  }
+  // ---- weight pieces of this wave: instruction i -> row i * 4 + (lane >> 4), slot lane & 15 (4 rows x 256 B)
+  const bf16_t* wp[4];
+  int wo[4];
+  const int wslot_k = (lane & 15) * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 4 + (lane >> 4);
+    const int n = min(t * 16 + row, Ntot - 1);
+    wp[i] = W + (int64_t)n * K;
+    wo[i] = cslot(row, lane & 15);
+  }
+  u32x4 xr_[D][MT], wr_[D][4];
+  auto load_x = [&](u32x4 (&dst)[MT], int c) {
+    const int k = (c0 + c) * CK;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      dst[j] = u32x4{0u, 0u, 0u, 0u};                                  // rows >= nrows and k >= K stay zero
+      if (xp[j] && k + ((tid + j * (KW * 64)) & 15) * 8 < K) dst[j] = *reinterpret_cast<const u32x4*>(xp[j] + k);
+    }
+  };
+  auto load_w = [&](u32x4 (&dst)[4], int c) {
+    const int k = min((c0 + c) * CK + wslot_k, K - 8);                // beyond K the x image is zero: any finite value will do
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[i] + k));
+  };
+  auto store_x = [&](const u32x4 (&src)[MT], int buf) {
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+      if (xo[j] >= 0) *reinterpret_cast<u32x4*>(lds + buf * XB + xo[j]) = src[j];
+  };
+  // ---- prologue: D chunks of x and of weights in flight; x chunk 0 becomes visible
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < nc) load_x(xr_[d], d);
+  if (active) {
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (d < nc) load_w(wr_[d], d);
+  }
+  store_x(xr_[0], 0);
+  if (D < nc) load_x(xr_[0], D);
+  __syncthreads();
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int cb = 0; cb < nc; cb += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int c = cb + d;
+      if (c < nc) {
+        const int buf = d & 1;                                        // D is even: chunk parity == d parity
+        if (active) {
+          // park the landed weight chunk, refill its registers with the chunk D ahead
+#pragma unroll
+          for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(wt + wo[i]) = wr_[d][i];
+          if (c + D < nc) load_w(wr_[d], c + D);
+          // 4 MFMA steps of 32 k against every populated x tile (hi and lo)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const bf16x8 w = *reinterpret_cast<const bf16x8*>(wt + cslot(fr, s * 4 + fq));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              if (mt < mtn) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(lds + buf * XB + cslot(mt * 16 + fr, s * 4 + fq));
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(lds + buf * XB + cslot(XR + mt * 16 + fr, s * 4 + fq));
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w, acc[mt], 0, 0, 0);
+              }
+            }
+          }
+        }
+        // next x chunk into the other buffer (its last readers passed the previous barrier), ring refilled
+        if (c + 1 < nc) {
+          const int dn = (d + 1) % D;
+          store_x(xr_[dn], buf ^ 1);
+          if (c + 1 + D < nc) load_x(xr_[dn], c + 1 + D);
+        }
+        __syncthreads();
+      }
+    }
+  }
+  // D layout: row m = fq*4 + r, col n = t*16 + fr
+  const int nn = t * 16 + fr;
+  if (active && nn < Ntot) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mt * 16 + fq * 4 + r;
+        if (m < nrows) P[(int64_t)z * p_slab + (int64_t)(row0 + m) * Ntot + nn] = acc[mt][r];
+      }
+    }
+  }
+}
+
+int g_kl_nz = 0, g_kl_depth = 0;
+
+// number of K-ranges: enough workgroups to fill `slots` CUs-worth of residency, never more ranges than chunks
+int kloop_nz(int Ntot, int K, int slots) {
+  if (g_kl_nz > 0) return g_kl_nz;
+  const int tb = (int)mn_cdiv(mn_cdiv(Ntot, 16), KW);
+  const int nch = (int)mn_cdiv(K, CK);
+  int nz = slots / tb;
+  if (nz < 1) nz = 1;
+  if (nz > nch) nz = nch;
+  return nz;
+}
+
+template <int MT, int D>
+void kloop_launch(int G, int nz, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab, int M, int Ntot,
+                  int K, const KGroups& g, hipStream_t st) {
+  const size_t lds = (size_t)2 * 2 * 16 * MT * ROWB + (size_t)KW * 16 * ROWB;
+  static bool opted = false;
+  if (!opted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_kloop_kernel<MT, D>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    opted = true;
+  }
+  const int tb = (int)mn_cdiv(mn_cdiv(Ntot, 16), KW);
+  hipLaunchKernelGGL((stream_kloop_kernel<MT, D>), dim3(tb, nz, G), dim3(KW * 64), lds, st, Y, y_lo, W, P, p_slab, M, Ntot, K,
+                     nz, g);
+}
+
+template <int MT>
+void kloop_launch_d(int G, int nz, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab, int M, int Ntot,
+                    int K, const KGroups& g, hipStream_t st) {
+  if (g_kl_depth == 2) kloop_launch<MT, 2>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+  else kloop_launch<MT, 4>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+}
+
+int kloop_dispatch(int G, int max_rows, int nz, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab,
+                   int M, int Ntot, int K, const KGroups& g, hipStream_t st) {
+  if (max_rows <= 16) kloop_launch_d<1>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+  else if (max_rows <= 32) kloop_launch_d<2>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+  else kloop_launch_d<4>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+  return nz;
+}
+
+}  // namespace
+
+extern "C" void mn_stream_kloop_tune(int nz, int depth) { g_kl_nz = nz; g_kl_depth = depth; }
+
+extern "C" int mn_stream_kloop_slices(int M, int Ntot, int K) { return kloop_nz(Ntot, K, mn_num_cus()); }
+
+// Dense: Y [2][M][K] bf16 (hi rows then lo rows), W [Ntot][K], P [nz][M][Ntot].  Returns nz (< 0: error).  M <= 64.
+extern "C" int mn_stream_kloop(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream) {
+  MN_CHECK_ARG(Y && W && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0, "mn_stream_kloop: bad args");
+  const int nz = kloop_nz(Ntot, K, mn_num_cus());
+  const KGroups g{nullptr, nullptr, 0};
+  kloop_dispatch(1, M, nz, Y, (int64_t)M * K, W, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
+  MN_CHECK_LAUNCH("mn_stream_kloop");
+  return nz;
+}
+
+extern "C" int mn_stream_kloop_grouped_slices(int G, int max_rows, int Ntot, int K) {
+  const int slots = (int)mn_cdiv((int64_t)4 * mn_num_cus(), G);
+  return kloop_nz(Ntot, K, slots < 1 ? 1 : slots);
+}
+
+extern "C" int mn_stream_kloop_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P,
+                                       int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows, int Ntot,
+                                       int K, void* stream) {
+  MN_CHECK_ARG(Y && W && P && off && G >= 1 && max_rows >= 1 && max_rows <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0,
+               "mn_stream_kloop_grouped: bad args");
+  const int nz = mn_stream_kloop_grouped_slices(G, max_rows, Ntot, K);
+  const KGroups g{off, xrows, w_stride};
+  kloop_dispatch(G, max_rows, nz, Y, (int64_t)y_rows * K, W, P, (int64_t)p_rows * Ntot, 0, Ntot, K, g, mn_stream(stream));
+  MN_CHECK_LAUNCH("mn_stream_kloop_grouped");
+  return nz;
+}
