@@ -313,15 +313,6 @@ size_t sk_ws_need(int M, std::initializer_list<std::array<int, 3>> shapes) {   /
   return mx;
 }
 
-// MN_DEBUG_SYNC=1: synchronise after every sub-launch and report which one faulted (debug aid only)
-static inline void dbg_sync(const char* what, hipStream_t st) {
-  static int on = -1;
-  if (on < 0) on = getenv("MN_DEBUG_SYNC") ? 1 : 0;
-  if (!on) return;
-  hipError_t e = hipStreamSynchronize(st);
-  fprintf(stderr, "[mn] %s: %s\n", what, hipGetErrorString(e));
-}
-
 #define MN_TRY(expr)            \
   do {                          \
     int rc__ = (expr);          \
@@ -405,11 +396,9 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   {
     mn_skinny_args a = sk(hidden, ld_hidden, h->vis_w, h->llm_hidden, h->vis_b, z, h->z_dim, rows, h->z_dim, h->llm_hidden);
     MN_TRY(mn_skinny_gemm(&a, stream));
-    dbg_sync("rf vis_head", st);
     a = sk(z, h->z_dim, h->cond_w, h->z_dim, h->cond_b, c, w, rows, w, h->z_dim);
     a.prologue = MN_PRO_LN; a.ln_g = h->vis_ln_g; a.ln_b = h->vis_ln_b; a.eps = 1e-6f;
     MN_TRY(mn_skinny_gemm(&a, stream));
-    dbg_sync("rf cond_embed", st);
   }
   hipLaunchKernelGGL(rf_init_x_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, noise, temperature, x, rows, T, rpi);
   // The adaLN inputs SiLU(t_emb[s] + c) do not depend on the ODE state, so the modulations of ALL
@@ -419,9 +408,7 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   const int64_t SR = (int64_t)h->steps * rows;
   hipLaunchKernelGGL(rf_build_y_kernel, dim3(mn_cdiv(SR * w, 256)), dim3(256), 0, st, h->temb, c, y, h->steps, rows, w);
   MN_TRY(mn_gemm_bf16(y, w, h->ada_w, w, nullptr, ada, A, (int)(2 * SR), A, w, MN_GEMM_F32, stream));
-  dbg_sync("rf ada gemm", st);
   hipLaunchKernelGGL(rf_ada_combine_kernel, dim3(2048), dim3(256), 0, st, ada, h->ada_b, SR, (int64_t)A);
-  dbg_sync("rf ada combine", st);
   const float step = 1.0f / (float)h->steps;
   const float* ada_all = ada;
   for (int s = 0; s < h->steps; ++s) {
@@ -429,7 +416,6 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
     // h = input_proj(x)  (diff_loss:371)
     mn_skinny_args a = sk(x, T, h->in_w, T, h->in_b, hh, w, rows, w, T);
     MN_TRY(mn_skinny_gemm(&a, stream));
-    dbg_sync("rf input_proj", st);
     if (chain) {
       // rows >= 5: stream(w12) -> [reduce + SwiGLU + split] -> stream(w3) -> [reduce + gated residual + next LN-modulate + split]
       const int hid_n = h->hidden;
@@ -453,7 +439,6 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
       if (nz < 0) return nz;
       hipLaunchKernelGGL(rf_glue_bias_out_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, pbuf, nz, rows, T, h->fin_b, v);
       hipLaunchKernelGGL(rf_euler_kernel, dim3(n_images), dim3(256), 0, st, v, x, rpi, T, text_cfg, image_cfg, step);
-      dbg_sync("rf chain step", st);
       continue;
     }
     const bool persistent = g_rf_persistent && h->depth <= 16 && rows <= 4 && (size_t)rows * h->hidden * 4 <= 150 * 1024;
@@ -468,17 +453,14 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
       a.pro_a = mod; a.ld_pro_a = A; a.pro_b = mod + w; a.ld_pro_b = A;
       a.epilogue = MN_EPI_SWIGLU;
       MN_TRY(mn_skinny_gemm(&a, stream));
-      dbg_sync("rf w12", st);
       a = sk(hid, h->hidden, h->w3[b], h->hidden, h->b3[b], hh, w, rows, w, h->hidden);
       a.epilogue = MN_EPI_RESID_GATE; a.res = hh; a.ldres = w; a.gate = mod + 2 * w; a.ldgate = A;
       MN_TRY(mn_skinny_gemm(&a, stream));
-      dbg_sync("rf w3", st);
     }
     const float* modf = ada + (int64_t)h->depth * 3 * w;
     a = sk(hh, w, h->fin_w, w, h->fin_b, v, T, rows, T, w);
     a.prologue = MN_PRO_LN_MOD; a.eps = 1e-6f; a.pro_a = modf; a.ld_pro_a = A; a.pro_b = modf + w; a.ld_pro_b = A;
     MN_TRY(mn_skinny_gemm(&a, stream));
-    dbg_sync("rf final", st);
     hipLaunchKernelGGL(rf_euler_kernel, dim3(n_images), dim3(256), 0, st, v, x, rpi, T, text_cfg, image_cfg, step);
   }
   hipLaunchKernelGGL(rf_gather_latent_kernel, dim3(mn_cdiv(n_images * T, 256)), dim3(256), 0, st, x, latent_out, n_images, rpi, T);

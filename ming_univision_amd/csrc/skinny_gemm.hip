@@ -308,16 +308,10 @@ static int skinny_medium(const mn_skinny_args& a, void* stream) {
   bf16_t* Y = reinterpret_cast<bf16_t*>(a.ws);
   float* P = reinterpret_cast<float*>(reinterpret_cast<char*>(a.ws) + (((size_t)2 * a.M * a.K * sizeof(bf16_t) + 255) & ~(size_t)255));
   hipStream_t st = mn_stream(stream);
-  const bool dbg = getenv("MN_DEBUG_SYNC") != nullptr;
-  if (dbg) fprintf(stderr, "[mn] medium M=%d N=%d K=%d pro=%d epi=%d ws=%p bytes=%zu need=%zu x=%p ldx=%lld\n", a.M, a.N, a.K,
-                   a.prologue, a.epilogue, a.ws, a.ws_bytes, need, (const void*)a.x, (long long)a.ldx);
   hipLaunchKernelGGL(medium_prologue_kernel, dim3(a.M), dim3(1024), 0, st, a, Y);
-  if (dbg) fprintf(stderr, "[mn]  prologue: %s\n", hipGetErrorString(hipStreamSynchronize(st)));
   const int nz = mn_stream_mfma(Y, a.w, P, a.M, Ntot, a.K, stream);
   if (nz < 0) return nz;
-  if (dbg) fprintf(stderr, "[mn]  gemm nz=%d: %s\n", nz, hipGetErrorString(hipStreamSynchronize(st)));
   hipLaunchKernelGGL(medium_epilogue_kernel, dim3((unsigned)mn_cdiv((int64_t)a.M * a.N, 256)), dim3(256), 0, st, a, P, nz, Ntot);
-  if (dbg) fprintf(stderr, "[mn]  epilogue: %s\n", hipGetErrorString(hipStreamSynchronize(st)));
   MN_CHECK_LAUNCH("mn_skinny_gemm(medium)");
   return MN_OK;
 }
