@@ -32,8 +32,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tokens", type=int, default=256, help="visual tokens per image (256 = 512^2)")
     ap.add_argument("--prompt-len", type=int, default=40)
-    ap.add_argument("--images", type=int, default=48,
-                    help="images generated in lock-step per GPU (an image batch; 1 = the reference's batch-size-1 call; 16 per group = 32 CFG rows)")
+    ap.add_argument("--images", type=int, default=96,
+                    help="images generated in lock-step per GPU (an image batch; 1 = the reference's batch-size-1 call; 32 per group = 64 CFG rows)")
     ap.add_argument("--groups", type=int, default=3,
                     help="split the image batch into this many lock-step groups on separate HIP streams")
     ap.add_argument("--no-batch1", action="store_true", help="skip the extra batch-size-1 measurement")

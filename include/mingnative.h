@@ -95,7 +95,7 @@ typedef struct mn_skinny_args {
   void* ws; size_t ws_bytes;
 } mn_skinny_args;
 
-/* 1 <= M <= 32 (batch / nseg forms: M <= 8). */
+/* 1 <= M <= 64 (batch / nseg forms: M <= 8). */
 int mn_skinny_gemm(const mn_skinny_args* args, void* stream);
 size_t mn_skinny_workspace_bytes(int M, int N, int K, int epilogue);
 
@@ -211,14 +211,14 @@ int mn_gemm_bf16_grouped(const uint16_t* A, int64_t lda, const uint16_t* W, int6
 /* Weight-streaming MFMA kernel behind the M >= 5 route of mn_skinny_gemm: Y bf16 [2][M][K] (activations split
  * into hi rows then lo rows), W bf16 [Ntot, K] dense, P fp32 [nz][M][Ntot] K-slice partials with
  * nz = mn_stream_mfma_slices(M, Ntot, K) (the launch plan picks slices of 256..1024 k so that every wave of the
- * chip gets the same number of 16-row weight tiles); returns nz.  M <= 32.  HBM-bound: every weight byte is read
- * once. */
+ * chip gets the same number of 16-row weight tiles); returns nz.  M <= 64 (33..64 rows run the K-loop form: 8 x 2
+ * tiles per workgroup over a long K-range, x chunks double-buffered in LDS).  HBM-bound: every weight byte is read once. */
 int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream);
 int mn_stream_mfma_slices(int M, int Ntot, int K);
 /* Grouped form (MoE experts; replaces the per-token expert loop of modeling_bailing_moe.py:605-639 for 5..32
  * rows): group g of G multiplies the x rows xrows[off[g] .. off[g+1]) (identity rows when xrows == NULL) by
  * W + g * w_stride and writes rows off[g].. of P [nz][p_rows][Ntot]; Y holds y_rows hi rows then y_rows lo rows;
- * no group may exceed max_rows (<= 32) rows.  off / xrows are device arrays.  Every distinct expert is streamed
+ * no group may exceed max_rows (<= 64) rows.  off / xrows are device arrays.  Every distinct expert is streamed
  * once for all the rows routed to it.  Returns nz = mn_stream_mfma_grouped_slices(G, max_rows, Ntot, K). */
 int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P, int p_rows,
                            const int32_t* off, const int32_t* xrows, int G, int max_rows, int Ntot, int K,
@@ -277,7 +277,7 @@ typedef struct mn_rf_head {
 } mn_rf_head;
 
 /* hidden [rows, llm_hidden] fp32 (last hidden states of the LLM step), rows = n_images x R image-major with
- * R = 1 (no CFG), 2 ([cond, uncond]) or 3 ([cond, uncond, text_uncond]) rows per image; rows <= 32.
+ * R = 1 (no CFG), 2 ([cond, uncond]) or 3 ([cond, uncond, text_uncond]) rows per image; rows <= 64.
  * noise [n_images, target] fp32; latent_out [n_images, target] fp32 (all CFG rows of an image carry the same
  * latent).  n_images = 1 is the reference's batch-size-1 call.  Workspace: mn_rf_workspace_bytes(h, rows). */
 size_t mn_rf_workspace_bytes(const mn_rf_head* h, int rows);
@@ -285,7 +285,7 @@ int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld_hidden, in
                  const float* noise, float temperature, float text_cfg, float image_cfg, float* latent_out,
                  void* workspace, size_t workspace_bytes, void* stream);
 
-/* Bailing-MoE decoder stack, decode-style step for M <= 32 rows
+/* Bailing-MoE decoder stack, decode-style step for M <= 64 rows
  * (BailingMoeModel.forward, modeling_bailing_moe.py:1391-1540, with q_len rows per sequence). */
 typedef struct mn_llm {
   int32_t hidden, n_layers, n_q, n_kv, head_dim, n_experts, top_k, n_shared_slots, moe_inter;
@@ -320,7 +320,7 @@ int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int
  * device-resident row_slot / row_pos / row_len arrays between autoregressive steps without a host round trip. */
 int mn_rows_advance(int32_t* a, int32_t* b, int32_t* c, int M, int delta, void* stream);
 
-/* MingTok semantic decoder, cached causal decode step for M <= 32 rows of ONE sequence each
+/* MingTok semantic decoder, cached causal decode step for M <= 64 rows of ONE sequence each
  * (MingTok.forward_feature_decoder, modeling_mingtok.py:165-174 -> TransformerDecoder.forward_features,
  * vision_transformer.py:382-451) followed by linear_proj (modeling_bailingmm.py:111-115). */
 typedef struct mn_semdec {

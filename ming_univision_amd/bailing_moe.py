@@ -158,7 +158,7 @@ class BailingMoeDecoder:
 
     def step(self, x, row_seq, row_slot, row_pos, row_len, key_mask=None, image_mask=None, out=None, rows=None,
              x_row_div=1):
-        """One pass of the 28-layer stack over M <= 32 rows.
+        """One pass of the 28-layer stack over M <= 64 rows.
         x fp32 [M,H]; or [1,H] with rows=M to broadcast; or [M / x_row_div, H] with rows=M when the x_row_div CFG
         rows of an image share one embedding.  int32 device arrays per row; key_mask uint8 [M, >=len].
         Returns the post-final-norm hidden states [M,H] fp32."""
@@ -302,7 +302,7 @@ def build_cfg_rows(attention_mask, uncond_attention_mask, text_uncond_attention_
     return am
 
 
-MAX_ROWS = 32   # rows of one lock-step pass (two 16-row MFMA tiles)
+MAX_ROWS = 64   # rows of one lock-step pass (four 16-row MFMA tiles)
 
 
 class ImageGenState:

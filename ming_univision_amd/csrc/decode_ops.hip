@@ -73,7 +73,7 @@ extern "C" int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w
   MN_CHECK_ARG(x && norm_w && gate_w && x_norm && topk_idx && topk_w && logits_ws, "mn_moe_router: null pointer");
   const bool both = image_mask && image_gate_w;
   // >= 5 rows with scratch: one launch on the matrix-core route; otherwise the fp32 path, 8 rows at a time
-  const bool mfma = M <= 32 && ws != nullptr && ws_bytes >= mn_skinny_workspace_bytes(M, E, H, 0) && mn_skinny_workspace_bytes(M, E, H, 0) > 0;
+  const bool mfma = M <= 64 && ws != nullptr && ws_bytes >= mn_skinny_workspace_bytes(M, E, H, 0) && mn_skinny_workspace_bytes(M, E, H, 0) > 0;
   const int mstep = mfma ? M : 8;
   for (int gsel = 0; gsel < (both ? 2 : 1); ++gsel)
     for (int m0 = 0; m0 < M; m0 += mstep) {

@@ -373,8 +373,8 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
                             const float* noise, float temperature, float text_cfg, float image_cfg,
                             float* latent_out, void* workspace, size_t workspace_bytes, void* stream) {
   MN_CHECK_ARG(h && hidden && noise && latent_out && workspace, "mn_rf_sample: null pointer");
-  MN_CHECK_ARG(n_images >= 1 && rows >= n_images && rows % n_images == 0 && rows / n_images <= 3 && rows <= 32,
-               "mn_rf_sample: rows=%d n_images=%d (1..3 CFG rows per image, <= 32 rows)", rows, n_images);
+  MN_CHECK_ARG(n_images >= 1 && rows >= n_images && rows % n_images == 0 && rows / n_images <= 3 && rows <= 64,
+               "mn_rf_sample: rows=%d n_images=%d (1..3 CFG rows per image, <= 64 rows)", rows, n_images);
   MN_CHECK_ARG(h->target <= 256, "mn_rf_sample: target too large");
   const int rpi = rows / n_images;
   float *z, *c, *ada, *hh, *hid, *v, *x;
@@ -609,7 +609,7 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
                            float* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
   MN_CHECK_ARG(m && x && row_seq && row_slot && row_pos && row_len && kv_cache && hidden_out && workspace,
                "mn_llm_step: null pointer");
-  MN_CHECK_ARG(M >= 1 && M <= 32 && x_row_div >= 1, "mn_llm_step: M=%d (1..32)", M);
+  MN_CHECK_ARG(M >= 1 && M <= 64 && x_row_div >= 1, "mn_llm_step: M=%d (1..64)", M);
   LlmWs w;
   const size_t need = llm_carve(m, M, t_max, workspace, workspace_bytes, &w);
   if (need > workspace_bytes) { mn_set_error("mn_llm_step: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
@@ -708,7 +708,7 @@ extern "C" int mn_semdec_step(const mn_semdec* s, const float* latent_norm, int 
                               int64_t t_max, float* sem_out, float* embed_out, void* workspace,
                               size_t workspace_bytes, void* stream) {
   MN_CHECK_ARG(s && latent_norm && row_seq && row_slot && row_len && kv_cache && workspace, "mn_semdec_step: null pointer");
-  MN_CHECK_ARG(M >= 1 && M <= 32 && s->dim == s->n_heads * 64 && s->dim % s->in_dim == 0, "mn_semdec_step: bad shape");
+  MN_CHECK_ARG(M >= 1 && M <= 64 && s->dim == s->n_heads * 64 && s->dim % s->in_dim == 0, "mn_semdec_step: bad shape");
 
   MN_CHECK_ARG(!embed_out || (s->proj_depth >= 1 && s->proj_depth <= 2), "mn_semdec_step: proj_depth must be 1 or 2");
   SemWs w;

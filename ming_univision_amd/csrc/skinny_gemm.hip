@@ -299,7 +299,7 @@ extern "C" size_t mn_skinny_workspace_bytes(int M, int N, int K, int epilogue) {
 }
 
 static int skinny_medium(const mn_skinny_args& a, void* stream) {
-  MN_CHECK_ARG(a.M <= 32, "mn_skinny_gemm: M=%d out of range [1,32]", a.M);
+  MN_CHECK_ARG(a.M <= 64, "mn_skinny_gemm: M=%d out of range [1,64]", a.M);
   MN_CHECK_ARG((a.batch <= 1) && (a.nseg <= 1), "mn_skinny_gemm: batch/nseg forms need M <= 8");
   MN_CHECK_ARG(a.ldw == a.K, "mn_skinny_gemm: M > 8 needs densely packed weights (ldw == K)");
   const int Ntot = a.epilogue == MN_EPI_SWIGLU ? 2 * a.N : a.N;
@@ -325,7 +325,7 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   KArgs ka;
   ka.a = *args;
   mn_skinny_args& a = ka.a;
-  MN_CHECK_ARG(a.M >= 1 && a.M <= 32, "mn_skinny_gemm: M=%d out of range [1,32]", a.M);
+  MN_CHECK_ARG(a.M >= 1 && a.M <= 64, "mn_skinny_gemm: M=%d out of range [1,64]", a.M);
   MN_CHECK_ARG(a.N >= 1 && a.K >= 8 && (a.K % 8) == 0, "mn_skinny_gemm: bad N=%d K=%d (K %% 8 must be 0)", a.N, a.K);
   MN_CHECK_ARG((a.ldw % 8) == 0, "mn_skinny_gemm: ldw=%lld must be a multiple of 8", (long long)a.ldw);
   MN_CHECK_ARG(a.x && a.w && a.out, "mn_skinny_gemm: null pointer");

@@ -12,12 +12,10 @@
 // Each wave streams its own 16 x 128 weight chunks (4 instructions of 4 rows x 256 B, nontemporal) through a D-deep
 // register ring into a wave-private swizzled 4 KiB LDS tile; one workgroup barrier per chunk orders the x buffers.
 //
-// STATUS (round 1): parity-green (tools/ab_kloop.py: <= 7e-7 against float64 on dense shapes) but NOT on the product
-// path.  Measured on MI355X: on par with the K-slice kernel at 32 rows (RF w12 23.0-24.9 vs 24.1 us, w3 15.1 vs 14.9);
-// at 64 rows RF w12 takes 39.8 us (2.5 TB/s) — no longer HBM-bound: with one weight tile per wave every 4 KiB weight
-// chunk costs 32 KiB of x fragment reads from LDS.  The 64-row regime needs two weight tiles per wave (or the 32x32x16
-// MFMA) to halve that traffic; that is next round's work, and this file is its starting point.  Entry points are
-// internal (not declared in mingnative.h).
+// Used for 33..64 rows (stream_mfma.hip forwards): there each wave owns TWO adjacent weight tiles (NT = 2) so that an x
+// fragment read from LDS feeds two MFMAs per half — with one tile per wave every 4 KiB weight chunk costs 32 KiB of x
+// fragment reads and the kernel is LDS-bound (RF w12 at 64 rows: 40 us with NT = 1, 28-29 us with NT = 2, ring depth 2;
+// a 4-deep ring spills).  At <= 32 rows it is on par with the K-slice kernel (23-25 vs 24 us), which stays the default there.
 #include "common.h"
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -40,11 +38,11 @@ struct KGroups {
 // (16 rows x 4 slots per lane group) conflict-free
 __device__ __forceinline__ int cslot(int row, int slot) { return row * ROWB + ((slot ^ (row & 15)) << 4); }
 
-template <int MT, int D>
+template <int MT, int NT, int D>
 __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
                                                                const bf16_t* __restrict__ W, float* __restrict__ P,
                                                                int64_t p_slab, int M, int Ntot, int K, int nz, KGroups g) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];          // x: [2 bufs][2 x 16MT rows][256 B]; w: [KW][16][256 B]
+  extern __shared__ __attribute__((aligned(16))) char lds[];          // x: [2 bufs][2 x 16MT rows][256 B]; w: [KW][16 NT][256 B]
   constexpr int XR = 16 * MT;                                         // x rows per half (hi / lo)
   constexpr int XB = 2 * XR * ROWB;                                   // bytes per x buffer
   int row0 = 0, nrows = M;
@@ -56,13 +54,13 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
-  char* wt = lds + 2 * XB + wave * 16 * ROWB;
+  char* wt = lds + 2 * XB + wave * (16 * NT) * ROWB;
   // K-range of this workgroup: chunks [c0, c0 + nc), balanced over the nz ranges
   const int nch = (K + CK - 1) / CK;
   const int z = blockIdx.y, base = nch / nz, rem = nch % nz;
   const int c0 = z * base + min(z, rem), nc = base + (z < rem ? 1 : 0);
   const int ntiles = (Ntot + 15) >> 4;
-  const int t = blockIdx.x * KW + wave;
+  const int t = (blockIdx.x * KW + wave) * NT;                        // first of this wave's NT adjacent tiles
   const bool active = t < ntiles;                                     // idle waves still help with x and the barriers
   const int mtn = (nrows + 15) >> 4;                                  // 16-row x tiles actually populated
 
@@ -81,18 +79,19 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
       xp[j] = Y + h * y_lo + (int64_t)xr * K + slot * 8;
     }
   }
-  // ---- weight pieces of this wave: instruction i -> row i * 4 + (lane >> 4), slot lane & 15 (4 rows x 256 B)
-  const bf16_t* wp[4];
-  int wo[4];
+  // ---- weight pieces of this wave: instruction i -> row i * 4 + (lane >> 4) of its 16 NT rows, slot lane & 15 (4 rows x 256 B)
+  constexpr int WI = 4 * NT;
+  const bf16_t* wp[WI];
+  int wo[WI];
   const int wslot_k = (lane & 15) * 8;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < WI; ++i) {
     const int row = i * 4 + (lane >> 4);
     const int n = min(t * 16 + row, Ntot - 1);
     wp[i] = W + (int64_t)n * K;
     wo[i] = cslot(row, lane & 15);
   }
-  u32x4 xr_[D][MT], wr_[D][4];
+  u32x4 xr_[D][MT], wr_[D][WI];
   auto load_x = [&](u32x4 (&dst)[MT], int c) {
     const int k = (c0 + c) * CK;
 #pragma unroll
@@ -101,10 +100,10 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
       if (xp[j] && k + ((tid + j * (KW * 64)) & 15) * 8 < K) dst[j] = *reinterpret_cast<const u32x4*>(xp[j] + k);
     }
   };
-  auto load_w = [&](u32x4 (&dst)[4], int c) {
+  auto load_w = [&](u32x4 (&dst)[WI], int c) {
     const int k = min((c0 + c) * CK + wslot_k, K - 8);                // beyond K the x image is zero: any finite value will do
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[i] + k));
+    for (int i = 0; i < WI; ++i) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[i] + k));
   };
   auto store_x = [&](const u32x4 (&src)[MT], int buf) {
 #pragma unroll
@@ -124,9 +123,11 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
   if (D < nc) load_x(xr_[0], D);
   __syncthreads();
 
-  f32x4 acc[MT];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int cb = 0; cb < nc; cb += D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -136,19 +137,24 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
         if (active) {
           // park the landed weight chunk, refill its registers with the chunk D ahead
 #pragma unroll
-          for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(wt + wo[i]) = wr_[d][i];
+          for (int i = 0; i < WI; ++i) *reinterpret_cast<u32x4*>(wt + wo[i]) = wr_[d][i];
           if (c + D < nc) load_w(wr_[d], c + D);
           // 4 MFMA steps of 32 k against every populated x tile (hi and lo)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const bf16x8 w = *reinterpret_cast<const bf16x8*>(wt + cslot(fr, s * 4 + fq));
+            bf16x8 w[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const bf16x8*>(wt + cslot(nt * 16 + fr, s * 4 + fq));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               if (mt < mtn) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(lds + buf * XB + cslot(mt * 16 + fr, s * 4 + fq));
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(lds + buf * XB + cslot(XR + mt * 16 + fr, s * 4 + fq));
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w[nt], acc[mt][nt], 0, 0, 0);
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w[nt], acc[mt][nt], 0, 0, 0);
+                }
               }
             }
           }
@@ -163,26 +169,34 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
       }
     }
   }
-  // D layout: row m = fq*4 + r, col n = t*16 + fr
-  const int nn = t * 16 + fr;
-  if (active && nn < Ntot) {
+  // D layout: row m = fq*4 + r, col n = tile*16 + fr
+  if (active) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int nt = 0; nt < NT; ++nt) {
+      const int nn = (t + nt) * 16 + fr;
+      if (nn < Ntot) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = mt * 16 + fq * 4 + r;
-        if (m < nrows) P[(int64_t)z * p_slab + (int64_t)(row0 + m) * Ntot + nn] = acc[mt][r];
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = mt * 16 + fq * 4 + r;
+            if (m < nrows) P[(int64_t)z * p_slab + (int64_t)(row0 + m) * Ntot + nn] = acc[mt][nt][r];
+          }
+        }
       }
     }
   }
 }
 
-int g_kl_nz = 0, g_kl_depth = 0;
+int g_kl_nz = 0, g_kl_depth = 0, g_kl_nt = 0;
+
+// weight tiles per wave: two above 32 rows (halves the x fragment reads per weight byte, which bound the 64-row regime)
+int kloop_nt(int max_rows) { return g_kl_nt > 0 ? g_kl_nt : (max_rows > 32 ? 2 : 1); }
 
 // number of K-ranges: enough workgroups to fill `slots` CUs-worth of residency, never more ranges than chunks
-int kloop_nz(int Ntot, int K, int slots) {
+int kloop_nz(int Ntot, int K, int slots, int nt) {
   if (g_kl_nz > 0) return g_kl_nz;
-  const int tb = (int)mn_cdiv(mn_cdiv(Ntot, 16), KW);
+  const int tb = (int)mn_cdiv(mn_cdiv(Ntot, 16), KW * nt);
   const int nch = (int)mn_cdiv(K, CK);
   int nz = slots / tb;
   if (nz < 1) nz = 1;
@@ -190,46 +204,53 @@ int kloop_nz(int Ntot, int K, int slots) {
   return nz;
 }
 
-template <int MT, int D>
+template <int MT, int NT, int D>
 void kloop_launch(int G, int nz, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab, int M, int Ntot,
                   int K, const KGroups& g, hipStream_t st) {
-  const size_t lds = (size_t)2 * 2 * 16 * MT * ROWB + (size_t)KW * 16 * ROWB;
+  const size_t lds = (size_t)2 * 2 * 16 * MT * ROWB + (size_t)KW * 16 * NT * ROWB;
   static bool opted = false;
   if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_kloop_kernel<MT, D>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_kloop_kernel<MT, NT, D>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     opted = true;
   }
-  const int tb = (int)mn_cdiv(mn_cdiv(Ntot, 16), KW);
-  hipLaunchKernelGGL((stream_kloop_kernel<MT, D>), dim3(tb, nz, G), dim3(KW * 64), lds, st, Y, y_lo, W, P, p_slab, M, Ntot, K,
-                     nz, g);
+  const int tb = (int)mn_cdiv(mn_cdiv(Ntot, 16), KW * NT);
+  hipLaunchKernelGGL((stream_kloop_kernel<MT, NT, D>), dim3(tb, nz, G), dim3(KW * 64), lds, st, Y, y_lo, W, P, p_slab, M, Ntot,
+                     K, nz, g);
 }
 
 template <int MT>
-void kloop_launch_d(int G, int nz, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab, int M, int Ntot,
-                    int K, const KGroups& g, hipStream_t st) {
-  if (g_kl_depth == 2) kloop_launch<MT, 2>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
-  else kloop_launch<MT, 4>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+void kloop_launch_d(int nt, int G, int nz, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab, int M,
+                    int Ntot, int K, const KGroups& g, hipStream_t st) {
+  const int depth = g_kl_depth > 0 ? g_kl_depth : (nt == 2 ? 2 : 4);
+  if (nt == 2) {
+    if (depth == 2) kloop_launch<MT, 2, 2>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+    else kloop_launch<MT, 2, 4>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+  } else {
+    if (depth == 2) kloop_launch<MT, 1, 2>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+    else kloop_launch<MT, 1, 4>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+  }
 }
 
 int kloop_dispatch(int G, int max_rows, int nz, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab,
                    int M, int Ntot, int K, const KGroups& g, hipStream_t st) {
-  if (max_rows <= 16) kloop_launch_d<1>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
-  else if (max_rows <= 32) kloop_launch_d<2>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
-  else kloop_launch_d<4>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+  const int nt = kloop_nt(max_rows);
+  if (max_rows <= 16) kloop_launch_d<1>(nt, G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+  else if (max_rows <= 32) kloop_launch_d<2>(nt, G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+  else kloop_launch_d<4>(nt, G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
   return nz;
 }
 
 }  // namespace
 
-extern "C" void mn_stream_kloop_tune(int nz, int depth) { g_kl_nz = nz; g_kl_depth = depth; }
+extern "C" void mn_stream_kloop_tune(int nz, int depth, int nt) { g_kl_nz = nz; g_kl_depth = depth; g_kl_nt = nt; }
 
-extern "C" int mn_stream_kloop_slices(int M, int Ntot, int K) { return kloop_nz(Ntot, K, mn_num_cus()); }
+extern "C" int mn_stream_kloop_slices(int M, int Ntot, int K) { return kloop_nz(Ntot, K, mn_num_cus(), kloop_nt(M)); }
 
 // Dense: Y [2][M][K] bf16 (hi rows then lo rows), W [Ntot][K], P [nz][M][Ntot].  Returns nz (< 0: error).  M <= 64.
 extern "C" int mn_stream_kloop(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream) {
   MN_CHECK_ARG(Y && W && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0, "mn_stream_kloop: bad args");
-  const int nz = kloop_nz(Ntot, K, mn_num_cus());
+  const int nz = kloop_nz(Ntot, K, mn_num_cus(), kloop_nt(M));
   const KGroups g{nullptr, nullptr, 0};
   kloop_dispatch(1, M, nz, Y, (int64_t)M * K, W, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
   MN_CHECK_LAUNCH("mn_stream_kloop");
@@ -238,7 +259,7 @@ extern "C" int mn_stream_kloop(const uint16_t* Y, const uint16_t* W, float* P, i
 
 extern "C" int mn_stream_kloop_grouped_slices(int G, int max_rows, int Ntot, int K) {
   const int slots = (int)mn_cdiv((int64_t)4 * mn_num_cus(), G);
-  return kloop_nz(Ntot, K, slots < 1 ? 1 : slots);
+  return kloop_nz(Ntot, K, slots < 1 ? 1 : slots, kloop_nt(max_rows));
 }
 
 extern "C" int mn_stream_kloop_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P,

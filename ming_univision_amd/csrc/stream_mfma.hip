@@ -1,4 +1,5 @@
-// stream_mfma.hip — weight-streaming GEMM for 5..32 activation rows on the matrix cores (gfx950).
+// stream_mfma.hip — weight-streaming GEMM for 5..32 activation rows on the matrix cores (gfx950); 33..64 rows are
+// forwarded to the K-loop form in stream_kloop.hip.
 //
 //   partial[z][row][n] = sum_{k in slice z} (x_hi[xrow,k] + x_lo[xrow,k]) * W_g[n,k]
 //
@@ -27,6 +28,14 @@
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// K-loop form for 33..64 rows (stream_kloop.hip)
+extern "C" int mn_stream_kloop(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream);
+extern "C" int mn_stream_kloop_slices(int M, int Ntot, int K);
+extern "C" int mn_stream_kloop_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P,
+                                       int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows, int Ntot,
+                                       int K, void* stream);
+extern "C" int mn_stream_kloop_grouped_slices(int G, int max_rows, int Ntot, int K);
 
 namespace {
 
@@ -246,12 +255,14 @@ int group_slots(int G) {
 extern "C" void mn_stream_tune_plan(int kch, int nw) { g_kch = kch; g_nw = nw; }
 
 extern "C" int mn_stream_mfma_slices(int M, int Ntot, int K) {
+  if (M > 32) return mn_stream_kloop_slices(M, Ntot, K);
   return stream_plan(M > 16 ? 2 : 1, Ntot, K, mn_num_cus()).nz;
 }
 
 // Dense: Y [2][M][K] bf16 (hi rows then lo rows), W [Ntot][K], P [nz][M][Ntot].  Returns nz (< 0: error).
 extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream) {
-  MN_CHECK_ARG(Y && W && P && M >= 1 && M <= 32 && Ntot >= 1 && K >= 8 && (K % 8) == 0, "mn_stream_mfma: bad args");
+  MN_CHECK_ARG(Y && W && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0, "mn_stream_mfma: bad args");
+  if (M > 32) return mn_stream_kloop(Y, W, P, M, Ntot, K, stream);      // 33..64 rows: K-loop form, two tiles per wave
   const int mt = M > 16 ? 2 : 1;
   const StreamPlan pl = stream_plan(mt, Ntot, K, mn_num_cus());
   const StreamGroups g{nullptr, nullptr, 0};
@@ -262,6 +273,7 @@ extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, in
 }
 
 extern "C" int mn_stream_mfma_grouped_slices(int G, int max_rows, int Ntot, int K) {
+  if (max_rows > 32) return mn_stream_kloop_grouped_slices(G, max_rows, Ntot, K);
   return stream_plan(max_rows > 16 ? 2 : 1, Ntot, K, group_slots(G)).nz;
 }
 
@@ -271,8 +283,10 @@ extern "C" int mn_stream_mfma_grouped_slices(int G, int max_rows, int Ntot, int 
 extern "C" int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P,
                                       int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows,
                                       int Ntot, int K, void* stream) {
-  MN_CHECK_ARG(Y && W && P && off && G >= 1 && max_rows >= 1 && max_rows <= 32 && Ntot >= 1 && K >= 8 && (K % 8) == 0,
+  MN_CHECK_ARG(Y && W && P && off && G >= 1 && max_rows >= 1 && max_rows <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0,
                "mn_stream_mfma_grouped: bad args");
+  if (max_rows > 32)
+    return mn_stream_kloop_grouped(Y, y_rows, W, w_stride, P, p_rows, off, xrows, G, max_rows, Ntot, K, stream);
   const int mt = max_rows > 16 ? 2 : 1;
   const StreamPlan pl = stream_plan(mt, Ntot, K, group_slots(G));
   const StreamGroups g{off, xrows, w_stride};

@@ -210,10 +210,13 @@ def test_attn_prefill_hd64(ops, B, T, nh, causal):
                                            (12, 3072, 8192, "resid_gate", "none"), (16, 32, 3072, "none", "ln_mod"),
                                            (10, 1000, 32, "silu", "none"), (16, 3072, 2048, "resid", "add_silu"),
                                            (32, 8192, 3072, "swiglu", "ln_mod"), (24, 3072, 2048, "resid", "rmsnorm"),
-                                           (17, 100, 1408, "none", "none"), (31, 3072, 8192, "resid_gate", "none")])
+                                           (17, 100, 1408, "none", "none"), (31, 3072, 8192, "resid_gate", "none"),
+                                           (64, 8192, 3072, "swiglu", "ln_mod"), (48, 3072, 8192, "resid_gate", "none"),
+                                           (33, 100, 264, "none", "rmsnorm"), (64, 2048, 2048, "resid", "rmsnorm")])
 def test_skinny_medium_rows(ops, M, N, K, epi, pro):
     """5..32 rows take the split-bf16 MFMA route (prologue -> K-sliced streaming GEMM -> reduce+epilogue);
-    > 16 rows use two 16-row MFMA tiles per weight tile."""
+    > 16 rows use two 16-row MFMA tiles per weight tile, > 32 rows the K-loop form (four row tiles, two weight tiles
+    per wave)."""
     x = rnd(M, K, seed=70) * 1.5 + 0.2
     rows = 2 * N if epi == "swiglu" else N
     w, wf = bw(rows, K, seed=71, scale=K ** -0.5)
@@ -249,7 +252,8 @@ def test_skinny_medium_rows(ops, M, N, K, epi, pro):
 
 
 @pytest.mark.parametrize("G,max_rows,N,K,gather", [(10, 16, 2816, 2048, True), (7, 32, 2048, 1408, False),
-                                                   (3, 5, 100, 264, True)])
+                                                   (3, 5, 100, 264, True), (9, 64, 2816, 2048, True),
+                                                   (5, 50, 2048, 1408, False)])
 def test_stream_mfma_grouped(ops, G, max_rows, N, K, gather):
     """Grouped weight-streaming kernel (MoE experts): ragged groups incl. empty ones, gathered or contiguous x rows,
     K not a multiple of the 256-k chunk; partial slabs summed here in float64."""
@@ -262,7 +266,7 @@ def test_stream_mfma_grouped(ops, G, max_rows, N, K, gather):
     off = torch.zeros(G + 1, dtype=torch.int32)
     off[1:] = cnt.cumsum(0)
     total = int(off[-1])
-    n_x = 9 if gather else total
+    n_x = (9 if max_rows <= 32 else 70) if gather else total
     xrows = torch.randint(0, n_x, (total,), generator=g, dtype=torch.int32) if gather else None
     x = rnd(n_x, K, seed=90)
     hi = x.to(torch.bfloat16)

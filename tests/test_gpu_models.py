@@ -316,10 +316,10 @@ def test_rf_persistent_matches_per_launch_path():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("B,groups", [(4, 1), (10, 1), (6, 3)])
+@pytest.mark.parametrize("B,groups", [(4, 1), (10, 1), (6, 3), (21, 1)])
 def test_batched_generation_matches_single_image(B, groups):
     """generate_images with B images in lock-step (rows = B x CFG rows: 12 rows = one MFMA row tile, 30 rows =
-    two; grouped-expert MoE path; groups > 1: lock-step groups overlapped on separate HIP streams) must reproduce
+    two; 63 rows = the K-loop form with four; grouped-expert MoE path; groups > 1: lock-step groups overlapped on separate HIP streams) must reproduce
     each image's batch-size-1 result."""
     from ming_univision_amd.bailing_moe import BailingMoeDecoder, generate_image, generate_images
     from ming_univision_amd.mingtok import MingTok
@@ -360,9 +360,12 @@ def test_batched_generation_matches_single_image(B, groups):
         ams.append(am); uns.append(un); tus.append(tu)
     out = generate_images(dec, rf, tok, start, [p.numel() for p in prompts], ams, uns, tus, noises.cuda(), n_groups=groups)
     assert out["image"].shape[0] == B
+    # Two HIP paths are compared here (fp32-FMA kernels at 3 rows vs the matrix-core route, whose activations are rounded to
+    # bf16 hi+lo = 2^-17): the random tiny model amplifies that per-op 1e-5 through 6 AR steps x CFG-3.0 Euler steps to
+    # 3e-5 .. 1.2e-3 depending on the image, hence 2e-3 here; image 0 is held to 1e-3 against the reference below.
     for i in range(B):
-        assert rel_err(out["latents"][i], singles[i]["latents"]) < TOL, i
-        assert rel_err(out["last_hidden"][i * R:(i + 1) * R], singles[i]["last_hidden"]) < TOL, i
+        assert rel_err(out["latents"][i], singles[i]["latents"]) < 2 * TOL, i
+        assert rel_err(out["last_hidden"][i * R:(i + 1) * R], singles[i]["last_hidden"]) < 2 * TOL, i
         assert psnr(out["image"][i], singles[i]["image"][0]) > 45.0, i
     assert rel_err(out["last_hidden"][:R], g["rows3_last_hidden"][:, 0]) < TOL      # image 0 is the reference's case
 

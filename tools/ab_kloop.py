@@ -7,7 +7,7 @@ L = lib()
 i, p = ctypes.c_int, ctypes.c_void_p
 L.mn_stream_kloop.argtypes = [p, p, p, i, i, i, p]; L.mn_stream_kloop.restype = i
 L.mn_stream_kloop_slices.argtypes = [i, i, i]; L.mn_stream_kloop_slices.restype = i
-L.mn_stream_kloop_tune.argtypes = [i, i]; L.mn_stream_kloop_tune.restype = None
+L.mn_stream_kloop_tune.argtypes = [i, i, i]; L.mn_stream_kloop_tune.restype = None
 
 def check(M, N, K):
     g = torch.Generator().manual_seed(1)
@@ -36,7 +36,7 @@ def bench(M, N2, K, variants, rounds=5, iters=24):
             if v[0] == "slice":
                 fn = lambda w: L.mn_stream_mfma(ptr(Y), ptr(w), ptr(P), M, N2, K, current_stream())
             else:
-                L.mn_stream_kloop_tune(v[1], v[2])
+                L.mn_stream_kloop_tune(v[1], v[2], v[3])
                 fn = lambda w: L.mn_stream_kloop(ptr(Y), ptr(w), ptr(P), M, N2, K, current_stream())
             for k in range(3): fn(ws[k % 6])
             torch.cuda.synchronize()
@@ -48,13 +48,15 @@ def bench(M, N2, K, variants, rounds=5, iters=24):
     for v in variants:
         t = sorted(res[v]); print(f"M={M} N={N2} K={K} {v}: median {t[len(t)//2]:.1f} us ({N2*K*2/t[len(t)//2]/1e3:.0f} GB/s)", flush=True)
 
-for shp in [(16, 512, 1408), (32, 16384, 3072), (64, 3072, 8192), (50, 100, 264), (5, 2816, 2048)]:
-    check(*shp)
-L.mn_stream_kloop_tune(0, 0)
+for nt in (1, 2):
+    L.mn_stream_kloop_tune(0, 0, nt)
+    for shp in [(16, 512, 1408), (32, 16384, 3072), (64, 3072, 8192), (50, 100, 264), (5, 2816, 2048), (64, 16384, 3072)]:
+        check(*shp)
+L.mn_stream_kloop_tune(0, 0, 0)
 for M in (32, 64):
-    V = [("kloop", nz, d) for nz in (0, 1, 2, 4) for d in (4, 2)]
-    if M <= 32: V = [("slice", 0, 0)] + V
+    V = [("kloop", nz, d, nt) for nt in (1, 2) for nz in (0, 2, 4) for d in (4, 2)]
+    if M <= 32: V = [("slice", 0, 0, 0)] + V
     bench(M, 16384, 3072, V)
-    V = [("kloop", nz, d) for nz in (0, 8, 16) for d in (4, 2)]
-    if M <= 32: V = [("slice", 0, 0)] + V
+    V = [("kloop", nz, d, nt) for nt in (1, 2) for nz in (0, 8, 16) for d in (4, 2)]
+    if M <= 32: V = [("slice", 0, 0, 0)] + V
     bench(M, 3072, 8192, V)
