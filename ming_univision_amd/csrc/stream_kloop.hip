@@ -32,6 +32,7 @@ struct KGroups {
   const int32_t* off;      // [G + 1] offsets into the sorted row list; nullptr = one dense group of M rows
   const int32_t* xrows;    // [total] x row of each sorted row; nullptr = identity (off[g] + r)
   int64_t w_stride;        // elements between consecutive groups' weight matrices
+  int row_lo;              // only groups with more than row_lo rows are processed by this launch
 };
 
 // byte offset of 16-byte slot `slot` (0..15) of chunk row `row`: XOR swizzle makes the b128 fragment reads
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
   if (g.off) {
     row0 = g.off[blockIdx.z];
     nrows = g.off[blockIdx.z + 1] - row0;
-    if (nrows <= 0) return;
+    if (nrows <= g.row_lo) return;
     W += (int64_t)blockIdx.z * g.w_stride;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -251,24 +252,21 @@ extern "C" int mn_stream_kloop_slices(int M, int Ntot, int K) { return kloop_nz(
 extern "C" int mn_stream_kloop(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream) {
   MN_CHECK_ARG(Y && W && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0, "mn_stream_kloop: bad args");
   const int nz = kloop_nz(Ntot, K, mn_num_cus(), kloop_nt(M));
-  const KGroups g{nullptr, nullptr, 0};
+  const KGroups g{nullptr, nullptr, 0, 0};
   kloop_dispatch(1, M, nz, Y, (int64_t)M * K, W, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
   MN_CHECK_LAUNCH("mn_stream_kloop");
   return nz;
 }
 
-extern "C" int mn_stream_kloop_grouped_slices(int G, int max_rows, int Ntot, int K) {
-  const int slots = (int)mn_cdiv((int64_t)4 * mn_num_cus(), G);
-  return kloop_nz(Ntot, K, slots < 1 ? 1 : slots, kloop_nt(max_rows));
-}
-
+// Grouped form: processes the groups with more than row_lo rows (<= 64), writing `nz` K-range slabs (the caller's
+// K-slice kernel covers the smaller groups with the same slab count).
 extern "C" int mn_stream_kloop_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P,
-                                       int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows, int Ntot,
-                                       int K, void* stream) {
-  MN_CHECK_ARG(Y && W && P && off && G >= 1 && max_rows >= 1 && max_rows <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0,
+                                       int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows, int row_lo,
+                                       int nz, int Ntot, int K, void* stream) {
+  MN_CHECK_ARG(Y && W && P && off && G >= 1 && max_rows >= 1 && max_rows <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0 &&
+                   nz >= 1 && nz <= (K + CK - 1) / CK,
                "mn_stream_kloop_grouped: bad args");
-  const int nz = mn_stream_kloop_grouped_slices(G, max_rows, Ntot, K);
-  const KGroups g{off, xrows, w_stride};
+  const KGroups g{off, xrows, w_stride, row_lo};
   kloop_dispatch(G, max_rows, nz, Y, (int64_t)y_rows * K, W, P, (int64_t)p_rows * Ntot, 0, Ntot, K, g, mn_stream(stream));
   MN_CHECK_LAUNCH("mn_stream_kloop_grouped");
   return nz;

@@ -33,9 +33,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 extern "C" int mn_stream_kloop(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream);
 extern "C" int mn_stream_kloop_slices(int M, int Ntot, int K);
 extern "C" int mn_stream_kloop_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P,
-                                       int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows, int Ntot,
-                                       int K, void* stream);
-extern "C" int mn_stream_kloop_grouped_slices(int G, int max_rows, int Ntot, int K);
+                                       int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows, int row_lo,
+                                       int nz, int Ntot, int K, void* stream);
 
 namespace {
 
@@ -51,6 +50,7 @@ struct StreamGroups {
   const int32_t* off;      // [G + 1] offsets into the sorted row list; nullptr = one dense group of M rows
   const int32_t* xrows;    // [total] x row of each sorted row; nullptr = identity (off[g] + r)
   int64_t w_stride;        // elements between consecutive groups' weight matrices
+  int row_lo, row_hi;      // only groups with row_lo < rows <= row_hi are processed by this launch
 };
 
 // Y: bf16, hi rows at Y, lo rows at Y + y_lo (row stride K).  P: [nz][p_rows][Ntot] fp32, p_slab = p_rows * Ntot.
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
   if (g.off) {
     row0 = g.off[blockIdx.z];
     nrows = g.off[blockIdx.z + 1] - row0;
-    if (nrows <= 0) return;
+    if (nrows <= g.row_lo || nrows > g.row_hi) return;
     W += (int64_t)blockIdx.z * g.w_stride;
   }
   constexpr int XR = 16 * MT;
@@ -265,7 +265,7 @@ extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, in
   if (M > 32) return mn_stream_kloop(Y, W, P, M, Ntot, K, stream);      // 33..64 rows: K-loop form, two tiles per wave
   const int mt = M > 16 ? 2 : 1;
   const StreamPlan pl = stream_plan(mt, Ntot, K, mn_num_cus());
-  const StreamGroups g{nullptr, nullptr, 0};
+  const StreamGroups g{nullptr, nullptr, 0, 0, 1 << 30};
   if (mt == 1) stream_launch<1>(pl, 1, Y, (int64_t)M * K, W, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
   else stream_launch<2>(pl, 1, Y, (int64_t)M * K, W, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
   MN_CHECK_LAUNCH("mn_stream_mfma");
@@ -273,25 +273,28 @@ extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, in
 }
 
 extern "C" int mn_stream_mfma_grouped_slices(int G, int max_rows, int Ntot, int K) {
-  if (max_rows > 32) return mn_stream_kloop_grouped_slices(G, max_rows, Ntot, K);
   return stream_plan(max_rows > 16 ? 2 : 1, Ntot, K, group_slots(G)).nz;
 }
 
 // Grouped: group g (of G) multiplies the x rows xrows[off[g] .. off[g+1]) (identity when xrows == NULL) by
 // W + g * w_stride and writes partial rows off[g].. of P [nz][p_rows][Ntot].  Y holds y_rows hi rows then y_rows lo
-// rows.  No group may have more than max_rows (<= 32) rows.  off / xrows live in device memory.
+// rows.  No group may have more than max_rows (<= 64) rows.  off / xrows live in device memory.
 extern "C" int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P,
                                       int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows,
                                       int Ntot, int K, void* stream) {
   MN_CHECK_ARG(Y && W && P && off && G >= 1 && max_rows >= 1 && max_rows <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0,
                "mn_stream_mfma_grouped: bad args");
-  if (max_rows > 32)
-    return mn_stream_kloop_grouped(Y, y_rows, W, w_stride, P, p_rows, off, xrows, G, max_rows, Ntot, K, stream);
+  // groups of <= 32 rows (the routed experts, a handful of rows each) run the K-slice kernel; larger ones (the shared
+  // experts at > 32 rows) the K-loop form with the same number of partial slabs — two launches, each skipping the other's groups
   const int mt = max_rows > 16 ? 2 : 1;
   const StreamPlan pl = stream_plan(mt, Ntot, K, group_slots(G));
-  const StreamGroups g{off, xrows, w_stride};
+  const StreamGroups g{off, xrows, w_stride, 0, 32};
   if (mt == 1) stream_launch<1>(pl, G, Y, (int64_t)y_rows * K, W, P, (int64_t)p_rows * Ntot, 0, Ntot, K, g, mn_stream(stream));
   else stream_launch<2>(pl, G, Y, (int64_t)y_rows * K, W, P, (int64_t)p_rows * Ntot, 0, Ntot, K, g, mn_stream(stream));
+  if (max_rows > 32) {
+    const int rc = mn_stream_kloop_grouped(Y, y_rows, W, w_stride, P, p_rows, off, xrows, G, max_rows, 32, pl.nz, Ntot, K, stream);
+    if (rc < 0) return rc;
+  }
   MN_CHECK_LAUNCH("mn_stream_mfma_grouped");
   return pl.nz;
 }
