@@ -52,6 +52,9 @@ def pack_experts(sd, prefix, cfg):
     return gu, dn
 
 
+MAX_ROWS = 64   # rows of one pass through the decode kernels (four 16-row MFMA tiles)
+
+
 class BailingMoeDecoder:
     """Weights + KV arena + C-ABI pointer table of the decoder stack."""
 
@@ -187,8 +190,8 @@ class BailingMoeDecoder:
                                 self.t_max, ptr(out), ptr(ws), ws.numel(), current_stream()), "mn_llm_step")
         return out
 
-    def prefill(self, embeds, seq=0, past=0, image_mask=None, chunk=8):
-        """Causal prefill of ONE sequence by chunks of <= 8 rows through the decode kernels
+    def prefill(self, embeds, seq=0, past=0, image_mask=None, chunk=MAX_ROWS):
+        """Causal prefill of ONE sequence by chunks of <= 64 rows through the decode kernels
         (each row m of a chunk attends cache[0 : past + m + 1]).  embeds fp32 [T,H].
         Returns the hidden states [T,H]."""
         T = embeds.shape[0]
@@ -300,9 +303,6 @@ def build_cfg_rows(attention_mask, uncond_attention_mask, text_uncond_attention_
         if int((text_uncond_attention_mask == uncond_attention_mask).sum()) != uncond_attention_mask.numel():
             am = torch.cat((am, text_uncond_attention_mask), dim=0)
     return am
-
-
-MAX_ROWS = 64   # rows of one lock-step pass (four 16-row MFMA tiles)
 
 
 class ImageGenState:
