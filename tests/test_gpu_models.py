@@ -316,11 +316,11 @@ def test_rf_persistent_matches_per_launch_path():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("B,groups", [(4, 1), (10, 1), (6, 3), (21, 1)])
-def test_batched_generation_matches_single_image(B, groups):
+@pytest.mark.parametrize("B,groups,R", [(4, 1, 3), (10, 1, 3), (6, 3, 3), (21, 1, 3), (32, 2, 2)])
+def test_batched_generation_matches_single_image(B, groups, R):
     """generate_images with B images in lock-step (rows = B x CFG rows: 12 rows = one MFMA row tile, 30 rows =
-    two; 63 rows = the K-loop form with four; grouped-expert MoE path; groups > 1: lock-step groups overlapped on separate HIP streams) must reproduce
-    each image's batch-size-1 result."""
+    two; 63 rows = the K-loop form with four; grouped-expert MoE path; groups > 1: lock-step groups overlapped on separate
+    HIP streams; R = 2: [cond, uncond] rows of text-to-image, 2 x 32 rows) must reproduce each image's batch-size-1 result."""
     from ming_univision_amd.bailing_moe import BailingMoeDecoder, generate_image, generate_images
     from ming_univision_amd.mingtok import MingTok
     from ming_univision_amd.rf_head import RectifiedFlowHead
@@ -328,7 +328,7 @@ def test_batched_generation_matches_single_image(B, groups):
     sd = llm_sd(g["llm_config"], g["rf_config"], g["seed"])
     dsd = to_dev(sd)
     cfg = C.BailingMoeConfig(**g["llm_config"])
-    R = 3
+    tag = "rows3" if R == 3 else "rows2"
     dec = BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=32, n_seq=B * R)
     rf = RectifiedFlowHead(dsd, cfg.hidden_size, g["rf_config"])
     lsd = to_dev(synth_state_dict(C.linear_proj_param_shapes(128, 256, 2), g["seed"]))
@@ -346,17 +346,17 @@ def test_batched_generation_matches_single_image(B, groups):
         am = torch.ones(1, n + 1, dtype=torch.long)
         un = am.clone(); un[0, 2:n - 2] = 0
         tu = am.clone(); tu[0, 2:4] = 0
-        return am, un, tu
+        return am, un, (tu if R == 3 else un.clone())
     singles = []
     for i in range(B):
         dec.prefill(dec.embed(prompts[i].cuda()), seq=0, past=0)
-        am, un, tu = (g["mask"], g["uncond"], g["rows3_tuncond"]) if i == 0 else masks(prompts[i].numel())
+        am, un, tu = (g["mask"], g["uncond"], g[tag + "_tuncond"]) if i == 0 else masks(prompts[i].numel())
         singles.append(generate_image(dec, rf, tok, start, prompts[i].numel(), am, un, tu, noises[i].cuda()))
         singles[-1] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in singles[-1].items()}
     ams, uns, tus = [], [], []
     for i in range(B):
         dec.prefill(dec.embed(prompts[i].cuda()), seq=i * R, past=0)
-        am, un, tu = (g["mask"], g["uncond"], g["rows3_tuncond"]) if i == 0 else masks(prompts[i].numel())
+        am, un, tu = (g["mask"], g["uncond"], g[tag + "_tuncond"]) if i == 0 else masks(prompts[i].numel())
         ams.append(am); uns.append(un); tus.append(tu)
     out = generate_images(dec, rf, tok, start, [p.numel() for p in prompts], ams, uns, tus, noises.cuda(), n_groups=groups)
     assert out["image"].shape[0] == B
@@ -370,7 +370,7 @@ def test_batched_generation_matches_single_image(B, groups):
     assert sorted(e_lat)[B // 2] < 5e-4 and sorted(e_hid)[B // 2] < 5e-4, (e_lat, e_hid)
     for i in range(B):
         assert psnr(out["image"][i], singles[i]["image"][0]) > 45.0, i
-    assert rel_err(out["last_hidden"][:R], g["rows3_last_hidden"][:, 0]) < TOL      # image 0 is the reference's case
+    assert rel_err(out["last_hidden"][:R], g[tag + "_last_hidden"][:, 0]) < TOL      # image 0 is the reference's case
 
 
 def test_prefill_mfma_vs_chunked_fp32_and_reference(llm):
