@@ -35,9 +35,12 @@ class ReplicaGroup:
         return base + self.rank
 
     def barrier(self):
+        cuda = self.device is not None and torch.device(self.device).type == "cuda"
+        if cuda:
+            torch.cuda.synchronize()          # this rank's GPU work is done before it reports to the barrier
         if self.dist is not None:
             self.dist.barrier()
-        if self.device is not None and torch.device(self.device).type == "cuda":
+        if cuda:
             torch.cuda.synchronize()
 
     def max_over_ranks(self, seconds):
