@@ -1,0 +1,93 @@
+"""Full-WIDTH parity: the 16B-A3B layer shapes (H = 2048, 64 experts top-6 + 2 shared, I = 1408), the full RF head
+(w = 3072, depth 12, hidden 8192, 16 Euler steps) and the full MingTok semantic decoder (D = 1024, 24 layers), with the
+LLM cut to 2 layers and 3 visual tokens so that the fp32 CPU oracle finishes in seconds.  Covers what the tiny-config
+fixtures cannot: the production launch plans, tile counts and K ranges of every streaming kernel, end to end."""
+import pytest
+import torch
+
+from ming_univision_amd import configuration as C
+from ming_univision_amd.synth import synth_state_dict
+from tests.util import llm_sd, mingtok_sd, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+def _dev(sd):
+    return {k: v.to("cuda", torch.bfloat16).contiguous() for k, v in sd.items()}
+
+
+@pytest.fixture(scope="module")
+def full():
+    from oracle import bailing_ref
+    seed = 5
+    d = C.BailingMoeConfig.ming_univision_16b_a3b().to_dict()
+    d.pop("model_type", None)
+    d.update(num_hidden_layers=2, vocab_size=1024, num_image_tokens_for_gen=3, image_start_token=1000, pad_token_id=0)
+    rf_cfg = dict(C.DEFAULT_VISHEAD_DIFFLOSS)
+    tcfg = C.MingTokConfig()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    sd = llm_sd(d, rf_cfg, seed)                                   # fp32 values of bf16-rounded weights (CPU)
+    ocfg = bailing_ref.LLMConfig(**{k: v for k, v in d.items() if k in bailing_ref.LLMConfig.__dataclass_fields__})
+    return d, rf_cfg, tcfg, sd, ocfg, seed
+
+
+@pytest.mark.parametrize("rows_tag", ["rows2", "rows3"])
+def test_full_width_generate_image_vs_oracle(full, rows_tag):
+    from oracle import bailing_ref, mingtok_ref
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder, generate_image, generate_images
+    from ming_univision_amd.mingtok import MingTok
+    from ming_univision_amd.rf_head import RectifiedFlowHead
+    d, rf_cfg, tcfg, sd, ocfg, seed = full
+    cfg = C.BailingMoeConfig(**d)
+    dsd = _dev(sd)
+    B = 12                                                          # batched run below: 24 / 36 rows
+    dec = BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=32, n_seq=3 * B)
+    rf = RectifiedFlowHead(dsd, cfg.hidden_size, rf_cfg)
+    lsd = synth_state_dict(C.linear_proj_param_shapes(1024, cfg.hidden_size, 2), seed)
+    dl = _dev(lsd)
+    tok = MingTok(tcfg, device="cuda", seed=seed,
+                  linear_proj=[(dl["linear_proj.0.weight"], dl["linear_proj.0.bias"]),
+                               (dl["linear_proj.2.weight"], dl["linear_proj.2.bias"])])
+    tsd = {k: v.float().cpu() for k, v in tok.sd.items()}           # the oracle sees the same (bf16-rounded) MingTok weights
+    g = torch.Generator().manual_seed(1)
+    T = 12
+    ids = torch.randint(0, 900, (1, T), generator=g)
+    noises = torch.randn(cfg.num_image_tokens_for_gen + 1, 32, generator=g)
+    am = torch.ones(1, T + 1, dtype=torch.long)
+    un = am.clone(); un[0, 2:T - 2] = 0
+    tu = am.clone(); tu[0, 2:5] = 0
+    if rows_tag == "rows2":
+        tu = un.clone()
+    # oracle
+    kvs = bailing_ref.new_kv(ocfg)
+    emb = sd["model.word_embeddings.weight"][ids]
+    bailing_ref.model_forward(emb, sd, ocfg, torch.ones(1, T, dtype=torch.long), None, kvs)
+    start = sd["model.word_embeddings.weight"][torch.tensor([[cfg.image_start_token]])]
+    caches = mingtok_ref.semdec_new_cache(tsd)
+    ref = bailing_ref.generate_image(
+        start, kvs, am, un, tu, sd, ocfg, noises,
+        latent_to_sem=lambda lat: mingtok_ref.mingtok_feature_decoder_step(lat, tsd, caches),
+        linear_proj=lambda s: bailing_ref.linear_proj(s, lsd), sem_to_pix=lambda s: None,
+        steps=int(rf_cfg["num_sampling_steps"]))
+    # HIP path
+    dec.prefill(dec.embed(ids[0].cuda()), seq=0, past=0)
+    out = generate_image(dec, rf, tok, dec.embed(torch.tensor([cfg.image_start_token]).cuda()), T, am, un, tu,
+                         noises.cuda(), decode_pixels=False)
+    rows = ref["last_hidden"].shape[0]
+    assert rows == (2 if rows_tag == "rows2" else 3)
+    assert rel_err(out["latents"], ref["latents"][:, 0]) < TOL
+    assert rel_err(out["sem"], ref["sem"][0]) < TOL
+    assert rel_err(out["last_hidden"], ref["last_hidden"][:, 0]) < TOL
+    # the same image inside a lock-step batch (matrix-core route: K-slice kernel at 24 rows, K-loop form at 36 rows,
+    # grouped experts), other images with their own noise: image 0 must still match the oracle
+    R = rows
+    for i in range(B):
+        dec.prefill(dec.embed(ids[0].cuda()), seq=i * R, past=0)
+    nb = torch.randn(B, cfg.num_image_tokens_for_gen + 1, 32, generator=g)
+    nb[0] = noises
+    outb = generate_images(dec, rf, tok, dec.embed(torch.tensor([cfg.image_start_token]).cuda()), [T] * B, [am] * B, [un] * B,
+                           [tu] * B, nb.cuda(), decode_pixels=False, n_groups=2 if rows_tag == "rows2" else 1)
+    assert rel_err(outb["latents"][0], ref["latents"][:, 0]) < TOL
+    assert rel_err(outb["last_hidden"][:R], ref["last_hidden"][:, 0]) < TOL
