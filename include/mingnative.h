@@ -202,6 +202,11 @@ int mn_gather_rows_bf16(const uint16_t* x, int64_t ldx, const int32_t* perm, uin
 /* h[t] += sum_j w[t, j] * y[slot_of[t, j]]  (fp32) */
 int mn_moe_combine(const float* y, int64_t ldy, const int32_t* slot_of, const float* w, int n_slot, float* h, int64_t ldh,
                    int T, int D, void* stream);
+/* C fp32 [M,N] = (A_hi + A_lo) W^T + bias: activations split into bf16 hi and lo halves (A_lo starts a_lo_off elements
+ * after A_hi, same row stride), both multiplied against the same W tiles in one launch — fp32-class products on the bf16
+ * MFMA (used for the RF head's adaLN projections of all Euler steps, diff_loss_rf_swiglu.py:263-266, 283-286). */
+int mn_gemm_bf16_hilo(const uint16_t* A_hi, int64_t lda, int64_t a_lo_off, const uint16_t* W, int64_t ldw,
+                      const uint16_t* bias, float* C, int64_t ldc, int M, int N, int K, void* stream);
 /* Grouped GEMM over experts: rows [off[g], off[g] + cnt[g]) of A / C use W + g * w_gstride.  off / cnt are device
  * arrays (from mn_moe_sort); m_max >= every cnt[g].  epilogue: MN_GEMM_BF16 or MN_GEMM_F32, no bias. */
 int mn_gemm_bf16_grouped(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int64_t w_gstride,

@@ -94,6 +94,7 @@ SYMBOLS = {
     "mn_num_cus": (_i, []),
     "mn_skinny_gemm": (_i, [C.POINTER(SkinnyArgs), _p]),
     "mn_skinny_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "mn_gemm_bf16_hilo": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _i, _i, _i, _p]),
     "mn_gemm_bf16_splitk": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _i, _i, _p]),
     "mn_stream_mfma": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "mn_rmsnorm_bf16": (_i, [_p, _i64, _p, _f, _p, _i64, _i, _i, _p]),

@@ -36,11 +36,12 @@ struct GemmGroups {
 // and again on the fragment read.  Needs whole k-tiles (K range a multiple of 64); out-of-range rows read a clamped row
 // (their products are never stored).
 template <int EPI, int BM, bool GROUPED = false, bool GLDS = false>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda,
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A_, int64_t lda,
                                                         const bf16_t* __restrict__ W, int64_t ldw,
                                                         const bf16_t* __restrict__ bias, void* __restrict__ Cv0,
                                                         int64_t ldc, int M, int N, int K, int Kc, int64_t c_zstride,
-                                                        GemmGroups grp = GemmGroups{nullptr, nullptr, 0}) {
+                                                        GemmGroups grp = GemmGroups{nullptr, nullptr, 0},
+                                                        int64_t a_lo_off = 0) {
   constexpr int MI = BM / 32;   // 16-row MFMA tiles per wave along M (wave grid is 2 x 2)
   constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
   __shared__ __attribute__((aligned(16))) char lds_raw[2][A_BYTES + W_BYTES];  // [buf][A | W]
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     const int g = blockIdx.y;
     const int row0 = grp.off[g];
     M = grp.cnt[g];
-    A += (int64_t)row0 * lda;
+    A_ += (int64_t)row0 * lda;
     W += (int64_t)g * grp.w_gstride;
     Cv = (EPI == MN_GEMM_F32 || EPI == MN_GEMM_F32_RESID) ? (void*)(reinterpret_cast<float*>(Cv0) + (int64_t)row0 * ldc)
                                                            : (void*)(reinterpret_cast<bf16_t*>(Cv0) + (int64_t)row0 * ldc);
@@ -75,7 +76,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   // thread t: row = t/8 + 32*i, slot = t%8
   const int ld_row = tid >> 3, ld_slot = tid & 7;
   u32x4 ra[4], rw[4];
+  // a_lo_off != 0: A is a bf16 hi/lo pair (lo rows a_lo_off elements after the hi rows); the K loop then runs twice over
+  // the same W tiles, second pass on the lo rows, so that C = (A_hi + A_lo) W^T comes out of one launch
+  const int nk1 = (kend - kbeg + BK - 1) / BK;
   auto gload = [&](int kt) {
+    const bf16_t* A = kt >= nk1 ? A_ + a_lo_off : A_;
+    if (kt >= nk1) kt -= nk1;
     const int k = kbeg + kt * BK + ld_slot * 8;
     const bool kok = k < kend;  // K % 8 == 0 so a slot is all-in or all-out
 #pragma unroll
@@ -101,12 +107,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (kend - kbeg + BK - 1) / BK;
+  const int nk = a_lo_off ? 2 * nk1 : nk1;
   // GLDS staging: wave w copies rows [w * BM/4, +BM/4) of A and [w * 32, +32) of W, 8 rows per instruction
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
   const int g_row = lane >> 3, g_ls = (lane & 7) ^ (g_row & 7);       // rows r0 + g_row with r0 % 8 == 0: swizzle by g_row
   auto gissue = [&](int kt, int buf) {
+    const bf16_t* A = kt >= nk1 ? A_ + a_lo_off : A_;
+    if (kt >= nk1) kt -= nk1;
     const int k = kbeg + kt * BK + g_ls * 8;
 #pragma unroll
     for (int q = 0; q < BM / 32; ++q) {
@@ -232,6 +240,30 @@ extern "C" int mn_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
   const int rc = gemm_launch(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, 1, 0, mn_stream(stream));
   if (rc < 0) return rc;
   MN_CHECK_LAUNCH("mn_gemm_bf16");
+  return MN_OK;
+}
+
+// C fp32 [M,N] = (A_hi + A_lo) W^T + bias for activations split into bf16 hi and lo halves (A_lo = A_hi + a_lo_off
+// elements): fp32-class products on the bf16 MFMA in ONE launch — the K loop runs over the hi rows, then over the lo
+// rows, against the same W tiles; no second output and no combine pass.
+extern "C" int mn_gemm_bf16_hilo(const uint16_t* A_hi, int64_t lda, int64_t a_lo_off, const uint16_t* W, int64_t ldw,
+                                 const uint16_t* bias, float* C, int64_t ldc, int M, int N, int K, void* stream) {
+  MN_CHECK_ARG(A_hi && W && C && a_lo_off > 0, "mn_gemm_bf16_hilo: null pointer");
+  MN_CHECK_ARG(M >= 1 && N >= 1 && K >= 8 && (K % 8) == 0, "mn_gemm_bf16_hilo: bad M=%d N=%d K=%d (K %% 8 == 0)", M, N, K);
+  MN_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0 && (a_lo_off % 8) == 0 && (((uintptr_t)A_hi | (uintptr_t)W) & 15) == 0,
+               "mn_gemm_bf16_hilo: A/W rows must be 16-byte aligned");
+  const int bm = (M <= 32) ? 32 : (M <= 64) ? 64 : 128;
+  dim3 grid((unsigned)(mn_cdiv(M, bm) * mn_cdiv(N, BN)), 1);
+  const bool glds = g_gemm_glds && (K % BK) == 0;
+  hipStream_t st = mn_stream(stream);
+  const GemmGroups ng{nullptr, nullptr, 0};
+#define MN_HL(B_, G_)                                                                                                  \
+  hipLaunchKernelGGL((gemm_bf16_kernel<MN_GEMM_F32, B_, false, G_>), grid, dim3(256), 0, st, A_hi, lda, W, ldw, bias, (void*)C, \
+                     ldc, M, N, K, K, (int64_t)0, ng, a_lo_off)
+  if (glds) { if (bm == 32) MN_HL(32, true); else if (bm == 64) MN_HL(64, true); else MN_HL(128, true); }
+  else { if (bm == 32) MN_HL(32, false); else if (bm == 64) MN_HL(64, false); else MN_HL(128, false); }
+#undef MN_HL
+  MN_CHECK_LAUNCH("mn_gemm_bf16_hilo");
   return MN_OK;
 }
 

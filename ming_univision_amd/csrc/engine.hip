@@ -105,12 +105,6 @@ __global__ void rf_build_y_kernel(const float* __restrict__ temb, const float* _
   y[SR * w + i] = f32_to_bf16(v - bf16_to_f32(hi));
 }
 
-// ada[i, n] = C[i, n] + C[SR + i, n] + bias[n]  (hi + lo halves of the split-bf16 GEMM), in place
-__global__ void rf_ada_combine_kernel(float* __restrict__ C, const bf16_t* __restrict__ bias, int64_t SR, int64_t A) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < SR * A; i += (int64_t)gridDim.x * blockDim.x)
-    C[i] = C[i] + C[SR * A + i] + bf16_to_f32(bias[i % A]);
-}
-
 // ---- glue kernels of the matrix-core RF chain (rows >= 5): they sit between two weight-streaming launches and
 // fuse "reduce the K-slice partials + bias + epilogue of GEMV i" with "prologue + bf16 hi/lo split of GEMV i+1".
 // P: [nz][M][Ntot] fp32 partials (stream_mfma.hip); Y: [2][M][K] bf16 (hi rows, lo rows).
@@ -336,7 +330,7 @@ static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, floa
   const int A = h->depth * 3 * h->w + 2 * h->w;
   *z = cv.take<float>((size_t)rows * h->z_dim);
   *c = cv.take<float>((size_t)rows * h->w);
-  *ada = cv.take<float>((size_t)2 * h->steps * rows * A);   // [hi | lo] GEMM output, combined in place
+  *ada = cv.take<float>((size_t)h->steps * rows * A);       // modulations of every Euler step
   *y = cv.take<bf16_t>((size_t)2 * h->steps * rows * h->w);
   *bar = cv.take<unsigned>(64);
   *hh = cv.take<float>((size_t)rows * h->w);
@@ -403,12 +397,11 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   hipLaunchKernelGGL(rf_init_x_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, noise, temperature, x, rows, T, rpi);
   // The adaLN inputs SiLU(t_emb[s] + c) do not depend on the ODE state, so the modulations of ALL
   // Euler steps are one [2*steps*rows, w] x [w, depth*3w+2w] MFMA GEMM that reads the 0.7 GB of adaLN
-  // weights once per token instead of once per step (activations split into bf16 hi+lo so that the
-  // products stay fp32-accurate).   Linear(SiLU(t_emb[s] + c))  (diff_loss:263-266,283-286,376)
+  // weights once per token instead of once per step (activations split into bf16 hi+lo, both passes of the K loop
+  // accumulate into one output, so that the products stay fp32-accurate).   Linear(SiLU(t_emb[s] + c))  (diff_loss:263-266,283-286,376)
   const int64_t SR = (int64_t)h->steps * rows;
   hipLaunchKernelGGL(rf_build_y_kernel, dim3(mn_cdiv(SR * w, 256)), dim3(256), 0, st, h->temb, c, y, h->steps, rows, w);
-  MN_TRY(mn_gemm_bf16(y, w, h->ada_w, w, nullptr, ada, A, (int)(2 * SR), A, w, MN_GEMM_F32, stream));
-  hipLaunchKernelGGL(rf_ada_combine_kernel, dim3(2048), dim3(256), 0, st, ada, h->ada_b, SR, (int64_t)A);
+  MN_TRY(mn_gemm_bf16_hilo(y, w, SR * w, h->ada_w, w, h->ada_b, ada, A, (int)SR, A, w, stream));
   const float step = 1.0f / (float)h->steps;
   const float* ada_all = ada;
   for (int s = 0; s < h->steps; ++s) {
