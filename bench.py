@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only; INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--kloop-ck128", action="store_true", help=argparse.SUPPRESS)   # A/B hook
     args = ap.parse_args()
     args.groups = max(1, min(args.groups, args.images))
     return args
@@ -233,6 +234,13 @@ def main():
     grp = ReplicaGroup(backend="nccl", device=device)   # "nccl" is RCCL on ROCm
     world, rank = grp.world, grp.rank
 
+    if args.kloop_ck128:
+        import ctypes
+        from ming_univision_amd._lib import lib
+        f = lib().mn_stream_kloop_tune
+        f.argtypes = [ctypes.c_int] * 3
+        f.restype = None
+        f(0, 16, 0)
     cfg, dec, rf, tok = build_models(args, device, seed=0)
     g = torch.Generator(device=device).manual_seed(grp.seed(1000))     # independent prompt / noise per replica
     prompt = torch.randint(0, min(cfg.vocab_size, 100000), (args.images, args.prompt_len), generator=g, device=device)

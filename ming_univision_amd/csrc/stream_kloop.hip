@@ -4,13 +4,13 @@
 //
 // Same contract as stream_mfma.hip (bf16 hi+lo activations, fp32 K-range partials, optional expert groups), different
 // decomposition: a workgroup of 8 waves owns 8 weight tiles (16 rows each) over a LONG K-range and walks it in chunks
-// of 128 k.  The x chunk of all rows is double-buffered in LDS and refilled from a register ring while the previous
+// of 64 k.  The x chunk of all rows is double-buffered in LDS and refilled from a register ring while the previous
 // chunk is multiplied, so
 //   * x never has to fit in LDS as a whole (64 rows x 4 B x K would not): the x image costs 8 KiB x MT per buffer;
 //   * the x fetch is pipelined along K instead of being a start-up bubble in front of the weight stream;
 //   * K-ranges are long, so few (often 1-2) partial slabs are written.
-// Each wave streams its own 16 x 128 weight chunks (4 instructions of 4 rows x 256 B, nontemporal) through a D-deep
-// register ring into a wave-private swizzled 4 KiB LDS tile; one workgroup barrier per chunk orders the x buffers.
+// Each wave streams its own 16 NT x 64 weight chunks (whole-line nontemporal loads) through a D-deep register ring into
+// a wave-private swizzled LDS tile; one workgroup barrier per chunk orders the x buffers.
 //
 // Used for 33..64 rows (stream_mfma.hip forwards): there each wave owns TWO adjacent weight tiles (NT = 2) so that an x
 // fragment read from LDS feeds two MFMAs per half — with one tile per wave every 4 KiB weight chunk costs 32 KiB of x
@@ -24,9 +24,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int CK = 128;              // k per chunk
-constexpr int KW = 8;                // waves (= weight tiles) per workgroup
-constexpr int ROWB = CK * 2;         // bytes per LDS row of a chunk (16 slots of 16 B)
+constexpr int KW = 8;                // waves per workgroup
 
 struct KGroups {
   const int32_t* off;      // [G + 1] offsets into the sorted row list; nullptr = one dense group of M rows
@@ -35,17 +33,21 @@ struct KGroups {
   int row_lo;              // only groups with more than row_lo rows are processed by this launch
 };
 
-// byte offset of 16-byte slot `slot` (0..15) of chunk row `row`: XOR swizzle makes the b128 fragment reads
-// (16 rows x 4 slots per lane group) conflict-free
-__device__ __forceinline__ int cslot(int row, int slot) { return row * ROWB + ((slot ^ (row & 15)) << 4); }
+// byte offset of 16-byte slot `slot` of chunk row `row` (CK k per chunk = CK/8 slots per row): the XOR swizzle makes
+// the b128 fragment reads (16 rows x 4 slots per lane group) conflict-free for 256-byte and 128-byte rows alike
+template <int CK>
+__device__ __forceinline__ int cslot(int row, int slot) { return row * (CK * 2) + ((slot ^ (row & (CK / 8 - 1))) << 4); }
 
-template <int MT, int NT, int D>
+template <int MT, int NT, int D, int CK>
 __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
                                                                const bf16_t* __restrict__ W, float* __restrict__ P,
                                                                int64_t p_slab, int M, int Ntot, int K, int nz, KGroups g) {
   extern __shared__ __attribute__((aligned(16))) char lds[];          // x: [2 bufs][2 x 16MT rows][256 B]; w: [KW][16 NT][256 B]
+  constexpr int ROWB = CK * 2;                                        // bytes per LDS row of a chunk
+  constexpr int SPR = CK / 8;                                         // 16-byte slots per row (16 or 8)
   constexpr int XR = 16 * MT;                                         // x rows per half (hi / lo)
   constexpr int XB = 2 * XR * ROWB;                                   // bytes per x buffer
+  constexpr int XJ = (2 * XR * SPR + KW * 64 - 1) / (KW * 64);        // x pieces per thread and chunk
   int row0 = 0, nrows = M;
   if (g.off) {
     row0 = g.off[blockIdx.z];
@@ -65,40 +67,41 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
   const bool active = t < ntiles;                                     // idle waves still help with x and the barriers
   const int mtn = (nrows + 15) >> 4;                                  // 16-row x tiles actually populated
 
-  // ---- x pieces of this thread: piece p = tid + j * 512 -> row p >> 4 (hi rows, then lo rows), slot p & 15
-  const bf16_t* xp[MT];
-  int xo[MT];                                                         // LDS byte offset inside a buffer, -1 = nothing to write
+  // ---- x pieces of this thread: piece p = tid + j * 512 -> row p / SPR (hi rows, then lo rows), slot p % SPR
+  const bf16_t* xp[XJ];
+  int xo[XJ];                                                         // LDS byte offset inside a buffer, -1 = nothing to write
 #pragma unroll
-  for (int j = 0; j < MT; ++j) {
+  for (int j = 0; j < XJ; ++j) {
     const int p = tid + j * (KW * 64);
-    const int rr = p >> 4, slot = p & 15;
+    const int rr = p / SPR, slot = p % SPR;
     const int h = rr >= XR ? 1 : 0, m = rr - h * XR;
-    xo[j] = m < mtn * 16 ? cslot(h * XR + m, slot) : -1;
+    xo[j] = (rr < 2 * XR && m < mtn * 16) ? cslot<CK>(h * XR + m, slot) : -1;
     xp[j] = nullptr;
-    if (m < nrows) {
+    if (rr < 2 * XR && m < nrows) {
       const int xr = g.xrows ? g.xrows[row0 + m] : row0 + m;
       xp[j] = Y + h * y_lo + (int64_t)xr * K + slot * 8;
     }
   }
-  // ---- weight pieces of this wave: instruction i -> row i * 4 + (lane >> 4) of its 16 NT rows, slot lane & 15 (4 rows x 256 B)
-  constexpr int WI = 4 * NT;
+  // ---- weight pieces of this wave: instruction i -> row i * RPI + lane / SPR of its 16 NT rows, slot lane % SPR
+  constexpr int RPI = 64 / SPR;                                       // rows per instruction (4 x 256 B or 8 x 128 B)
+  constexpr int WI = 16 * NT / RPI;
   const bf16_t* wp[WI];
   int wo[WI];
-  const int wslot_k = (lane & 15) * 8;
+  const int wslot_k = (lane % SPR) * 8;
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
-    const int row = i * 4 + (lane >> 4);
+    const int row = i * RPI + lane / SPR;
     const int n = min(t * 16 + row, Ntot - 1);
     wp[i] = W + (int64_t)n * K;
-    wo[i] = cslot(row, lane & 15);
+    wo[i] = cslot<CK>(row, lane % SPR);
   }
-  u32x4 xr_[D][MT], wr_[D][WI];
-  auto load_x = [&](u32x4 (&dst)[MT], int c) {
+  u32x4 xr_[D][XJ], wr_[D][WI];
+  auto load_x = [&](u32x4 (&dst)[XJ], int c) {
     const int k = (c0 + c) * CK;
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
+    for (int j = 0; j < XJ; ++j) {
       dst[j] = u32x4{0u, 0u, 0u, 0u};                                  // rows >= nrows and k >= K stay zero
-      if (xp[j] && k + ((tid + j * (KW * 64)) & 15) * 8 < K) dst[j] = *reinterpret_cast<const u32x4*>(xp[j] + k);
+      if (xp[j] && k + ((tid + j * (KW * 64)) % SPR) * 8 < K) dst[j] = *reinterpret_cast<const u32x4*>(xp[j] + k);
     }
   };
   auto load_w = [&](u32x4 (&dst)[WI], int c) {
@@ -106,9 +109,9 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
 #pragma unroll
     for (int i = 0; i < WI; ++i) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[i] + k));
   };
-  auto store_x = [&](const u32x4 (&src)[MT], int buf) {
+  auto store_x = [&](const u32x4 (&src)[XJ], int buf) {
 #pragma unroll
-    for (int j = 0; j < MT; ++j)
+    for (int j = 0; j < XJ; ++j)
       if (xo[j] >= 0) *reinterpret_cast<u32x4*>(lds + buf * XB + xo[j]) = src[j];
   };
   // ---- prologue: D chunks of x and of weights in flight; x chunk 0 becomes visible
@@ -140,17 +143,17 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
 #pragma unroll
           for (int i = 0; i < WI; ++i) *reinterpret_cast<u32x4*>(wt + wo[i]) = wr_[d][i];
           if (c + D < nc) load_w(wr_[d], c + D);
-          // 4 MFMA steps of 32 k against every populated x tile (hi and lo)
+          // CK / 32 MFMA steps of 32 k against every populated x tile (hi and lo)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
+          for (int s = 0; s < CK / 32; ++s) {
             bf16x8 w[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const bf16x8*>(wt + cslot(nt * 16 + fr, s * 4 + fq));
+            for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const bf16x8*>(wt + cslot<CK>(nt * 16 + fr, s * 4 + fq));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               if (mt < mtn) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(lds + buf * XB + cslot(mt * 16 + fr, s * 4 + fq));
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(lds + buf * XB + cslot(XR + mt * 16 + fr, s * 4 + fq));
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(lds + buf * XB + cslot<CK>(mt * 16 + fr, s * 4 + fq));
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(lds + buf * XB + cslot<CK>(XR + mt * 16 + fr, s * 4 + fq));
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                   acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w[nt], acc[mt][nt], 0, 0, 0);
@@ -189,7 +192,11 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
   }
 }
 
-int g_kl_nz = 0, g_kl_depth = 0, g_kl_nt = 0;
+int g_kl_nz = 0, g_kl_depth = 0, g_kl_nt = 0, g_kl_ck = 0;
+
+// k per chunk: 64 (x double buffer 32 KiB + weight tiles 32 KiB at 64 rows: two workgroups fit a CU, also one of another
+// stream's kernels) measured 27.0 vs 28.0 us on RF w12 and 17.2 vs 20.2 us on w3 against 128
+int kloop_ck() { return g_kl_ck > 0 ? g_kl_ck : 64; }
 
 // weight tiles per wave: two above 32 rows (halves the x fragment reads per weight byte, which bound the 64-row regime)
 int kloop_nt(int max_rows) { return g_kl_nt > 0 ? g_kl_nt : (max_rows > 32 ? 2 : 1); }
@@ -198,25 +205,26 @@ int kloop_nt(int max_rows) { return g_kl_nt > 0 ? g_kl_nt : (max_rows > 32 ? 2 :
 int kloop_nz(int Ntot, int K, int slots, int nt) {
   if (g_kl_nz > 0) return g_kl_nz;
   const int tb = (int)mn_cdiv(mn_cdiv(Ntot, 16), KW * nt);
-  const int nch = (int)mn_cdiv(K, CK);
+  const int nch = (int)mn_cdiv(K, kloop_ck());
   int nz = slots / tb;
   if (nz < 1) nz = 1;
   if (nz > nch) nz = nch;
   return nz;
 }
 
-template <int MT, int NT, int D>
+template <int MT, int NT, int D, int CK>
 void kloop_launch(int G, int nz, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab, int M, int Ntot,
                   int K, const KGroups& g, hipStream_t st) {
+  constexpr int ROWB = CK * 2;
   const size_t lds = (size_t)2 * 2 * 16 * MT * ROWB + (size_t)KW * 16 * NT * ROWB;
   static bool opted = false;
   if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_kloop_kernel<MT, NT, D>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_kloop_kernel<MT, NT, D, CK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     opted = true;
   }
   const int tb = (int)mn_cdiv(mn_cdiv(Ntot, 16), KW * NT);
-  hipLaunchKernelGGL((stream_kloop_kernel<MT, NT, D>), dim3(tb, nz, G), dim3(KW * 64), lds, st, Y, y_lo, W, P, p_slab, M, Ntot,
+  hipLaunchKernelGGL((stream_kloop_kernel<MT, NT, D, CK>), dim3(tb, nz, G), dim3(KW * 64), lds, st, Y, y_lo, W, P, p_slab, M, Ntot,
                      K, nz, g);
 }
 
@@ -224,13 +232,15 @@ template <int MT>
 void kloop_launch_d(int nt, int G, int nz, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab, int M,
                     int Ntot, int K, const KGroups& g, hipStream_t st) {
   const int depth = g_kl_depth > 0 ? g_kl_depth : (nt == 2 ? 2 : 4);
-  if (nt == 2) {
-    if (depth == 2) kloop_launch<MT, 2, 2>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
-    else kloop_launch<MT, 2, 4>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
-  } else {
-    if (depth == 2) kloop_launch<MT, 1, 2>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
-    else kloop_launch<MT, 1, 4>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
-  }
+  const int ck = kloop_ck();
+#define MN_KL(NT_, D_)                                                                                      \
+  do {                                                                                                      \
+    if (ck == 64) kloop_launch<MT, NT_, D_, 64>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);           \
+    else kloop_launch<MT, NT_, D_, 128>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);                   \
+  } while (0)
+  if (nt == 2) { if (depth == 2) MN_KL(2, 2); else MN_KL(2, 4); }
+  else { if (depth == 2) MN_KL(1, 2); else MN_KL(1, 4); }
+#undef MN_KL
 }
 
 int kloop_dispatch(int G, int max_rows, int nz, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab,
@@ -244,7 +254,7 @@ int kloop_dispatch(int G, int max_rows, int nz, const bf16_t* Y, int64_t y_lo, c
 
 }  // namespace
 
-extern "C" void mn_stream_kloop_tune(int nz, int depth, int nt) { g_kl_nz = nz; g_kl_depth = depth; g_kl_nt = nt; }
+extern "C" void mn_stream_kloop_tune(int nz, int depth, int nt) { g_kl_nz = nz; g_kl_depth = depth & 15; g_kl_nt = nt; g_kl_ck = (depth >> 4) ? 128 : 0; }
 
 extern "C" int mn_stream_kloop_slices(int M, int Ntot, int K) { return kloop_nz(Ntot, K, mn_num_cus(), kloop_nt(M)); }
 
@@ -264,7 +274,7 @@ extern "C" int mn_stream_kloop_grouped(const uint16_t* Y, int y_rows, const uint
                                        int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows, int row_lo,
                                        int nz, int Ntot, int K, void* stream) {
   MN_CHECK_ARG(Y && W && P && off && G >= 1 && max_rows >= 1 && max_rows <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0 &&
-                   nz >= 1 && nz <= (K + CK - 1) / CK,
+                   nz >= 1 && nz <= (K + kloop_ck() - 1) / kloop_ck(),
                "mn_stream_kloop_grouped: bad args");
   const KGroups g{off, xrows, w_stride, row_lo};
   kloop_dispatch(G, max_rows, nz, Y, (int64_t)y_rows * K, W, P, (int64_t)p_rows * Ntot, 0, Ntot, K, g, mn_stream(stream));

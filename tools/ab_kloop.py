@@ -48,15 +48,13 @@ def bench(M, N2, K, variants, rounds=5, iters=24):
     for v in variants:
         t = sorted(res[v]); print(f"M={M} N={N2} K={K} {v}: median {t[len(t)//2]:.1f} us ({N2*K*2/t[len(t)//2]/1e3:.0f} GB/s)", flush=True)
 
-for nt in (1, 2):
-    L.mn_stream_kloop_tune(0, 0, nt)
+for dck in (2, 18):     # depth | ck64 << 4
+    L.mn_stream_kloop_tune(0, dck, 2)
     for shp in [(16, 512, 1408), (32, 16384, 3072), (64, 3072, 8192), (50, 100, 264), (5, 2816, 2048), (64, 16384, 3072)]:
         check(*shp)
 L.mn_stream_kloop_tune(0, 0, 0)
-for M in (32, 64):
-    V = [("kloop", nz, d, nt) for nt in (1, 2) for nz in (0, 2, 4) for d in (4, 2)]
-    if M <= 32: V = [("slice", 0, 0, 0)] + V
+for M in (64,):
+    V = [("kloop", nz, d, 2) for d in (2, 18) for nz in (0, 4, 6, 8)]
     bench(M, 16384, 3072, V)
-    V = [("kloop", nz, d, nt) for nt in (1, 2) for nz in (0, 8, 16) for d in (4, 2)]
-    if M <= 32: V = [("slice", 0, 0, 0)] + V
+    V = [("kloop", nz, d, 2) for d in (2, 18) for nz in (0, 21, 32, 42)]
     bench(M, 3072, 8192, V)
