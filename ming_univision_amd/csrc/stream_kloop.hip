@@ -30,7 +30,7 @@ struct KGroups {
   const int32_t* off;      // [G + 1] offsets into the sorted row list; nullptr = one dense group of M rows
   const int32_t* xrows;    // [total] x row of each sorted row; nullptr = identity (off[g] + r)
   int64_t w_stride;        // elements between consecutive groups' weight matrices
-  int row_lo;              // only groups with more than row_lo rows are processed by this launch
+  int row_lo, row_hi;      // only groups with row_lo < rows <= row_hi are processed by this launch
 };
 
 // byte offset of 16-byte slot `slot` of chunk row `row` (CK k per chunk = CK/8 slots per row): the XOR swizzle makes
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
   if (g.off) {
     row0 = g.off[blockIdx.z];
     nrows = g.off[blockIdx.z + 1] - row0;
-    if (nrows <= g.row_lo) return;
+    if (nrows <= g.row_lo || nrows > g.row_hi) return;
     W += (int64_t)blockIdx.z * g.w_stride;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -262,7 +262,7 @@ extern "C" int mn_stream_kloop_slices(int M, int Ntot, int K) { return kloop_nz(
 extern "C" int mn_stream_kloop(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream) {
   MN_CHECK_ARG(Y && W && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0, "mn_stream_kloop: bad args");
   const int nz = kloop_nz(Ntot, K, mn_num_cus(), kloop_nt(M));
-  const KGroups g{nullptr, nullptr, 0, 0};
+  const KGroups g{nullptr, nullptr, 0, 0, 1 << 30};
   kloop_dispatch(1, M, nz, Y, (int64_t)M * K, W, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
   MN_CHECK_LAUNCH("mn_stream_kloop");
   return nz;
@@ -276,7 +276,7 @@ extern "C" int mn_stream_kloop_grouped(const uint16_t* Y, int y_rows, const uint
   MN_CHECK_ARG(Y && W && P && off && G >= 1 && max_rows >= 1 && max_rows <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0 &&
                    nz >= 1 && nz <= (K + kloop_ck() - 1) / kloop_ck(),
                "mn_stream_kloop_grouped: bad args");
-  const KGroups g{off, xrows, w_stride, row_lo};
+  const KGroups g{off, xrows, w_stride, row_lo, max_rows};
   kloop_dispatch(G, max_rows, nz, Y, (int64_t)y_rows * K, W, P, (int64_t)p_rows * Ntot, 0, Ntot, K, g, mn_stream(stream));
   MN_CHECK_LAUNCH("mn_stream_kloop_grouped");
   return nz;

@@ -19,8 +19,7 @@
 //   * D: lane l, reg r holds out[m = (l >> 4) * 4 + r][n0 + (l & 15)].
 // K-slice partials are reduced (with bias / activation / residual epilogues) by the caller's next kernel.
 //
-// Grouped form (MoE experts): blockIdx.z selects a weight matrix and a list of x rows (off[g]..off[g+1]),
-// so every distinct expert is streamed once for all the rows routed to it; empty groups exit at once.
+// The grouped form (MoE experts) runs on the K-loop kernel (stream_kloop.hip) at every row count.
 #include <stdlib.h>
 
 #include "common.h"
@@ -46,27 +45,13 @@ __device__ __forceinline__ int wslot(int row, int slot) { return row * (WCH * 2)
 // x image: element offset of 16-byte slot `slot` of row `row` (row stride = ks elements, a multiple of 256)
 __device__ __forceinline__ int xslot(int row, int srow, int slot) { return row * srow + ((slot ^ (row & 15)) << 3); }
 
-struct StreamGroups {
-  const int32_t* off;      // [G + 1] offsets into the sorted row list; nullptr = one dense group of M rows
-  const int32_t* xrows;    // [total] x row of each sorted row; nullptr = identity (off[g] + r)
-  int64_t w_stride;        // elements between consecutive groups' weight matrices
-  int row_lo, row_hi;      // only groups with row_lo < rows <= row_hi are processed by this launch
-};
-
 // Y: bf16, hi rows at Y, lo rows at Y + y_lo (row stride K).  P: [nz][p_rows][Ntot] fp32, p_slab = p_rows * Ntot.
 template <int MT, int DEPTH, int MAXT>
 __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
                                                                const bf16_t* __restrict__ W, float* __restrict__ P,
-                                                               int64_t p_slab, int M, int Ntot, int K, int ks,
-                                                               StreamGroups g) {
+                                                               int64_t p_slab, int M, int Ntot, int K, int ks) {
   extern __shared__ __attribute__((aligned(16))) bf16_t xs_raw[];      // [2][16*MT][ks] x image, then nw x 8 KiB weight tiles
-  int row0 = 0, nrows = M;
-  if (g.off) {
-    row0 = g.off[blockIdx.z];
-    nrows = g.off[blockIdx.z + 1] - row0;
-    if (nrows <= g.row_lo || nrows > g.row_hi) return;
-    W += (int64_t)blockIdx.z * g.w_stride;
-  }
+  const int row0 = 0, nrows = M;
   constexpr int XR = 16 * MT;
   constexpr int RPW = (2 * XR + 7) / 8;                                  // x rows (hi and lo) per wave at >= 8 waves
   const int srow = ks;                                                  // 16-byte slots XOR-swizzled by row (xslot)
@@ -101,7 +86,7 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
         const int slot = lane + u * 64;
         xv[j][u] = u32x4{0u, 0u, 0u, 0u};
         if (rr < 2 * xr_used && m < nrows && slot * 8 < klen) {   // rows >= nrows stay zero: unused MFMA rows contribute nothing
-          const int xr = g.xrows ? g.xrows[row0 + m] : row0 + m;
+          const int xr = row0 + m;
           xv[j][u] = *reinterpret_cast<const u32x4*>(Y + h * y_lo + (int64_t)xr * K + k0 + slot * 8);
         }
       }
@@ -224,7 +209,7 @@ StreamPlan stream_plan(int mt, int Ntot, int K, int slots) {
 
 template <int MT, int DEPTH, int MAXT>
 void stream_launch_d(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab,
-                     int M, int Ntot, int K, const StreamGroups& g, hipStream_t st) {
+                     int M, int Ntot, int K, hipStream_t st) {
   static bool opted = false;
   if (!opted) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_lds_kernel<MT, DEPTH, MAXT>),
@@ -232,22 +217,16 @@ void stream_launch_d(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo,
     opted = true;
   }
   hipLaunchKernelGGL((stream_mfma_lds_kernel<MT, DEPTH, MAXT>), dim3(pl.gx, pl.nz, G), dim3(pl.nw * 64), pl.lds, st, Y, y_lo, W, P,
-                     p_slab, M, Ntot, K, pl.ks, g);
+                     p_slab, M, Ntot, K, pl.ks);
 }
 
 template <int MT>
 void stream_launch(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab,
-                   int M, int Ntot, int K, const StreamGroups& g, hipStream_t st) {
+                   int M, int Ntot, int K, hipStream_t st) {
   // 8-wave workgroups compile for 512 threads, larger ones for 1024
   // (a 2-deep ring measured 2-4 % slower at every shape: 20.4 vs 20.0 us on RF w12 at 16 rows, 24.6 vs 23.8 at 32)
-  if (pl.nw <= 8) stream_launch_d<MT, 1, 512>(pl, G, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
-  else stream_launch_d<MT, 1, 1024>(pl, G, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
-}
-
-// CUs one group of a grouped launch can count on: ~4 workgroups per CU over the groups expected to be active
-int group_slots(int G) {
-  const int s = (int)mn_cdiv((int64_t)4 * mn_num_cus(), G);
-  return s < 1 ? 1 : s;
+  if (pl.nw <= 8) stream_launch_d<MT, 1, 512>(pl, G, Y, y_lo, W, P, p_slab, M, Ntot, K, st);
+  else stream_launch_d<MT, 1, 1024>(pl, G, Y, y_lo, W, P, p_slab, M, Ntot, K, st);
 }
 
 }  // namespace
@@ -265,36 +244,26 @@ extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, in
   if (M > 32) return mn_stream_kloop(Y, W, P, M, Ntot, K, stream);      // 33..64 rows: K-loop form, two tiles per wave
   const int mt = M > 16 ? 2 : 1;
   const StreamPlan pl = stream_plan(mt, Ntot, K, mn_num_cus());
-  const StreamGroups g{nullptr, nullptr, 0, 0, 1 << 30};
-  if (mt == 1) stream_launch<1>(pl, 1, Y, (int64_t)M * K, W, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
-  else stream_launch<2>(pl, 1, Y, (int64_t)M * K, W, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
+  if (mt == 1) stream_launch<1>(pl, 1, Y, (int64_t)M * K, W, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream));
+  else stream_launch<2>(pl, 1, Y, (int64_t)M * K, W, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream));
   MN_CHECK_LAUNCH("mn_stream_mfma");
   return pl.nz;
 }
 
+// ---- grouped form (MoE experts): every row count runs the K-loop kernel with 2 K-ranges — measured against this file's
+// K-slice kernel with a blockIdx.z = group dimension (tools/ab_moe_grouped.py, all 66 experts of a 16B-A3B layer):
+// 64 rows 207 vs 236 us per layer, 32 rows 201 vs 227, 16 rows 158 vs 162.
 extern "C" int mn_stream_mfma_grouped_slices(int G, int max_rows, int Ntot, int K) {
-  return stream_plan(max_rows > 16 ? 2 : 1, Ntot, K, group_slots(G)).nz;
+  (void)G; (void)max_rows; (void)Ntot;
+  return K > 64 ? 2 : 1;
 }
 
-// Grouped: group g (of G) multiplies the x rows xrows[off[g] .. off[g+1]) (identity when xrows == NULL) by
-// W + g * w_stride and writes partial rows off[g].. of P [nz][p_rows][Ntot].  Y holds y_rows hi rows then y_rows lo
-// rows.  No group may have more than max_rows (<= 64) rows.  off / xrows live in device memory.
+// Group g (of G) multiplies the x rows xrows[off[g] .. off[g+1]) (identity when xrows == NULL) by W + g * w_stride and
+// writes partial rows off[g].. of P [nz][p_rows][Ntot].  Y holds y_rows hi rows then y_rows lo rows.  No group may have
+// more than max_rows (<= 64) rows.  off / xrows live in device memory.
 extern "C" int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P,
                                       int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows,
                                       int Ntot, int K, void* stream) {
-  MN_CHECK_ARG(Y && W && P && off && G >= 1 && max_rows >= 1 && max_rows <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0,
-               "mn_stream_mfma_grouped: bad args");
-  // groups of <= 32 rows (the routed experts, a handful of rows each) run the K-slice kernel; larger ones (the shared
-  // experts at > 32 rows) the K-loop form with the same number of partial slabs — two launches, each skipping the other's groups
-  const int mt = max_rows > 16 ? 2 : 1;
-  const StreamPlan pl = stream_plan(mt, Ntot, K, group_slots(G));
-  const StreamGroups g{off, xrows, w_stride, 0, 32};
-  if (mt == 1) stream_launch<1>(pl, G, Y, (int64_t)y_rows * K, W, P, (int64_t)p_rows * Ntot, 0, Ntot, K, g, mn_stream(stream));
-  else stream_launch<2>(pl, G, Y, (int64_t)y_rows * K, W, P, (int64_t)p_rows * Ntot, 0, Ntot, K, g, mn_stream(stream));
-  if (max_rows > 32) {
-    const int rc = mn_stream_kloop_grouped(Y, y_rows, W, w_stride, P, p_rows, off, xrows, G, max_rows, 32, pl.nz, Ntot, K, stream);
-    if (rc < 0) return rc;
-  }
-  MN_CHECK_LAUNCH("mn_stream_mfma_grouped");
-  return pl.nz;
+  const int nz = mn_stream_mfma_grouped_slices(G, max_rows, Ntot, K);
+  return mn_stream_kloop_grouped(Y, y_rows, W, w_stride, P, p_rows, off, xrows, G, max_rows, 0, nz, Ntot, K, stream);
 }
