@@ -161,7 +161,7 @@ def dominant_kernel_roofline_stream(rf, rows, iters=48):
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_stream_rows%d.json" % rows)   # PMC passes of this kernel at this row count
     if os.path.exists(pmc) and hid == 8192 and w == 3072:
         traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-    name = "stream_kloop_kernel<4,2,2>" if rows > 32 else "stream_mfma_lds_kernel<%d,1,512>" % (2 if rows > 16 else 1)
+    name = "stream_kloop_kernel<4,2,2,64>" if rows > 32 else "stream_mfma_lds_kernel<%d,1,512>" % (2 if rows > 16 else 1)
     return dict(traffic=traffic, kernel="%s (RF w12: Ntot=2x%d, K=%d, rows=%d)" % (name, hid, w, rows), us=us,
                 bytes=nbytes, gbs=nbytes / us * 1e-3)
 

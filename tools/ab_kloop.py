@@ -48,13 +48,10 @@ def bench(M, N2, K, variants, rounds=5, iters=24):
     for v in variants:
         t = sorted(res[v]); print(f"M={M} N={N2} K={K} {v}: median {t[len(t)//2]:.1f} us ({N2*K*2/t[len(t)//2]/1e3:.0f} GB/s)", flush=True)
 
-for dck in (2, 18):     # depth | ck64 << 4
-    L.mn_stream_kloop_tune(0, dck, 2)
-    for shp in [(16, 512, 1408), (32, 16384, 3072), (64, 3072, 8192), (50, 100, 264), (5, 2816, 2048), (64, 16384, 3072)]:
-        check(*shp)
 L.mn_stream_kloop_tune(0, 0, 0)
-for M in (64,):
-    V = [("kloop", nz, d, 2) for d in (2, 18) for nz in (0, 4, 6, 8)]
-    bench(M, 16384, 3072, V)
-    V = [("kloop", nz, d, 2) for d in (2, 18) for nz in (0, 21, 32, 42)]
-    bench(M, 3072, 8192, V)
+M = 64
+bench(M, 16384, 3072, [("kloop", nz, 2, 2) for nz in (0, 2, 3, 4, 5)])
+bench(M, 3072, 8192, [("kloop", nz, 2, 2) for nz in (0, 8, 10, 12, 16, 21, 26)])
+bench(M, 3072, 2048, [("kloop", nz, 2, 2) for nz in (0, 2, 4, 8, 16)])
+bench(M, 2048, 2048, [("kloop", nz, 2, 2) for nz in (0, 2, 4, 8, 16)])
+bench(M, 64, 2048, [("kloop", nz, 2, 2) for nz in (0, 2, 4, 8, 16, 32)])
