@@ -430,6 +430,10 @@ def generate_images(dec: BailingMoeDecoder, rf, tok, start_embed, past_lens, att
                 run.token(ti)
     for s in streams:
         main.wait_stream(s)
+    if n_groups > 1:      # side-stream allocations are consumed on the caller's stream below
+        for r in runs:
+            for t in (r.latents, r.sems, r.hidden):
+                t.record_stream(main)
     latents = torch.cat([r.latents for r in runs], dim=1)
     sem_b = torch.cat([r.sems for r in runs], dim=1).transpose(0, 1).contiguous()
     hidden = torch.cat([r.hidden for r in runs], dim=0)
