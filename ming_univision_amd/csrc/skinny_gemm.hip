@@ -202,10 +202,10 @@ int launch_m(const KArgs& ka, int R, int sw, int nt, dim3 grid, size_t lds, hipS
 }  // namespace
 
 // ===========================================================================================
-// 5 <= M <= 16 rows (batched generation): weights are still read once, but the fp32 FMA path would be
+// 5 <= M <= 64 rows (batched generation): weights are still read once, but the fp32 FMA path would be
 // VALU-bound, so the product runs on the matrix cores:
 //   prologue kernel : x' = prologue(x) in fp32, split into bf16 hi + lo rows  -> Y[2M, K]
-//   stream_mfma_kernel : partials[z][M][Ntot] = (Y_hi + Y_lo)[:, kz] W[:, kz]^T   (stream_mfma.hip)
+//   streaming kernel : partials[z][M][Ntot] = (Y_hi + Y_lo)[:, kz] W[:, kz]^T   (stream_mfma.hip <= 32 rows, stream_kloop.hip above)
 //   epilogue kernel : out = epilogue( sum_z partials + bias )
 // hi + lo keeps the products fp32-accurate (x' = hi + lo to 2^-17 relative).
 // ===========================================================================================
@@ -288,7 +288,7 @@ int medium_ksplit(int Ntot, int K) {
 }  // namespace
 
 // Rows at or above this count take the MFMA route (measured on MI355X: the fp32-FMA kernel wins up to 4 rows,
-// RF w12 37.6 us at M = 4 vs ~36 us for the MFMA route at any M <= 16).
+// RF w12 37.6 us at M = 4 against 20 us + the two small launches of the MFMA route at 16 rows).
 constexpr int MEDIUM_MIN_M = 5;
 
 extern "C" size_t mn_skinny_workspace_bytes(int M, int N, int K, int epilogue) {
