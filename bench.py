@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--kloop-ck128", action="store_true", help=argparse.SUPPRESS)   # A/B hook
+    ap.add_argument("--cfg-rows", type=int, default=2, help=argparse.SUPPRESS)       # 3 = editing-style CFG (experiments)
     args = ap.parse_args()
     args.groups = max(1, min(args.groups, args.images))
     return args
@@ -70,7 +71,7 @@ def build_models(args, device, seed):
         rf_cfg = dict(C.DEFAULT_VISHEAD_DIFFLOSS)
         tcfg = C.MingTokConfig()
     t_max = args.prompt_len + args.tokens + 8
-    dec = BailingMoeDecoder.synthetic(cfg, device, seed=seed, t_max=t_max, n_seq=2 * args.images)
+    dec = BailingMoeDecoder.synthetic(cfg, device, seed=seed, t_max=t_max, n_seq=3 * args.images)
     full = C.llm_param_shapes(cfg, rf_cfg, 32)
     rf_sd = {k: synth_tensor(k, s, seed, device, torch.bfloat16) for k, s in full.items()
              if k.startswith("vis_head") or k.startswith("diffloss")}
@@ -84,18 +85,22 @@ def build_models(args, device, seed):
     return cfg, dec, rf, tok
 
 
-def one_image(cfg, dec, rf, tok, prompts, noises, groups=1):
+def one_image(cfg, dec, rf, tok, prompts, noises, groups=1, cfg_rows=2):
     """prefill -> forced <image> -> generate_images (2 CFG rows per image) -> pixel decode.
     prompts [B, T] ids, noises [B, n+1, 32]; B images advance in lock-step (B = 1: the reference's call)."""
     from ming_univision_amd.bailing_moe import generate_images
     B, T = prompts.shape
     for i in range(B):
-        dec.prefill(dec.embed(prompts[i]), seq=2 * i, past=0)
+        dec.prefill(dec.embed(prompts[i]), seq=cfg_rows * i, past=0)
     start = dec.embed(torch.tensor([cfg.image_start_token], device=prompts.device))
     am = torch.ones(1, T + 1, dtype=torch.long)
     unc = torch.ones(1, T + 1, dtype=torch.long)
     unc[0, 2:T - 2] = 0                     # uncond row: the user's text span is masked out
-    return generate_images(dec, rf, tok, start, [T] * B, [am] * B, [unc] * B, [unc.clone()] * B, noises, n_groups=groups)
+    tunc = unc.clone()
+    if cfg_rows == 3:
+        tunc = am.clone()
+        tunc[0, 2:6] = 0                    # text-uncond row of the editing path: a different hole
+    return generate_images(dec, rf, tok, start, [T] * B, [am] * B, [unc] * B, [tunc] * B, noises, n_groups=groups)
 
 
 def dominant_kernel_roofline(rf, rows, iters=48):
@@ -248,8 +253,8 @@ def main():
     rows = 2
 
     for _ in range(args.warmup):
-        one_image(cfg, dec, rf, tok, prompt, noises, args.groups)
-    dt, out = grp.timed(lambda: one_image(cfg, dec, rf, tok, prompt, noises, args.groups), args.steps)
+        one_image(cfg, dec, rf, tok, prompt, noises, args.groups, args.cfg_rows)
+    dt, out = grp.timed(lambda: one_image(cfg, dec, rf, tok, prompt, noises, args.groups, args.cfg_rows), args.steps)
     finite = bool(torch.isfinite(out["image"]).all()) and bool(torch.isfinite(out["latents"]).all())
 
     batch1 = None
@@ -261,7 +266,7 @@ def main():
                   "ms_per_image": dt1 * 1e3}
 
     if rank == 0:
-        if rows * ((args.images + args.groups - 1) // args.groups) >= 5:
+        if rows * ((args.images + args.groups - 1) // args.groups) >= 2:   # the matrix-core route (MEDIUM_MIN_M)
             dom = dominant_kernel_roofline_stream(rf, rows * ((args.images + args.groups - 1) // args.groups))
         else:
             dom = dominant_kernel_roofline(rf, rows)

@@ -287,9 +287,10 @@ int medium_ksplit(int Ntot, int K) {
 
 }  // namespace
 
-// Rows at or above this count take the MFMA route (measured on MI355X: the fp32-FMA kernel wins up to 4 rows,
-// RF w12 37.6 us at M = 4 against 20 us + the two small launches of the MFMA route at 16 rows).
-constexpr int MEDIUM_MIN_M = 5;
+// Rows at or above this count take the MFMA route when the caller provides scratch.  Measured end to end on the 16B-A3B
+// 512^2 workload (same box, tokens/s): 2 rows 76.8 vs 70.6 with the fp32-FMA kernels, 3 rows 74.2 vs 56.1, 4 rows 136 vs 97;
+// one row (text decode) stays on the fp32-FMA kernel.
+constexpr int MEDIUM_MIN_M = 2;
 
 extern "C" size_t mn_skinny_workspace_bytes(int M, int N, int K, int epilogue) {
   if (M < MEDIUM_MIN_M) return 0;
