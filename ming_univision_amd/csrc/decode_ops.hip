@@ -97,7 +97,9 @@ extern "C" int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w
 // -------------------------------------------------------------------------------------------
 // RoPE + KV append. grid (M, n_q + 2*n_kv), block hd/2 threads.
 // -------------------------------------------------------------------------------------------
-__global__ void rope_kv_append_kernel(const float* __restrict__ qkv, int64_t ldqkv, int n_q, int n_kv, int hd,
+// nz > 1: qkv is a stack of nz K-slice partial slabs (slab elements apart) of the QKV projection, summed here — the
+// reduction of the streaming GEMM folded into the consumer (no bias: use_qkv_bias is false on this path).
+__global__ void rope_kv_append_kernel(const float* __restrict__ qkv, int64_t ldqkv, int nz, int64_t slab, int n_q, int n_kv, int hd,
                                       int rope, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
                                       const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_slot,
                                       const int32_t* __restrict__ row_pos, int M, int sec_t, int sec_h, float q_scale,
@@ -105,6 +107,7 @@ __global__ void rope_kv_append_kernel(const float* __restrict__ qkv, int64_t ldq
   const int m = blockIdx.x, h = blockIdx.y, i = threadIdx.x, half = hd >> 1;
   const float* src = qkv + (int64_t)m * ldqkv + (int64_t)h * hd;
   float x1 = src[i], x2 = src[i + half];
+  for (int z = 1; z < nz; ++z) { x1 += src[z * slab + i]; x2 += src[z * slab + i + half]; }
   const bool is_q = h < n_q, is_k = !is_q && h < n_q + n_kv;
   if (rope && (is_q || is_k)) {
     // 3D rotary (sec_t > 0): row_pos is [3][M] = t, h, w positions; frequency i of each half follows the t stream for
@@ -128,19 +131,28 @@ __global__ void rope_kv_append_kernel(const float* __restrict__ qkv, int64_t ldq
   }
 }
 
-extern "C" int mn_rope_kv_append_3d(const float* qkv, int64_t ldqkv, int M, int n_q, int n_kv, int hd, int rope,
-                                    const float* cos_tab, const float* sin_tab, const int32_t* row_seq,
-                                    const int32_t* row_slot, const int32_t* row_pos, int sec_t, int sec_h, float q_scale,
-                                    float* q_out, float* kv_cache, int64_t t_max, void* stream) {
-  MN_CHECK_ARG(M >= 1 && n_q >= 1 && n_kv >= 1 && (hd == 64 || hd == 128), "mn_rope_kv_append: bad shape");
+// Internal (engine.hip): as mn_rope_kv_append_3d, reading the QKV projection as nz partial slabs.
+extern "C" int mn_rope_kv_from_partials(const float* qkv, int64_t ldqkv, int nz, int64_t slab, int M, int n_q, int n_kv, int hd,
+                                        int rope, const float* cos_tab, const float* sin_tab, const int32_t* row_seq,
+                                        const int32_t* row_slot, const int32_t* row_pos, int sec_t, int sec_h, float q_scale,
+                                        float* q_out, float* kv_cache, int64_t t_max, void* stream) {
+  MN_CHECK_ARG(M >= 1 && n_q >= 1 && n_kv >= 1 && (hd == 64 || hd == 128) && nz >= 1, "mn_rope_kv_append: bad shape");
   MN_CHECK_ARG(qkv && row_seq && row_slot && q_out && kv_cache, "mn_rope_kv_append: null pointer");
   MN_CHECK_ARG(!rope || (cos_tab && sin_tab && row_pos), "mn_rope_kv_append: rope needs tables and positions");
   MN_CHECK_ARG(sec_t >= 0 && sec_h >= 0 && sec_t + sec_h <= hd / 2, "mn_rope_kv_append: bad rotary sections %d/%d", sec_t, sec_h);
-  hipLaunchKernelGGL(rope_kv_append_kernel, dim3(M, n_q + 2 * n_kv), dim3(hd / 2), 0, mn_stream(stream), qkv, ldqkv,
+  hipLaunchKernelGGL(rope_kv_append_kernel, dim3(M, n_q + 2 * n_kv), dim3(hd / 2), 0, mn_stream(stream), qkv, ldqkv, nz, slab,
                      n_q, n_kv, hd, rope, cos_tab, sin_tab, row_seq, row_slot, row_pos, M, sec_t, sec_h, q_scale, q_out,
                      kv_cache, t_max);
   MN_CHECK_LAUNCH("mn_rope_kv_append");
   return MN_OK;
+}
+
+extern "C" int mn_rope_kv_append_3d(const float* qkv, int64_t ldqkv, int M, int n_q, int n_kv, int hd, int rope,
+                                    const float* cos_tab, const float* sin_tab, const int32_t* row_seq,
+                                    const int32_t* row_slot, const int32_t* row_pos, int sec_t, int sec_h, float q_scale,
+                                    float* q_out, float* kv_cache, int64_t t_max, void* stream) {
+  return mn_rope_kv_from_partials(qkv, ldqkv, 1, 0, M, n_q, n_kv, hd, rope, cos_tab, sin_tab, row_seq, row_slot, row_pos, sec_t,
+                                  sec_h, q_scale, q_out, kv_cache, t_max, stream);
 }
 
 extern "C" int mn_rope_kv_append(const float* qkv, int64_t ldqkv, int M, int n_q, int n_kv, int hd, int rope,
@@ -248,8 +260,10 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(
   }
 }
 
+// out (fp32 [M, n_q*HD]) and / or split (bf16 [2][M][n_q*HD]: hi rows then lo rows, the next GEMV's MFMA operand)
 template <int HD>
-__global__ void attn_decode_combine_kernel(const float* __restrict__ partial, int n_q, int S, float* __restrict__ out) {
+__global__ void attn_decode_combine_kernel(const float* __restrict__ partial, int n_q, int S, float* __restrict__ out,
+                                           bf16_t* __restrict__ split, int M) {
   const int m = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
   const float* p = partial + (((int64_t)m * n_q + h) * S) * (HD + 2);
   float mx = -INFINITY;
@@ -261,7 +275,14 @@ __global__ void attn_decode_combine_kernel(const float* __restrict__ partial, in
     l = fmaf(f, p[s * (HD + 2) + HD + 1], l);
     acc = fmaf(f, p[s * (HD + 2) + d], acc);
   }
-  out[((int64_t)m * n_q + h) * HD + d] = acc / l;
+  const float v = acc / l;
+  const int64_t o = ((int64_t)m * n_q + h) * HD + d;
+  if (out) out[o] = v;
+  if (split) {
+    const bf16_t hi = f32_to_bf16(v);
+    split[o] = hi;
+    split[(int64_t)M * n_q * HD + o] = f32_to_bf16(v - bf16_to_f32(hi));
+  }
 }
 
 extern "C" size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t t_max) {
@@ -271,12 +292,13 @@ extern "C" size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t
   return (size_t)M * n_q * S * (hd + 2) * sizeof(float);
 }
 
-extern "C" int mn_attn_decode(const float* q, int M, int n_q, int n_kv, int hd, const float* kv_cache,
-                                 int64_t t_max, const int32_t* row_seq, const int32_t* row_len,
-                                 const uint8_t* key_mask, int64_t ld_mask, float* out, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
+// Internal (engine.hip): mn_attn_decode whose output can also (or only) be written as bf16 hi/lo rows.
+extern "C" int mn_attn_decode_split(const float* q, int M, int n_q, int n_kv, int hd, const float* kv_cache,
+                                    int64_t t_max, const int32_t* row_seq, const int32_t* row_len,
+                                    const uint8_t* key_mask, int64_t ld_mask, float* out, uint16_t* split, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
   MN_CHECK_ARG(M >= 1 && n_q >= 1 && n_kv >= 1 && n_q % n_kv == 0 && (hd == 64 || hd == 128), "mn_attn_decode: bad shape");
-  MN_CHECK_ARG(q && kv_cache && row_seq && row_len && out && workspace, "mn_attn_decode: null pointer");
+  MN_CHECK_ARG(q && kv_cache && row_seq && row_len && (out || split) && workspace, "mn_attn_decode: null pointer");
   int S = (int)mn_cdiv(t_max, 32);
   if (S > 32) S = 32;
   if (S < 1) S = 1;
@@ -291,12 +313,21 @@ extern "C" int mn_attn_decode(const float* q, int M, int n_q, int n_kv, int hd, 
   if (hd == 128) {
     hipLaunchKernelGGL(attn_decode_split_kernel<128>, grid, dim3(256), lds, st, q, n_q, n_kv, kv_cache, t_max, row_seq,
                        row_len, key_mask, ld_mask, S, chunk_cap, partial);
-    hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(M, n_q), dim3(128), 0, st, partial, n_q, S, out);
+    hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(M, n_q), dim3(128), 0, st, partial, n_q, S, out, split, M);
   } else {
     hipLaunchKernelGGL(attn_decode_split_kernel<64>, grid, dim3(256), lds, st, q, n_q, n_kv, kv_cache, t_max, row_seq,
                        row_len, key_mask, ld_mask, S, chunk_cap, partial);
-    hipLaunchKernelGGL(attn_decode_combine_kernel<64>, dim3(M, n_q), dim3(64), 0, st, partial, n_q, S, out);
+    hipLaunchKernelGGL(attn_decode_combine_kernel<64>, dim3(M, n_q), dim3(64), 0, st, partial, n_q, S, out, split, M);
   }
   MN_CHECK_LAUNCH("mn_attn_decode");
   return MN_OK;
+}
+
+extern "C" int mn_attn_decode(const float* q, int M, int n_q, int n_kv, int hd, const float* kv_cache,
+                                 int64_t t_max, const int32_t* row_seq, const int32_t* row_len,
+                                 const uint8_t* key_mask, int64_t ld_mask, float* out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  MN_CHECK_ARG(out, "mn_attn_decode: null pointer");
+  return mn_attn_decode_split(q, M, n_q, n_kv, hd, kv_cache, t_max, row_seq, row_len, key_mask, ld_mask, out, nullptr, workspace,
+                              workspace_bytes, stream);
 }

@@ -17,6 +17,13 @@ extern "C" size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t
 extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream);
 extern "C" int mn_stream_mfma_slices(int M, int Ntot, int K);
 extern "C" int mn_stream_mfma_grouped_slices(int G, int max_rows, int Ntot, int K);
+extern "C" int mn_rope_kv_from_partials(const float* qkv, int64_t ldqkv, int nz, int64_t slab, int M, int n_q, int n_kv, int hd,
+                                        int rope, const float* cos_tab, const float* sin_tab, const int32_t* row_seq,
+                                        const int32_t* row_slot, const int32_t* row_pos, int sec_t, int sec_h, float q_scale,
+                                        float* q_out, float* kv_cache, int64_t t_max, void* stream);
+extern "C" int mn_attn_decode_split(const float* q, int M, int n_q, int n_kv, int hd, const float* kv_cache, int64_t t_max,
+                                    const int32_t* row_seq, const int32_t* row_len, const uint8_t* key_mask, int64_t ld_mask,
+                                    float* out, uint16_t* split, void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P,
                                       int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows,
                                       int Ntot, int K, void* stream);
@@ -528,6 +535,121 @@ __global__ __launch_bounds__(256) void moe_combine_resid_kernel(const float* __r
   *reinterpret_cast<f4*>(h + i) = acc;
 }
 
+// ---- decoder-stack chain (rows >= 2): between two weight-streaming launches ONE kernel reduces the K-slice partials of
+// the producer, applies the residual / expert combine, and builds the RMSNorm'ed bf16 hi/lo operand of the consumer.
+// One workgroup per row (the RMS statistic needs the whole row), 4 columns per thread.
+//   mode 0: h[m] = x[m / row_div]                                              (stack input)
+//   mode 1: h[m] += sum_z P[z][m][:]                                           (attention output projection)
+//   mode 2: h[m] += sum_s tw[m,s] * sum_z P[z][pos(m,s)][:]                    (routed + shared experts)
+//   mode 3: h[m] as it is                                                      (experts already accumulated into h)
+// then, with norm_w: xn = RMSNorm(h[m]) -> xn_out fp32 (optional) and Y bf16 hi rows / lo rows (optional).
+__global__ __launch_bounds__(1024) void llm_glue_kernel(int mode, const float* __restrict__ x, int64_t ldx, int row_div,
+                                                        const float* __restrict__ P, int nz, int64_t slab,
+                                                        const int32_t* __restrict__ pair_pos, const float* __restrict__ tw,
+                                                        int n_slot, float* __restrict__ h, int M, int H,
+                                                        const bf16_t* __restrict__ norm_w, float eps,
+                                                        float* __restrict__ xn_out, bf16_t* __restrict__ Y) {
+  __shared__ float red[32];
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  const int m = blockIdx.x, col = threadIdx.x * 4;
+  const bool act = col < H;
+  f4 v = {0.f, 0.f, 0.f, 0.f};
+  if (act) {
+    if (mode == 0) {
+      v = *reinterpret_cast<const f4*>(x + (int64_t)(m / row_div) * ldx + col);
+    } else {
+      v = *reinterpret_cast<const f4*>(h + (int64_t)m * H + col);
+      if (mode == 1) {
+        const float* pp = P + (int64_t)m * H + col;
+        for (int z = 0; z < nz; ++z) v += *reinterpret_cast<const f4*>(pp + z * slab);
+      } else if (mode == 2) {
+        for (int s = 0; s < n_slot; ++s) {
+          const float* pp = P + (int64_t)pair_pos[m * n_slot + s] * H + col;
+          f4 y = {0.f, 0.f, 0.f, 0.f};
+          for (int z = 0; z < nz; ++z) y += *reinterpret_cast<const f4*>(pp + z * slab);
+          v += tw[m * n_slot + s] * y;
+        }
+      }
+    }
+    if (mode != 3) *reinterpret_cast<f4*>(h + (int64_t)m * H + col) = v;
+  }
+  if (!norm_w) return;
+  const float ss = block_sum(act ? v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w : 0.f, red);
+  const float rstd = rsqrtf(ss / (float)H + eps);
+  if (act) {
+    float o[4] = {v.x, v.y, v.z, v.w};
+    bf16_t hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = o[j] * rstd * bf16_to_f32(norm_w[col + j]);
+      hi[j] = f32_to_bf16(o[j]);
+      lo[j] = f32_to_bf16(o[j] - bf16_to_f32(hi[j]));
+    }
+    if (xn_out) *reinterpret_cast<f4*>(xn_out + (int64_t)m * H + col) = f4{o[0], o[1], o[2], o[3]};
+    if (Y) {
+      *reinterpret_cast<u2*>(Y + (int64_t)m * H + col) = u2{(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
+      *reinterpret_cast<u2*>(Y + (int64_t)(M + m) * H + col) = u2{(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
+    }
+  }
+}
+
+// Router tail in ONE workgroup: reduce the gate GEMV's K-slice partials, softmax + top-k + renormalise per row (one wave
+// per row, 64 experts = 64 lanes; BailingMoeGate.forward :505-520), append the shared pseudo-experts, and — when off is
+// given — sort the (row, slot) pairs by expert for the grouped expert GEMMs (same layout as moe_group_split_kernel).
+__global__ __launch_bounds__(1024) void moe_route_group_kernel(const float* __restrict__ P, int nz, int M, int E, int top_k,
+                                                               int norm_topk_prob, int n_shared, float* __restrict__ topk_w,
+                                                               int32_t* __restrict__ topk_idx, int G, int32_t* __restrict__ off,
+                                                               int32_t* __restrict__ xrows, int32_t* __restrict__ pair_pos) {
+  __shared__ int32_t s_idx[1024];
+  __shared__ int32_t s_off[257];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_slot = top_k + n_shared;
+  for (int m = wave; m < M; m += 16) {
+    float s = -INFINITY;
+    if (lane < E) {
+      s = 0.f;
+      for (int z = 0; z < nz; ++z) s += P[((int64_t)z * M + m) * E + lane];
+    }
+    const float mx = wave_max(s);
+    float p = lane < E ? __expf(s - mx) : 0.f;
+    p = p / wave_sum(p);
+    float cur = lane < E ? p : -1.f, wsum = 0.f, myw = 0.f;
+    int myidx = 0;
+    for (int k = 0; k < top_k; ++k) {             // iterative arg-max; ties -> lowest expert index
+      const float best = wave_max(cur);
+      const int sel = __ffsll((long long)__ballot(cur == best)) - 1;
+      if (lane == k) { myw = best; myidx = sel; }
+      if (lane == sel) cur = -1.f;
+      wsum += best;
+    }
+    if (lane < n_slot) {
+      const int idx = lane < top_k ? myidx : E + (lane - top_k);
+      const float wv = lane < top_k ? ((norm_topk_prob && top_k > 1) ? myw / wsum : myw) : 1.0f;
+      topk_idx[m * n_slot + lane] = idx;
+      topk_w[m * n_slot + lane] = wv;
+      s_idx[m * n_slot + lane] = idx;
+    }
+  }
+  if (!off) return;
+  const int Pn = M * n_slot;
+  for (int g = tid; g <= G; g += 1024) s_off[g] = 0;
+  __syncthreads();
+  for (int p = tid; p < Pn; p += 1024) atomicAdd(&s_off[s_idx[p] + 1], 1);
+  __syncthreads();
+  if (tid == 0) for (int g = 0; g < G; ++g) s_off[g + 1] += s_off[g];
+  __syncthreads();
+  for (int g = tid; g <= G; g += 1024) off[g] = s_off[g];
+  for (int p = tid; p < Pn; p += 1024) {
+    const int e = s_idx[p];
+    int rank = 0;
+    for (int q = 0; q < p; ++q) rank += (s_idx[q] == e);
+    const int pos = s_off[e] + rank;
+    xrows[pos] = p / n_slot;
+    pair_pos[p] = pos;
+  }
+}
+
 struct MoeWs {
   int32_t *off, *xrows, *pair_pos;
   bf16_t *y1, *y2;
@@ -554,10 +676,21 @@ static bool moe_mfma_ok(const mn_llm* m, int rows) {
          m->n_experts + m->n_shared_slots <= 256 && (m->hidden % 8) == 0 && (m->moe_inter % 8) == 0;   // % 4: vector glue
 }
 
+// 2..32 rows run the decoder stack as a chain of weight-streaming launches and fused glue kernels (4 columns per thread,
+// one wave per router row: 64 experts at most).  Measured end to end against the unfused sequence (same box, tokens/s):
+// 2 rows 78.5 vs 76.5, 8 rows 254 vs 247, 16 rows 451 vs 442, 32 rows 699 vs 698; at 64 rows the one-workgroup-per-row
+// glue kernels lose to the wider unfused ones (1084 vs 1122), so the chain stops at 32.
+static bool llm_chain_ok(const mn_llm* m, int rows) {
+  return rows >= 2 && rows <= 32 && (m->hidden % 8) == 0 && m->hidden <= 4096 && ((m->n_q * m->head_dim) % 8) == 0 &&
+         m->n_experts <= 64 && rows * (m->top_k + m->n_shared_slots) <= 1024 && m->n_experts + m->n_shared_slots <= 256;
+}
+
 struct LlmWs {
   float *h, *qkv, *q, *attn, *xn, *tw, *hmid, *logits;
   int32_t* ti;
   MoeWs moe;
+  bf16_t *yh, *ya;      // chain: bf16 hi/lo operands of width H and n_q * head_dim
+  float* pp;            // chain: K-slice partials of the QKV / dense / gate launches
   void* attn_ws;
   size_t attn_ws_bytes;
   char* sk_ws;
@@ -582,11 +715,22 @@ static size_t llm_carve(const mn_llm* m, int rows, int64_t t_max, void* ws, size
   o->sk_ws_bytes = sk_ws_need(rows, {{qkv_dim, m->hidden, 0}, {m->hidden, m->n_q * m->head_dim, 0}, {m->n_experts, m->hidden, 0}});
   o->sk_ws = cv.take<char>(o->sk_ws_bytes);
   if (moe_mfma_ok(m, rows)) moe_carve(cv, rows, m->hidden, m->moe_inter, m->n_experts + m->n_shared_slots, n_slot, &o->moe);
+  if (llm_chain_ok(m, rows)) {
+    const int ad = m->n_q * m->head_dim;
+    o->yh = cv.take<bf16_t>((size_t)2 * rows * m->hidden);
+    o->ya = cv.take<bf16_t>((size_t)2 * rows * ad);
+    size_t pmax = (size_t)mn_stream_mfma_slices(rows, qkv_dim, m->hidden) * qkv_dim;
+    const size_t p2 = (size_t)mn_stream_mfma_slices(rows, m->hidden, ad) * m->hidden;
+    const size_t p3 = (size_t)mn_stream_mfma_slices(rows, m->n_experts, m->hidden) * m->n_experts;
+    if (p2 > pmax) pmax = p2;
+    if (p3 > pmax) pmax = p3;
+    o->pp = cv.take<float>(pmax * rows);
+  }
   return cv.off;
 }
 
 extern "C" size_t mn_llm_workspace_bytes(const mn_llm* m, int rows, int64_t t_max) {
-  LlmWs w;
+  LlmWs w{};
   return llm_carve(m, rows, t_max, nullptr, 0, &w);
 }
 
@@ -604,7 +748,7 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
   MN_CHECK_ARG(m && x && row_seq && row_slot && row_pos && row_len && kv_cache && hidden_out && workspace,
                "mn_llm_step: null pointer");
   MN_CHECK_ARG(M >= 1 && M <= 64 && x_row_div >= 1, "mn_llm_step: M=%d (1..64)", M);
-  LlmWs w;
+  LlmWs w{};
   const size_t need = llm_carve(m, M, t_max, workspace, workspace_bytes, &w);
   if (need > workspace_bytes) { mn_set_error("mn_llm_step: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
   hipStream_t st = mn_stream(stream);
@@ -613,6 +757,74 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
   const int64_t layer_kv = (int64_t)n_seq * 2 * nkv * t_max * hd;
   const float q_scale = 1.0f / sqrtf((float)hd);
   t_sk_ws = w.sk_ws; t_sk_ws_bytes = w.sk_ws_bytes;
+  if (llm_chain_ok(m, M) && !(image_mask && m->image_gate)) {
+    // ---- chain path: 12 launches per layer (11 at 2 rows) instead of 18.  glue = llm_glue_kernel.
+    const int E = m->n_experts, S = m->n_shared_slots, G = E + S, ad = nq * hd, P = M * n_slot;
+    const bool grouped = moe_mfma_ok(m, M);
+    const int gt = ((H / 4 + 63) / 64) * 64;                           // threads of a glue workgroup
+    int nz2 = 0;                                                       // slabs of the previous layer's expert down-projection
+    for (int l = 0; l < m->n_layers; ++l) {
+      float* kv_l = kv_cache + (int64_t)l * layer_kv;
+      // glue: (previous experts' combine + residual | stack input) -> RMSNorm(ln1) -> yh
+      if (l == 0)
+        hipLaunchKernelGGL(llm_glue_kernel, dim3(M), dim3(gt), 0, st, 0, x, ldx, x_row_div, (const float*)nullptr, 0, (int64_t)0,
+                           (const int32_t*)nullptr, (const float*)nullptr, n_slot, w.h, M, H, m->ln1[l], m->rms_eps,
+                           (float*)nullptr, w.yh);
+      else
+        hipLaunchKernelGGL(llm_glue_kernel, dim3(M), dim3(gt), 0, st, grouped ? 2 : 3, (const float*)nullptr, (int64_t)0, 1,
+                           (const float*)w.moe.p2, nz2, (int64_t)P * H, (const int32_t*)w.moe.pair_pos, (const float*)w.tw,
+                           n_slot, w.h, M, H, m->ln1[l], m->rms_eps, (float*)nullptr, w.yh);
+      // QKV launch -> partials; RoPE + KV append reduce them  (:743-789)
+      int nz = mn_stream_mfma(w.yh, m->wqkv[l], w.pp, M, qkv_dim, H, stream);
+      if (nz < 0) return nz;
+      MN_TRY(mn_rope_kv_from_partials(w.pp, qkv_dim, nz, (int64_t)M * qkv_dim, M, nq, nkv, hd, 1, m->cos_tab, m->sin_tab,
+                                      row_seq, row_slot, row_pos, m->mrope_sec_t, m->mrope_sec_h, q_scale, w.q, kv_l, t_max,
+                                      stream));
+      // masked GQA; the combine writes the dense projection's bf16 operand directly  (:791-812)
+      MN_TRY(mn_attn_decode_split(w.q, M, nq, nkv, hd, kv_l, t_max, row_seq, row_len, key_mask, ld_mask, nullptr, w.ya, w.attn_ws,
+                                  w.attn_ws_bytes, stream));
+      nz = mn_stream_mfma(w.ya, m->wdense[l], w.pp, M, H, ad, stream);
+      if (nz < 0) return nz;
+      // glue: h += dense partials; RMSNorm(ln2) -> xn (fp32 for the 2-row expert kernels) and yh (gate + expert operand)
+      hipLaunchKernelGGL(llm_glue_kernel, dim3(M), dim3(gt), 0, st, 1, (const float*)nullptr, (int64_t)0, 1, (const float*)w.pp, nz,
+                         (int64_t)M * H, (const int32_t*)nullptr, (const float*)nullptr, n_slot, w.h, M, H, m->ln2[l],
+                         m->rms_eps, grouped ? (float*)nullptr : w.xn, w.yh);
+      // gate launch -> partials; ONE workgroup does softmax / top-k / expert sort  (:505-520, 565-592)
+      nz = mn_stream_mfma(w.yh, m->gate[l], w.pp, M, E, H, stream);
+      if (nz < 0) return nz;
+      hipLaunchKernelGGL(moe_route_group_kernel, dim3(1), dim3(1024), 0, st, (const float*)w.pp, nz, M, E, m->top_k,
+                         m->norm_topk_prob, S, w.tw, w.ti, G, grouped ? w.moe.off : (int32_t*)nullptr, w.moe.xrows,
+                         w.moe.pair_pos);
+      if (grouped) {
+        nz = mn_stream_mfma_grouped(w.yh, M, m->w_gate_up[l], (int64_t)2 * I * H, w.moe.p1, P, w.moe.off, w.moe.xrows, G, M,
+                                    2 * I, H, stream);
+        if (nz < 0) return nz;
+        hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)P * I, 1024)), dim3(256), 0, st, w.moe.p1, nz, P,
+                           I, (const bf16_t*)nullptr, w.moe.y2);
+        nz2 = mn_stream_mfma_grouped(w.moe.y2, P, m->w_down[l], (int64_t)H * I, w.moe.p2, P, w.moe.off, nullptr, G, M, H, I,
+                                     stream);
+        if (nz2 < 0) return nz2;
+      } else {   // 2 rows: (row, expert) pairs on the fp32-FMA kernels, accumulated straight into h
+        mn_skinny_args a = sk(w.xn, H, m->w_gate_up[l], H, nullptr, w.hmid, I, 1, I, H);
+        a.epilogue = MN_EPI_SWIGLU;
+        a.batch = M * n_slot; a.w_index = w.ti; a.w_batch_stride = (int64_t)2 * I * H;
+        a.x_batch_stride = H; a.x_batch_div = n_slot; a.out_batch_stride = I;
+        MN_TRY(mn_skinny_gemm(&a, stream));
+        a = sk(w.hmid, (int64_t)n_slot * I, m->w_down[l], I, nullptr, w.h, H, 1, H, I);
+        a.epilogue = MN_EPI_RESID; a.res = w.h; a.ldres = H; a.res_batch_stride = H;
+        a.batch = M; a.w_index = nullptr; a.w_batch_stride = 0;
+        a.x_batch_stride = (int64_t)n_slot * I; a.x_batch_div = 1; a.out_batch_stride = H;
+        a.nseg = n_slot; a.seg_index = w.ti; a.seg_scale = w.tw; a.seg_w_stride = (int64_t)H * I;
+        MN_TRY(mn_skinny_gemm(&a, stream));
+      }
+    }
+    // last experts' combine + residual -> final RMSNorm -> hidden_out
+    hipLaunchKernelGGL(llm_glue_kernel, dim3(M), dim3(gt), 0, st, grouped ? 2 : 3, (const float*)nullptr, (int64_t)0, 1,
+                       (const float*)w.moe.p2, nz2, (int64_t)P * H, (const int32_t*)w.moe.pair_pos, (const float*)w.tw, n_slot,
+                       w.h, M, H, m->final_norm, m->rms_eps, hidden_out, (bf16_t*)nullptr);
+    MN_CHECK_LAUNCH("mn_llm_step");
+    return MN_OK;
+  }
   hipLaunchKernelGGL(copy_rows_f32_kernel, dim3(mn_cdiv((int64_t)M * H, 256)), dim3(256), 0, st, x, ldx, x_row_div, w.h, M, H);
   for (int l = 0; l < m->n_layers; ++l) {
     float* kv_l = kv_cache + (int64_t)l * layer_kv;
