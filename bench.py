@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--kloop-ck128", action="store_true", help=argparse.SUPPRESS)   # A/B hook
+    ap.add_argument("--chain-max-rows", type=int, default=0, help=argparse.SUPPRESS)  # A/B hook
     ap.add_argument("--cfg-rows", type=int, default=2, help=argparse.SUPPRESS)       # 3 = editing-style CFG (experiments)
     args = ap.parse_args()
     args.groups = max(1, min(args.groups, args.images))
@@ -246,6 +247,13 @@ def main():
         f.argtypes = [ctypes.c_int] * 3
         f.restype = None
         f(0, 16, 0)
+    if args.chain_max_rows:
+        import ctypes
+        from ming_univision_amd._lib import lib
+        f = lib().mn_llm_tune_chain
+        f.argtypes = [ctypes.c_int]
+        f.restype = None
+        f(args.chain_max_rows)
     cfg, dec, rf, tok = build_models(args, device, seed=0)
     g = torch.Generator(device=device).manual_seed(grp.seed(1000))     # independent prompt / noise per replica
     prompt = torch.randint(0, min(cfg.vocab_size, 100000), (args.images, args.prompt_len), generator=g, device=device)

@@ -564,11 +564,22 @@ __global__ __launch_bounds__(1024) void llm_glue_kernel(int mode, const float* _
         const float* pp = P + (int64_t)m * H + col;
         for (int z = 0; z < nz; ++z) v += *reinterpret_cast<const f4*>(pp + z * slab);
       } else if (mode == 2) {
-        for (int s = 0; s < n_slot; ++s) {
-          const float* pp = P + (int64_t)pair_pos[m * n_slot + s] * H + col;
-          f4 y = {0.f, 0.f, 0.f, 0.f};
-          for (int z = 0; z < nz; ++z) y += *reinterpret_cast<const f4*>(pp + z * slab);
-          v += tw[m * n_slot + s] * y;
+        for (int s = 0; s < n_slot; s += 4) {       // four slots x nz slabs of independent 16-byte loads in flight
+          const float* pp[4];
+          float wv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int sj = s + j < n_slot ? s + j : s;
+            pp[j] = P + (int64_t)pair_pos[m * n_slot + sj] * H + col;
+            wv[j] = s + j < n_slot ? tw[m * n_slot + sj] : 0.f;
+          }
+          f4 y[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+          for (int z = 0; z < nz; ++z) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] += *reinterpret_cast<const f4*>(pp[j] + z * slab);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v += wv[j] * y[j];
         }
       }
     }
@@ -680,8 +691,10 @@ static bool moe_mfma_ok(const mn_llm* m, int rows) {
 // one wave per router row: 64 experts at most).  Measured end to end against the unfused sequence (same box, tokens/s):
 // 2 rows 78.5 vs 76.5, 8 rows 254 vs 247, 16 rows 451 vs 442, 32 rows 699 vs 698; at 64 rows the one-workgroup-per-row
 // glue kernels lose to the wider unfused ones (1084 vs 1122), so the chain stops at 32.
+static int g_chain_max_rows = 32;
+extern "C" void mn_llm_tune_chain(int max_rows) { g_chain_max_rows = max_rows; }   // A/B hook
 static bool llm_chain_ok(const mn_llm* m, int rows) {
-  return rows >= 2 && rows <= 32 && (m->hidden % 8) == 0 && m->hidden <= 4096 && ((m->n_q * m->head_dim) % 8) == 0 &&
+  return rows >= 2 && rows <= g_chain_max_rows && (m->hidden % 8) == 0 && m->hidden <= 4096 && ((m->n_q * m->head_dim) % 8) == 0 &&
          m->n_experts <= 64 && rows * (m->top_k + m->n_shared_slots) <= 1024 && m->n_experts + m->n_shared_slots <= 256;
 }
 
