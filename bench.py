@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--layers", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--kloop-ck128", action="store_true", help=argparse.SUPPRESS)   # A/B hook
     ap.add_argument("--chain-max-rows", type=int, default=0, help=argparse.SUPPRESS)  # A/B hook
+    ap.add_argument("--kloop-small-div", type=int, default=0, help=argparse.SUPPRESS)  # A/B hook
     ap.add_argument("--cfg-rows", type=int, default=2, help=argparse.SUPPRESS)       # 3 = editing-style CFG (experiments)
     args = ap.parse_args()
     args.groups = max(1, min(args.groups, args.images))
@@ -254,6 +255,13 @@ def main():
         f.argtypes = [ctypes.c_int]
         f.restype = None
         f(args.chain_max_rows)
+    if args.kloop_small_div:
+        import ctypes
+        from ming_univision_amd._lib import lib
+        f = lib().mn_stream_kloop_tune_small
+        f.argtypes = [ctypes.c_int]
+        f.restype = None
+        f(args.kloop_small_div)
     cfg, dec, rf, tok = build_models(args, device, seed=0)
     g = torch.Generator(device=device).manual_seed(grp.seed(1000))     # independent prompt / noise per replica
     prompt = torch.randint(0, min(cfg.vocab_size, 100000), (args.images, args.prompt_len), generator=g, device=device)

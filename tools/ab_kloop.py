@@ -50,8 +50,6 @@ def bench(M, N2, K, variants, rounds=5, iters=24):
 
 L.mn_stream_kloop_tune(0, 0, 0)
 M = 64
-bench(M, 16384, 3072, [("kloop", nz, 2, 2) for nz in (0, 2, 3, 4, 5)])
-bench(M, 3072, 8192, [("kloop", nz, 2, 2) for nz in (0, 8, 10, 12, 16, 21, 26)])
-bench(M, 3072, 2048, [("kloop", nz, 2, 2) for nz in (0, 2, 4, 8, 16)])
-bench(M, 2048, 2048, [("kloop", nz, 2, 2) for nz in (0, 2, 4, 8, 16)])
-bench(M, 64, 2048, [("kloop", nz, 2, 2) for nz in (0, 2, 4, 8, 16, 32)])
+bench(M, 16384, 3072, [("kloop", 0, d, 2) for d in (2, 4)] + [("kloop", 0, d, 1) for d in (2, 4)])
+bench(M, 3072, 8192, [("kloop", 0, d, 2) for d in (2, 4)] + [("kloop", 0, d, 1) for d in (2, 4)])
+bench(M, 3072, 2048, [("kloop", 0, d, 2) for d in (2, 4)])
