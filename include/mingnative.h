@@ -213,6 +213,26 @@ int mn_gemm_bf16_grouped(const uint16_t* A, int64_t lda, const uint16_t* W, int6
                          const int32_t* off, const int32_t* cnt, int n_groups, void* C, int64_t ldc, int m_max, int N,
                          int K, int epilogue, void* stream);
 
+/* ---- wide-row GEMM (gemm256.hip): 256 x 256 x 64 tiles, 8 waves, 4-phase-per-K-tile schedule with counted vmcnt --------
+ * The nn.Linear call sites above when hundreds of rows are in flight (lock-step generation of 128+ images: RF head
+ * w12 / w3 / adaLN, diff_loss_rf_swiglu.py:54-72, 263-272, 283-292; MingTok batches; long-prompt prefill).
+ * Needs K % 64 == 0, N % 4 == 0, 16-byte aligned rows and operands below 4 GiB (mn_gemm256_supported).
+ *   a_lo_off == 0: A bf16 [M,K].   a_lo_off != 0: A is a bf16 hi/lo pair (lo rows a_lo_off elements after the hi rows),
+ *   the product is (A_hi + A_lo) W^T with both halves riding the same W tiles (a tile then covers 128 rows).
+ * epilogue: enum mn_gemm_epilogue. */
+int mn_gemm256_supported(int64_t lda, int64_t a_lo_off, int64_t ldw, int64_t w_rows, int M, int N, int K);
+int mn_gemm256(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W, int64_t ldw, const uint16_t* bias,
+               void* C, int64_t ldc, int M, int N, int K, int epilogue, void* stream);
+/* Split-K: slice z of the K range writes fp32 partials[z][M][N] (bias folded into slice 0); returns the slice count. */
+int mn_gemm256_splitk(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W, int64_t ldw,
+                      const uint16_t* bias, float* partials, int M, int N, int K, int ksplit, void* stream);
+/* SwiGLU-fused (swiglu_ffn.py:30-34, diff_loss_rf_swiglu.py:54-72): W12 bf16 [2*hidden, K] (gate rows then up rows),
+ * b12 bf16 [2*hidden] or NULL.  Y receives silu(A Wg^T + bg) * (A Wu^T + bu) split into bf16 hi rows [M, hidden] (ldy)
+ * and lo rows y_lo_off elements further — the operand layout of the next hi/lo GEMM. */
+int mn_gemm256_swiglu_split(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W12, int64_t ldw,
+                            const uint16_t* b12, uint16_t* Y, int64_t ldy, int64_t y_lo_off, int M, int hidden, int K,
+                            void* stream);
+
 /* Weight-streaming MFMA kernel behind the M >= 5 route of mn_skinny_gemm: Y bf16 [2][M][K] (activations split
  * into hi rows then lo rows), W bf16 [Ntot, K] dense, P fp32 [nz][M][Ntot] K-slice partials with
  * nz = mn_stream_mfma_slices(M, Ntot, K) (the launch plan picks slices of 256..1024 k so that every wave of the

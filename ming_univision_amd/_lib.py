@@ -105,6 +105,10 @@ SYMBOLS = {
     "mn_gather_rows_bf16": (_i, [_p, _i64, _p, _p, _i64, _i, _i, _p]),
     "mn_moe_combine": (_i, [_p, _i64, _p, _p, _i, _p, _i64, _i, _i, _p]),
     "mn_gemm_bf16_grouped": (_i, [_p, _i64, _p, _i64, _i64, _p, _p, _i, _p, _i64, _i, _i, _i, _i, _p]),
+    "mn_gemm256_supported": (_i, [_i64, _i64, _i64, _i64, _i, _i, _i]),
+    "mn_gemm256": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _i, _i, _i, _i, _p]),
+    "mn_gemm256_splitk": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i, _i, _i, _i, _p]),
+    "mn_gemm256_swiglu_split": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _i64, _i, _i, _i, _p]),
     "mn_stream_mfma_slices": (_i, [_i, _i, _i]),
     "mn_stream_mfma_grouped": (_i, [_p, _i, _p, _i64, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "mn_stream_mfma_grouped_slices": (_i, [_i, _i, _i, _i]),

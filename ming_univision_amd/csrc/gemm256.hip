@@ -1,0 +1,389 @@
+// gemm256.hip — the wide-row bf16 MFMA GEMM of the lock-step generation path (gfx950).
+//
+//   C[M, N] = epilogue( A[M, K] · W[N, K]^T )        A, W bf16 row-major (nn.Linear weight layout), fp32 accumulate
+//
+// Replaces the cuBLAS calls behind nn.Linear when hundreds of rows are in flight: the rectified-flow head's w12 / w3 /
+// adaLN projections (diff_loss_rf_swiglu.py:54-72, 263-272, 283-292) for 128+ images advancing in lock-step, the
+// MingTok encoder / decoder linears on image batches (mingtok layers/attention.py:49-51, mlp.py:34-40,
+// swiglu_ffn.py:27-34) and the Bailing-MoE projections on long prompts (modeling_bailing_moe.py:760, 824).
+//
+// Structure (one 512-thread workgroup per CU, 8 waves as 2 (M) x 4 (N), each wave a 128 x 64 output block):
+//   * 256 x 256 output tile, K step 64.  LDS: 2 K-tile buffers x {A, W} x 2 half-tiles of 128 rows x 128 B = 128 KiB.
+//   * tiles are copied HBM/L2 -> LDS by global_load_lds_dwordx4 (no VGPR round trip); the LDS image of a wave
+//     instruction is lane-linear (8 rows x 8 slots of 16 B), so the bank swizzle slot ^= row & 7 is applied to the
+//     per-lane SOURCE address and again on the fragment read (conflict-free ds_read_b128).
+//   * "half-tiles" follow the wave's fragment halves, not its rows: A half h holds the rows of M-fragments 4h..4h+3 of
+//     both wave rows, W half h the columns of N-fragments 2h..2h+1 of all four wave columns.  A K-tile is then four
+//     quadrant phases  (A0,W0) (A0,W1) (A1,W1) (A1,W0)  of 16 MFMAs each, and a half-tile is dead — free to be
+//     re-filled — two phases after the phase that read it.
+//   * SCHED 1 (default): 4 phases per K-tile, every phase = { ds_read the next quadrant's fragments, issue ONE half-tile
+//     (2 global_load_lds per lane) of a later K-tile, s_waitcnt vmcnt(8) — never 0 in the steady state, four half-tiles
+//     stay in flight across the barriers —, s_barrier, 16 x v_mfma_f32_16x16x32_bf16 at raised priority, s_barrier }.
+//     The two wave rows run one barrier apart, so on every SIMD one wave is in its MFMA cluster while its partner
+//     reads LDS and issues loads.  Hazard distances are by construction (see tile_step): a half-tile is read >= 5 phases
+//     after it was issued and one phase after the counted wait that retires it; it is re-filled >= 2 phases after its
+//     last read.
+//   * SCHED 0: same tile, one barrier per K-tile (all four half-tiles of the next K-tile issued up front, vmcnt(0)
+//     before the barrier) — the simple reference schedule the A/B tool compares against.
+//   * The MFMA takes the W fragment as its A operand and the activation fragment as B, so a lane's 4 accumulator
+//     registers are 4 CONSECUTIVE output columns of one row: 16-byte fp32 / 8-byte bf16 stores.
+//
+// Pairing modes (both are free: they only change which global row an LDS row is filled from):
+//   * a_lo_off != 0 — hi/lo-stacked activations: A is a bf16 hi/lo pair (x = hi + lo to 2^-17); A half 0 holds 128 hi
+//     rows, half 1 the same rows' lo parts, and the epilogue adds the two accumulator halves: fp32-class products from
+//     bf16 MFMAs, a tile covers 128 real rows.
+//   * w_pair_rows != 0 — gate/up pairing (SwiGLU): W half 0 holds 128 gate rows, half 1 the matching up rows
+//     (w_pair_rows further down), so a lane holds silu-gate and up of the same hidden unit: the SwiGLU, its bias and
+//     the bf16 hi/lo split of the next GEMM's operand happen in the epilogue, a tile covers 128 hidden units.
+#include <type_traits>
+
+#include "common.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 64;                       // k per K-tile
+constexpr int HALF_BYTES = 128 * 128;        // one half-tile: 128 rows x 64 k bf16
+constexpr int LDS_BYTES = 2 * 2 * 2 * HALF_BYTES;   // [buf][A|W][half] = 128 KiB
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+struct G256 {
+  const bf16_t* A; int64_t lda; int64_t a_lo_off;       // a_lo_off (elements) != 0: hi/lo-stacked rows
+  const bf16_t* W; int64_t ldw; int64_t w_pair_rows;    // w_pair_rows != 0: gate/up pairing, N counts hidden units
+  const bf16_t* bias;                                    // bf16 [N] (paired: [2 * w_pair_rows... ] gate at n, up at n + w_pair_rows) or NULL
+  void* C; int64_t ldc; int64_t c_zstride;               // split-K: slice z writes C + z * c_zstride (fp32 epilogues)
+  int64_t c_lo_off;                                      // SWIGLU_SPLIT / BF16_SPLIT: lo rows c_lo_off elements after the hi rows
+  const float* gate; int64_t ldgate;                     // RESID_GATE: C += gate * (acc + bias)
+  int M, N, K, Kc;                                       // Kc: k per split-K slice (multiple of 64)
+};
+
+enum { E_F32 = 0, E_BF16 = 1, E_BF16_GELU = 2, E_F32_RESID = 3, E_SWIGLU_SPLIT = 4, E_F32_RESID_GATE = 5 };
+
+__device__ __forceinline__ int lds_off(int buf, int op, int half) { return ((buf * 2 + op) * 2 + half) * HALF_BYTES; }
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(N == 0 || N == 8, "counts used by the schedules");
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+template <int EPI, int SCHED, bool HILO>
+__global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  constexpr bool hilo = HILO, paired = EPI == E_SWIGLU_SPLIT;
+  const int rows_per_tile = hilo ? 128 : 256, cols_per_tile = paired ? 128 : 256;
+  const int tiles_m = (p.M + rows_per_tile - 1) / rows_per_tile, tiles_n = (p.N + cols_per_tile - 1) / cols_per_tile;
+  // XCD-aware tile order (bijective for any tile count): the tiles of one XCD are consecutive, tm fastest, so the M-tiles
+  // that share a W column panel sit in one L2.
+  int bid = blockIdx.x;
+  {
+    const int nt = tiles_m * tiles_n;
+    const int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  const int m0 = tm * rows_per_tile, n0 = tn * cols_per_tile;
+  const int kbeg = blockIdx.y * p.Kc, kend = min(p.K, kbeg + p.Kc);
+  const int nk = (kend - kbeg) / BK;
+
+  // ---- staging: wave w fills LDS rows [16w, 16w+16) of a half-tile with two instructions of 8 rows x 8 slots ----
+  // per-lane byte offsets (from A / W) of the global row behind LDS row L = 16*wave + 8*q + (lane >> 3) of half h,
+  // with the k-slot swizzle (lane & 7) ^ (row & 7) folded in.  All offsets fit 32 bits (checked by the host).
+  uint32_t srcA[2][2], srcW[2][2];
+  {
+    const int rin = lane >> 3, ks = ((lane & 7) ^ rin) * 16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int L = wave * 16 + q * 8 + rin;
+        int gm, gn;
+        if (hilo) gm = m0 + L;                                      // half = hi / lo part of the same rows
+        else gm = m0 + (L >> 6) * 128 + h * 64 + (L & 63);          // wave row L / 64, fragment half h
+        gm = min(gm, p.M - 1);
+        if (paired) gn = min(n0 + L, p.N - 1) + (h ? (int)p.w_pair_rows : 0);
+        else gn = min(n0 + (L >> 5) * 64 + h * 32 + (L & 31), p.N - 1);
+        srcA[h][q] = (uint32_t)(((int64_t)gm * p.lda + (hilo && h ? p.a_lo_off : 0) + kbeg) * 2 + ks);
+        srcW[h][q] = (uint32_t)(((int64_t)gn * p.ldw + kbeg) * 2 + ks);
+      }
+  }
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+  const char* Wb = reinterpret_cast<const char*>(p.W);
+  auto stage = [&](int op, int h, int kt, int buf) {   // op 0 = A, 1 = W; all arguments compile-time or wave-uniform
+    char* dst = &lds[lds_off(buf, op, h) + wave * 2048];
+    const uint32_t koff = (uint32_t)kt * (BK * 2);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const char* src = op == 0 ? Ab + (srcA[h][q] + koff) : Wb + (srcW[h][q] + koff);
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + q * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment reads: row (of a half) = wave part + 16 * frag + fr, slot = (4 kk + fq) ^ (row & 7) ----
+  const int lane_off0 = fr * 128 + (((fq) ^ (fr & 7)) << 4);          // kk = 0
+  const int lane_off1 = fr * 128 + (((4 + fq) ^ (fr & 7)) << 4);      // kk = 1
+  const int a_wave = wr * 64 * 128, w_wave = wc * 32 * 128;
+  bf16x8 af[4][2], wf0[2][2], wf1[2][2];
+  auto read_a = [&](int buf, int h) {
+    const char* base = &lds[lds_off(buf, 0, h) + a_wave];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i][0] = *reinterpret_cast<const bf16x8*>(base + i * 2048 + lane_off0);
+      af[i][1] = *reinterpret_cast<const bf16x8*>(base + i * 2048 + lane_off1);
+    }
+  };
+  auto read_w = [&](int buf, int h, bf16x8 (&wf)[2][2]) {
+    const char* base = &lds[lds_off(buf, 1, h) + w_wave];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      wf[j][0] = *reinterpret_cast<const bf16x8*>(base + j * 2048 + lane_off0);
+      wf[j][1] = *reinterpret_cast<const bf16x8*>(base + j * 2048 + lane_off1);
+    }
+  };
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // quadrant (mh, nh): D[n][m] += W-frag (as A operand) x activation frag (as B operand)
+  auto quad = [&](int mh, int nh, bf16x8 (&wf)[2][2]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[mh * 4 + i][nh * 2 + j] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], af[i][kk], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+  };
+
+  if (SCHED == 0) {
+    // ---------------- one barrier per K-tile ----------------
+    stage(0, 0, 0, 0); stage(1, 0, 0, 0); stage(1, 1, 0, 0); stage(0, 1, 0, 0);
+    for (int t = 0; t < nk; ++t) {
+      const int X = t & 1;
+      wait_vm<0>();
+      __builtin_amdgcn_s_barrier();          // tile t landed for everyone; buffer X^1 no longer read by anyone
+      if (t + 1 < nk) { stage(0, 0, t + 1, X ^ 1); stage(1, 0, t + 1, X ^ 1); stage(1, 1, t + 1, X ^ 1); stage(0, 1, t + 1, X ^ 1); }
+      read_a(X, 0); read_w(X, 0, wf0);
+      quad(0, 0, wf0);
+      read_w(X, 1, wf1);
+      quad(0, 1, wf1);
+      read_a(X, 1);
+      quad(1, 1, wf1);
+      quad(1, 0, wf0);
+    }
+  } else {
+    // ---------------- 4 phases per K-tile, counted vmcnt, wave rows one barrier apart ----------------
+    // Issue order of half-tiles (virtual time, one per phase) for the K-tile T held in buffer X (Y = X ^ 1):
+    //   phase 0 of T: Y.W1 <- T+1      phase 1: Y.A1 <- T+1      phase 2: X.A0 <- T+2      phase 3: X.W0 <- T+2
+    // Reads: phase 0: X.A0, X.W0   phase 1: X.W1   phase 2: X.A1   phase 3: none (W0 fragments stay in registers).
+    //   RAW: issue -> first read is >= 5 phases; the vmcnt(8) of phase p (4 half-tiles = 8 loads may stay in flight)
+    //        retires the half-tile issued in phase p-4, which is read in phase p+1 or later, i.e. after a barrier every
+    //        wave reaches only after its own wait (also across the one-barrier stagger).
+    //   WAR: last read -> re-issue is >= 2 phases (A0: read ph 0, issued ph 2; W0: 0 -> 3; W1: 1 -> 4; A1: 2 -> 5).
+    auto phase = [&](auto Xc, auto PHc, int T) {
+      constexpr int X = decltype(Xc)::value, PH = decltype(PHc)::value, Y = X ^ 1;
+      if (PH == 0) { read_w(X, 0, wf0); __builtin_amdgcn_sched_barrier(0); read_a(X, 0); }
+      if (PH == 1) read_w(X, 1, wf1);
+      if (PH == 2) read_a(X, 1);
+      const int tgt = PH < 2 ? T + 1 : T + 2;
+      if (tgt < nk) {
+        if (PH == 0) stage(1, 1, tgt, Y);
+        if (PH == 1) stage(0, 1, tgt, Y);
+        if (PH == 2) stage(0, 0, tgt, X);
+        if (PH == 3) stage(1, 0, tgt, X);
+        wait_vm<8>();
+      } else {
+        wait_vm<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      if (PH == 0) quad(0, 0, wf0);
+      if (PH == 1) quad(0, 1, wf1);
+      if (PH == 2) quad(1, 1, wf1);
+      if (PH == 3) quad(1, 0, wf0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    // prologue = the issues of the virtual phases before tile 0, in their order
+    stage(0, 0, 0, 0); stage(1, 0, 0, 0); stage(1, 1, 0, 0); stage(0, 1, 0, 0);
+    if (nk > 1) { stage(0, 0, 1, 1); stage(1, 0, 1, 1); wait_vm<8>(); }
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs one barrier behind wave row 0
+    for (int t = 0; t < nk; t += 2) {
+      phase(I0{}, I0{}, t); phase(I0{}, I1{}, t); phase(I0{}, I2{}, t); phase(I0{}, I3{}, t);
+      if (t + 1 < nk) { phase(I1{}, I0{}, t + 1); phase(I1{}, I1{}, t + 1); phase(I1{}, I2{}, t + 1); phase(I1{}, I3{}, t + 1); }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue: lane holds, per (i, j), output row m = .. + 16 i + fr and 4 consecutive columns 16 j + 4 fq .. +3 ----
+  constexpr int mi_n = hilo ? 4 : 8, nj_n = paired ? 2 : 4;
+  char* Cz = reinterpret_cast<char*>(p.C);
+  if (EPI == E_F32) Cz += (int64_t)blockIdx.y * p.c_zstride * 4;
+#pragma unroll
+  for (int i = 0; i < mi_n; ++i) {
+    const int m = hilo ? m0 + wr * 64 + i * 16 + fr : m0 + wr * 128 + i * 16 + fr;
+#pragma unroll
+    for (int j = 0; j < nj_n; ++j) {
+      const int n = paired ? n0 + wc * 32 + j * 16 + fq * 4 : n0 + wc * 64 + j * 16 + fq * 4;
+      if (m >= p.M || n >= p.N) continue;         // N % 4 == 0 (host check): a lane's 4 columns are all in or all out
+      f32x4 v = acc[i][j];
+      if (hilo) v += acc[(i + 4) & 7][j];
+      f32x4 u = {0.f, 0.f, 0.f, 0.f};
+      if (paired) { u = acc[i][(j + 2) & 3]; if (hilo) u += acc[(i + 4) & 7][(j + 2) & 3]; }
+      if (p.bias && blockIdx.y == 0) {
+        const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
+        v += f32x4{bf16lo_to_f32(b.x), bf16hi_to_f32(b.x), bf16lo_to_f32(b.y), bf16hi_to_f32(b.y)};
+        if (paired) {
+          const u32x2 b2 = *reinterpret_cast<const u32x2*>(p.bias + p.w_pair_rows + n);
+          u += f32x4{bf16lo_to_f32(b2.x), bf16hi_to_f32(b2.x), bf16lo_to_f32(b2.y), bf16hi_to_f32(b2.y)};
+        }
+      }
+      if (EPI == E_F32) {
+        *reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4) = v;
+      } else if (EPI == E_F32_RESID) {
+        f32x4* c = reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4);
+        *c += v;
+      } else if (EPI == E_F32_RESID_GATE) {
+        f32x4* c = reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(p.gate + (int64_t)m * p.ldgate + n);
+        *c += g * v;
+      } else if (EPI == E_BF16 || EPI == E_BF16_GELU) {
+        if (EPI == E_BF16_GELU) v = f32x4{gelu_erf_f(v.x), gelu_erf_f(v.y), gelu_erf_f(v.z), gelu_erf_f(v.w)};
+        *reinterpret_cast<u32x2*>(Cz + ((int64_t)m * p.ldc + n) * 2) = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+      } else {  // E_SWIGLU_SPLIT: y = silu(gate) * up, stored as bf16 hi rows and lo rows
+        float y[4] = {silu_f(v.x) * u.x, silu_f(v.y) * u.y, silu_f(v.z) * u.z, silu_f(v.w) * u.w};
+        bf16_t hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hi[e] = f32_to_bf16(y[e]); lo[e] = f32_to_bf16(y[e] - bf16_to_f32(hi[e])); }
+        bf16_t* c = reinterpret_cast<bf16_t*>(Cz) + (int64_t)m * p.ldc + n;
+        *reinterpret_cast<u32x2*>(c) = u32x2{(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
+        *reinterpret_cast<u32x2*>(c + p.c_lo_off) = u32x2{(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
+      }
+    }
+  }
+}
+
+}  // namespace
+
+static int g_g256_sched = 1;
+extern "C" void mn_gemm256_tune(int sched) { g_g256_sched = sched; }   // A/B hook, not part of the stable ABI
+
+// Generic launcher.  Returns the number of split-K slices used (>= 1) or a negative error.
+static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {
+  const bool hilo = a.a_lo_off != 0, paired = a.w_pair_rows != 0;
+  const int tiles = (int)(mn_cdiv(a.M, hilo ? 128 : 256) * mn_cdiv(a.N, paired ? 128 : 256));
+  G256 p = a;
+  p.Kc = p.K;
+  if (ksplit > 1) p.Kc = (int)(mn_cdiv(mn_cdiv(p.K, ksplit), 2 * BK) * 2 * BK);   // even number of K-tiles per slice
+  const int nz = (int)mn_cdiv(p.K, p.Kc);
+  dim3 grid(tiles, nz);
+#define G256_GO(E)                                                                                             \
+  do {                                                                                                         \
+    if (hilo) {                                                                                                \
+      if (g_g256_sched) hipLaunchKernelGGL((gemm256_kernel<E, 1, true>), grid, dim3(512), 0, st, p);          \
+      else hipLaunchKernelGGL((gemm256_kernel<E, 0, true>), grid, dim3(512), 0, st, p);                       \
+    } else {                                                                                                   \
+      if (g_g256_sched) hipLaunchKernelGGL((gemm256_kernel<E, 1, false>), grid, dim3(512), 0, st, p);         \
+      else hipLaunchKernelGGL((gemm256_kernel<E, 0, false>), grid, dim3(512), 0, st, p);                      \
+    }                                                                                                          \
+  } while (0)
+  switch (epi) {
+    case E_F32: G256_GO(E_F32); break;
+    case E_BF16: G256_GO(E_BF16); break;
+    case E_BF16_GELU: G256_GO(E_BF16_GELU); break;
+    case E_F32_RESID: G256_GO(E_F32_RESID); break;
+    case E_SWIGLU_SPLIT: G256_GO(E_SWIGLU_SPLIT); break;
+    case E_F32_RESID_GATE: G256_GO(E_F32_RESID_GATE); break;
+    default: mn_set_error("gemm256: bad epilogue %d", epi); return MN_EINVAL;
+  }
+#undef G256_GO
+  return nz;
+}
+
+static bool g256_shape_ok(const void* A, int64_t lda, int64_t a_lo_off, const void* W, int64_t ldw, int64_t w_rows, int M, int N,
+                          int K) {
+  // whole K-tiles; 16-byte aligned rows; every per-lane source offset fits 32 bits; 4 output columns per lane
+  return M >= 1 && N >= 4 && (N % 4) == 0 && K >= BK && (K % BK) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && (a_lo_off % 8) == 0 &&
+         (((uintptr_t)A | (uintptr_t)W) & 15) == 0 && ((int64_t)M * lda + a_lo_off) * 2 < ((int64_t)1 << 32) &&
+         w_rows * ldw * 2 < ((int64_t)1 << 32);
+}
+
+extern "C" int mn_gemm256_supported(int64_t lda, int64_t a_lo_off, int64_t ldw, int64_t w_rows, int M, int N, int K) {
+  return g256_shape_ok(nullptr, lda, a_lo_off, nullptr, ldw, w_rows, M, N, K) ? 1 : 0;
+}
+
+// C = epilogue(A W^T + bias).  epilogue: MN_GEMM_BF16 / BF16_GELU / F32 / F32_RESID (same enum as mn_gemm_bf16).
+// a_lo_off != 0: A is a bf16 hi/lo pair (lo rows a_lo_off elements after the hi rows), C = (A_hi + A_lo) W^T.
+extern "C" int mn_gemm256(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W, int64_t ldw,
+                          const uint16_t* bias, void* C, int64_t ldc, int M, int N, int K, int epilogue, void* stream) {
+  MN_CHECK_ARG(A && W && C, "mn_gemm256: null pointer");
+  MN_CHECK_ARG(g256_shape_ok(A, lda, a_lo_off, W, ldw, N, M, N, K),
+               "mn_gemm256: unsupported shape M=%d N=%d K=%d (K %% 64 == 0, N %% 4 == 0, 16-byte rows, < 4 GiB operands)", M, N, K);
+  int e;
+  switch (epilogue) {
+    case MN_GEMM_BF16: e = E_BF16; break;
+    case MN_GEMM_BF16_GELU: e = E_BF16_GELU; break;
+    case MN_GEMM_F32: e = E_F32; break;
+    case MN_GEMM_F32_RESID: e = E_F32_RESID; break;
+    default: mn_set_error("mn_gemm256: bad epilogue %d", epilogue); return MN_EINVAL;
+  }
+  G256 p{};
+  p.A = A; p.lda = lda; p.a_lo_off = a_lo_off; p.W = W; p.ldw = ldw; p.bias = bias; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K;
+  const int rc = g256_launch(p, e, 1, mn_stream(stream));
+  if (rc < 0) return rc;
+  MN_CHECK_LAUNCH("mn_gemm256");
+  return MN_OK;
+}
+
+// Split-K form: slice z writes the fp32 partial product (bias in slice 0) to partials + z * M * N (ldc = N).
+// Returns the number of slices used.
+extern "C" int mn_gemm256_splitk(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W, int64_t ldw,
+                                 const uint16_t* bias, float* partials, int M, int N, int K, int ksplit, void* stream) {
+  MN_CHECK_ARG(A && W && partials && ksplit >= 1, "mn_gemm256_splitk: bad args");
+  MN_CHECK_ARG(g256_shape_ok(A, lda, a_lo_off, W, ldw, N, M, N, K), "mn_gemm256_splitk: unsupported shape M=%d N=%d K=%d", M, N, K);
+  G256 p{};
+  p.A = A; p.lda = lda; p.a_lo_off = a_lo_off; p.W = W; p.ldw = ldw; p.bias = bias; p.C = partials; p.ldc = N;
+  p.c_zstride = (int64_t)M * N; p.M = M; p.N = N; p.K = K;
+  const int nz = g256_launch(p, E_F32, ksplit, mn_stream(stream));
+  if (nz < 0) return nz;
+  MN_CHECK_LAUNCH("mn_gemm256_splitk");
+  return nz;
+}
+
+// SwiGLU-fused form (swiglu_ffn.py:30-34; diff_loss_rf_swiglu.py:54-72): W12 bf16 [2 * hidden, K] (gate rows, then up rows),
+// b12 bf16 [2 * hidden] or NULL; Y bf16: hi rows [M, hidden] at Y, lo rows y_lo_off elements further:
+//   Y_hi + Y_lo = silu(A W_gate^T + b_gate) * (A W_up^T + b_up)   to 2^-17.
+extern "C" int mn_gemm256_swiglu_split(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W12, int64_t ldw,
+                                       const uint16_t* b12, uint16_t* Y, int64_t ldy, int64_t y_lo_off, int M, int hidden,
+                                       int K, void* stream) {
+  MN_CHECK_ARG(A && W12 && Y && y_lo_off > 0, "mn_gemm256_swiglu_split: bad args");
+  MN_CHECK_ARG(g256_shape_ok(A, lda, a_lo_off, W12, ldw, 2 * (int64_t)hidden, M, hidden, K) && (ldy % 4) == 0 && (y_lo_off % 4) == 0,
+               "mn_gemm256_swiglu_split: unsupported shape M=%d hidden=%d K=%d", M, hidden, K);
+  G256 p{};
+  p.A = A; p.lda = lda; p.a_lo_off = a_lo_off; p.W = W12; p.ldw = ldw; p.w_pair_rows = hidden; p.bias = b12;
+  p.C = Y; p.ldc = ldy; p.c_lo_off = y_lo_off; p.M = M; p.N = hidden; p.K = K;
+  const int rc = g256_launch(p, E_SWIGLU_SPLIT, 1, mn_stream(stream));
+  if (rc < 0) return rc;
+  MN_CHECK_LAUNCH("mn_gemm256_swiglu_split");
+  return MN_OK;
+}
