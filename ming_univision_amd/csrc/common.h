@@ -83,3 +83,22 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 
 static inline hipStream_t mn_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t mn_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+
+// ---- internal argument block of the wide-row GEMM (gemm256.hip), shared with the composites in engine.hip ----
+typedef struct mn_g256 {
+  const bf16_t* A; int64_t lda; int64_t a_lo_off;       // a_lo_off (elements) != 0: hi/lo-stacked rows
+  const bf16_t* W; int64_t ldw; int64_t w_pair_rows;    // w_pair_rows != 0: gate/up pairing (SWIGLU_SPLIT), N counts hidden units
+  const bf16_t* bias;                                    // bf16 [N] (paired: gate bias at n, up bias at n + w_pair_rows) or NULL
+  void* C; int64_t ldc; int64_t c_zstride;               // split-K: slice z writes C + z * c_zstride (F32 epilogue)
+  int64_t c_lo_off;                                      // SWIGLU_SPLIT: lo rows c_lo_off elements after the hi rows
+  const float* gate; int64_t ldgate;                     // F32_RESID_GATE: C += gate * (acc + bias)
+  int M, N, K, Kc;                                       // Kc is set by the launcher (k per split-K slice)
+  // grouped form: group g = blockIdx.z owns rows [g_off[g], g_off[g] + g_cnt[g]) (device arrays), weights W + g * w_gstride;
+  // a_rows (optional) maps a row position to its source row in A (gather); M bounds every group's row count
+  const int32_t* g_off; const int32_t* g_cnt; int64_t w_gstride; const int32_t* a_rows; int n_groups;
+} mn_g256;
+enum { MN_G256_F32 = 0, MN_G256_BF16 = 1, MN_G256_BF16_GELU = 2, MN_G256_F32_RESID = 3, MN_G256_SWIGLU_SPLIT = 4,
+       MN_G256_F32_RESID_GATE = 5 };
+extern "C" int mn_gemm256_ex(const mn_g256* a, int epi, int ksplit, void* stream);
+extern "C" int mn_gemm256_slices(int K, int ksplit);

@@ -322,6 +322,9 @@ size_t sk_ws_need(int M, std::initializer_list<std::array<int, 3>> shapes) {   /
 
 }  // namespace
 
+#include "wide_glue.h"
+#include "wide_rf.inl"
+
 // ===========================================================================================
 // Rectified-flow head
 // ===========================================================================================
@@ -360,6 +363,7 @@ static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, floa
 }
 
 extern "C" size_t mn_rf_workspace_bytes(const mn_rf_head* h, int rows) {
+  if (rf_wide_ok(h, rows)) { RfWideWs ww; return rf_wide_carve(h, rows, nullptr, 0, &ww); }
   float *a, *b, *c, *d, *e, *f, *g;
   bf16_t* y;
   unsigned* bar;
@@ -374,9 +378,12 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
                             const float* noise, float temperature, float text_cfg, float image_cfg,
                             float* latent_out, void* workspace, size_t workspace_bytes, void* stream) {
   MN_CHECK_ARG(h && hidden && noise && latent_out && workspace, "mn_rf_sample: null pointer");
-  MN_CHECK_ARG(n_images >= 1 && rows >= n_images && rows % n_images == 0 && rows / n_images <= 3 && rows <= 64,
-               "mn_rf_sample: rows=%d n_images=%d (1..3 CFG rows per image, <= 64 rows)", rows, n_images);
+  MN_CHECK_ARG(n_images >= 1 && rows >= n_images && rows % n_images == 0 && rows / n_images <= 3 && (rows <= 64 || rf_wide_ok(h, rows)),
+               "mn_rf_sample: rows=%d n_images=%d (1..3 CFG rows per image; <= 64 rows, or <= 2048 with 64-aligned widths)", rows, n_images);
   MN_CHECK_ARG(h->target <= 256, "mn_rf_sample: target too large");
+  if (rows > 64)
+    return rf_sample_wide(h, hidden, ld_hidden, rows, n_images, noise, temperature, text_cfg, image_cfg, latent_out, workspace,
+                          workspace_bytes, stream);
   const int rpi = rows / n_images;
   float *z, *c, *ada, *hh, *hid, *v, *x;
   bf16_t* y;

@@ -53,17 +53,10 @@ constexpr int LDS_BYTES = 2 * 2 * 2 * HALF_BYTES;   // [buf][A|W][half] = 128 Ki
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-struct G256 {
-  const bf16_t* A; int64_t lda; int64_t a_lo_off;       // a_lo_off (elements) != 0: hi/lo-stacked rows
-  const bf16_t* W; int64_t ldw; int64_t w_pair_rows;    // w_pair_rows != 0: gate/up pairing, N counts hidden units
-  const bf16_t* bias;                                    // bf16 [N] (paired: [2 * w_pair_rows... ] gate at n, up at n + w_pair_rows) or NULL
-  void* C; int64_t ldc; int64_t c_zstride;               // split-K: slice z writes C + z * c_zstride (fp32 epilogues)
-  int64_t c_lo_off;                                      // SWIGLU_SPLIT / BF16_SPLIT: lo rows c_lo_off elements after the hi rows
-  const float* gate; int64_t ldgate;                     // RESID_GATE: C += gate * (acc + bias)
-  int M, N, K, Kc;                                       // Kc: k per split-K slice (multiple of 64)
-};
+typedef mn_g256 G256;
 
-enum { E_F32 = 0, E_BF16 = 1, E_BF16_GELU = 2, E_F32_RESID = 3, E_SWIGLU_SPLIT = 4, E_F32_RESID_GATE = 5 };
+enum { E_F32 = MN_G256_F32, E_BF16 = MN_G256_BF16, E_BF16_GELU = MN_G256_BF16_GELU, E_F32_RESID = MN_G256_F32_RESID,
+       E_SWIGLU_SPLIT = MN_G256_SWIGLU_SPLIT, E_F32_RESID_GATE = MN_G256_F32_RESID_GATE };
 
 __device__ __forceinline__ int lds_off(int buf, int op, int half) { return ((buf * 2 + op) * 2 + half) * HALF_BYTES; }
 
@@ -94,6 +87,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   }
   const int tm = bid % tiles_m, tn = bid / tiles_m;
   const int m0 = tm * rows_per_tile, n0 = tn * cols_per_tile;
+  // grouped form (MoE experts): blockIdx.z = group g owns rows [g_off[g], g_off[g] + g_cnt[g]) of A (through a_rows when
+  // given: a gather by index while staging) and of C, and the weights W + g * w_gstride; p.M bounds every group
+  int Mg = p.M, row0 = 0;
+  if (p.g_off) {
+    const int g = blockIdx.z;
+    row0 = p.g_off[g];
+    Mg = p.g_cnt[g];
+    if (m0 >= Mg) return;                      // uniform per workgroup
+  }
   const int kbeg = blockIdx.y * p.Kc, kend = min(p.K, kbeg + p.Kc);
   const int nk = (kend - kbeg) / BK;
 
@@ -111,7 +113,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
         int gm, gn;
         if (hilo) gm = m0 + L;                                      // half = hi / lo part of the same rows
         else gm = m0 + (L >> 6) * 128 + h * 64 + (L & 63);          // wave row L / 64, fragment half h
-        gm = min(gm, p.M - 1);
+        gm = row0 + min(gm, Mg - 1);
+        if (p.a_rows) gm = p.a_rows[gm];
         if (paired) gn = min(n0 + L, p.N - 1) + (h ? (int)p.w_pair_rows : 0);
         else gn = min(n0 + (L >> 5) * 64 + h * 32 + (L & 31), p.N - 1);
         srcA[h][q] = (uint32_t)(((int64_t)gm * p.lda + (hilo && h ? p.a_lo_off : 0) + kbeg) * 2 + ks);
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
       }
   }
   const char* Ab = reinterpret_cast<const char*>(p.A);
-  const char* Wb = reinterpret_cast<const char*>(p.W);
+  const char* Wb = reinterpret_cast<const char*>(p.W) + (p.g_off ? (int64_t)blockIdx.z * p.w_gstride * 2 : 0);
   auto stage = [&](int op, int h, int kt, int buf) {   // op 0 = A, 1 = W; all arguments compile-time or wave-uniform
     char* dst = &lds[lds_off(buf, op, h) + wave * 2048];
     const uint32_t koff = (uint32_t)kt * (BK * 2);
@@ -240,11 +243,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   if (EPI == E_F32) Cz += (int64_t)blockIdx.y * p.c_zstride * 4;
 #pragma unroll
   for (int i = 0; i < mi_n; ++i) {
-    const int m = hilo ? m0 + wr * 64 + i * 16 + fr : m0 + wr * 128 + i * 16 + fr;
+    const int ml = hilo ? m0 + wr * 64 + i * 16 + fr : m0 + wr * 128 + i * 16 + fr;
+    const int m = row0 + ml;
 #pragma unroll
     for (int j = 0; j < nj_n; ++j) {
       const int n = paired ? n0 + wc * 32 + j * 16 + fq * 4 : n0 + wc * 64 + j * 16 + fq * 4;
-      if (m >= p.M || n >= p.N) continue;         // N % 4 == 0 (host check): a lane's 4 columns are all in or all out
+      if (ml >= Mg || n >= p.N) continue;         // N % 4 == 0 (host check): a lane's 4 columns are all in or all out
       f32x4 v = acc[i][j];
       if (hilo) v += acc[(i + 4) & 7][j];
       f32x4 u = {0.f, 0.f, 0.f, 0.f};
@@ -295,7 +299,7 @@ static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {
   p.Kc = p.K;
   if (ksplit > 1) p.Kc = (int)(mn_cdiv(mn_cdiv(p.K, ksplit), 2 * BK) * 2 * BK);   // even number of K-tiles per slice
   const int nz = (int)mn_cdiv(p.K, p.Kc);
-  dim3 grid(tiles, nz);
+  dim3 grid(tiles, nz, a.g_off ? a.n_groups : 1);
 #define G256_GO(E)                                                                                             \
   do {                                                                                                         \
     if (hilo) {                                                                                                \
@@ -317,6 +321,21 @@ static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {
   }
 #undef G256_GO
   return nz;
+}
+
+// Internal generic entry (engine.hip): any combination of hi/lo rows, gate/up pairing, groups, split-K.
+extern "C" int mn_gemm256_ex(const mn_g256* a, int epi, int ksplit, void* stream) {
+  const int nz = g256_launch(*a, epi, ksplit, mn_stream(stream));
+  if (nz < 0) return nz;
+  MN_CHECK_LAUNCH("mn_gemm256_ex");
+  return nz;
+}
+
+// slices mn_gemm256_ex will use for a ksplit request (whole pairs of K-tiles per slice)
+extern "C" int mn_gemm256_slices(int K, int ksplit) {
+  if (ksplit <= 1) return 1;
+  const int Kc = (int)(mn_cdiv(mn_cdiv(K, ksplit), 2 * BK) * 2 * BK);
+  return (int)mn_cdiv(K, Kc);
 }
 
 static bool g256_shape_ok(const void* A, int64_t lda, int64_t a_lo_off, const void* W, int64_t ldw, int64_t w_rows, int M, int N,

@@ -1,0 +1,136 @@
+// wide_glue.h — the row kernel between two wide-row GEMMs (gemm256.hip) of the lock-step generation path.
+//
+// With hundreds of rows in flight every nn.Linear of the decode path is a gemm256 launch whose operand is a bf16 hi/lo
+// pair; everything the reference does between two Linears (residual adds, gated residuals, RMSNorm / LayerNorm, adaLN
+// modulate, the MoE weighted combine, the input projection of the RF net) is ONE launch of this kernel: one workgroup
+// per row, 4 columns per thread, row statistics by a block reduction, output as fp32 and / or as the next GEMM's
+// hi/lo operand.  Call sites cite the reference lines they replace.
+#pragma once
+#include "common.h"
+
+struct WideGlue {
+  // ---- source value v[m, :] ----
+  const float* h; int64_t ldh;                         // residual stream row (used when neither x nor xin is given)
+  const float* x; int64_t ldx; int x_row_div;          // v = x[(m / x_row_div) * ldx]        (stack input; ldx 0 broadcasts)
+  const float* xin; int kin; const bf16_t* win; const bf16_t* bin;   // v = bin + xin[m, :kin] · win[n, :kin]   (kin <= 64)
+  // ---- accumulate ----
+  const float* P; int nz; int64_t slab; const bf16_t* pbias;         // y = sum_z P[z * slab + m * D + :] (+ pbias)
+  const float* gate; int64_t ldgate;                                  // v += gate[m] * y   (else v += y)
+  const float* cy; const int32_t* cpos; const float* cw; int n_slot;  // v += sum_s cw[m, s] * cy[cpos[m, s] * D + :]
+  float* h_out; int64_t ldho;                          // store the updated stream (may alias h), or NULL
+  // ---- normalise + modulate ----
+  int norm;                                            // 0 none, 1 RMSNorm(ng), 2 LayerNorm(ng?, nb?)
+  const bf16_t* ng; const bf16_t* nb; float eps;
+  const float* scale; const float* shift; int64_t ldmod;              // v = v * (1 + scale[m]) + shift[m]   (both or neither)
+  // ---- outputs ----
+  float* out; int64_t ldo;                             // fp32 result, or NULL
+  bf16_t* Y; int64_t ldy; int64_t y_lo_off;            // bf16 hi rows at Y, lo rows y_lo_off elements further, or NULL
+  int M, D;
+};
+
+namespace {
+
+__global__ __launch_bounds__(1024) void wide_glue_kernel(const WideGlue p) {
+  __shared__ float red[32];
+  __shared__ float xs[64];
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  const int m = blockIdx.x, col = threadIdx.x * 4, D = p.D;
+  const bool act = col < D;
+  if (p.xin) {                                           // stage the row of the tiny-K projection
+    if (threadIdx.x < p.kin) xs[threadIdx.x] = p.xin[(int64_t)m * p.kin + threadIdx.x];
+    __syncthreads();
+  }
+  f4 v = {0.f, 0.f, 0.f, 0.f};
+  if (act) {
+    if (p.xin) {
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = p.bin ? bf16_to_f32(p.bin[col + j]) : 0.f;
+        const bf16_t* wr = p.win + (int64_t)(col + j) * p.kin;
+        for (int k = 0; k < p.kin; ++k) a = fmaf(bf16_to_f32(wr[k]), xs[k], a);
+        o[j] = a;
+      }
+      v = f4{o[0], o[1], o[2], o[3]};
+    } else if (p.x) {
+      v = *reinterpret_cast<const f4*>(p.x + (int64_t)(m / p.x_row_div) * p.ldx + col);
+    } else {
+      v = *reinterpret_cast<const f4*>(p.h + (int64_t)m * p.ldh + col);
+    }
+    if (p.P) {
+      f4 y = {0.f, 0.f, 0.f, 0.f};
+      if (p.pbias) y = f4{bf16_to_f32(p.pbias[col]), bf16_to_f32(p.pbias[col + 1]), bf16_to_f32(p.pbias[col + 2]), bf16_to_f32(p.pbias[col + 3])};
+      const float* pp = p.P + (int64_t)m * D + col;
+      int z = 0;
+      for (; z + 4 <= p.nz; z += 4) {                    // independent 16-byte loads in flight
+        const f4 a = *reinterpret_cast<const f4*>(pp + (z + 0) * p.slab), b = *reinterpret_cast<const f4*>(pp + (z + 1) * p.slab);
+        const f4 c = *reinterpret_cast<const f4*>(pp + (z + 2) * p.slab), d = *reinterpret_cast<const f4*>(pp + (z + 3) * p.slab);
+        y += (a + b) + (c + d);
+      }
+      for (; z < p.nz; ++z) y += *reinterpret_cast<const f4*>(pp + z * p.slab);
+      if (p.gate) v += *reinterpret_cast<const f4*>(p.gate + (int64_t)m * p.ldgate + col) * y;
+      else v += y;
+    }
+    if (p.cy) {
+      for (int s = 0; s < p.n_slot; s += 4) {            // four slots of independent loads in flight
+        f4 y[4];
+        float wv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int sj = s + j < p.n_slot ? s + j : s;
+          y[j] = *reinterpret_cast<const f4*>(p.cy + (int64_t)p.cpos[(int64_t)m * p.n_slot + sj] * D + col);
+          wv[j] = s + j < p.n_slot ? p.cw[(int64_t)m * p.n_slot + sj] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v += wv[j] * y[j];
+      }
+    }
+    if (p.h_out) *reinterpret_cast<f4*>(p.h_out + (int64_t)m * p.ldho + col) = v;
+  }
+  if (p.norm == 1) {
+    const float ss = block_sum(act ? v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w : 0.f, red);
+    const float rstd = rsqrtf(ss / (float)D + p.eps);
+    if (act) v = f4{v.x * rstd * bf16_to_f32(p.ng[col]), v.y * rstd * bf16_to_f32(p.ng[col + 1]),
+                    v.z * rstd * bf16_to_f32(p.ng[col + 2]), v.w * rstd * bf16_to_f32(p.ng[col + 3])};
+  } else if (p.norm == 2) {
+    const float mean = block_sum(act ? (v.x + v.y) + (v.z + v.w) : 0.f, red) / (float)D;
+    float ss = 0.f;
+    if (act) { const f4 d = v - mean; ss = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w; }
+    const float rstd = rsqrtf(block_sum(ss, red) / (float)D + p.eps);
+    if (act) {
+      float o[4] = {(v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (p.ng) o[j] *= bf16_to_f32(p.ng[col + j]);
+        if (p.nb) o[j] += bf16_to_f32(p.nb[col + j]);
+      }
+      v = f4{o[0], o[1], o[2], o[3]};
+    }
+  }
+  if (!act) return;
+  if (p.scale) {
+    const f4 sc = *reinterpret_cast<const f4*>(p.scale + (int64_t)m * p.ldmod + col);
+    const f4 sh = *reinterpret_cast<const f4*>(p.shift + (int64_t)m * p.ldmod + col);
+    v = v * (1.0f + sc) + sh;
+  }
+  if (p.out) *reinterpret_cast<f4*>(p.out + (int64_t)m * p.ldo + col) = v;
+  if (p.Y) {
+    const float o[4] = {v.x, v.y, v.z, v.w};
+    bf16_t hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { hi[j] = f32_to_bf16(o[j]); lo[j] = f32_to_bf16(o[j] - bf16_to_f32(hi[j])); }
+    bf16_t* yr = p.Y + (int64_t)m * p.ldy + col;
+    *reinterpret_cast<u2*>(yr) = u2{(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
+    *reinterpret_cast<u2*>(yr + p.y_lo_off) = u2{(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
+  }
+}
+
+inline bool wide_glue_ok(int D) { return D >= 4 && (D % 4) == 0 && D <= 4096; }
+
+inline void wide_glue(const WideGlue& g, hipStream_t st) {
+  const int threads = ((g.D / 4 + 63) / 64) * 64;
+  hipLaunchKernelGGL(wide_glue_kernel, dim3(g.M), dim3(threads), 0, st, g);
+}
+
+}  // namespace

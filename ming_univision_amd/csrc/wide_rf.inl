@@ -1,0 +1,141 @@
+// wide_rf.inl — RectifiedFlowLoss.sample (diff_loss_rf_swiglu.py:103-181) for 65..2048 CFG rows advancing in lock-step
+// (textually part of engine.hip).  Same arithmetic as the <= 64-row route of mn_rf_sample; at this width the launches are
+// MFMA-bound, so every Linear is a gemm256 launch on bf16 hi/lo operands (fp32-class products) and the work between two
+// Linears is one wide_glue launch:
+//
+//   per visual token   vis_head Linear -> LayerNorm -> cond_embed           (modeling_bailing_moe.py:1571-1574, diff_loss:374)
+//                      adaLN projections of all Euler steps as ONE GEMM     (diff_loss:263-266, 283-286)
+//   per Euler step     [input_proj + in_ln + modulate]                      (diff_loss:371, 270)
+//     per ResBlock     w12 GEMM with SwiGLU + hi/lo split in the epilogue   (diff_loss:54-72)
+//                      w3 GEMM, split-K partial slabs
+//                      [slab reduce + b3 + gated residual + next in_ln / final LN + modulate]   (diff_loss:270-272, 290)
+//                      final Linear (split-K) -> bias -> CFG combine + Euler step              (diff_loss:144-179, 291)
+struct RfWideWs {
+  float *z, *c, *ada, *hh, *v, *x, *pbuf;
+  bf16_t *hs, *zs, *y, *ya, *yb;
+  int ks3, ksf;          // split-K requests of the w3 and final GEMMs
+};
+
+static int rf_wide_ksplit(int rows, int N, int K) {   // fill ~256 CUs with (row tiles x column tiles x K slices)
+  const int tiles = (int)(mn_cdiv(rows, 128) * mn_cdiv(N, 256));
+  int ks = 256 / tiles;
+  const int kt = K / 64;
+  if (ks > kt / 4) ks = kt / 4;                        // >= 4 K-tiles per slice
+  return ks < 1 ? 1 : ks;
+}
+
+static size_t rf_wide_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, RfWideWs* o) {
+  Carver cv(ws, cap, ws == nullptr);
+  const int64_t SR = (int64_t)h->steps * rows;
+  const int A = h->depth * 3 * h->w + 2 * h->w;
+  o->ks3 = rf_wide_ksplit(rows, h->w, h->hidden);
+  o->ksf = rf_wide_ksplit(rows, h->target, h->w);
+  const size_t p3 = (size_t)mn_gemm256_slices(h->hidden, o->ks3) * rows * h->w;
+  const size_t pf = (size_t)mn_gemm256_slices(h->w, o->ksf) * rows * h->target;
+  o->z = cv.take<float>((size_t)rows * h->z_dim);
+  o->c = cv.take<float>((size_t)rows * h->w);
+  o->ada = cv.take<float>((size_t)SR * A);
+  o->hh = cv.take<float>((size_t)rows * h->w);
+  o->v = cv.take<float>((size_t)rows * h->target);
+  o->x = cv.take<float>((size_t)rows * h->target);
+  o->pbuf = cv.take<float>(p3 > pf ? p3 : pf);
+  o->hs = cv.take<bf16_t>((size_t)2 * rows * h->llm_hidden);
+  o->zs = cv.take<bf16_t>((size_t)2 * rows * h->z_dim);
+  o->y = cv.take<bf16_t>((size_t)2 * SR * h->w);
+  o->ya = cv.take<bf16_t>((size_t)2 * rows * h->w);
+  o->yb = cv.take<bf16_t>((size_t)2 * rows * h->hidden);
+  return cv.off;
+}
+
+static bool rf_wide_ok(const mn_rf_head* h, int rows) {
+  return rows > 64 && rows <= 2048 && wide_glue_ok(h->w) && wide_glue_ok(h->z_dim) && wide_glue_ok(h->llm_hidden) &&
+         (h->w % 64) == 0 && (h->hidden % 64) == 0 && (h->z_dim % 64) == 0 && (h->llm_hidden % 64) == 0 && h->target <= 64 &&
+         (h->target % 4) == 0;
+}
+
+static mn_g256 g256_hilo(const bf16_t* A, int64_t lda, int64_t lo_off, const bf16_t* W, int64_t ldw, const bf16_t* bias, void* C,
+                         int64_t ldc, int M, int N, int K) {
+  mn_g256 a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.a_lo_off = lo_off; a.W = W; a.ldw = ldw; a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  return a;
+}
+
+#define MN_TRYZ(expr)            \
+  do {                           \
+    int rc__ = (expr);           \
+    if (rc__ < 0) return rc__;   \
+  } while (0)
+
+static int rf_sample_wide(const mn_rf_head* h, const float* hidden, int64_t ld_hidden, int rows, int n_images, const float* noise,
+                          float temperature, float text_cfg, float image_cfg, float* latent_out, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  RfWideWs w;
+  const size_t need = rf_wide_carve(h, rows, workspace, workspace_bytes, &w);
+  if (need > workspace_bytes) { mn_set_error("mn_rf_sample: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
+  hipStream_t st = mn_stream(stream);
+  const int W = h->w, HID = h->hidden, T = h->target, A = h->depth * 3 * W + 2 * W, rpi = rows / n_images;
+  const int64_t SR = (int64_t)h->steps * rows;
+
+  // z = vis_head Linear(hidden);  c = cond_embed(LayerNorm(z))
+  WideGlue g;
+  memset(&g, 0, sizeof(g));
+  g.h = hidden; g.ldh = ld_hidden; g.Y = w.hs; g.ldy = h->llm_hidden; g.y_lo_off = (int64_t)rows * h->llm_hidden;
+  g.M = rows; g.D = h->llm_hidden;
+  wide_glue(g, st);
+  mn_g256 a = g256_hilo(w.hs, h->llm_hidden, (int64_t)rows * h->llm_hidden, h->vis_w, h->llm_hidden, h->vis_b, w.z, h->z_dim, rows,
+                        h->z_dim, h->llm_hidden);
+  MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
+  memset(&g, 0, sizeof(g));
+  g.h = w.z; g.ldh = h->z_dim; g.norm = 2; g.ng = h->vis_ln_g; g.nb = h->vis_ln_b; g.eps = 1e-6f;
+  g.Y = w.zs; g.ldy = h->z_dim; g.y_lo_off = (int64_t)rows * h->z_dim; g.M = rows; g.D = h->z_dim;
+  wide_glue(g, st);
+  a = g256_hilo(w.zs, h->z_dim, (int64_t)rows * h->z_dim, h->cond_w, h->z_dim, h->cond_b, w.c, W, rows, W, h->z_dim);
+  MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
+
+  hipLaunchKernelGGL(rf_init_x_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, noise, temperature, w.x, rows, T, rpi);
+  // modulations of every Euler step: [steps * rows, w] x [w, depth*3w + 2w], adaLN weights read once per token
+  hipLaunchKernelGGL(rf_build_y_kernel, dim3(mn_cdiv(SR * W, 256)), dim3(256), 0, st, h->temb, w.c, w.y, h->steps, rows, W);
+  a = g256_hilo(w.y, W, SR * W, h->ada_w, W, h->ada_b, w.ada, A, (int)SR, A, W);
+  MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
+
+  const float step = 1.0f / (float)h->steps;
+  const int64_t lo_a = (int64_t)rows * W, lo_b = (int64_t)rows * HID;
+  for (int s = 0; s < h->steps; ++s) {
+    const float* ada = w.ada + (int64_t)s * rows * A;
+    // h = input_proj(x); ya = split(in_ln_0(h) * (1 + scale_0) + shift_0)
+    memset(&g, 0, sizeof(g));
+    g.xin = w.x; g.kin = T; g.win = h->in_w; g.bin = h->in_b; g.h_out = w.hh; g.ldho = W;
+    g.norm = 2; g.ng = h->ln_g[0]; g.nb = h->ln_b[0]; g.eps = 1e-6f; g.shift = ada; g.scale = ada + W; g.ldmod = A;
+    g.Y = w.ya; g.ldy = W; g.y_lo_off = lo_a; g.M = rows; g.D = W;
+    wide_glue(g, st);
+    for (int b = 0; b < h->depth; ++b) {
+      const float* mod = ada + (int64_t)b * 3 * W;
+      a = g256_hilo(w.ya, W, lo_a, h->w12[b], W, h->b12[b], w.yb, HID, rows, HID, W);
+      a.w_pair_rows = HID; a.c_lo_off = lo_b;
+      MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
+      a = g256_hilo(w.yb, HID, lo_b, h->w3[b], HID, nullptr, w.pbuf, W, rows, W, HID);
+      a.c_zstride = (int64_t)rows * W;
+      const int nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks3, stream);
+      if (nz < 0) return nz;
+      const bool last = b + 1 == h->depth;
+      const float* nmod = last ? ada + (int64_t)h->depth * 3 * W : ada + (int64_t)(b + 1) * 3 * W;
+      memset(&g, 0, sizeof(g));
+      g.h = w.hh; g.ldh = W; g.P = w.pbuf; g.nz = nz; g.slab = (int64_t)rows * W; g.pbias = h->b3[b];
+      g.gate = mod + 2 * W; g.ldgate = A; g.h_out = w.hh; g.ldho = W;
+      g.norm = 2; g.ng = last ? nullptr : h->ln_g[b + 1]; g.nb = last ? nullptr : h->ln_b[b + 1]; g.eps = 1e-6f;
+      g.shift = nmod; g.scale = nmod + W; g.ldmod = A;
+      g.Y = w.ya; g.ldy = W; g.y_lo_off = lo_a; g.M = rows; g.D = W;
+      wide_glue(g, st);
+    }
+    a = g256_hilo(w.ya, W, lo_a, h->fin_w, W, nullptr, w.pbuf, T, rows, T, W);
+    a.c_zstride = (int64_t)rows * T;
+    const int nz = mn_gemm256_ex(&a, MN_G256_F32, w.ksf, stream);
+    if (nz < 0) return nz;
+    hipLaunchKernelGGL(rf_glue_bias_out_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, w.pbuf, nz, rows, T, h->fin_b, w.v);
+    hipLaunchKernelGGL(rf_euler_kernel, dim3(n_images), dim3(256), 0, st, w.v, w.x, rpi, T, text_cfg, image_cfg, step);
+  }
+  hipLaunchKernelGGL(rf_gather_latent_kernel, dim3(mn_cdiv(n_images * T, 256)), dim3(256), 0, st, w.x, latent_out, n_images, rpi, T);
+  MN_CHECK_LAUNCH("mn_rf_sample(wide)");
+  return MN_OK;
+}
