@@ -360,6 +360,11 @@ typedef struct mn_semdec {
   const uint16_t* const* w3;    const uint16_t* const* b3;
   const uint16_t *norm_g, *norm_b;
   const uint16_t* const* proj_w; const uint16_t* const* proj_b;  /* [proj_depth] linear_proj layers */
+  /* Wide-row route (M > 64, optional; NULL arrays = route unavailable): the SwiGLU hidden width zero-padded to a
+   * multiple of 64 (hidden_pad): w12p [2*hidden_pad, dim] (gate rows, zero rows, up rows, zero rows), b12p [2*hidden_pad],
+   * w3p [dim, hidden_pad] (zero columns) — load-time copies, results unchanged. */
+  int32_t hidden_pad;
+  const uint16_t* const* w12p; const uint16_t* const* b12p; const uint16_t* const* w3p;
 } mn_semdec;
 
 size_t mn_semdec_workspace_bytes(const mn_semdec* s, int rows, int64_t t_max);

@@ -81,6 +81,7 @@ class SemDec(C.Structure):
         ("ln2_g", PP), ("ln2_b", PP), ("w12", PP), ("b12", PP), ("w3", PP), ("b3", PP),
         ("norm_g", C.c_void_p), ("norm_b", C.c_void_p),
         ("proj_w", PP), ("proj_b", PP),
+        ("hidden_pad", C.c_int32), ("w12p", PP), ("b12p", PP), ("w3p", PP),
     ]
 
 

@@ -52,7 +52,8 @@ def pack_experts(sd, prefix, cfg):
     return gu, dn
 
 
-MAX_ROWS = 64   # rows of one pass through the decode kernels (four 16-row MFMA tiles)
+MAX_ROWS = 64        # rows of one pass through the weight-streaming decode kernels (four 16-row MFMA tiles)
+MAX_ROWS_WIDE = 2048 # rows of one pass through the wide route (every Linear a 256 x 256-tile MFMA GEMM on hi/lo operands)
 
 
 class BailingMoeDecoder:
@@ -161,7 +162,7 @@ class BailingMoeDecoder:
 
     def step(self, x, row_seq, row_slot, row_pos, row_len, key_mask=None, image_mask=None, out=None, rows=None,
              x_row_div=1):
-        """One pass of the 28-layer stack over M <= 64 rows.
+        """One pass of the 28-layer stack over M <= 64 rows (weight-streaming kernels) or 65..2048 rows (wide route).
         x fp32 [M,H]; or [1,H] with rows=M to broadcast; or [M / x_row_div, H] with rows=M when the x_row_div CFG
         rows of an image share one embedding.  int32 device arrays per row; key_mask uint8 [M, >=len].
         Returns the post-final-norm hidden states [M,H] fp32."""
@@ -408,7 +409,8 @@ def generate_images(dec: BailingMoeDecoder, rf, tok, start_embed, past_lens, att
     n_tok = cfg.num_image_tokens_for_gen
     assert 1 <= n_groups <= B
     per = (B + n_groups - 1) // n_groups                     # images per group
-    assert max(past_lens) + n_tok + 1 <= dec.t_max and per * rpi <= MAX_ROWS
+    n_groups = (B + per - 1) // per                          # e.g. 5 images in 4 groups -> 3 groups of 2 + 2 + 1, no empty group
+    assert max(past_lens) + n_tok + 1 <= dec.t_max and per * rpi <= MAX_ROWS_WIDE
     if rpi > 1:   # replicate each prompt's KV to its CFG rows (:1891-1902) — device memcpy
         for i, past in enumerate(past_lens):
             for r in range(1, rpi):

@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void attn_prefill_hd64_kernel(const bf16_t* __
     }
   }
   if (q_idx < T) {
-    const float inv = 1.0f / l_run;
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;   // no attended key: 0, not NaN
     bf16_t* op = out + ((int64_t)b * T + q_idx) * (nh * 64) + h * 64;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {

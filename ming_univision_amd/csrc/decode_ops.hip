@@ -275,7 +275,7 @@ __global__ void attn_decode_combine_kernel(const float* __restrict__ partial, in
     l = fmaf(f, p[s * (HD + 2) + HD + 1], l);
     acc = fmaf(f, p[s * (HD + 2) + d], acc);
   }
-  const float v = acc / l;
+  const float v = l > 0.f ? acc / l : 0.f;     // a row with no attended key yields 0, not NaN (precondition: see mingnative.h)
   const int64_t o = ((int64_t)m * n_q + h) * HD + d;
   if (out) out[o] = v;
   if (split) {
@@ -285,11 +285,22 @@ __global__ void attn_decode_combine_kernel(const float* __restrict__ partial, in
   }
 }
 
-extern "C" size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t t_max) {
+// Key-range splits (flash-decoding): enough workgroups to fill the chip at few rows, none needed at hundreds of rows;
+// one split never holds more than 4096 keys (its scores live in LDS).
+static int attn_splits(int M, int n_q, int64_t t_max) {
   int S = (int)mn_cdiv(t_max, 32);
   if (S > 32) S = 32;
+  const int64_t blocks = (int64_t)M * ((n_q + 3) / 4);
+  const int want = (int)mn_cdiv(2048, blocks);
+  if (S > want) S = want;
+  const int need = (int)mn_cdiv(t_max, 4096);
+  if (S < need) S = need;
   if (S < 1) S = 1;
-  return (size_t)M * n_q * S * (hd + 2) * sizeof(float);
+  return S;
+}
+
+extern "C" size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t t_max) {
+  return (size_t)M * n_q * attn_splits(M, n_q, t_max) * (hd + 2) * sizeof(float);
 }
 
 // Internal (engine.hip): mn_attn_decode whose output can also (or only) be written as bf16 hi/lo rows.
@@ -299,9 +310,7 @@ extern "C" int mn_attn_decode_split(const float* q, int M, int n_q, int n_kv, in
                                     size_t workspace_bytes, void* stream) {
   MN_CHECK_ARG(M >= 1 && n_q >= 1 && n_kv >= 1 && n_q % n_kv == 0 && (hd == 64 || hd == 128), "mn_attn_decode: bad shape");
   MN_CHECK_ARG(q && kv_cache && row_seq && row_len && (out || split) && workspace, "mn_attn_decode: null pointer");
-  int S = (int)mn_cdiv(t_max, 32);
-  if (S > 32) S = 32;
-  if (S < 1) S = 1;
+  const int S = attn_splits(M, n_q, t_max);
   const size_t need = (size_t)M * n_q * S * (hd + 2) * sizeof(float);
   if (workspace_bytes < need) { mn_set_error("mn_attn_decode: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
   int chunk_cap = (int)mn_cdiv(t_max, S);

@@ -283,7 +283,7 @@ __global__ void copy_rows_f32_kernel(const float* __restrict__ a, int64_t lda, i
 }
 
 __global__ void rows_advance_kernel(int32_t* a, int32_t* b, int32_t* c, int M, int delta) {
-  const int i = threadIdx.x;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < M) {
     if (a) a[i] += delta;
     if (b) b[i] += delta;
@@ -668,6 +668,8 @@ __global__ __launch_bounds__(1024) void moe_route_group_kernel(const float* __re
   }
 }
 
+#include "wide_llm.inl"
+
 struct MoeWs {
   int32_t *off, *xrows, *pair_pos;
   bf16_t *y1, *y2;
@@ -750,13 +752,14 @@ static size_t llm_carve(const mn_llm* m, int rows, int64_t t_max, void* ws, size
 }
 
 extern "C" size_t mn_llm_workspace_bytes(const mn_llm* m, int rows, int64_t t_max) {
+  if (llm_wide_ok(m, rows)) { LlmWideWs ww; return llm_wide_carve(m, rows, t_max, nullptr, 0, &ww); }
   LlmWs w{};
   return llm_carve(m, rows, t_max, nullptr, 0, &w);
 }
 
 extern "C" int mn_rows_advance(int32_t* a, int32_t* b, int32_t* c, int M, int delta, void* stream) {
-  MN_CHECK_ARG(M >= 1 && M <= 64, "mn_rows_advance: M=%d", M);
-  hipLaunchKernelGGL(rows_advance_kernel, dim3(1), dim3(64), 0, mn_stream(stream), a, b, c, M, delta);
+  MN_CHECK_ARG(M >= 1, "mn_rows_advance: M=%d", M);
+  hipLaunchKernelGGL(rows_advance_kernel, dim3(mn_cdiv(M, 256)), dim3(256), 0, mn_stream(stream), a, b, c, M, delta);
   MN_CHECK_LAUNCH("mn_rows_advance");
   return MN_OK;
 }
@@ -767,7 +770,13 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
                            float* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
   MN_CHECK_ARG(m && x && row_seq && row_slot && row_pos && row_len && kv_cache && hidden_out && workspace,
                "mn_llm_step: null pointer");
-  MN_CHECK_ARG(M >= 1 && M <= 64 && x_row_div >= 1, "mn_llm_step: M=%d (1..64)", M);
+  MN_CHECK_ARG(M >= 1 && (M <= 64 || llm_wide_ok(m, M)) && x_row_div >= 1,
+               "mn_llm_step: M=%d (1..64, or up to 2048 rows with 64-aligned widths)", M);
+  if (M > 64) {
+    MN_CHECK_ARG(!(image_mask && m->image_gate), "mn_llm_step: the image-gate override is not available above 64 rows");
+    return llm_step_wide(m, x, ldx, x_row_div, M, row_seq, row_slot, row_pos, row_len, key_mask, ld_mask, kv_cache, n_seq, t_max,
+                         hidden_out, workspace, workspace_bytes, stream);
+  }
   LlmWs w{};
   const size_t need = llm_carve(m, M, t_max, workspace, workspace_bytes, &w);
   if (need > workspace_bytes) { mn_set_error("mn_llm_step: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
@@ -925,6 +934,7 @@ static size_t sem_carve(const mn_semdec* s, int rows, int64_t t_max, void* ws, s
 }
 
 extern "C" size_t mn_semdec_workspace_bytes(const mn_semdec* s, int rows, int64_t t_max) {
+  if (sem_wide_ok(s, rows)) { SemWideWs ww; return sem_wide_carve(s, rows, t_max, nullptr, 0, &ww); }
   SemWs w;
   return sem_carve(s, rows, t_max, nullptr, 0, &w);
 }
@@ -934,9 +944,13 @@ extern "C" int mn_semdec_step(const mn_semdec* s, const float* latent_norm, int 
                               int64_t t_max, float* sem_out, float* embed_out, void* workspace,
                               size_t workspace_bytes, void* stream) {
   MN_CHECK_ARG(s && latent_norm && row_seq && row_slot && row_len && kv_cache && workspace, "mn_semdec_step: null pointer");
-  MN_CHECK_ARG(M >= 1 && M <= 64 && s->dim == s->n_heads * 64 && s->dim % s->in_dim == 0, "mn_semdec_step: bad shape");
+  MN_CHECK_ARG(M >= 1 && (M <= 64 || sem_wide_ok(s, M)) && s->dim == s->n_heads * 64 && s->dim % s->in_dim == 0,
+               "mn_semdec_step: bad shape (M = %d: 1..64 rows, or up to 2048 with the padded SwiGLU weights)", M);
 
   MN_CHECK_ARG(!embed_out || (s->proj_depth >= 1 && s->proj_depth <= 2), "mn_semdec_step: proj_depth must be 1 or 2");
+  if (M > 64)
+    return semdec_step_wide(s, latent_norm, M, row_seq, row_slot, row_len, kv_cache, n_seq, t_max, sem_out, embed_out, workspace,
+                            workspace_bytes, stream);
   SemWs w;
   const size_t need = sem_carve(s, M, t_max, workspace, workspace_bytes, &w);
   if (need > workspace_bytes) { mn_set_error("mn_semdec_step: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void attn_prefill_gqa_hd128_kernel(
     }
   }
   if (q_idx < T) {
-    const float inv = 1.0f / l_run;
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;   // no attended key: 0, not NaN
     bf16_t* op = out + ((int64_t)q_idx * n_q + h) * 128;
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) {

@@ -22,6 +22,7 @@ struct WideGlue {
   int norm;                                            // 0 none, 1 RMSNorm(ng), 2 LayerNorm(ng?, nb?)
   const bf16_t* ng; const bf16_t* nb; float eps;
   const float* scale; const float* shift; int64_t ldmod;              // v = v * (1 + scale[m]) + shift[m]   (both or neither)
+  int act;                                             // 1: v = gelu(v) (exact erf form) before the outputs
   // ---- outputs ----
   float* out; int64_t ldo;                             // fp32 result, or NULL
   bf16_t* Y; int64_t ldy; int64_t y_lo_off;            // bf16 hi rows at Y, lo rows y_lo_off elements further, or NULL
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(1024) void wide_glue_kernel(const WideGlue p) {
     const f4 sh = *reinterpret_cast<const f4*>(p.shift + (int64_t)m * p.ldmod + col);
     v = v * (1.0f + sc) + sh;
   }
+  if (p.act == 1) v = f4{gelu_erf_f(v.x), gelu_erf_f(v.y), gelu_erf_f(v.z), gelu_erf_f(v.w)};
   if (p.out) *reinterpret_cast<f4*>(p.out + (int64_t)m * p.ldo + col) = v;
   if (p.Y) {
     const float o[4] = {v.x, v.y, v.z, v.w};

@@ -210,6 +210,24 @@ class MingTok:
         for k, arr in self._sem_arrays.items():
             setattr(s, k, C.cast(arr, _lib.PP))
         s.norm_g, s.norm_b = ptr(self._w("semantic_decoder.norm.weight")), ptr(self._w("semantic_decoder.norm.bias"))
+        # wide-row route (> 64 rows in lock-step): SwiGLU hidden width zero-padded to a multiple of 64 so that w3's K is whole
+        # 64-k tiles — load-time copies, the padded units are silu(0) * 0 = 0 against zero w3 columns
+        hid = s.hidden
+        hp = (hid + 63) // 64 * 64
+        w12p, b12p, w3p = [], [], []
+        for p_ in b:
+            w12, b12, w3 = self._w(p_ + ".mlp.w12.weight"), self._w(p_ + ".mlp.w12.bias"), self._w(p_ + ".mlp.w3.weight")
+            a = torch.zeros(2 * hp, D, dtype=torch.bfloat16, device=self.device)
+            a[:hid], a[hp:hp + hid] = w12[:hid], w12[hid:]
+            bb = torch.zeros(2 * hp, dtype=torch.bfloat16, device=self.device)
+            bb[:hid], bb[hp:hp + hid] = b12[:hid], b12[hid:]
+            c = torch.zeros(D, hp, dtype=torch.bfloat16, device=self.device)
+            c[:, :hid] = w3
+            w12p.append(a); b12p.append(bb); w3p.append(c)
+        self._sem_pad = (w12p, b12p, w3p)
+        self._sem_pad_arrays = tuple(ptr_array(t) for t in self._sem_pad)
+        s.hidden_pad = hp
+        s.w12p, s.b12p, s.w3p = (C.cast(a_, _lib.PP) for a_ in self._sem_pad_arrays)
         if self.linear_proj:
             self._proj_arrays = (ptr_array([w for w, _ in self.linear_proj]), ptr_array([b_ for _, b_ in self.linear_proj]))
             s.proj_w, s.proj_b = C.cast(self._proj_arrays[0], _lib.PP), C.cast(self._proj_arrays[1], _lib.PP)

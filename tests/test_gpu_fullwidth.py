@@ -91,3 +91,18 @@ def test_full_width_generate_image_vs_oracle(full, rows_tag):
                            [tu] * B, nb.cuda(), decode_pixels=False, n_groups=1)
     assert rel_err(outb["latents"][0], ref["latents"][:, 0]) < TOL
     assert rel_err(outb["last_hidden"][:R], ref["last_hidden"][:, 0]) < TOL
+    # the same images on the WIDE route (> 64 rows: every Linear a gemm256 launch on hi/lo operands, grouped-GEMM experts,
+    # one lock-step group): image 0 against the oracle, the images both runs share against the <= 64-row route
+    Bw = 3 * B // 2                                               # 96 / 93 rows (rows2 / rows3)
+    decw = BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=32, n_seq=R * Bw)
+    for i in range(Bw):
+        decw.prefill(decw.embed(ids[0].cuda()), seq=i * R, past=0)
+    nw = torch.cat([nb, torch.randn(Bw - B, cfg.num_image_tokens_for_gen + 1, 32, generator=g)])
+    outw = generate_images(decw, rf, tok, decw.embed(torch.tensor([cfg.image_start_token]).cuda()), [T] * Bw, [am] * Bw, [un] * Bw,
+                           [tu] * Bw, nw.cuda(), decode_pixels=False, n_groups=1)
+    assert torch.isfinite(outw["latents"]).all()
+    assert rel_err(outw["latents"][0], ref["latents"][:, 0]) < TOL
+    assert rel_err(outw["sem"][0], ref["sem"][0]) < TOL
+    assert rel_err(outw["last_hidden"][:R], ref["last_hidden"][:, 0]) < TOL
+    per_img = torch.stack([(outw["latents"][i] - outb["latents"][i]).abs().max() / outb["latents"][i].abs().max() for i in range(B)])
+    assert float(per_img.median()) < 5e-4 and float(per_img.max()) < 5e-3, (float(per_img.median()), float(per_img.max()))
