@@ -25,7 +25,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak (same guide; the 2:1-sparsity figure is never used)
 
 
 def parse():
@@ -95,8 +96,10 @@ def one_image(cfg, dec, rf, tok, prompts, noises, groups=1, cfg_rows=2):
     prompts [B, T] ids, noises [B, n+1, 32]; B images advance in lock-step (B = 1: the reference's call)."""
     from ming_univision_amd.bailing_moe import generate_images
     B, T = prompts.shape
-    for i in range(B):
-        dec.prefill(dec.embed(prompts[i]), seq=cfg_rows * i, past=0)
+    if B == 1:
+        dec.prefill(dec.embed(prompts[0]), seq=0, past=0)
+    else:   # the prompts of the batch prefill in lock-step, many rows per pass through the stack
+        dec.prefill_many(dec.embed(prompts).reshape(B, T, -1), [cfg_rows * i for i in range(B)])
     start = dec.embed(torch.tensor([cfg.image_start_token], device=prompts.device))
     am = torch.ones(1, T + 1, dtype=torch.long)
     unc = torch.ones(1, T + 1, dtype=torch.long)
@@ -174,6 +177,40 @@ def dominant_kernel_roofline_stream(rf, rows, iters=48):
     name = "stream_kloop_kernel<4,2,2,64>" if rows > 32 else "stream_mfma_lds_kernel<%d,1,512>" % (2 if rows > 16 else 1)
     return dict(traffic=traffic, kernel="%s (RF w12: Ntot=2x%d, K=%d, rows=%d)" % (name, hid, w, rows), us=us,
                 bytes=nbytes, gbs=nbytes / us * 1e-3)
+
+
+def dominant_kernel_roofline_wide(rf, rows, iters=48):
+    """Wide route (> 64 rows in lock-step): the dominant kernel is gemm256_kernel<SWIGLU_SPLIT, hi/lo rows> on the RF head's
+    w12 matrices — MFMA-bound.  Timed alone with HIP events on the launch stream, cycling the 12 real matrices.
+    Algorithmic flops = 2 * rows * (2 * hidden) * w (the Linear itself); the kernel issues twice that on the matrix cores
+    because the fp32 activations enter as bf16 hi + lo halves (numerics policy)."""
+    from ming_univision_amd._lib import lib, ptr, current_stream, check
+    dev = rf.t["vis_w"].device
+    w, hid = rf.w, rf.hidden
+    A = (torch.randn(2, rows, w, device=dev) * 0.5).to(torch.bfloat16)
+    A[1] *= 2.0 ** -9
+    Y = torch.empty(2, rows, hid, dtype=torch.bfloat16, device=dev)
+
+    def launch(b):
+        check(lib().mn_gemm256_swiglu_split(ptr(A), w, A.stride(0), ptr(rf.lists["w12"][b]), w, ptr(rf.lists["b12"][b]), ptr(Y),
+                                            hid, Y.stride(0), rows, hid, w, current_stream()), "mn_gemm256_swiglu_split")
+    for b in range(rf.depth):
+        launch(b)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for i in range(iters):
+        launch(i % rf.depth)
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / iters
+    flops = 2.0 * rows * 2 * hid * w
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_gemm256_w12_rows%d.json" % rows)
+    if os.path.exists(pmc) and hid == 8192 and w == 3072:
+        traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+    return dict(traffic=traffic, kernel="gemm256_kernel<SWIGLU_SPLIT,4-phase,hi/lo> (RF w12: N=2x%d, K=%d, rows=%d)" % (hid, w, rows),
+                us=us, flops=flops, tflops=flops / us * 1e-6)
 
 
 def cpu_baseline(args, rows=2):
@@ -269,7 +306,6 @@ def main():
     g = torch.Generator(device=device).manual_seed(grp.seed(1000))     # independent prompt / noise per replica
     prompt = torch.randint(0, min(cfg.vocab_size, 100000), (args.images, args.prompt_len), generator=g, device=device)
     noises = torch.randn(args.images, args.tokens + 1, 32, generator=g, device=device)
-    rows = 2
 
     for _ in range(args.warmup):
         one_image(cfg, dec, rf, tok, prompt, noises, args.groups, args.cfg_rows)
@@ -285,29 +321,38 @@ def main():
                   "ms_per_image": dt1 * 1e3}
 
     if rank == 0:
-        if rows * ((args.images + args.groups - 1) // args.groups) >= 2:   # the matrix-core route (MEDIUM_MIN_M)
-            dom = dominant_kernel_roofline_stream(rf, rows * ((args.images + args.groups - 1) // args.groups))
+        rows = args.cfg_rows
+        per_group = (args.images + args.groups - 1) // args.groups
+        sys.stderr.write("[bench] %d images x %d tokens x %d steps in %.2f s = %.1f visual tokens/s\n"
+                         % (args.images, args.tokens, args.steps, dt, args.tokens * args.steps * world * args.images / dt))
+        if rows * per_group > 64:            # wide route: MFMA-bound GEMMs
+            dom = dominant_kernel_roofline_wide(rf, rows * per_group)
+            roof = {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": dom["tflops"] / MFMA_PEAK_TFLOPS, "traffic": dom["traffic"], "kernel": dom["kernel"],
+                    "flops_per_launch": dom["flops"], "us_per_launch": dom["us"],
+                    "mfma_issued_tflops": 2 * dom["tflops"]}
         else:
-            dom = dominant_kernel_roofline(rf, rows)
+            dom = (dominant_kernel_roofline_stream(rf, rows * per_group) if rows * per_group >= 2   # matrix-core route
+                   else dominant_kernel_roofline(rf, rows))
+            roof = {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": dom["traffic"], "kernel": dom["kernel"],
+                    "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"]}
         total_tokens = args.tokens * args.steps * world * args.images
         res = {
             "metric": "visual tokens/sec (16B-A3B 512^2 gen)", "value": total_tokens / dt, "unit": "visual_tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "Ming-UniVision-16B-A3B text->image 512^2 (BASELINE configs[3]): %d-token prompt, "
-                                   "2 CFG rows, %d visual tokens/image, RF head w=%d d=%d steps=%d, MingTok pixel decode; "
-                                   "random-init bf16 weights" % (args.prompt_len, args.tokens, rf.w, rf.depth, rf.steps),
+                                   "%d CFG rows, %d visual tokens/image, RF head w=%d d=%d steps=%d, MingTok pixel decode; "
+                                   "random-init bf16 weights" % (args.prompt_len, args.cfg_rows, args.tokens, rf.w, rf.depth, rf.steps),
                        "images_per_step_per_gpu": args.images, "stream_groups": args.groups, "parallelism": "replicas x%d" % world, "tiny": bool(args.tiny)},
-            "roofline": {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": dom["traffic"], "kernel": dom["kernel"],
-                         "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"]},
+            "roofline": roof,
             "outputs_finite": finite,
         }
         if batch1 is not None:
             res["batch1"] = batch1
         # whole-token HBM accounting: bytes that must cross HBM per visual token / measured time per token
         ada_bytes = rf.t["ada_w"].numel() * 2          # read once per token (all steps in one GEMM)
-        per_group = (args.images + args.groups - 1) // args.groups
         tok_bytes = (rf.steps * (rf.weight_bytes_per_step() - ada_bytes) + ada_bytes
                      + dec.weight_bytes_active(min(64, 6 * rows * per_group)) + 0.61e9)
         # every group streams the weights once per lock-step token

@@ -306,6 +306,9 @@ typedef struct mn_rf_head {
  * noise [n_images, target] fp32; latent_out [n_images, target] fp32 (all CFG rows of an image carry the same
  * latent).  n_images = 1 is the reference's batch-size-1 call.  Workspace: mn_rf_workspace_bytes(h, rows). */
 size_t mn_rf_workspace_bytes(const mn_rf_head* h, int rows);
+/* Rows one call accepts: 64 (weight-streaming kernels), or 2048 when every width is a multiple of 64 — then calls with more
+ * than 64 rows take the wide route (each Linear a 256 x 256-tile MFMA GEMM on bf16 hi/lo operands, gemm256.hip). */
+int mn_rf_max_rows(const mn_rf_head* h);
 int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld_hidden, int rows, int n_images,
                  const float* noise, float temperature, float text_cfg, float image_cfg, float* latent_out,
                  void* workspace, size_t workspace_bytes, void* stream);
@@ -331,6 +334,7 @@ typedef struct mn_llm {
 } mn_llm;
 
 size_t mn_llm_workspace_bytes(const mn_llm* m, int rows, int64_t t_max);
+int mn_llm_max_rows(const mn_llm* m);      /* 64, or 2048 (wide route: see mn_rf_max_rows; no image-gate override there) */
 /* x fp32 in (embeddings): row m is read from x + (m / x_row_div) * ldx (ldx == 0 broadcasts one row to all M
  * rows; x_row_div = R shares one embedding between the R CFG rows of an image)
  * -> hidden_out [M,H] fp32 (after the final RMSNorm).
@@ -368,6 +372,7 @@ typedef struct mn_semdec {
 } mn_semdec;
 
 size_t mn_semdec_workspace_bytes(const mn_semdec* s, int rows, int64_t t_max);
+int mn_semdec_max_rows(const mn_semdec* s);   /* 64, or 2048 when the padded SwiGLU weights are given */
 /* latent_norm [M, in_dim] fp32 (normalised latent from the RF head) -> sem_out [M, dim] fp32 (x_norm),
  * embed_out [M, proj_dim] fp32 (linear_proj(sem)), either may be NULL.
  * kv_cache fp32 [depth][n_seq][2][n_heads][t_max][64]. */

@@ -126,6 +126,9 @@ SYMBOLS = {
     "mn_bf16_to_f32": (_i, [_p, _p, _i64, _p]),
     "mn_f32_split_bf16": (_i, [_p, _p, _p, _i64, _p]),
     "mn_rf_workspace_bytes": (_sz, [C.POINTER(RfHead), _i]),
+    "mn_rf_max_rows": (_i, [C.POINTER(RfHead)]),
+    "mn_llm_max_rows": (_i, [C.POINTER(Llm)]),
+    "mn_semdec_max_rows": (_i, [C.POINTER(SemDec)]),
     "mn_rf_sample": (_i, [C.POINTER(RfHead), _p, _i64, _i, _i, _p, _f, _f, _f, _p, _p, _sz, _p]),
     "mn_llm_workspace_bytes": (_sz, [C.POINTER(Llm), _i, _i64]),
     "mn_llm_step": (_i, [C.POINTER(Llm), _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _i, _i64, _p, _p, _sz, _p]),

@@ -206,6 +206,28 @@ class BailingMoeDecoder:
             outs.append(self.step(embeds[c0:c0 + m].contiguous(), seqs, slot, slot, slot + 1, None, im))
         return torch.cat(outs, 0)
 
+    def max_rows(self):
+        """Rows one step() accepts: 64, or 2048 when the wide route applies to this configuration."""
+        return int(lib().mn_llm_max_rows(C.byref(self.struct)))
+
+    def prefill_many(self, embeds, seqs, past=0):
+        """Causal prefill of B sequences of the same length in lock-step (the prompts of an image batch): embeds fp32
+        [B, T, H]; sequence b goes to cache sequence seqs[b].  Rows of all sequences share each pass through the stack
+        (<= max_rows() rows per pass); row (b, t) attends cache[seqs[b]][0 : past + t + 1].  Returns hidden [B, T, H]."""
+        B, T, H = embeds.shape
+        assert past + T <= self.t_max and len(seqs) == B
+        dev = self.device
+        x = embeds.reshape(B * T, H).contiguous()
+        seq = torch.tensor(list(seqs), dtype=torch.int32, device=dev).repeat_interleave(T)
+        slot = (torch.arange(T, dtype=torch.int32, device=dev) + past).repeat(B)
+        out = torch.empty(B * T, H, dtype=torch.float32, device=dev)
+        step = self.max_rows()
+        for r0 in range(0, B * T, step):
+            r1 = min(B * T, r0 + step)
+            sl = slot[r0:r1].contiguous()
+            self.step(x[r0:r1], seq[r0:r1].contiguous(), sl, sl, (sl + 1).contiguous(), None, None, out=out[r0:r1])
+        return out.reshape(B, T, H)
+
     def prefill_mfma(self, embeds, seq=0, past=0, image_mask=None, positions=None, key_mask=None):
         """Causal prefill of ONE sequence for long prompts on the bf16 MFMA path: per layer
         RMSNorm -> QKV GEMM -> RoPE + KV append -> GQA flash attention (hd 128) -> dense GEMM (+residual) ->
@@ -410,7 +432,8 @@ def generate_images(dec: BailingMoeDecoder, rf, tok, start_embed, past_lens, att
     assert 1 <= n_groups <= B
     per = (B + n_groups - 1) // n_groups                     # images per group
     n_groups = (B + per - 1) // per                          # e.g. 5 images in 4 groups -> 3 groups of 2 + 2 + 1, no empty group
-    assert max(past_lens) + n_tok + 1 <= dec.t_max and per * rpi <= MAX_ROWS_WIDE
+    row_cap = min(dec.max_rows(), rf.max_rows(), tok.max_decode_rows() * rpi)
+    assert max(past_lens) + n_tok + 1 <= dec.t_max and per * rpi <= row_cap, f"{per * rpi} rows per group > {row_cap}"
     if rpi > 1:   # replicate each prompt's KV to its CFG rows (:1891-1902) — device memcpy
         for i, past in enumerate(past_lens):
             for r in range(1, rpi):

@@ -6,6 +6,8 @@
 //   mn_attn_prefill_hd64  flash attention, head_dim 64, S^T = K Q^T / O^T = V^T P^T formulation so
 //                         that the softmax probabilities never leave registers
 //   mn_layernorm_bf16, mn_swiglu_bf16, fp32<->bf16 converters
+#include <string.h>
+
 #include "common.h"
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -190,8 +192,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 }
 }  // namespace
 
-static int g_gemm_glds = 1;
+static int g_gemm_glds = 1, g_gemm_route256 = 1;
 extern "C" void mn_gemm_tune(int glds) { g_gemm_glds = glds; }   // A/B hook, not part of the stable ABI
+extern "C" void mn_gemm_route256(int on) { g_gemm_route256 = on; }   // A/B hook: large problems go to gemm256.hip
 
 static int gemm_launch(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias, void* C,
                        int64_t ldc, int M, int N, int K, int epilogue, int ksplit, int64_t c_zstride, hipStream_t st) {
@@ -237,6 +240,18 @@ extern "C" int mn_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
   MN_CHECK_ARG(M >= 1 && N >= 1 && K >= 8 && (K % 8) == 0, "mn_gemm_bf16: bad M=%d N=%d K=%d (K %% 8 == 0)", M, N, K);
   MN_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0,
                "mn_gemm_bf16: A/W rows must be 16-byte aligned");
+  // enough 256 x 256 tiles to fill half the chip: the 8-wave 4-phase kernel (gemm256.hip: 1.2 PFLOP/s at 4096^3 against
+  // 0.76 here); smaller problems keep the 128 x 128 tiles (more workgroups, 2-3 per CU)
+  if (g_gemm_route256 && (K % 64) == 0 && (N % 4) == 0 && mn_cdiv(M, 256) * mn_cdiv(N, 256) >= 128 &&
+      (int64_t)M * lda * 2 < ((int64_t)1 << 32) && (int64_t)N * ldw * 2 < ((int64_t)1 << 32) && epilogue >= MN_GEMM_BF16 &&
+      epilogue <= MN_GEMM_F32_RESID) {
+    static const int map[4] = {MN_G256_BF16, MN_G256_BF16_GELU, MN_G256_F32, MN_G256_F32_RESID};
+    mn_g256 a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    const int rc = mn_gemm256_ex(&a, map[epilogue], 1, stream);
+    return rc < 0 ? rc : MN_OK;
+  }
   const int rc = gemm_launch(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, 1, 0, mn_stream(stream));
   if (rc < 0) return rc;
   MN_CHECK_LAUNCH("mn_gemm_bf16");

@@ -751,6 +751,12 @@ static size_t llm_carve(const mn_llm* m, int rows, int64_t t_max, void* ws, size
   return cv.off;
 }
 
+// Largest row count one call of each composite accepts for this configuration: 2048 when the wide route applies
+// (64-aligned widths), else 64.
+extern "C" int mn_llm_max_rows(const mn_llm* m) { return llm_wide_ok(m, 2048) ? 2048 : 64; }
+extern "C" int mn_rf_max_rows(const mn_rf_head* h) { return rf_wide_ok(h, 2048) ? 2048 : 64; }
+extern "C" int mn_semdec_max_rows(const mn_semdec* s) { return sem_wide_ok(s, 2048) ? 2048 : 64; }
+
 extern "C" size_t mn_llm_workspace_bytes(const mn_llm* m, int rows, int64_t t_max) {
   if (llm_wide_ok(m, rows)) { LlmWideWs ww; return llm_wide_carve(m, rows, t_max, nullptr, 0, &ww); }
   LlmWs w{};

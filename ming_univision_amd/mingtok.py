@@ -237,6 +237,10 @@ class MingTok:
         self._semdec_struct = s
         return s
 
+    def max_decode_rows(self):
+        """Rows one decode_step() accepts: 64, or 2048 on the wide route."""
+        return int(lib().mn_semdec_max_rows(C.byref(self._semdec())))
+
     def new_decode_state(self, n_seq=1, t_max=256):
         return SemDecodeState(self.sem_depth, self.feature_dim // 64, n_seq, t_max, self.device)
 

@@ -86,6 +86,10 @@ class RectifiedFlowHead:
         per_block = (2 * self.hidden * self.w + self.w * self.hidden) * 2
         return self.depth * per_block + self.t["ada_w"].numel() * 2
 
+    def max_rows(self):
+        """Rows one sample() accepts: 64, or 2048 when the wide route applies (all widths multiples of 64)."""
+        return int(lib().mn_rf_max_rows(C.byref(self.struct)))
+
     def _workspace(self, rows, device):
         key = (rows, torch.cuda.current_stream().cuda_stream)      # one scratch area per stream: groups overlap
         if key not in self._ws:

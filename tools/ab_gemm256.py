@@ -7,6 +7,8 @@ from ming_univision_amd import ops
 from ming_univision_amd._lib import lib, ptr, check, current_stream
 L = lib()
 L.mn_gemm256_tune.argtypes = [ctypes.c_int]; L.mn_gemm256_tune.restype = None
+L.mn_gemm_route256.argtypes = [ctypes.c_int]; L.mn_gemm_route256.restype = None
+L.mn_gemm_route256(0)   # "round-1 kernel" below = the 128 x 128 kernel itself
 EPI = {"bf16": 0, "f32": 2}
 dev = "cuda"
 
