@@ -43,6 +43,18 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
+// hardware conversion (v_cvt_pk_bf16_f32, round-to-nearest-even: bit-identical to f32_to_bf16 on finite values)
+typedef float mn_f2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 mn_b2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(mn_f2_t{lo, hi}, mn_b2_t));
+}
+// (a, b) -> packed bf16 hi parts and packed bf16 lo parts: a = hi.a + lo.a to 2^-17
+__device__ __forceinline__ void split_pk_bf16(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = cvt_pk_bf16(a, b);
+  lo = cvt_pk_bf16(a - bf16lo_to_f32(hi), b - bf16hi_to_f32(hi));
+}
+
 // ---- activations ----------------------------------------------------------------------------
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -101,15 +101,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
 
   // ---- staging: wave w fills LDS rows [16w, 16w+16) of a half-tile with two instructions of 8 rows x 8 slots ----
   // per-lane byte offsets (from A / W) of the global row behind LDS row L = 16*wave + 8*q + (lane >> 3) of half h,
-  // with the k-slot swizzle (lane & 7) ^ (row & 7) folded in.  All offsets fit 32 bits (checked by the host).
+  // with the k-slot swizzle (lane & 7) ^ f(L), f(row) = (row >> 1) & 7, folded in (conflict-free for the 16-row fragments
+  // of the 16x16x32 MFMA and the 32-row fragments of the 32x32x16 MFMA alike).  All offsets fit 32 bits (host check).
   uint32_t srcA[2][2], srcW[2][2];
   {
-    const int rin = lane >> 3, ks = ((lane & 7) ^ rin) * 16;
+    const int rin = lane >> 3;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int L = wave * 16 + q * 8 + rin;
+        const int ks = ((lane & 7) ^ ((L >> 1) & 7)) * 16;         // k-slot swizzle f(row) = (row >> 1) & 7
         int gm, gn;
         if (hilo) gm = m0 + L;                                      // half = hi / lo part of the same rows
         else gm = m0 + (L >> 6) * 128 + h * 64 + (L & 63);          // wave row L / 64, fragment half h
@@ -133,34 +135,31 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
     }
   };
 
-  // ---- fragment reads: row (of a half) = wave part + 16 * frag + fr, slot = (4 kk + fq) ^ (row & 7) ----
-  const int lane_off0 = fr * 128 + (((fq) ^ (fr & 7)) << 4);          // kk = 0
-  const int lane_off1 = fr * 128 + (((4 + fq) ^ (fr & 7)) << 4);      // kk = 1
+  // ---- fragment reads (v_mfma_f32_16x16x32_bf16): row = 16 * frag + (lane & 15), k-slot = (4 kk + (lane >> 4)) ^ f(row) ----
+  // (A 32x32x16 form of the same schedule was built and measured: 1048 vs 1243 TFLOP/s at 4096^3 — a quadrant phase then
+  //  has only two independent accumulators for an MFMA of 64-cycle latency.)
+  int lane_off[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) lane_off[kk] = fr * 128 + (((4 * kk + fq) ^ ((fr >> 1) & 7)) << 4);
   const int a_wave = wr * 64 * 128, w_wave = wc * 32 * 128;
-  bf16x8 af[4][2], wf0[2][2], wf1[2][2];
+  bf16x8 af[8], wf0[4], wf1[4];
   auto read_a = [&](int buf, int h) {
     const char* base = &lds[lds_off(buf, 0, h) + a_wave];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      af[i][0] = *reinterpret_cast<const bf16x8*>(base + i * 2048 + lane_off0);
-      af[i][1] = *reinterpret_cast<const bf16x8*>(base + i * 2048 + lane_off1);
-    }
+    for (int x = 0; x < 8; ++x) af[x] = *reinterpret_cast<const bf16x8*>(base + (x >> 1) * 2048 + lane_off[x & 1]);   // x = 2 i + kk
   };
-  auto read_w = [&](int buf, int h, bf16x8 (&wf)[2][2]) {
+  auto read_w = [&](int buf, int h, bf16x8 (&wf)[4]) {
     const char* base = &lds[lds_off(buf, 1, h) + w_wave];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      wf[j][0] = *reinterpret_cast<const bf16x8*>(base + j * 2048 + lane_off0);
-      wf[j][1] = *reinterpret_cast<const bf16x8*>(base + j * 2048 + lane_off1);
-    }
+    for (int x = 0; x < 4; ++x) wf[x] = *reinterpret_cast<const bf16x8*>(base + (x >> 1) * 2048 + lane_off[x & 1]);   // x = 2 j + kk
   };
-  f32x4 acc[8][4];
+  f32x4 acc[8][4];                    // [M fragment][N fragment]
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // quadrant (mh, nh): D[n][m] += W-frag (as A operand) x activation frag (as B operand)
-  auto quad = [&](int mh, int nh, bf16x8 (&wf)[2][2]) {
+  auto quad = [&](int mh, int nh, bf16x8 (&wf)[4]) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[mh * 4 + i][nh * 2 + j] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], af[i][kk], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * j + kk], af[2 * i + kk], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
   };
 
   if (SCHED == 0) {
@@ -237,50 +236,56 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
     if (wr == 0) __builtin_amdgcn_s_barrier();
   }
 
-  // ---- epilogue: lane holds, per (i, j), output row m = .. + 16 i + fr and 4 consecutive columns 16 j + 4 fq .. +3 ----
-  constexpr int mi_n = hilo ? 4 : 8, nj_n = paired ? 2 : 4;
+  // ---- epilogue ----
+  // emit(row-in-tile ml, first column n, v[4], u[4]): 4 CONSECUTIVE columns n..n+3 of one output row (u: the paired up half)
   char* Cz = reinterpret_cast<char*>(p.C);
   if (EPI == E_F32) Cz += (int64_t)blockIdx.y * p.c_zstride * 4;
-#pragma unroll
-  for (int i = 0; i < mi_n; ++i) {
-    const int ml = hilo ? m0 + wr * 64 + i * 16 + fr : m0 + wr * 128 + i * 16 + fr;
+  auto emit = [&](int ml, int n, f32x4 v, f32x4 u) {
+    if (ml >= Mg || n >= p.N) return;             // N % 4 == 0 (host check): the 4 columns are all in or all out
     const int m = row0 + ml;
-#pragma unroll
-    for (int j = 0; j < nj_n; ++j) {
-      const int n = paired ? n0 + wc * 32 + j * 16 + fq * 4 : n0 + wc * 64 + j * 16 + fq * 4;
-      if (ml >= Mg || n >= p.N) continue;         // N % 4 == 0 (host check): a lane's 4 columns are all in or all out
-      f32x4 v = acc[i][j];
-      if (hilo) v += acc[(i + 4) & 7][j];
-      f32x4 u = {0.f, 0.f, 0.f, 0.f};
-      if (paired) { u = acc[i][(j + 2) & 3]; if (hilo) u += acc[(i + 4) & 7][(j + 2) & 3]; }
-      if (p.bias && blockIdx.y == 0) {
-        const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
-        v += f32x4{bf16lo_to_f32(b.x), bf16hi_to_f32(b.x), bf16lo_to_f32(b.y), bf16hi_to_f32(b.y)};
-        if (paired) {
-          const u32x2 b2 = *reinterpret_cast<const u32x2*>(p.bias + p.w_pair_rows + n);
-          u += f32x4{bf16lo_to_f32(b2.x), bf16hi_to_f32(b2.x), bf16lo_to_f32(b2.y), bf16hi_to_f32(b2.y)};
-        }
+    if (p.bias && blockIdx.y == 0) {
+      const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
+      v += f32x4{bf16lo_to_f32(b.x), bf16hi_to_f32(b.x), bf16lo_to_f32(b.y), bf16hi_to_f32(b.y)};
+      if (paired) {
+        const u32x2 b2 = *reinterpret_cast<const u32x2*>(p.bias + p.w_pair_rows + n);
+        u += f32x4{bf16lo_to_f32(b2.x), bf16hi_to_f32(b2.x), bf16lo_to_f32(b2.y), bf16hi_to_f32(b2.y)};
       }
-      if (EPI == E_F32) {
-        *reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4) = v;
-      } else if (EPI == E_F32_RESID) {
-        f32x4* c = reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4);
-        *c += v;
-      } else if (EPI == E_F32_RESID_GATE) {
-        f32x4* c = reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(p.gate + (int64_t)m * p.ldgate + n);
-        *c += g * v;
-      } else if (EPI == E_BF16 || EPI == E_BF16_GELU) {
-        if (EPI == E_BF16_GELU) v = f32x4{gelu_erf_f(v.x), gelu_erf_f(v.y), gelu_erf_f(v.z), gelu_erf_f(v.w)};
-        *reinterpret_cast<u32x2*>(Cz + ((int64_t)m * p.ldc + n) * 2) = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
-      } else {  // E_SWIGLU_SPLIT: y = silu(gate) * up, stored as bf16 hi rows and lo rows
-        float y[4] = {silu_f(v.x) * u.x, silu_f(v.y) * u.y, silu_f(v.z) * u.z, silu_f(v.w) * u.w};
-        bf16_t hi[4], lo[4];
+    }
+    if (EPI == E_F32) {
+      *reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4) = v;
+    } else if (EPI == E_F32_RESID) {
+      f32x4* c = reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4);
+      *c += v;
+    } else if (EPI == E_F32_RESID_GATE) {
+      f32x4* c = reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p.gate + (int64_t)m * p.ldgate + n);
+      *c += g * v;
+    } else if (EPI == E_BF16 || EPI == E_BF16_GELU) {
+      if (EPI == E_BF16_GELU) v = f32x4{gelu_erf_f(v.x), gelu_erf_f(v.y), gelu_erf_f(v.z), gelu_erf_f(v.w)};
+      *reinterpret_cast<u32x2*>(Cz + ((int64_t)m * p.ldc + n) * 2) = u32x2{cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w)};
+    } else {  // E_SWIGLU_SPLIT: y = silu(gate) * up, stored as bf16 hi rows and lo rows
+      uint32_t h0, l0, h1, l1;
+      split_pk_bf16(silu_f(v.x) * u.x, silu_f(v.y) * u.y, h0, l0);
+      split_pk_bf16(silu_f(v.z) * u.z, silu_f(v.w) * u.w, h1, l1);
+      bf16_t* c = reinterpret_cast<bf16_t*>(Cz) + (int64_t)m * p.ldc + n;
+      *reinterpret_cast<u32x2*>(c) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(c + p.c_lo_off) = u32x2{l0, l1};
+    }
+  };
+  {
+    // lane holds, per (i, j), row 16 i + fr and columns 16 j + 4 fq .. +3
+    constexpr int mi_n = hilo ? 4 : 8, nj_n = paired ? 2 : 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { hi[e] = f32_to_bf16(y[e]); lo[e] = f32_to_bf16(y[e] - bf16_to_f32(hi[e])); }
-        bf16_t* c = reinterpret_cast<bf16_t*>(Cz) + (int64_t)m * p.ldc + n;
-        *reinterpret_cast<u32x2*>(c) = u32x2{(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
-        *reinterpret_cast<u32x2*>(c + p.c_lo_off) = u32x2{(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
+    for (int i = 0; i < mi_n; ++i) {
+      const int ml = hilo ? m0 + wr * 64 + i * 16 + fr : m0 + wr * 128 + i * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < nj_n; ++j) {
+        const int n = paired ? n0 + wc * 32 + j * 16 + fq * 4 : n0 + wc * 64 + j * 16 + fq * 4;
+        f32x4 v = acc[i][j];
+        if (hilo) v += acc[(i + 4) & 7][j];
+        f32x4 u = {0.f, 0.f, 0.f, 0.f};
+        if (paired) { u = acc[i][(j + 2) & 3]; if (hilo) u += acc[(i + 4) & 7][(j + 2) & 3]; }
+        emit(ml, n, v, u);
       }
     }
   }
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
 }  // namespace
 
 static int g_g256_sched = 1;
-extern "C" void mn_gemm256_tune(int sched) { g_g256_sched = sched; }   // A/B hook, not part of the stable ABI
+extern "C" void mn_gemm256_tune(int sched) { g_g256_sched = sched & 1; }   // A/B hook, not part of the stable ABI
 
 // Generic launcher.  Returns the number of split-K slices used (>= 1) or a negative error.
 static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {

@@ -118,13 +118,12 @@ __global__ __launch_bounds__(1024) void wide_glue_kernel(const WideGlue p) {
   if (p.act == 1) v = f4{gelu_erf_f(v.x), gelu_erf_f(v.y), gelu_erf_f(v.z), gelu_erf_f(v.w)};
   if (p.out) *reinterpret_cast<f4*>(p.out + (int64_t)m * p.ldo + col) = v;
   if (p.Y) {
-    const float o[4] = {v.x, v.y, v.z, v.w};
-    bf16_t hi[4], lo[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { hi[j] = f32_to_bf16(o[j]); lo[j] = f32_to_bf16(o[j] - bf16_to_f32(hi[j])); }
+    uint32_t h0, l0, h1, l1;
+    split_pk_bf16(v.x, v.y, h0, l0);
+    split_pk_bf16(v.z, v.w, h1, l1);
     bf16_t* yr = p.Y + (int64_t)m * p.ldy + col;
-    *reinterpret_cast<u2*>(yr) = u2{(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
-    *reinterpret_cast<u2*>(yr + p.y_lo_off) = u2{(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
+    *reinterpret_cast<u2*>(yr) = u2{h0, h1};
+    *reinterpret_cast<u2*>(yr + p.y_lo_off) = u2{l0, l1};
   }
 }
 
