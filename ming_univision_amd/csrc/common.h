@@ -109,6 +109,9 @@ typedef struct mn_g256 {
   // grouped form: group g = blockIdx.z owns rows [g_off[g], g_off[g] + g_cnt[g]) (device arrays), weights W + g * w_gstride;
   // a_rows (optional) maps a row position to its source row in A (gather); M bounds every group's row count
   const int32_t* g_off; const int32_t* g_cnt; int64_t w_gstride; const int32_t* a_rows; int n_groups;
+  // optional device-built list of the LIVE row tiles of the grouped form (mn_moe_sort_tiles): tile t = rows
+  // [tile_m0[t], +128 or 256) of group tile_g[t], *n_tiles entries, at most max_mtiles; the grid then has no empty groups
+  const int32_t* tile_g; const int32_t* tile_m0; const int32_t* n_tiles; int max_mtiles;
 } mn_g256;
 enum { MN_G256_F32 = 0, MN_G256_BF16 = 1, MN_G256_BF16_GELU = 2, MN_G256_F32_RESID = 3, MN_G256_SWIGLU_SPLIT = 4,
        MN_G256_F32_RESID_GATE = 5 };

@@ -260,6 +260,126 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(
   }
 }
 
+// GQA form for many rows: one wave per (row, KV head, split) serves all G = n_q / n_kv query heads of its group, so every
+// K / V line is loaded ONCE per group instead of once per query head (the per-head kernel above re-reads them through L1:
+// 4x the load instructions at G = 4).  Same partial layout, same combine kernel.  Block = 4 waves = 4 KV heads of one row.
+template <int HD, int G>
+__global__ __launch_bounds__(256) void attn_decode_gqa_kernel(
+    const float* __restrict__ q, int n_q, int n_kv, const float* __restrict__ kv_cache, int64_t t_max,
+    const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_len, const uint8_t* __restrict__ key_mask,
+    int64_t ld_mask, int S, int chunk_cap, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x, s = blockIdx.z;
+  const int kvh_raw = blockIdx.y * 4 + wave;
+  const bool active = kvh_raw < n_kv;          // inactive waves shadow the last KV head, store nothing
+  const int kvh = active ? kvh_raw : n_kv - 1;
+  float* sc = sm + (size_t)wave * G * chunk_cap;            // [G][chunk_cap]
+  const int len = row_len[m];
+  int chunk = (len + S - 1) / S;
+  chunk = (chunk + 3) & ~3;
+  const int j0 = s * chunk, j1 = min(len, j0 + chunk);
+  const int64_t seq = row_seq[m];
+  const float* Kb = kv_cache + ((seq * 2 + 0) * n_kv + kvh) * t_max * HD;
+  const float* Vb = kv_cache + ((seq * 2 + 1) * n_kv + kvh) * t_max * HD;
+  const uint8_t* mk = key_mask ? key_mask + (int64_t)m * ld_mask : nullptr;
+  constexpr int PER = HD / 16;                 // floats per lane in the score pass (16 lanes per key)
+  const int sub = lane & 15, kq = lane >> 4;
+  float qv[G][PER];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int i = 0; i < PER; ++i) qv[g][i] = q[((int64_t)m * n_q + kvh * G + g) * HD + sub * PER + i];
+  float mx[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) mx[g] = -INFINITY;
+#pragma unroll 2
+  for (int j = j0 + kq; j < j0 + chunk; j += 4) {
+    float d[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) d[g] = 0.f;
+    const bool ok = j < j1;
+    if (ok) {
+      const float* kr = Kb + (int64_t)j * HD + sub * PER;
+#pragma unroll
+      for (int i = 0; i < PER; i += 4) {
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(kr + i);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          d[g] = fmaf(kv.x, qv[g][i], d[g]); d[g] = fmaf(kv.y, qv[g][i + 1], d[g]);
+          d[g] = fmaf(kv.z, qv[g][i + 2], d[g]); d[g] = fmaf(kv.w, qv[g][i + 3], d[g]);
+        }
+      }
+    }
+    const bool keep = ok && (!mk || mk[j] != 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float v = d[g];
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+      const float sv = keep ? v : -INFINITY;
+      if (sub == 0 && (j - j0) < chunk_cap) sc[g * chunk_cap + (j - j0)] = sv;
+      mx[g] = fmaxf(mx[g], sv);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) mx[g] = wave_max(mx[g]);
+  __syncthreads();
+  const int n = max(0, j1 - j0);
+  float l[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float a = 0.f;
+    for (int j = lane; j < n; j += 64) {
+      const float pj = (mx[g] == -INFINITY) ? 0.f : __expf(sc[g * chunk_cap + j] - mx[g]);
+      sc[g * chunk_cap + j] = pj;
+      a += pj;
+    }
+    l[g] = wave_sum(a);
+  }
+  __syncthreads();
+  constexpr int DPL = HD / 64;                 // dims per lane in the PV pass
+  float acc[G][DPL];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) acc[g][i] = 0.f;
+  const float* vr = Vb + (int64_t)j0 * HD + lane * DPL;
+  int j = 0;
+  for (; j + 4 <= n; j += 4) {
+    float v[4][DPL];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < DPL; ++i) v[u][i] = vr[(int64_t)(j + u) * HD + i];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const f32x4 pj = *reinterpret_cast<const f32x4*>(sc + g * chunk_cap + j);      // chunk_cap % 4 == 0, j % 4 == 0
+      const float pv[4] = {pj.x, pj.y, pj.z, pj.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) acc[g][i] = fmaf(pv[u], v[u][i], acc[g][i]);
+    }
+  }
+  for (; j < n; ++j) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float pj = sc[g * chunk_cap + j];
+#pragma unroll
+      for (int i = 0; i < DPL; ++i) acc[g][i] = fmaf(pj, vr[(int64_t)j * HD + i], acc[g][i]);
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float* out = partial + (((int64_t)m * n_q + kvh * G + g) * S + s) * (HD + 2);
+#pragma unroll
+      for (int i = 0; i < DPL; ++i) out[lane * DPL + i] = acc[g][i];
+      if (lane == 0) { out[HD] = mx[g]; out[HD + 1] = l[g]; }
+    }
+  }
+}
+
 // out (fp32 [M, n_q*HD]) and / or split (bf16 [2][M][n_q*HD]: hi rows then lo rows, the next GEMV's MFMA operand)
 template <int HD>
 __global__ void attn_decode_combine_kernel(const float* __restrict__ partial, int n_q, int S, float* __restrict__ out,
@@ -287,13 +407,13 @@ __global__ void attn_decode_combine_kernel(const float* __restrict__ partial, in
 
 // Key-range splits (flash-decoding): enough workgroups to fill the chip at few rows, none needed at hundreds of rows;
 // one split never holds more than 4096 keys (its scores live in LDS).
+static bool attn_use_gqa(int M, int n_q, int n_kv, int hd) { return M > 64 && hd == 128 && n_q == 4 * n_kv; }
 static int attn_splits(int M, int n_q, int64_t t_max) {
   int S = (int)mn_cdiv(t_max, 32);
   if (S > 32) S = 32;
-  const int64_t blocks = (int64_t)M * ((n_q + 3) / 4);
-  const int want = (int)mn_cdiv(2048, blocks);
+  const int want = (int)mn_cdiv(4096, M);       // a few thousand waves on the chip whatever the row count
   if (S > want) S = want;
-  const int need = (int)mn_cdiv(t_max, 4096);
+  const int need = (int)mn_cdiv(t_max, 1024);   // scores of a split live in LDS (4 heads x 1024 keys per wave at most)
   if (S < need) S = need;
   if (S < 1) S = 1;
   return S;
@@ -319,7 +439,11 @@ extern "C" int mn_attn_decode_split(const float* q, int M, int n_q, int n_kv, in
   float* partial = reinterpret_cast<float*>(workspace);
   dim3 grid(M, (n_q + 3) / 4, S);
   hipStream_t st = mn_stream(stream);
-  if (hd == 128) {
+  if (attn_use_gqa(M, n_q, n_kv, hd)) {
+    hipLaunchKernelGGL((attn_decode_gqa_kernel<128, 4>), dim3(M, (n_kv + 3) / 4, S), dim3(256), lds * 4, st, q, n_q, n_kv, kv_cache,
+                       t_max, row_seq, row_len, key_mask, ld_mask, S, chunk_cap, partial);
+    hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(M, n_q), dim3(128), 0, st, partial, n_q, S, out, split, M);
+  } else if (hd == 128) {
     hipLaunchKernelGGL(attn_decode_split_kernel<128>, grid, dim3(256), lds, st, q, n_q, n_kv, kv_cache, t_max, row_seq,
                        row_len, key_mask, ld_mask, S, chunk_cap, partial);
     hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(M, n_q), dim3(128), 0, st, partial, n_q, S, out, split, M);

@@ -81,21 +81,32 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   // that share a W column panel sit in one L2.
   int bid = blockIdx.x;
   {
-    const int nt = tiles_m * tiles_n;
+    const int nt = gridDim.x;
     const int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tm = bid % tiles_m, tn = bid / tiles_m;
-  const int m0 = tm * rows_per_tile, n0 = tn * cols_per_tile;
-  // grouped form (MoE experts): blockIdx.z = group g owns rows [g_off[g], g_off[g] + g_cnt[g]) of A (through a_rows when
-  // given: a gather by index while staging) and of C, and the weights W + g * w_gstride; p.M bounds every group
-  int Mg = p.M, row0 = 0;
+  int tm = bid % tiles_m, tn = bid / tiles_m;
+  int m0 = tm * rows_per_tile;
+  // grouped form (MoE experts): group g owns rows [g_off[g], g_off[g] + g_cnt[g]) of A (through a_rows when given: a
+  // gather by index while staging) and of C, and the weights W + g * w_gstride; p.M bounds every group.  The group is
+  // blockIdx.z, or — with a device-built tile list — row tile t = bid / tiles_n of the list (no empty workgroups; the
+  // N-tiles of one row tile are consecutive, so its gathered rows stay in one L2).
+  int Mg = p.M, row0 = 0, grp = 0;
   if (p.g_off) {
-    const int g = blockIdx.z;
-    row0 = p.g_off[g];
-    Mg = p.g_cnt[g];
-    if (m0 >= Mg) return;                      // uniform per workgroup
+    if (p.tile_g) {
+      const int t = bid / tiles_n;
+      tn = bid % tiles_n;
+      if (t >= *p.n_tiles) return;               // uniform per workgroup
+      grp = p.tile_g[t];
+      m0 = p.tile_m0[t];
+    } else {
+      grp = blockIdx.z;
+    }
+    row0 = p.g_off[grp];
+    Mg = p.g_cnt[grp];
+    if (m0 >= Mg) return;                        // uniform per workgroup
   }
+  const int n0 = tn * cols_per_tile;
   const int kbeg = blockIdx.y * p.Kc, kend = min(p.K, kbeg + p.Kc);
   const int nk = (kend - kbeg) / BK;
 
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
       }
   }
   const char* Ab = reinterpret_cast<const char*>(p.A);
-  const char* Wb = reinterpret_cast<const char*>(p.W) + (p.g_off ? (int64_t)blockIdx.z * p.w_gstride * 2 : 0);
+  const char* Wb = reinterpret_cast<const char*>(p.W) + (int64_t)grp * p.w_gstride * 2;
   auto stage = [&](int op, int h, int kt, int buf) {   // op 0 = A, 1 = W; all arguments compile-time or wave-uniform
     char* dst = &lds[lds_off(buf, op, h) + wave * 2048];
     const uint32_t koff = (uint32_t)kt * (BK * 2);
@@ -299,12 +310,12 @@ extern "C" void mn_gemm256_tune(int sched) { g_g256_sched = sched & 1; }   // A/
 // Generic launcher.  Returns the number of split-K slices used (>= 1) or a negative error.
 static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {
   const bool hilo = a.a_lo_off != 0, paired = a.w_pair_rows != 0;
-  const int tiles = (int)(mn_cdiv(a.M, hilo ? 128 : 256) * mn_cdiv(a.N, paired ? 128 : 256));
+  const int tiles = (int)((a.tile_g ? a.max_mtiles : mn_cdiv(a.M, hilo ? 128 : 256)) * mn_cdiv(a.N, paired ? 128 : 256));
   G256 p = a;
   p.Kc = p.K;
   if (ksplit > 1) p.Kc = (int)(mn_cdiv(mn_cdiv(p.K, ksplit), 2 * BK) * 2 * BK);   // even number of K-tiles per slice
   const int nz = (int)mn_cdiv(p.K, p.Kc);
-  dim3 grid(tiles, nz, a.g_off ? a.n_groups : 1);
+  dim3 grid(tiles, nz, (a.g_off && !a.tile_g) ? a.n_groups : 1);
 #define G256_GO(E)                                                                                             \
   do {                                                                                                         \
     if (hilo) {                                                                                                \

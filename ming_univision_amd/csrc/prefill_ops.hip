@@ -261,7 +261,8 @@ extern "C" int mn_moe_topk_logits(const float* logits_text, const float* logits_
 __global__ __launch_bounds__(1024) void moe_sort_kernel(const int32_t* __restrict__ topk_idx, int n_pairs, int n_groups,
                                                         int32_t* __restrict__ counts, int32_t* __restrict__ offsets,
                                                         int32_t* __restrict__ perm, int32_t* __restrict__ slot_of,
-                                                        int n_slot) {
+                                                        int n_slot, int tile_rows, int32_t* __restrict__ tile_g,
+                                                        int32_t* __restrict__ tile_m0, int32_t* __restrict__ n_tiles) {
   __shared__ int cnt[128], off[129], cur[128];
   const int tid = threadIdx.x;
   for (int i = tid; i < n_groups; i += 1024) { cnt[i] = 0; cur[i] = 0; }
@@ -276,6 +277,12 @@ __global__ __launch_bounds__(1024) void moe_sort_kernel(const int32_t* __restric
   __syncthreads();
   for (int i = tid; i < n_groups; i += 1024) { counts[i] = cnt[i]; offsets[i] = off[i]; }
   if (tid == 0) offsets[n_groups] = off[n_groups];
+  if (tile_g && tid == 0) {        // live row tiles of the grouped GEMMs, in group order
+    int t = 0;
+    for (int e = 0; e < n_groups; ++e)
+      for (int m0 = 0; m0 < cnt[e]; m0 += tile_rows) { tile_g[t] = e; tile_m0[t] = m0; ++t; }
+    *n_tiles = t;
+  }
   for (int i = tid; i < n_pairs; i += 1024) {
     const int e = topk_idx[i];
     const int pos = off[e] + atomicAdd(&cur[e], 1);
@@ -289,8 +296,21 @@ extern "C" int mn_moe_sort(const int32_t* topk_idx, int T, int n_slot, int n_gro
   MN_CHECK_ARG(topk_idx && counts && offsets && perm && slot_of && T >= 1 && n_slot >= 1 && n_groups >= 1 && n_groups <= 128 &&
                    (int64_t)T * n_slot <= 65536, "mn_moe_sort: bad args");
   hipLaunchKernelGGL(moe_sort_kernel, dim3(1), dim3(1024), 0, mn_stream(stream), topk_idx, T * n_slot, n_groups, counts,
-                     offsets, perm, slot_of, n_slot);
+                     offsets, perm, slot_of, n_slot, 0, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
   MN_CHECK_LAUNCH("mn_moe_sort");
+  return MN_OK;
+}
+
+// Internal (engine.hip): mn_moe_sort that also lists the live row tiles (tile_rows rows each) of the grouped GEMMs:
+// tile_g / tile_m0 [<= T * n_slot / tile_rows + n_groups], *n_tiles.
+extern "C" int mn_moe_sort_tiles(const int32_t* topk_idx, int T, int n_slot, int n_groups, int32_t* counts, int32_t* offsets,
+                                 int32_t* perm, int32_t* slot_of, int tile_rows, int32_t* tile_g, int32_t* tile_m0,
+                                 int32_t* n_tiles, void* stream) {
+  MN_CHECK_ARG(topk_idx && counts && offsets && perm && slot_of && tile_g && tile_m0 && n_tiles && tile_rows >= 1 && T >= 1 &&
+                   n_slot >= 1 && n_groups >= 1 && n_groups <= 128 && (int64_t)T * n_slot <= 65536, "mn_moe_sort_tiles: bad args");
+  hipLaunchKernelGGL(moe_sort_kernel, dim3(1), dim3(1024), 0, mn_stream(stream), topk_idx, T * n_slot, n_groups, counts,
+                     offsets, perm, slot_of, n_slot, tile_rows, tile_g, tile_m0, n_tiles);
+  MN_CHECK_LAUNCH("mn_moe_sort_tiles");
   return MN_OK;
 }
 

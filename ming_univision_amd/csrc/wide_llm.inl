@@ -4,8 +4,9 @@
 // bf16 hi/lo operands, every stretch between two Linears one wide_glue launch, and the MoE expert loop (:605-639) is two
 // GROUPED gemm256 launches over the expert-sorted (row, pick) pairs — the gate/up launch gathers its rows by index while
 // staging and applies SwiGLU + hi/lo split in its epilogue, the weighted un-permute + residual rides the next glue.
-extern "C" int mn_moe_sort(const int32_t* topk_idx, int T, int n_slot, int n_groups, int32_t* counts, int32_t* offsets,
-                           int32_t* perm, int32_t* slot_of, void* stream);
+extern "C" int mn_moe_sort_tiles(const int32_t* topk_idx, int T, int n_slot, int n_groups, int32_t* counts, int32_t* offsets,
+                                 int32_t* perm, int32_t* slot_of, int tile_rows, int32_t* tile_g, int32_t* tile_m0,
+                                 int32_t* n_tiles, void* stream);
 
 // Router tail for many rows: one wave per row sums the gate GEMM's split-K slabs, fp32 softmax, iterative arg-max top-k
 // (ties -> lowest expert), renormalise, append the shared pseudo-experts  (BailingMoeGate.forward :505-520).
@@ -44,7 +45,8 @@ __global__ __launch_bounds__(256) void moe_topk_partials_kernel(const float* __r
 struct LlmWideWs {
   float *h, *pp, *q, *yg, *tw;
   bf16_t *yh, *ya, *y2;
-  int32_t *ti, *cnt, *off, *perm, *slot_of;
+  int32_t *ti, *cnt, *off, *perm, *slot_of, *tile_g, *tile_m0, *n_tiles;
+  int max_mtiles;
   void* attn_ws;
   size_t attn_ws_bytes;
   int ks_qkv, ks_dense, ks_gate;
@@ -83,6 +85,10 @@ static size_t llm_wide_carve(const mn_llm* m, int rows, int64_t t_max, void* ws,
   o->off = cv.take<int32_t>((size_t)G + 1);
   o->perm = cv.take<int32_t>(P);
   o->slot_of = cv.take<int32_t>(P);
+  o->max_mtiles = (int)(P / 128) + G;                   // sum_g ceil(cnt_g / 128) <= P / 128 + G
+  o->tile_g = cv.take<int32_t>((size_t)o->max_mtiles);
+  o->tile_m0 = cv.take<int32_t>((size_t)o->max_mtiles);
+  o->n_tiles = cv.take<int32_t>(4);
   o->attn_ws_bytes = mn_attn_decode_workspace_bytes(rows, m->n_q, m->head_dim, t_max);
   o->attn_ws = cv.take<char>(o->attn_ws_bytes);
   return cv.off;
@@ -142,14 +148,16 @@ static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row
     if (nz < 0) return nz;
     hipLaunchKernelGGL(moe_topk_partials_kernel, dim3(mn_cdiv(M, 4)), dim3(256), 0, st, (const float*)w.pp, nz, (int64_t)M * E, M, E,
                        m->top_k, m->norm_topk_prob, m->n_shared_slots, w.ti, w.tw);
-    MN_TRY(mn_moe_sort(w.ti, M, n_slot, G, w.cnt, w.off, w.perm, w.slot_of, stream));
+    MN_TRY(mn_moe_sort_tiles(w.ti, M, n_slot, G, w.cnt, w.off, w.perm, w.slot_of, 128, w.tile_g, w.tile_m0, w.n_tiles, stream));
     // experts: grouped gate/up (rows gathered by perm, SwiGLU + split epilogue), grouped down -> yg [P, H]  (:617-628, 483-484)
     a = g256_hilo(w.yh, H, (int64_t)M * H, m->w_gate_up[l], H, nullptr, w.y2, I, M, I, H);
     a.w_pair_rows = I; a.c_lo_off = P * I;
     a.g_off = w.off; a.g_cnt = w.cnt; a.w_gstride = (int64_t)2 * I * H; a.a_rows = w.perm; a.n_groups = G;
+    a.tile_g = w.tile_g; a.tile_m0 = w.tile_m0; a.n_tiles = w.n_tiles; a.max_mtiles = w.max_mtiles;
     MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
     a = g256_hilo(w.y2, I, P * I, m->w_down[l], I, nullptr, w.yg, H, M, H, I);
     a.g_off = w.off; a.g_cnt = w.cnt; a.w_gstride = (int64_t)H * I; a.n_groups = G;
+    a.tile_g = w.tile_g; a.tile_m0 = w.tile_m0; a.n_tiles = w.n_tiles; a.max_mtiles = w.max_mtiles;
     MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
   }
   MN_CHECK_LAUNCH("mn_llm_step(wide)");
