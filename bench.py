@@ -6,7 +6,8 @@ Workload (BASELINE.json configs[3], the configuration the metric is quoted on; f
   0.70 B MingTok), a 40-token text prompt, forced `<image>`, 2 CFG rows (text->image), 256 visual
   tokens: per token one 28-layer MoE step over the CFG rows, the 16-step rectified-flow SwiGLU
   sampler, one cached semantic-decoder step + linear_proj; then the 24-layer pixel decoder.
-  A "step" = one full image (prompt prefill + 257 LLM steps + 256 samplers + pixel decode).
+  A "step" = one batch of images generated in lock-step (prompt prefill + 257 LLM steps + 256 samplers + pixel
+  decode); default 512 images = 1024 CFG rows in one group, the wide route.
 
 One process per GPU (independent prompts per rank = replicas, no data-path collective: the path
 is a strictly sequential AR chain per image).  Prints ONE JSON line on rank 0.
@@ -36,10 +37,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tokens", type=int, default=256, help="visual tokens per image (256 = 512^2)")
     ap.add_argument("--prompt-len", type=int, default=40)
-    ap.add_argument("--images", type=int, default=128,
-                    help="images generated in lock-step per GPU (an image batch; 1 = the reference's batch-size-1 call; 32 per group = 64 CFG rows)")
-    ap.add_argument("--groups", type=int, default=4,
-                    help="split the image batch into this many lock-step groups on separate HIP streams")
+    ap.add_argument("--images", type=int, default=512,
+                    help="images generated in lock-step per GPU (an image batch; 1 = the reference's batch-size-1 call). More than "
+                         "32 images per group (64 CFG rows) take the wide route: every Linear a 256x256-tile MFMA GEMM")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="split the image batch into this many lock-step groups on separate HIP streams (pays below 64 rows per "
+                         "group, where launches are HBM/latency-bound; the wide route fills the chip from one group)")
     ap.add_argument("--no-batch1", action="store_true", help="skip the extra batch-size-1 measurement")
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only; INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -233,6 +233,15 @@ int mn_gemm256_swiglu_split(const uint16_t* A, int64_t lda, int64_t a_lo_off, co
                             const uint16_t* b12, uint16_t* Y, int64_t ldy, int64_t y_lo_off, int M, int hidden, int K,
                             void* stream);
 
+/* Grouped form (MoE experts, modeling_bailing_moe.py:605-639, hundreds of rows in flight): group g multiplies row positions
+ * [off[g], off[g] + cnt[g]) — position r reads A row a_rows[r] when a_rows != NULL (the gather of the expert-sorted order,
+ * done while staging) — by W + g * w_gstride and writes rows off[g].. of C.  A is a bf16 hi/lo pair (a_lo_off > 0).
+ *   swiglu == 0: C fp32 [*, N];   swiglu == 1: W_g holds 2N rows (gate rows, up rows), C = bf16 hi rows [*, N] (ldc) and
+ *   lo rows c_lo_off elements further of silu(gate) * up.   off / cnt: device arrays (mn_moe_sort); cnt[g] <= m_max. */
+int mn_gemm256_grouped(const uint16_t* A, int64_t lda, int64_t a_lo_off, const int32_t* a_rows, const uint16_t* W, int64_t ldw,
+                       int64_t w_gstride, const int32_t* off, const int32_t* cnt, int n_groups, void* C, int64_t ldc,
+                       int64_t c_lo_off, int m_max, int N, int K, int swiglu, void* stream);
+
 /* Weight-streaming MFMA kernel behind the M >= 5 route of mn_skinny_gemm: Y bf16 [2][M][K] (activations split
  * into hi rows then lo rows), W bf16 [Ntot, K] dense, P fp32 [nz][M][Ntot] K-slice partials with
  * nz = mn_stream_mfma_slices(M, Ntot, K) (the launch plan picks slices of 256..1024 k so that every wave of the

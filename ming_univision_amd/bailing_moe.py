@@ -358,11 +358,24 @@ class ImageGenState:
                                     current_stream()), "mn_rows_advance")
 
 
+def split_groups(n_images, n_groups):
+    """Image ranges [(lo, hi), ...] of the lock-step groups: ceil(B / n_groups) images per group and only as many groups as
+    that needs (5 images in 4 groups -> 2 + 2 + 1, never an empty group)."""
+    assert 1 <= n_groups <= n_images
+    per = (n_images + n_groups - 1) // n_groups
+    return [(lo, min(n_images, lo + per)) for lo in range(0, n_images, per)]
+
+
 _STREAM_POOL = {}
 
 
 def _group_streams(device, n):
     """n side streams for lock-step groups (created once per device and reused)."""
+    import os
+    import warnings
+    if n > 2 and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 2 * n:
+        warnings.warn(f"{n} lock-step groups want GPU_MAX_HW_QUEUES >= {2 * n} (set before HIP initialises; the package sets 8 on "
+                      "import): with fewer hardware queues some groups serialise (4 groups: 1447 vs 1686 tokens/s)")
     pool = _STREAM_POOL.setdefault(str(device), [])
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=device))
@@ -429,9 +442,8 @@ def generate_images(dec: BailingMoeDecoder, rf, tok, start_embed, past_lens, att
     rpi = ams[0].shape[0]
     assert all(a.shape[0] == rpi for a in ams), "all images of a batch must have the same number of CFG rows"
     n_tok = cfg.num_image_tokens_for_gen
-    assert 1 <= n_groups <= B
-    per = (B + n_groups - 1) // n_groups                     # images per group
-    n_groups = (B + per - 1) // per                          # e.g. 5 images in 4 groups -> 3 groups of 2 + 2 + 1, no empty group
+    groups = split_groups(B, n_groups)
+    n_groups, per = len(groups), groups[0][1]
     row_cap = min(dec.max_rows(), rf.max_rows(), tok.max_decode_rows() * rpi)
     assert max(past_lens) + n_tok + 1 <= dec.t_max and per * rpi <= row_cap, f"{per * rpi} rows per group > {row_cap}"
     if rpi > 1:   # replicate each prompt's KV to its CFG rows (:1891-1902) — device memcpy
@@ -443,8 +455,7 @@ def generate_images(dec: BailingMoeDecoder, rf, tok, start_embed, past_lens, att
     main = torch.cuda.current_stream()
     streams = [main] if n_groups == 1 else _group_streams(dec.device, n_groups)
     runs = []
-    for g, s in enumerate(streams):
-        lo, hi = g * per, min(B, (g + 1) * per)
+    for (lo, hi), s in zip(groups, streams):
         s.wait_stream(main)
         with torch.cuda.stream(s):
             runs.append(_GroupRun(dec, rf, tok, ams[lo:hi], past_lens[lo:hi], noises[lo:hi], lo * rpi, start_embed, kw,

@@ -422,3 +422,26 @@ extern "C" int mn_gemm256_swiglu_split(const uint16_t* A, int64_t lda, int64_t a
   MN_CHECK_LAUNCH("mn_gemm256_swiglu_split");
   return MN_OK;
 }
+
+// Grouped form (MoE experts; replaces the per-expert loop of modeling_bailing_moe.py:605-639 when hundreds of rows are in
+// flight): group g multiplies rows [off[g], off[g] + cnt[g]) — row position r reads A row a_rows[r] when a_rows is given (the
+// gather of the expert-sorted order, done while staging) — by W + g * w_gstride and writes rows off[g].. of C.
+//   swiglu == 0: C fp32 [*, N] = (A_hi + A_lo) W_g^T
+//   swiglu == 1: W_g holds 2N rows (gate, up); C bf16 hi rows [*, N] and lo rows c_lo_off elements further = silu(gate) * up
+// off / cnt are device arrays (mn_moe_sort); no group may exceed m_max rows.
+extern "C" int mn_gemm256_grouped(const uint16_t* A, int64_t lda, int64_t a_lo_off, const int32_t* a_rows, const uint16_t* W,
+                                  int64_t ldw, int64_t w_gstride, const int32_t* off, const int32_t* cnt, int n_groups, void* C,
+                                  int64_t ldc, int64_t c_lo_off, int m_max, int N, int K, int swiglu, void* stream) {
+  MN_CHECK_ARG(A && W && C && off && cnt && n_groups >= 1 && m_max >= 1 && a_lo_off > 0, "mn_gemm256_grouped: bad args");
+  MN_CHECK_ARG(N >= 4 && (N % 4) == 0 && K >= BK && (K % BK) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && (a_lo_off % 8) == 0 &&
+                   (w_gstride % 8) == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0 && (!swiglu || c_lo_off > 0),
+               "mn_gemm256_grouped: unsupported shape N=%d K=%d", N, K);
+  G256 p{};
+  p.A = A; p.lda = lda; p.a_lo_off = a_lo_off; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.c_lo_off = c_lo_off;
+  p.w_pair_rows = swiglu ? N : 0; p.M = m_max; p.N = N; p.K = K;
+  p.g_off = off; p.g_cnt = cnt; p.w_gstride = w_gstride; p.a_rows = a_rows; p.n_groups = n_groups;
+  const int rc = g256_launch(p, swiglu ? E_SWIGLU_SPLIT : E_F32, 1, mn_stream(stream));
+  if (rc < 0) return rc;
+  MN_CHECK_LAUNCH("mn_gemm256_grouped");
+  return MN_OK;
+}

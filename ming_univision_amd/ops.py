@@ -157,6 +157,72 @@ def gemm_bf16(a, w, bias=None, epilogue="bf16", out=None):
     return out
 
 
+def split_hilo(x):
+    """fp32 [M, K] -> bf16 [2, M, K]: hi rows then lo rows (x = hi + lo to 2^-17), the operand layout of the hi/lo GEMMs."""
+    _req(x, torch.float32, "x")
+    x = x.contiguous()
+    y = torch.empty((2,) + tuple(x.shape), dtype=torch.bfloat16, device=x.device)
+    check(lib().mn_f32_split_bf16(ptr(x), ptr(y[0]), ptr(y[1]), x.numel(), current_stream()), "mn_f32_split_bf16")
+    return y
+
+
+def gemm256(a, w, bias=None, epilogue="bf16", out=None):
+    """Wide-row GEMM (256 x 256 tiles).  a: bf16 [M, K], or a hi/lo pair bf16 [2, M, K] (fp32-class products).
+    w bf16 [N, K] -> bf16 or fp32 [M, N] (f32_resid accumulates into `out`)."""
+    _req(a, torch.bfloat16, "a"); _req(w, torch.bfloat16, "w"); _req(bias, torch.bfloat16, "bias")
+    hilo = a.dim() == 3
+    M, K = a.shape[-2:]
+    N = w.shape[0]
+    assert a.is_contiguous() and w.shape[1] == K and w.stride(1) == 1
+    if out is None:
+        assert epilogue != "f32_resid"
+        out = torch.empty(M, N, dtype=torch.bfloat16 if epilogue.startswith("bf16") else torch.float32, device=a.device)
+    check(lib().mn_gemm256(ptr(a), K, a.stride(0) if hilo else 0, ptr(w), w.stride(0), ptr(bias), ptr(out), out.stride(0), M, N, K,
+                           GEMM_EPI[epilogue], current_stream()), "mn_gemm256")
+    return out
+
+
+def gemm256_splitk(a2, w, bias, ksplit):
+    """Split-K form on a hi/lo pair a2 bf16 [2, M, K]: returns the fp32 partial slabs [nz, M, N] (bias in slab 0)."""
+    _req(a2, torch.bfloat16, "a2"); _req(w, torch.bfloat16, "w"); _req(bias, torch.bfloat16, "bias")
+    _, M, K = a2.shape
+    N = w.shape[0]
+    P = torch.empty(max(1, ksplit), M, N, dtype=torch.float32, device=a2.device)
+    nz = lib().mn_gemm256_splitk(ptr(a2), K, a2.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(P), M, N, K, ksplit, current_stream())
+    if nz < 0:
+        check(nz, "mn_gemm256_splitk")
+    return P[:nz]
+
+
+def gemm256_swiglu_split(a2, w12, b12=None):
+    """a2 bf16 [2, M, K] hi/lo pair; w12 bf16 [2 * hidden, K] -> bf16 [2, M, hidden] hi/lo pair of silu(gate) * up."""
+    _req(a2, torch.bfloat16, "a2"); _req(w12, torch.bfloat16, "w12"); _req(b12, torch.bfloat16, "b12")
+    _, M, K = a2.shape
+    hidden = w12.shape[0] // 2
+    y = torch.empty(2, M, hidden, dtype=torch.bfloat16, device=a2.device)
+    check(lib().mn_gemm256_swiglu_split(ptr(a2), K, a2.stride(0), ptr(w12), w12.stride(0), ptr(b12), ptr(y), hidden, y.stride(0), M,
+                                        hidden, K, current_stream()), "mn_gemm256_swiglu_split")
+    return y
+
+
+def gemm256_grouped(a2, a_rows, w, off, cnt, n_pos, m_max, swiglu):
+    """Grouped (MoE) form: a2 bf16 [2, R, K] hi/lo pair; a_rows int32 [n_pos] or None; w bf16 [G, N or 2N, K];
+    off / cnt int32 device arrays.  Returns fp32 [n_pos, N] or the bf16 hi/lo pair [2, n_pos, N] (swiglu)."""
+    _req(a2, torch.bfloat16, "a2"); _req(w, torch.bfloat16, "w"); _req(off, torch.int32, "off"); _req(cnt, torch.int32, "cnt")
+    _req(a_rows, torch.int32, "a_rows")
+    G, NW, K = w.shape
+    N = NW // 2 if swiglu else NW
+    if swiglu:
+        out = torch.zeros(2, n_pos, N, dtype=torch.bfloat16, device=a2.device)
+        lo_off = out.stride(0)
+    else:
+        out = torch.zeros(n_pos, N, dtype=torch.float32, device=a2.device)
+        lo_off = 0
+    check(lib().mn_gemm256_grouped(ptr(a2), K, a2.stride(0), ptr(a_rows), ptr(w), K, w.stride(0), ptr(off), ptr(cnt), G, ptr(out), N,
+                                   lo_off, m_max, N, K, int(swiglu), current_stream()), "mn_gemm256_grouped")
+    return out
+
+
 def layernorm_bf16(x, g, b, eps=1e-6, gelu=False):
     _req(x, torch.float32, "x"); _req(g, torch.bfloat16, "g"); _req(b, torch.bfloat16, "b")
     M, D = x.shape

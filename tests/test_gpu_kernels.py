@@ -318,3 +318,76 @@ def test_rope3d_kv_append(ops):
     qo = ops.rope_kv_append(qkv.cuda(), nq, nkv, hd, kv, row_seq, row_slot, pos3[0].reshape(M).to(torch.int32).cuda(), cos, sin,
                             q_scale=0.5)
     assert rel(qo, torch.from_numpy(z["q_same"]).permute(0, 2, 1, 3).reshape(M, nq * hd) * 0.5) < 1e-6
+
+
+# ---- wide-row GEMM (gemm256.hip): 256 x 256 tiles, hi/lo rows, fused SwiGLU + split, split-K, grouped + gathered ----
+@pytest.mark.parametrize("M,N,K", [(300, 1000, 192), (1, 4, 64), (257, 260, 128), (4160, 2304, 768)])
+def test_gemm256_plain_epilogues(ops, M, N, K):
+    a = rnd(M, K, seed=21).to(torch.bfloat16)
+    w, wf = bw(N, K, seed=22, scale=K ** -0.5)
+    b, bf = bw(N, seed=23)
+    ref = a.double() @ wf.double().T + bf.double()
+    assert rel(ops.gemm256(a.cuda(), w, b, "f32"), ref) < 1e-5
+    assert rel(ops.gemm256(a.cuda(), w, b, "bf16"), ref) < 2 ** -8
+    assert rel(ops.gemm256(a.cuda(), w, b, "bf16_gelu"), F.gelu(ref)) < 2 ** -8
+    r0 = rnd(M, N, seed=24)
+    out = r0.cuda().clone()
+    ops.gemm256(a.cuda(), w, b, "f32_resid", out=out)
+    assert rel(out, r0.double() + ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 516, 1024), (130, 64, 3072), (1100, 260, 192)])
+def test_gemm256_hilo_and_splitk(ops, M, N, K):
+    x = rnd(M, K, seed=25)
+    w, wf = bw(N, K, seed=26, scale=K ** -0.5)
+    b, bf = bw(N, seed=27)
+    a2 = ops.split_hilo(x.cuda())
+    xr = a2[0].double().cpu() + a2[1].double().cpu()
+    assert rel(xr, x) < 2 ** -16                                      # the operand itself: x = hi + lo to 2^-17
+    ref = xr @ wf.double().T + bf.double()
+    assert rel(ops.gemm256(a2, w, b, "f32"), ref) < 1e-5
+    for ks in (1, 2, 3, 8):
+        P = ops.gemm256_splitk(a2, w, b, ks)
+        assert 1 <= P.shape[0] <= ks
+        assert rel(P.double().sum(0), ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,hidden,K", [(130, 200, 256), (512, 2752, 1024), (96, 1408, 2048)])
+def test_gemm256_swiglu_split(ops, M, hidden, K):
+    x = rnd(M, K, seed=28)
+    w, wf = bw(2 * hidden, K, seed=29, scale=K ** -0.5)
+    b, bf = bw(2 * hidden, seed=30, scale=0.1)
+    a2 = ops.split_hilo(x.cuda())
+    xr = a2[0].double().cpu() + a2[1].double().cpu()
+    r = xr @ wf.double().T + bf.double()
+    ref = F.silu(r[:, :hidden]) * r[:, hidden:]
+    y = ops.gemm256_swiglu_split(a2, w, b)
+    assert rel(y[0].double() + y[1].double(), ref) < 3e-5            # the result is itself a hi/lo pair (2^-17)
+    y = ops.gemm256_swiglu_split(a2, w, None)
+    r = xr @ wf.double().T
+    assert rel(y[0].double() + y[1].double(), F.silu(r[:, :hidden]) * r[:, hidden:]) < 3e-5
+
+
+@pytest.mark.parametrize("gather", [True, False])
+def test_gemm256_grouped(ops, gather):
+    G, K, N, R = 6, 256, 132, 150
+    counts = [0, 7, 128, 300, 1, 129]                               # empty group, one row, exact tile, several tiles, tile + 1
+    n_pos = sum(counts)
+    off = torch.tensor([sum(counts[:g]) for g in range(G + 1)], dtype=torch.int32)
+    cnt = torch.tensor(counts, dtype=torch.int32)
+    x = rnd(R if gather else n_pos, K, seed=31)
+    g = torch.Generator().manual_seed(32)
+    rows = torch.randint(0, R, (n_pos,), generator=g, dtype=torch.int32) if gather else None
+    a2 = ops.split_hilo(x.cuda())
+    xr = a2[0].double().cpu() + a2[1].double().cpu()
+    xs = xr[rows.long()] if gather else xr
+    for swiglu in (False, True):
+        w, wf = bw(G, 2 * N if swiglu else N, K, seed=33 + swiglu, scale=K ** -0.5)
+        out = ops.gemm256_grouped(a2, None if rows is None else rows.cuda(), w, off.cuda(), cnt.cuda(), n_pos, max(counts), swiglu)
+        ref = torch.zeros(n_pos, N, dtype=torch.float64)
+        for gi in range(G):
+            lo, hi = int(off[gi]), int(off[gi]) + counts[gi]
+            r = xs[lo:hi] @ wf[gi].double().T
+            ref[lo:hi] = F.silu(r[:, :N]) * r[:, N:] if swiglu else r
+        got = out[0].double() + out[1].double() if swiglu else out
+        assert rel(got, ref) < 3e-5

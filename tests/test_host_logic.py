@@ -82,6 +82,17 @@ def test_build_cfg_rows_matches_reference_masks():
     assert am.shape == (2, g["mask"].shape[1]) and torch.equal(am[1, 6:], g["mask"][0, 6:])
 
 
+def test_lockstep_group_split_has_no_empty_group():
+    from ming_univision_amd.bailing_moe import split_groups
+    for B in range(1, 40):
+        for n in range(1, B + 1):
+            gs = split_groups(B, n)
+            assert len(gs) <= n and gs[0][0] == 0 and gs[-1][1] == B
+            assert all(lo < hi for lo, hi in gs) and all(a[1] == b[0] for a, b in zip(gs, gs[1:]))
+            assert max(hi - lo for lo, hi in gs) == -(-B // n)
+    assert split_groups(5, 4) == [(0, 2), (2, 4), (4, 5)] and split_groups(9, 4) == [(0, 3), (3, 6), (6, 9)]
+
+
 def test_config_shapes_and_sizes():
     cfg = C.MingUniVisionConfig.ming_univision_16b_a3b()
     n_llm = sum(int(torch.tensor(s).prod()) for s in C.llm_param_shapes(cfg.llm_config).values())
@@ -160,9 +171,13 @@ g.close()
 def test_replica_group_world2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    import socket
+    with socket.socket() as sk:                    # a free port, so concurrent jobs / stale workers cannot collide
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
