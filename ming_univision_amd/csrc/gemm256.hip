@@ -25,6 +25,11 @@
 //     last read.
 //   * SCHED 0: same tile, one barrier per K-tile (all four half-tiles of the next K-tile issued up front, vmcnt(0)
 //     before the barrier) — the simple reference schedule the A/B tool compares against.
+//   * Rejected after measurement (tools/ab_gemm256.py, MI355X): the 32x32x16 MFMA in the same schedule (1048 vs 1243
+//     TFLOP/s at 4096^3: a quadrant phase then has two independent accumulators for a 64-cycle MFMA); a one-wave-per-SIMD
+//     form (4 waves x 128x128, 256 AGPR accumulators pinned by inline-asm MFMAs, double-buffered fragments, one barrier per
+//     K-tile): +5..9 % on plain bf16 problems (1263 vs 1154 at 4096^3) but 0.65-0.78x on the hi/lo F32 / SwiGLU problems that
+//     dominate this path — four waves carry the whole epilogue and hipcc spills 86 dwords per lane there.
 //   * The MFMA takes the W fragment as its A operand and the activation fragment as B, so a lane's 4 accumulator
 //     registers are 4 CONSECUTIVE output columns of one row: 16-byte fp32 / 8-byte bf16 stores.
 //
@@ -301,6 +306,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
     }
   }
 }
+
 
 }  // namespace
 

@@ -101,6 +101,10 @@ def test_full_width_generate_image_vs_oracle(full, rows_tag):
     outw = generate_images(decw, rf, tok, decw.embed(torch.tensor([cfg.image_start_token]).cuda()), [T] * Bw, [am] * Bw, [un] * Bw,
                            [tu] * Bw, nw.cuda(), decode_pixels=False, n_groups=1)
     assert torch.isfinite(outw["latents"]).all()
+    print("wide route vs oracle:", rows_tag, "latents %.2e sem %.2e hidden %.2e" % (
+        rel_err(outw["latents"][0], ref["latents"][:, 0]), rel_err(outw["sem"][0], ref["sem"][0]),
+        rel_err(outw["last_hidden"][:R], ref["last_hidden"][:, 0])), "| narrow: latents %.2e hidden %.2e" % (
+        rel_err(outb["latents"][0], ref["latents"][:, 0]), rel_err(outb["last_hidden"][:R], ref["last_hidden"][:, 0])))
     assert rel_err(outw["latents"][0], ref["latents"][:, 0]) < TOL
     assert rel_err(outw["sem"][0], ref["sem"][0]) < TOL
     assert rel_err(outw["last_hidden"][:R], ref["last_hidden"][:, 0]) < TOL
