@@ -7,7 +7,7 @@ Workload (BASELINE.json configs[3], the configuration the metric is quoted on; f
   tokens: per token one 28-layer MoE step over the CFG rows, the 16-step rectified-flow SwiGLU
   sampler, one cached semantic-decoder step + linear_proj; then the 24-layer pixel decoder.
   A "step" = one batch of images generated in lock-step (prompt prefill + 257 LLM steps + 256 samplers + pixel
-  decode); default 512 images = 1024 CFG rows in one group, the wide route.
+  decode); default 768 images = 1536 CFG rows in one group, the wide route.
 
 One process per GPU (independent prompts per rank = replicas, no data-path collective: the path
 is a strictly sequential AR chain per image).  Prints ONE JSON line on rank 0.
@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tokens", type=int, default=256, help="visual tokens per image (256 = 512^2)")
     ap.add_argument("--prompt-len", type=int, default=40)
-    ap.add_argument("--images", type=int, default=512,
+    ap.add_argument("--images", type=int, default=768,
                     help="images generated in lock-step per GPU (an image batch; 1 = the reference's batch-size-1 call). More than "
                          "32 images per group (64 CFG rows) take the wide route: every Linear a 256x256-tile MFMA GEMM")
     ap.add_argument("--groups", type=int, default=1,
@@ -80,7 +80,7 @@ def build_models(args, device, seed):
         rf_cfg = dict(C.DEFAULT_VISHEAD_DIFFLOSS)
         tcfg = C.MingTokConfig()
     t_max = args.prompt_len + args.tokens + 8
-    dec = BailingMoeDecoder.synthetic(cfg, device, seed=seed, t_max=t_max, n_seq=3 * args.images)
+    dec = BailingMoeDecoder.synthetic(cfg, device, seed=seed, t_max=t_max, n_seq=max(2, args.cfg_rows) * args.images)
     full = C.llm_param_shapes(cfg, rf_cfg, 32)
     rf_sd = {k: synth_tensor(k, s, seed, device, torch.bfloat16) for k, s in full.items()
              if k.startswith("vis_head") or k.startswith("diffloss")}
@@ -354,13 +354,31 @@ def main():
         }
         if batch1 is not None:
             res["batch1"] = batch1
-        # whole-token HBM accounting: bytes that must cross HBM per visual token / measured time per token
+        # whole-token accounting
         ada_bytes = rf.t["ada_w"].numel() * 2          # read once per token (all steps in one GEMM)
-        tok_bytes = (rf.steps * (rf.weight_bytes_per_step() - ada_bytes) + ada_bytes
-                     + dec.weight_bytes_active(min(64, 6 * rows * per_group)) + 0.61e9)
-        # every group streams the weights once per lock-step token
-        res["token_level"] = {"algorithmic_GB_per_group_token": tok_bytes / 1e9, "groups": args.groups,
-                              "achieved_GBs": args.groups * tok_bytes / (dt / (args.tokens * args.steps)) / 1e9}
+        sec_per_token = dt / (args.tokens * args.steps)
+        if rows * per_group > 64:
+            # wide route (MFMA-bound): algorithmic flops of one image-token = 2 x (parameters each row multiplies), CFG rows
+            # included; the kernels issue twice that on the matrix cores (bf16 hi + lo activation halves)
+            A = rf.t["ada_w"].shape[0]
+            rf_row = 2.0 * (rf.steps * rf.depth * 3 * rf.hidden * rf.w + rf.steps * A * rf.w + rf.w * (cfg.hidden_size + rf.w)
+                            + rf.steps * 2 * rf.target * rf.w)
+            c = dec.cfg
+            llm_row = 2.0 * c.num_hidden_layers * ((c.num_attention_heads + 2 * c.num_key_value_heads) * c.head_dim * c.hidden_size
+                                                   + c.num_attention_heads * c.head_dim * c.hidden_size + c.num_experts * c.hidden_size
+                                                   + (c.num_experts_per_tok + dec.n_shared) * 3 * c.moe_intermediate_size * c.hidden_size)
+            sem_img = 2.0 * 303.0e6
+            per_image_token = rows * (rf_row + llm_row) + sem_img
+            res["token_level"] = {"algorithmic_GFLOP_per_image_token": per_image_token / 1e9,
+                                  "achieved_TFLOPs": per_image_token * args.images / sec_per_token / 1e12,
+                                  "mfma_issued_TFLOPs": 2 * per_image_token * args.images / sec_per_token / 1e12,
+                                  "ms_per_lockstep_token": sec_per_token * 1e3}
+        else:
+            tok_bytes = (rf.steps * (rf.weight_bytes_per_step() - ada_bytes) + ada_bytes
+                         + dec.weight_bytes_active(min(64, 6 * rows * per_group)) + 0.61e9)
+            # every group streams the weights once per lock-step token
+            res["token_level"] = {"algorithmic_GB_per_group_token": tok_bytes / 1e9, "groups": args.groups,
+                                  "achieved_GBs": args.groups * tok_bytes / sec_per_token / 1e9}
         if not args.no_cpu_baseline and not args.tiny:
             try:
                 res["cpu_baseline"] = cpu_baseline(args, rows)
