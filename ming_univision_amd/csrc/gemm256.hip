@@ -30,6 +30,9 @@
 //     form (4 waves x 128x128, 256 AGPR accumulators pinned by inline-asm MFMAs, double-buffered fragments, one barrier per
 //     K-tile): +5..9 % on plain bf16 problems (1263 vs 1154 at 4096^3) but 0.65-0.78x on the hi/lo F32 / SwiGLU problems that
 //     dominate this path — four waves carry the whole epilogue and hipcc spills 86 dwords per lane there.
+//     A persistent tile loop whose LDS pipeline runs across output tiles (the next tile's first half-tiles issued during
+//     the last phases and the epilogue of the current one) measured within +-1.5 % of the plain grid (adaLN 4589 vs 4646 us,
+//     w12 at 1024 rows 177 vs 163 us): the dispatcher already starts the next workgroup's prologue while others compute.
 //   * The MFMA takes the W fragment as its A operand and the activation fragment as B, so a lane's 4 accumulator
 //     registers are 4 CONSECUTIVE output columns of one row: 16-byte fp32 / 8-byte bf16 stores.
 //
@@ -70,6 +73,82 @@ __device__ __forceinline__ void wait_vm() {
   static_assert(N == 0 || N == 8, "counts used by the schedules");
   if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+// per-lane byte offsets (from A / W) of the global row behind LDS row L = 16*wave + 8*q + (lane >> 3) of half h, with
+// the k-slot swizzle (lane & 7) ^ f(L), f(row) = (row >> 1) & 7, folded in.  All offsets fit 32 bits (host check).
+template <bool HILO, bool PAIRED>
+__device__ __forceinline__ void g256_src_offsets(const G256& p, int wave, int lane, int m0, int n0, int row0, int Mg, int kbeg,
+                                                 uint32_t (&srcA)[2][2], uint32_t (&srcW)[2][2]) {
+  const int rin = lane >> 3;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int L = wave * 16 + q * 8 + rin;
+      const int ks = ((lane & 7) ^ ((L >> 1) & 7)) * 16;
+      int gm, gn;
+      if (HILO) gm = m0 + L;                                      // half = hi / lo part of the same rows
+      else gm = m0 + (L >> 6) * 128 + h * 64 + (L & 63);          // wave row L / 64, fragment half h
+      gm = row0 + min(gm, Mg - 1);
+      if (p.a_rows) gm = p.a_rows[gm];
+      if (PAIRED) gn = min(n0 + L, p.N - 1) + (h ? (int)p.w_pair_rows : 0);
+      else gn = min(n0 + (L >> 5) * 64 + h * 32 + (L & 31), p.N - 1);
+      srcA[h][q] = (uint32_t)(((int64_t)gm * p.lda + (HILO && h ? p.a_lo_off : 0) + kbeg) * 2 + ks);
+      srcW[h][q] = (uint32_t)(((int64_t)gn * p.ldw + kbeg) * 2 + ks);
+    }
+}
+
+// Epilogue of one output tile.  A lane holds, per (i, j), output row 16 i + fr and the 4 CONSECUTIVE columns 16 j + 4 fq .. +3.
+template <int EPI, bool HILO>
+__device__ __forceinline__ void g256_epilogue(const G256& p, const f32x4 (&acc)[8][4], int wr, int wc, int fr, int fq, int m0,
+                                              int n0, int row0, int Mg, int zslice) {
+  constexpr bool hilo = HILO, paired = EPI == E_SWIGLU_SPLIT;
+  char* Cz = reinterpret_cast<char*>(p.C);
+  if (EPI == E_F32) Cz += (int64_t)zslice * p.c_zstride * 4;
+  constexpr int mi_n = hilo ? 4 : 8, nj_n = paired ? 2 : 4;
+#pragma unroll
+  for (int i = 0; i < mi_n; ++i) {
+    const int ml = hilo ? m0 + wr * 64 + i * 16 + fr : m0 + wr * 128 + i * 16 + fr;
+#pragma unroll
+    for (int j = 0; j < nj_n; ++j) {
+      const int n = paired ? n0 + wc * 32 + j * 16 + fq * 4 : n0 + wc * 64 + j * 16 + fq * 4;
+      if (ml >= Mg || n >= p.N) continue;           // N % 4 == 0 (host check): the 4 columns are all in or all out
+      f32x4 v = acc[i][j];
+      if (hilo) v += acc[(i + 4) & 7][j];
+      f32x4 u = {0.f, 0.f, 0.f, 0.f};
+      if (paired) { u = acc[i][(j + 2) & 3]; if (hilo) u += acc[(i + 4) & 7][(j + 2) & 3]; }
+      const int m = row0 + ml;
+      if (p.bias && zslice == 0) {
+        const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
+        v += f32x4{bf16lo_to_f32(b.x), bf16hi_to_f32(b.x), bf16lo_to_f32(b.y), bf16hi_to_f32(b.y)};
+        if (paired) {
+          const u32x2 b2 = *reinterpret_cast<const u32x2*>(p.bias + p.w_pair_rows + n);
+          u += f32x4{bf16lo_to_f32(b2.x), bf16hi_to_f32(b2.x), bf16lo_to_f32(b2.y), bf16hi_to_f32(b2.y)};
+        }
+      }
+      if (EPI == E_F32) {
+        *reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4) = v;
+      } else if (EPI == E_F32_RESID) {
+        f32x4* c = reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4);
+        *c += v;
+      } else if (EPI == E_F32_RESID_GATE) {
+        f32x4* c = reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(p.gate + (int64_t)m * p.ldgate + n);
+        *c += g * v;
+      } else if (EPI == E_BF16 || EPI == E_BF16_GELU) {
+        if (EPI == E_BF16_GELU) v = f32x4{gelu_erf_f(v.x), gelu_erf_f(v.y), gelu_erf_f(v.z), gelu_erf_f(v.w)};
+        *reinterpret_cast<u32x2*>(Cz + ((int64_t)m * p.ldc + n) * 2) = u32x2{cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w)};
+      } else {  // E_SWIGLU_SPLIT: y = silu(gate) * up, stored as bf16 hi rows and lo rows
+        uint32_t h0, l0, h1, l1;
+        split_pk_bf16(silu_f(v.x) * u.x, silu_f(v.y) * u.y, h0, l0);
+        split_pk_bf16(silu_f(v.z) * u.z, silu_f(v.w) * u.w, h1, l1);
+        bf16_t* c = reinterpret_cast<bf16_t*>(Cz) + (int64_t)m * p.ldc + n;
+        *reinterpret_cast<u32x2*>(c) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(c + p.c_lo_off) = u32x2{l0, l1};
+      }
+    }
+  }
 }
 
 template <int EPI, int SCHED, bool HILO>
@@ -116,29 +195,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   const int nk = (kend - kbeg) / BK;
 
   // ---- staging: wave w fills LDS rows [16w, 16w+16) of a half-tile with two instructions of 8 rows x 8 slots ----
-  // per-lane byte offsets (from A / W) of the global row behind LDS row L = 16*wave + 8*q + (lane >> 3) of half h,
-  // with the k-slot swizzle (lane & 7) ^ f(L), f(row) = (row >> 1) & 7, folded in (conflict-free for the 16-row fragments
-  // of the 16x16x32 MFMA and the 32-row fragments of the 32x32x16 MFMA alike).  All offsets fit 32 bits (host check).
   uint32_t srcA[2][2], srcW[2][2];
-  {
-    const int rin = lane >> 3;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int L = wave * 16 + q * 8 + rin;
-        const int ks = ((lane & 7) ^ ((L >> 1) & 7)) * 16;         // k-slot swizzle f(row) = (row >> 1) & 7
-        int gm, gn;
-        if (hilo) gm = m0 + L;                                      // half = hi / lo part of the same rows
-        else gm = m0 + (L >> 6) * 128 + h * 64 + (L & 63);          // wave row L / 64, fragment half h
-        gm = row0 + min(gm, Mg - 1);
-        if (p.a_rows) gm = p.a_rows[gm];
-        if (paired) gn = min(n0 + L, p.N - 1) + (h ? (int)p.w_pair_rows : 0);
-        else gn = min(n0 + (L >> 5) * 64 + h * 32 + (L & 31), p.N - 1);
-        srcA[h][q] = (uint32_t)(((int64_t)gm * p.lda + (hilo && h ? p.a_lo_off : 0) + kbeg) * 2 + ks);
-        srcW[h][q] = (uint32_t)(((int64_t)gn * p.ldw + kbeg) * 2 + ks);
-      }
-  }
+  g256_src_offsets<hilo, paired>(p, wave, lane, m0, n0, row0, Mg, kbeg, srcA, srcW);
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Wb = reinterpret_cast<const char*>(p.W) + (int64_t)grp * p.w_gstride * 2;
   auto stage = [&](int op, int h, int kt, int buf) {   // op 0 = A, 1 = W; all arguments compile-time or wave-uniform
@@ -252,59 +310,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
     if (wr == 0) __builtin_amdgcn_s_barrier();
   }
 
-  // ---- epilogue ----
-  // emit(row-in-tile ml, first column n, v[4], u[4]): 4 CONSECUTIVE columns n..n+3 of one output row (u: the paired up half)
-  char* Cz = reinterpret_cast<char*>(p.C);
-  if (EPI == E_F32) Cz += (int64_t)blockIdx.y * p.c_zstride * 4;
-  auto emit = [&](int ml, int n, f32x4 v, f32x4 u) {
-    if (ml >= Mg || n >= p.N) return;             // N % 4 == 0 (host check): the 4 columns are all in or all out
-    const int m = row0 + ml;
-    if (p.bias && blockIdx.y == 0) {
-      const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
-      v += f32x4{bf16lo_to_f32(b.x), bf16hi_to_f32(b.x), bf16lo_to_f32(b.y), bf16hi_to_f32(b.y)};
-      if (paired) {
-        const u32x2 b2 = *reinterpret_cast<const u32x2*>(p.bias + p.w_pair_rows + n);
-        u += f32x4{bf16lo_to_f32(b2.x), bf16hi_to_f32(b2.x), bf16lo_to_f32(b2.y), bf16hi_to_f32(b2.y)};
-      }
-    }
-    if (EPI == E_F32) {
-      *reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4) = v;
-    } else if (EPI == E_F32_RESID) {
-      f32x4* c = reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4);
-      *c += v;
-    } else if (EPI == E_F32_RESID_GATE) {
-      f32x4* c = reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4);
-      const f32x4 g = *reinterpret_cast<const f32x4*>(p.gate + (int64_t)m * p.ldgate + n);
-      *c += g * v;
-    } else if (EPI == E_BF16 || EPI == E_BF16_GELU) {
-      if (EPI == E_BF16_GELU) v = f32x4{gelu_erf_f(v.x), gelu_erf_f(v.y), gelu_erf_f(v.z), gelu_erf_f(v.w)};
-      *reinterpret_cast<u32x2*>(Cz + ((int64_t)m * p.ldc + n) * 2) = u32x2{cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w)};
-    } else {  // E_SWIGLU_SPLIT: y = silu(gate) * up, stored as bf16 hi rows and lo rows
-      uint32_t h0, l0, h1, l1;
-      split_pk_bf16(silu_f(v.x) * u.x, silu_f(v.y) * u.y, h0, l0);
-      split_pk_bf16(silu_f(v.z) * u.z, silu_f(v.w) * u.w, h1, l1);
-      bf16_t* c = reinterpret_cast<bf16_t*>(Cz) + (int64_t)m * p.ldc + n;
-      *reinterpret_cast<u32x2*>(c) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(c + p.c_lo_off) = u32x2{l0, l1};
-    }
-  };
-  {
-    // lane holds, per (i, j), row 16 i + fr and columns 16 j + 4 fq .. +3
-    constexpr int mi_n = hilo ? 4 : 8, nj_n = paired ? 2 : 4;
-#pragma unroll
-    for (int i = 0; i < mi_n; ++i) {
-      const int ml = hilo ? m0 + wr * 64 + i * 16 + fr : m0 + wr * 128 + i * 16 + fr;
-#pragma unroll
-      for (int j = 0; j < nj_n; ++j) {
-        const int n = paired ? n0 + wc * 32 + j * 16 + fq * 4 : n0 + wc * 64 + j * 16 + fq * 4;
-        f32x4 v = acc[i][j];
-        if (hilo) v += acc[(i + 4) & 7][j];
-        f32x4 u = {0.f, 0.f, 0.f, 0.f};
-        if (paired) { u = acc[i][(j + 2) & 3]; if (hilo) u += acc[(i + 4) & 7][(j + 2) & 3]; }
-        emit(ml, n, v, u);
-      }
-    }
-  }
+  g256_epilogue<EPI, HILO>(p, acc, wr, wc, fr, fq, m0, n0, row0, Mg, blockIdx.y);
 }
 
 
