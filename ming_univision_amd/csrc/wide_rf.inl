@@ -16,12 +16,23 @@ struct RfWideWs {
   int ks3, ksf;          // split-K requests of the w3 and final GEMMs
 };
 
-static int rf_wide_ksplit(int rows, int N, int K) {   // fill ~256 CUs with (row tiles x column tiles x K slices)
-  const int tiles = (int)(mn_cdiv(rows, 128) * mn_cdiv(N, 256));
-  int ks = 256 / tiles;
+// Split-K request of a hi/lo GEMM with `rows` rows: minimise a small cost model of the launch — rounds of workgroups over the
+// 256 CUs x (K-tiles per slice at ~1.9 us each + ~10 us of prologue / epilogue) + the fp32 slab round trip through HBM
+// (written by the GEMM, read by the consumer) — over the slice counts that keep >= 4 K-tiles per slice.  E.g. RF w3
+// (N = 3072, K = 8192): 1024 rows -> 96 tiles -> 2 slices (192 workgroups, one round); 1536 rows -> 144 tiles -> 3 slices
+// (432 workgroups, two rounds of 43 K-tiles instead of one round of 128 on 56 % of the chip).
+static int rf_wide_ksplit(int rows, int N, int K) {
+  const double tiles = (double)(mn_cdiv(rows, 128) * mn_cdiv(N, 256));
   const int kt = K / 64;
-  if (ks > kt / 4) ks = kt / 4;                        // >= 4 K-tiles per slice
-  return ks < 1 ? 1 : ks;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int ks = 1; ks <= 16 && kt / ks >= 4; ++ks) {
+    const double rounds = (double)mn_cdiv((int64_t)(tiles * ks), 256);
+    const double slabs = ks > 1 ? (double)ks * rows * N * 8.0 / 4.0e6 : 0.0;      // us at ~4 TB/s, write + read
+    const double cost = rounds * ((double)mn_cdiv(kt, ks) * 1.9 + 10.0) + slabs;
+    if (cost < best_cost) { best_cost = cost; best = ks; }
+  }
+  return best;
 }
 
 static size_t rf_wide_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, RfWideWs* o) {

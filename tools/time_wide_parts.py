@@ -6,7 +6,7 @@ import torch
 import bench
 ap = argparse.ArgumentParser(); ap.add_argument("--images", type=int, default=512); ap.add_argument("--layers", type=int, default=None)
 a = ap.parse_args()
-args = argparse.Namespace(tiny=False, tokens=256, layers=a.layers, prompt_len=40, images=a.images)
+args = argparse.Namespace(tiny=False, tokens=256, layers=a.layers, prompt_len=40, images=a.images, cfg_rows=2)
 dev = torch.device("cuda", 0)
 cfg, dec, rf, tok = bench.build_models(args, dev, 0)
 B, R = a.images, 2 * a.images
