@@ -228,6 +228,32 @@ class BailingMoeDecoder:
             self.step(x[r0:r1], seq[r0:r1].contiguous(), sl, sl, (sl + 1).contiguous(), None, None, out=out[r0:r1])
         return out.reshape(B, T, H)
 
+    def ensure_sequences(self, n_seq):
+        """Grow the KV arena to hold `n_seq` cache sequences (contents of the existing ones are kept)."""
+        if n_seq <= self.n_seq:
+            return
+        kv = torch.zeros((self.kv_cache.shape[0], n_seq) + tuple(self.kv_cache.shape[2:]), dtype=torch.float32, device=self.device)
+        kv[:, :self.n_seq] = self.kv_cache
+        self.kv_cache, self.n_seq = kv, n_seq
+
+    def prefill_ragged(self, embeds_list, seqs, past=0):
+        """Causal prefill of several sequences of DIFFERENT lengths in shared passes through the stack: embeds_list[i] fp32
+        [T_i, H] goes to cache sequence seqs[i] from slot `past`.  Returns the last-token hidden state of each, [B, H]."""
+        dev = self.device
+        lens = [int(e.shape[0]) for e in embeds_list]
+        assert len(seqs) == len(lens) and past + max(lens) <= self.t_max
+        x = torch.cat([e.to(dev, torch.float32) for e in embeds_list], 0).contiguous()
+        seq = torch.cat([torch.full((n,), s, dtype=torch.int32) for n, s in zip(lens, seqs)]).to(dev)
+        slot = torch.cat([torch.arange(past, past + n, dtype=torch.int32) for n in lens]).to(dev)
+        out = torch.empty(x.shape[0], x.shape[1], dtype=torch.float32, device=dev)
+        step = self.max_rows()
+        for r0 in range(0, x.shape[0], step):
+            r1 = min(x.shape[0], r0 + step)
+            sl = slot[r0:r1].contiguous()
+            self.step(x[r0:r1], seq[r0:r1].contiguous(), sl, sl, (sl + 1).contiguous(), None, None, out=out[r0:r1])
+        last = torch.tensor(lens).cumsum(0) - 1
+        return out[last.to(dev)]
+
     def prefill_mfma(self, embeds, seq=0, past=0, image_mask=None, positions=None, key_mask=None):
         """Causal prefill of ONE sequence for long prompts on the bf16 MFMA path: per layer
         RMSNorm -> QKV GEMM -> RoPE + KV append -> GQA flash attention (hd 128) -> dense GEMM (+residual) ->
@@ -301,6 +327,9 @@ class BailingMoeDecoder:
 
     def logits(self, hidden):
         """lm_head -> fp32 logits (compute_logit, :1604-1620, norm_head=False)."""
+        if hidden.shape[0] > MAX_ROWS and lib().mn_gemm256_supported(hidden.shape[1], 8, self.lm_head.stride(0), self.lm_head.shape[0],
+                                                                     hidden.shape[0], self.lm_head.shape[0], hidden.shape[1]):
+            return ops.gemm256(ops.split_hilo(hidden.contiguous()), self.lm_head, None, "f32")    # many rows: one MFMA GEMM
         outs = [ops.skinny_gemm(hidden[i:i + 8].contiguous(), self.lm_head) for i in range(0, hidden.shape[0], 8)]
         return torch.cat(outs, 0)
 

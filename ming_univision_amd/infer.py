@@ -96,5 +96,16 @@ class MingUniVisionInfer:
         trimmed = [out_ids[len(in_ids):] for in_ids, out_ids in zip(inputs["input_ids"], generated_ids)]
         return self.processor.batch_decode(trimmed, skip_special_tokens=True, clean_up_tokenization_spaces=False)[0]
 
+    def generate_batch(self, messages_list, output_image_prefixes=None, **kw):
+        """Extension: B independent text->image conversations generated in lock-step (one pass of every weight serves all of
+        them; > 32 images take the wide MFMA route).  Same chat template / processor as `generate`; returns the PNG names."""
+        reqs = []
+        for messages in messages_list:
+            text = self.processor.apply_chat_template(messages, tokenize=False, add_generation_prompt=True, use_system=True)
+            reqs.append(self.processor(text=[text], images=None, return_tensors="pt", image_patch_size=self.model.vision.patch_size,
+                                       for_edit=False))
+        with torch.no_grad():
+            return self.model.generate_image_batch(reqs, output_image_prefixes=output_image_prefixes, **kw)["files"]
+
     def reset_inner_state(self):
         self.model.reset_inner_state()

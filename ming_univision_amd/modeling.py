@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import ops
-from .bailing_moe import BailingMoeDecoder, generate_image
+from .bailing_moe import BailingMoeDecoder, build_cfg_rows, generate_image, generate_images
 from .configuration import MingUniVisionConfig, linear_proj_param_shapes, llm_param_shapes
 from .mingtok import MingTok
 from .rf_head import RectifiedFlowHead
@@ -101,6 +101,56 @@ class MingUniVisionForConditionalGeneration:
         out = inputs_embeds.clone()
         out[sel.to(out.device)] = vision_embeds.reshape(n_feat, -1).to(out.dtype)
         return out, sel
+
+    # ---- batched text -> image (extension: the reference generates one image per call, modeling_bailing_moe.py:1865) ------
+    @torch.no_grad()
+    def generate_image_batch(self, requests, output_image_prefixes=None, forced_first_token=None, n_groups=1, noises=None,
+                             image_gen_temperature=1.0, save=True):
+        """B independent single-round text->image requests advanced in lock-step (bailing_moe.generate_images): each image is
+        what `generate` would produce for its request alone with the same noise.  requests: dicts with `input_ids` [1, T_i],
+        `attention_mask`, `uncond_attention_mask`, `text_uncond_attention_mask` (as BailingMMProcessor returns them; prompt
+        lengths may differ, the CFG row count must not).  The first generated token of every request must be `<image>` (or be
+        forced).  Does not touch the multi-round state.  Returns dict(images [B,3,R,R], files, latents, sem)."""
+        cfg, dev = self.config.llm_config, self.device
+        B = len(requests)
+        ids, ams, uncs, tuncs = [], [], [], []
+        one = torch.ones(1, 1, dtype=torch.long)
+        for r in requests:
+            i = r["input_ids"].reshape(1, -1)
+            am = torch.ones_like(i) if r.get("attention_mask") is None else r["attention_mask"].cpu().long()
+            unc = am.clone() if r.get("uncond_attention_mask") is None else r["uncond_attention_mask"].cpu().long()
+            tunc = am.clone() if r.get("text_uncond_attention_mask") is None else r["text_uncond_attention_mask"].cpu().long()
+            ids.append(i.clip(0, cfg.vocab_size - 1)); ams.append(torch.cat((am, one), 1)); uncs.append(unc); tuncs.append(tunc)
+        rpi = {build_cfg_rows(a, u, t).shape[0] for a, u, t in zip(ams, uncs, tuncs)}
+        if len(rpi) != 1:
+            raise ValueError(f"all requests of a batch must have the same number of CFG rows, got {sorted(rpi)}")
+        rpi = rpi.pop()
+        lens = [int(i.shape[1]) for i in ids]
+        n_tok = cfg.num_image_tokens_for_gen
+        if max(lens) + n_tok + 2 > self.model.t_max:
+            raise ValueError(f"prompt of {max(lens)} tokens + {n_tok} image tokens exceed the KV arena (t_max = {self.model.t_max})")
+        self.model.ensure_sequences(rpi * B)
+        hidden = self.model.prefill_ragged([self.model.embed(i[0].to(dev)) for i in ids], [rpi * b for b in range(B)])
+        first = torch.argmax(self.model.logits(hidden), dim=-1).tolist()
+        if forced_first_token is not None:
+            first = [int(forced_first_token)] * B
+        bad = [b for b, t in enumerate(first) if t != cfg.image_start_token]
+        if bad:
+            raise ValueError(f"requests {bad} do not start an image (first tokens {[first[b] for b in bad]}); use generate() for them")
+        if noises is None:   # the same draws, in the same order, as B successive generate() calls
+            noises = torch.stack([torch.randn(n_tok + 1, self.vision.latent_dim, generator=self.noise_generator, device=dev)
+                                  for _ in range(B)])
+        start = self.model.embed(torch.tensor([cfg.image_start_token], device=dev))
+        out = generate_images(self.model, self.rf, self.vision, start, lens, ams, uncs, tuncs, noises.to(dev),
+                              temperature=image_gen_temperature, text_cfg=3.0, image_cfg=1.1, n_groups=n_groups)
+        files = []
+        if save:
+            prefixes = output_image_prefixes or [f"output_{b}" for b in range(B)]
+            for b in range(B):
+                name = f"{prefixes[b]}.png"
+                tensor_to_pil(out["image"][b:b + 1]).save(name)
+                files.append(name)
+        return dict(images=out["image"], files=files, latents=out["latents"], sem=out["sem"])
 
     # ---- generation --------------------------------------------------------------------------------
     @torch.no_grad()

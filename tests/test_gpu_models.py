@@ -256,6 +256,58 @@ def test_facade_generate_text_and_image(tmp_path):
     assert seqs2.shape[1] == 6 and model.past_len > ids.shape[1] + n_tok
 
 
+def test_facade_batched_generation_matches_sequential(tmp_path):
+    """generate_image_batch / MingUniVisionInfer.generate_batch (extension): B requests with different prompt lengths advance in
+    lock-step; every image must equal the one `generate` produces for that request alone (same noise draws, in order)."""
+    from ming_univision_amd.infer import MingUniVisionInfer
+    from ming_univision_amd.modeling import MingUniVisionForConditionalGeneration
+    g = load_golden("genimg_tiny")
+    llm_cfg = dict(g["llm_config"]); llm_cfg["eos_token_id"] = 1
+    cfg = C.MingUniVisionConfig(mlp_depth=2, llm_config=llm_cfg, vishead_diffloss_config=g["rf_config"],
+                                mingtok_config=g["mingtok_config"])
+    model = MingUniVisionForConditionalGeneration(cfg, state_dict=None, seed=3, t_max=64)
+    ids = g["ids"]
+    T = ids.shape[1]
+    gen = torch.Generator().manual_seed(11)
+    reqs = []
+    for b, n in enumerate((T, T - 2, T - 1, T)):
+        i = torch.randint(2, 200, (1, n), generator=gen)
+        unc = torch.ones(1, n, dtype=torch.long); unc[0, 1:n - 2] = 0
+        reqs.append(dict(input_ids=i, attention_mask=torch.ones(1, n, dtype=torch.long), uncond_attention_mask=unc,
+                         text_uncond_attention_mask=unc.clone()))
+    img_tok = llm_cfg["image_start_token"]
+    seq_imgs = []
+    model.noise_generator.manual_seed(5)
+    for b, r in enumerate(reqs):
+        model.reset_inner_state()
+        model.generate(**r, max_new_tokens=2, forced_first_token=img_tok, output_image_prefix=str(tmp_path / f"s{b}"))
+        seq_imgs.append(model.last_image[0].clone())
+    model.reset_inner_state()
+    model.noise_generator.manual_seed(5)
+    out = model.generate_image_batch(reqs, output_image_prefixes=[str(tmp_path / f"b{b}") for b in range(4)],
+                                     forced_first_token=img_tok)
+    import os
+    assert all(os.path.exists(f) for f in out["files"]) and out["images"].shape[0] == 4
+    for b in range(4):
+        assert psnr(out["images"][b], seq_imgs[b]) > 45.0, b
+    mixed = [dict(reqs[0]), dict(reqs[1])]                               # 3 CFG rows next to 2: rejected, like a ragged batch
+    t3 = torch.ones_like(mixed[0]["attention_mask"]); t3[0, 1:3] = 0
+    mixed[0]["text_uncond_attention_mask"] = t3
+    with pytest.raises(ValueError):
+        model.generate_image_batch(mixed, forced_first_token=img_tok, save=False)
+    infer = MingUniVisionInfer.__new__(MingUniVisionInfer)              # chat-level entry point
+    infer.model = model
+    from ming_univision_amd.processing import BailingMMProcessor
+    infer.processor = BailingMMProcessor()
+    msgs = [[{"role": "HUMAN", "content": [{"type": "text", "text": t}]}] for t in ("a cat", "a much longer prompt about a dog")]
+    try:
+        files = infer.generate_batch(msgs, output_image_prefixes=[str(tmp_path / "c0"), str(tmp_path / "c1")],
+                                     forced_first_token=img_tok)
+        assert len(files) == 2 and all(os.path.exists(f) for f in files)
+    except ValueError as e:                                               # chat prompts longer than this tiny model's KV arena
+        assert "exceed the KV arena" in str(e)
+
+
 def test_checkpoint_directory_roundtrip(tmp_path):
     """MingUniVisionInfer(model_dir): config.json + safetensors shards keyed by the reference's parameter names
     (vision.*, model.model.layers.*, model.vis_head.*, model.diffloss.*, linear_proj.*) load
