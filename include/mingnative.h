@@ -233,6 +233,9 @@ int mn_gemm256_swiglu_split(const uint16_t* A, int64_t lda, int64_t a_lo_off, co
                             const uint16_t* b12, uint16_t* Y, int64_t ldy, int64_t y_lo_off, int M, int hidden, int K,
                             void* stream);
 
+/* The same with a plain bf16 result Y [M, hidden] (batched bf16 path: MingTok SwiGLU blocks); a_lo_off = 0 for bf16 activations. */
+int mn_gemm256_swiglu(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W12, int64_t ldw, const uint16_t* b12,
+                      uint16_t* Y, int64_t ldy, int M, int hidden, int K, void* stream);
 /* Grouped form (MoE experts, modeling_bailing_moe.py:605-639, hundreds of rows in flight): group g multiplies row positions
  * [off[g], off[g] + cnt[g]) — position r reads A row a_rows[r] when a_rows != NULL (the gather of the expert-sorted order,
  * done while staging) — by W + g * w_gstride and writes rows off[g].. of C.  A is a bf16 hi/lo pair (a_lo_off > 0).

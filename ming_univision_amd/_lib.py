@@ -110,6 +110,7 @@ SYMBOLS = {
     "mn_gemm256": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _i, _i, _i, _i, _p]),
     "mn_gemm256_splitk": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i, _i, _i, _i, _p]),
     "mn_gemm256_swiglu_split": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _i64, _i, _i, _i, _p]),
+    "mn_gemm256_swiglu": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _i, _i, _i, _p]),
     "mn_gemm256_grouped": (_i, [_p, _i64, _i64, _p, _p, _i64, _i64, _p, _p, _i, _p, _i64, _i64, _i, _i, _i, _i, _p]),
     "mn_stream_mfma_slices": (_i, [_i, _i, _i]),
     "mn_stream_mfma_grouped": (_i, [_p, _i, _p, _i64, _p, _i, _p, _p, _i, _i, _i, _i, _p]),

@@ -326,6 +326,8 @@ extern "C" int mn_gemm_bf16_splitk(const uint16_t* A, int64_t lda, const uint16_
 // ===========================================================================================
 // LayerNorm fp32 -> bf16 (one wave per row), SwiGLU, converters
 // ===========================================================================================
+// one wave per row; the row is read ONCE (D <= 4096: at most 16 float4 per lane stay in registers), statistics by wave
+// reductions, two-pass variance on the register copy
 __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __restrict__ x, int64_t ldx,
                                                              const bf16_t* __restrict__ g, const bf16_t* __restrict__ b,
                                                              float eps, bf16_t* __restrict__ y, int64_t ldy, int M, int D,
@@ -333,22 +335,27 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float* xr = x + (int64_t)row * ldx;
+  f32x4 v[16];
   float s = 0.f;
-  for (int k = lane * 4; k < D; k += 256) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
-    s += v.x + v.y + v.z + v.w;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int k = c * 256 + lane * 4;
+    v[c] = k < D ? *reinterpret_cast<const f32x4*>(xr + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
   }
   const float mean = wave_sum(s) / (float)D;
   float ss = 0.f;
-  for (int k = lane * 4; k < D; k += 256) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
-    const float a = v.x - mean, b2 = v.y - mean, c = v.z - mean, d = v.w - mean;
-    ss += a * a + b2 * b2 + c * c + d * d;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int k = c * 256 + lane * 4;
+    if (k < D) { const f32x4 d = v[c] - mean; ss += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
   }
   const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
-  for (int k = lane * 4; k < D; k += 256) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
-    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int k = c * 256 + lane * 4;
+    if (k >= D) continue;
+    float o[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float t = (o[i] - mean) * rstd;
@@ -357,14 +364,14 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
       if (gelu) t = gelu_erf_f(t);
       o[i] = t;
     }
-    u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-    *reinterpret_cast<u32x2*>(y + (int64_t)row * ldy + k) = pk;
+    *reinterpret_cast<u32x2*>(y + (int64_t)row * ldy + k) = u32x2{cvt_pk_bf16(o[0], o[1]), cvt_pk_bf16(o[2], o[3])};
   }
 }
 
 extern "C" int mn_layernorm_bf16(const float* x, int64_t ldx, const uint16_t* g, const uint16_t* b, float eps,
                                  uint16_t* y, int64_t ldy, int M, int D, int gelu, void* stream) {
-  MN_CHECK_ARG(x && y && M >= 1 && D >= 4 && (D % 4) == 0 && (ldx % 4) == 0 && (ldy % 4) == 0, "mn_layernorm_bf16: bad args");
+  MN_CHECK_ARG(x && y && M >= 1 && D >= 4 && D <= 4096 && (D % 4) == 0 && (ldx % 4) == 0 && (ldy % 4) == 0,
+               "mn_layernorm_bf16: bad args (D = %d: a multiple of 4, at most 4096)", D);
   hipLaunchKernelGGL(layernorm_bf16_kernel, dim3(mn_cdiv(M, 4)), dim3(256), 0, mn_stream(stream), x, ldx, g, b, eps, y,
                      ldy, M, D, gelu);
   MN_CHECK_LAUNCH("mn_layernorm_bf16");

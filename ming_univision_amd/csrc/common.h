@@ -114,6 +114,6 @@ typedef struct mn_g256 {
   const int32_t* tile_g; const int32_t* tile_m0; const int32_t* n_tiles; int max_mtiles;
 } mn_g256;
 enum { MN_G256_F32 = 0, MN_G256_BF16 = 1, MN_G256_BF16_GELU = 2, MN_G256_F32_RESID = 3, MN_G256_SWIGLU_SPLIT = 4,
-       MN_G256_F32_RESID_GATE = 5 };
+       MN_G256_F32_RESID_GATE = 5, MN_G256_SWIGLU_BF16 = 6 };
 extern "C" int mn_gemm256_ex(const mn_g256* a, int epi, int ksplit, void* stream);
 extern "C" int mn_gemm256_slices(int K, int ksplit);

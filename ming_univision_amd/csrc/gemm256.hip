@@ -64,7 +64,8 @@ typedef const __attribute__((address_space(1))) void glb_void;
 typedef mn_g256 G256;
 
 enum { E_F32 = MN_G256_F32, E_BF16 = MN_G256_BF16, E_BF16_GELU = MN_G256_BF16_GELU, E_F32_RESID = MN_G256_F32_RESID,
-       E_SWIGLU_SPLIT = MN_G256_SWIGLU_SPLIT, E_F32_RESID_GATE = MN_G256_F32_RESID_GATE };
+       E_SWIGLU_SPLIT = MN_G256_SWIGLU_SPLIT, E_F32_RESID_GATE = MN_G256_F32_RESID_GATE, E_SWIGLU_BF16 = MN_G256_SWIGLU_BF16 };
+__host__ __device__ constexpr bool epi_paired(int epi) { return epi == E_SWIGLU_SPLIT || epi == E_SWIGLU_BF16; }
 
 __device__ __forceinline__ int lds_off(int buf, int op, int half) { return ((buf * 2 + op) * 2 + half) * HALF_BYTES; }
 
@@ -103,7 +104,7 @@ __device__ __forceinline__ void g256_src_offsets(const G256& p, int wave, int la
 template <int EPI, bool HILO>
 __device__ __forceinline__ void g256_epilogue(const G256& p, const f32x4 (&acc)[8][4], int wr, int wc, int fr, int fq, int m0,
                                               int n0, int row0, int Mg, int zslice) {
-  constexpr bool hilo = HILO, paired = EPI == E_SWIGLU_SPLIT;
+  constexpr bool hilo = HILO, paired = epi_paired(EPI);
   char* Cz = reinterpret_cast<char*>(p.C);
   if (EPI == E_F32) Cz += (int64_t)zslice * p.c_zstride * 4;
   constexpr int mi_n = hilo ? 4 : 8, nj_n = paired ? 2 : 4;
@@ -139,6 +140,9 @@ __device__ __forceinline__ void g256_epilogue(const G256& p, const f32x4 (&acc)[
       } else if (EPI == E_BF16 || EPI == E_BF16_GELU) {
         if (EPI == E_BF16_GELU) v = f32x4{gelu_erf_f(v.x), gelu_erf_f(v.y), gelu_erf_f(v.z), gelu_erf_f(v.w)};
         *reinterpret_cast<u32x2*>(Cz + ((int64_t)m * p.ldc + n) * 2) = u32x2{cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w)};
+      } else if (EPI == E_SWIGLU_BF16) {   // y = silu(gate) * up as plain bf16 (the batched bf16 path)
+        *reinterpret_cast<u32x2*>(Cz + ((int64_t)m * p.ldc + n) * 2) =
+            u32x2{cvt_pk_bf16(silu_f(v.x) * u.x, silu_f(v.y) * u.y), cvt_pk_bf16(silu_f(v.z) * u.z, silu_f(v.w) * u.w)};
       } else {  // E_SWIGLU_SPLIT: y = silu(gate) * up, stored as bf16 hi rows and lo rows
         uint32_t h0, l0, h1, l1;
         split_pk_bf16(silu_f(v.x) * u.x, silu_f(v.y) * u.y, h0, l0);
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int fr = lane & 15, fq = lane >> 4;
-  constexpr bool hilo = HILO, paired = EPI == E_SWIGLU_SPLIT;
+  constexpr bool hilo = HILO, paired = epi_paired(EPI);
   const int rows_per_tile = hilo ? 128 : 256, cols_per_tile = paired ? 128 : 256;
   const int tiles_m = (p.M + rows_per_tile - 1) / rows_per_tile, tiles_n = (p.N + cols_per_tile - 1) / cols_per_tile;
   // XCD-aware tile order (bijective for any tile count): the tiles of one XCD are consecutive, tm fastest, so the M-tiles
@@ -322,6 +326,7 @@ extern "C" void mn_gemm256_tune(int sched) { g_g256_sched = sched & 1; }   // A/
 // Generic launcher.  Returns the number of split-K slices used (>= 1) or a negative error.
 static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {
   const bool hilo = a.a_lo_off != 0, paired = a.w_pair_rows != 0;
+  if (paired != epi_paired(epi)) { mn_set_error("gemm256: epilogue %d and w_pair_rows disagree", epi); return MN_EINVAL; }
   const int tiles = (int)((a.tile_g ? a.max_mtiles : mn_cdiv(a.M, hilo ? 128 : 256)) * mn_cdiv(a.N, paired ? 128 : 256));
   G256 p = a;
   p.Kc = p.K;
@@ -345,6 +350,7 @@ static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {
     case E_F32_RESID: G256_GO(E_F32_RESID); break;
     case E_SWIGLU_SPLIT: G256_GO(E_SWIGLU_SPLIT); break;
     case E_F32_RESID_GATE: G256_GO(E_F32_RESID_GATE); break;
+    case E_SWIGLU_BF16: G256_GO(E_SWIGLU_BF16); break;
     default: mn_set_error("gemm256: bad epilogue %d", epi); return MN_EINVAL;
   }
 #undef G256_GO
@@ -432,6 +438,22 @@ extern "C" int mn_gemm256_swiglu_split(const uint16_t* A, int64_t lda, int64_t a
   const int rc = g256_launch(p, E_SWIGLU_SPLIT, 1, mn_stream(stream));
   if (rc < 0) return rc;
   MN_CHECK_LAUNCH("mn_gemm256_swiglu_split");
+  return MN_OK;
+}
+
+// SwiGLU-fused form with a plain bf16 result (the batched bf16 path: MingTok encoder / semantic-decoder blocks,
+// swiglu_ffn.py:30-34): Y bf16 [M, hidden] = silu(A Wg^T + bg) * (A Wu^T + bu).  a_lo_off = 0 for plain bf16 activations.
+extern "C" int mn_gemm256_swiglu(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W12, int64_t ldw,
+                                 const uint16_t* b12, uint16_t* Y, int64_t ldy, int M, int hidden, int K, void* stream) {
+  MN_CHECK_ARG(A && W12 && Y, "mn_gemm256_swiglu: bad args");
+  MN_CHECK_ARG(g256_shape_ok(A, lda, a_lo_off, W12, ldw, 2 * (int64_t)hidden, M, hidden, K) && (ldy % 4) == 0,
+               "mn_gemm256_swiglu: unsupported shape M=%d hidden=%d K=%d", M, hidden, K);
+  G256 p{};
+  p.A = A; p.lda = lda; p.a_lo_off = a_lo_off; p.W = W12; p.ldw = ldw; p.w_pair_rows = hidden; p.bias = b12;
+  p.C = Y; p.ldc = ldy; p.M = M; p.N = hidden; p.K = K;
+  const int rc = g256_launch(p, E_SWIGLU_BF16, 1, mn_stream(stream));
+  if (rc < 0) return rc;
+  MN_CHECK_LAUNCH("mn_gemm256_swiglu");
   return MN_OK;
 }
 

@@ -82,9 +82,18 @@ class MingTok:
         ops.gemm_bf16(att, self._w(prefix + ".attn.proj.weight"), self._w(prefix + ".attn.proj.bias"), "f32_resid", out=x)
         xn = ops.layernorm_bf16(x, self._w(prefix + ".norm2.weight"), self._w(prefix + ".norm2.bias"))
         if (prefix + ".mlp.w12.weight") in self.sd:
-            h12 = ops.gemm_bf16(xn, self._w(prefix + ".mlp.w12.weight"), self._w(prefix + ".mlp.w12.bias"))
-            h = ops.swiglu_bf16(h12)
-            ops.gemm_bf16(h, self._w(prefix + ".mlp.w3.weight"), self._w(prefix + ".mlp.w3.bias"), "f32_resid", out=x)
+            w12, b12, w3 = self._w(prefix + ".mlp.w12.weight"), self._w(prefix + ".mlp.w12.bias"), self._w(prefix + ".mlp.w3.weight")
+            if prefix.startswith("semantic_decoder.blocks.0."):
+                # the zero-padded copies (hidden 2736 -> 2752): whole 64-k tiles for w3, results unchanged
+                self._semdec()
+                li = int(prefix.rsplit(".", 1)[1])
+                w12, b12, w3 = self._sem_pad[0][li], self._sem_pad[1][li], self._sem_pad[2][li]
+            hid = w12.shape[0] // 2
+            if x.shape[0] >= 1024 and hid % 4 == 0 and D % 64 == 0:
+                h = ops.gemm256_swiglu(xn, w12, b12)                 # SwiGLU in the GEMM epilogue: no [M, 2*hidden] round trip
+            else:
+                h = ops.swiglu_bf16(ops.gemm_bf16(xn, w12, b12))
+            ops.gemm_bf16(h, w3, self._w(prefix + ".mlp.w3.bias"), "f32_resid", out=x)
         else:
             h = ops.gemm_bf16(xn, self._w(prefix + ".mlp.fc1.weight"), self._w(prefix + ".mlp.fc1.bias"), "bf16_gelu")
             ops.gemm_bf16(h, self._w(prefix + ".mlp.fc2.weight"), self._w(prefix + ".mlp.fc2.bias"), "f32_resid", out=x)

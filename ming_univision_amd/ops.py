@@ -205,6 +205,17 @@ def gemm256_swiglu_split(a2, w12, b12=None):
     return y
 
 
+def gemm256_swiglu(a, w12, b12=None):
+    """a bf16 [M, K]; w12 bf16 [2 * hidden, K] (gate rows, up rows) -> bf16 [M, hidden] = silu(gate) * up, one launch."""
+    _req(a, torch.bfloat16, "a"); _req(w12, torch.bfloat16, "w12"); _req(b12, torch.bfloat16, "b12")
+    M, K = a.shape
+    hidden = w12.shape[0] // 2
+    y = torch.empty(M, hidden, dtype=torch.bfloat16, device=a.device)
+    check(lib().mn_gemm256_swiglu(ptr(a), a.stride(0), 0, ptr(w12), w12.stride(0), ptr(b12), ptr(y), hidden, M, hidden, K,
+                                  current_stream()), "mn_gemm256_swiglu")
+    return y
+
+
 def gemm256_grouped(a2, a_rows, w, off, cnt, n_pos, m_max, swiglu):
     """Grouped (MoE) form: a2 bf16 [2, R, K] hi/lo pair; a_rows int32 [n_pos] or None; w bf16 [G, N or 2N, K];
     off / cnt int32 device arrays.  Returns fp32 [n_pos, N] or the bf16 hi/lo pair [2, n_pos, N] (swiglu)."""
