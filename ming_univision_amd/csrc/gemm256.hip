@@ -264,6 +264,47 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
       quad(1, 1, wf1);
       quad(1, 0, wf0);
     }
+  } else if (SCHED == 2) {
+    // ---------------- 2 long phases per K-tile (32 MFMAs each), counted vmcnt, wave rows one barrier apart ----------------
+    // K-tile T in buffer X (Y = X ^ 1):
+    //   phase 1: read X.A0, X.W0, X.W1 (retired by lgkmcnt(0) BEFORE the barrier: free for re-issue one phase later);
+    //            issue Y.A1 <- T+1;                  MFMAs (A0,W0) (A0,W1)
+    //   phase 2: read X.A1 (same rule);  issue X.A0, X.W0, X.W1 <- T+2;      MFMAs (A1,W1) (A1,W0)
+    //   RAW: X.A1(T) issued (T-1).1, retired by the vmcnt(8) of T.1 (8 = Y.A1 + the three half-tiles of (T-1).2), read T.2;
+    //        Y.{A0,W0,W1}(T+1) issued (T-1).2, retired by the vmcnt(8) of T.2, read (T+1).1 — always one phase after the wait.
+    //   WAR: one phase, safe because every wave's reads completed before the barrier that precedes the re-issue.
+    auto phase2 = [&](auto Xc, auto PHc, int T) {
+      constexpr int X = decltype(Xc)::value, PH = decltype(PHc)::value, Y = X ^ 1;
+      if (PH == 0) { read_w(X, 0, wf0); read_w(X, 1, wf1); __builtin_amdgcn_sched_barrier(0); read_a(X, 0); }
+      else read_a(X, 1);
+      const int tgt = PH == 0 ? T + 1 : T + 2;
+      if (tgt < nk) {
+        if (PH == 0) stage(0, 1, tgt, Y);
+        else { stage(0, 0, tgt, X); stage(1, 0, tgt, X); stage(1, 1, tgt, X); }
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      if (PH == 0) { quad(0, 0, wf0); quad(0, 1, wf1); }
+      else { quad(1, 1, wf1); quad(1, 0, wf0); }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    stage(0, 0, 0, 0); stage(1, 0, 0, 0); stage(1, 1, 0, 0); stage(0, 1, 0, 0);
+    if (nk > 1) { stage(0, 0, 1, 1); stage(1, 0, 1, 1); stage(1, 1, 1, 1); wait_vm<8>(); }
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nk; t += 2) {
+      phase2(I0{}, I0{}, t); phase2(I0{}, I1{}, t);
+      if (t + 1 < nk) { phase2(I1{}, I0{}, t + 1); phase2(I1{}, I1{}, t + 1); }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
   } else {
     // ---------------- 4 phases per K-tile, counted vmcnt, wave rows one barrier apart ----------------
     // Issue order of half-tiles (virtual time, one per phase) for the K-tile T held in buffer X (Y = X ^ 1):
@@ -320,8 +361,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
 
 }  // namespace
 
-static int g_g256_sched = 1;
-extern "C" void mn_gemm256_tune(int sched) { g_g256_sched = sched & 1; }   // A/B hook, not part of the stable ABI
+static int g_g256_sched = 2;
+extern "C" void mn_gemm256_tune(int sched) { g_g256_sched = sched; }   // A/B hook (0 / 1 / 2 = schedule), not part of the stable ABI
 
 // Generic launcher.  Returns the number of split-K slices used (>= 1) or a negative error.
 static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {
@@ -336,10 +377,12 @@ static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {
 #define G256_GO(E)                                                                                             \
   do {                                                                                                         \
     if (hilo) {                                                                                                \
-      if (g_g256_sched) hipLaunchKernelGGL((gemm256_kernel<E, 1, true>), grid, dim3(512), 0, st, p);          \
+      if (g_g256_sched == 2) hipLaunchKernelGGL((gemm256_kernel<E, 2, true>), grid, dim3(512), 0, st, p);     \
+      else if (g_g256_sched) hipLaunchKernelGGL((gemm256_kernel<E, 1, true>), grid, dim3(512), 0, st, p);     \
       else hipLaunchKernelGGL((gemm256_kernel<E, 0, true>), grid, dim3(512), 0, st, p);                       \
     } else {                                                                                                   \
-      if (g_g256_sched) hipLaunchKernelGGL((gemm256_kernel<E, 1, false>), grid, dim3(512), 0, st, p);         \
+      if (g_g256_sched == 2) hipLaunchKernelGGL((gemm256_kernel<E, 2, false>), grid, dim3(512), 0, st, p);    \
+      else if (g_g256_sched) hipLaunchKernelGGL((gemm256_kernel<E, 1, false>), grid, dim3(512), 0, st, p);    \
       else hipLaunchKernelGGL((gemm256_kernel<E, 0, false>), grid, dim3(512), 0, st, p);                      \
     }                                                                                                          \
   } while (0)

@@ -46,7 +46,7 @@ def run_plain(M, N, K, epi="bf16", hilo=False, check_ref=True, nmat=1):
         it[0] += 1
         check(L.mn_gemm256(ptr(a), K, lo_off, ptr(ws[it[0] % nmat]), K, None, ptr(out), N, M, N, K, EPI[epi], current_stream()), "g256")
     res = {}
-    for sched in (1, 0):
+    for sched in (2, 1):
         L.mn_gemm256_tune(sched)
         it[0] = -1
         new(); torch.cuda.synchronize()
@@ -65,7 +65,7 @@ def run_plain(M, N, K, epi="bf16", hilo=False, check_ref=True, nmat=1):
         old = timeit(lambda: check(L.mn_gemm_bf16_hilo(ptr(a), K, lo_off, ptr(w), K, None, ptr(o2), N, M, N, K, current_stream()), "hilo"))
     f = 2.0 * M * N * K * (2 if hilo else 1)
     s = f"M={M} N={N} K={K} {epi}{' hilo' if hilo else ''}: "
-    for sched in (1, 0):
+    for sched in (2, 1):
         (med, mn), err = res[sched]
         s += f"sched{sched} {med*1e3:.1f} us {f/med/1e9:.0f} TF (min {f/mn/1e9:.0f}) err {err:.1e} | "
     if old: s += f"round-1 kernel {old[0]*1e3:.1f} us {f/old[0]/1e9:.0f} TF"
@@ -83,7 +83,7 @@ def run_swiglu(M, hidden, K, nmat=4):
         it[0] += 1
         check(L.mn_gemm256_swiglu_split(ptr(a2), K, a2.stride(0), ptr(ws[it[0] % nmat]), K, ptr(b), ptr(y), hidden, y.stride(0), M, hidden, K, current_stream()), "swiglu")
     s = f"swiglu-split M={M} hidden={hidden} K={K}: "
-    for sched in (1, 0):
+    for sched in (2, 1):
         L.mn_gemm256_tune(sched)
         it[0] = -1
         new(); torch.cuda.synchronize()
