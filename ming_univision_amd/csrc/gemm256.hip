@@ -16,13 +16,15 @@
 //     both wave rows, W half h the columns of N-fragments 2h..2h+1 of all four wave columns.  A K-tile is then four
 //     quadrant phases  (A0,W0) (A0,W1) (A1,W1) (A1,W0)  of 16 MFMAs each, and a half-tile is dead — free to be
 //     re-filled — two phases after the phase that read it.
-//   * SCHED 1 (default): 4 phases per K-tile, every phase = { ds_read the next quadrant's fragments, issue ONE half-tile
-//     (2 global_load_lds per lane) of a later K-tile, s_waitcnt vmcnt(8) — never 0 in the steady state, four half-tiles
-//     stay in flight across the barriers —, s_barrier, 16 x v_mfma_f32_16x16x32_bf16 at raised priority, s_barrier }.
-//     The two wave rows run one barrier apart, so on every SIMD one wave is in its MFMA cluster while its partner
-//     reads LDS and issues loads.  Hazard distances are by construction (see tile_step): a half-tile is read >= 5 phases
-//     after it was issued and one phase after the counted wait that retires it; it is re-filled >= 2 phases after its
-//     last read.
+//   * SCHED 2 (default): 2 long phases per K-tile, every phase = { ds_read the fragments of the next two quadrants — retired by
+//     lgkmcnt(0) BEFORE the barrier, so their half-tiles may be re-filled one phase later —, issue one (phase 1) or three
+//     (phase 2) half-tiles of a later K-tile, s_waitcnt vmcnt(8) — never 0 in the steady state, four half-tiles stay in
+//     flight across the barriers —, s_barrier, 32 x v_mfma_f32_16x16x32_bf16 at raised priority, s_barrier }.  The two wave
+//     rows run one barrier apart, so on every SIMD one wave is in its MFMA cluster while its partner reads LDS and issues
+//     loads.  Hazard distances are by construction (see the schedule comments in the kernel): a half-tile is read >= 3 long
+//     phases after it was issued and one phase after the counted wait that retires it.
+//   * SCHED 1: 4 phases of 16 MFMAs per K-tile (8 barriers per K-tile instead of 4; re-fill >= 2 phases after the last read):
+//     4-8 % slower on every shape measured (4096^3: 1148-1243 vs 1325 TFLOP/s; adaLN 4.65 vs 4.47 ms).  Kept as an A/B arm.
 //   * SCHED 0: same tile, one barrier per K-tile (all four half-tiles of the next K-tile issued up front, vmcnt(0)
 //     before the barrier) — the simple reference schedule the A/B tool compares against.
 //   * Rejected after measurement (tools/ab_gemm256.py, MI355X): the 32x32x16 MFMA in the same schedule (1048 vs 1243
