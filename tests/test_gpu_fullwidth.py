@@ -110,3 +110,31 @@ def test_full_width_generate_image_vs_oracle(full, rows_tag):
     assert rel_err(outw["last_hidden"][:R], ref["last_hidden"][:, 0]) < TOL
     per_img = torch.stack([(outw["latents"][i] - outb["latents"][i]).abs().max() / outb["latents"][i].abs().max() for i in range(B)])
     assert float(per_img.median()) < 5e-4 and float(per_img.max()) < 5e-3, (float(per_img.median()), float(per_img.max()))
+
+
+def test_full_width_facade_batch_on_wide_route(tmp_path):
+    """MingUniVisionForConditionalGeneration.generate_image_batch with 40 ragged requests at the production width (80 CFG rows:
+    wide route, lm_head through gemm256, KV arena grown on demand): images 0 and 39 equal what generate() produces for those
+    requests alone with the same noise."""
+    from ming_univision_amd.modeling import MingUniVisionForConditionalGeneration
+    d = C.BailingMoeConfig.ming_univision_16b_a3b().to_dict()
+    d.pop("model_type", None)
+    d.update(num_hidden_layers=2, vocab_size=1024, num_image_tokens_for_gen=4, image_start_token=1000, pad_token_id=0, eos_token_id=1)
+    cfg = C.MingUniVisionConfig(mlp_depth=2, llm_config=d, vishead_diffloss_config=dict(C.DEFAULT_VISHEAD_DIFFLOSS))
+    model = MingUniVisionForConditionalGeneration(cfg, state_dict=None, seed=9, t_max=48)
+    g = torch.Generator().manual_seed(2)
+    B = 40
+    reqs = []
+    for b in range(B):
+        n = 10 + (b % 5)
+        unc = torch.ones(1, n, dtype=torch.long); unc[0, 2:n - 2] = 0
+        reqs.append(dict(input_ids=torch.randint(2, 900, (1, n), generator=g), attention_mask=torch.ones(1, n, dtype=torch.long),
+                         uncond_attention_mask=unc, text_uncond_attention_mask=unc.clone()))
+    noises = torch.randn(B, 5, 32, generator=g)
+    out = model.generate_image_batch(reqs, forced_first_token=1000, noises=noises, save=False)
+    assert out["images"].shape == (B, 3, 64, 64) and torch.isfinite(out["images"]).all()
+    for b in (0, B - 1):
+        model.reset_inner_state()
+        one = model.generate_image_batch([reqs[b]], forced_first_token=1000, noises=noises[b:b + 1], save=False)
+        assert rel_err(out["latents"][b], one["latents"][0]) < 5e-3      # two HIP routes (80 rows wide vs 2 rows), chaotic random model
+        assert rel_err(out["images"][b], one["images"][0]) < 5e-2
