@@ -295,6 +295,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);        // the next phase's LDS reads stay behind this barrier
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     stage(0, 0, 0, 0); stage(1, 0, 0, 0); stage(1, 1, 0, 0); stage(0, 1, 0, 0);
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);        // the next phase's LDS reads stay behind this barrier
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;

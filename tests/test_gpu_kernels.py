@@ -391,3 +391,29 @@ def test_gemm256_grouped(ops, gather):
             ref[lo:hi] = F.silu(r[:, :N]) * r[:, N:] if swiglu else r
         got = out[0].double() + out[1].double() if swiglu else out
         assert rel(got, ref) < 3e-5
+
+
+def test_gemm256_race_screen(ops):
+    """The counted-vmcnt pipeline has no hardware interlock between LDS-DMA writes and fragment reads: a schedule error shows
+    as RARE wrong tiles.  Screen: many launches of production shapes under load must be bitwise identical and right."""
+    x = rnd(1024, 3072, seed=41)
+    w, wf = bw(2 * 4096, 3072, seed=42, scale=3072 ** -0.5)
+    a2 = ops.split_hilo(x.cuda())
+    xr = a2[0].double().cpu() + a2[1].double().cpu()
+    r = xr @ wf.double().T
+    ref_sw = F.silu(r[:, :4096]) * r[:, 4096:]
+    first_sw = first_f = None
+    for it in range(40):
+        y = ops.gemm256_swiglu_split(a2, w, None)
+        o = ops.gemm256(a2, w, None, "f32")
+        if first_sw is None:
+            first_sw, first_f = y.clone(), o.clone()
+            assert rel(y[0].double() + y[1].double(), ref_sw) < 3e-5 and rel(o, r) < 1e-5
+        else:
+            assert torch.equal(y, first_sw) and torch.equal(o, first_f), it
+    big = rnd(4096, 4096, seed=43).to(torch.bfloat16).cuda()            # many K-tiles, many tiles per CU
+    wb, wbf = bw(4096, 4096, seed=44, scale=4096 ** -0.5)
+    o0 = ops.gemm256(big, wb, None, "f32")
+    assert rel(o0, big.double().cpu() @ wbf.double().T) < 1e-5
+    for it in range(20):
+        assert torch.equal(ops.gemm256(big, wb, None, "f32"), o0), it
