@@ -13,17 +13,27 @@ EPI = {"bf16": 0, "f32": 2}
 dev = "cuda"
 
 def timeit(fn, n=10, rounds=5):
-    for _ in range(3): fn()
+    return timeit_arms([fn], n, rounds)[0]
+
+
+def timeit_arms(fns, n=10, rounds=7):
+    """Interleaved rounds of all arms in one process (a first-measured arm otherwise pays the clock ramp): (median, min) per arm."""
+    for fn in fns:
+        for _ in range(3): fn()
     torch.cuda.synchronize()
-    ts = []
+    ts = [[] for _ in fns]
     for r in range(rounds):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(n): fn()
-        e.record(); torch.cuda.synchronize()
-        ts.append(s.elapsed_time(e) / n)
-    ts.sort()
-    return ts[len(ts) // 2], ts[0]
+        for i, fn in enumerate(fns):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(n): fn()
+            e.record(); torch.cuda.synchronize()
+            ts[i].append(s.elapsed_time(e) / n)
+    out = []
+    for t in ts:
+        t.sort()
+        out.append((t[len(t) // 2], t[0]))
+    return out
 
 def split(x):
     hi = x.to(torch.bfloat16)
@@ -46,7 +56,8 @@ def run_plain(M, N, K, epi="bf16", hilo=False, check_ref=True, nmat=1):
         it[0] += 1
         check(L.mn_gemm256(ptr(a), K, lo_off, ptr(ws[it[0] % nmat]), K, None, ptr(out), N, M, N, K, EPI[epi], current_stream()), "g256")
     res = {}
-    for sched in (2, 1):
+    ARMS = (2, 1)
+    for sched in ARMS:
         L.mn_gemm256_tune(sched)
         it[0] = -1
         new(); torch.cuda.synchronize()
@@ -54,8 +65,14 @@ def run_plain(M, N, K, epi="bf16", hilo=False, check_ref=True, nmat=1):
         if check_ref:
             ref = xr @ w.double().T
             err = float((out.double() - ref).abs().max() / ref.abs().max())
-        res[sched] = (timeit(new), err)
-    L.mn_gemm256_tune(1)
+        res[sched] = [None, err]
+    def arm(sched):
+        def f():
+            L.mn_gemm256_tune(sched); new()
+        return f
+    for sched, t in zip(ARMS, timeit_arms([arm(a_) for a_ in ARMS])):
+        res[sched][0] = t
+    L.mn_gemm256_tune(2)
     old = None
     if not hilo:
         o2 = torch.empty_like(out)
@@ -65,7 +82,7 @@ def run_plain(M, N, K, epi="bf16", hilo=False, check_ref=True, nmat=1):
         old = timeit(lambda: check(L.mn_gemm_bf16_hilo(ptr(a), K, lo_off, ptr(w), K, None, ptr(o2), N, M, N, K, current_stream()), "hilo"))
     f = 2.0 * M * N * K * (2 if hilo else 1)
     s = f"M={M} N={N} K={K} {epi}{' hilo' if hilo else ''}: "
-    for sched in (2, 1):
+    for sched in ARMS:
         (med, mn), err = res[sched]
         s += f"sched{sched} {med*1e3:.1f} us {f/med/1e9:.0f} TF (min {f/mn/1e9:.0f}) err {err:.1e} | "
     if old: s += f"round-1 kernel {old[0]*1e3:.1f} us {f/old[0]/1e9:.0f} TF"
@@ -83,7 +100,9 @@ def run_swiglu(M, hidden, K, nmat=4):
         it[0] += 1
         check(L.mn_gemm256_swiglu_split(ptr(a2), K, a2.stride(0), ptr(ws[it[0] % nmat]), K, ptr(b), ptr(y), hidden, y.stride(0), M, hidden, K, current_stream()), "swiglu")
     s = f"swiglu-split M={M} hidden={hidden} K={K}: "
-    for sched in (2, 1):
+    ARMS = (2, 1)
+    errs = {}
+    for sched in ARMS:
         L.mn_gemm256_tune(sched)
         it[0] = -1
         new(); torch.cuda.synchronize()
@@ -91,11 +110,15 @@ def run_swiglu(M, hidden, K, nmat=4):
         r = xr @ ws[0].double().T + b.double()
         ref = torch.nn.functional.silu(r[:, :hidden]) * r[:, hidden:]
         got = y[0].double() + y[1].double()
-        err = float((got - ref).abs().max() / ref.abs().max())
-        med, mn = timeit(new)
-        f = 2.0 * M * 2 * hidden * K * 2
-        s += f"sched{sched} {med*1e3:.1f} us {f/med/1e9:.0f} TF (min {f/mn/1e9:.0f}) err {err:.1e} | "
-    L.mn_gemm256_tune(1)
+        errs[sched] = float((got - ref).abs().max() / ref.abs().max())
+    def arm(sched):
+        def f_():
+            L.mn_gemm256_tune(sched); new()
+        return f_
+    f = 2.0 * M * 2 * hidden * K * 2
+    for sched, (med, mn) in zip(ARMS, timeit_arms([arm(a_) for a_ in ARMS])):
+        s += f"sched{sched} {med*1e3:.1f} us {f/med/1e9:.0f} TF (min {f/mn/1e9:.0f}) err {errs[sched]:.1e} | "
+    L.mn_gemm256_tune(2)
     print(s, flush=True)
 
 def run_splitk(M, N, K, ks, nmat=4):
