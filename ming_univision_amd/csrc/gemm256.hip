@@ -515,7 +515,8 @@ extern "C" int mn_gemm256_grouped(const uint16_t* A, int64_t lda, int64_t a_lo_o
                                   int64_t ldc, int64_t c_lo_off, int m_max, int N, int K, int swiglu, void* stream) {
   MN_CHECK_ARG(A && W && C && off && cnt && n_groups >= 1 && m_max >= 1 && a_lo_off > 0, "mn_gemm256_grouped: bad args");
   MN_CHECK_ARG(N >= 4 && (N % 4) == 0 && K >= BK && (K % BK) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && (a_lo_off % 8) == 0 &&
-                   (w_gstride % 8) == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0 && (!swiglu || c_lo_off > 0),
+                   (w_gstride % 8) == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0 && (!swiglu || c_lo_off > 0) &&
+                   a_lo_off * 4 < ((int64_t)1 << 32) && (int64_t)(swiglu ? 2 : 1) * N * ldw * 2 < ((int64_t)1 << 32),
                "mn_gemm256_grouped: unsupported shape N=%d K=%d", N, K);
   G256 p{};
   p.A = A; p.lda = lda; p.a_lo_off = a_lo_off; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.c_lo_off = c_lo_off;
