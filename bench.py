@@ -212,7 +212,7 @@ def dominant_kernel_roofline_wide(rf, rows, iters=48):
     pmc = os.path.join(ROOT, "profiles", "r02_pmc_gemm256_w12_rows%d.json" % rows)
     if os.path.exists(pmc) and hid == 8192 and w == 3072:
         traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-    return dict(traffic=traffic, kernel="gemm256_kernel<SWIGLU_SPLIT,4-phase,hi/lo> (RF w12: N=2x%d, K=%d, rows=%d)" % (hid, w, rows),
+    return dict(traffic=traffic, kernel="gemm256_kernel<SWIGLU_SPLIT,2-phase,hi/lo> (RF w12: N=2x%d, K=%d, rows=%d)" % (hid, w, rows),
                 us=us, flops=flops, tflops=flops / us * 1e-6)
 
 

@@ -243,14 +243,22 @@ extern "C" int mn_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
   // enough 256 x 256 tiles to fill half the chip: the 8-wave 4-phase kernel (gemm256.hip: 1.2 PFLOP/s at 4096^3 against
   // 0.76 here); smaller problems keep the 128 x 128 tiles (more workgroups, 2-3 per CU)
   if (g_gemm_route256 && (K % 64) == 0 && (N % 4) == 0 && mn_cdiv(M, 256) * mn_cdiv(N, 256) >= 128 &&
-      (int64_t)M * lda * 2 < ((int64_t)1 << 32) && (int64_t)N * ldw * 2 < ((int64_t)1 << 32) && epilogue >= MN_GEMM_BF16 &&
-      epilogue <= MN_GEMM_F32_RESID) {
+      (int64_t)N * ldw * 2 < ((int64_t)1 << 32) && epilogue >= MN_GEMM_BF16 && epilogue <= MN_GEMM_F32_RESID) {
     static const int map[4] = {MN_G256_BF16, MN_G256_BF16_GELU, MN_G256_F32, MN_G256_F32_RESID};
-    mn_g256 a;
-    memset(&a, 0, sizeof(a));
-    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
-    const int rc = mn_gemm256_ex(&a, map[epilogue], 1, stream);
-    return rc < 0 ? rc : MN_OK;
+    // gemm256 addresses its operands with 32-bit byte offsets: an activation matrix beyond 4 GiB goes in row chunks
+    int64_t chunk = ((((int64_t)1 << 32) - 1) / (lda * 2)) / 256 * 256;
+    if (chunk >= M) chunk = M;
+    const int64_t c_elt = (epilogue == MN_GEMM_F32 || epilogue == MN_GEMM_F32_RESID) ? 4 : 2;
+    for (int64_t m0 = 0; m0 < M; m0 += chunk) {
+      mn_g256 a;
+      memset(&a, 0, sizeof(a));
+      a.A = A + m0 * lda; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias;
+      a.C = reinterpret_cast<char*>(C) + m0 * ldc * c_elt; a.ldc = ldc;
+      a.M = (int)((M - m0) < chunk ? (M - m0) : chunk); a.N = N; a.K = K;
+      const int rc = mn_gemm256_ex(&a, map[epilogue], 1, stream);
+      if (rc < 0) return rc;
+    }
+    return MN_OK;
   }
   const int rc = gemm_launch(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, 1, 0, mn_stream(stream));
   if (rc < 0) return rc;
