@@ -12,6 +12,7 @@ import os
 import torch
 
 from . import ops
+from ._lib import check, current_stream, lib, ptr
 from .bailing_moe import BailingMoeDecoder, build_cfg_rows, generate_image, generate_images
 from .configuration import MingUniVisionConfig, linear_proj_param_shapes, llm_param_shapes
 from .mingtok import MingTok
@@ -66,6 +67,7 @@ class MingUniVisionForConditionalGeneration:
         self.rf = RectifiedFlowHead(rf_sd, cfg.hidden_size, config.vishead_diffloss_config, self.vision.latent_dim)
         self.tokenizer = None
         self.mfma_prefill_threshold = 64   # prompts longer than this prefill on the MFMA path
+        self.decode_chunk = 8              # greedy text tokens per host round trip
         self.noise_generator = torch.Generator(device=self.device)
         self.noise_generator.manual_seed(seed)
         self.reset_inner_state()
@@ -191,41 +193,56 @@ class MingUniVisionForConditionalGeneration:
         new_ids = []
         n_img = 0
         one = torch.ones(1, 1, dtype=am.dtype)
-        for step in range(max_new_tokens):
-            logits = self.model.logits(hidden)
-            tok = int(torch.argmax(logits[0]).item())
-            if step == 0 and forced_first_token is not None:
-                tok = int(forced_first_token)
-            new_ids.append(tok)
-            if tok == cfg.eos_token_id:
-                break
-            if step == max_new_tokens - 1:
-                break
-            if am.shape[1] < cache_len:                                  # pad the mask over generated image tokens
-                am = torch.cat((am, torch.ones(1, cache_len - am.shape[1], dtype=am.dtype)), dim=1)
-            x = self.model.embed(torch.tensor([tok], device=dev))
-            if tok == cfg.image_start_token:
-                n_tok = cfg.num_image_tokens_for_gen
-                noises = torch.randn(n_tok + 1, self.vision.latent_dim, generator=self.noise_generator, device=dev)
-                # NB: the reference swallows the caller's CFG scales and always runs 3.0 / 1.1
-                out = generate_image(self.model, self.rf, self.vision, x, cache_len, torch.cat((am, one), 1), unc, tunc,
-                                     noises, temperature=image_gen_temperature, text_cfg=3.0, image_cfg=1.1)
-                cache_len = out["cache_len"]
-                hidden = out["last_hidden"][0:1]
-                pil = tensor_to_pil(out["image"])
-                for i in range(100):                                     # modeling_bailing_moe.py:1788-1796
-                    name = f"{output_image_prefix}.png" if i == 0 else f"{output_image_prefix}_{i}.png"
-                    if not os.path.exists(name):
-                        print(f"Saving to {name}")
-                        pil.save(name)
-                        break
-                n_img += 1
-                self.last_image = out["image"]
+        seq0 = torch.zeros(1, dtype=torch.int32, device=dev)
+        done = False
+        # Greedy decode in chunks of `decode_chunk` tokens: argmax, embedding lookup and the row bookkeeping stay on the device, the
+        # host reads the chunk's token ids once (one sync per chunk instead of one per token) and rolls back to the first EOS /
+        # `<image>` it finds — greedy decoding is deterministic, the speculative steps behind such a token only wrote cache slots
+        # that the next real step overwrites.
+        while not done and len(new_ids) < max_new_tokens:
+            n = min(self.decode_chunk, max_new_tokens - len(new_ids))
+            slot = torch.tensor([cache_len], dtype=torch.int32, device=dev)
+            ln = slot + 1
+            toks_dev = []
+            for j in range(n):
+                tok_dev = torch.argmax(self.model.logits(hidden)[0]).reshape(1)
+                if not new_ids and j == 0 and forced_first_token is not None:
+                    tok_dev = torch.tensor([int(forced_first_token)], device=dev)
+                toks_dev.append(tok_dev)
+                if j + 1 < n or len(new_ids) + n < max_new_tokens:       # the last token of the call is never fed
+                    hidden = self.model.step(self.model.embed(tok_dev), seq0, slot, slot, ln)
+                    check(lib().mn_rows_advance(ptr(slot), ptr(ln), None, 1, 1, current_stream()), "mn_rows_advance")
+            toks = torch.cat(toks_dev).tolist()                          # the chunk's only host sync
+            for j, tok in enumerate(toks):
+                new_ids.append(tok)
+                if tok == cfg.eos_token_id or len(new_ids) == max_new_tokens:
+                    cache_len += j                                       # tokens 0..j-1 of the chunk were fed
+                    done = True
+                    break
+                if tok == cfg.image_start_token:
+                    cache_len += j
+                    if am.shape[1] < cache_len:                          # pad the mask over generated tokens
+                        am = torch.cat((am, torch.ones(1, cache_len - am.shape[1], dtype=am.dtype)), dim=1)
+                    x = self.model.embed(torch.tensor([tok], device=dev))
+                    n_tok = cfg.num_image_tokens_for_gen
+                    noises = torch.randn(n_tok + 1, self.vision.latent_dim, generator=self.noise_generator, device=dev)
+                    # NB: the reference swallows the caller's CFG scales and always runs 3.0 / 1.1
+                    out = generate_image(self.model, self.rf, self.vision, x, cache_len, torch.cat((am, one), 1), unc, tunc,
+                                         noises, temperature=image_gen_temperature, text_cfg=3.0, image_cfg=1.1)
+                    cache_len = out["cache_len"]
+                    hidden = out["last_hidden"][0:1]
+                    pil = tensor_to_pil(out["image"])
+                    for i in range(100):                                 # modeling_bailing_moe.py:1788-1796
+                        name = f"{output_image_prefix}.png" if i == 0 else f"{output_image_prefix}_{i}.png"
+                        if not os.path.exists(name):
+                            print(f"Saving to {name}")
+                            pil.save(name)
+                            break
+                    n_img += 1
+                    self.last_image = out["image"]
+                    break                                                # speculative tokens behind `<image>` are dropped
             else:
-                slot = torch.tensor([cache_len], dtype=torch.int32, device=dev)
-                seq0 = torch.zeros(1, dtype=torch.int32, device=dev)
-                hidden = self.model.step(x, seq0, slot, slot, slot + 1)
-                cache_len += 1
+                cache_len += n                                           # every token of the chunk was fed
         # state for the next round (:273-299)
         self.past_len = cache_len
         pad1 = torch.ones(1, cache_len - prompt_mask_len, dtype=attention_mask.dtype)
