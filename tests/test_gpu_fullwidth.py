@@ -138,3 +138,54 @@ def test_full_width_facade_batch_on_wide_route(tmp_path):
         one = model.generate_image_batch([reqs[b]], forced_first_token=1000, noises=noises[b:b + 1], save=False)
         assert rel_err(out["latents"][b], one["latents"][0]) < 5e-3      # two HIP routes (80 rows wide vs 2 rows), chaotic random model
         assert rel_err(out["images"][b], one["images"][0]) < 5e-2
+
+
+@pytest.mark.parametrize("n_images,rpi", [(33, 2), (22, 3), (65, 2), (129, 2)])
+def test_wide_rf_sampler_matches_narrow_route(n_images, rpi):
+    """RectifiedFlowLoss.sample at production width on the wide route (66 / 66 / 130 / 258 rows: partial row tiles, 2 and 3 CFG
+    rows) against the <= 64-row route of the same library, image by image (both are fp32-class: 2^-17 operands)."""
+    from ming_univision_amd.rf_head import RectifiedFlowHead
+    from ming_univision_amd.synth import synth_tensor
+    cfg = C.BailingMoeConfig.ming_univision_16b_a3b()
+    rf_cfg = dict(C.DEFAULT_VISHEAD_DIFFLOSS)
+    shapes = C.llm_param_shapes(cfg, rf_cfg, 32)
+    sd = {k: synth_tensor(k, s_, 7, "cuda", torch.bfloat16) for k, s_ in shapes.items() if k.startswith("vis_head") or k.startswith("diffloss")}
+    rf = RectifiedFlowHead(sd, cfg.hidden_size, rf_cfg)
+    g = torch.Generator().manual_seed(n_images)
+    hidden = torch.randn(n_images * rpi, cfg.hidden_size, generator=g).cuda()
+    noise = torch.randn(n_images, 32, generator=g).cuda()
+    wide = rf.sample(hidden, noise, n_images=n_images)
+    per = 64 // rpi
+    nar = torch.cat([rf.sample(hidden[i * rpi:(i + per) * rpi].contiguous(), noise[i:i + per].contiguous(),
+                               n_images=min(per, n_images - i)) for i in range(0, n_images, per)])
+    assert torch.isfinite(wide).all()
+    err = (wide - nar).abs().amax(dim=1) / nar.abs().amax(dim=1)
+    assert float(err.max()) < 2e-4, float(err.max())
+
+
+def test_wide_llm_step_matches_narrow_route_ragged_rows():
+    """One decoder-stack step at production layer shapes for 150 rows with ragged cache lengths, holey key masks and shared
+    embeddings (x_row_div = 2): wide route against the same rows pushed through the <= 64-row route in three calls."""
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder
+    cfg = C.BailingMoeConfig.ming_univision_16b_a3b()
+    cfg.num_hidden_layers = 2
+    dec = BailingMoeDecoder.synthetic(cfg, torch.device("cuda"), seed=4, with_vocab=False, t_max=48, n_seq=150)
+    g = torch.Generator().manual_seed(0)
+    M = 150
+    dec.kv_cache.copy_(torch.randn(dec.kv_cache.shape, generator=g).cuda() * 0.5)      # a populated cache
+    kv0 = dec.kv_cache.clone()
+    x = torch.randn(M // 2, cfg.hidden_size, generator=g).cuda()
+    slot = torch.randint(5, 40, (M,), generator=g).to(torch.int32).cuda()
+    seq = torch.arange(M, dtype=torch.int32).cuda()
+    km = (torch.rand(M, 48, generator=g) > 0.2).to(torch.uint8)
+    km[torch.arange(M), slot.cpu().long()] = 1                                         # the current token is always attended
+    km = km.cuda()
+    wide = dec.step(x, seq, slot, slot, slot + 1, km, None, rows=M, x_row_div=2)
+    kv_w = dec.kv_cache.clone()
+    dec.kv_cache.copy_(kv0)
+    xr = x.repeat_interleave(2, dim=0)
+    nar = torch.cat([dec.step(xr[i:i + 50].contiguous(), seq[i:i + 50].contiguous(), slot[i:i + 50].contiguous(),
+                              slot[i:i + 50].contiguous(), (slot[i:i + 50] + 1).contiguous(), km[i:i + 50].contiguous(), None)
+                     for i in range(0, M, 50)])
+    assert rel_err(wide, nar) < 2e-4
+    assert rel_err(kv_w, dec.kv_cache) < 1e-5                                           # same K / V rows appended
