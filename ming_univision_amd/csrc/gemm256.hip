@@ -29,9 +29,11 @@
 //     before the barrier) — the simple reference schedule the A/B tool compares against.
 //   * Rejected after measurement (tools/ab_gemm256.py, MI355X): the 32x32x16 MFMA in the same schedule (1048 vs 1243
 //     TFLOP/s at 4096^3: a quadrant phase then has two independent accumulators for a 64-cycle MFMA); a one-wave-per-SIMD
-//     form (4 waves x 128x128, 256 AGPR accumulators pinned by inline-asm MFMAs, double-buffered fragments, one barrier per
-//     K-tile): +5..9 % on plain bf16 problems (1263 vs 1154 at 4096^3) but 0.65-0.78x on the hi/lo F32 / SwiGLU problems that
-//     dominate this path — four waves carry the whole epilogue and hipcc spills 86 dwords per lane there.
+//     form (4 waves x 128 x 128, the 64 accumulator fragments addressed literally as a[0:255] by inline-asm MFMAs — 154 VGPRs, no
+//     scratch —, two fragment register sets, the reads / LDS-DMA of the next step interleaved 1 : 1 : 4 with the MFMAs by source
+//     order, ONE barrier per K-tile): 8-25 % SLOWER than the two-phase 8-wave schedule on every shape (4096^3: 1268 vs 1375,
+//     adaLN 1050 vs 1328, w12 at 1024 rows 1189 vs 1353 TFLOP/s) — with one wave per SIMD nothing covers the per-K-tile
+//     vmcnt(0) + barrier, the issue slots of the interleaved instructions, or the epilogue.
 //     A persistent tile loop whose LDS pipeline runs across output tiles (the next tile's first half-tiles issued during
 //     the last phases and the epilogue of the current one) measured within +-1.5 % of the plain grid (adaLN 4589 vs 4646 us,
 //     w12 at 1024 rows 177 vs 163 us): the dispatcher already starts the next workgroup's prologue while others compute.
@@ -46,6 +48,7 @@
 //     (w_pair_rows further down), so a lane holds silu-gate and up of the same hidden unit: the SwiGLU, its bias and
 //     the bf16 hi/lo split of the next GEMM's operand happen in the epilogue, a tile covers 128 hidden units.
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -103,6 +106,45 @@ __device__ __forceinline__ void g256_src_offsets(const G256& p, int wave, int la
 }
 
 // Epilogue of one output tile.  A lane holds, per (i, j), output row 16 i + fr and the 4 CONSECUTIVE columns 16 j + 4 fq .. +3.
+// One lane's 4 CONSECUTIVE output columns n..n+3 of row m (u: the paired "up" values): bias, epilogue, store.
+template <int EPI>
+__device__ __forceinline__ void g256_emit(const G256& p, char* Cz, int m, int n, f32x4 v, f32x4 u, int zslice) {
+  constexpr bool paired = epi_paired(EPI);
+  if (p.bias && zslice == 0) {
+    const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
+    v += f32x4{bf16lo_to_f32(b.x), bf16hi_to_f32(b.x), bf16lo_to_f32(b.y), bf16hi_to_f32(b.y)};
+    if (paired) {
+      const u32x2 b2 = *reinterpret_cast<const u32x2*>(p.bias + p.w_pair_rows + n);
+      u += f32x4{bf16lo_to_f32(b2.x), bf16hi_to_f32(b2.x), bf16lo_to_f32(b2.y), bf16hi_to_f32(b2.y)};
+    }
+  }
+  if (EPI == E_F32) {
+    *reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4) = v;
+  } else if (EPI == E_F32_RESID) {
+    f32x4* c = reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4);
+    *c += v;
+  } else if (EPI == E_F32_RESID_GATE) {
+    f32x4* c = reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(p.gate + (int64_t)m * p.ldgate + n);
+    *c += g * v;
+  } else if (EPI == E_BF16 || EPI == E_BF16_GELU) {
+    if (EPI == E_BF16_GELU) v = f32x4{gelu_erf_f(v.x), gelu_erf_f(v.y), gelu_erf_f(v.z), gelu_erf_f(v.w)};
+    *reinterpret_cast<u32x2*>(Cz + ((int64_t)m * p.ldc + n) * 2) = u32x2{cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w)};
+  } else if (EPI == E_SWIGLU_BF16) {   // y = silu(gate) * up as plain bf16 (the batched bf16 path)
+    *reinterpret_cast<u32x2*>(Cz + ((int64_t)m * p.ldc + n) * 2) =
+        u32x2{cvt_pk_bf16(silu_f(v.x) * u.x, silu_f(v.y) * u.y), cvt_pk_bf16(silu_f(v.z) * u.z, silu_f(v.w) * u.w)};
+  } else {  // E_SWIGLU_SPLIT: y = silu(gate) * up, stored as bf16 hi rows and lo rows
+    uint32_t h0, l0, h1, l1;
+    split_pk_bf16(silu_f(v.x) * u.x, silu_f(v.y) * u.y, h0, l0);
+    split_pk_bf16(silu_f(v.z) * u.z, silu_f(v.w) * u.w, h1, l1);
+    bf16_t* c = reinterpret_cast<bf16_t*>(Cz) + (int64_t)m * p.ldc + n;
+    *reinterpret_cast<u32x2*>(c) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(c + p.c_lo_off) = u32x2{l0, l1};
+  }
+}
+
+// Epilogue of one output tile of the 8-wave kernel.  A lane holds, per (i, j), output row 16 i + fr and the 4 CONSECUTIVE
+// columns 16 j + 4 fq .. +3.
 template <int EPI, bool HILO>
 __device__ __forceinline__ void g256_epilogue(const G256& p, const f32x4 (&acc)[8][4], int wr, int wc, int fr, int fq, int m0,
                                               int n0, int row0, int Mg, int zslice) {
@@ -121,38 +163,7 @@ __device__ __forceinline__ void g256_epilogue(const G256& p, const f32x4 (&acc)[
       if (hilo) v += acc[(i + 4) & 7][j];
       f32x4 u = {0.f, 0.f, 0.f, 0.f};
       if (paired) { u = acc[i][(j + 2) & 3]; if (hilo) u += acc[(i + 4) & 7][(j + 2) & 3]; }
-      const int m = row0 + ml;
-      if (p.bias && zslice == 0) {
-        const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
-        v += f32x4{bf16lo_to_f32(b.x), bf16hi_to_f32(b.x), bf16lo_to_f32(b.y), bf16hi_to_f32(b.y)};
-        if (paired) {
-          const u32x2 b2 = *reinterpret_cast<const u32x2*>(p.bias + p.w_pair_rows + n);
-          u += f32x4{bf16lo_to_f32(b2.x), bf16hi_to_f32(b2.x), bf16lo_to_f32(b2.y), bf16hi_to_f32(b2.y)};
-        }
-      }
-      if (EPI == E_F32) {
-        *reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4) = v;
-      } else if (EPI == E_F32_RESID) {
-        f32x4* c = reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4);
-        *c += v;
-      } else if (EPI == E_F32_RESID_GATE) {
-        f32x4* c = reinterpret_cast<f32x4*>(Cz + ((int64_t)m * p.ldc + n) * 4);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(p.gate + (int64_t)m * p.ldgate + n);
-        *c += g * v;
-      } else if (EPI == E_BF16 || EPI == E_BF16_GELU) {
-        if (EPI == E_BF16_GELU) v = f32x4{gelu_erf_f(v.x), gelu_erf_f(v.y), gelu_erf_f(v.z), gelu_erf_f(v.w)};
-        *reinterpret_cast<u32x2*>(Cz + ((int64_t)m * p.ldc + n) * 2) = u32x2{cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w)};
-      } else if (EPI == E_SWIGLU_BF16) {   // y = silu(gate) * up as plain bf16 (the batched bf16 path)
-        *reinterpret_cast<u32x2*>(Cz + ((int64_t)m * p.ldc + n) * 2) =
-            u32x2{cvt_pk_bf16(silu_f(v.x) * u.x, silu_f(v.y) * u.y), cvt_pk_bf16(silu_f(v.z) * u.z, silu_f(v.w) * u.w)};
-      } else {  // E_SWIGLU_SPLIT: y = silu(gate) * up, stored as bf16 hi rows and lo rows
-        uint32_t h0, l0, h1, l1;
-        split_pk_bf16(silu_f(v.x) * u.x, silu_f(v.y) * u.y, h0, l0);
-        split_pk_bf16(silu_f(v.z) * u.z, silu_f(v.w) * u.w, h1, l1);
-        bf16_t* c = reinterpret_cast<bf16_t*>(Cz) + (int64_t)m * p.ldc + n;
-        *reinterpret_cast<u32x2*>(c) = u32x2{h0, h1};
-        *reinterpret_cast<u32x2*>(c + p.c_lo_off) = u32x2{l0, l1};
-      }
+      g256_emit<EPI>(p, Cz, row0 + ml, n, v, u, zslice);
     }
   }
 }
@@ -361,6 +372,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
 
   g256_epilogue<EPI, HILO>(p, acc, wr, wc, fr, fq, m0, n0, row0, Mg, blockIdx.y);
 }
+
 
 
 }  // namespace
