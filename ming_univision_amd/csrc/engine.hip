@@ -381,7 +381,7 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   MN_CHECK_ARG(n_images >= 1 && rows >= n_images && rows % n_images == 0 && rows / n_images <= 3 && (rows <= 64 || rf_wide_ok(h, rows)),
                "mn_rf_sample: rows=%d n_images=%d (1..3 CFG rows per image; <= 64 rows, or <= 2048 with 64-aligned widths)", rows, n_images);
   MN_CHECK_ARG(h->target <= 256, "mn_rf_sample: target too large");
-  if (rows > 64)
+  if (rf_wide_ok(h, rows))
     return rf_sample_wide(h, hidden, ld_hidden, rows, n_images, noise, temperature, text_cfg, image_cfg, latent_out, workspace,
                           workspace_bytes, stream);
   const int rpi = rows / n_images;
@@ -758,9 +758,15 @@ extern "C" int mn_rf_max_rows(const mn_rf_head* h) { return rf_wide_ok(h, 2048) 
 extern "C" int mn_semdec_max_rows(const mn_semdec* s) { return sem_wide_ok(s, 2048) ? 2048 : 64; }
 
 extern "C" size_t mn_llm_workspace_bytes(const mn_llm* m, int rows, int64_t t_max) {
-  if (llm_wide_ok(m, rows)) { LlmWideWs ww; return llm_wide_carve(m, rows, t_max, nullptr, 0, &ww); }
-  LlmWs w{};
-  return llm_carve(m, rows, t_max, nullptr, 0, &w);
+  size_t wide = 0;
+  if (llm_wide_ok(m, rows)) {
+    LlmWideWs ww;
+    wide = llm_wide_carve(m, rows, t_max, nullptr, 0, &ww);
+    if (rows > 64) return wide;
+  }
+  LlmWs w{};                                 // <= 64 rows: a step with the image-gate override stays on the streaming route
+  const size_t narrow = llm_carve(m, rows, t_max, nullptr, 0, &w);
+  return narrow > wide ? narrow : wide;
 }
 
 extern "C" int mn_rows_advance(int32_t* a, int32_t* b, int32_t* c, int M, int delta, void* stream) {
@@ -778,7 +784,7 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
                "mn_llm_step: null pointer");
   MN_CHECK_ARG(M >= 1 && (M <= 64 || llm_wide_ok(m, M)) && x_row_div >= 1,
                "mn_llm_step: M=%d (1..64, or up to 2048 rows with 64-aligned widths)", M);
-  if (M > 64) {
+  if (llm_wide_ok(m, M) && (M > 64 || !(image_mask && m->image_gate))) {
     MN_CHECK_ARG(!(image_mask && m->image_gate), "mn_llm_step: the image-gate override is not available above 64 rows");
     return llm_step_wide(m, x, ldx, x_row_div, M, row_seq, row_slot, row_pos, row_len, key_mask, ld_mask, kv_cache, n_seq, t_max,
                          hidden_out, workspace, workspace_bytes, stream);
@@ -954,7 +960,7 @@ extern "C" int mn_semdec_step(const mn_semdec* s, const float* latent_norm, int 
                "mn_semdec_step: bad shape (M = %d: 1..64 rows, or up to 2048 with the padded SwiGLU weights)", M);
 
   MN_CHECK_ARG(!embed_out || (s->proj_depth >= 1 && s->proj_depth <= 2), "mn_semdec_step: proj_depth must be 1 or 2");
-  if (M > 64)
+  if (sem_wide_ok(s, M))
     return semdec_step_wide(s, latent_norm, M, row_seq, row_slot, row_len, kv_cache, n_seq, t_max, sem_out, embed_out, workspace,
                             workspace_bytes, stream);
   SemWs w;

@@ -54,7 +54,7 @@ struct LlmWideWs {
 
 static bool llm_wide_ok(const mn_llm* m, int rows) {
   const int ad = m->n_q * m->head_dim, n_slot = m->top_k + m->n_shared_slots;
-  return rows > 64 && rows <= 2048 && wide_glue_ok(m->hidden) && (m->hidden % 64) == 0 && (ad % 64) == 0 && (m->moe_inter % 64) == 0 &&
+  return rows >= g_wide_min_llm && rows <= 2048 && wide_glue_ok(m->hidden) && (m->hidden % 64) == 0 && (ad % 64) == 0 && (m->moe_inter % 64) == 0 &&
          m->n_experts <= 64 && (m->n_experts % 4) == 0 && m->n_experts + m->n_shared_slots <= 128 && (int64_t)rows * n_slot <= 65536 &&
          (m->head_dim == 64 || m->head_dim == 128);
 }
@@ -176,7 +176,7 @@ struct SemWideWs {
 };
 
 static bool sem_wide_ok(const mn_semdec* s, int rows) {
-  return rows > 64 && rows <= 2048 && s->w12p && s->b12p && s->w3p && s->hidden_pad >= s->hidden && (s->hidden_pad % 64) == 0 &&
+  return rows >= g_wide_min_sem && rows <= 2048 && s->w12p && s->b12p && s->w3p && s->hidden_pad >= s->hidden && (s->hidden_pad % 64) == 0 &&
          wide_glue_ok(s->dim) && (s->dim % 64) == 0 && s->dim == s->n_heads * 64 &&
          (s->proj_depth == 0 || (wide_glue_ok(s->proj_dim) && (s->proj_dim % 64) == 0));
 }

@@ -10,11 +10,45 @@
 //                      w3 GEMM, split-K partial slabs
 //                      [slab reduce + b3 + gated residual + next in_ln / final LN + modulate]   (diff_loss:270-272, 290)
 //                      final Linear (split-K) -> bias -> CFG combine + Euler step              (diff_loss:144-179, 291)
+// First row count that takes the wide route, per stage (measured crossovers); mn_wide_tune is the A/B hook.
+static int g_wide_min_llm = 65, g_wide_min_rf = 41, g_wide_min_sem = 65;
+extern "C" void mn_wide_tune(int llm_min_rows, int rf_min_rows, int sem_min_rows) {
+  if (llm_min_rows > 0) g_wide_min_llm = llm_min_rows;
+  if (rf_min_rows > 0) g_wide_min_rf = rf_min_rows;
+  if (sem_min_rows > 0) g_wide_min_sem = sem_min_rows;
+}
+
 struct RfWideWs {
   float *z, *c, *ada, *hh, *v, *x, *pbuf;
   bf16_t *hs, *zs, *y, *ya, *yb;
-  int ks3, ksf;          // split-K requests of the w3 and final GEMMs
+  int ks12, ks3, ksf;    // split-K requests of the w12 (1 = SwiGLU in the GEMM epilogue), w3 and final GEMMs
 };
+
+// y = silu(gate) * up from the split-K slabs of a w12 GEMM run without its SwiGLU epilogue (columns [0, HID) gate, [HID, 2 HID)
+// up; b12 in the same order), stored as the w3 GEMM's bf16 hi / lo operand.  Used when the row count leaves the SwiGLU form of
+// the GEMM (one workgroup per 128 rows x 128 hidden units, no split) on a fraction of the chip (diff_loss:54-72).
+__global__ __launch_bounds__(256) void rf_swiglu_slabs_kernel(const float* __restrict__ P, int nz, int64_t slab, const bf16_t* __restrict__ b12,
+                                                              bf16_t* __restrict__ Y, int64_t lo_off, int rows, int HID) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int q = HID / 4;
+  if (idx >= (int64_t)rows * q) return;
+  const int m = (int)(idx / q), j = (int)(idx % q) * 4;
+  f4 g = {bf16_to_f32(b12[j]), bf16_to_f32(b12[j + 1]), bf16_to_f32(b12[j + 2]), bf16_to_f32(b12[j + 3])};
+  f4 u = {bf16_to_f32(b12[HID + j]), bf16_to_f32(b12[HID + j + 1]), bf16_to_f32(b12[HID + j + 2]), bf16_to_f32(b12[HID + j + 3])};
+  const float* pp = P + (int64_t)m * 2 * HID + j;
+  for (int z = 0; z < nz; ++z) {
+    g += *reinterpret_cast<const f4*>(pp + z * slab);
+    u += *reinterpret_cast<const f4*>(pp + z * slab + HID);
+  }
+  uint32_t h0, l0, h1, l1;
+  split_pk_bf16(silu_f(g.x) * u.x, silu_f(g.y) * u.y, h0, l0);
+  split_pk_bf16(silu_f(g.z) * u.z, silu_f(g.w) * u.w, h1, l1);
+  bf16_t* yr = Y + (int64_t)m * HID + j;
+  *reinterpret_cast<u2*>(yr) = u2{h0, h1};
+  *reinterpret_cast<u2*>(yr + lo_off) = u2{l0, l1};
+}
 
 // Split-K request of a hi/lo GEMM with `rows` rows: minimise a small cost model of the launch — rounds of workgroups over the
 // 256 CUs x (K-tiles per slice at ~1.9 us each + ~10 us of prologue / epilogue) + the fp32 slab round trip through HBM
@@ -39,17 +73,21 @@ static size_t rf_wide_carve(const mn_rf_head* h, int rows, void* ws, size_t cap,
   Carver cv(ws, cap, ws == nullptr);
   const int64_t SR = (int64_t)h->steps * rows;
   const int A = h->depth * 3 * h->w + 2 * h->w;
+  // w12: the SwiGLU epilogue needs the whole K sum, i.e. cdiv(rows, 128) * hidden / 128 workgroups; below a chip's worth of them
+  // the plain split-K form + rf_swiglu_slabs_kernel is the faster pair (128 rows: 69 -> 3x us per block)
+  o->ks12 = mn_cdiv(rows, 128) * (h->hidden / 128) >= 256 ? 1 : rf_wide_ksplit(rows, 2 * h->hidden, h->w);
   o->ks3 = rf_wide_ksplit(rows, h->w, h->hidden);
   o->ksf = rf_wide_ksplit(rows, h->target, h->w);
   const size_t p3 = (size_t)mn_gemm256_slices(h->hidden, o->ks3) * rows * h->w;
   const size_t pf = (size_t)mn_gemm256_slices(h->w, o->ksf) * rows * h->target;
+  const size_t p12 = o->ks12 > 1 ? (size_t)mn_gemm256_slices(h->w, o->ks12) * rows * 2 * h->hidden : 0;
   o->z = cv.take<float>((size_t)rows * h->z_dim);
   o->c = cv.take<float>((size_t)rows * h->w);
   o->ada = cv.take<float>((size_t)SR * A);
   o->hh = cv.take<float>((size_t)rows * h->w);
   o->v = cv.take<float>((size_t)rows * h->target);
   o->x = cv.take<float>((size_t)rows * h->target);
-  o->pbuf = cv.take<float>(p3 > pf ? p3 : pf);
+  o->pbuf = cv.take<float>(p12 > p3 && p12 > pf ? p12 : p3 > pf ? p3 : pf);
   o->hs = cv.take<bf16_t>((size_t)2 * rows * h->llm_hidden);
   o->zs = cv.take<bf16_t>((size_t)2 * rows * h->z_dim);
   o->y = cv.take<bf16_t>((size_t)2 * SR * h->w);
@@ -59,7 +97,7 @@ static size_t rf_wide_carve(const mn_rf_head* h, int rows, void* ws, size_t cap,
 }
 
 static bool rf_wide_ok(const mn_rf_head* h, int rows) {
-  return rows > 64 && rows <= 2048 && wide_glue_ok(h->w) && wide_glue_ok(h->z_dim) && wide_glue_ok(h->llm_hidden) &&
+  return rows >= g_wide_min_rf && rows <= 2048 && wide_glue_ok(h->w) && wide_glue_ok(h->z_dim) && wide_glue_ok(h->llm_hidden) &&
          (h->w % 64) == 0 && (h->hidden % 64) == 0 && (h->z_dim % 64) == 0 && (h->llm_hidden % 64) == 0 && h->target <= 64 &&
          (h->target % 4) == 0;
 }
@@ -122,9 +160,18 @@ static int rf_sample_wide(const mn_rf_head* h, const float* hidden, int64_t ld_h
     wide_glue(g, st);
     for (int b = 0; b < h->depth; ++b) {
       const float* mod = ada + (int64_t)b * 3 * W;
-      a = g256_hilo(w.ya, W, lo_a, h->w12[b], W, h->b12[b], w.yb, HID, rows, HID, W);
-      a.w_pair_rows = HID; a.c_lo_off = lo_b;
-      MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
+      if (w.ks12 > 1) {
+        a = g256_hilo(w.ya, W, lo_a, h->w12[b], W, nullptr, w.pbuf, 2 * HID, rows, 2 * HID, W);
+        a.c_zstride = (int64_t)rows * 2 * HID;
+        const int nz12 = mn_gemm256_ex(&a, MN_G256_F32, w.ks12, stream);
+        if (nz12 < 0) return nz12;
+        hipLaunchKernelGGL(rf_swiglu_slabs_kernel, dim3(mn_cdiv((int64_t)rows * (HID / 4), 256)), dim3(256), 0, st, w.pbuf, nz12,
+                           (int64_t)rows * 2 * HID, h->b12[b], w.yb, lo_b, rows, HID);
+      } else {
+        a = g256_hilo(w.ya, W, lo_a, h->w12[b], W, h->b12[b], w.yb, HID, rows, HID, W);
+        a.w_pair_rows = HID; a.c_lo_off = lo_b;
+        MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
+      }
       a = g256_hilo(w.yb, HID, lo_b, h->w3[b], HID, nullptr, w.pbuf, W, rows, W, HID);
       a.c_zstride = (int64_t)rows * W;
       const int nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks3, stream);

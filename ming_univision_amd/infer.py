@@ -107,5 +107,18 @@ class MingUniVisionInfer:
         with torch.no_grad():
             return self.model.generate_image_batch(reqs, output_image_prefixes=output_image_prefixes, **kw)["files"]
 
+    def generate_batch_text(self, messages_list, max_new_tokens=64, **kw):
+        """Extension: B independent understanding / chat conversations (text and images in, text out) decoded in lock-step.
+        Returns the list of decoded answers."""
+        reqs = []
+        for messages in messages_list:
+            text = self.processor.apply_chat_template(messages, tokenize=False, add_generation_prompt=True, use_system=True)
+            image_inputs, _, _ = self.processor.process_vision_info(messages)
+            reqs.append(self.processor(text=[text], images=image_inputs, return_tensors="pt",
+                                       image_patch_size=self.model.vision.patch_size, for_edit=False))
+        with torch.no_grad():
+            ids = self.model.generate_text_batch(reqs, max_new_tokens=max_new_tokens, **kw)
+        return self.processor.batch_decode(ids, skip_special_tokens=True, clean_up_tokenization_spaces=False)
+
     def reset_inner_state(self):
         self.model.reset_inner_state()

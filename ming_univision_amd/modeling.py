@@ -154,6 +154,72 @@ class MingUniVisionForConditionalGeneration:
                 files.append(name)
         return dict(images=out["image"], files=files, latents=out["latents"], sem=out["sem"])
 
+    # ---- batched greedy text decoding (extension: image -> text understanding for B conversations in lock-step) -----------
+    @torch.no_grad()
+    def generate_text_batch(self, requests, max_new_tokens=64, sync_every=8, timings=None):
+        """B independent single-round conversations decoded greedily in lock-step: one pass through the decoder stack per new
+        token serves all B sequences (rows = B: the weight-streaming kernels up to 64 sequences, the wide MFMA route with
+        grouped-GEMM experts above), lm_head as one GEMM, argmax / embedding lookup / row bookkeeping on the device; the host
+        looks at the finished flags every `sync_every` tokens.  requests: dicts with `input_ids` [1, T_i] and optionally
+        `pixel_values` / `image_grid_thw` (as BailingMMProcessor returns them; attention masks must be all ones).  Every
+        sequence gets the tokens `generate` would give it alone (greedy, up to its first EOS).  Image generation is not
+        triggered here (`<image>` is returned as a token).  Does not touch the multi-round state.
+        Returns a list of B token-id lists (EOS included when reached).  `timings` (a dict, measurement only): synchronises
+        after the prefills and at the end and stores `prefill_s` / `decode_s`."""
+        import time
+        cfg, dev = self.config.llm_config, self.device
+        B = len(requests)
+        t_start = time.perf_counter()
+        lens, last = [], []
+        self.model.ensure_sequences(B)
+        for b, r in enumerate(requests):
+            ids = r["input_ids"].reshape(1, -1).to(dev).clip(0, cfg.vocab_size - 1)
+            am = r.get("attention_mask")
+            if am is not None and int(am.sum()) != am.numel():
+                raise ValueError("generate_text_batch: attention masks with holes are not supported (use generate)")
+            T = ids.shape[1]
+            if T + max_new_tokens > self.model.t_max:
+                raise ValueError(f"request {b}: {T} prompt tokens + {max_new_tokens} new tokens exceed the KV arena (t_max = {self.model.t_max})")
+            embeds = self.model.embed(ids[0])
+            image_mask = None
+            if r.get("pixel_values") is not None and T > 1:
+                feats = self.extract_image_feature(r["pixel_values"].to(dev), r.get("image_grid_thw"))
+                embeds, image_mask = self.prompt_wrap_vision(ids, embeds, feats)
+            if T > self.mfma_prefill_threshold and cfg.head_dim == 128:
+                h = self.model.prefill_mfma(embeds, seq=b, past=0, image_mask=image_mask)
+            else:
+                h = self.model.prefill(embeds, seq=b, past=0, image_mask=image_mask)[-1:]
+            last.append(h)
+            lens.append(T)
+        hidden = torch.cat(last, 0).contiguous()
+        if timings is not None:
+            torch.cuda.synchronize(dev)
+            t_prefill = time.perf_counter()
+        seq = torch.arange(B, dtype=torch.int32, device=dev)
+        slot = torch.tensor(lens, dtype=torch.int32, device=dev)
+        ln = slot + 1
+        finished = torch.zeros(B, dtype=torch.bool, device=dev)
+        toks = []
+        for step in range(max_new_tokens):
+            tok = torch.argmax(self.model.logits(hidden), dim=-1)
+            toks.append(tok)
+            finished |= tok == cfg.eos_token_id
+            if step + 1 == max_new_tokens:
+                break
+            if (step + 1) % sync_every == 0 and bool(finished.all()):      # the only host syncs of the loop
+                break
+            hidden = self.model.step(self.model.embed(tok), seq, slot, slot, ln)
+            check(lib().mn_rows_advance(ptr(slot), ptr(ln), None, B, 1, current_stream()), "mn_rows_advance")
+        out = torch.stack(toks, 1).tolist()
+        if timings is not None:
+            timings.update(prefill_s=t_prefill - t_start, decode_s=time.perf_counter() - t_prefill, steps=len(toks) - 1)
+        res = []
+        for row in out:
+            if cfg.eos_token_id in row:
+                row = row[:row.index(cfg.eos_token_id) + 1]
+            res.append(row)
+        return res
+
     # ---- generation --------------------------------------------------------------------------------
     @torch.no_grad()
     def generate(self, input_ids=None, attention_mask=None, uncond_attention_mask=None, text_uncond_attention_mask=None,

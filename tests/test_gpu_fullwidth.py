@@ -109,7 +109,12 @@ def test_full_width_generate_image_vs_oracle(full, rows_tag):
     assert rel_err(outw["sem"][0], ref["sem"][0]) < TOL
     assert rel_err(outw["last_hidden"][:R], ref["last_hidden"][:, 0]) < TOL
     per_img = torch.stack([(outw["latents"][i] - outb["latents"][i]).abs().max() / outb["latents"][i].abs().max() for i in range(B)])
-    assert float(per_img.median()) < 5e-4 and float(per_img.max()) < 5e-3, (float(per_img.median()), float(per_img.max()))
+    # two HIP routes with different fp32 summation orders: they agree to ~2e-4 image by image, except where a 2^-17 difference
+    # flips a near-tie of the (random-init, N(0, 0.006)) router, after which that image is a different sample (top-k is
+    # discontinuous; the oracle comparison above is the parity gate) - at most one image in 16 may do that
+    n_flip = int((per_img >= 5e-3).sum())
+    print("wide vs <= 64-row route, per image: median %.2e, %d of %d above 5e-3" % (float(per_img.median()), n_flip, B))
+    assert float(per_img.median()) < 5e-4 and n_flip <= max(1, B // 16), (float(per_img.median()), per_img.tolist())
 
 
 def test_full_width_facade_batch_on_wide_route(tmp_path):
@@ -140,10 +145,11 @@ def test_full_width_facade_batch_on_wide_route(tmp_path):
         assert rel_err(out["images"][b], one["images"][0]) < 5e-2
 
 
-@pytest.mark.parametrize("n_images,rpi", [(33, 2), (22, 3), (65, 2), (129, 2)])
+@pytest.mark.parametrize("n_images,rpi", [(33, 2), (22, 3), (65, 2), (129, 2), (200, 2)])
 def test_wide_rf_sampler_matches_narrow_route(n_images, rpi):
-    """RectifiedFlowLoss.sample at production width on the wide route (66 / 66 / 130 / 258 rows: partial row tiles, 2 and 3 CFG
-    rows) against the <= 64-row route of the same library, image by image (both are fp32-class: 2^-17 operands)."""
+    """RectifiedFlowLoss.sample at production width on the wide route (66 / 66 / 130 / 258 / 400 rows: partial row tiles, 2 and 3 CFG
+    rows; below 385 rows w12 runs split-K + slab SwiGLU, at 400 rows with the SwiGLU epilogue) against the <= 64-row route of the same
+    library, image by image (both are fp32-class: 2^-17 operands)."""
     from ming_univision_amd.rf_head import RectifiedFlowHead
     from ming_univision_amd.synth import synth_tensor
     cfg = C.BailingMoeConfig.ming_univision_16b_a3b()

@@ -308,6 +308,30 @@ def test_facade_batched_generation_matches_sequential(tmp_path):
         assert "exceed the KV arena" in str(e)
 
 
+def test_facade_batched_text_decode_matches_sequential():
+    """generate_text_batch (extension): B prompts of different lengths decoded greedily in lock-step give, sequence by
+    sequence, the tokens generate() gives (up to each sequence's first EOS)."""
+    from ming_univision_amd.modeling import MingUniVisionForConditionalGeneration
+    g = load_golden("genimg_tiny")
+    llm_cfg = dict(g["llm_config"]); llm_cfg["eos_token_id"] = 1
+    cfg = C.MingUniVisionConfig(mlp_depth=2, llm_config=llm_cfg, vishead_diffloss_config=g["rf_config"],
+                                mingtok_config=g["mingtok_config"])
+    model = MingUniVisionForConditionalGeneration(cfg, state_dict=None, seed=5, t_max=64)
+    gen = torch.Generator().manual_seed(3)
+    reqs = [dict(input_ids=torch.randint(2, 200, (1, n), generator=gen)) for n in (7, 12, 9, 12, 5)]
+    seqs = []
+    for r in reqs:
+        model.reset_inner_state()
+        out = model.generate(input_ids=r["input_ids"], max_new_tokens=10)
+        seqs.append(out[0, r["input_ids"].shape[1]:].tolist())
+    batch = model.generate_text_batch(reqs, max_new_tokens=10, sync_every=4)
+    img = llm_cfg["image_start_token"]
+    for a, b in zip(seqs, batch):
+        if img in a:                      # generate() switches to image generation there; the text batch does not
+            a, b = a[:a.index(img) + 1], b[:a.index(img) + 1]
+        assert a == b[:len(a)], (a, b)
+
+
 def test_checkpoint_directory_roundtrip(tmp_path):
     """MingUniVisionInfer(model_dir): config.json + safetensors shards keyed by the reference's parameter names
     (vision.*, model.model.layers.*, model.vis_head.*, model.diffloss.*, linear_proj.*) load

@@ -73,12 +73,31 @@ def c3(args):
     print(json.dumps({"config": "C3 16B-A3B image(1024^2)->text", "prompt_tokens": ids.shape[1], "mingtok_1024_ms": t_img * 1e3,
                       "prefill_incl_vision_s": t_prefill, "decode_tokens_per_s": 64 / max(1e-9, t_all - t_prefill), "new_tokens": int(seq.shape[1] - ids.shape[1]),
                       "note": "prompts > 64 tokens prefill on the bf16 MFMA path (GQA flash attention + grouped-GEMM MoE)"}), flush=True)
+    # B conversations in lock-step (generate_text_batch): same prompt shape per conversation, different token ids
+    for B in args.c3_batches:
+        del model
+        torch.cuda.empty_cache()
+        model = MingUniVisionForConditionalGeneration(cfg, device="cuda", seed=0, t_max=1152)
+        reqs = []
+        for b in range(B):
+            r = ids.clone()
+            r[0, :12] = torch.randint(0, 100000, (12,))
+            reqs.append(dict(input_ids=r, pixel_values=px))
+        model.generate_text_batch(reqs[:2], max_new_tokens=2)
+        tm = {}
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = model.generate_text_batch(reqs, max_new_tokens=65, sync_every=1 << 30, timings=tm)
+        torch.cuda.synchronize(); t_all = time.perf_counter() - t0
+        print(json.dumps({"config": f"C3 x{B} conversations in lock-step", "prefill_incl_vision_s_per_conversation": tm["prefill_s"] / B,
+                          "decode_tokens_per_s": tm["steps"] * B / tm["decode_s"], "ms_per_decode_step": tm["decode_s"] / tm["steps"] * 1e3,
+                          "end_to_end_tokens_per_s": 65 * B / t_all, "new_tokens": len(out[0])}), flush=True)
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--no-oracle", action="store_true")
     ap.add_argument("--c3", action="store_true")
+    ap.add_argument("--c3-batches", type=int, nargs="*", default=[16, 64, 256])
     a = ap.parse_args()
     c1_c2(a)
     if a.c3:
