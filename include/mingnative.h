@@ -245,6 +245,21 @@ int mn_gemm256_grouped(const uint16_t* A, int64_t lda, int64_t a_lo_off, const i
                        int64_t w_gstride, const int32_t* off, const int32_t* cnt, int n_groups, void* C, int64_t ldc,
                        int64_t c_lo_off, int m_max, int N, int K, int swiglu, void* stream);
 
+/* mn_moe_sort plus the list of LIVE row tiles of the grouped GEMMs: tile t (t < *n_tiles) = rows [tile_m0[t], tile_m0[t] +
+ * tile_rows) of group tile_g[t]; tile_g / tile_m0 hold up to T * n_slot / tile_rows + n_groups entries.  All device arrays.
+ * (modeling_bailing_moe.py:608-616: the expert-count / argsort bookkeeping of moe_infer, without the host sync.) */
+int mn_moe_sort_tiles(const int32_t* topk_idx, int T, int n_slot, int n_groups, int32_t* counts, int32_t* offsets, int32_t* perm,
+                      int32_t* slot_of, int tile_rows, int32_t* tile_g, int32_t* tile_m0, int32_t* n_tiles, void* stream);
+
+/* Grouped gemm256 over that tile list (tile_rows = 128 for a hi/lo A, 256 for a plain bf16 A with a_lo_off = 0): no workgroup
+ * runs for an empty tile, whatever the split of the rows over the experts.  A has a_rows_total rows.
+ *   epi 0: C fp32 [*, N];  1: C bf16 [*, N];  4: W_g holds 2N rows (gate, up), C = bf16 hi rows + lo rows c_lo_off further of
+ *   silu(gate) * up;  6: the same as plain bf16.   max_mtiles >= sum_g ceil(cnt[g] / tile_rows). */
+int mn_gemm256_grouped_tiles(const uint16_t* A, int64_t lda, int64_t a_lo_off, int64_t a_rows_total, const int32_t* a_rows,
+                             const uint16_t* W, int64_t ldw, int64_t w_gstride, const int32_t* off, const int32_t* cnt, int n_groups,
+                             const int32_t* tile_g, const int32_t* tile_m0, const int32_t* n_tiles, int max_mtiles, void* C,
+                             int64_t ldc, int64_t c_lo_off, int N, int K, int epi, void* stream);
+
 /* Weight-streaming MFMA kernel behind the M >= 5 route of mn_skinny_gemm: Y bf16 [2][M][K] (activations split
  * into hi rows then lo rows), W bf16 [Ntot, K] dense, P fp32 [nz][M][Ntot] K-slice partials with
  * nz = mn_stream_mfma_slices(M, Ntot, K) (the launch plan picks slices of 256..1024 k so that every wave of the

@@ -255,26 +255,45 @@ class BailingMoeDecoder:
         return out[last.to(dev)]
 
     def prefill_mfma(self, embeds, seq=0, past=0, image_mask=None, positions=None, key_mask=None):
-        """Causal prefill of ONE sequence for long prompts on the bf16 MFMA path: per layer
-        RMSNorm -> QKV GEMM -> RoPE + KV append -> GQA flash attention (hd 128) -> dense GEMM (+residual) ->
+        """Causal prefill of ONE sequence for long prompts on the bf16 MFMA path (see prefill_mfma_many).  embeds fp32 [T,H].
+        Returns the final-norm hidden state of the LAST token [1,H] fp32 (what the next-token logits need)."""
+        return self.prefill_mfma_many([embeds], [seq], past=past, image_masks=None if image_mask is None else [image_mask],
+                                      positions=None if positions is None else [positions],
+                                      key_masks=None if key_mask is None else [key_mask])
+
+    def prefill_mfma_many(self, embeds_list, seqs, past=0, image_masks=None, positions=None, key_masks=None):
+        """Causal prefill of one or several sequences (lengths may differ) on the bf16 MFMA path, their tokens stacked into
+        one row block: per layer
+        RMSNorm -> QKV GEMM -> [per sequence: RoPE + KV append -> GQA flash attention (hd 128)] -> dense GEMM (+residual) ->
         RMSNorm -> gate GEMM -> top-k -> expert sort -> grouped gate/up GEMM -> SwiGLU -> grouped down GEMM ->
-        weighted combine (+residual).  fp32 residual stream, bf16 GEMM operands (like the reference's autocast
-        path); the KV arena stays fp32.  embeds fp32 [T,H].  Returns the final-norm hidden state of the LAST
-        token [1,H] fp32 (what the next-token logits need)."""
+        weighted combine (+residual).  Every GEMM and the expert grouping see all sequences' tokens at once (the expert weights
+        are read once per call instead of once per sequence; 8 x 1058 tokens put ~800 rows in front of every expert).
+        fp32 residual stream, bf16 GEMM operands (like the reference's autocast path); the KV arena stays fp32.
+        embeds_list[i] fp32 [T_i,H] goes to cache sequence seqs[i] from slot `past`.  Returns the final-norm hidden state of
+        the LAST token of each sequence [B,H] fp32 (what the next-token logits need)."""
         import math
         cfg, L_ = self.cfg, lib()
-        T, H = embeds.shape
-        assert past + T <= self.t_max and cfg.head_dim == 128
+        lens = [int(e.shape[0]) for e in embeds_list]
+        H = embeds_list[0].shape[1]
+        assert len(seqs) == len(lens) and past + max(lens) <= self.t_max and cfg.head_dim == 128
         dev = self.device
         nq, nkv, hd, I = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.moe_intermediate_size
         E, k, S = cfg.num_experts, cfg.num_experts_per_tok, self.n_shared
         n_slot, G = k + S, E + S
         st = current_stream()
-        h = embeds.to(torch.float32).contiguous().clone()
-        pos = (torch.arange(past, past + T, dtype=torch.int32, device=dev) if positions is None
-               else positions.to(dev, torch.int32).contiguous())
-        im = None if image_mask is None else image_mask.to(dev, torch.uint8).contiguous()
-        km = None if key_mask is None else key_mask.to(dev, torch.uint8).contiguous()
+        h = torch.cat([e.to(dev, torch.float32) for e in embeds_list], 0).contiguous()
+        if len(embeds_list) == 1:
+            h = h.clone()
+        T = h.shape[0]
+        r0s = [sum(lens[:i]) for i in range(len(lens))]
+        pos = [torch.arange(past, past + n, dtype=torch.int32, device=dev) if positions is None or positions[i] is None
+               else positions[i].to(dev, torch.int32).contiguous() for i, n in enumerate(lens)]
+        im = None
+        if image_masks is not None and any(m is not None for m in image_masks):
+            im = torch.cat([torch.zeros(n, dtype=torch.uint8, device=dev) if m is None else m.reshape(-1).to(dev, torch.uint8)
+                            for m, n in zip(image_masks, lens)]).contiguous()
+        kms = [None if key_masks is None or key_masks[i] is None else key_masks[i].to(dev, torch.uint8).contiguous()
+               for i in range(len(lens))]
         bf = torch.bfloat16
         xn = torch.empty(T, H, dtype=bf, device=dev)
         qkv = torch.empty(T, (nq + 2 * nkv) * hd, dtype=torch.float32, device=dev)
@@ -287,18 +306,28 @@ class BailingMoeDecoder:
         off = torch.empty(G + 1, dtype=torch.int32, device=dev)
         perm = torch.empty(T * n_slot, dtype=torch.int32, device=dev)
         slot_of = torch.empty(T * n_slot, dtype=torch.int32, device=dev)
-        xg = torch.empty(T * n_slot, H, dtype=bf, device=dev)
-        gu = torch.empty(T * n_slot, 2 * I, dtype=bf, device=dev)
         hm = torch.empty(T * n_slot, I, dtype=bf, device=dev)
         yg = torch.empty(T * n_slot, H, dtype=torch.float32, device=dev)
+        # expert GEMMs: gemm256 over the live 256-row tiles of the expert-sorted pairs (gather while staging, SwiGLU in the
+        # epilogue) when the shapes allow, else the 128-tile grouped kernel with separate gather / SwiGLU passes
+        tiled = (H % 64 == 0 and I % 64 == 0 and T * n_slot * max(H, I) * 2 < (1 << 32) and 2 * I * H * 2 < (1 << 32))
+        if tiled:
+            max_mt = T * n_slot // 256 + G
+            tile_g = torch.empty(max_mt, dtype=torch.int32, device=dev)
+            tile_m0 = torch.empty(max_mt, dtype=torch.int32, device=dev)
+            n_tiles = torch.empty(1, dtype=torch.int32, device=dev)
+        else:
+            xg = torch.empty(T * n_slot, H, dtype=bf, device=dev)
+            gu = torch.empty(T * n_slot, 2 * I, dtype=bf, device=dev)
         for li, ly in enumerate(self.layers):
-            kv_seq = self.kv_cache[li, seq]
             check(L_.mn_rmsnorm_bf16(ptr(h), H, ptr(ly["ln1"]), cfg.rms_norm_eps, ptr(xn), H, T, H, st), "mn_rmsnorm_bf16")
             ops.gemm_bf16(xn, ly["wqkv"], None, "f32", out=qkv)
-            check(L_.mn_rope_kv_prefill(ptr(qkv), qkv.stride(0), T, nq, nkv, hd, ptr(self.cos), ptr(self.sin), ptr(pos), past,
-                                        1.0 / math.sqrt(hd), ptr(qb), ptr(kv_seq), self.t_max, st), "mn_rope_kv_prefill")
-            check(L_.mn_attn_prefill_gqa_hd128(ptr(qb), ptr(kv_seq), self.t_max, nq, nkv, past, T, ptr(km), ptr(att), st),
-                  "mn_attn_prefill_gqa_hd128")
+            for i, n in enumerate(lens):
+                kv_seq, r0 = self.kv_cache[li, seqs[i]], r0s[i]
+                check(L_.mn_rope_kv_prefill(ptr(qkv[r0:]), qkv.stride(0), n, nq, nkv, hd, ptr(self.cos), ptr(self.sin), ptr(pos[i]),
+                                            past, 1.0 / math.sqrt(hd), ptr(qb[r0:]), ptr(kv_seq), self.t_max, st), "mn_rope_kv_prefill")
+                check(L_.mn_attn_prefill_gqa_hd128(ptr(qb[r0:]), ptr(kv_seq), self.t_max, nq, nkv, past, n, ptr(kms[i]), ptr(att[r0:]),
+                                                   st), "mn_attn_prefill_gqa_hd128")
             ops.gemm_bf16(att, ly["wdense"], None, "f32_resid", out=h)
             check(L_.mn_rmsnorm_bf16(ptr(h), H, ptr(ly["ln2"]), cfg.rms_norm_eps, ptr(xn), H, T, H, st), "mn_rmsnorm_bf16")
             ops.gemm_bf16(xn, ly["gate"], None, "f32", out=lg[0])
@@ -307,15 +336,26 @@ class BailingMoeDecoder:
                 ops.gemm_bf16(xn, ly["image_gate"], None, "f32", out=lg[1])
             check(L_.mn_moe_topk_logits(ptr(lg[0]), ptr(lg[1]) if use_img else None, ptr(im) if use_img else None, T, E, k,
                                         int(cfg.norm_topk_prob), S, ptr(ti), ptr(tw), st), "mn_moe_topk_logits")
-            check(L_.mn_moe_sort(ptr(ti), T, n_slot, G, ptr(cnt), ptr(off), ptr(perm), ptr(slot_of), st), "mn_moe_sort")
-            check(L_.mn_gather_rows_bf16(ptr(xn), H, ptr(perm), ptr(xg), H, T * n_slot, H, st), "mn_gather_rows_bf16")
-            check(L_.mn_gemm_bf16_grouped(ptr(xg), H, ptr(ly["w_gate_up"]), H, 2 * I * H, ptr(off), ptr(cnt), G, ptr(gu), 2 * I,
-                                          T, 2 * I, H, ops.GEMM_EPI["bf16"], st), "mn_gemm_bf16_grouped(gate_up)")
-            check(L_.mn_swiglu_bf16(ptr(gu), 2 * I, ptr(hm), I, T * n_slot, I, st), "mn_swiglu_bf16")
-            check(L_.mn_gemm_bf16_grouped(ptr(hm), I, ptr(ly["w_down"]), I, H * I, ptr(off), ptr(cnt), G, ptr(yg), H, T, H, I,
-                                          ops.GEMM_EPI["f32"], st), "mn_gemm_bf16_grouped(down)")
+            if tiled:
+                check(L_.mn_moe_sort_tiles(ptr(ti), T, n_slot, G, ptr(cnt), ptr(off), ptr(perm), ptr(slot_of), 256, ptr(tile_g),
+                                           ptr(tile_m0), ptr(n_tiles), st), "mn_moe_sort_tiles")
+                check(L_.mn_gemm256_grouped_tiles(ptr(xn), H, 0, T, ptr(perm), ptr(ly["w_gate_up"]), H, 2 * I * H, ptr(off), ptr(cnt), G,
+                                                  ptr(tile_g), ptr(tile_m0), ptr(n_tiles), max_mt, ptr(hm), I, 0, I, H, 6, st),
+                      "mn_gemm256_grouped_tiles(gate_up)")
+                check(L_.mn_gemm256_grouped_tiles(ptr(hm), I, 0, T * n_slot, None, ptr(ly["w_down"]), I, H * I, ptr(off), ptr(cnt), G,
+                                                  ptr(tile_g), ptr(tile_m0), ptr(n_tiles), max_mt, ptr(yg), H, 0, H, I, 0, st),
+                      "mn_gemm256_grouped_tiles(down)")
+            else:
+                check(L_.mn_moe_sort(ptr(ti), T, n_slot, G, ptr(cnt), ptr(off), ptr(perm), ptr(slot_of), st), "mn_moe_sort")
+                check(L_.mn_gather_rows_bf16(ptr(xn), H, ptr(perm), ptr(xg), H, T * n_slot, H, st), "mn_gather_rows_bf16")
+                check(L_.mn_gemm_bf16_grouped(ptr(xg), H, ptr(ly["w_gate_up"]), H, 2 * I * H, ptr(off), ptr(cnt), G, ptr(gu), 2 * I,
+                                              T, 2 * I, H, ops.GEMM_EPI["bf16"], st), "mn_gemm_bf16_grouped(gate_up)")
+                check(L_.mn_swiglu_bf16(ptr(gu), 2 * I, ptr(hm), I, T * n_slot, I, st), "mn_swiglu_bf16")
+                check(L_.mn_gemm_bf16_grouped(ptr(hm), I, ptr(ly["w_down"]), I, H * I, ptr(off), ptr(cnt), G, ptr(yg), H, T, H, I,
+                                              ops.GEMM_EPI["f32"], st), "mn_gemm_bf16_grouped(down)")
             check(L_.mn_moe_combine(ptr(yg), H, ptr(slot_of), ptr(tw), n_slot, ptr(h), H, T, H, st), "mn_moe_combine")
-        return self._final_norm_rows(h[T - 1:T].contiguous())
+        last = torch.tensor([r0 + n - 1 for r0, n in zip(r0s, lens)], dtype=torch.long, device=dev)
+        return self._final_norm_rows(h[last].contiguous())
 
     def _final_norm_rows(self, x):
         """model.norm on the prefill path (modeling_bailing_moe.py:1521): bf16 output like the rest of that path."""

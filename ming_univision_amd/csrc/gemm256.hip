@@ -539,3 +539,32 @@ extern "C" int mn_gemm256_grouped(const uint16_t* A, int64_t lda, int64_t a_lo_o
   MN_CHECK_LAUNCH("mn_gemm256_grouped");
   return MN_OK;
 }
+
+// Grouped form over a device-built row-tile list (mn_moe_sort_tiles: tile t = rows [tile_m0[t], ..) of group tile_g[t]; tile_rows =
+// 128 for hi/lo activations, 256 for plain bf16 ones): no workgroup is launched for an empty tile slot beyond *n_tiles, whatever
+// the split of the rows over the groups.  a_lo_off = 0: plain bf16 activations (the bf16 prefill path).
+//   epi 0: C fp32 [*, N]           1: C bf16 [*, N]
+//   epi 4: W_g holds 2N rows (gate, up); C bf16 hi rows and lo rows c_lo_off further = silu(gate) * up       6: the same, plain bf16
+// max_mtiles >= sum_g ceil(cnt[g] / tile_rows) (e.g. total_rows / tile_rows + n_groups).
+extern "C" int mn_gemm256_grouped_tiles(const uint16_t* A, int64_t lda, int64_t a_lo_off, int64_t a_rows_total, const int32_t* a_rows,
+                                        const uint16_t* W, int64_t ldw, int64_t w_gstride, const int32_t* off, const int32_t* cnt,
+                                        int n_groups, const int32_t* tile_g, const int32_t* tile_m0, const int32_t* n_tiles,
+                                        int max_mtiles, void* C, int64_t ldc, int64_t c_lo_off, int N, int K, int epi, void* stream) {
+  const bool paired = epi == E_SWIGLU_SPLIT || epi == E_SWIGLU_BF16;
+  MN_CHECK_ARG(A && W && C && off && cnt && tile_g && tile_m0 && n_tiles && n_groups >= 1 && max_mtiles >= 1 && a_lo_off >= 0 &&
+                   a_rows_total >= 1, "mn_gemm256_grouped_tiles: bad args");
+  MN_CHECK_ARG(epi == E_F32 || epi == E_BF16 || epi == E_SWIGLU_SPLIT || epi == E_SWIGLU_BF16, "mn_gemm256_grouped_tiles: epi %d", epi);
+  MN_CHECK_ARG(N >= 4 && (N % 4) == 0 && K >= BK && (K % BK) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && (a_lo_off % 8) == 0 &&
+                   (w_gstride % 8) == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0 && (epi != E_SWIGLU_SPLIT || c_lo_off > 0) &&
+                   (a_rows_total * lda + a_lo_off) * 2 < ((int64_t)1 << 32) && (int64_t)(paired ? 2 : 1) * N * ldw * 2 < ((int64_t)1 << 32),
+               "mn_gemm256_grouped_tiles: unsupported shape N=%d K=%d", N, K);
+  G256 p{};
+  p.A = A; p.lda = lda; p.a_lo_off = a_lo_off; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.c_lo_off = c_lo_off;
+  p.w_pair_rows = paired ? N : 0; p.M = (int)a_rows_total; p.N = N; p.K = K;
+  p.g_off = off; p.g_cnt = cnt; p.w_gstride = w_gstride; p.a_rows = a_rows; p.n_groups = n_groups;
+  p.tile_g = tile_g; p.tile_m0 = tile_m0; p.n_tiles = n_tiles; p.max_mtiles = max_mtiles;
+  const int rc = g256_launch(p, epi, 1, mn_stream(stream));
+  if (rc < 0) return rc;
+  MN_CHECK_LAUNCH("mn_gemm256_grouped_tiles");
+  return MN_OK;
+}

@@ -170,8 +170,8 @@ class MingUniVisionForConditionalGeneration:
         cfg, dev = self.config.llm_config, self.device
         B = len(requests)
         t_start = time.perf_counter()
-        lens, last = [], []
         self.model.ensure_sequences(B)
+        lens, ids_l, embeds, masks = [], [], [], [None] * B
         for b, r in enumerate(requests):
             ids = r["input_ids"].reshape(1, -1).to(dev).clip(0, cfg.vocab_size - 1)
             am = r.get("attention_mask")
@@ -180,17 +180,40 @@ class MingUniVisionForConditionalGeneration:
             T = ids.shape[1]
             if T + max_new_tokens > self.model.t_max:
                 raise ValueError(f"request {b}: {T} prompt tokens + {max_new_tokens} new tokens exceed the KV arena (t_max = {self.model.t_max})")
-            embeds = self.model.embed(ids[0])
-            image_mask = None
-            if r.get("pixel_values") is not None and T > 1:
-                feats = self.extract_image_feature(r["pixel_values"].to(dev), r.get("image_grid_thw"))
-                embeds, image_mask = self.prompt_wrap_vision(ids, embeds, feats)
-            if T > self.mfma_prefill_threshold and cfg.head_dim == 128:
-                h = self.model.prefill_mfma(embeds, seq=b, past=0, image_mask=image_mask)
-            else:
-                h = self.model.prefill(embeds, seq=b, past=0, image_mask=image_mask)[-1:]
-            last.append(h)
+            ids_l.append(ids)
             lens.append(T)
+            embeds.append(self.model.embed(ids[0]))
+        # vision tower: requests whose images have the same shape go through MingTok as batches (<= ~8M pixels per pass)
+        by_shape = {}
+        for b, r in enumerate(requests):
+            if r.get("pixel_values") is not None and lens[b] > 1:
+                by_shape.setdefault(tuple(r["pixel_values"].shape), []).append(b)
+        for shape, members in by_shape.items():
+            per = max(1, (8 << 20) // max(1, shape[0] * shape[-1] * shape[-2]))
+            for c0 in range(0, len(members), per):
+                chunk = members[c0:c0 + per]
+                px = torch.cat([requests[b]["pixel_values"].to(dev) for b in chunk], 0)
+                feats = self.extract_image_feature(px)
+                feats = feats.reshape(len(chunk), -1, feats.shape[-1])
+                for j, b in enumerate(chunk):
+                    embeds[b], masks[b] = self.prompt_wrap_vision(ids_l[b], embeds[b], feats[j])
+        # prompts: long ones on the bf16 MFMA path, stacked up to 8192 tokens per pass; short ones through the decode kernels
+        last = [None] * B
+        long_ = [b for b in range(B) if lens[b] > self.mfma_prefill_threshold and cfg.head_dim == 128]
+        c0 = 0
+        while c0 < len(long_):
+            c1, tot = c0, 0
+            while c1 < len(long_) and (c1 == c0 or tot + lens[long_[c1]] <= 8192):
+                tot += lens[long_[c1]]
+                c1 += 1
+            chunk = long_[c0:c1]
+            hs = self.model.prefill_mfma_many([embeds[b] for b in chunk], chunk, past=0, image_masks=[masks[b] for b in chunk])
+            for j, b in enumerate(chunk):
+                last[b] = hs[j:j + 1]
+            c0 = c1
+        for b in range(B):
+            if last[b] is None:
+                last[b] = self.model.prefill(embeds[b], seq=b, past=0, image_mask=masks[b])[-1:]
         hidden = torch.cat(last, 0).contiguous()
         if timings is not None:
             torch.cuda.synchronize(dev)

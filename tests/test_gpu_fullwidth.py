@@ -169,6 +169,27 @@ def test_wide_rf_sampler_matches_narrow_route(n_images, rpi):
     assert float(err.max()) < 2e-4, float(err.max())
 
 
+def test_prefill_mfma_many_matches_one_sequence_at_a_time():
+    """bf16 MFMA prefill of three prompts of different lengths stacked into one row block (production layer shapes, 2 layers,
+    one prompt with image-token rows): last-token hidden states and KV entries against the same prompts prefilled one by one
+    (same kernels; only the GEMM row-block composition differs)."""
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder
+    cfg = C.BailingMoeConfig.ming_univision_16b_a3b()
+    cfg.num_hidden_layers = 2
+    dec = BailingMoeDecoder.synthetic(cfg, torch.device("cuda"), seed=6, with_vocab=False, t_max=160, n_seq=6)
+    g = torch.Generator().manual_seed(1)
+    lens = [70, 131, 100]
+    embeds = [torch.randn(n, cfg.hidden_size, generator=g).cuda() * 0.3 for n in lens]
+    masks = [None, (torch.arange(131) % 3 == 0).cuda(), None]
+    one = torch.cat([dec.prefill_mfma(e, seq=i, past=0, image_mask=m) for i, (e, m) in enumerate(zip(embeds, masks))])
+    many = dec.prefill_mfma_many(embeds, [3, 4, 5], past=0, image_masks=masks)
+    assert torch.isfinite(many).all()
+    assert rel_err(many, one) < 2e-3, rel_err(many, one)
+    for i, n in enumerate(lens):
+        a, b = dec.kv_cache[:, i, ..., :n, :], dec.kv_cache[:, 3 + i, ..., :n, :]
+        assert rel_err(b, a) < 2e-3
+
+
 def test_wide_llm_step_matches_narrow_route_ragged_rows():
     """One decoder-stack step at production layer shapes for 150 rows with ragged cache lengths, holey key masks and shared
     embeddings (x_row_div = 2): wide route against the same rows pushed through the <= 64-row route in three calls."""
