@@ -245,6 +245,15 @@ int mn_gemm256_grouped(const uint16_t* A, int64_t lda, int64_t a_lo_off, const i
                        int64_t w_gstride, const int32_t* off, const int32_t* cnt, int n_groups, void* C, int64_t ldc,
                        int64_t c_lo_off, int m_max, int N, int K, int swiglu, void* stream);
 
+/* GQA 4:1 flash attention (head dim 128, bottom-right causal; modeling_bailing_moe.py:848-1045) of several prompt spans in one
+ * launch, K / V read from the fp32 KV arena of one layer (kv_layer [n_seq_total, 2, n_kv, t_max, 128]): span i = rows
+ * [r0_i, r0_i + len_i) of q / out (bf16 [rows, n_q, 128], q RoPE'd and pre-scaled) against keys [0, past + len_i) of cache
+ * sequence seq_i.  seq_tab: device int32 [n_spans][3] = (seq_i, r0_i, len_i); max_len >= every len_i; key_mask optional
+ * uint8 [n_spans, mask_stride] (1 = attend). */
+int mn_flash_prefill_gqa_hd128(const uint16_t* q, const float* kv_layer, int64_t t_max, int n_q, int n_kv, int past,
+                               const int32_t* seq_tab, int n_spans, int max_len, const uint8_t* key_mask, int64_t mask_stride,
+                               uint16_t* out, void* stream);
+
 /* mn_moe_sort plus the list of LIVE row tiles of the grouped GEMMs: tile t (t < *n_tiles) = rows [tile_m0[t], tile_m0[t] +
  * tile_rows) of group tile_g[t]; tile_g / tile_m0 hold up to T * n_slot / tile_rows + n_groups entries.  All device arrays.
  * (modeling_bailing_moe.py:608-616: the expert-count / argsort bookkeeping of moe_infer, without the host sync.) */

@@ -294,6 +294,14 @@ class BailingMoeDecoder:
                             for m, n in zip(image_masks, lens)]).contiguous()
         kms = [None if key_masks is None or key_masks[i] is None else key_masks[i].to(dev, torch.uint8).contiguous()
                for i in range(len(lens))]
+        seq_tab = km_all = None
+        if nq == 4 * nkv and len(lens) > 1:
+            seq_tab = torch.tensor([[int(s_), r0, n] for s_, r0, n in zip(seqs, r0s, lens)], dtype=torch.int32).to(dev)
+            if any(m is not None for m in kms):
+                km_all = torch.ones(len(lens), self.t_max, dtype=torch.uint8, device=dev)
+                for i, m in enumerate(kms):
+                    if m is not None:
+                        km_all[i, :m.numel()] = m.reshape(-1)
         bf = torch.bfloat16
         xn = torch.empty(T, H, dtype=bf, device=dev)
         qkv = torch.empty(T, (nq + 2 * nkv) * hd, dtype=torch.float32, device=dev)
@@ -326,8 +334,13 @@ class BailingMoeDecoder:
                 kv_seq, r0 = self.kv_cache[li, seqs[i]], r0s[i]
                 check(L_.mn_rope_kv_prefill(ptr(qkv[r0:]), qkv.stride(0), n, nq, nkv, hd, ptr(self.cos), ptr(self.sin), ptr(pos[i]),
                                             past, 1.0 / math.sqrt(hd), ptr(qb[r0:]), ptr(kv_seq), self.t_max, st), "mn_rope_kv_prefill")
-                check(L_.mn_attn_prefill_gqa_hd128(ptr(qb[r0:]), ptr(kv_seq), self.t_max, nq, nkv, past, n, ptr(kms[i]), ptr(att[r0:]),
-                                                   st), "mn_attn_prefill_gqa_hd128")
+                if seq_tab is None:
+                    check(L_.mn_attn_prefill_gqa_hd128(ptr(qb[r0:]), ptr(kv_seq), self.t_max, nq, nkv, past, n, ptr(kms[i]),
+                                                       ptr(att[r0:]), st), "mn_attn_prefill_gqa_hd128")
+            if seq_tab is not None:      # all spans in one launch (flash_prefill.hip)
+                check(L_.mn_flash_prefill_gqa_hd128(ptr(qb), ptr(self.kv_cache[li]), self.t_max, nq, nkv, past, ptr(seq_tab), len(lens),
+                                                    max(lens), ptr(km_all), 0 if km_all is None else km_all.stride(0), ptr(att), st),
+                      "mn_flash_prefill_gqa_hd128")
             ops.gemm_bf16(att, ly["wdense"], None, "f32_resid", out=h)
             check(L_.mn_rmsnorm_bf16(ptr(h), H, ptr(ly["ln2"]), cfg.rms_norm_eps, ptr(xn), H, T, H, st), "mn_rmsnorm_bf16")
             ops.gemm_bf16(xn, ly["gate"], None, "f32", out=lg[0])

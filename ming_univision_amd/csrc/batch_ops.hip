@@ -634,9 +634,13 @@ __global__ __launch_bounds__(256) void attn_prefill_hd64_kernel(const bf16_t* __
 }
 }  // namespace
 
+extern "C" int mn_flash_enabled();
+extern "C" int mn_flash_prefill_hd64(const uint16_t* qkv, uint16_t* out, int B, int T, int n_heads, int causal, void* stream);
+
 extern "C" int mn_attn_prefill_hd64(const uint16_t* qkv, uint16_t* out, int B, int T, int n_heads, int causal,
                                     void* stream) {
   MN_CHECK_ARG(qkv && out && B >= 1 && T >= 1 && n_heads >= 1, "mn_attn_prefill_hd64: bad args");
+  if (mn_flash_enabled()) return mn_flash_prefill_hd64(qkv, out, B, T, n_heads, causal, stream);   // flash_prefill.hip (64-key tiles)
   hipLaunchKernelGGL(attn_prefill_hd64_kernel, dim3(mn_cdiv(T, 64), n_heads, B), dim3(256), 0, mn_stream(stream), qkv,
                      out, B, T, n_heads, causal);
   MN_CHECK_LAUNCH("mn_attn_prefill_hd64");
