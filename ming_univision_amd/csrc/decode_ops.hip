@@ -386,14 +386,32 @@ __global__ void attn_decode_combine_kernel(const float* __restrict__ partial, in
                                            bf16_t* __restrict__ split, int M) {
   const int m = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
   const float* p = partial + (((int64_t)m * n_q + h) * S) * (HD + 2);
-  float mx = -INFINITY;
-  for (int s = 0; s < S; ++s) mx = fmaxf(mx, p[s * (HD + 2) + HD]);
   float l = 0.f, acc = 0.f;
-  for (int s = 0; s < S; ++s) {
-    const float ms = p[s * (HD + 2) + HD];
+  if (S <= 64) {
+    // lane s of every wave holds split s: the statistics are one parallel load + wave reductions, and the weighted sum over
+    // the splits runs on independent loads (the serial form cost 14 us at 32 splits: 64 dependent round trips to L2)
+    const int lane = d & 63;
+    float ms = -INFINITY, ls = 0.f;
+    if (lane < S) { ms = p[lane * (HD + 2) + HD]; ls = p[lane * (HD + 2) + HD + 1]; }
+    const float mx = wave_max(ms);
     const float f = (ms == -INFINITY) ? 0.f : __expf(ms - mx);
-    l = fmaf(f, p[s * (HD + 2) + HD + 1], l);
-    acc = fmaf(f, p[s * (HD + 2) + d], acc);
+    l = wave_sum(f * ls);
+    for (int s0 = 0; s0 < S; s0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = s0 + j < S ? p[(s0 + j) * (HD + 2) + d] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = fmaf(__shfl(f, (s0 + j) & 63, 64), v[j], acc);
+    }
+  } else {
+    float mx = -INFINITY;
+    for (int s = 0; s < S; ++s) mx = fmaxf(mx, p[s * (HD + 2) + HD]);
+    for (int s = 0; s < S; ++s) {
+      const float ms = p[s * (HD + 2) + HD];
+      const float f = (ms == -INFINITY) ? 0.f : __expf(ms - mx);
+      l = fmaf(f, p[s * (HD + 2) + HD + 1], l);
+      acc = fmaf(f, p[s * (HD + 2) + d], acc);
+    }
   }
   const float v = l > 0.f ? acc / l : 0.f;     // a row with no attended key yields 0, not NaN (precondition: see mingnative.h)
   const int64_t o = ((int64_t)m * n_q + h) * HD + d;
