@@ -164,15 +164,25 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const FlashP p) {
     const bool whole = k0 + FKT <= k_total && (!p.causal || k0 + FKT - 1 <= past + q0) && !km;
     if (!whole) {
 #pragma unroll
-      for (int qg = 0; qg < 2; ++qg)
+      for (int f = 0; f < 4; ++f) {
+        const int kb4 = k0 + f * 16 + g * 4;                 // this lane's four keys of fragment f
+        uint32_t live = 0xf;                                  // bit r: key kb4 + r exists and is not masked out
+        if (km) {
+          live = 0;
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+          for (int r = 0; r < 4; ++r) live |= (km[min(kb4 + r, k_total - 1)] != 0 ? 1u : 0u) << r;
+        }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = k0 + f * 16 + g * 4 + r;
-            const bool ok = key < k_total && (!p.causal || key <= past + q_idx[qg]) && (!km || km[min(key, k_total - 1)] != 0);
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb4 + r;
+          const bool there = key < k_total && ((live >> r) & 1u);
+#pragma unroll
+          for (int qg = 0; qg < 2; ++qg) {
+            const bool ok = there && (!p.causal || key <= past + q_idx[qg]);
             s[qg][f][r] = ok ? s[qg][f][r] : -INFINITY;
           }
+        }
+      }
     }
     bf16x8 pf[2][2];
 #pragma unroll

@@ -206,6 +206,49 @@ def test_attn_prefill_hd64(ops, B, T, nh, causal):
     assert rel(out, ref) < 3 * 2 ** -8
 
 
+@pytest.mark.parametrize("past,with_mask", [(0, False), (37, False), (5, True)])
+def test_flash_prefill_gqa_hd128_spans(ops, past, with_mask):
+    """GQA 16:4 flash attention (hd 128, bottom-right causal) of three prompt spans of different lengths in ONE launch, K / V
+    read from the fp32 arena (sequences 2, 0, 3 of 4), with keys before the span (past) and holey key masks; and the
+    one-span entry mn_attn_prefill_gqa_hd128, against fp64 softmax attention."""
+    from ming_univision_amd._lib import lib, ptr, check, current_stream
+    L = lib()
+    nq, nkv, t_max, hd = 16, 4, 200, 128
+    lens, seqs = [70, 33, 129], [2, 0, 3]
+    g = torch.Generator().manual_seed(61)
+    kv = torch.randn(4, 2, nkv, t_max, hd, generator=g)
+    q = (torch.randn(sum(lens), nq, hd, generator=g) * 0.2).to(torch.bfloat16)
+    km = None
+    if with_mask:
+        km = (torch.rand(len(lens), t_max, generator=g) > 0.3).to(torch.uint8)
+        for i, n in enumerate(lens):
+            km[i, past:past + n] |= (torch.arange(n) % 7 == 0).to(torch.uint8)     # a few guaranteed keys (incl. query 0's own)
+    r0s = [sum(lens[:i]) for i in range(len(lens))]
+    tab = torch.tensor([[s_, r0, n] for s_, r0, n in zip(seqs, r0s, lens)], dtype=torch.int32).cuda()
+    kvd, qd = kv.cuda(), q.cuda()
+    kmd = km.cuda() if with_mask else None
+    out = torch.zeros(sum(lens), nq * hd, dtype=torch.bfloat16, device="cuda")
+    check(L.mn_flash_prefill_gqa_hd128(ptr(qd), ptr(kvd), t_max, nq, nkv, past, ptr(tab), len(lens), max(lens),
+                                       ptr(kmd), t_max, ptr(out), current_stream()), "flash")
+    kb = kv.to(torch.bfloat16).double()                      # the kernel multiplies bf16 K / V
+    for i, (s_, r0, n) in enumerate(zip(seqs, r0s, lens)):
+        T = past + n
+        K = kb[s_, 0, :, :T].repeat_interleave(nq // nkv, 0)  # [nq, T, hd]
+        V = kb[s_, 1, :, :T].repeat_interleave(nq // nkv, 0)
+        Q = q[r0:r0 + n].double().permute(1, 0, 2)            # [nq, n, hd]
+        att = Q @ K.transpose(-1, -2)
+        ok = torch.arange(T)[None, :] <= (past + torch.arange(n))[:, None]
+        if with_mask:
+            ok = ok & km[i, :T].bool()[None, :]
+        att = att.masked_fill(~ok[None], float("-inf"))
+        ref = (att.softmax(-1) @ V).permute(1, 0, 2).reshape(n, nq * hd)
+        assert rel(out[r0:r0 + n], ref) < 3 * 2 ** -8, (i, rel(out[r0:r0 + n], ref))
+        one = torch.zeros(n, nq * hd, dtype=torch.bfloat16, device="cuda")
+        check(L.mn_attn_prefill_gqa_hd128(ptr(qd[r0:]), ptr(kvd[s_]), t_max, nq, nkv, past, n,
+                                          ptr(kmd[i]) if with_mask else None, ptr(one), current_stream()), "attn")
+        assert torch.equal(one, out[r0:r0 + n])
+
+
 @pytest.mark.parametrize("M,N,K,epi,pro", [(9, 515, 2048, "none", "rmsnorm"), (16, 8192, 3072, "swiglu", "ln_mod"),
                                            (12, 3072, 8192, "resid_gate", "none"), (16, 32, 3072, "none", "ln_mod"),
                                            (10, 1000, 32, "silu", "none"), (16, 3072, 2048, "resid", "add_silu"),
