@@ -245,6 +245,12 @@ int mn_gemm256_grouped(const uint16_t* A, int64_t lda, int64_t a_lo_off, const i
                        int64_t w_gstride, const int32_t* off, const int32_t* cnt, int n_groups, void* C, int64_t ldc,
                        int64_t c_lo_off, int m_max, int N, int K, int swiglu, void* stream);
 
+/* Tail of a split-K Linear that joins the fp32 residual stream, fused with the next LayerNorm (MingTok layers/block.py:80-105):
+ * h[m] += sum_z P[z * slab + m * D + :] (bias already in slab 0, as mn_gemm256_splitk leaves it); if y != NULL:
+ * y[m] = bf16(LayerNorm(h[m]; ln_g, ln_b optional, eps)), followed by exact-erf GELU when gelu != 0.  D % 4 == 0, D <= 4096. */
+int mn_slab_resid_norm(const float* P, int nz, int64_t slab, float* h, int64_t ldh, const uint16_t* ln_g, const uint16_t* ln_b,
+                       float eps, int gelu, uint16_t* y, int64_t ldy, int M, int D, void* stream);
+
 /* GQA 4:1 flash attention (head dim 128, bottom-right causal; modeling_bailing_moe.py:848-1045) of several prompt spans in one
  * launch, K / V read from the fp32 KV arena of one layer (kv_layer [n_seq_total, 2, n_kv, t_max, 128]): span i = rows
  * [r0_i, r0_i + len_i) of q / out (bf16 [rows, n_q, 128], q RoPE'd and pre-scaled) against keys [0, past + len_i) of cache

@@ -753,6 +753,23 @@ static size_t llm_carve(const mn_llm* m, int rows, int64_t t_max, void* ws, size
 
 // Largest row count one call of each composite accepts for this configuration: 2048 when the wide route applies
 // (64-aligned widths), else 64.
+// Tail of a split-K nn.Linear whose result joins the fp32 residual stream (MingTok Block.forward, layers/block.py:80-105: x = x +
+// proj(attn) / x = x + mlp(...)), fused with the LayerNorm of the NEXT consumer: h[m] += sum_z P[z][m][:] (the bias rides slab 0);
+// if y: y[m] = bf16(LayerNorm(h[m]) (ln_g, ln_b optional), GELU after it when gelu != 0).  One launch instead of a reduce pass
+// and a LayerNorm pass; used when the row count leaves a 256 x 256-tile GEMM without split-K on a fraction of the chip.
+extern "C" int mn_slab_resid_norm(const float* P, int nz, int64_t slab, float* h, int64_t ldh, const uint16_t* ln_g, const uint16_t* ln_b,
+                                  float eps, int gelu, uint16_t* y, int64_t ldy, int M, int D, void* stream) {
+  MN_CHECK_ARG(P && h && nz >= 1 && M >= 1 && wide_glue_ok(D) && (ldh % 4) == 0 && (!y || (ldy % 4) == 0), "mn_slab_resid_norm: bad args");
+  WideGlue g;
+  memset(&g, 0, sizeof(g));
+  g.h = h; g.ldh = ldh; g.P = P; g.nz = nz; g.slab = slab; g.h_out = h; g.ldho = ldh;
+  if (y) { g.norm = 2; g.ng = ln_g; g.nb = ln_b; g.eps = eps; g.act = gelu ? 1 : 0; g.Y = y; g.ldy = ldy; g.y_lo_off = 0; }
+  g.M = M; g.D = D;
+  wide_glue(g, mn_stream(stream));
+  MN_CHECK_LAUNCH("mn_slab_resid_norm");
+  return MN_OK;
+}
+
 extern "C" int mn_llm_max_rows(const mn_llm* m) { return llm_wide_ok(m, 2048) ? 2048 : 64; }
 extern "C" int mn_rf_max_rows(const mn_rf_head* h) { return rf_wide_ok(h, 2048) ? 2048 : 64; }
 extern "C" int mn_semdec_max_rows(const mn_semdec* s) { return sem_wide_ok(s, 2048) ? 2048 : 64; }

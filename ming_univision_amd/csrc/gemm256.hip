@@ -105,6 +105,21 @@ __device__ __forceinline__ void g256_src_offsets(const G256& p, int wave, int la
     }
 }
 
+// Exact-erf GELU (nn.GELU(), mingtok mlp.py:34-40) for a bf16 result: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, five
+// fma + rcp + exp2 where erff costs ~40 instructions; 128 values per lane of a 256 x 256 tile made erff 8 us of a 50 us tile).
+// The absolute error is 2^-14 of a bf16 ulp at |y| ~ 1; only the bf16 epilogue uses it.
+__device__ __forceinline__ float gelu_erf_bf16out(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float q = fmaf(1.061405429f, t, -1.453152027f);
+  q = fmaf(q, t, 1.421413741f);
+  q = fmaf(q, t, -0.284496736f);
+  q = fmaf(q, t, 0.254829592f);
+  const float e = q * t * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);      // 1 - erf(|x| / sqrt 2)
+  const float one_plus_erf = x >= 0.f ? 2.0f - e : e;
+  return 0.5f * x * one_plus_erf;
+}
+
 // Epilogue of one output tile.  A lane holds, per (i, j), output row 16 i + fr and the 4 CONSECUTIVE columns 16 j + 4 fq .. +3.
 // One lane's 4 CONSECUTIVE output columns n..n+3 of row m (u: the paired "up" values): bias, epilogue, store.
 template <int EPI>
@@ -128,7 +143,7 @@ __device__ __forceinline__ void g256_emit(const G256& p, char* Cz, int m, int n,
     const f32x4 g = *reinterpret_cast<const f32x4*>(p.gate + (int64_t)m * p.ldgate + n);
     *c += g * v;
   } else if (EPI == E_BF16 || EPI == E_BF16_GELU) {
-    if (EPI == E_BF16_GELU) v = f32x4{gelu_erf_f(v.x), gelu_erf_f(v.y), gelu_erf_f(v.z), gelu_erf_f(v.w)};
+    if (EPI == E_BF16_GELU) v = f32x4{gelu_erf_bf16out(v.x), gelu_erf_bf16out(v.y), gelu_erf_bf16out(v.z), gelu_erf_bf16out(v.w)};
     *reinterpret_cast<u32x2*>(Cz + ((int64_t)m * p.ldc + n) * 2) = u32x2{cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w)};
   } else if (EPI == E_SWIGLU_BF16) {   // y = silu(gate) * up as plain bf16 (the batched bf16 path)
     *reinterpret_cast<u32x2*>(Cz + ((int64_t)m * p.ldc + n) * 2) =

@@ -25,7 +25,7 @@ struct WideGlue {
   int act;                                             // 1: v = gelu(v) (exact erf form) before the outputs
   // ---- outputs ----
   float* out; int64_t ldo;                             // fp32 result, or NULL
-  bf16_t* Y; int64_t ldy; int64_t y_lo_off;            // bf16 hi rows at Y, lo rows y_lo_off elements further, or NULL
+  bf16_t* Y; int64_t ldy; int64_t y_lo_off;            // bf16 hi rows at Y, lo rows y_lo_off elements further (0: plain bf16, no lo rows), or NULL
   int M, D;
 };
 
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(1024) void wide_glue_kernel(const WideGlue p) {
     split_pk_bf16(v.z, v.w, h1, l1);
     bf16_t* yr = p.Y + (int64_t)m * p.ldy + col;
     *reinterpret_cast<u2*>(yr) = u2{h0, h1};
-    *reinterpret_cast<u2*>(yr + p.y_lo_off) = u2{l0, l1};
+    if (p.y_lo_off) *reinterpret_cast<u2*>(yr + p.y_lo_off) = u2{l0, l1};
   }
 }
 

@@ -73,14 +73,32 @@ class MingTok:
     def _w(self, k):
         return self.sd[k]
 
-    def _block(self, x, prefix, D, B, T, causal):
-        """Block.forward / CausalBlock.forward (layers/block.py:80-105, 301-327) on the fp32 residual x [B*T, D]."""
+    def _resid_linear(self, a, w, bias, x, next_norm):
+        """x (fp32 residual stream) += a @ w^T + bias; returns bf16 next_norm(x) when it was fused into the tail, else None.
+        next_norm: None or (weight, bias, gelu).  With few rows (a 256 x 256-tile GEMM would fill under half the chip) the
+        product runs split-K and ONE launch reduces the slabs, updates the stream and applies the consumer's LayerNorm."""
+        ks = ops.splitk_plan(a.shape[0], w.shape[0], a.shape[1])
+        if ks and lib().mn_gemm256_supported(a.shape[1], 0, w.stride(0), w.shape[0], a.shape[0], w.shape[0], a.shape[1]):
+            P = ops.gemm256_splitk_bf16(a, w, bias, ks)
+            if next_norm is None:
+                return ops.slab_resid_norm(P, x, norm=False)
+            return ops.slab_resid_norm(P, x, next_norm[0], next_norm[1], gelu=next_norm[2])
+        ops.gemm_bf16(a, w, bias, "f32_resid", out=x)
+        return None
+
+    def _block(self, x, prefix, D, B, T, causal, xn=None, next_norm=None):
+        """Block.forward / CausalBlock.forward (layers/block.py:80-105, 301-327) on the fp32 residual x [B*T, D].
+        xn: bf16 norm1(x) when the previous block's tail already produced it; next_norm = (weight, bias, gelu) of the LayerNorm
+        that consumes this block's output.  Returns that LayerNorm's bf16 output when it was fused into the tail, else None."""
         nh = D // 64
-        xn = ops.layernorm_bf16(x, self._w(prefix + ".norm1.weight"), self._w(prefix + ".norm1.bias"))
+        if xn is None:
+            xn = ops.layernorm_bf16(x, self._w(prefix + ".norm1.weight"), self._w(prefix + ".norm1.bias"))
         qkv = ops.gemm_bf16(xn, self._w(prefix + ".attn.qkv.weight"), self._w(prefix + ".attn.qkv.bias"))
         att = ops.attn_prefill_hd64(qkv, B, T, nh, causal)
-        ops.gemm_bf16(att, self._w(prefix + ".attn.proj.weight"), self._w(prefix + ".attn.proj.bias"), "f32_resid", out=x)
-        xn = ops.layernorm_bf16(x, self._w(prefix + ".norm2.weight"), self._w(prefix + ".norm2.bias"))
+        xn = self._resid_linear(att, self._w(prefix + ".attn.proj.weight"), self._w(prefix + ".attn.proj.bias"), x,
+                                (self._w(prefix + ".norm2.weight"), self._w(prefix + ".norm2.bias"), False))
+        if xn is None:
+            xn = ops.layernorm_bf16(x, self._w(prefix + ".norm2.weight"), self._w(prefix + ".norm2.bias"))
         if (prefix + ".mlp.w12.weight") in self.sd:
             w12, b12, w3 = self._w(prefix + ".mlp.w12.weight"), self._w(prefix + ".mlp.w12.bias"), self._w(prefix + ".mlp.w3.weight")
             if prefix.startswith("semantic_decoder.blocks.0."):
@@ -93,11 +111,21 @@ class MingTok:
                 h = ops.gemm256_swiglu(xn, w12, b12)                 # SwiGLU in the GEMM epilogue: no [M, 2*hidden] round trip
             else:
                 h = ops.swiglu_bf16(ops.gemm_bf16(xn, w12, b12))
-            ops.gemm_bf16(h, w3, self._w(prefix + ".mlp.w3.bias"), "f32_resid", out=x)
-        else:
-            h = ops.gemm_bf16(xn, self._w(prefix + ".mlp.fc1.weight"), self._w(prefix + ".mlp.fc1.bias"), "bf16_gelu")
-            ops.gemm_bf16(h, self._w(prefix + ".mlp.fc2.weight"), self._w(prefix + ".mlp.fc2.bias"), "f32_resid", out=x)
-        return x
+            return self._resid_linear(h, w3, self._w(prefix + ".mlp.w3.bias"), x, next_norm)
+        h = ops.gemm_bf16(xn, self._w(prefix + ".mlp.fc1.weight"), self._w(prefix + ".mlp.fc1.bias"), "bf16_gelu")
+        return self._resid_linear(h, self._w(prefix + ".mlp.fc2.weight"), self._w(prefix + ".mlp.fc2.bias"), x, next_norm)
+
+    def _blocks(self, x, stem, depth, D, B, T, causal, final_norm):
+        """`depth` blocks `stem`.i in sequence; final_norm = (weight, bias, gelu) of the LayerNorm after the last one.
+        Returns its bf16 output.  Each block's tail is asked for the next LayerNorm (fused when the tail runs split-K)."""
+        xn = None
+        for i in range(depth):
+            nxt = (final_norm if i + 1 == depth else
+                   (self._w(f"{stem}.{i + 1}.norm1.weight"), self._w(f"{stem}.{i + 1}.norm1.bias"), False))
+            xn = self._block(x, f"{stem}.{i}", D, B, T, causal, xn=xn, next_norm=nxt)
+        if xn is None:
+            xn = ops.layernorm_bf16(x, final_norm[0], final_norm[1], gelu=final_norm[2])
+        return xn
 
     def _pos_embed(self, npatch, w, h):
         """interpolate_pos_encoding (vision_transformer.py:183-215) — cached per resolution (load-time table)."""
@@ -137,10 +165,9 @@ class MingTok:
         pe = self._pos_embed(N, W, H)
         xf = xt.reshape(B * T, D)
         check(lib().mn_add_bcast_f32(ptr(xf), ptr(pe), ptr(xf), xf.numel(), pe.numel(), current_stream()), "mn_add_bcast_f32")
-        for i in range(self.enc_depth):
-            self._block(xf, f"low_level_encoder.blocks.0.{i}", D, B, T, causal=False)
-        # forward_out_layer (:173-178)
-        xn = ops.layernorm_bf16(xf, self._w("low_level_encoder.out_norm.weight"), self._w("low_level_encoder.out_norm.bias"), gelu=True)
+        # blocks, then forward_out_layer (:173-178) whose LayerNorm + GELU rides the last block's tail
+        xn = self._blocks(xf, "low_level_encoder.blocks.0", self.enc_depth, D, B, T, False,
+                          (self._w("low_level_encoder.out_norm.weight"), self._w("low_level_encoder.out_norm.bias"), True))
         y = ops.gemm_bf16(xn, self._w("low_level_encoder.out_proj.weight"), self._w("low_level_encoder.out_proj.bias"), "f32")
         out = torch.empty_like(y)
         check(lib().mn_group_mean_add(ptr(y), ptr(xf), ptr(out), B * T, D, self.latent_dim, current_stream()), "mn_group_mean_add")
@@ -156,9 +183,8 @@ class MingTok:
                           self._w("semantic_decoder.in_proj.bias"), "f32")
         x = torch.empty_like(y)
         check(lib().mn_repeat_add(ptr(y), ptr(lat), ptr(x), B * T, D, Cin, 1.0, 0.0, current_stream()), "mn_repeat_add")
-        for i in range(self.sem_depth):
-            self._block(x, f"semantic_decoder.blocks.0.{i}", D, B, T, causal=True)
-        xn = ops.layernorm_bf16(x, self._w("semantic_decoder.norm.weight"), self._w("semantic_decoder.norm.bias"))
+        xn = self._blocks(x, "semantic_decoder.blocks.0", self.sem_depth, D, B, T, True,
+                          (self._w("semantic_decoder.norm.weight"), self._w("semantic_decoder.norm.bias"), False))
         return ops.bf16_to_f32(xn).reshape(B, T, D)
 
     def forward(self, x):
@@ -186,9 +212,8 @@ class MingTok:
         # rearrange "b (h w) (x y c) -> b (h x w y) c" (view/permute only)
         x = y.reshape(B, h, w, r, r, Dp).permute(0, 1, 3, 2, 4, 5).reshape(B * h * r * w * r, Dp).contiguous()
         T = N * r * r
-        for i in range(self.pix_depth):
-            self._block(x, f"pixel_decoder.blocks.0.{i}", Dp, B, T, causal=False)
-        xn = ops.layernorm_bf16(x, self._w("pixel_decoder.norm.weight"), self._w("pixel_decoder.norm.bias"))
+        xn = self._blocks(x, "pixel_decoder.blocks.0", self.pix_depth, Dp, B, T, False,
+                          (self._w("pixel_decoder.norm.weight"), self._w("pixel_decoder.norm.bias"), False))
         o = ops.gemm_bf16(xn, self._w("pixel_decoder.head.weight"), self._w("pixel_decoder.head.bias"), "f32")
         p = self.pix_patch
         hh = ww = int(math.sqrt(T))

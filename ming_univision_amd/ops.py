@@ -234,6 +234,40 @@ def gemm256_grouped(a2, a_rows, w, off, cnt, n_pos, m_max, swiglu):
     return out
 
 
+def gemm256_splitk_bf16(a, w, bias, ksplit):
+    """Split-K form on plain bf16 activations a [M, K]: fp32 partial slabs [nz, M, N] (bias in slab 0)."""
+    _req(a, torch.bfloat16, "a"); _req(w, torch.bfloat16, "w"); _req(bias, torch.bfloat16, "bias")
+    M, K = a.shape
+    N = w.shape[0]
+    P = torch.empty(max(1, ksplit), M, N, dtype=torch.float32, device=a.device)
+    nz = lib().mn_gemm256_splitk(ptr(a), a.stride(0), 0, ptr(w), w.stride(0), ptr(bias), ptr(P), M, N, K, ksplit, current_stream())
+    if nz < 0:
+        check(nz, "mn_gemm256_splitk")
+    return P[:nz]
+
+
+def slab_resid_norm(P, x, g=None, b=None, eps=1e-6, gelu=False, norm=True):
+    """x fp32 [M, D] += sum of the slabs P [nz, M, D] (in place); with norm: returns bf16 LayerNorm(x) (then GELU), else None."""
+    _req(P, torch.float32, "P"); _req(x, torch.float32, "x"); _req(g, torch.bfloat16, "g"); _req(b, torch.bfloat16, "b")
+    nz, M, D = P.shape
+    assert x.shape == (M, D) and P.is_contiguous() and x.stride(1) == 1
+    y = torch.empty(M, D, dtype=torch.bfloat16, device=x.device) if norm else None
+    check(lib().mn_slab_resid_norm(ptr(P), nz, M * D, ptr(x), x.stride(0), ptr(g), ptr(b), eps, int(gelu), ptr(y), D, M, D,
+                                   current_stream()), "mn_slab_resid_norm")
+    return y
+
+
+def splitk_plan(M, N, K):
+    """Split-K request for a residual GEMM on M rows that would leave 256 x 256 tiles on under half the chip: 0 = do not split."""
+    tiles = -(-M // 256) * -(-N // 256)
+    if tiles >= 128 or K < 512 or K % 64 or N % 4:
+        return 0
+    ks = max(2, min(8, 256 // tiles))
+    while ks > 2 and K // ks < 256:
+        ks -= 1
+    return ks
+
+
 def layernorm_bf16(x, g, b, eps=1e-6, gelu=False):
     _req(x, torch.float32, "x"); _req(g, torch.bfloat16, "g"); _req(b, torch.bfloat16, "b")
     M, D = x.shape
