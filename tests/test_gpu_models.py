@@ -446,7 +446,10 @@ def test_batched_generation_matches_single_image(B, groups, R):
     assert sorted(e_lat)[B // 2] < 5e-4 and sorted(e_hid)[B // 2] < 5e-4, (e_lat, e_hid)
     for i in range(B):
         assert psnr(out["image"][i], singles[i]["image"][0]) > 45.0, i
-    assert rel_err(out["last_hidden"][:R], g[tag + "_last_hidden"][:, 0]) < TOL      # image 0 is the reference's case
+    e_ref = rel_err(out["last_hidden"][:R], g[tag + "_last_hidden"][:, 0])
+    print("batch %d x %d rows: image 0 vs reference %.2e (bar %.0e); vs batch-1 runs: latents median %.1e max %.1e" % (
+        B, R, e_ref, TOL, sorted(e_lat)[B // 2], max(e_lat)))
+    assert e_ref < TOL      # image 0 is the reference's case
 
 
 def test_prefill_mfma_vs_chunked_fp32_and_reference(llm):
