@@ -43,7 +43,7 @@ struct FlashP {
 };
 
 template <int HD, int SRC>
-__global__ __launch_bounds__(256) void flash_prefill_kernel(const FlashP p) {
+__global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
   constexpr int KROW = HD + 8, VROW = HD + 16, NKK = HD / 32, NDT = HD / 16;
   constexpr int ESZ = SRC == 0 ? 2 : 4, PPR = HD * ESZ / 16, KPP = 256 / PPR, NP = FKT / KPP;
   __shared__ __attribute__((aligned(16))) bf16_t ks[FKT * KROW];
