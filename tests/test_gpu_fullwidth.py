@@ -145,6 +145,30 @@ def test_full_width_facade_batch_on_wide_route(tmp_path):
         assert rel_err(out["images"][b], one["images"][0]) < 5e-2
 
 
+def test_full_width_text_batch_on_wide_route():
+    """generate_text_batch with 70 conversations at the production width (decode on the wide route: grouped-GEMM experts,
+    lm_head through gemm256; prompts of 6..11 tokens through the decode kernels, two of 80 / 97 tokens stacked on the bf16 MFMA
+    prefill path): conversations 0, 35, 68 and 69 get the greedy tokens generate() gives them alone."""
+    from ming_univision_amd.modeling import MingUniVisionForConditionalGeneration
+    d = C.BailingMoeConfig.ming_univision_16b_a3b().to_dict()
+    d.pop("model_type", None)
+    d.update(num_hidden_layers=2, vocab_size=1024, num_image_tokens_for_gen=4, image_start_token=1000, pad_token_id=0, eos_token_id=1)
+    cfg = C.MingUniVisionConfig(mlp_depth=2, llm_config=d, vishead_diffloss_config=dict(C.DEFAULT_VISHEAD_DIFFLOSS))
+    model = MingUniVisionForConditionalGeneration(cfg, state_dict=None, seed=11, t_max=128)
+    g = torch.Generator().manual_seed(4)
+    lens = [6 + (b % 6) for b in range(68)] + [80, 97]
+    reqs = [dict(input_ids=torch.randint(2, 900, (1, n), generator=g)) for n in lens]
+    tm = {}
+    batch = model.generate_text_batch(reqs, max_new_tokens=6, sync_every=4, timings=tm)
+    assert len(batch) == 70 and tm["steps"] <= 5
+    for b in (0, 35, 68, 69):
+        model.reset_inner_state()
+        seq = model.generate(input_ids=reqs[b]["input_ids"], max_new_tokens=6)[0, lens[b]:].tolist()
+        if 1000 in seq:                   # generate() starts an image there; the text batch returns the token
+            seq = seq[:seq.index(1000) + 1]
+        assert seq == batch[b][:len(seq)], (b, seq, batch[b])
+
+
 @pytest.mark.parametrize("n_images,rpi", [(33, 2), (22, 3), (65, 2), (129, 2), (200, 2)])
 def test_wide_rf_sampler_matches_narrow_route(n_images, rpi):
     """RectifiedFlowLoss.sample at production width on the wide route (66 / 66 / 130 / 258 / 400 rows: partial row tiles, 2 and 3 CFG
