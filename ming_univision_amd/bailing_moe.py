@@ -501,15 +501,15 @@ class _GroupRun:
 
 def generate_images(dec: BailingMoeDecoder, rf, tok, start_embed, past_lens, attention_masks, uncond_attention_masks,
                     text_uncond_attention_masks, noises, temperature=1.0, text_cfg=3.0, image_cfg=1.1,
-                    decode_pixels=True, skip_last_sample=True, n_groups=1):
+                    decode_pixels=True, skip_last_sample=True, n_groups=1, seq0=0):
     """BailingMoeForCausalLM.generate_image (modeling_bailing_moe.py:1844-1965) for B >= 1 independent images
     (B = 1 is the reference's call).  The images advance in lock-step, so every weight byte streamed from HBM is
     shared by all rows of a group (<= MAX_ROWS rows); with n_groups > 1 the batch is cut into groups that run on
     separate HIP streams, so one group's short kernels (norms, attention, reductions) run beside another's
     weight streaming.
 
-    dec: decoder whose KV sequence i*R already holds image i's `past_lens[i]` prompt tokens (R = CFG rows per
-    image, equal for all images of the batch).  start_embed fp32 [1,H]: the `<image>` token embedding.
+    dec: decoder whose KV sequence seq0 + i*R already holds image i's `past_lens[i]` prompt tokens (R = CFG rows per
+    image, equal for all images of the batch; seq0: first cache sequence of the batch).  start_embed fp32 [1,H]: the `<image>` token embedding.
     The three mask arguments are lists of [1, T*] tensors (one per image).  noises fp32 [B, n_tokens(+1), latent]:
     the noise RectifiedFlowLoss.sample would draw per iteration (torch.randn, diff_loss_rf_swiglu.py:117-122).
     CFG scales: the reference always runs 3.0 / 1.1 (its kwargs are swallowed).  Differences from
@@ -531,7 +531,7 @@ def generate_images(dec: BailingMoeDecoder, rf, tok, start_embed, past_lens, att
     if rpi > 1:   # replicate each prompt's KV to its CFG rows (:1891-1902) — device memcpy
         for i, past in enumerate(past_lens):
             for r in range(1, rpi):
-                dec.kv_cache[:, i * rpi + r, :, :, :past].copy_(dec.kv_cache[:, i * rpi, :, :, :past])
+                dec.kv_cache[:, seq0 + i * rpi + r, :, :, :past].copy_(dec.kv_cache[:, seq0 + i * rpi, :, :, :past])
     noises = noises.reshape(B, -1, rf.target)
     kw = dict(temperature=temperature, text_cfg=text_cfg, image_cfg=image_cfg)
     main = torch.cuda.current_stream()
@@ -540,7 +540,7 @@ def generate_images(dec: BailingMoeDecoder, rf, tok, start_embed, past_lens, att
     for (lo, hi), s in zip(groups, streams):
         s.wait_stream(main)
         with torch.cuda.stream(s):
-            runs.append(_GroupRun(dec, rf, tok, ams[lo:hi], past_lens[lo:hi], noises[lo:hi], lo * rpi, start_embed, kw,
+            runs.append(_GroupRun(dec, rf, tok, ams[lo:hi], past_lens[lo:hi], noises[lo:hi], seq0 + lo * rpi, start_embed, kw,
                                   skip_last_sample))
     for ti in range(n_tok + 1):
         for run, s in zip(runs, streams):

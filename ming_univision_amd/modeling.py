@@ -29,6 +29,7 @@ def tensor_to_pil(image_tensor):
 
 class MingUniVisionForConditionalGeneration:
     config_class = MingUniVisionConfig
+    BATCH_SEQ0 = 3      # cache sequences 0..2 hold the (up to 3) CFG rows of the multi-round conversation of generate()
 
     def __init__(self, config: MingUniVisionConfig, state_dict=None, device="cuda", seed=0, t_max=4096):
         """state_dict: reference-named tensors (`vision.*`, `model.model.*`, `model.lm_head.*`, `model.vis_head.*`,
@@ -131,8 +132,9 @@ class MingUniVisionForConditionalGeneration:
         n_tok = cfg.num_image_tokens_for_gen
         if max(lens) + n_tok + 2 > self.model.t_max:
             raise ValueError(f"prompt of {max(lens)} tokens + {n_tok} image tokens exceed the KV arena (t_max = {self.model.t_max})")
-        self.model.ensure_sequences(rpi * B)
-        hidden = self.model.prefill_ragged([self.model.embed(i[0].to(dev)) for i in ids], [rpi * b for b in range(B)])
+        s0 = self.BATCH_SEQ0            # the multi-round conversation keeps its cache sequences
+        self.model.ensure_sequences(s0 + rpi * B)
+        hidden = self.model.prefill_ragged([self.model.embed(i[0].to(dev)) for i in ids], [s0 + rpi * b for b in range(B)])
         first = torch.argmax(self.model.logits(hidden), dim=-1).tolist()
         if forced_first_token is not None:
             first = [int(forced_first_token)] * B
@@ -144,7 +146,7 @@ class MingUniVisionForConditionalGeneration:
                                   for _ in range(B)])
         start = self.model.embed(torch.tensor([cfg.image_start_token], device=dev))
         out = generate_images(self.model, self.rf, self.vision, start, lens, ams, uncs, tuncs, noises.to(dev),
-                              temperature=image_gen_temperature, text_cfg=3.0, image_cfg=1.1, n_groups=n_groups)
+                              temperature=image_gen_temperature, text_cfg=3.0, image_cfg=1.1, n_groups=n_groups, seq0=s0)
         files = []
         if save:
             prefixes = output_image_prefixes or [f"output_{b}" for b in range(B)]
@@ -163,14 +165,15 @@ class MingUniVisionForConditionalGeneration:
         looks at the finished flags every `sync_every` tokens.  requests: dicts with `input_ids` [1, T_i] and optionally
         `pixel_values` / `image_grid_thw` (as BailingMMProcessor returns them; attention masks must be all ones).  Every
         sequence gets the tokens `generate` would give it alone (greedy, up to its first EOS).  Image generation is not
-        triggered here (`<image>` is returned as a token).  Does not touch the multi-round state.
+        triggered here (`<image>` is returned as a token).  Does not touch the multi-round state (its cache sequences included).
         Returns a list of B token-id lists (EOS included when reached).  `timings` (a dict, measurement only): synchronises
         after the prefills and at the end and stores `prefill_s` / `decode_s`."""
         import time
         cfg, dev = self.config.llm_config, self.device
         B = len(requests)
         t_start = time.perf_counter()
-        self.model.ensure_sequences(B)
+        s0 = self.BATCH_SEQ0                # the multi-round conversation keeps its cache sequences
+        self.model.ensure_sequences(s0 + B)
         lens, ids_l, embeds, masks = [], [], [], [None] * B
         for b, r in enumerate(requests):
             ids = r["input_ids"].reshape(1, -1).to(dev).clip(0, cfg.vocab_size - 1)
@@ -207,18 +210,19 @@ class MingUniVisionForConditionalGeneration:
                 tot += lens[long_[c1]]
                 c1 += 1
             chunk = long_[c0:c1]
-            hs = self.model.prefill_mfma_many([embeds[b] for b in chunk], chunk, past=0, image_masks=[masks[b] for b in chunk])
+            hs = self.model.prefill_mfma_many([embeds[b] for b in chunk], [s0 + b for b in chunk], past=0,
+                                              image_masks=[masks[b] for b in chunk])
             for j, b in enumerate(chunk):
                 last[b] = hs[j:j + 1]
             c0 = c1
         for b in range(B):
             if last[b] is None:
-                last[b] = self.model.prefill(embeds[b], seq=b, past=0, image_mask=masks[b])[-1:]
+                last[b] = self.model.prefill(embeds[b], seq=s0 + b, past=0, image_mask=masks[b])[-1:]
         hidden = torch.cat(last, 0).contiguous()
         if timings is not None:
             torch.cuda.synchronize(dev)
             t_prefill = time.perf_counter()
-        seq = torch.arange(B, dtype=torch.int32, device=dev)
+        seq = torch.arange(s0, s0 + B, dtype=torch.int32, device=dev)
         slot = torch.tensor(lens, dtype=torch.int32, device=dev)
         ln = slot + 1
         finished = torch.zeros(B, dtype=torch.bool, device=dev)

@@ -332,6 +332,33 @@ def test_facade_batched_text_decode_matches_sequential():
         assert a == b[:len(a)], (a, b)
 
 
+def test_batch_calls_leave_the_multi_round_conversation_alone():
+    """A conversation run through generate() keeps its KV sequences across generate_text_batch / generate_image_batch calls:
+    round 2 gives the same tokens whether or not batch calls happened between the rounds."""
+    from ming_univision_amd.modeling import MingUniVisionForConditionalGeneration
+    g = load_golden("genimg_tiny")
+    llm_cfg = dict(g["llm_config"]); llm_cfg["eos_token_id"] = 1
+    cfg = C.MingUniVisionConfig(mlp_depth=2, llm_config=llm_cfg, vishead_diffloss_config=g["rf_config"],
+                                mingtok_config=g["mingtok_config"])
+    gen = torch.Generator().manual_seed(8)
+    r1, r2 = torch.randint(2, 200, (1, 9), generator=gen), torch.randint(2, 200, (1, 5), generator=gen)
+    reqs = [dict(input_ids=torch.randint(2, 200, (1, n), generator=gen)) for n in (7, 11, 6, 9)]
+
+    def rounds(with_batches):
+        model = MingUniVisionForConditionalGeneration(cfg, state_dict=None, seed=5, t_max=64)
+        a = model.generate(input_ids=r1, max_new_tokens=4)[0].tolist()
+        if with_batches:
+            model.generate_text_batch(reqs, max_new_tokens=5)
+            unc = [torch.ones(1, r["input_ids"].shape[1], dtype=torch.long) for r in reqs]
+            for u in unc:
+                u[0, 2:-2] = 0
+            model.generate_image_batch([dict(r, uncond_attention_mask=u, text_uncond_attention_mask=u.clone()) for r, u in zip(reqs, unc)],
+                                       forced_first_token=llm_cfg["image_start_token"], save=False)
+        b = model.generate(input_ids=r2, max_new_tokens=4)[0].tolist()
+        return a, b, model.past_len
+    assert rounds(False) == rounds(True)
+
+
 def test_checkpoint_directory_roundtrip(tmp_path):
     """MingUniVisionInfer(model_dir): config.json + safetensors shards keyed by the reference's parameter names
     (vision.*, model.model.layers.*, model.vis_head.*, model.diffloss.*, linear_proj.*) load
