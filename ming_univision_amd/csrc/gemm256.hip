@@ -193,8 +193,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   constexpr bool hilo = HILO, paired = epi_paired(EPI);
   const int rows_per_tile = hilo ? 128 : 256, cols_per_tile = paired ? 128 : 256;
   const int tiles_m = (p.M + rows_per_tile - 1) / rows_per_tile, tiles_n = (p.N + cols_per_tile - 1) / cols_per_tile;
-  // XCD-aware tile order (bijective for any tile count): the tiles of one XCD are consecutive, tm fastest, so the M-tiles
-  // that share a W column panel sit in one L2.
+  // XCD-aware tile order (bijective for any tile count): the tiles of one XCD are consecutive; inside that range tiles run in
+  // bands of group_m M-tiles (below), so the ~32 tiles an XCD has in flight share few activation AND few weight panels in its L2.
   int bid = blockIdx.x;
   {
     const int nt = gridDim.x;
@@ -202,6 +202,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   int tm = bid % tiles_m, tn = bid / tiles_m;
+  if (p.group_m > 0 && !p.g_off) {
+    // banded order: bands of group_m M-tiles, N-tiles fastest across a band's columns, so the ~32 tiles an XCD runs at a time
+    // span group_m activation panels x 32 / group_m weight panels instead of all M-tiles x 2-3 weight panels
+    const int width = p.group_m * tiles_n, gid = bid / width, first = gid * p.group_m;
+    const int gsz = min(tiles_m - first, p.group_m), r = bid % width;
+    tm = first + r % gsz;
+    tn = r / gsz;
+  }
   int m0 = tm * rows_per_tile;
   // grouped form (MoE experts): group g owns rows [g_off[g], g_off[g] + g_cnt[g]) of A (through a_rows when given: a
   // gather by index while staging) and of C, and the weights W + g * w_gstride; p.M bounds every group.  The group is
@@ -392,8 +400,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
 
 }  // namespace
 
-static int g_g256_sched = 2;
+static int g_g256_sched = 2, g_g256_groupm = 4;
 extern "C" void mn_gemm256_tune(int sched) { g_g256_sched = sched; }   // A/B hook (0 / 1 / 2 = schedule), not part of the stable ABI
+extern "C" void mn_gemm256_tune_order(int group_m) { g_g256_groupm = group_m; }   // A/B hook: banded tile order
 
 // Generic launcher.  Returns the number of split-K slices used (>= 1) or a negative error.
 static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {
@@ -401,6 +410,7 @@ static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {
   if (paired != epi_paired(epi)) { mn_set_error("gemm256: epilogue %d and w_pair_rows disagree", epi); return MN_EINVAL; }
   const int tiles = (int)((a.tile_g ? a.max_mtiles : mn_cdiv(a.M, hilo ? 128 : 256)) * mn_cdiv(a.N, paired ? 128 : 256));
   G256 p = a;
+  p.group_m = g_g256_groupm;
   p.Kc = p.K;
   if (ksplit > 1) p.Kc = (int)(mn_cdiv(mn_cdiv(p.K, ksplit), 2 * BK) * 2 * BK);   // even number of K-tiles per slice
   const int nz = (int)mn_cdiv(p.K, p.Kc);

@@ -14,6 +14,14 @@ if which == "hd64":
     out = torch.empty(B, T, nh * 64, dtype=torch.bfloat16, device="cuda")
     for _ in range(3):
         check(L.mn_attn_prefill_hd64(ptr(qkv), ptr(out), B, T, nh, 0, current_stream()), "attn")
+elif which == "hd128x7":
+    nq, nkv, t_max, T, S = 16, 4, 1152, 1058, 7
+    q = (torch.randn(S * T, nq, 128, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    kv = torch.randn(S, 2, nkv, t_max, 128, device="cuda", generator=g)
+    tab = torch.tensor([[i, i * T, T] for i in range(S)], dtype=torch.int32).cuda()
+    out = torch.empty(S * T, nq * 128, dtype=torch.bfloat16, device="cuda")
+    for _ in range(3):
+        check(L.mn_flash_prefill_gqa_hd128(ptr(q), ptr(kv), t_max, nq, nkv, 0, ptr(tab), S, T, None, 0, ptr(out), current_stream()), "attn")
 else:
     nq, nkv, t_max, T = 16, 4, 1152, 1058
     q = (torch.randn(T, nq, 128, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
