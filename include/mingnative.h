@@ -251,6 +251,18 @@ int mn_gemm256_grouped(const uint16_t* A, int64_t lda, int64_t a_lo_off, const i
 int mn_slab_resid_norm(const float* P, int nz, int64_t slab, float* h, int64_t ldh, const uint16_t* ln_g, const uint16_t* ln_b,
                        float eps, int gelu, uint16_t* y, int64_t ldy, int M, int D, void* stream);
 
+/* mn_rope_kv_prefill for several prompt spans in one launch: span i = rows [r0_i, r0_i + len_i) of qkv / q_out (rotary position
+ * pos[row]), appended to cache sequence seq_i from slot slot0 of kv_layer [n_seq_total, 2, n_kv, t_max, hd];
+ * seq_tab: device int32 [n_spans][3] = (seq_i, r0_i, len_i). */
+int mn_rope_kv_prefill_spans(const float* qkv, int64_t ldqkv, int n_q, int n_kv, int hd, const float* cos_tab, const float* sin_tab,
+                             const int32_t* pos, int slot0, float q_scale, uint16_t* q_out, float* kv_layer, int64_t t_max,
+                             const int32_t* seq_tab, int n_spans, int max_len, void* stream);
+
+/* mn_moe_combine fused with the RMSNorm of the next consumer: h[t] += sum_s tw[t, s] * yg[slot_of[t, s]] (moe_infer,
+ * modeling_bailing_moe.py:630-639); if y != NULL: y[t] = bf16(RMSNorm(h[t]; eps) * norm_w).  H % 4 == 0, H <= 4096. */
+int mn_moe_combine_norm(const float* yg, const int32_t* slot_of, const float* tw, int n_slot, float* h, int64_t ldh,
+                        const uint16_t* norm_w, float eps, uint16_t* y, int64_t ldy, int T, int H, void* stream);
+
 /* GQA 4:1 flash attention (head dim 128, bottom-right causal; modeling_bailing_moe.py:848-1045) of several prompt spans in one
  * launch, K / V read from the fp32 KV arena of one layer (kv_layer [n_seq_total, 2, n_kv, t_max, 128]): span i = rows
  * [r0_i, r0_i + len_i) of q / out (bf16 [rows, n_q, 128], q RoPE'd and pre-scaled) against keys [0, past + len_i) of cache

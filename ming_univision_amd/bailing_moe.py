@@ -327,17 +327,24 @@ class BailingMoeDecoder:
         else:
             xg = torch.empty(T * n_slot, H, dtype=bf, device=dev)
             gu = torch.empty(T * n_slot, 2 * I, dtype=bf, device=dev)
+        pos_all = torch.cat(pos).contiguous() if seq_tab is not None else None
+        fuse_norm = H % 4 == 0 and H <= 4096          # the expert combine also applies the next layer's RMSNorm
+        xn_ready = False
         for li, ly in enumerate(self.layers):
-            check(L_.mn_rmsnorm_bf16(ptr(h), H, ptr(ly["ln1"]), cfg.rms_norm_eps, ptr(xn), H, T, H, st), "mn_rmsnorm_bf16")
+            if not xn_ready:
+                check(L_.mn_rmsnorm_bf16(ptr(h), H, ptr(ly["ln1"]), cfg.rms_norm_eps, ptr(xn), H, T, H, st), "mn_rmsnorm_bf16")
             ops.gemm_bf16(xn, ly["wqkv"], None, "f32", out=qkv)
-            for i, n in enumerate(lens):
-                kv_seq, r0 = self.kv_cache[li, seqs[i]], r0s[i]
-                check(L_.mn_rope_kv_prefill(ptr(qkv[r0:]), qkv.stride(0), n, nq, nkv, hd, ptr(self.cos), ptr(self.sin), ptr(pos[i]),
-                                            past, 1.0 / math.sqrt(hd), ptr(qb[r0:]), ptr(kv_seq), self.t_max, st), "mn_rope_kv_prefill")
-                if seq_tab is None:
+            if seq_tab is None:
+                for i, n in enumerate(lens):
+                    kv_seq, r0 = self.kv_cache[li, seqs[i]], r0s[i]
+                    check(L_.mn_rope_kv_prefill(ptr(qkv[r0:]), qkv.stride(0), n, nq, nkv, hd, ptr(self.cos), ptr(self.sin), ptr(pos[i]),
+                                                past, 1.0 / math.sqrt(hd), ptr(qb[r0:]), ptr(kv_seq), self.t_max, st), "mn_rope_kv_prefill")
                     check(L_.mn_attn_prefill_gqa_hd128(ptr(qb[r0:]), ptr(kv_seq), self.t_max, nq, nkv, past, n, ptr(kms[i]),
                                                        ptr(att[r0:]), st), "mn_attn_prefill_gqa_hd128")
-            if seq_tab is not None:      # all spans in one launch (flash_prefill.hip)
+            else:                        # all spans in one launch each (prefill_ops.hip, flash_prefill.hip)
+                check(L_.mn_rope_kv_prefill_spans(ptr(qkv), qkv.stride(0), nq, nkv, hd, ptr(self.cos), ptr(self.sin), ptr(pos_all), past,
+                                                  1.0 / math.sqrt(hd), ptr(qb), ptr(self.kv_cache[li]), self.t_max, ptr(seq_tab),
+                                                  len(lens), max(lens), st), "mn_rope_kv_prefill_spans")
                 check(L_.mn_flash_prefill_gqa_hd128(ptr(qb), ptr(self.kv_cache[li]), self.t_max, nq, nkv, past, ptr(seq_tab), len(lens),
                                                     max(lens), ptr(km_all), 0 if km_all is None else km_all.stride(0), ptr(att), st),
                       "mn_flash_prefill_gqa_hd128")
@@ -366,7 +373,13 @@ class BailingMoeDecoder:
                 check(L_.mn_swiglu_bf16(ptr(gu), 2 * I, ptr(hm), I, T * n_slot, I, st), "mn_swiglu_bf16")
                 check(L_.mn_gemm_bf16_grouped(ptr(hm), I, ptr(ly["w_down"]), I, H * I, ptr(off), ptr(cnt), G, ptr(yg), H, T, H, I,
                                               ops.GEMM_EPI["f32"], st), "mn_gemm_bf16_grouped(down)")
-            check(L_.mn_moe_combine(ptr(yg), H, ptr(slot_of), ptr(tw), n_slot, ptr(h), H, T, H, st), "mn_moe_combine")
+            if fuse_norm and li + 1 < len(self.layers):
+                check(L_.mn_moe_combine_norm(ptr(yg), ptr(slot_of), ptr(tw), n_slot, ptr(h), H, ptr(self.layers[li + 1]["ln1"]),
+                                             cfg.rms_norm_eps, ptr(xn), H, T, H, st), "mn_moe_combine_norm")
+                xn_ready = True
+            else:
+                check(L_.mn_moe_combine(ptr(yg), H, ptr(slot_of), ptr(tw), n_slot, ptr(h), H, T, H, st), "mn_moe_combine")
+                xn_ready = False
         last = torch.tensor([r0 + n - 1 for r0, n in zip(r0s, lens)], dtype=torch.long, device=dev)
         return self._final_norm_rows(h[last].contiguous())
 

@@ -770,6 +770,22 @@ extern "C" int mn_slab_resid_norm(const float* P, int nz, int64_t slab, float* h
   return MN_OK;
 }
 
+// Weighted un-permute of the expert outputs + residual (moe_infer, modeling_bailing_moe.py:630-639) fused with the RMSNorm of the
+// next consumer (:1186 of the following layer): h[t] += sum_s tw[t, s] * yg[slot_of[t, s]];  if y: y[t] = bf16(RMSNorm(h[t]) * norm_w).
+extern "C" int mn_moe_combine_norm(const float* yg, const int32_t* slot_of, const float* tw, int n_slot, float* h, int64_t ldh,
+                                   const uint16_t* norm_w, float eps, uint16_t* y, int64_t ldy, int T, int H, void* stream) {
+  MN_CHECK_ARG(yg && slot_of && tw && h && n_slot >= 1 && T >= 1 && wide_glue_ok(H) && (ldh % 4) == 0 && (!y || (norm_w && (ldy % 4) == 0)),
+               "mn_moe_combine_norm: bad args");
+  WideGlue g;
+  memset(&g, 0, sizeof(g));
+  g.h = h; g.ldh = ldh; g.cy = yg; g.cpos = slot_of; g.cw = tw; g.n_slot = n_slot; g.h_out = h; g.ldho = ldh;
+  if (y) { g.norm = 1; g.ng = norm_w; g.eps = eps; g.Y = y; g.ldy = ldy; g.y_lo_off = 0; }
+  g.M = T; g.D = H;
+  wide_glue(g, mn_stream(stream));
+  MN_CHECK_LAUNCH("mn_moe_combine_norm");
+  return MN_OK;
+}
+
 extern "C" int mn_llm_max_rows(const mn_llm* m) { return llm_wide_ok(m, 2048) ? 2048 : 64; }
 extern "C" int mn_rf_max_rows(const mn_rf_head* h) { return rf_wide_ok(h, 2048) ? 2048 : 64; }
 extern "C" int mn_semdec_max_rows(const mn_semdec* s) { return sem_wide_ok(s, 2048) ? 2048 : 64; }

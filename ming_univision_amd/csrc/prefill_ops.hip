@@ -83,6 +83,48 @@ extern "C" int mn_rope_kv_prefill(const float* qkv, int64_t ldqkv, int T, int n_
   return MN_OK;
 }
 
+// The same for several prompt spans in one launch: span s = rows [r0, r0 + len) of qkv / q_out (positions pos[row]) appended to
+// cache sequence seq at slots slot0 .. of kv_layer [n_seq_total, 2, n_kv, t_max, hd]; seq_tab [n_spans][3] = (seq, r0, len).
+__global__ void rope_kv_prefill_spans_kernel(const float* __restrict__ qkv, int64_t ldqkv, int n_q, int n_kv, int hd,
+                                             const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+                                             const int32_t* __restrict__ pos, int slot0, float q_scale, bf16_t* __restrict__ q_out,
+                                             float* __restrict__ kv_layer, int64_t t_max, const int32_t* __restrict__ seq_tab) {
+  const int s = blockIdx.z, seq = seq_tab[s * 3], r0 = seq_tab[s * 3 + 1], len = seq_tab[s * 3 + 2];
+  const int t = blockIdx.x, h = blockIdx.y, i = threadIdx.x, half = hd >> 1;
+  if (t >= len) return;
+  const int64_t row = r0 + t;
+  const float* src = qkv + row * ldqkv + (int64_t)h * hd;
+  float x1 = src[i], x2 = src[i + half];
+  const bool is_q = h < n_q, is_k = !is_q && h < n_q + n_kv;
+  if (is_q || is_k) {
+    const int p = pos[row];
+    const float c = cos_tab[(int64_t)p * half + i], sn = sin_tab[(int64_t)p * half + i];
+    const float o1 = x1 * c - x2 * sn, o2 = x2 * c + x1 * sn;
+    x1 = o1; x2 = o2;
+  }
+  if (is_q) {
+    bf16_t* dst = q_out + (row * n_q + h) * hd;
+    dst[i] = f32_to_bf16(x1 * q_scale);
+    dst[i + half] = f32_to_bf16(x2 * q_scale);
+  } else {
+    const int kvh = is_k ? h - n_q : h - n_q - n_kv;
+    float* dst = kv_layer + (int64_t)seq * 2 * n_kv * t_max * hd + ((((int64_t)(is_k ? 0 : 1)) * n_kv + kvh) * t_max + slot0 + t) * hd;
+    dst[i] = x1;
+    dst[i + half] = x2;
+  }
+}
+
+extern "C" int mn_rope_kv_prefill_spans(const float* qkv, int64_t ldqkv, int n_q, int n_kv, int hd, const float* cos_tab,
+                                        const float* sin_tab, const int32_t* pos, int slot0, float q_scale, uint16_t* q_out,
+                                        float* kv_layer, int64_t t_max, const int32_t* seq_tab, int n_spans, int max_len, void* stream) {
+  MN_CHECK_ARG(qkv && cos_tab && sin_tab && pos && q_out && kv_layer && seq_tab && n_spans >= 1 && max_len >= 1 &&
+                   (hd == 64 || hd == 128) && slot0 >= 0 && slot0 + max_len <= t_max, "mn_rope_kv_prefill_spans: bad args");
+  hipLaunchKernelGGL(rope_kv_prefill_spans_kernel, dim3(max_len, n_q + 2 * n_kv, n_spans), dim3(hd / 2), 0, mn_stream(stream), qkv,
+                     ldqkv, n_q, n_kv, hd, cos_tab, sin_tab, pos, slot0, q_scale, q_out, kv_layer, t_max, seq_tab);
+  MN_CHECK_LAUNCH("mn_rope_kv_prefill_spans");
+  return MN_OK;
+}
+
 // ------------------------------------------------------------------------------------------- GQA flash attention hd=128
 // Block = (64-query tile, q head); wave = 16 queries (a query COLUMN per lane & 15, as in attn_prefill_hd64_kernel).
 // Per 32-key tile the block converts K [32][128] and V^T [128][32] from the fp32 arena to bf16 in LDS once;

@@ -93,6 +93,17 @@ def test_lockstep_group_split_has_no_empty_group():
     assert split_groups(5, 4) == [(0, 2), (2, 4), (4, 5)] and split_groups(9, 4) == [(0, 3), (3, 6), (6, 9)]
 
 
+def test_splitk_plan_for_few_row_residual_gemms():
+    """ops.splitk_plan: split only when 256 x 256 tiles would cover under half the chip, keep >= 256 k per slice."""
+    from ming_univision_amd.ops import splitk_plan
+    assert splitk_plan(16384, 1024, 1024) == 0            # 64 x 4 tiles: a full round already
+    assert splitk_plan(4160, 1024, 256) == 0              # K too short to split
+    for M, N, K in ((4160, 1024, 1024), (4160, 1024, 2752), (4160, 768, 768), (65, 1024, 1024), (65, 768, 3072), (1024, 1024, 4096)):
+        ks = splitk_plan(M, N, K)
+        tiles = -(-M // 256) * -(-N // 256)
+        assert 2 <= ks <= 8 and K // ks >= 256 and tiles * ks <= 512, (M, N, K, ks)
+
+
 def test_config_shapes_and_sizes():
     cfg = C.MingUniVisionConfig.ming_univision_16b_a3b()
     n_llm = sum(int(torch.tensor(s).prod()) for s in C.llm_param_shapes(cfg.llm_config).values())
