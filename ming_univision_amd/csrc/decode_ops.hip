@@ -62,6 +62,87 @@ __global__ __launch_bounds__(256) void moe_topk_kernel(
   }
 }
 
+// Few rows (text decode, one image): the whole router in ONE launch — a 1024-thread workgroup per row does the RMSNorm, the gate
+// GEMV of that row's own gate (image rows read image_gate only; 64 x H bf16 = 256 KB from L2, four experts per wave), and wave 0
+// the softmax / top-k.  Replaces a 16-workgroup GEMV launch (9 us) + moe_topk_kernel (5 us) per layer.
+__global__ __launch_bounds__(1024) void moe_router_row_kernel(
+    const float* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ norm_w, float eps, const bf16_t* __restrict__ gate_w,
+    const bf16_t* __restrict__ image_gate_w, const uint8_t* __restrict__ image_mask, int M, int H, int E, int top_k,
+    int norm_topk_prob, int n_shared, float* __restrict__ x_norm, int32_t* __restrict__ topk_idx, float* __restrict__ topk_w,
+    float* __restrict__ logits_out) {
+  __shared__ __attribute__((aligned(16))) float xs[4096];
+  __shared__ float red[16];
+  __shared__ float lg[64];
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xr = x + (int64_t)m * ldx;
+  float ss = 0.f;
+  for (int k = tid; k < H; k += 1024) { const float v = xr[k]; ss += v * v; }
+  ss = block_sum(ss, red);
+  const float rstd = rsqrtf(ss / (float)H + eps);
+  for (int k = tid; k < H; k += 1024) {
+    const float v = xr[k] * rstd * bf16_to_f32(norm_w[k]);
+    xs[k] = v;
+    x_norm[(int64_t)m * H + k] = v;
+  }
+  __syncthreads();
+  const bool img = image_mask && image_gate_w && image_mask[m];
+  const bf16_t* G = img ? image_gate_w : gate_w;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};          // experts wave, wave + 16, wave + 32, wave + 48: four weight rows in flight per lane
+  for (int k = lane * 8; k < H; k += 512) {
+    const f4 xa = *reinterpret_cast<const f4*>(&xs[k]), xb = *reinterpret_cast<const f4*>(&xs[k + 4]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = wave + 16 * j;
+      if (e < E) {
+        const u4 wv = *reinterpret_cast<const u4*>(G + (int64_t)e * H + k);
+        float a = acc[j];
+        a = fmaf(bf16lo_to_f32(wv.x), xa.x, a); a = fmaf(bf16hi_to_f32(wv.x), xa.y, a);
+        a = fmaf(bf16lo_to_f32(wv.y), xa.z, a); a = fmaf(bf16hi_to_f32(wv.y), xa.w, a);
+        a = fmaf(bf16lo_to_f32(wv.z), xb.x, a); a = fmaf(bf16hi_to_f32(wv.z), xb.y, a);
+        a = fmaf(bf16lo_to_f32(wv.w), xb.z, a); a = fmaf(bf16hi_to_f32(wv.w), xb.w, a);
+        acc[j] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float t = wave_sum(acc[j]);
+    if (lane == 0 && wave + 16 * j < E) lg[wave + 16 * j] = t;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // softmax over E (fp32) then iterative arg-max; ties -> lowest expert index  (BailingMoeGate.forward :505-520)
+    float s = lane < E ? lg[lane] : -INFINITY;
+    if (lane < E) logits_out[((int64_t)(img ? 1 : 0) * M + m) * E + lane] = s;
+    const float mx = wave_max(s);
+    float p = lane < E ? __expf(s - mx) : 0.f;
+    const float denom = wave_sum(p);
+    p = p / denom;
+    float cur = lane < E ? p : -1.f, wsum = 0.f, myw = 0.f;
+    int myidx = 0;
+    const int n_slot = top_k + n_shared;
+    for (int k = 0; k < top_k; ++k) {
+      const float best = wave_max(cur);
+      const int sel = __ffsll((long long)__ballot(cur == best)) - 1;
+      if (lane == k) { myw = best; myidx = sel; }
+      if (lane == sel) cur = -1.f;
+      wsum += best;
+    }
+    if (lane < top_k) {
+      topk_idx[(int64_t)m * n_slot + lane] = myidx;
+      topk_w[(int64_t)m * n_slot + lane] = (norm_topk_prob && top_k > 1) ? myw / wsum : myw;
+    } else if (lane < n_slot) {
+      topk_idx[(int64_t)m * n_slot + lane] = E + (lane - top_k);
+      topk_w[(int64_t)m * n_slot + lane] = 1.0f;
+    }
+  }
+}
+
+static int g_router_rows = 4;      // rows up to which mn_moe_router runs as one launch (A/B hook: mn_moe_router_tune)
+extern "C" void mn_moe_router_tune(int max_rows) { g_router_rows = max_rows; }
+
 extern "C" int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w, float eps,
                              const uint16_t* gate_w, const uint16_t* image_gate_w, const uint8_t* image_mask,
                              int M, int H, int E, int top_k, int norm_topk_prob, int n_shared_slots,
@@ -72,6 +153,12 @@ extern "C" int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w
                "mn_moe_router: bad E=%d top_k=%d", E, top_k);
   MN_CHECK_ARG(x && norm_w && gate_w && x_norm && topk_idx && topk_w && logits_ws, "mn_moe_router: null pointer");
   const bool both = image_mask && image_gate_w;
+  if (M <= g_router_rows && H <= 4096) {
+    hipLaunchKernelGGL(moe_router_row_kernel, dim3(M), dim3(1024), 0, mn_stream(stream), x, ldx, norm_w, eps, gate_w, image_gate_w,
+                       image_mask, M, H, E, top_k, norm_topk_prob, n_shared_slots, x_norm, topk_idx, topk_w, logits_ws);
+    MN_CHECK_LAUNCH("mn_moe_router");
+    return MN_OK;
+  }
   // >= 5 rows with scratch: one launch on the matrix-core route; otherwise the fp32 path, 8 rows at a time
   const bool mfma = M <= 64 && ws != nullptr && ws_bytes >= mn_skinny_workspace_bytes(M, E, H, 0) && mn_skinny_workspace_bytes(M, E, H, 0) > 0;
   const int mstep = mfma ? M : 8;
