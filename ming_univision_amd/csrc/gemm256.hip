@@ -218,9 +218,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   int Mg = p.M, row0 = 0, grp = 0;
   if (p.g_off) {
     if (p.tile_g) {
-      const int t = bid / tiles_n;
-      tn = bid % tiles_n;
-      if (t >= *p.n_tiles) return;               // uniform per workgroup
+      // list order: bands of group_m consecutive row tiles (mostly the tiles of one expert: same weights), row tile fastest,
+      // so the workgroups an XCD runs together share weight panels as well as gathered rows; the tail band is narrower
+      const int nl = *p.n_tiles, gb = p.group_m > 0 ? p.group_m : 1;
+      const int band = bid / (gb * tiles_n), first = band * gb, r = bid % (gb * tiles_n);
+      const int gsz = min(nl - first, gb);
+      if (first >= nl || r >= gsz * tiles_n) return;   // uniform per workgroup
+      const int t = first + r % gsz;
+      tn = r / gsz;
       grp = p.tile_g[t];
       m0 = p.tile_m0[t];
     } else {
@@ -400,9 +405,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
 
 }  // namespace
 
-static int g_g256_sched = 2, g_g256_groupm = 4;
+static int g_g256_sched = 2, g_g256_groupm = 4, g_g256_groupb = 1;   // tile list: N-tiles of a row tile together (bands of 2-8 row tiles measured 0.7 % slower end to end)
 extern "C" void mn_gemm256_tune(int sched) { g_g256_sched = sched; }   // A/B hook (0 / 1 / 2 = schedule), not part of the stable ABI
-extern "C" void mn_gemm256_tune_order(int group_m) { g_g256_groupm = group_m; }   // A/B hook: banded tile order
+extern "C" void mn_gemm256_tune_order(int group_m, int group_list) {                // A/B hook: banded tile orders (dense / tile list)
+  g_g256_groupm = group_m;
+  g_g256_groupb = group_list;
+}
 
 // Generic launcher.  Returns the number of split-K slices used (>= 1) or a negative error.
 static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {
@@ -410,7 +418,7 @@ static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {
   if (paired != epi_paired(epi)) { mn_set_error("gemm256: epilogue %d and w_pair_rows disagree", epi); return MN_EINVAL; }
   const int tiles = (int)((a.tile_g ? a.max_mtiles : mn_cdiv(a.M, hilo ? 128 : 256)) * mn_cdiv(a.N, paired ? 128 : 256));
   G256 p = a;
-  p.group_m = g_g256_groupm;
+  p.group_m = a.tile_g ? g_g256_groupb : g_g256_groupm;
   p.Kc = p.K;
   if (ksplit > 1) p.Kc = (int)(mn_cdiv(mn_cdiv(p.K, ksplit), 2 * BK) * 2 * BK);   // even number of K-tiles per slice
   const int nz = (int)mn_cdiv(p.K, p.Kc);

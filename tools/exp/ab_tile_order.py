@@ -5,7 +5,7 @@ import torch
 from ming_univision_amd import ops
 from ming_univision_amd._lib import lib
 L = lib()
-L.mn_gemm256_tune_order.argtypes = [ctypes.c_int]; L.mn_gemm256_tune_order.restype = None
+L.mn_gemm256_tune_order.argtypes = [ctypes.c_int, ctypes.c_int]; L.mn_gemm256_tune_order.restype = None
 g = torch.Generator(device="cuda").manual_seed(0)
 def rnd(*s): return (torch.randn(*s, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1536
@@ -25,9 +25,9 @@ for name, f in cases.items():
     res = []
     for rnd_ in range(5):
         for gm in (0, 2, 3, 4, 5, 6):
-            L.mn_gemm256_tune_order(gm)
+            L.mn_gemm256_tune_order(gm, 1)
             res.append((gm, ev(f)))
-    L.mn_gemm256_tune_order(4)
+    L.mn_gemm256_tune_order(4, 1)
     by = {}
     for gm, t in res: by.setdefault(gm, []).append(t)
     print(name, {gm: "%.1f us" % sorted(v)[len(v) // 2] for gm, v in by.items()}, flush=True)

@@ -5,7 +5,7 @@ import torch
 import bench
 from ming_univision_amd._lib import lib
 L = lib()
-L.mn_gemm256_tune_order.argtypes = [ctypes.c_int]; L.mn_gemm256_tune_order.restype = None
+L.mn_gemm256_tune_order.argtypes = [ctypes.c_int, ctypes.c_int]; L.mn_gemm256_tune_order.restype = None
 dev = torch.device("cuda", 0)
 B = 768
 args = argparse.Namespace(tiny=False, tokens=256, layers=None, prompt_len=40, images=B, cfg_rows=2)
@@ -21,8 +21,8 @@ def wall(fn, n=3):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 for rnd in range(2):
     for gm in (0, 3, 4, 6, 8, 12):
-        L.mn_gemm256_tune_order(gm)
+        L.mn_gemm256_tune_order(gm, 1)
         t_rf = wall(lambda: rf.sample(hid, noise, n_images=B, out=lat), 2)
         t_c2 = wall(lambda: tok.forward_enc_dec(imgs), 3)
         print(f"group_m {gm:2d}: RF sample 1536 rows {t_rf:7.2f} ms   C2 {t_c2:6.2f} ms", flush=True)
-L.mn_gemm256_tune_order(4)
+L.mn_gemm256_tune_order(4, 1)
