@@ -1,0 +1,26 @@
+"""End-to-end A/B of the gemm256 schedule (mn_gemm256_tune) on the lock-step token loop: 768 images, 25 tokens per run."""
+import sys, os, argparse, ctypes, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import bench
+from ming_univision_amd._lib import lib
+L = lib()
+L.mn_gemm256_tune.argtypes = [ctypes.c_int]; L.mn_gemm256_tune.restype = None
+dev = torch.device("cuda", 0)
+B, NT = 768, 25
+args = argparse.Namespace(tiny=False, tokens=NT, layers=None, prompt_len=40, images=B, cfg_rows=2)
+cfg, dec, rf, tok = bench.build_models(args, dev, 0)
+g = torch.Generator(device=dev).manual_seed(0)
+prompt = torch.randint(0, 100000, (B, 40), generator=g, device=dev)
+noises = torch.randn(B, NT + 1, 32, generator=g, device=dev)
+def run():
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    bench.one_image(cfg, dec, rf, tok, prompt, noises, 1, 2)
+    torch.cuda.synchronize(); return time.perf_counter() - t0
+run()
+for rnd in range(3):
+    for sched in (2, 1, 0):
+        L.mn_gemm256_tune(sched)
+        t = run()
+        print(f"round {rnd} schedule {sched}: {t:.3f} s = {B * NT / t:.0f} tokens/s", flush=True)
+L.mn_gemm256_tune(2)
