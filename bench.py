@@ -46,10 +46,10 @@ def parse():
     ap.add_argument("--no-batch1", action="store_true", help="skip the extra batch-size-1 measurement")
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only; INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / JSON plumbing only (gloo, no GPU, no kernels; `value` is null): the CPU test of --gpus N")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself (0 = a free one)")
     ap.add_argument("--layers", type=int, default=None, help=argparse.SUPPRESS)
-    ap.add_argument("--kloop-ck128", action="store_true", help=argparse.SUPPRESS)   # A/B hook
-    ap.add_argument("--chain-max-rows", type=int, default=0, help=argparse.SUPPRESS)  # A/B hook
-    ap.add_argument("--kloop-small-div", type=int, default=0, help=argparse.SUPPRESS)  # A/B hook
     ap.add_argument("--cfg-rows", type=int, default=2, help=argparse.SUPPRESS)       # 3 = editing-style CFG (experiments)
     args = ap.parse_args()
     args.groups = max(1, min(args.groups, args.images))
@@ -273,8 +273,50 @@ def cpu_baseline(args, rows=2):
                         "and prompt prefill not included (favours the CPU)" % (rows, t_rf, T, t_layer, t_sem)))
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) under torch.distributed.run as a CHILD
+    process — this process has not touched the GPU (no torch.cuda call yet) and never execs —, relay their output (rank 0
+    prints the JSON line) and return the child's exit code."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:]]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    sys.stderr.write("[bench] starting %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args):
+    """Plumbing check of the multi-rank harness on CPU (gloo): rendezvous, barrier-bracketed timing, MAX over ranks, one JSON
+    line on rank 0.  No kernel runs and no throughput is claimed (`value` null)."""
+    from ming_univision_amd.dist_util import ReplicaGroup
+    grp = ReplicaGroup(backend="gloo")
+    dt, _ = grp.timed(lambda: time.sleep(0.01 * (grp.rank + 1)), args.steps)
+    ranks = grp.dist.get_world_size() if grp.dist is not None else 1
+    if grp.rank == 0:
+        print(json.dumps({"metric": "visual tokens/sec (16B-A3B 512^2 gen)", "value": None, "unit": "visual_tokens/s",
+                          "n_gpus": grp.world, "rccl_ranks": ranks, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "dry_run": True,
+                          "config": {"workload": "dry run: no kernels", "parallelism": "replicas x%d" % grp.world}}), flush=True)
+    grp.close()
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        raise SystemExit(launch_ranks(args))        # before anything initialises the GPU in this process
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, env_world))
+    if args.dry_run:
+        return dry_run(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     from ming_univision_amd.dist_util import ReplicaGroup
@@ -283,28 +325,8 @@ def main():
     device = torch.device("cuda", local)
     grp = ReplicaGroup(backend="nccl", device=device)   # "nccl" is RCCL on ROCm
     world, rank = grp.world, grp.rank
+    rccl_ranks = grp.dist.get_world_size() if grp.dist is not None else 1
 
-    if args.kloop_ck128:
-        import ctypes
-        from ming_univision_amd._lib import lib
-        f = lib().mn_stream_kloop_tune
-        f.argtypes = [ctypes.c_int] * 3
-        f.restype = None
-        f(0, 16, 0)
-    if args.chain_max_rows:
-        import ctypes
-        from ming_univision_amd._lib import lib
-        f = lib().mn_llm_tune_chain
-        f.argtypes = [ctypes.c_int]
-        f.restype = None
-        f(args.chain_max_rows)
-    if args.kloop_small_div:
-        import ctypes
-        from ming_univision_amd._lib import lib
-        f = lib().mn_stream_kloop_tune_small
-        f.argtypes = [ctypes.c_int]
-        f.restype = None
-        f(args.kloop_small_div)
     cfg, dec, rf, tok = build_models(args, device, seed=0)
     g = torch.Generator(device=device).manual_seed(grp.seed(1000))     # independent prompt / noise per replica
     prompt = torch.randint(0, min(cfg.vocab_size, 100000), (args.images, args.prompt_len), generator=g, device=device)
@@ -343,7 +365,7 @@ def main():
         total_tokens = args.tokens * args.steps * world * args.images
         res = {
             "metric": "visual tokens/sec (16B-A3B 512^2 gen)", "value": total_tokens / dt, "unit": "visual_tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "Ming-UniVision-16B-A3B text->image 512^2 (BASELINE configs[3]): %d-token prompt, "
                                    "%d CFG rows, %d visual tokens/image, RF head w=%d d=%d steps=%d, MingTok pixel decode; "

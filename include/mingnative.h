@@ -28,7 +28,17 @@
 extern "C" {
 #endif
 
-#define MN_VERSION 100 /* 0.1.0 */
+#define MN_VERSION 110 /* 0.1.10: hidden visibility + MN_API, tune hooks out of the product library, mn_gemm256_grouped takes
+                          the row count of A, TP/EP entry points, mn_lmhead_argmax */
+
+/* Only the entry points declared here are exported (the library is built with -fvisibility=hidden; tests/test_host_logic.py
+ * holds `nm -D` to exactly this list).  The launchers keep no mutable process state: launch plans are pure functions of the
+ * arguments, so calls are re-entrant per stream.  The A/B hooks of tools/ live in libmingnative_dev.so (mingnative_dev.h). */
+#if defined(__GNUC__)
+#define MN_API __attribute__((visibility("default")))
+#else
+#define MN_API
+#endif
 
 enum {
   MN_OK = 0,
@@ -37,10 +47,10 @@ enum {
   MN_ENOSPACE = -3  /* workspace too small */
 };
 
-int mn_version(void);
-const char* mn_last_error(void);
+MN_API int mn_version(void);
+MN_API const char* mn_last_error(void);
 /* Number of compute units of the current device (host query, cached). */
-int mn_num_cus(void);
+MN_API int mn_num_cus(void);
 
 /* ------------------------------------------------------------------------------------------
  * 1. Skinny GEMM (M <= 8 rows): out = epilogue( prologue(x) @ W^T + bias )
@@ -96,8 +106,8 @@ typedef struct mn_skinny_args {
 } mn_skinny_args;
 
 /* 1 <= M <= 64 (batch / nseg forms: M <= 8). */
-int mn_skinny_gemm(const mn_skinny_args* args, void* stream);
-size_t mn_skinny_workspace_bytes(int M, int N, int K, int epilogue);
+MN_API int mn_skinny_gemm(const mn_skinny_args* args, void* stream);
+MN_API size_t mn_skinny_workspace_bytes(int M, int N, int K, int epilogue);
 
 /* ------------------------------------------------------------------------------------------
  * 2. MoE router: RMSNorm + gate GEMV + fp32 softmax + top-k + renormalise, with the
@@ -111,7 +121,7 @@ size_t mn_skinny_workspace_bytes(int M, int N, int K, int epilogue);
  *         n_slot = top_k + n_shared_slots; the trailing shared slots are filled with
  *         (E + j, 1.0) so that shared experts ride the same grouped GEMV.
  * ------------------------------------------------------------------------------------------ */
-int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w, float eps,
+MN_API int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w, float eps,
                   const uint16_t* gate_w, const uint16_t* image_gate_w, const uint8_t* image_mask,
                   int M, int H, int E, int top_k, int norm_topk_prob, int n_shared_slots,
                   float* x_norm, int32_t* topk_idx, float* topk_w, float* logits_ws /* [2*M*E] scratch */,
@@ -131,7 +141,7 @@ int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w, float eps
  *    position (cumsum(mask)-1, :1905).  cos/sin tables fp32 [n_pos, hd/2].
  *    q_out [M, n_q*hd] fp32 receives rotated (and scaled by q_scale) queries.
  * ------------------------------------------------------------------------------------------ */
-int mn_rope_kv_append(const float* qkv, int64_t ldqkv, int M, int n_q, int n_kv, int hd,
+MN_API int mn_rope_kv_append(const float* qkv, int64_t ldqkv, int M, int n_q, int n_kv, int hd,
                       int rope, const float* cos_tab, const float* sin_tab,
                       const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_pos,
                       float q_scale, float* q_out, float* kv_cache, int64_t t_max, void* stream);
@@ -140,7 +150,7 @@ int mn_rope_kv_append(const float* qkv, int64_t ldqkv, int M, int n_q, int n_kv,
  *    frequency i (of each half of the head) follows the t stream for i < sec_t, the h stream for the next sec_h, the
  *    w stream for the rest (mrope_section [16, 24, 24] at hd = 128).  sec_t == 0 is the Legacy rotary above.  With
  *    equal t/h/w positions the result is bit-identical to Legacy. */
-int mn_rope_kv_append_3d(const float* qkv, int64_t ldqkv, int M, int n_q, int n_kv, int hd,
+MN_API int mn_rope_kv_append_3d(const float* qkv, int64_t ldqkv, int M, int n_q, int n_kv, int hd,
                          int rope, const float* cos_tab, const float* sin_tab,
                          const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_pos, int sec_t, int sec_h,
                          float q_scale, float* q_out, float* kv_cache, int64_t t_max, void* stream);
@@ -149,8 +159,8 @@ int mn_rope_kv_append_3d(const float* qkv, int64_t ldqkv, int M, int n_q, int n_
  *    key_mask[m*ld_mask + j] != 0 (key_mask NULL = all ones; a row with every key masked is undefined).
  *    q is pre-scaled.  out [M, n_q*hd] fp32.  The key range is split over workgroups
  *    (flash-decoding); workspace holds the per-split partials. */
-size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t t_max);
-int mn_attn_decode(const float* q, int M, int n_q, int n_kv, int hd, const float* kv_cache, int64_t t_max,
+MN_API size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t t_max);
+MN_API int mn_attn_decode(const float* q, int M, int n_q, int n_kv, int hd, const float* kv_cache, int64_t t_max,
                    const int32_t* row_seq, const int32_t* row_len, const uint8_t* key_mask, int64_t ld_mask,
                    float* out, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -167,100 +177,102 @@ enum mn_gemm_epilogue {
   MN_GEMM_F32_RESID = 3    /* C fp32 += A W^T + bias   (residual stream accumulate) */
 };
 /* A bf16 [M,K] (lda), W bf16 [N,K] (ldw), bias bf16 [N] or NULL, C [M,N] (ldc). K % 32 == 0. */
-int mn_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias,
+MN_API int mn_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias,
                  void* C, int64_t ldc, int M, int N, int K, int epilogue, void* stream);
 
 /* Split-K form for few-row weight-streaming problems: slice z of the K range writes partials[z][M][N] (fp32);
  * returns the number of slices used (>= 1) or a negative error. */
-int mn_gemm_bf16_splitk(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, float* partials,
+MN_API int mn_gemm_bf16_splitk(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, float* partials,
                         int M, int N, int K, int ksplit, void* stream);
 
 /* ---- many-token (prefill) operators of the Bailing-MoE decoder, bf16 MFMA path -------------------------------
  * Replace, for q_len > 16: BailingMoeRMSNorm (modeling_bailing_moe.py:131-136), apply_rotary_pos_emb +
  * DynamicCache.update (:428-461, :789), the flash-attn varlen prefill (:946-1007), BailingMoeGate (:505-520) and
  * moe_infer's argsort / per-expert loop / un-permute / weighted sum (:608-639). */
-int mn_rmsnorm_bf16(const float* x, int64_t ldx, const uint16_t* g, float eps, uint16_t* y, int64_t ldy, int M, int D,
+MN_API int mn_rmsnorm_bf16(const float* x, int64_t ldx, const uint16_t* g, float eps, uint16_t* y, int64_t ldy, int M, int D,
                     void* stream);
 /* qkv fp32 [T, (n_q + 2 n_kv) hd]; token t gets rotary position pos[t] and cache slot slot0 + t of ONE sequence:
  * kv_seq fp32 [2][n_kv][t_max][hd].  q_out bf16 [T, n_q, hd] (rotated, scaled). */
-int mn_rope_kv_prefill(const float* qkv, int64_t ldqkv, int T, int n_q, int n_kv, int hd, const float* cos_tab,
+MN_API int mn_rope_kv_prefill(const float* qkv, int64_t ldqkv, int T, int n_q, int n_kv, int hd, const float* cos_tab,
                        const float* sin_tab, const int32_t* pos, int slot0, float q_scale, uint16_t* q_out,
                        float* kv_seq, int64_t t_max, void* stream);
 /* Flash attention, head_dim 128, GQA: query i of the T new tokens attends keys j <= past + i with
  * key_mask[j] != 0 (NULL = all).  Keys/values come from the fp32 arena of the sequence.  out bf16 [T, n_q*128]. */
-int mn_attn_prefill_gqa_hd128(const uint16_t* q, const float* kv_seq, int64_t t_max, int n_q, int n_kv, int past, int T,
+MN_API int mn_attn_prefill_gqa_hd128(const uint16_t* q, const float* kv_seq, int64_t t_max, int n_q, int n_kv, int past, int T,
                               const uint8_t* key_mask, uint16_t* out, void* stream);
 /* top-k routing from precomputed gate logits [T, E] (image-gate logits chosen where image_mask is set). */
-int mn_moe_topk_logits(const float* logits_text, const float* logits_image, const uint8_t* image_mask, int T, int E,
+MN_API int mn_moe_topk_logits(const float* logits_text, const float* logits_image, const uint8_t* image_mask, int T, int E,
                        int top_k, int norm_topk_prob, int n_shared_slots, int32_t* topk_idx, float* topk_w, void* stream);
 /* Expert-sort of the (token, pick) pairs: counts[g], offsets[g+1], perm[sorted pos] = token,
  * slot_of[token * n_slot + pick] = sorted pos.  T * n_slot <= 65536, n_groups <= 128.  All device arrays. */
-int mn_moe_sort(const int32_t* topk_idx, int T, int n_slot, int n_groups, int32_t* counts, int32_t* offsets,
+MN_API int mn_moe_sort(const int32_t* topk_idx, int T, int n_slot, int n_groups, int32_t* counts, int32_t* offsets,
                 int32_t* perm, int32_t* slot_of, void* stream);
-int mn_gather_rows_bf16(const uint16_t* x, int64_t ldx, const int32_t* perm, uint16_t* y, int64_t ldy, int n_rows, int D,
+MN_API int mn_gather_rows_bf16(const uint16_t* x, int64_t ldx, const int32_t* perm, uint16_t* y, int64_t ldy, int n_rows, int D,
                         void* stream);
 /* h[t] += sum_j w[t, j] * y[slot_of[t, j]]  (fp32) */
-int mn_moe_combine(const float* y, int64_t ldy, const int32_t* slot_of, const float* w, int n_slot, float* h, int64_t ldh,
+MN_API int mn_moe_combine(const float* y, int64_t ldy, const int32_t* slot_of, const float* w, int n_slot, float* h, int64_t ldh,
                    int T, int D, void* stream);
 /* C fp32 [M,N] = (A_hi + A_lo) W^T + bias: activations split into bf16 hi and lo halves (A_lo starts a_lo_off elements
  * after A_hi, same row stride), both multiplied against the same W tiles in one launch — fp32-class products on the bf16
  * MFMA (used for the RF head's adaLN projections of all Euler steps, diff_loss_rf_swiglu.py:263-266, 283-286). */
-int mn_gemm_bf16_hilo(const uint16_t* A_hi, int64_t lda, int64_t a_lo_off, const uint16_t* W, int64_t ldw,
+MN_API int mn_gemm_bf16_hilo(const uint16_t* A_hi, int64_t lda, int64_t a_lo_off, const uint16_t* W, int64_t ldw,
                       const uint16_t* bias, float* C, int64_t ldc, int M, int N, int K, void* stream);
 /* Grouped GEMM over experts: rows [off[g], off[g] + cnt[g]) of A / C use W + g * w_gstride.  off / cnt are device
  * arrays (from mn_moe_sort); m_max >= every cnt[g].  epilogue: MN_GEMM_BF16 or MN_GEMM_F32, no bias. */
-int mn_gemm_bf16_grouped(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int64_t w_gstride,
+MN_API int mn_gemm_bf16_grouped(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int64_t w_gstride,
                          const int32_t* off, const int32_t* cnt, int n_groups, void* C, int64_t ldc, int m_max, int N,
                          int K, int epilogue, void* stream);
 
-/* ---- wide-row GEMM (gemm256.hip): 256 x 256 x 64 tiles, 8 waves, 4-phase-per-K-tile schedule with counted vmcnt --------
+/* ---- wide-row GEMM (gemm256.hip): 256 x 256 x 64 tiles, 8 waves, two long phases per K-tile with counted vmcnt ----------
  * The nn.Linear call sites above when hundreds of rows are in flight (lock-step generation of 128+ images: RF head
  * w12 / w3 / adaLN, diff_loss_rf_swiglu.py:54-72, 263-272, 283-292; MingTok batches; long-prompt prefill).
- * Needs K % 64 == 0, N % 4 == 0, 16-byte aligned rows and operands below 4 GiB (mn_gemm256_supported).
+ * Needs K % 64 == 0, N % 4 == 0, 16-byte aligned rows and operands below 4 GiB (mn_gemm256_supported); C 16-byte (fp32) /
+ * 8-byte (bf16) aligned with ldc % 4 == 0 and an 8-byte aligned bias (the epilogue stores 4 consecutive columns per lane).
  *   a_lo_off == 0: A bf16 [M,K].   a_lo_off != 0: A is a bf16 hi/lo pair (lo rows a_lo_off elements after the hi rows),
  *   the product is (A_hi + A_lo) W^T with both halves riding the same W tiles (a tile then covers 128 rows).
  * epilogue: enum mn_gemm_epilogue. */
-int mn_gemm256_supported(int64_t lda, int64_t a_lo_off, int64_t ldw, int64_t w_rows, int M, int N, int K);
-int mn_gemm256(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W, int64_t ldw, const uint16_t* bias,
+MN_API int mn_gemm256_supported(int64_t lda, int64_t a_lo_off, int64_t ldw, int64_t w_rows, int M, int N, int K);
+MN_API int mn_gemm256(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W, int64_t ldw, const uint16_t* bias,
                void* C, int64_t ldc, int M, int N, int K, int epilogue, void* stream);
 /* Split-K: slice z of the K range writes fp32 partials[z][M][N] (bias folded into slice 0); returns the slice count. */
-int mn_gemm256_splitk(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W, int64_t ldw,
+MN_API int mn_gemm256_splitk(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W, int64_t ldw,
                       const uint16_t* bias, float* partials, int M, int N, int K, int ksplit, void* stream);
 /* SwiGLU-fused (swiglu_ffn.py:30-34, diff_loss_rf_swiglu.py:54-72): W12 bf16 [2*hidden, K] (gate rows then up rows),
  * b12 bf16 [2*hidden] or NULL.  Y receives silu(A Wg^T + bg) * (A Wu^T + bu) split into bf16 hi rows [M, hidden] (ldy)
  * and lo rows y_lo_off elements further — the operand layout of the next hi/lo GEMM. */
-int mn_gemm256_swiglu_split(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W12, int64_t ldw,
+MN_API int mn_gemm256_swiglu_split(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W12, int64_t ldw,
                             const uint16_t* b12, uint16_t* Y, int64_t ldy, int64_t y_lo_off, int M, int hidden, int K,
                             void* stream);
 
 /* The same with a plain bf16 result Y [M, hidden] (batched bf16 path: MingTok SwiGLU blocks); a_lo_off = 0 for bf16 activations. */
-int mn_gemm256_swiglu(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W12, int64_t ldw, const uint16_t* b12,
+MN_API int mn_gemm256_swiglu(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W12, int64_t ldw, const uint16_t* b12,
                       uint16_t* Y, int64_t ldy, int M, int hidden, int K, void* stream);
 /* Grouped form (MoE experts, modeling_bailing_moe.py:605-639, hundreds of rows in flight): group g multiplies row positions
  * [off[g], off[g] + cnt[g]) — position r reads A row a_rows[r] when a_rows != NULL (the gather of the expert-sorted order,
  * done while staging) — by W + g * w_gstride and writes rows off[g].. of C.  A is a bf16 hi/lo pair (a_lo_off > 0).
  *   swiglu == 0: C fp32 [*, N];   swiglu == 1: W_g holds 2N rows (gate rows, up rows), C = bf16 hi rows [*, N] (ldc) and
- *   lo rows c_lo_off elements further of silu(gate) * up.   off / cnt: device arrays (mn_moe_sort); cnt[g] <= m_max. */
-int mn_gemm256_grouped(const uint16_t* A, int64_t lda, int64_t a_lo_off, const int32_t* a_rows, const uint16_t* W, int64_t ldw,
-                       int64_t w_gstride, const int32_t* off, const int32_t* cnt, int n_groups, void* C, int64_t ldc,
-                       int64_t c_lo_off, int m_max, int N, int K, int swiglu, void* stream);
+ *   lo rows c_lo_off elements further of silu(gate) * up.   off / cnt: device arrays (mn_moe_sort); cnt[g] <= m_max.
+ *   A has a_rows_total rows (every a_rows entry is below it: bounds the 32-bit source offsets). */
+MN_API int mn_gemm256_grouped(const uint16_t* A, int64_t lda, int64_t a_lo_off, int64_t a_rows_total, const int32_t* a_rows,
+                              const uint16_t* W, int64_t ldw, int64_t w_gstride, const int32_t* off, const int32_t* cnt, int n_groups,
+                              void* C, int64_t ldc, int64_t c_lo_off, int m_max, int N, int K, int swiglu, void* stream);
 
 /* Tail of a split-K Linear that joins the fp32 residual stream, fused with the next LayerNorm (MingTok layers/block.py:80-105):
  * h[m] += sum_z P[z * slab + m * D + :] (bias already in slab 0, as mn_gemm256_splitk leaves it); if y != NULL:
  * y[m] = bf16(LayerNorm(h[m]; ln_g, ln_b optional, eps)), followed by exact-erf GELU when gelu != 0.  D % 4 == 0, D <= 4096. */
-int mn_slab_resid_norm(const float* P, int nz, int64_t slab, float* h, int64_t ldh, const uint16_t* ln_g, const uint16_t* ln_b,
+MN_API int mn_slab_resid_norm(const float* P, int nz, int64_t slab, float* h, int64_t ldh, const uint16_t* ln_g, const uint16_t* ln_b,
                        float eps, int gelu, uint16_t* y, int64_t ldy, int M, int D, void* stream);
 
 /* mn_rope_kv_prefill for several prompt spans in one launch: span i = rows [r0_i, r0_i + len_i) of qkv / q_out (rotary position
  * pos[row]), appended to cache sequence seq_i from slot slot0 of kv_layer [n_seq_total, 2, n_kv, t_max, hd];
  * seq_tab: device int32 [n_spans][3] = (seq_i, r0_i, len_i). */
-int mn_rope_kv_prefill_spans(const float* qkv, int64_t ldqkv, int n_q, int n_kv, int hd, const float* cos_tab, const float* sin_tab,
+MN_API int mn_rope_kv_prefill_spans(const float* qkv, int64_t ldqkv, int n_q, int n_kv, int hd, const float* cos_tab, const float* sin_tab,
                              const int32_t* pos, int slot0, float q_scale, uint16_t* q_out, float* kv_layer, int64_t t_max,
                              const int32_t* seq_tab, int n_spans, int max_len, void* stream);
 
 /* mn_moe_combine fused with the RMSNorm of the next consumer: h[t] += sum_s tw[t, s] * yg[slot_of[t, s]] (moe_infer,
  * modeling_bailing_moe.py:630-639); if y != NULL: y[t] = bf16(RMSNorm(h[t]; eps) * norm_w).  H % 4 == 0, H <= 4096. */
-int mn_moe_combine_norm(const float* yg, const int32_t* slot_of, const float* tw, int n_slot, float* h, int64_t ldh,
+MN_API int mn_moe_combine_norm(const float* yg, const int32_t* slot_of, const float* tw, int n_slot, float* h, int64_t ldh,
                         const uint16_t* norm_w, float eps, uint16_t* y, int64_t ldy, int T, int H, void* stream);
 
 /* GQA 4:1 flash attention (head dim 128, bottom-right causal; modeling_bailing_moe.py:848-1045) of several prompt spans in one
@@ -268,21 +280,21 @@ int mn_moe_combine_norm(const float* yg, const int32_t* slot_of, const float* tw
  * [r0_i, r0_i + len_i) of q / out (bf16 [rows, n_q, 128], q RoPE'd and pre-scaled) against keys [0, past + len_i) of cache
  * sequence seq_i.  seq_tab: device int32 [n_spans][3] = (seq_i, r0_i, len_i); max_len >= every len_i; key_mask optional
  * uint8 [n_spans, mask_stride] (1 = attend). */
-int mn_flash_prefill_gqa_hd128(const uint16_t* q, const float* kv_layer, int64_t t_max, int n_q, int n_kv, int past,
+MN_API int mn_flash_prefill_gqa_hd128(const uint16_t* q, const float* kv_layer, int64_t t_max, int n_q, int n_kv, int past,
                                const int32_t* seq_tab, int n_spans, int max_len, const uint8_t* key_mask, int64_t mask_stride,
                                uint16_t* out, void* stream);
 
 /* mn_moe_sort plus the list of LIVE row tiles of the grouped GEMMs: tile t (t < *n_tiles) = rows [tile_m0[t], tile_m0[t] +
  * tile_rows) of group tile_g[t]; tile_g / tile_m0 hold up to T * n_slot / tile_rows + n_groups entries.  All device arrays.
  * (modeling_bailing_moe.py:608-616: the expert-count / argsort bookkeeping of moe_infer, without the host sync.) */
-int mn_moe_sort_tiles(const int32_t* topk_idx, int T, int n_slot, int n_groups, int32_t* counts, int32_t* offsets, int32_t* perm,
+MN_API int mn_moe_sort_tiles(const int32_t* topk_idx, int T, int n_slot, int n_groups, int32_t* counts, int32_t* offsets, int32_t* perm,
                       int32_t* slot_of, int tile_rows, int32_t* tile_g, int32_t* tile_m0, int32_t* n_tiles, void* stream);
 
 /* Grouped gemm256 over that tile list (tile_rows = 128 for a hi/lo A, 256 for a plain bf16 A with a_lo_off = 0): no workgroup
  * runs for an empty tile, whatever the split of the rows over the experts.  A has a_rows_total rows.
  *   epi 0: C fp32 [*, N];  1: C bf16 [*, N];  4: W_g holds 2N rows (gate, up), C = bf16 hi rows + lo rows c_lo_off further of
  *   silu(gate) * up;  6: the same as plain bf16.   max_mtiles >= sum_g ceil(cnt[g] / tile_rows). */
-int mn_gemm256_grouped_tiles(const uint16_t* A, int64_t lda, int64_t a_lo_off, int64_t a_rows_total, const int32_t* a_rows,
+MN_API int mn_gemm256_grouped_tiles(const uint16_t* A, int64_t lda, int64_t a_lo_off, int64_t a_rows_total, const int32_t* a_rows,
                              const uint16_t* W, int64_t ldw, int64_t w_gstride, const int32_t* off, const int32_t* cnt, int n_groups,
                              const int32_t* tile_g, const int32_t* tile_m0, const int32_t* n_tiles, int max_mtiles, void* C,
                              int64_t ldc, int64_t c_lo_off, int N, int K, int epi, void* stream);
@@ -292,46 +304,46 @@ int mn_gemm256_grouped_tiles(const uint16_t* A, int64_t lda, int64_t a_lo_off, i
  * nz = mn_stream_mfma_slices(M, Ntot, K) (the launch plan picks slices of 256..1024 k so that every wave of the
  * chip gets the same number of 16-row weight tiles); returns nz.  M <= 64 (33..64 rows run the K-loop form: 8 x 2
  * tiles per workgroup over a long K-range, x chunks double-buffered in LDS).  HBM-bound: every weight byte is read once. */
-int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream);
-int mn_stream_mfma_slices(int M, int Ntot, int K);
+MN_API int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream);
+MN_API int mn_stream_mfma_slices(int M, int Ntot, int K);
 /* Grouped form (MoE experts; replaces the per-token expert loop of modeling_bailing_moe.py:605-639 for 5..32
  * rows): group g of G multiplies the x rows xrows[off[g] .. off[g+1]) (identity rows when xrows == NULL) by
  * W + g * w_stride and writes rows off[g].. of P [nz][p_rows][Ntot]; Y holds y_rows hi rows then y_rows lo rows;
  * no group may exceed max_rows (<= 64) rows.  off / xrows are device arrays.  Every distinct expert is streamed
  * once for all the rows routed to it.  Returns nz = mn_stream_mfma_grouped_slices(G, max_rows, Ntot, K). */
-int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P, int p_rows,
+MN_API int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P, int p_rows,
                            const int32_t* off, const int32_t* xrows, int G, int max_rows, int Ntot, int K,
                            void* stream);
-int mn_stream_mfma_grouped_slices(int G, int max_rows, int Ntot, int K);
+MN_API int mn_stream_mfma_grouped_slices(int G, int max_rows, int Ntot, int K);
 
 /* y bf16 [M,D] = LayerNorm(x fp32 [M,D]; g,b bf16, eps) ; optional GELU afterwards (encoder out layer,
  * vision_transformer.py:173-178). */
-int mn_layernorm_bf16(const float* x, int64_t ldx, const uint16_t* g, const uint16_t* b, float eps,
+MN_API int mn_layernorm_bf16(const float* x, int64_t ldx, const uint16_t* g, const uint16_t* b, float eps,
                       uint16_t* y, int64_t ldy, int M, int D, int gelu, void* stream);
 
 /* h bf16 [M,H] = silu(x12[:, :H]) * x12[:, H:]   (x12 bf16 [M,2H]) */
-int mn_swiglu_bf16(const uint16_t* x12, int64_t ldx, uint16_t* h, int64_t ldh, int M, int H, void* stream);
+MN_API int mn_swiglu_bf16(const uint16_t* x12, int64_t ldx, uint16_t* h, int64_t ldh, int M, int H, void* stream);
 
 /* Flash attention, head_dim 64, bf16 in/out, fp32 softmax.
  * qkv bf16 [B, T, 3, n_heads, 64] (the reshape of attention.py:83,98); out bf16 [B, T, n_heads*64].
  * causal: 0 = bidirectional (Attention / MemEffAttention), 1 = causal (MemEffCausalAttention). */
-int mn_attn_prefill_hd64(const uint16_t* qkv, uint16_t* out, int B, int T, int n_heads, int causal, void* stream);
+MN_API int mn_attn_prefill_hd64(const uint16_t* qkv, uint16_t* out, int B, int T, int n_heads, int causal, void* stream);
 
 /* Small fp32 elementwise helpers of the ViT glue (all [M, D] row-major contiguous):
  *   mn_add_bcast_f32    out[i] = a[i] + b[i % period]     (+pos-embed, vision_transformer.py:222)
  *   mn_group_mean_add   out[m,c] = y[m,c] + mean_g x[m, c*G + g], G = D/C   (encoder out shortcut, :174)
  *   mn_repeat_add       out[m,n] = y[m,n] + s[m, n / (D/C)] * scale + shift   (decoder in shortcut, :375-379)
  *   mn_clamp_f32        x = clamp(x, lo, hi) in place            (modeling_mingtok.py:194) */
-int mn_add_bcast_f32(const float* a, const float* b, float* out, int64_t n, int64_t period, void* stream);
-int mn_group_mean_add(const float* y, const float* x, float* out, int M, int D, int Cout, void* stream);
-int mn_repeat_add(const float* y, const float* s, float* out, int M, int D, int Cin, float scale, float shift, void* stream);
-int mn_clamp_f32(float* x, int64_t n, float lo, float hi, void* stream);
+MN_API int mn_add_bcast_f32(const float* a, const float* b, float* out, int64_t n, int64_t period, void* stream);
+MN_API int mn_group_mean_add(const float* y, const float* x, float* out, int M, int D, int Cout, void* stream);
+MN_API int mn_repeat_add(const float* y, const float* s, float* out, int M, int D, int Cin, float scale, float shift, void* stream);
+MN_API int mn_clamp_f32(float* x, int64_t n, float lo, float hi, void* stream);
 
 /* fp32 <-> bf16 conversion and hi/lo split helpers (elementwise, n elements). */
-int mn_f32_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
-int mn_bf16_to_f32(const uint16_t* x, float* y, int64_t n, void* stream);
+MN_API int mn_f32_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
+MN_API int mn_bf16_to_f32(const uint16_t* x, float* y, int64_t n, void* stream);
 /* hi = bf16(x), lo = bf16(x - hi): lets an fp32 activation go through the bf16 MFMA twice at fp32-class accuracy */
-int mn_f32_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, void* stream);
+MN_API int mn_f32_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 5. Composite device-side sequences (one C call = many launches, no host sync).
@@ -359,11 +371,11 @@ typedef struct mn_rf_head {
  * R = 1 (no CFG), 2 ([cond, uncond]) or 3 ([cond, uncond, text_uncond]) rows per image; rows <= 64.
  * noise [n_images, target] fp32; latent_out [n_images, target] fp32 (all CFG rows of an image carry the same
  * latent).  n_images = 1 is the reference's batch-size-1 call.  Workspace: mn_rf_workspace_bytes(h, rows). */
-size_t mn_rf_workspace_bytes(const mn_rf_head* h, int rows);
+MN_API size_t mn_rf_workspace_bytes(const mn_rf_head* h, int rows);
 /* Rows one call accepts: 64 (weight-streaming kernels), or 2048 when every width is a multiple of 64 — then calls with more
  * than 64 rows take the wide route (each Linear a 256 x 256-tile MFMA GEMM on bf16 hi/lo operands, gemm256.hip). */
-int mn_rf_max_rows(const mn_rf_head* h);
-int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld_hidden, int rows, int n_images,
+MN_API int mn_rf_max_rows(const mn_rf_head* h);
+MN_API int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld_hidden, int rows, int n_images,
                  const float* noise, float temperature, float text_cfg, float image_cfg, float* latent_out,
                  void* workspace, size_t workspace_bytes, void* stream);
 
@@ -387,21 +399,21 @@ typedef struct mn_llm {
   int32_t mrope_sec_t, mrope_sec_h;  /* 0, 0: Legacy rotary, row_pos [M]; else 3D rotary sections, row_pos [3][M] (t, h, w) */
 } mn_llm;
 
-size_t mn_llm_workspace_bytes(const mn_llm* m, int rows, int64_t t_max);
-int mn_llm_max_rows(const mn_llm* m);      /* 64, or 2048 (wide route: see mn_rf_max_rows; no image-gate override there) */
+MN_API size_t mn_llm_workspace_bytes(const mn_llm* m, int rows, int64_t t_max);
+MN_API int mn_llm_max_rows(const mn_llm* m);      /* 64, or 2048 (wide route: see mn_rf_max_rows; no image-gate override there) */
 /* x fp32 in (embeddings): row m is read from x + (m / x_row_div) * ldx (ldx == 0 broadcasts one row to all M
  * rows; x_row_div = R shares one embedding between the R CFG rows of an image)
  * -> hidden_out [M,H] fp32 (after the final RMSNorm).
  * kv_cache: fp32 [n_layers][n_seq][2][n_kv][t_max][hd]; per-row int32 device arrays as in
  * mn_rope_kv_append / mn_attn_decode (row_len = row_slot + 1 is computed by the caller). */
-int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int M, const uint8_t* image_mask,
+MN_API int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int M, const uint8_t* image_mask,
                 const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len,
                 const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
                 float* hidden_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* a[i] += delta, b[i] += delta, c[i] += delta for i < M (any pointer may be NULL): advances the
  * device-resident row_slot / row_pos / row_len arrays between autoregressive steps without a host round trip. */
-int mn_rows_advance(int32_t* a, int32_t* b, int32_t* c, int M, int delta, void* stream);
+MN_API int mn_rows_advance(int32_t* a, int32_t* b, int32_t* c, int M, int delta, void* stream);
 
 /* MingTok semantic decoder, cached causal decode step for M <= 64 rows of ONE sequence each
  * (MingTok.forward_feature_decoder, modeling_mingtok.py:165-174 -> TransformerDecoder.forward_features,
@@ -425,12 +437,12 @@ typedef struct mn_semdec {
   const uint16_t* const* w12p; const uint16_t* const* b12p; const uint16_t* const* w3p;
 } mn_semdec;
 
-size_t mn_semdec_workspace_bytes(const mn_semdec* s, int rows, int64_t t_max);
-int mn_semdec_max_rows(const mn_semdec* s);   /* 64, or 2048 when the padded SwiGLU weights are given */
+MN_API size_t mn_semdec_workspace_bytes(const mn_semdec* s, int rows, int64_t t_max);
+MN_API int mn_semdec_max_rows(const mn_semdec* s);   /* 64, or 2048 when the padded SwiGLU weights are given */
 /* latent_norm [M, in_dim] fp32 (normalised latent from the RF head) -> sem_out [M, dim] fp32 (x_norm),
  * embed_out [M, proj_dim] fp32 (linear_proj(sem)), either may be NULL.
  * kv_cache fp32 [depth][n_seq][2][n_heads][t_max][64]. */
-int mn_semdec_step(const mn_semdec* s, const float* latent_norm, int M,
+MN_API int mn_semdec_step(const mn_semdec* s, const float* latent_norm, int M,
                    const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_len,
                    float* kv_cache, int n_seq, int64_t t_max, float* sem_out, float* embed_out,
                    void* workspace, size_t workspace_bytes, void* stream);

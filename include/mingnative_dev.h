@@ -1,0 +1,32 @@
+/*
+ * mingnative_dev.h — A/B hooks of tools/ (NOT part of the product ABI).
+ *
+ * Present only in libmingnative_dev.so (`make -C ming_univision_amd/csrc dev`, compiled with -DMN_DEV_HOOKS); the shipped
+ * libmingnative.so does not contain these symbols.  They overwrite process-global launch-plan parameters, are not thread-safe
+ * and must be called before the first launch / before any workspace size is queried (workspace carving depends on them).
+ */
+#ifndef MINGNATIVE_DEV_H
+#define MINGNATIVE_DEV_H
+#include "mingnative.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MN_DEV_API MN_API
+
+MN_DEV_API void mn_skinny_tune(int R, int nt, int bpc);                 /* skinny_gemm.hip launch plan */
+MN_DEV_API void mn_stream_tune_plan(int kch, int nw);                   /* stream_mfma.hip K-slice length / waves */
+MN_DEV_API void mn_stream_kloop_tune(int nz, int depth, int nt);        /* stream_kloop.hip */
+MN_DEV_API void mn_stream_kloop_tune_small(int div);
+MN_DEV_API void mn_moe_router_tune(int max_rows);                       /* one-launch router up to this many rows */
+MN_DEV_API void mn_llm_tune_chain(int max_rows);                        /* fused decoder chain up to this many rows */
+MN_DEV_API void mn_gemm_tune(int glds);                                 /* batch_ops.hip: global_load_lds staging */
+MN_DEV_API void mn_gemm_route256(int on);                               /* mn_gemm_bf16 -> gemm256 for large problems */
+MN_DEV_API void mn_gemm256_tune_order(int group_m, int group_list);     /* gemm256 tile order */
+MN_DEV_API void mn_wide_tune(int llm_min_rows, int rf_min_rows, int sem_min_rows);   /* first row count on the wide route */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

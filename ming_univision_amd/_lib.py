@@ -117,7 +117,7 @@ SYMBOLS = {
     "mn_gemm256_splitk": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i, _i, _i, _i, _p]),
     "mn_gemm256_swiglu_split": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _i64, _i, _i, _i, _p]),
     "mn_gemm256_swiglu": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _i, _i, _i, _p]),
-    "mn_gemm256_grouped": (_i, [_p, _i64, _i64, _p, _p, _i64, _i64, _p, _p, _i, _p, _i64, _i64, _i, _i, _i, _i, _p]),
+    "mn_gemm256_grouped": (_i, [_p, _i64, _i64, _i64, _p, _p, _i64, _i64, _p, _p, _i, _p, _i64, _i64, _i, _i, _i, _i, _p]),
     "mn_stream_mfma_slices": (_i, [_i, _i, _i]),
     "mn_stream_mfma_grouped": (_i, [_p, _i, _p, _i64, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "mn_stream_mfma_grouped_slices": (_i, [_i, _i, _i, _i]),
@@ -164,7 +164,7 @@ def lib():
         fn = getattr(handle, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if handle.mn_version() < 100:
+    if handle.mn_version() < 110:
         raise RuntimeError("libmingnative.so is too old")
     _lib = handle
     return _lib

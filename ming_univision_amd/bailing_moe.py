@@ -229,12 +229,28 @@ class BailingMoeDecoder:
         return out.reshape(B, T, H)
 
     def ensure_sequences(self, n_seq):
-        """Grow the KV arena to hold `n_seq` cache sequences (contents of the existing ones are kept)."""
+        """Grow the KV arena to hold `n_seq` cache sequences (contents of the existing ones are kept).  Every sequence costs
+        L * 2 * n_kv * t_max * hd * 4 bytes (16B-A3B at t_max = 4096: 470 MB) and the old arena stays live during the copy:
+        raises MemoryError naming the bytes instead of letting the allocator fail half-way."""
         if n_seq <= self.n_seq:
             return
+        per_seq = self.kv_cache[:, 0].numel() * 4
+        need = n_seq * per_seq
+        free, _ = torch.cuda.mem_get_info(self.device)
+        if need > free:
+            raise MemoryError(f"KV arena for {n_seq} sequences at t_max = {self.t_max} needs {need / 2**30:.1f} GiB "
+                              f"({per_seq / 2**20:.0f} MiB per sequence), {free / 2**30:.1f} GiB free: "
+                              "use a smaller batch or build the model with a smaller t_max")
         kv = torch.zeros((self.kv_cache.shape[0], n_seq) + tuple(self.kv_cache.shape[2:]), dtype=torch.float32, device=self.device)
         kv[:, :self.n_seq] = self.kv_cache
         self.kv_cache, self.n_seq = kv, n_seq
+
+    def release_sequences(self, n_keep):
+        """Shrink the KV arena back to its first `n_keep` sequences (after a batch call: the batch sequences are dead)."""
+        if n_keep >= self.n_seq:
+            return
+        self.kv_cache = self.kv_cache[:, :n_keep].clone()
+        self.n_seq = n_keep
 
     def prefill_ragged(self, embeds_list, seqs, past=0):
         """Causal prefill of several sequences of DIFFERENT lengths in shared passes through the stack: embeds_list[i] fp32

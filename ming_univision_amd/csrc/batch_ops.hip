@@ -194,8 +194,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 }  // namespace
 
 static int g_gemm_glds = 1, g_gemm_route256 = 1;
-extern "C" void mn_gemm_tune(int glds) { g_gemm_glds = glds; }   // A/B hook, not part of the stable ABI
-extern "C" void mn_gemm_route256(int on) { g_gemm_route256 = on; }   // A/B hook: large problems go to gemm256.hip
+#ifdef MN_DEV_HOOKS   // A/B hooks of tools/ (libmingnative_dev.so only, include/mingnative_dev.h)
+extern "C" MN_DEV_API void mn_gemm_tune(int glds) { g_gemm_glds = glds; }
+extern "C" MN_DEV_API void mn_gemm_route256(int on) { g_gemm_route256 = on; }   // large problems go to gemm256.hip
+#endif
 
 static int gemm_launch(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias, void* C,
                        int64_t ldc, int M, int N, int K, int epilogue, int ksplit, int64_t c_zstride, hipStream_t st) {
@@ -243,8 +245,12 @@ extern "C" int mn_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
                "mn_gemm_bf16: A/W rows must be 16-byte aligned");
   // enough 256 x 256 tiles to fill half the chip: the 8-wave 4-phase kernel (gemm256.hip: 1.2 PFLOP/s at 4096^3 against
   // 0.76 here); smaller problems keep the 128 x 128 tiles (more workgroups, 2-3 per CU)
+  // (gemm256's epilogue stores 4 consecutive columns per lane and loads the bias 8 bytes at a time: C / bias alignment and ldc % 4
+  //  are part of the routing condition, anything else stays on the 128-tile kernel with its scalar epilogue)
+  const bool f32_out = epilogue == MN_GEMM_F32 || epilogue == MN_GEMM_F32_RESID;
   if (g_gemm_route256 && (K % 64) == 0 && (N % 4) == 0 && mn_cdiv(M, 256) * mn_cdiv(N, 256) >= 128 &&
-      (int64_t)N * ldw * 2 < ((int64_t)1 << 32) && epilogue >= MN_GEMM_BF16 && epilogue <= MN_GEMM_F32_RESID) {
+      (int64_t)N * ldw * 2 < ((int64_t)1 << 32) && epilogue >= MN_GEMM_BF16 && epilogue <= MN_GEMM_F32_RESID &&
+      (ldc % 4) == 0 && ((uintptr_t)C & (f32_out ? 15 : 7)) == 0 && ((uintptr_t)bias & 7) == 0) {
     static const int map[4] = {MN_G256_BF16, MN_G256_BF16_GELU, MN_G256_F32, MN_G256_F32_RESID};
     // gemm256 addresses its operands with 32-bit byte offsets: an activation matrix beyond 4 GiB goes in row chunks
     int64_t chunk = ((((int64_t)1 << 32) - 1) / (lda * 2)) / 256 * 256;
@@ -510,148 +516,5 @@ extern "C" int mn_f32_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int
   if (n == 0) return MN_OK;
   hipLaunchKernelGGL(f32_split_bf16_kernel, dim3(ew_blocks(n)), dim3(256), 0, mn_stream(stream), x, hi, lo, n);
   MN_CHECK_LAUNCH("mn_f32_split_bf16");
-  return MN_OK;
-}
-
-// ===========================================================================================
-// Flash attention, head_dim 64.  Block = (b, head, 64-query tile); wave = 16 queries.
-//
-// Per 32-key tile, with q = lane & 15 (a query COLUMN) and g = lane >> 4:
-//   S^T[key, q] = sum_d K[key, d] Q[q, d]      A = K fragment (16 keys x 32 d, 16 B per lane straight
-//                                              from global), B = Q fragment (registers, loaded once)
-//     -> accumulator reg r of sub-tile t holds key t*16 + g*4 + r for query q.
-//   online softmax per query: max/sum over 8 registers + xor-16 / xor-32 shuffles.
-//   O^T[d, q] += sum_key V[key, d] P[q, key]   B = P^T built in registers: MFMA k-slot (g, i) is
-//     DEFINED as key (i < 4 ? g*4 + i : 16 + g*4 + i - 4), which is exactly what the lane already holds;
-//     A = V^T fragment read from an LDS image Vt[d][key] with the same slot map.
-// ===========================================================================================
-namespace {
-constexpr int KT = 32;
-
-__global__ __launch_bounds__(256) void attn_prefill_hd64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                int B, int T, int nh, int causal) {
-  __shared__ __attribute__((aligned(16))) bf16_t vt[64][KT + 8];  // V^T tile, +8 pad (row = 80 B)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int64_t row_stride = (int64_t)3 * nh * 64;
-  const bf16_t* base = qkv + (int64_t)b * T * row_stride;
-  const bf16_t* Qp = base + (int64_t)h * 64;
-  const bf16_t* Kp = base + (int64_t)(nh + h) * 64;
-  const bf16_t* Vp = base + (int64_t)(2 * nh + h) * 64;
-  const int ql = lane & 15, g = lane >> 4;
-  const int q_idx = qt * 64 + wave * 16 + ql;
-  const int q_ld = min(q_idx, T - 1);
-  // Q fragments (B operand): Q[q][d = kk*32 + g*8 .. +8], pre-scaled by 64^-0.5 = 0.125 (exact in bf16)
-  bf16x8 qf[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    const u32x4 raw = *reinterpret_cast<const u32x4*>(Qp + (int64_t)q_ld * row_stride + kk * 32 + g * 8);
-    u32x4 sc;
-    sc.x = pack_bf16x2(bf16lo_to_f32(raw.x) * 0.125f, bf16hi_to_f32(raw.x) * 0.125f);
-    sc.y = pack_bf16x2(bf16lo_to_f32(raw.y) * 0.125f, bf16hi_to_f32(raw.y) * 0.125f);
-    sc.z = pack_bf16x2(bf16lo_to_f32(raw.z) * 0.125f, bf16hi_to_f32(raw.z) * 0.125f);
-    sc.w = pack_bf16x2(bf16lo_to_f32(raw.w) * 0.125f, bf16hi_to_f32(raw.w) * 0.125f);
-    qf[kk] = __builtin_bit_cast(bf16x8, sc);
-  }
-  f32x4 o[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
-
-  const int q_hi = min(T, qt * 64 + 64) - 1;          // last query row of this block
-  const int k_end = causal ? (q_hi + 1) : T;          // keys needed by the block
-  const int ntile = (k_end + KT - 1) / KT;
-  for (int kt = 0; kt < ntile; ++kt) {
-    const int k0 = kt * KT;
-    __syncthreads();  // previous tile's V^T fully consumed
-    {  // stage V^T: thread -> key = tid/8 (0..31), d-chunk = tid%8 (8 d each)
-      const int key = tid >> 3, dc = tid & 7;
-      const int kr = min(k0 + key, T - 1);
-      const u32x4 raw = *reinterpret_cast<const u32x4*>(Vp + (int64_t)kr * row_stride + dc * 8);
-      const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        vt[dc * 8 + 2 * i][key] = (bf16_t)(wv[i] & 0xffffu);
-        vt[dc * 8 + 2 * i + 1][key] = (bf16_t)(wv[i] >> 16);
-      }
-    }
-    // S^T: two 16-key sub-tiles
-    f32x4 s[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int kr = min(k0 + t * 16 + ql, T - 1);  // A row = key (lane & 15)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kp + (int64_t)kr * row_stride + kk * 32 + g * 8);
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
-      }
-    }
-    // mask + online softmax (per query column q = lane & 15)
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = k0 + t * 16 + g * 4 + r;
-        const bool ok = key < T && (!causal || key <= q_idx);
-        s[t][r] = ok ? s[t][r] : -INFINITY;
-        mx = fmaxf(mx, s[t][r]);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
-    float psum = 0.f;
-    float p[8];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = (m_new == -INFINITY) ? 0.f : __expf(s[t][r] - m_new);
-        p[t * 4 + r] = e;
-        psum += e;
-      }
-    psum += __shfl_xor(psum, 16, 64);
-    psum += __shfl_xor(psum, 32, 64);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] *= alpha;
-    u32x4 pk = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
-    const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
-    __syncthreads();  // V^T tile visible
-    // O^T += V^T P^T : A row = d (lane & 15) + 16*dt, k-slots (g, i) as defined above
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const bf16_t* vr = &vt[dt * 16 + ql][0];
-      const u32x2 lo = *reinterpret_cast<const u32x2*>(vr + g * 4);
-      const u32x2 hi = *reinterpret_cast<const u32x2*>(vr + 16 + g * 4);
-      u32x4 vv = {lo.x, lo.y, hi.x, hi.y};
-      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
-    }
-  }
-  if (q_idx < T) {
-    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;   // no attended key: 0, not NaN
-    bf16_t* op = out + ((int64_t)b * T + q_idx) * (nh * 64) + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      u32x2 pk = {pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
-      *reinterpret_cast<u32x2*>(op + dt * 16 + g * 4) = pk;
-    }
-  }
-}
-}  // namespace
-
-extern "C" int mn_flash_enabled();
-extern "C" int mn_flash_prefill_hd64(const uint16_t* qkv, uint16_t* out, int B, int T, int n_heads, int causal, void* stream);
-
-extern "C" int mn_attn_prefill_hd64(const uint16_t* qkv, uint16_t* out, int B, int T, int n_heads, int causal,
-                                    void* stream) {
-  MN_CHECK_ARG(qkv && out && B >= 1 && T >= 1 && n_heads >= 1, "mn_attn_prefill_hd64: bad args");
-  if (mn_flash_enabled()) return mn_flash_prefill_hd64(qkv, out, B, T, n_heads, causal, stream);   // flash_prefill.hip (64-key tiles)
-  hipLaunchKernelGGL(attn_prefill_hd64_kernel, dim3(mn_cdiv(T, 64), n_heads, B), dim3(256), 0, mn_stream(stream), qkv,
-                     out, B, T, n_heads, causal);
-  MN_CHECK_LAUNCH("mn_attn_prefill_hd64");
   return MN_OK;
 }

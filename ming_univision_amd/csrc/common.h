@@ -5,6 +5,9 @@
 #include <stdio.h>
 
 #include "mingnative.h"
+#ifdef MN_DEV_HOOKS
+#include "mingnative_dev.h"
+#endif
 
 typedef uint16_t bf16_t;
 

@@ -141,7 +141,9 @@ __global__ __launch_bounds__(1024) void moe_router_row_kernel(
 }
 
 static int g_router_rows = 4;      // rows up to which mn_moe_router runs as one launch (A/B hook: mn_moe_router_tune)
-extern "C" void mn_moe_router_tune(int max_rows) { g_router_rows = max_rows; }
+#ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_moe_router_tune(int max_rows) { g_router_rows = max_rows; }
+#endif
 
 extern "C" int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w, float eps,
                              const uint16_t* gate_w, const uint16_t* image_gate_w, const uint8_t* image_mask,

@@ -27,18 +27,6 @@ extern "C" int mn_attn_decode_split(const float* q, int M, int n_q, int n_kv, in
 extern "C" int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P,
                                       int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows,
                                       int Ntot, int K, void* stream);
-extern "C" int mn_rf_blocks_persistent(int rows, int w, int hidden, int depth, int A, const uint16_t* const* w12,
-                                       const uint16_t* const* b12, const uint16_t* const* w3,
-                                       const uint16_t* const* b3, const uint16_t* const* ln_g,
-                                       const uint16_t* const* ln_b, const float* ada, float* h, float* hid,
-                                       unsigned* bar, void* stream);
-// 1: all residual blocks of an Euler step run as ONE persistent launch (rf_persistent.hip); 0 (default): two
-// launches per block.  Measured on MI355X (round 1): the persistent form is correct but SLOWER (52.6 vs 71.6
-// tok/s) because a 256-workgroup counter barrier costs more than a launch boundary and the 4-deep register
-// ring only covers ~2.5 us of it; kept for the next round (LDS-DMA ring, XCD-hierarchical barrier).
-static int g_rf_persistent = 0;
-extern "C" void mn_rf_set_persistent(int on) { g_rf_persistent = on; }
-
 namespace {
 
 struct Carver {  // carve 256-byte aligned pieces out of a caller-provided workspace
@@ -448,12 +436,7 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
       hipLaunchKernelGGL(rf_euler_kernel, dim3(n_images), dim3(256), 0, st, v, x, rpi, T, text_cfg, image_cfg, step);
       continue;
     }
-    const bool persistent = g_rf_persistent && h->depth <= 16 && rows <= 4 && (size_t)rows * h->hidden * 4 <= 150 * 1024;
-    if (persistent) {
-      MN_TRY(mn_rf_blocks_persistent(rows, w, h->hidden, h->depth, A, h->w12, h->b12, h->w3, h->b3, h->ln_g, h->ln_b, ada,
-                                     hh, hid, bar, stream));
-    }
-    for (int b = 0; b < (persistent ? 0 : h->depth); ++b) {
+    for (int b = 0; b < h->depth; ++b) {
       const float* mod = ada + (int64_t)b * 3 * w;
       a = sk(hh, w, h->w12[b], w, h->b12[b], hid, h->hidden, rows, h->hidden, w);
       a.prologue = MN_PRO_LN_MOD; a.ln_g = h->ln_g[b]; a.ln_b = h->ln_b[b]; a.eps = 1e-6f;
@@ -701,7 +684,9 @@ static bool moe_mfma_ok(const mn_llm* m, int rows) {
 // 2 rows 78.5 vs 76.5, 8 rows 254 vs 247, 16 rows 451 vs 442, 32 rows 699 vs 698; at 64 rows the one-workgroup-per-row
 // glue kernels lose to the wider unfused ones (1084 vs 1122), so the chain stops at 32.
 static int g_chain_max_rows = 32;
-extern "C" void mn_llm_tune_chain(int max_rows) { g_chain_max_rows = max_rows; }   // A/B hook
+#ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_llm_tune_chain(int max_rows) { g_chain_max_rows = max_rows; }   // A/B hook (tools/)
+#endif
 static bool llm_chain_ok(const mn_llm* m, int rows) {
   return rows >= 2 && rows <= g_chain_max_rows && (m->hidden % 8) == 0 && m->hidden <= 4096 && ((m->n_q * m->head_dim) % 8) == 0 &&
          m->n_experts <= 64 && rows * (m->top_k + m->n_shared_slots) <= 1024 && m->n_experts + m->n_shared_slots <= 256;

@@ -251,8 +251,8 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
 }  // namespace
 
 // flash_attn_func on packed qkv bf16 [B, T, 3, nh, 64] -> out bf16 [B, T, nh * 64]  (mingtok attention.py:78-108, 177-239)
-extern "C" int mn_flash_prefill_hd64(const uint16_t* qkv, uint16_t* out, int B, int T, int n_heads, int causal, void* stream) {
-  MN_CHECK_ARG(qkv && out && B >= 1 && T >= 1 && n_heads >= 1, "mn_flash_prefill_hd64: bad args");
+extern "C" int mn_attn_prefill_hd64(const uint16_t* qkv, uint16_t* out, int B, int T, int n_heads, int causal, void* stream) {
+  MN_CHECK_ARG(qkv && out && B >= 1 && T >= 1 && n_heads >= 1, "mn_attn_prefill_hd64: bad args");
   FlashP p{};
   const int64_t rs = (int64_t)3 * n_heads * 64;
   p.q = qkv; p.k = qkv + (int64_t)n_heads * 64; p.v = qkv + (int64_t)2 * n_heads * 64; p.out = out;
@@ -260,14 +260,9 @@ extern "C" int mn_flash_prefill_hd64(const uint16_t* qkv, uint16_t* out, int B, 
   p.q_bs = (int64_t)T * rs; p.kv_bs = (int64_t)T * rs; p.o_bs = (int64_t)T * n_heads * 64;
   p.T = T; p.past = 0; p.causal = causal;
   hipLaunchKernelGGL((flash_prefill_kernel<64, 0>), dim3(mn_cdiv(T, 128), n_heads, B), dim3(256), 0, mn_stream(stream), p);
-  MN_CHECK_LAUNCH("mn_flash_prefill_hd64");
+  MN_CHECK_LAUNCH("mn_attn_prefill_hd64");
   return MN_OK;
 }
-
-// A/B hook (tools): 0 = the round-1 32-key-tile kernels behind mn_attn_prefill_hd64 / mn_attn_prefill_gqa_hd128, 1 = this file
-static int g_flash_on = 1;
-extern "C" void mn_attn_tune(int flash) { g_flash_on = flash; }
-extern "C" int mn_flash_enabled() { return g_flash_on; }
 
 // one span against one cache sequence (kv_seq [2, n_kv, t_max, 128]): the form mn_attn_prefill_gqa_hd128 forwards to
 extern "C" int mn_flash_prefill_gqa_hd128_one(const uint16_t* q, const float* kv_seq, int64_t t_max, int n_q, int n_kv, int past, int T,

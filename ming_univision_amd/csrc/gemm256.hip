@@ -16,17 +16,16 @@
 //     both wave rows, W half h the columns of N-fragments 2h..2h+1 of all four wave columns.  A K-tile is then four
 //     quadrant phases  (A0,W0) (A0,W1) (A1,W1) (A1,W0)  of 16 MFMAs each, and a half-tile is dead — free to be
 //     re-filled — two phases after the phase that read it.
-//   * SCHED 2 (default): 2 long phases per K-tile, every phase = { ds_read the fragments of the next two quadrants — retired by
+//   * Schedule: 2 long phases per K-tile, every phase = { ds_read the fragments of the next two quadrants — retired by
 //     lgkmcnt(0) BEFORE the barrier, so their half-tiles may be re-filled one phase later —, issue one (phase 1) or three
 //     (phase 2) half-tiles of a later K-tile, s_waitcnt vmcnt(8) — never 0 in the steady state, four half-tiles stay in
 //     flight across the barriers —, s_barrier, 32 x v_mfma_f32_16x16x32_bf16 at raised priority, s_barrier }.  The two wave
 //     rows run one barrier apart, so on every SIMD one wave is in its MFMA cluster while its partner reads LDS and issues
 //     loads.  Hazard distances are by construction (see the schedule comments in the kernel): a half-tile is read >= 3 long
 //     phases after it was issued and one phase after the counted wait that retires it.
-//   * SCHED 1: 4 phases of 16 MFMAs per K-tile (8 barriers per K-tile instead of 4; re-fill >= 2 phases after the last read):
-//     4-8 % slower on every shape measured (4096^3: 1148-1243 vs 1325 TFLOP/s; adaLN 4.65 vs 4.47 ms).  Kept as an A/B arm.
-//   * SCHED 0: same tile, one barrier per K-tile (all four half-tiles of the next K-tile issued up front, vmcnt(0)
-//     before the barrier) — the simple reference schedule the A/B tool compares against.
+//     (Round-2 A/B arms, removed from the shipped build: four phases of 16 MFMAs with 8 barriers per K-tile — 4-8 % slower on
+//     every shape measured, 4096^3 1148-1243 vs 1325 TFLOP/s —, and one barrier per K-tile with vmcnt(0) — 9-13 % slower on the
+//     hi/lo shapes of this path.)
 //   * Rejected after measurement (tools/ab_gemm256.py, MI355X): the 32x32x16 MFMA in the same schedule (1048 vs 1243
 //     TFLOP/s at 4096^3: a quadrant phase then has two independent accumulators for a 64-cycle MFMA); a one-wave-per-SIMD
 //     form (4 waves x 128 x 128, the 64 accumulator fragments addressed literally as a[0:255] by inline-asm MFMAs — 154 VGPRs, no
@@ -183,7 +182,7 @@ __device__ __forceinline__ void g256_epilogue(const G256& p, const f32x4 (&acc)[
   }
 }
 
-template <int EPI, int SCHED, bool HILO>
+template <int EPI, bool HILO>
 __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -289,114 +288,47 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
               __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * j + kk], af[2 * i + kk], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
   };
 
-  if (SCHED == 0) {
-    // ---------------- one barrier per K-tile ----------------
-    stage(0, 0, 0, 0); stage(1, 0, 0, 0); stage(1, 1, 0, 0); stage(0, 1, 0, 0);
-    for (int t = 0; t < nk; ++t) {
-      const int X = t & 1;
-      wait_vm<0>();
-      __builtin_amdgcn_s_barrier();          // tile t landed for everyone; buffer X^1 no longer read by anyone
-      if (t + 1 < nk) { stage(0, 0, t + 1, X ^ 1); stage(1, 0, t + 1, X ^ 1); stage(1, 1, t + 1, X ^ 1); stage(0, 1, t + 1, X ^ 1); }
-      read_a(X, 0); read_w(X, 0, wf0);
-      quad(0, 0, wf0);
-      read_w(X, 1, wf1);
-      quad(0, 1, wf1);
-      read_a(X, 1);
-      quad(1, 1, wf1);
-      quad(1, 0, wf0);
+  // ---------------- 2 long phases per K-tile (32 MFMAs each), counted vmcnt, wave rows one barrier apart ----------------
+  // K-tile T in buffer X (Y = X ^ 1):
+  //   phase 1: read X.A0, X.W0, X.W1 (retired by lgkmcnt(0) BEFORE the barrier: free for re-issue one phase later);
+  //            issue Y.A1 <- T+1;                  MFMAs (A0,W0) (A0,W1)
+  //   phase 2: read X.A1 (same rule);  issue X.A0, X.W0, X.W1 <- T+2;      MFMAs (A1,W1) (A1,W0)
+  //   RAW: X.A1(T) issued (T-1).1, retired by the vmcnt(8) of T.1 (8 = Y.A1 + the three half-tiles of (T-1).2), read T.2;
+  //        Y.{A0,W0,W1}(T+1) issued (T-1).2, retired by the vmcnt(8) of T.2, read (T+1).1 — always one phase after the wait.
+  //   WAR: one phase, safe because every wave's reads completed before the barrier that precedes the re-issue.
+  auto phase2 = [&](auto Xc, auto PHc, int T) {
+    constexpr int X = decltype(Xc)::value, PH = decltype(PHc)::value, Y = X ^ 1;
+    const int tgt = PH == 0 ? T + 1 : T + 2;
+    if (PH == 0) { read_w(X, 0, wf0); read_w(X, 1, wf1); __builtin_amdgcn_sched_barrier(0); read_a(X, 0); }
+    else read_a(X, 1);
+    if (tgt < nk) {   // (issuing the LDS-DMA before the fragment reads instead measured within +-1 %)
+      if (PH == 0) stage(0, 1, tgt, Y);
+      else { stage(0, 0, tgt, X); stage(1, 0, tgt, X); stage(1, 1, tgt, X); }
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
-  } else if (SCHED == 2) {
-    // ---------------- 2 long phases per K-tile (32 MFMAs each), counted vmcnt, wave rows one barrier apart ----------------
-    // K-tile T in buffer X (Y = X ^ 1):
-    //   phase 1: read X.A0, X.W0, X.W1 (retired by lgkmcnt(0) BEFORE the barrier: free for re-issue one phase later);
-    //            issue Y.A1 <- T+1;                  MFMAs (A0,W0) (A0,W1)
-    //   phase 2: read X.A1 (same rule);  issue X.A0, X.W0, X.W1 <- T+2;      MFMAs (A1,W1) (A1,W0)
-    //   RAW: X.A1(T) issued (T-1).1, retired by the vmcnt(8) of T.1 (8 = Y.A1 + the three half-tiles of (T-1).2), read T.2;
-    //        Y.{A0,W0,W1}(T+1) issued (T-1).2, retired by the vmcnt(8) of T.2, read (T+1).1 — always one phase after the wait.
-    //   WAR: one phase, safe because every wave's reads completed before the barrier that precedes the re-issue.
-    auto phase2 = [&](auto Xc, auto PHc, int T) {
-      constexpr int X = decltype(Xc)::value, PH = decltype(PHc)::value, Y = X ^ 1;
-      const int tgt = PH == 0 ? T + 1 : T + 2;
-      if (PH == 0) { read_w(X, 0, wf0); read_w(X, 1, wf1); __builtin_amdgcn_sched_barrier(0); read_a(X, 0); }
-      else read_a(X, 1);
-      if (tgt < nk) {   // (issuing the LDS-DMA before the fragment reads instead measured within +-1 %)
-        if (PH == 0) stage(0, 1, tgt, Y);
-        else { stage(0, 0, tgt, X); stage(1, 0, tgt, X); stage(1, 1, tgt, X); }
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-      if (PH == 0) { quad(0, 0, wf0); quad(0, 1, wf1); }
-      else { quad(1, 1, wf1); quad(1, 0, wf0); }
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);        // the next phase's LDS reads stay behind this barrier
-    };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    stage(0, 0, 0, 0); stage(1, 0, 0, 0); stage(1, 1, 0, 0); stage(0, 1, 0, 0);
-    if (nk > 1) { stage(0, 0, 1, 1); stage(1, 0, 1, 1); stage(1, 1, 1, 1); wait_vm<8>(); }
-    else wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < nk; t += 2) {
-      phase2(I0{}, I0{}, t); phase2(I0{}, I1{}, t);
-      if (t + 1 < nk) { phase2(I1{}, I0{}, t + 1); phase2(I1{}, I1{}, t + 1); }
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();
-  } else {
-    // ---------------- 4 phases per K-tile, counted vmcnt, wave rows one barrier apart ----------------
-    // Issue order of half-tiles (virtual time, one per phase) for the K-tile T held in buffer X (Y = X ^ 1):
-    //   phase 0 of T: Y.W1 <- T+1      phase 1: Y.A1 <- T+1      phase 2: X.A0 <- T+2      phase 3: X.W0 <- T+2
-    // Reads: phase 0: X.A0, X.W0   phase 1: X.W1   phase 2: X.A1   phase 3: none (W0 fragments stay in registers).
-    //   RAW: issue -> first read is >= 5 phases; the vmcnt(8) of phase p (4 half-tiles = 8 loads may stay in flight)
-    //        retires the half-tile issued in phase p-4, which is read in phase p+1 or later, i.e. after a barrier every
-    //        wave reaches only after its own wait (also across the one-barrier stagger).
-    //   WAR: last read -> re-issue is >= 2 phases (A0: read ph 0, issued ph 2; W0: 0 -> 3; W1: 1 -> 4; A1: 2 -> 5).
-    auto phase = [&](auto Xc, auto PHc, int T) {
-      constexpr int X = decltype(Xc)::value, PH = decltype(PHc)::value, Y = X ^ 1;
-      if (PH == 0) { read_w(X, 0, wf0); __builtin_amdgcn_sched_barrier(0); read_a(X, 0); }
-      if (PH == 1) read_w(X, 1, wf1);
-      if (PH == 2) read_a(X, 1);
-      const int tgt = PH < 2 ? T + 1 : T + 2;
-      if (tgt < nk) {
-        if (PH == 0) stage(1, 1, tgt, Y);
-        if (PH == 1) stage(0, 1, tgt, Y);
-        if (PH == 2) stage(0, 0, tgt, X);
-        if (PH == 3) stage(1, 0, tgt, X);
-        wait_vm<8>();
-      } else {
-        wait_vm<0>();
-      }
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-      if (PH == 0) quad(0, 0, wf0);
-      if (PH == 1) quad(0, 1, wf1);
-      if (PH == 2) quad(1, 1, wf1);
-      if (PH == 3) quad(1, 0, wf0);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);        // the next phase's LDS reads stay behind this barrier
-    };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    // prologue = the issues of the virtual phases before tile 0, in their order
-    stage(0, 0, 0, 0); stage(1, 0, 0, 0); stage(1, 1, 0, 0); stage(0, 1, 0, 0);
-    if (nk > 1) { stage(0, 0, 1, 1); stage(1, 0, 1, 1); wait_vm<8>(); }
-    else wait_vm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    if (PH == 0) { quad(0, 0, wf0); quad(0, 1, wf1); }
+    else { quad(1, 1, wf1); quad(1, 0, wf0); }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs one barrier behind wave row 0
-    for (int t = 0; t < nk; t += 2) {
-      phase(I0{}, I0{}, t); phase(I0{}, I1{}, t); phase(I0{}, I2{}, t); phase(I0{}, I3{}, t);
-      if (t + 1 < nk) { phase(I1{}, I0{}, t + 1); phase(I1{}, I1{}, t + 1); phase(I1{}, I2{}, t + 1); phase(I1{}, I3{}, t + 1); }
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);        // the next phase's LDS reads stay behind this barrier
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  stage(0, 0, 0, 0); stage(1, 0, 0, 0); stage(1, 1, 0, 0); stage(0, 1, 0, 0);
+  if (nk > 1) { stage(0, 0, 1, 1); stage(1, 0, 1, 1); stage(1, 1, 1, 1); wait_vm<8>(); }
+  else wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+  for (int t = 0; t < nk; t += 2) {
+    phase2(I0{}, I0{}, t); phase2(I0{}, I1{}, t);
+    if (t + 1 < nk) { phase2(I1{}, I0{}, t + 1); phase2(I1{}, I1{}, t + 1); }
   }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
 
   g256_epilogue<EPI, HILO>(p, acc, wr, wc, fr, fq, m0, n0, row0, Mg, blockIdx.y);
 }
@@ -405,12 +337,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
 
 }  // namespace
 
-static int g_g256_sched = 2, g_g256_groupm = 4, g_g256_groupb = 1;   // tile list: N-tiles of a row tile together (bands of 2-8 row tiles measured 0.7 % slower end to end)
-extern "C" void mn_gemm256_tune(int sched) { g_g256_sched = sched; }   // A/B hook (0 / 1 / 2 = schedule), not part of the stable ABI
-extern "C" void mn_gemm256_tune_order(int group_m, int group_list) {                // A/B hook: banded tile orders (dense / tile list)
+// Tile order: dense problems run in bands of 4 M-tiles inside an XCD's tile range; tile lists keep the N-tiles of a row tile together
+// (bands of 2-8 row tiles measured 0.7 % slower end to end).
+static int g_g256_groupm = 4, g_g256_groupb = 1;
+#ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_gemm256_tune_order(int group_m, int group_list) {   // A/B hook (tools/, libmingnative_dev.so only)
   g_g256_groupm = group_m;
   g_g256_groupb = group_list;
 }
+#endif
 
 // Generic launcher.  Returns the number of split-K slices used (>= 1) or a negative error.
 static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {
@@ -423,17 +358,10 @@ static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {
   if (ksplit > 1) p.Kc = (int)(mn_cdiv(mn_cdiv(p.K, ksplit), 2 * BK) * 2 * BK);   // even number of K-tiles per slice
   const int nz = (int)mn_cdiv(p.K, p.Kc);
   dim3 grid(tiles, nz, (a.g_off && !a.tile_g) ? a.n_groups : 1);
-#define G256_GO(E)                                                                                             \
-  do {                                                                                                         \
-    if (hilo) {                                                                                                \
-      if (g_g256_sched == 2) hipLaunchKernelGGL((gemm256_kernel<E, 2, true>), grid, dim3(512), 0, st, p);     \
-      else if (g_g256_sched) hipLaunchKernelGGL((gemm256_kernel<E, 1, true>), grid, dim3(512), 0, st, p);     \
-      else hipLaunchKernelGGL((gemm256_kernel<E, 0, true>), grid, dim3(512), 0, st, p);                       \
-    } else {                                                                                                   \
-      if (g_g256_sched == 2) hipLaunchKernelGGL((gemm256_kernel<E, 2, false>), grid, dim3(512), 0, st, p);    \
-      else if (g_g256_sched) hipLaunchKernelGGL((gemm256_kernel<E, 1, false>), grid, dim3(512), 0, st, p);    \
-      else hipLaunchKernelGGL((gemm256_kernel<E, 0, false>), grid, dim3(512), 0, st, p);                      \
-    }                                                                                                          \
+#define G256_GO(E)                                                                          \
+  do {                                                                                      \
+    if (hilo) hipLaunchKernelGGL((gemm256_kernel<E, true>), grid, dim3(512), 0, st, p);     \
+    else hipLaunchKernelGGL((gemm256_kernel<E, false>), grid, dim3(512), 0, st, p);         \
   } while (0)
   switch (epi) {
     case E_F32: G256_GO(E_F32); break;
@@ -472,6 +400,11 @@ static bool g256_shape_ok(const void* A, int64_t lda, int64_t a_lo_off, const vo
          w_rows * ldw * 2 < ((int64_t)1 << 32);
 }
 
+// the epilogue's vector accesses: 16-byte fp32 / 8-byte bf16 stores of 4 consecutive columns, 8-byte bias loads
+static bool g256_out_ok(const void* C, int64_t ldc, int64_t c_lo_off, const void* bias, bool f32_out) {
+  return (ldc % 4) == 0 && (c_lo_off % 4) == 0 && ((uintptr_t)C & (f32_out ? 15 : 7)) == 0 && ((uintptr_t)bias & 7) == 0;
+}
+
 extern "C" int mn_gemm256_supported(int64_t lda, int64_t a_lo_off, int64_t ldw, int64_t w_rows, int M, int N, int K) {
   return g256_shape_ok(nullptr, lda, a_lo_off, nullptr, ldw, w_rows, M, N, K) ? 1 : 0;
 }
@@ -491,6 +424,8 @@ extern "C" int mn_gemm256(const uint16_t* A, int64_t lda, int64_t a_lo_off, cons
     case MN_GEMM_F32_RESID: e = E_F32_RESID; break;
     default: mn_set_error("mn_gemm256: bad epilogue %d", epilogue); return MN_EINVAL;
   }
+  MN_CHECK_ARG(g256_out_ok(C, ldc, 0, bias, e == E_F32 || e == E_F32_RESID),
+               "mn_gemm256: C must be 16-byte (fp32) / 8-byte (bf16) aligned with ldc %% 4 == 0, bias 8-byte aligned (ldc=%lld)", (long long)ldc);
   G256 p{};
   p.A = A; p.lda = lda; p.a_lo_off = a_lo_off; p.W = W; p.ldw = ldw; p.bias = bias; p.C = C; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K;
@@ -506,6 +441,7 @@ extern "C" int mn_gemm256_splitk(const uint16_t* A, int64_t lda, int64_t a_lo_of
                                  const uint16_t* bias, float* partials, int M, int N, int K, int ksplit, void* stream) {
   MN_CHECK_ARG(A && W && partials && ksplit >= 1, "mn_gemm256_splitk: bad args");
   MN_CHECK_ARG(g256_shape_ok(A, lda, a_lo_off, W, ldw, N, M, N, K), "mn_gemm256_splitk: unsupported shape M=%d N=%d K=%d", M, N, K);
+  MN_CHECK_ARG(g256_out_ok(partials, N, 0, bias, true), "mn_gemm256_splitk: partials must be 16-byte aligned, bias 8-byte aligned");
   G256 p{};
   p.A = A; p.lda = lda; p.a_lo_off = a_lo_off; p.W = W; p.ldw = ldw; p.bias = bias; p.C = partials; p.ldc = N;
   p.c_zstride = (int64_t)M * N; p.M = M; p.N = N; p.K = K;
@@ -522,8 +458,8 @@ extern "C" int mn_gemm256_swiglu_split(const uint16_t* A, int64_t lda, int64_t a
                                        const uint16_t* b12, uint16_t* Y, int64_t ldy, int64_t y_lo_off, int M, int hidden,
                                        int K, void* stream) {
   MN_CHECK_ARG(A && W12 && Y && y_lo_off > 0, "mn_gemm256_swiglu_split: bad args");
-  MN_CHECK_ARG(g256_shape_ok(A, lda, a_lo_off, W12, ldw, 2 * (int64_t)hidden, M, hidden, K) && (ldy % 4) == 0 && (y_lo_off % 4) == 0,
-               "mn_gemm256_swiglu_split: unsupported shape M=%d hidden=%d K=%d", M, hidden, K);
+  MN_CHECK_ARG(g256_shape_ok(A, lda, a_lo_off, W12, ldw, 2 * (int64_t)hidden, M, hidden, K) && g256_out_ok(Y, ldy, y_lo_off, b12, false),
+               "mn_gemm256_swiglu_split: unsupported shape M=%d hidden=%d K=%d (or Y / b12 not 8-byte aligned, ldy / y_lo_off %% 4)", M, hidden, K);
   G256 p{};
   p.A = A; p.lda = lda; p.a_lo_off = a_lo_off; p.W = W12; p.ldw = ldw; p.w_pair_rows = hidden; p.bias = b12;
   p.C = Y; p.ldc = ldy; p.c_lo_off = y_lo_off; p.M = M; p.N = hidden; p.K = K;
@@ -538,8 +474,8 @@ extern "C" int mn_gemm256_swiglu_split(const uint16_t* A, int64_t lda, int64_t a
 extern "C" int mn_gemm256_swiglu(const uint16_t* A, int64_t lda, int64_t a_lo_off, const uint16_t* W12, int64_t ldw,
                                  const uint16_t* b12, uint16_t* Y, int64_t ldy, int M, int hidden, int K, void* stream) {
   MN_CHECK_ARG(A && W12 && Y, "mn_gemm256_swiglu: bad args");
-  MN_CHECK_ARG(g256_shape_ok(A, lda, a_lo_off, W12, ldw, 2 * (int64_t)hidden, M, hidden, K) && (ldy % 4) == 0,
-               "mn_gemm256_swiglu: unsupported shape M=%d hidden=%d K=%d", M, hidden, K);
+  MN_CHECK_ARG(g256_shape_ok(A, lda, a_lo_off, W12, ldw, 2 * (int64_t)hidden, M, hidden, K) && g256_out_ok(Y, ldy, 0, b12, false),
+               "mn_gemm256_swiglu: unsupported shape M=%d hidden=%d K=%d (or Y / b12 not 8-byte aligned, ldy %% 4)", M, hidden, K);
   G256 p{};
   p.A = A; p.lda = lda; p.a_lo_off = a_lo_off; p.W = W12; p.ldw = ldw; p.w_pair_rows = hidden; p.bias = b12;
   p.C = Y; p.ldc = ldy; p.M = M; p.N = hidden; p.K = K;
@@ -555,14 +491,17 @@ extern "C" int mn_gemm256_swiglu(const uint16_t* A, int64_t lda, int64_t a_lo_of
 //   swiglu == 0: C fp32 [*, N] = (A_hi + A_lo) W_g^T
 //   swiglu == 1: W_g holds 2N rows (gate, up); C bf16 hi rows [*, N] and lo rows c_lo_off elements further = silu(gate) * up
 // off / cnt are device arrays (mn_moe_sort); no group may exceed m_max rows.
-extern "C" int mn_gemm256_grouped(const uint16_t* A, int64_t lda, int64_t a_lo_off, const int32_t* a_rows, const uint16_t* W,
-                                  int64_t ldw, int64_t w_gstride, const int32_t* off, const int32_t* cnt, int n_groups, void* C,
-                                  int64_t ldc, int64_t c_lo_off, int m_max, int N, int K, int swiglu, void* stream) {
-  MN_CHECK_ARG(A && W && C && off && cnt && n_groups >= 1 && m_max >= 1 && a_lo_off > 0, "mn_gemm256_grouped: bad args");
+extern "C" int mn_gemm256_grouped(const uint16_t* A, int64_t lda, int64_t a_lo_off, int64_t a_rows_total, const int32_t* a_rows,
+                                  const uint16_t* W, int64_t ldw, int64_t w_gstride, const int32_t* off, const int32_t* cnt,
+                                  int n_groups, void* C, int64_t ldc, int64_t c_lo_off, int m_max, int N, int K, int swiglu,
+                                  void* stream) {
+  MN_CHECK_ARG(A && W && C && off && cnt && n_groups >= 1 && m_max >= 1 && a_lo_off > 0 && a_rows_total >= 1, "mn_gemm256_grouped: bad args");
+  // every per-lane source offset (gathered row * lda + a_lo_off, in bytes) must fit 32 bits: bounded by the row count of A
   MN_CHECK_ARG(N >= 4 && (N % 4) == 0 && K >= BK && (K % BK) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && (a_lo_off % 8) == 0 &&
                    (w_gstride % 8) == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0 && (!swiglu || c_lo_off > 0) &&
-                   a_lo_off * 4 < ((int64_t)1 << 32) && (int64_t)(swiglu ? 2 : 1) * N * ldw * 2 < ((int64_t)1 << 32),
-               "mn_gemm256_grouped: unsupported shape N=%d K=%d", N, K);
+                   (a_rows_total * lda + a_lo_off) * 2 < ((int64_t)1 << 32) && (int64_t)(swiglu ? 2 : 1) * N * ldw * 2 < ((int64_t)1 << 32) &&
+                   g256_out_ok(C, ldc, c_lo_off, nullptr, !swiglu),
+               "mn_gemm256_grouped: unsupported shape N=%d K=%d (or C misaligned / ldc %% 4)", N, K);
   G256 p{};
   p.A = A; p.lda = lda; p.a_lo_off = a_lo_off; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.c_lo_off = c_lo_off;
   p.w_pair_rows = swiglu ? N : 0; p.M = m_max; p.N = N; p.K = K;
@@ -589,8 +528,9 @@ extern "C" int mn_gemm256_grouped_tiles(const uint16_t* A, int64_t lda, int64_t 
   MN_CHECK_ARG(epi == E_F32 || epi == E_BF16 || epi == E_SWIGLU_SPLIT || epi == E_SWIGLU_BF16, "mn_gemm256_grouped_tiles: epi %d", epi);
   MN_CHECK_ARG(N >= 4 && (N % 4) == 0 && K >= BK && (K % BK) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && (a_lo_off % 8) == 0 &&
                    (w_gstride % 8) == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0 && (epi != E_SWIGLU_SPLIT || c_lo_off > 0) &&
-                   (a_rows_total * lda + a_lo_off) * 2 < ((int64_t)1 << 32) && (int64_t)(paired ? 2 : 1) * N * ldw * 2 < ((int64_t)1 << 32),
-               "mn_gemm256_grouped_tiles: unsupported shape N=%d K=%d", N, K);
+                   (a_rows_total * lda + a_lo_off) * 2 < ((int64_t)1 << 32) && (int64_t)(paired ? 2 : 1) * N * ldw * 2 < ((int64_t)1 << 32) &&
+                   g256_out_ok(C, ldc, c_lo_off, nullptr, epi == E_F32),
+               "mn_gemm256_grouped_tiles: unsupported shape N=%d K=%d (or C misaligned / ldc %% 4)", N, K);
   G256 p{};
   p.A = A; p.lda = lda; p.a_lo_off = a_lo_off; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.c_lo_off = c_lo_off;
   p.w_pair_rows = paired ? N : 0; p.M = (int)a_rows_total; p.N = N; p.K = K;

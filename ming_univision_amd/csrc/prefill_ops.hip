@@ -242,7 +242,6 @@ __global__ __launch_bounds__(256) void attn_prefill_gqa_hd128_kernel(
 }
 }  // namespace
 
-extern "C" int mn_flash_enabled();
 extern "C" int mn_flash_prefill_gqa_hd128_one(const uint16_t* q, const float* kv_seq, int64_t t_max, int n_q, int n_kv, int past, int T,
                                               const uint8_t* key_mask, uint16_t* out, void* stream);
 
@@ -250,8 +249,9 @@ extern "C" int mn_attn_prefill_gqa_hd128(const uint16_t* q, const float* kv_seq,
                                          int T, const uint8_t* key_mask, uint16_t* out, void* stream) {
   MN_CHECK_ARG(q && kv_seq && out && T >= 1 && past >= 0 && past + T <= t_max && n_q >= 1 && n_kv >= 1 && n_q % n_kv == 0,
                "mn_attn_prefill_gqa_hd128: bad args");
-  if (mn_flash_enabled() && n_q == 4 * n_kv)     // flash_prefill.hip: 64-key tiles, the 4 query heads of a KV head share its tiles
+  if (n_q == 4 * n_kv)     // flash_prefill.hip: 64-key tiles, the 4 query heads of a KV head share its tiles (the 16B-A3B ratio)
     return mn_flash_prefill_gqa_hd128_one(q, kv_seq, t_max, n_q, n_kv, past, T, key_mask, out, stream);
+  // any other GQA ratio (the tiny test configurations): one query head per workgroup, 32-key tiles
   hipLaunchKernelGGL(attn_prefill_gqa_hd128_kernel, dim3(mn_cdiv(T, 64), n_q), dim3(256), 0, mn_stream(stream), q, kv_seq,
                      t_max, n_q, n_kv, past, T, key_mask, out);
   MN_CHECK_LAUNCH("mn_attn_prefill_gqa_hd128");

@@ -319,7 +319,9 @@ static int skinny_medium(const mn_skinny_args& a, void* stream) {
 
 // Tuning overrides for micro-benchmarks (0 = heuristic). Not part of the stable ABI.
 static struct { int R, nt, bpc; } g_tune = {0, 0, 0};
-extern "C" void mn_skinny_tune(int R, int nt, int bpc) { g_tune.R = R; g_tune.nt = nt; g_tune.bpc = bpc; }
+#ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_skinny_tune(int R, int nt, int bpc) { g_tune.R = R; g_tune.nt = nt; g_tune.bpc = bpc; }
+#endif
 
 extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   MN_CHECK_ARG(args != nullptr, "mn_skinny_gemm: null args");

@@ -254,7 +254,9 @@ int kloop_dispatch(int G, int max_rows, int nz, const bf16_t* Y, int64_t y_lo, c
 
 }  // namespace
 
-extern "C" void mn_stream_kloop_tune(int nz, int depth, int nt) { g_kl_nz = nz; g_kl_depth = depth & 15; g_kl_nt = nt; g_kl_ck = (depth >> 4) ? 128 : 0; }
+#ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_stream_kloop_tune(int nz, int depth, int nt) { g_kl_nz = nz; g_kl_depth = depth & 15; g_kl_nt = nt; g_kl_ck = (depth >> 4) ? 128 : 0; }
+#endif
 
 // CUs a dense launch asks for: matrices under 64 MB (QKV, dense, gate, semantic-decoder GEMVs, RF w3) take half the chip — fewer
 // K-ranges to reduce, and other streams' kernels run beside them (end to end +3 % with three stream groups; a third or a
@@ -264,7 +266,9 @@ int kloop_dense_slots(int Ntot, int K) {
   const int cus = mn_num_cus();
   return ((int64_t)Ntot * K * 2 < ((int64_t)g_kl_small_mb << 20) && g_kl_small_div > 1) ? cus / g_kl_small_div : cus;
 }
-extern "C" void mn_stream_kloop_tune_small(int div) { g_kl_small_div = div & 15; if (div >> 4) g_kl_small_mb = div >> 4; }
+#ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_stream_kloop_tune_small(int div) { g_kl_small_div = div & 15; if (div >> 4) g_kl_small_mb = div >> 4; }
+#endif
 extern "C" int mn_stream_kloop_slices(int M, int Ntot, int K) { return kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K), kloop_nt(M)); }
 
 // Dense: Y [2][M][K] bf16 (hi rows then lo rows), W [Ntot][K], P [nz][M][Ntot].  Returns nz (< 0: error).  M <= 64.

@@ -231,7 +231,9 @@ void stream_launch(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, c
 
 }  // namespace
 
-extern "C" void mn_stream_tune_plan(int kch, int nw) { g_kch = kch; g_nw = nw; }
+#ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_stream_tune_plan(int kch, int nw) { g_kch = kch; g_nw = nw; }
+#endif
 
 extern "C" int mn_stream_mfma_slices(int M, int Ntot, int K) {
   if (M > 32) return mn_stream_kloop_slices(M, Ntot, K);

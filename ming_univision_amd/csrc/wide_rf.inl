@@ -12,11 +12,13 @@
 //                      final Linear (split-K) -> bias -> CFG combine + Euler step              (diff_loss:144-179, 291)
 // First row count that takes the wide route, per stage (measured crossovers); mn_wide_tune is the A/B hook.
 static int g_wide_min_llm = 65, g_wide_min_rf = 41, g_wide_min_sem = 65;
-extern "C" void mn_wide_tune(int llm_min_rows, int rf_min_rows, int sem_min_rows) {
+#ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_wide_tune(int llm_min_rows, int rf_min_rows, int sem_min_rows) {
   if (llm_min_rows > 0) g_wide_min_llm = llm_min_rows;
   if (rf_min_rows > 0) g_wide_min_rf = rf_min_rows;
   if (sem_min_rows > 0) g_wide_min_sem = sem_min_rows;
 }
+#endif
 
 struct RfWideWs {
   float *z, *c, *ada, *hh, *v, *x, *pbuf;

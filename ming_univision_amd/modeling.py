@@ -93,17 +93,44 @@ class MingUniVisionForConditionalGeneration:
         return x
 
     def prompt_wrap_vision(self, input_ids, inputs_embeds, vision_embeds, image_token_id=None):
-        """masked_scatter of image features at `<imagePatch>` positions (modeling_bailingmm.py:152-177)."""
+        """masked_scatter of image features at `<imagePatch>` positions (modeling_bailingmm.py:152-177).
+        input_ids [1, T] (or [T]); inputs_embeds fp32 [T, H] (or [1, T, H]); vision_embeds [N, H] or [B, N, H].
+        Returns (inputs_embeds, image_router_mask): the mask is bool, shaped like input_ids, True on image rows; it is None
+        when there is nothing to scatter (the reference returns the bare embeddings in that case, :153-154 — its only
+        caller, prompt_wrap_navit, never takes that branch; here the result is always a pair).  Raises ValueError when the
+        number of `<imagePatch>` tokens and of feature rows differ (:163-166)."""
         if vision_embeds is None or input_ids is None:
-            return inputs_embeds
-        patch = image_token_id if image_token_id is not None else self.config.llm_config.image_patch_token
-        sel = (input_ids.reshape(-1) == patch)
-        n_tok, n_feat = int(sel.sum()), vision_embeds.reshape(-1, vision_embeds.shape[-1]).shape[0]
+            return inputs_embeds, None
+        if image_token_id is not None:                                   # the reference stores the override in the config (:159)
+            self.config.llm_config.image_patch_token = image_token_id
+        patch = self.config.llm_config.image_patch_token
+        vision_embeds = vision_embeds.reshape(-1, vision_embeds.shape[-1])
+        router_mask = input_ids == patch
+        n_tok, n_feat = int(router_mask.sum()), vision_embeds.shape[0]
         if n_tok != n_feat:
             raise ValueError(f"Image features and image tokens do not match: tokens: {n_tok}, features {n_feat}")
         out = inputs_embeds.clone()
-        out[sel.to(out.device)] = vision_embeds.reshape(n_feat, -1).to(out.dtype)
-        return out, sel
+        flat = out.reshape(-1, out.shape[-1])
+        flat[router_mask.reshape(-1).to(out.device)] = vision_embeds.to(out.device, out.dtype)
+        return out, router_mask
+
+    def prompt_wrap_navit(self, input_ids, query_embeds_image=None, query_embeds_video=None, query_embeds_audio=None,
+                          query_embeds_audio_lengths=None, placeholder_audio_loc_lens=None, target_embeds=None):
+        """modeling_bailingmm.py:179-204: embedding lookup, then the image (or video) features scattered over the
+        `<imagePatch>` rows.  Returns the bare embeddings [T, H] fp32 when no modality is given (as the reference does),
+        else (inputs_embeds, image_mask, audio_mask).  Audio is outside the hot path."""
+        if query_embeds_audio is not None:
+            raise NotImplementedError("audio inputs are outside the hot path (SURVEY.md a27)")
+        ids = input_ids.to(self.device)
+        inputs_embeds = self.model.embed(ids.reshape(-1))
+        if query_embeds_image is None and query_embeds_video is None and target_embeds is None:
+            return inputs_embeds
+        image_mask = None
+        if query_embeds_image is not None:
+            inputs_embeds, image_mask = self.prompt_wrap_vision(ids, inputs_embeds, query_embeds_image)
+        if query_embeds_video is not None:
+            inputs_embeds, image_mask = self.prompt_wrap_vision(ids, inputs_embeds, query_embeds_video)
+        return inputs_embeds, image_mask, None
 
     # ---- batched text -> image (extension: the reference generates one image per call, modeling_bailing_moe.py:1865) ------
     @torch.no_grad()
@@ -145,8 +172,11 @@ class MingUniVisionForConditionalGeneration:
             noises = torch.stack([torch.randn(n_tok + 1, self.vision.latent_dim, generator=self.noise_generator, device=dev)
                                   for _ in range(B)])
         start = self.model.embed(torch.tensor([cfg.image_start_token], device=dev))
-        out = generate_images(self.model, self.rf, self.vision, start, lens, ams, uncs, tuncs, noises.to(dev),
-                              temperature=image_gen_temperature, text_cfg=3.0, image_cfg=1.1, n_groups=n_groups, seq0=s0)
+        try:
+            out = generate_images(self.model, self.rf, self.vision, start, lens, ams, uncs, tuncs, noises.to(dev),
+                                  temperature=image_gen_temperature, text_cfg=3.0, image_cfg=1.1, n_groups=n_groups, seq0=s0)
+        finally:
+            self.model.release_sequences(s0)         # the batch's cache sequences are dead: give the arena back
         files = []
         if save:
             prefixes = output_image_prefixes or [f"output_{b}" for b in range(B)]
@@ -168,6 +198,12 @@ class MingUniVisionForConditionalGeneration:
         triggered here (`<image>` is returned as a token).  Does not touch the multi-round state (its cache sequences included).
         Returns a list of B token-id lists (EOS included when reached).  `timings` (a dict, measurement only): synchronises
         after the prefills and at the end and stores `prefill_s` / `decode_s`."""
+        try:
+            return self._generate_text_batch(requests, max_new_tokens, sync_every, timings)
+        finally:
+            self.model.release_sequences(self.BATCH_SEQ0)     # the batch's cache sequences are dead: give the arena back
+
+    def _generate_text_batch(self, requests, max_new_tokens, sync_every, timings):
         import time
         cfg, dev = self.config.llm_config, self.device
         B = len(requests)
@@ -199,7 +235,8 @@ class MingUniVisionForConditionalGeneration:
                 feats = self.extract_image_feature(px)
                 feats = feats.reshape(len(chunk), -1, feats.shape[-1])
                 for j, b in enumerate(chunk):
-                    embeds[b], masks[b] = self.prompt_wrap_vision(ids_l[b], embeds[b], feats[j])
+                    embeds[b], m = self.prompt_wrap_vision(ids_l[b], embeds[b], feats[j])
+                    masks[b] = m.reshape(-1)
         # prompts: long ones on the bf16 MFMA path, stacked up to 8192 tokens per pass; short ones through the decode kernels
         last = [None] * B
         long_ = [b for b in range(B) if lens[b] > self.mfma_prefill_threshold and cfg.head_dim == 128]
@@ -270,12 +307,18 @@ class MingUniVisionForConditionalGeneration:
             tunc = torch.cat((self.past_text_uncond_attention_mask, tunc), dim=1)
         prompt_mask_len = attention_mask.shape[1]
         ids = input_ids.clip(0, cfg.vocab_size - 1)
-        embeds = self.model.embed(ids[0])
         image_mask = None
-        if pixel_values is not None and T > 1:
+        if pixel_values is not None and T > 1:                           # :237-248
             feats = self.extract_image_feature(pixel_values.to(dev), image_grid_thw)
-            embeds, image_mask = self.prompt_wrap_vision(ids, embeds, feats)
+            embeds, image_mask, _ = self.prompt_wrap_navit(ids, feats)
+            image_mask = image_mask.reshape(-1)
+        else:
+            embeds = self.model.embed(ids[0])
         past = self.past_len
+        n_img_tok = cfg.num_image_tokens_for_gen
+        if past + T > self.model.t_max:
+            raise ValueError(f"{past} cached + {T} prompt tokens exceed the KV arena (t_max = {self.model.t_max}); "
+                             "call reset_inner_state() or build the model with a larger t_max")
         if T > self.mfma_prefill_threshold and self.config.llm_config.head_dim == 128:
             # long prompts (image understanding: 256-1024 image tokens): bf16 MFMA prefill with grouped-GEMM MoE
             hidden = self.model.prefill_mfma(embeds, seq=0, past=past, image_mask=image_mask)
@@ -293,7 +336,12 @@ class MingUniVisionForConditionalGeneration:
         # `<image>` it finds — greedy decoding is deterministic, the speculative steps behind such a token only wrote cache slots
         # that the next real step overwrites.
         while not done and len(new_ids) < max_new_tokens:
-            n = min(self.decode_chunk, max_new_tokens - len(new_ids))
+            # every token of a chunk is fed (cache slot + rotary position cache_len + j) before the host looks at it: the
+            # chunk must end inside the arena, also when the conversation stops a few slots short of t_max
+            room = self.model.t_max - cache_len
+            if room <= 0:
+                raise ValueError(f"the conversation filled the KV arena (t_max = {self.model.t_max}) after {len(new_ids)} new tokens")
+            n = min(self.decode_chunk, max_new_tokens - len(new_ids), room)
             slot = torch.tensor([cache_len], dtype=torch.int32, device=dev)
             ln = slot + 1
             toks_dev = []
@@ -317,7 +365,9 @@ class MingUniVisionForConditionalGeneration:
                     if am.shape[1] < cache_len:                          # pad the mask over generated tokens
                         am = torch.cat((am, torch.ones(1, cache_len - am.shape[1], dtype=am.dtype)), dim=1)
                     x = self.model.embed(torch.tensor([tok], device=dev))
-                    n_tok = cfg.num_image_tokens_for_gen
+                    n_tok = n_img_tok
+                    if cache_len + n_tok + 1 > self.model.t_max:
+                        raise ValueError(f"{cache_len} cached tokens + {n_tok + 1} image slots exceed the KV arena (t_max = {self.model.t_max})")
                     noises = torch.randn(n_tok + 1, self.vision.latent_dim, generator=self.noise_generator, device=dev)
                     # NB: the reference swallows the caller's CFG scales and always runs 3.0 / 1.1
                     out = generate_image(self.model, self.rf, self.vision, x, cache_len, torch.cat((am, one), 1), unc, tunc,

@@ -229,7 +229,7 @@ def gemm256_grouped(a2, a_rows, w, off, cnt, n_pos, m_max, swiglu):
     else:
         out = torch.zeros(n_pos, N, dtype=torch.float32, device=a2.device)
         lo_off = 0
-    check(lib().mn_gemm256_grouped(ptr(a2), K, a2.stride(0), ptr(a_rows), ptr(w), K, w.stride(0), ptr(off), ptr(cnt), G, ptr(out), N,
+    check(lib().mn_gemm256_grouped(ptr(a2), K, a2.stride(0), a2.shape[1], ptr(a_rows), ptr(w), K, w.stride(0), ptr(off), ptr(cnt), G, ptr(out), N,
                                    lo_off, m_max, N, K, int(swiglu), current_stream()), "mn_gemm256_grouped")
     return out
 

@@ -392,33 +392,6 @@ def test_checkpoint_directory_roundtrip(tmp_path):
     assert isinstance(text, str)
 
 
-def test_rf_persistent_matches_per_launch_path():
-    """The persistent RF-block kernel (grid barriers, cross-phase prefetch) must give the same latents as the
-    two-launches-per-block path, at the full head size and for 1/2/3 CFG rows; the barrier error word stays 0."""
-    import ctypes
-    from ming_univision_amd._lib import lib
-    from ming_univision_amd.rf_head import RectifiedFlowHead
-    from ming_univision_amd.synth import synth_tensor
-    L = lib()
-    L.mn_rf_set_persistent.argtypes = [ctypes.c_int]
-    L.mn_rf_set_persistent.restype = None
-    rf_cfg = dict(diffloss_w=1024, diffloss_d=3, num_sampling_steps="4", gen_method="flow_matching_swiglu-4")
-    shapes = C.rf_param_shapes(1024, 3, 1024, 32, 4)
-    shapes.update({"vis_head.0.weight": (1024, 256), "vis_head.0.bias": (1024,), "vis_head.1.weight": (1024,), "vis_head.1.bias": (1024,)})
-    sd = {k: synth_tensor(k, s, 3, "cuda", torch.bfloat16) for k, s in shapes.items()}
-    head = RectifiedFlowHead(sd, 256, rf_cfg)
-    hid = torch.randn(3, 256, device="cuda")
-    noise = torch.randn(32, device="cuda")
-    for rows in (1, 2, 3):
-        L.mn_rf_set_persistent(0)
-        ref = head.sample(hid[:rows].contiguous(), noise).clone()
-        L.mn_rf_set_persistent(1)
-        for _ in range(3):
-            out = head.sample(hid[:rows].contiguous(), noise)
-            assert rel_err(out, ref) < 1e-5, rows
-    torch.cuda.synchronize()
-
-
 @pytest.mark.parametrize("B,groups,R", [(4, 1, 3), (10, 1, 3), (6, 3, 3), (21, 1, 3), (32, 2, 2)])
 def test_batched_generation_matches_single_image(B, groups, R):
     """generate_images with B images in lock-step (rows = B x CFG rows: 12 rows = one MFMA row tile, 30 rows =

@@ -135,9 +135,14 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in mingnative.h but not exported"
         assert name in _lib.SYMBOLS, f"{name} has no ctypes prototype"
-    assert handle.mn_version() >= 100
+    assert handle.mn_version() >= 110
     for name in _lib.SYMBOLS:
         assert name in declared, f"{name} bound in _lib.py but not declared in the header"
+    # ... and nothing else: the library is built with -fvisibility=hidden, the A/B hooks of tools/ live in libmingnative_dev.so
+    nm = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in nm.splitlines() if " T " in l)
+    assert exported == declared, (sorted(set(exported) - set(declared)), sorted(set(declared) - set(exported)))
+    assert not any("tune" in n for n in exported)
 
 
 def test_product_never_imports_oracle():
@@ -194,3 +199,20 @@ def test_replica_group_world2_gloo(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["total"] == 1024 and 0.19 <= res["dt"] < 5.0
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment starts 2 ranks itself (child torch.distributed.run, gloo in the
+    --dry-run plumbing mode) and rank 0's line reports them; with a launcher present the flag must agree with WORLD_SIZE."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--tiny", "--dry-run", "--steps", "2"],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                       # ONE JSON line, from rank 0
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["dry_run"] is True and res["value"] is None
+    assert res["ms_per_step"] >= 19.0                            # MAX over ranks: rank 1 sleeps 20 ms per step
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True,
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr

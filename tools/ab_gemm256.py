@@ -3,10 +3,11 @@ correctness against an fp64 product and in-process interleaved timing (rule: sam
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import tools.devlib  # noqa: F401  (A/B hooks live in libmingnative_dev.so)
 from ming_univision_amd import ops
 from ming_univision_amd._lib import lib, ptr, check, current_stream
 L = lib()
-L.mn_gemm256_tune.argtypes = [ctypes.c_int]; L.mn_gemm256_tune.restype = None
+L.mn_gemm256_tune = lambda sched: None   # the SCHED 0/1 arms were removed in round 3 (only the two-phase schedule is built)
 L.mn_gemm_route256.argtypes = [ctypes.c_int]; L.mn_gemm_route256.restype = None
 L.mn_gemm_route256(0)   # "round-1 kernel" below = the 128 x 128 kernel itself
 EPI = {"bf16": 0, "f32": 2}

@@ -2,6 +2,7 @@
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import tools.devlib  # noqa: F401  (A/B hooks live in libmingnative_dev.so)
 from ming_univision_amd._lib import lib, ptr, current_stream
 L = lib()
 L.mn_stream_tune_plan.argtypes = [ctypes.c_int] * 2; L.mn_stream_tune_plan.restype = None

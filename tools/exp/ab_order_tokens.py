@@ -2,6 +2,7 @@
 import sys, os, argparse, ctypes, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
+import tools.devlib  # noqa: F401  (A/B hooks live in libmingnative_dev.so)
 import bench
 from ming_univision_amd._lib import lib
 L = lib()

@@ -4,9 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from ming_univision_amd._lib import lib, ptr, check, current_stream
 L = lib()
-L.mn_attn_tune.argtypes = [ctypes.c_int]; L.mn_attn_tune.restype = None
-which, flash = sys.argv[1], int(sys.argv[2])
-L.mn_attn_tune(flash)
+which = sys.argv[1]      # (argv[2] selected the round-1 32-key kernels until they were removed in round 3)
 g = torch.Generator(device="cuda").manual_seed(0)
 if which == "hd64":
     B, T, nh = 64, 1024, 16

@@ -1,7 +1,11 @@
+#!/bin/bash
 # HBM traffic of the roofline kernel (gemm256 SwiGLU-split on RF w12) per launch: separate --pmc passes (FETCH_SIZE, WRITE_SIZE),
 # FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md §HBM.  usage: bash tools/pmc_w12.sh ROWS
 ROWS=${1:-1536}
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}"
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/pmcw
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcw/$c -- python3 tools/prof_gemm256.py w12 $ROWS > gpurun_out/pmcw/$c.log 2>&1
