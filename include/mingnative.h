@@ -257,6 +257,13 @@ MN_API int mn_gemm256_grouped(const uint16_t* A, int64_t lda, int64_t a_lo_off, 
                               const uint16_t* W, int64_t ldw, int64_t w_gstride, const int32_t* off, const int32_t* cnt, int n_groups,
                               void* C, int64_t ldc, int64_t c_lo_off, int m_max, int N, int K, int swiglu, void* stream);
 
+/* Operand of a hi/lo gemm256 launch from an fp32 row block: Y = act(norm(x)) as bf16 hi rows [M, D] (ldy) and lo rows y_lo_off
+ * elements further (y_lo_off == 0: plain bf16, no lo rows) and / or as fp32 rows `out` (ldo); either may be NULL.  norm 0: none; 1: RMSNorm(g) (modeling_bailing_moe.py:131-136);
+ * 2: LayerNorm(g, b optional) (mingtok layers/block.py:80-105).  act 1: exact-erf GELU (mlp.py:34-40).  D % 4 == 0, D <= 4096.
+ * The fp32-class ("precise") form of the MingTok blocks and of linear_proj is built from this + mn_gemm256 on hi/lo operands. */
+MN_API int mn_norm_act_split(const float* x, int64_t ldx, int norm, const uint16_t* g, const uint16_t* b, float eps, int act,
+                             uint16_t* Y, int64_t ldy, int64_t y_lo_off, float* out, int64_t ldo, int M, int D, void* stream);
+
 /* Tail of a split-K Linear that joins the fp32 residual stream, fused with the next LayerNorm (MingTok layers/block.py:80-105):
  * h[m] += sum_z P[z * slab + m * D + :] (bias already in slab 0, as mn_gemm256_splitk leaves it); if y != NULL:
  * y[m] = bf16(LayerNorm(h[m]; ln_g, ln_b optional, eps)), followed by exact-erf GELU when gelu != 0.  D % 4 == 0, D <= 4096. */
@@ -400,7 +407,7 @@ typedef struct mn_llm {
 } mn_llm;
 
 MN_API size_t mn_llm_workspace_bytes(const mn_llm* m, int rows, int64_t t_max);
-MN_API int mn_llm_max_rows(const mn_llm* m);      /* 64, or 2048 (wide route: see mn_rf_max_rows; no image-gate override there) */
+MN_API int mn_llm_max_rows(const mn_llm* m);      /* 64, or 2048 (wide route: see mn_rf_max_rows) */
 /* x fp32 in (embeddings): row m is read from x + (m / x_row_div) * ldx (ldx == 0 broadcasts one row to all M
  * rows; x_row_div = R shares one embedding between the R CFG rows of an image)
  * -> hidden_out [M,H] fp32 (after the final RMSNorm).

@@ -25,6 +25,10 @@ MN_DEV_API void mn_gemm_tune(int glds);                                 /* batch
 MN_DEV_API void mn_gemm_route256(int on);                               /* mn_gemm_bf16 -> gemm256 for large problems */
 MN_DEV_API void mn_gemm256_tune_order(int group_m, int group_list);     /* gemm256 tile order */
 MN_DEV_API void mn_wide_tune(int llm_min_rows, int rf_min_rows, int sem_min_rows);   /* first row count on the wide route */
+/* Measurement only ("lo-pass map"): bit s = Linear site s of the wide route multiplies plain bf16 activations (the hi
+ * rows only).  Sites: 0 vis_head, 1 cond_embed, 2 adaLN, 3 RF w12, 4 RF w3, 5 RF final, 6 QKV, 7 dense, 8 gate, 9 experts (gate/up +
+ * down), 10 semdec qkv, 11 semdec proj, 12 semdec w12, 13 semdec w3, 14 linear_proj. */
+MN_DEV_API void mn_lo_drop_mask(unsigned mask);
 
 #ifdef __cplusplus
 }

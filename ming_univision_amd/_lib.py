@@ -104,6 +104,7 @@ SYMBOLS = {
     "mn_moe_topk_logits": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "mn_moe_sort": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "mn_flash_prefill_gqa_hd128": (_i, [_p, _p, _i64, _i, _i, _i, _p, _i, _i, _p, _i64, _p, _p]),
+    "mn_norm_act_split": (_i, [_p, _i64, _i, _p, _p, _f, _i, _p, _i64, _i64, _p, _i64, _i, _i, _p]),
     "mn_slab_resid_norm": (_i, [_p, _i, _i64, _p, _i64, _p, _p, _f, _i, _p, _i64, _i, _i, _p]),
     "mn_rope_kv_prefill_spans": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _i, _f, _p, _p, _i64, _p, _i, _i, _p]),
     "mn_moe_combine_norm": (_i, [_p, _p, _p, _i, _p, _i64, _p, _f, _p, _i64, _i, _i, _p]),

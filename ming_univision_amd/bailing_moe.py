@@ -228,6 +228,26 @@ class BailingMoeDecoder:
             self.step(x[r0:r1], seq[r0:r1].contiguous(), sl, sl, (sl + 1).contiguous(), None, None, out=out[r0:r1])
         return out.reshape(B, T, H)
 
+    def prefill_wide(self, embeds, seq=0, past=0, image_mask=None):
+        """fp32-class causal prefill of ONE long prompt: all its rows go through the stack in passes of <= max_rows() rows on the
+        wide route (every Linear a gemm256 launch on hi/lo operands — 2^-17 activations, the decode path's numerics —, masked GQA
+        against the fp32 arena, image-gate routing on the rows flagged by image_mask).  Same results as `prefill` to summation
+        order, at MFMA rate; `prefill_mfma` is the bf16-activation form (2x fewer MFMA passes, ~1e-2 of the fp32 result).
+        embeds fp32 [T,H].  Returns the final-norm hidden states [T,H]."""
+        T = embeds.shape[0]
+        assert past + T <= self.t_max
+        dev = self.device
+        step = self.max_rows()
+        out = torch.empty(T, embeds.shape[1], dtype=torch.float32, device=dev)
+        x = embeds.to(dev, torch.float32).contiguous()
+        im = None if image_mask is None else image_mask.reshape(-1).to(dev, torch.uint8).contiguous()
+        for c0 in range(0, T, step):
+            m = min(step, T - c0)
+            slot = torch.arange(past + c0, past + c0 + m, dtype=torch.int32, device=dev)
+            seqs = torch.full((m,), seq, dtype=torch.int32, device=dev)
+            self.step(x[c0:c0 + m], seqs, slot, slot, slot + 1, None, None if im is None else im[c0:c0 + m], out=out[c0:c0 + m])
+        return out
+
     def ensure_sequences(self, n_seq):
         """Grow the KV arena to hold `n_seq` cache sequences (contents of the existing ones are kept).  Every sequence costs
         L * 2 * n_kv * t_max * hd * 4 bytes (16B-A3B at t_max = 4096: 470 MB) and the old arena stays live during the copy:
@@ -252,9 +272,10 @@ class BailingMoeDecoder:
         self.kv_cache = self.kv_cache[:, :n_keep].clone()
         self.n_seq = n_keep
 
-    def prefill_ragged(self, embeds_list, seqs, past=0):
+    def prefill_ragged(self, embeds_list, seqs, past=0, image_masks=None):
         """Causal prefill of several sequences of DIFFERENT lengths in shared passes through the stack: embeds_list[i] fp32
-        [T_i, H] goes to cache sequence seqs[i] from slot `past`.  Returns the last-token hidden state of each, [B, H]."""
+        [T_i, H] goes to cache sequence seqs[i] from slot `past`; image_masks[i] (optional, bool / uint8 [T_i]) flags the rows
+        routed by the image gate.  fp32-class (decode-path numerics).  Returns the last-token hidden state of each, [B, H]."""
         dev = self.device
         lens = [int(e.shape[0]) for e in embeds_list]
         assert len(seqs) == len(lens) and past + max(lens) <= self.t_max
@@ -262,11 +283,16 @@ class BailingMoeDecoder:
         seq = torch.cat([torch.full((n,), s, dtype=torch.int32) for n, s in zip(lens, seqs)]).to(dev)
         slot = torch.cat([torch.arange(past, past + n, dtype=torch.int32) for n in lens]).to(dev)
         out = torch.empty(x.shape[0], x.shape[1], dtype=torch.float32, device=dev)
+        im = None
+        if image_masks is not None and any(m is not None for m in image_masks):
+            im = torch.cat([torch.zeros(n, dtype=torch.uint8, device=dev) if m is None else m.reshape(-1).to(dev, torch.uint8)
+                            for m, n in zip(image_masks, lens)]).contiguous()
         step = self.max_rows()
         for r0 in range(0, x.shape[0], step):
             r1 = min(x.shape[0], r0 + step)
             sl = slot[r0:r1].contiguous()
-            self.step(x[r0:r1], seq[r0:r1].contiguous(), sl, sl, (sl + 1).contiguous(), None, None, out=out[r0:r1])
+            self.step(x[r0:r1], seq[r0:r1].contiguous(), sl, sl, (sl + 1).contiguous(), None, None if im is None else im[r0:r1],
+                      out=out[r0:r1])
         last = torch.tensor(lens).cumsum(0) - 1
         return out[last.to(dev)]
 

@@ -652,6 +652,7 @@ __global__ __launch_bounds__(1024) void moe_route_group_kernel(const float* __re
 }
 
 #include "wide_llm.inl"
+#include "tp.inl"
 
 struct MoeWs {
   int32_t *off, *xrows, *pair_pos;
@@ -742,6 +743,23 @@ static size_t llm_carve(const mn_llm* m, int rows, int64_t t_max, void* ws, size
 // proj(attn) / x = x + mlp(...)), fused with the LayerNorm of the NEXT consumer: h[m] += sum_z P[z][m][:] (the bias rides slab 0);
 // if y: y[m] = bf16(LayerNorm(h[m]) (ln_g, ln_b optional), GELU after it when gelu != 0).  One launch instead of a reduce pass
 // and a LayerNorm pass; used when the row count leaves a 256 x 256-tile GEMM without split-K on a fraction of the chip.
+// Y (bf16 hi rows, lo rows y_lo_off elements further; y_lo_off = 0: plain bf16) = act(norm(x)): the operand of a hi/lo gemm256
+// launch from an fp32 row block.  norm 0: none, 1: RMSNorm(g), 2: LayerNorm(g?, b?); act 1: exact-erf GELU.
+extern "C" int mn_norm_act_split(const float* x, int64_t ldx, int norm, const uint16_t* g, const uint16_t* b, float eps, int act,
+                                 uint16_t* Y, int64_t ldy, int64_t y_lo_off, float* out, int64_t ldo, int M, int D, void* stream) {
+  MN_CHECK_ARG(x && (Y || out) && M >= 1 && wide_glue_ok(D) && (ldx % 4) == 0 && (ldy % 4) == 0 && (y_lo_off % 4) == 0 && (ldo % 4) == 0 &&
+                   norm >= 0 && norm <= 2 && (norm != 1 || g) && (act == 0 || act == 1) && (((uintptr_t)x | (uintptr_t)out) & 15) == 0 &&
+                   (((uintptr_t)Y & 7) == 0),
+               "mn_norm_act_split: bad args (D %% 4 == 0, D <= 4096, 16-byte rows)");
+  WideGlue gl;
+  memset(&gl, 0, sizeof(gl));
+  gl.h = x; gl.ldh = ldx; gl.norm = norm; gl.ng = g; gl.nb = b; gl.eps = eps; gl.act = act;
+  gl.Y = Y; gl.ldy = ldy; gl.y_lo_off = y_lo_off; gl.out = out; gl.ldo = ldo; gl.M = M; gl.D = D;
+  wide_glue(gl, mn_stream(stream));
+  MN_CHECK_LAUNCH("mn_norm_act_split");
+  return MN_OK;
+}
+
 extern "C" int mn_slab_resid_norm(const float* P, int nz, int64_t slab, float* h, int64_t ldh, const uint16_t* ln_g, const uint16_t* ln_b,
                                   float eps, int gelu, uint16_t* y, int64_t ldy, int M, int D, void* stream) {
   MN_CHECK_ARG(P && h && nz >= 1 && M >= 1 && wide_glue_ok(D) && (ldh % 4) == 0 && (!y || (ldy % 4) == 0), "mn_slab_resid_norm: bad args");
@@ -802,11 +820,9 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
                "mn_llm_step: null pointer");
   MN_CHECK_ARG(M >= 1 && (M <= 64 || llm_wide_ok(m, M)) && x_row_div >= 1,
                "mn_llm_step: M=%d (1..64, or up to 2048 rows with 64-aligned widths)", M);
-  if (llm_wide_ok(m, M) && (M > 64 || !(image_mask && m->image_gate))) {
-    MN_CHECK_ARG(!(image_mask && m->image_gate), "mn_llm_step: the image-gate override is not available above 64 rows");
-    return llm_step_wide(m, x, ldx, x_row_div, M, row_seq, row_slot, row_pos, row_len, key_mask, ld_mask, kv_cache, n_seq, t_max,
+  if (llm_wide_ok(m, M))
+    return llm_step_wide(m, x, ldx, x_row_div, M, image_mask, row_seq, row_slot, row_pos, row_len, key_mask, ld_mask, kv_cache, n_seq, t_max,
                          hidden_out, workspace, workspace_bytes, stream);
-  }
   LlmWs w{};
   const size_t need = llm_carve(m, M, t_max, workspace, workspace_bytes, &w);
   if (need > workspace_bytes) { mn_set_error("mn_llm_step: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
@@ -1027,5 +1043,81 @@ extern "C" int mn_semdec_step(const mn_semdec* s, const float* latent_norm, int 
     }
   }
   MN_CHECK_LAUNCH("mn_semdec_step");
+  return MN_OK;
+}
+
+
+// ===========================================================================================
+// lm_head + greedy pick  (compute_logit, modeling_bailing_moe.py:1604-1620, followed by the argmax of greedy decoding)
+// ===========================================================================================
+namespace {
+// one workgroup per row: arg-max over V fp32 logits, ties -> the lowest index (torch.argmax's rule)
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* __restrict__ logits, int64_t ld, int V, int64_t vocab_offset,
+                                                           int64_t* __restrict__ idx, float* __restrict__ val) {
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* r = logits + (int64_t)m * ld;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = threadIdx.x; j < V; j += 1024) {
+    const float v = r[j];
+    if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w2 = 1; w2 < 16; ++w2)
+      if (sv[w2] > bv || (sv[w2] == bv && si[w2] < bi)) { bv = sv[w2]; bi = si[w2]; }
+    idx[m] = (int64_t)bi + vocab_offset;
+    if (val) val[m] = bv;
+  }
+}
+}  // namespace
+
+extern "C" size_t mn_lmhead_argmax_workspace_bytes(int M, int V, int H) {
+  size_t n = (((size_t)M * V * sizeof(float)) + 255) & ~(size_t)255;        // the logits
+  if (M > 8) n += (((size_t)2 * M * H * sizeof(bf16_t)) + 255) & ~(size_t)255;   // hi/lo operand of the MFMA route
+  return n;
+}
+
+// idx[m] = vocab_offset + argmax_v ( hidden[m] . W[v] ), val[m] = that logit (fp32; may be NULL).  W bf16 [V, H] is the whole
+// lm_head or, under tensor parallelism, this rank's vocabulary slice starting at vocab_offset (the ranks' (val, idx) pairs are
+// then reduced by max-val / lowest-idx).  <= 8 rows: the weight-streaming skinny kernel (HBM-bound: 0.52 GB per token at V =
+// 126 464); more rows: one gemm256 launch on the hi/lo operand.  The logits stay in the workspace (fp32 [M, V], its first bytes).
+extern "C" int mn_lmhead_argmax(const float* hidden, int64_t ld_hidden, int M, const uint16_t* W, int64_t ldw, int V, int H,
+                                int64_t vocab_offset, int64_t* idx, float* val, void* workspace, size_t workspace_bytes, void* stream) {
+  MN_CHECK_ARG(hidden && W && idx && workspace && M >= 1 && V >= 1 && H >= 8 && (H % 8) == 0, "mn_lmhead_argmax: bad args");
+  const size_t need = mn_lmhead_argmax_workspace_bytes(M, V, H);
+  if (workspace_bytes < need) { mn_set_error("mn_lmhead_argmax: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
+  float* logits = reinterpret_cast<float*>(workspace);
+  hipStream_t st = mn_stream(stream);
+  const bool mfma = M > 8 && (H % 64) == 0 && (V % 4) == 0 && wide_glue_ok(H) && (ld_hidden % 4) == 0 &&
+                    (int64_t)V * ldw * 2 < ((int64_t)1 << 32) && (int64_t)2 * M * H * 2 < ((int64_t)1 << 32);
+  if (mfma) {
+    bf16_t* y = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(workspace) + ((((size_t)M * V * sizeof(float)) + 255) & ~(size_t)255));
+    WideGlue g;
+    memset(&g, 0, sizeof(g));
+    g.h = hidden; g.ldh = ld_hidden; g.Y = y; g.ldy = H; g.y_lo_off = (int64_t)M * H; g.M = M; g.D = H;
+    wide_glue(g, st);
+    mn_g256 a = g256_hilo(y, H, (int64_t)M * H, W, ldw, nullptr, logits, V, M, V, H);
+    MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
+  } else {
+    for (int m0 = 0; m0 < M; m0 += 8) {
+      mn_skinny_args a;
+      memset(&a, 0, sizeof(a));
+      a.x = hidden + (int64_t)m0 * ld_hidden; a.ldx = ld_hidden; a.w = W; a.ldw = ldw; a.out = logits + (int64_t)m0 * V; a.ldo = V;
+      a.M = M - m0 < 8 ? M - m0 : 8; a.N = V; a.K = H;
+      MN_TRY(mn_skinny_gemm(&a, stream));
+    }
+  }
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(M), dim3(1024), 0, st, (const float*)logits, (int64_t)V, V, vocab_offset, idx, val);
+  MN_CHECK_LAUNCH("mn_lmhead_argmax");
   return MN_OK;
 }

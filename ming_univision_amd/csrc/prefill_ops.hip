@@ -310,7 +310,8 @@ __global__ __launch_bounds__(1024) void moe_sort_kernel(const int32_t* __restric
                                                         int32_t* __restrict__ counts, int32_t* __restrict__ offsets,
                                                         int32_t* __restrict__ perm, int32_t* __restrict__ slot_of,
                                                         int n_slot, int tile_rows, int32_t* __restrict__ tile_g,
-                                                        int32_t* __restrict__ tile_m0, int32_t* __restrict__ n_tiles) {
+                                                        int32_t* __restrict__ tile_m0, int32_t* __restrict__ n_tiles,
+                                                        int g_lo, int g_hi) {
   __shared__ int cnt[128], off[129], cur[128];
   const int tid = threadIdx.x;
   for (int i = tid; i < n_groups; i += 1024) { cnt[i] = 0; cur[i] = 0; }
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(1024) void moe_sort_kernel(const int32_t* __restric
   if (tid == 0) offsets[n_groups] = off[n_groups];
   if (tile_g && tid == 0) {        // live row tiles of the grouped GEMMs, in group order
     int t = 0;
-    for (int e = 0; e < n_groups; ++e)
+    for (int e = g_lo; e < g_hi; ++e)           // expert parallelism: only the groups this rank holds get tiles
       for (int m0 = 0; m0 < cnt[e]; m0 += tile_rows) { tile_g[t] = e; tile_m0[t] = m0; ++t; }
     *n_tiles = t;
   }
@@ -344,7 +345,7 @@ extern "C" int mn_moe_sort(const int32_t* topk_idx, int T, int n_slot, int n_gro
   MN_CHECK_ARG(topk_idx && counts && offsets && perm && slot_of && T >= 1 && n_slot >= 1 && n_groups >= 1 && n_groups <= 128 &&
                    (int64_t)T * n_slot <= 65536, "mn_moe_sort: bad args");
   hipLaunchKernelGGL(moe_sort_kernel, dim3(1), dim3(1024), 0, mn_stream(stream), topk_idx, T * n_slot, n_groups, counts,
-                     offsets, perm, slot_of, n_slot, 0, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+                     offsets, perm, slot_of, n_slot, 0, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, 0, 0);
   MN_CHECK_LAUNCH("mn_moe_sort");
   return MN_OK;
 }
@@ -357,8 +358,23 @@ extern "C" int mn_moe_sort_tiles(const int32_t* topk_idx, int T, int n_slot, int
   MN_CHECK_ARG(topk_idx && counts && offsets && perm && slot_of && tile_g && tile_m0 && n_tiles && tile_rows >= 1 && T >= 1 &&
                    n_slot >= 1 && n_groups >= 1 && n_groups <= 128 && (int64_t)T * n_slot <= 65536, "mn_moe_sort_tiles: bad args");
   hipLaunchKernelGGL(moe_sort_kernel, dim3(1), dim3(1024), 0, mn_stream(stream), topk_idx, T * n_slot, n_groups, counts,
-                     offsets, perm, slot_of, n_slot, tile_rows, tile_g, tile_m0, n_tiles);
+                     offsets, perm, slot_of, n_slot, tile_rows, tile_g, tile_m0, n_tiles, 0, n_groups);
   MN_CHECK_LAUNCH("mn_moe_sort_tiles");
+  return MN_OK;
+}
+
+// Expert-parallel dispatch (replicate-and-reduce EP): every rank holds all rows and the global routing; it sorts the
+// (row, pick) pairs by GLOBAL expert id like mn_moe_sort_tiles but lists row tiles only for the experts [expert0, expert0 + n_local)
+// it owns — the grouped GEMMs then touch only local weights (W biased by -expert0 groups) and local pairs.
+extern "C" int mn_ep_dispatch(const int32_t* topk_idx, int T, int n_slot, int n_experts, int expert0, int n_local, int32_t* counts,
+                              int32_t* offsets, int32_t* perm, int32_t* slot_of, int tile_rows, int32_t* tile_g, int32_t* tile_m0,
+                              int32_t* n_tiles, void* stream) {
+  MN_CHECK_ARG(topk_idx && counts && offsets && perm && slot_of && tile_g && tile_m0 && n_tiles && tile_rows >= 1 && T >= 1 &&
+                   n_slot >= 1 && n_experts >= 1 && n_experts <= 128 && (int64_t)T * n_slot <= 65536 && expert0 >= 0 && n_local >= 1 &&
+                   expert0 + n_local <= n_experts, "mn_ep_dispatch: bad args");
+  hipLaunchKernelGGL(moe_sort_kernel, dim3(1), dim3(1024), 0, mn_stream(stream), topk_idx, T * n_slot, n_experts, counts,
+                     offsets, perm, slot_of, n_slot, tile_rows, tile_g, tile_m0, n_tiles, expert0, expert0 + n_local);
+  MN_CHECK_LAUNCH("mn_ep_dispatch");
   return MN_OK;
 }
 

@@ -1,0 +1,411 @@
+// tp.inl — tensor / expert parallelism of the decode path over one xGMI node (textually part of engine.hip).
+//
+// Partitioning (no reference counterpart — the reference runs the 16B-A3B model on one device):
+//   attention   q heads split over the ranks, each KV head on world / n_kv ranks (16 q / 4 kv heads at TP = 8: 2 q heads + 1 KV
+//               head per rank); query_key_value split by rows (column-parallel), dense by columns (row-parallel)
+//               (modeling_bailing_moe.py:656-829)                                                  -> all-reduce 1 of a layer
+//   experts     E / world routed experts per rank (expert parallelism); every rank holds all rows and the global routing
+//               (replicate-and-reduce: no token all-to-all for a few rows), computes its experts' share of sum_k w_k y_k, plus
+//               its slice of the shared expert's intermediate width (:556-639)                     -> all-reduce 2 of a layer
+//   RF head     w12 split by hidden units (column-parallel), w3 by columns (row-parallel): one all-reduce per ResBlock per
+//               Euler step; vis_head / cond / adaLN / input / final layers replicated (diff_loss_rf_swiglu.py:54-72, 263-292)
+//
+// All-reduce = push + arrival flags + the slab sum the consumer already does.  Every rank owns an INBOX (fine-grained device
+// memory, peer-mapped on the other ranks over xGMI): fp32 [2 (epoch parity)][world (sender)][cap], and FLAGS uint32
+// [world (sender)][rows_cap].  The producer's tail kernel (tp_push) reduces the local split-K slabs / expert outputs of a row and
+// stores the row into slab (parity, rank) of EVERY rank's inbox (posted xGMI writes), fences at system scope and then stores the
+// all-reduce's epoch into flag (rank, row) on every rank.  The consumer is the wide_glue launch that follows anyway (residual +
+// norm + next operand): row m spins (bounded) on its `world` LOCAL flags, then sums the `world` slabs like split-K slabs.
+// One-shot: one xGMI hop, no ring, 4-18 KB per rank at decode sizes.  Two parities suffice: a rank can push all-reduce k + 2 only
+// after it consumed k + 1, which every peer pushed after consuming k.  Epochs are monotonic over the communicator's lifetime
+// (compared as signed differences), so flags are never reset.
+//
+// Segments: a composite is a straight-line launch sequence cut at its all-reduces into segments; [seg_begin, seg_end) selects
+// which run.  Production runs all of them in one call (waits are real).  The single-GPU parity harness runs segment k of every
+// rank before segment k + 1 of any rank on one stream — same kernels, same flags, every wait already satisfied.
+
+struct TpPush {
+  const float* P; int nz; int64_t slab;                                    // local split-K slabs [nz][M][D] (or NULL)
+  const float* cy; const int32_t* cpos; const float* cw; const int32_t* ci; int n_slot; int e0, e1;   // local experts' outputs (or NULL)
+  float* inbox[MN_TP_MAX_WORLD];
+  uint32_t* flags[MN_TP_MAX_WORLD];
+  int world, rank, rows_cap, M, D;
+  int64_t cap;
+  uint32_t epoch;
+};
+
+// Row m of this rank's partial: v = sum_z P[z][m] + sum_{s : expert(m, s) local} cw[m, s] * cy[cpos[m, s]]  ->  every rank's inbox.
+__global__ __launch_bounds__(1024) void tp_push_kernel(const TpPush p) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int m = blockIdx.x, col = threadIdx.x * 4, D = p.D;
+  if (col < D) {
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (p.P) {
+      const float* pp = p.P + (int64_t)m * D + col;
+      for (int z = 0; z < p.nz; ++z) v += *reinterpret_cast<const f4*>(pp + z * p.slab);
+    }
+    if (p.cy) {
+      for (int s = 0; s < p.n_slot; ++s) {
+        const int e = p.ci[(int64_t)m * p.n_slot + s];
+        if (e >= p.e0 && e < p.e1)
+          v += p.cw[(int64_t)m * p.n_slot + s] * *reinterpret_cast<const f4*>(p.cy + (int64_t)p.cpos[(int64_t)m * p.n_slot + s] * D + col);
+      }
+    }
+    const int64_t off = ((int64_t)(p.epoch & 1u) * p.world + p.rank) * p.cap + (int64_t)m * D + col;
+    for (int r = 0; r < p.world; ++r) *reinterpret_cast<f4*>(p.inbox[r] + off) = v;
+  }
+  __threadfence_system();          // the row is visible on every rank before any of its flags
+  __syncthreads();
+  if ((int)threadIdx.x < p.world)
+    __hip_atomic_store(p.flags[threadIdx.x] + (int64_t)p.rank * p.rows_cap + m, p.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static bool tp_comm_ok(const mn_tp_comm* c, int rows, int D) {
+  return c && c->world >= 1 && c->world <= MN_TP_MAX_WORLD && c->rank >= 0 && c->rank < c->world && c->inbox && c->flags &&
+         rows <= c->rows_cap && (int64_t)rows * D <= c->cap && (D % 4) == 0 && D >= 64 && D <= 4096;
+}
+
+static void tp_push(const mn_tp_comm* c, uint32_t epoch, TpPush p, int M, int D, hipStream_t st) {
+  for (int r = 0; r < c->world; ++r) { p.inbox[r] = c->inbox[r]; p.flags[r] = c->flags[r]; }
+  p.world = c->world; p.rank = c->rank; p.rows_cap = c->rows_cap; p.cap = c->cap; p.epoch = epoch; p.M = M; p.D = D;
+  hipLaunchKernelGGL(tp_push_kernel, dim3(M), dim3(((D / 4 + 63) / 64) * 64), 0, st, p);
+}
+
+// Consumer side: the glue's slab sum reads this rank's inbox (one slab per sender) after the row's arrival flags.
+static void tp_consume(WideGlue& g, const mn_tp_comm* c, uint32_t epoch) {
+  g.P = c->inbox[c->rank] + (int64_t)(epoch & 1u) * c->world * c->cap;
+  g.nz = c->world; g.slab = c->cap;
+  g.wait_flags = c->flags[c->rank]; g.wait_n = c->world; g.wait_stride = c->rows_cap; g.wait_epoch = epoch; g.wait_err = c->err;
+}
+
+// out[m] = sum over ranks of x[m] (fp32 [M, D] partial per rank).  Stand-alone form of the mechanism above (push + reduce).
+extern "C" int mn_allreduce_oneshot(mn_tp_comm* comm, const float* x, int64_t ldx, float* out, int64_t ldo, int M, int D, void* stream) {
+  MN_CHECK_ARG(x && out && M >= 1 && tp_comm_ok(comm, M, D) && ldx == D && (ldo % 4) == 0,
+               "mn_allreduce_oneshot: bad args (rows <= rows_cap, rows * D <= cap, D %% 4 == 0, 64 <= D <= 4096, ldx == D)");
+  hipStream_t st = mn_stream(stream);
+  const uint32_t ep = comm->epoch + 1;
+  TpPush p;
+  memset(&p, 0, sizeof(p));
+  p.P = x; p.nz = 1; p.slab = 0;
+  tp_push(comm, ep, p, M, D, st);
+  WideGlue g;
+  memset(&g, 0, sizeof(g));
+  g.xin = nullptr; g.h = nullptr;
+  tp_consume(g, comm, ep);
+  g.out = out; g.ldo = ldo; g.M = M; g.D = D;
+  g.x = nullptr;
+  // v starts from the (zero) source: give the glue a zero row source by pointing h at slab 0 and skipping it in the sum
+  g.h = g.P; g.ldh = D; g.P += g.slab; g.nz -= 1;
+  if (g.nz == 0) g.P = nullptr;
+  wide_glue(g, st);
+  comm->epoch = ep;
+  MN_CHECK_LAUNCH("mn_allreduce_oneshot");
+  return MN_OK;
+}
+
+// Expert-parallel combine (moe_infer's weighted un-permute, modeling_bailing_moe.py:630-639, across ranks): rank-local
+//   part[m] = sum_{s : topk_idx[m, s] in [expert0, expert0 + n_local)} topk_w[m, s] * yg[slot_of[m, s]]  (+ sum_z P[z][m])
+// pushed to every rank; out[m] = h[m] + sum over ranks of part[m].  P: optional extra fp32 slabs of the rank (its slice of the
+// shared expert's down projection).  Counterpart of mn_ep_dispatch.
+extern "C" int mn_ep_combine(mn_tp_comm* comm, const float* yg, const int32_t* slot_of, const int32_t* topk_idx, const float* topk_w,
+                             int n_slot, int expert0, int n_local, const float* P, int nz, int64_t slab, const float* h, int64_t ldh,
+                             float* out, int64_t ldo, int M, int D, void* stream) {
+  MN_CHECK_ARG(yg && slot_of && topk_idx && topk_w && h && out && n_slot >= 1 && n_local >= 1 && M >= 1 && tp_comm_ok(comm, M, D) &&
+                   (ldh % 4) == 0 && (ldo % 4) == 0 && (!P || nz >= 1), "mn_ep_combine: bad args");
+  hipStream_t st = mn_stream(stream);
+  const uint32_t ep = comm->epoch + 1;
+  TpPush p;
+  memset(&p, 0, sizeof(p));
+  p.P = P; p.nz = nz; p.slab = slab;
+  p.cy = yg; p.cpos = slot_of; p.cw = topk_w; p.ci = topk_idx; p.n_slot = n_slot; p.e0 = expert0; p.e1 = expert0 + n_local;
+  tp_push(comm, ep, p, M, D, st);
+  WideGlue g;
+  memset(&g, 0, sizeof(g));
+  g.h = h; g.ldh = ldh;
+  tp_consume(g, comm, ep);
+  g.out = out; g.ldo = ldo; g.M = M; g.D = D;
+  wide_glue(g, st);
+  comm->epoch = ep;
+  MN_CHECK_LAUNCH("mn_ep_combine");
+  return MN_OK;
+}
+
+// ===========================================================================================
+// Bailing-MoE decoder stack, one step, tensor + expert parallel
+// ===========================================================================================
+struct LlmTpWs {
+  LlmWideWs w;
+  bf16_t* ysh;          // hi/lo operand of the shared slice's down projection [2][rows][shared_inter]
+  float* psh;           // its split-K slabs
+  int ks_sh3;
+};
+
+static bool llm_tp_ok(const mn_llm* m, const mn_llm_tp* tp, const mn_tp_comm* c, int rows) {
+  if (!m || !tp || rows < 1 || rows > 2048 || !tp_comm_ok(c, rows, m->hidden)) return false;
+  const int ad = m->n_q * m->head_dim;
+  return wide_glue_ok(m->hidden) && (m->hidden % 64) == 0 && (ad % 64) == 0 && (m->moe_inter % 64) == 0 && m->n_experts <= 64 &&
+         (m->n_experts % 4) == 0 && (int64_t)rows * m->top_k <= 65536 && (m->head_dim == 64 || m->head_dim == 128) &&
+         m->n_q % m->n_kv == 0 && m->n_shared_slots == 0 && tp->n_local_experts >= 1 && tp->expert0 >= 0 &&
+         tp->expert0 + tp->n_local_experts <= m->n_experts && tp->shared_inter >= 0 && (tp->shared_inter % 64) == 0 &&
+         (tp->shared_inter == 0 || (tp->ws_gate_up && tp->ws_down));
+}
+
+static size_t llm_tp_carve(const mn_llm* m, const mn_llm_tp* tp, int rows, int64_t t_max, void* ws, size_t cap, LlmTpWs* o) {
+  // the wide route's carve on the SHARD's dimensions (local heads; n_experts = the global count: the router is replicated) ...
+  size_t off = llm_wide_carve(m, rows, t_max, ws, cap, &o->w);
+  Carver cv(ws ? (char*)ws + off : nullptr, cap > off ? cap - off : 0, ws == nullptr);
+  // ... + the shared slice: its down projection's slabs share pp (sized below), its operand is ysh
+  o->ks_sh3 = tp->shared_inter ? rf_wide_ksplit(rows, m->hidden, tp->shared_inter) : 1;
+  o->ysh = cv.take<bf16_t>((size_t)2 * rows * (tp->shared_inter ? tp->shared_inter : 64));
+  o->psh = cv.take<float>((size_t)mn_gemm256_slices(tp->shared_inter ? tp->shared_inter : 64, o->ks_sh3) * rows * m->hidden);
+  return off + cv.off;
+}
+
+extern "C" size_t mn_llm_tp_workspace_bytes(const mn_llm* m, const mn_llm_tp* tp, int rows, int64_t t_max) {
+  LlmTpWs w;
+  return llm_tp_carve(m, tp, rows, t_max, nullptr, 0, &w);
+}
+
+extern "C" int mn_llm_tp_segments(const mn_llm* m) { return 2 * m->n_layers + 1; }
+
+extern "C" int mn_llm_step_tp(const mn_llm* m, const mn_llm_tp* tp, mn_tp_comm* comm, const float* x, int64_t ldx, int x_row_div, int M,
+                              const uint8_t* image_mask, const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_pos,
+                              const int32_t* row_len, const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
+                              float* hidden_out, void* workspace, size_t workspace_bytes, int seg_begin, int seg_end, void* stream) {
+  MN_CHECK_ARG(m && tp && comm && x && row_seq && row_slot && row_pos && row_len && kv_cache && hidden_out && workspace,
+               "mn_llm_step_tp: null pointer");
+  MN_CHECK_ARG(llm_tp_ok(m, tp, comm, M) && x_row_div >= 1, "mn_llm_step_tp: unsupported shard / communicator for M=%d rows", M);
+  const int n_seg = 2 * m->n_layers + 1;
+  MN_CHECK_ARG(seg_begin >= 0 && seg_begin < seg_end && seg_end <= n_seg, "mn_llm_step_tp: segments [%d, %d) of %d", seg_begin, seg_end, n_seg);
+  LlmTpWs tw;
+  const size_t need = llm_tp_carve(m, tp, M, t_max, workspace, workspace_bytes, &tw);
+  if (need > workspace_bytes) { mn_set_error("mn_llm_step_tp: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
+  LlmWideWs& w = tw.w;
+  float* psh = tw.psh;
+  hipStream_t st = mn_stream(stream);
+  const int H = m->hidden, hd = m->head_dim, nq = m->n_q, nkv = m->n_kv, I = m->moe_inter, E = m->n_experts, SI = tp->shared_inter;
+  const int ad = nq * hd, qkv_dim = (nq + 2 * nkv) * hd, n_slot = m->top_k, e0 = tp->expert0, e1 = tp->expert0 + tp->n_local_experts;
+  const int64_t P = (int64_t)M * n_slot;
+  const int64_t layer_kv = (int64_t)n_seq * 2 * nkv * t_max * hd;
+  const float q_scale = 1.0f / sqrtf((float)hd);
+  int seg = 0;
+  uint32_t ep = comm->epoch;                       // epoch of the all-reduce the NEXT consumer waits for
+  auto on = [&]() { return seg >= seg_begin && seg < seg_end; };
+  WideGlue g;
+  for (int l = 0; l <= m->n_layers; ++l) {
+    const bool fin = l == m->n_layers;
+    // ---- segment 2l: glue (stack input | h += all-reduced expert partials of layer l-1) -> RMSNorm(ln1 | final norm)
+    if (on()) {
+      memset(&g, 0, sizeof(g));
+      if (l == 0) { g.x = x; g.ldx = ldx; g.x_row_div = x_row_div; }
+      else { g.h = w.h; g.ldh = H; tp_consume(g, comm, ep); }
+      g.h_out = fin ? nullptr : w.h; g.ldho = H;
+      g.norm = 1; g.ng = fin ? m->final_norm : m->ln1[l]; g.eps = m->rms_eps;
+      if (fin) { g.out = hidden_out; g.ldo = H; }
+      else { g.Y = w.yh; g.ldy = H; g.y_lo_off = (int64_t)M * H; }
+      g.M = M; g.D = H;
+      wide_glue(g, st);
+    }
+    if (fin) break;
+    float* kv_l = kv_cache + (int64_t)l * layer_kv;
+    if (on()) {
+      // local heads: QKV rows of this rank -> RoPE + KV append (its KV head) -> masked GQA -> dense over its columns  (:743-829)
+      mn_g256 a = g256_hilo(w.yh, H, (int64_t)M * H, m->wqkv[l], H, nullptr, w.pp, qkv_dim, M, qkv_dim, H);
+      a.c_zstride = (int64_t)M * qkv_dim;
+      int nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks_qkv, stream);
+      if (nz < 0) return nz;
+      MN_TRY(mn_rope_kv_from_partials(w.pp, qkv_dim, nz, (int64_t)M * qkv_dim, M, nq, nkv, hd, 1, m->cos_tab, m->sin_tab, row_seq,
+                                      row_slot, row_pos, m->mrope_sec_t, m->mrope_sec_h, q_scale, w.q, kv_l, t_max, stream));
+      MN_TRY(mn_attn_decode_split(w.q, M, nq, nkv, hd, kv_l, t_max, row_seq, row_len, key_mask, ld_mask, nullptr, w.ya, w.attn_ws,
+                                  w.attn_ws_bytes, stream));
+      a = g256_hilo(w.ya, ad, (int64_t)M * ad, m->wdense[l], ad, nullptr, w.pp, H, M, H, ad);
+      a.c_zstride = (int64_t)M * H;
+      nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks_dense, stream);
+      if (nz < 0) return nz;
+      TpPush p;                                     // all-reduce 1: the dense partial of this rank's heads
+      memset(&p, 0, sizeof(p));
+      p.P = w.pp; p.nz = nz; p.slab = (int64_t)M * H;
+      tp_push(comm, ep + 1, p, M, H, st);
+    }
+    ++seg; ++ep;
+    // ---- segment 2l + 1: h += all-reduced attention partials; RMSNorm(ln2); router (replicated); local experts + shared slice
+    if (on()) {
+      memset(&g, 0, sizeof(g));
+      g.h = w.h; g.ldh = H; tp_consume(g, comm, ep); g.h_out = w.h; g.ldho = H;
+      g.norm = 1; g.ng = m->ln2[l]; g.eps = m->rms_eps; g.Y = w.yh; g.ldy = H; g.y_lo_off = (int64_t)M * H; g.M = M; g.D = H;
+      wide_glue(g, st);
+      mn_g256 a = g256_hilo(w.yh, H, (int64_t)M * H, m->gate[l], H, nullptr, w.pp, E, M, E, H);
+      a.c_zstride = (int64_t)M * E;
+      int nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks_gate, stream);
+      if (nz < 0) return nz;
+      const float* p_img = nullptr;
+      if (image_mask && m->image_gate && m->image_gate[l]) {
+        float* pi = w.pp + (int64_t)nz * M * E;
+        a = g256_hilo(w.yh, H, (int64_t)M * H, m->image_gate[l], H, nullptr, pi, E, M, E, H);
+        a.c_zstride = (int64_t)M * E;
+        const int nzi = mn_gemm256_ex(&a, MN_G256_F32, w.ks_gate, stream);
+        if (nzi < 0) return nzi;
+        p_img = pi;
+      }
+      hipLaunchKernelGGL(moe_topk_partials_kernel, dim3(mn_cdiv(M, 4)), dim3(256), 0, st, (const float*)w.pp, p_img, image_mask, nz,
+                         (int64_t)M * E, M, E, m->top_k, m->norm_topk_prob, 0, w.ti, w.tw);
+      MN_TRY(mn_ep_dispatch(w.ti, M, n_slot, E, e0, e1 - e0, w.cnt, w.off, w.perm, w.slot_of, 128, w.tile_g, w.tile_m0, w.n_tiles, stream));
+      // local experts (weights biased by -e0 groups: only local group ids appear in the tile list)  (:617-628, 483-484)
+      a = g256_hilo(w.yh, H, (int64_t)M * H, m->w_gate_up[l] - (int64_t)e0 * 2 * I * H, H, nullptr, w.y2, I, M, I, H);
+      a.w_pair_rows = I; a.c_lo_off = P * I;
+      a.g_off = w.off; a.g_cnt = w.cnt; a.w_gstride = (int64_t)2 * I * H; a.a_rows = w.perm; a.n_groups = E;
+      a.tile_g = w.tile_g; a.tile_m0 = w.tile_m0; a.n_tiles = w.n_tiles; a.max_mtiles = w.max_mtiles;
+      MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
+      a = g256_hilo(w.y2, I, P * I, m->w_down[l] - (int64_t)e0 * H * I, I, nullptr, w.yg, H, M, H, I);
+      a.g_off = w.off; a.g_cnt = w.cnt; a.w_gstride = (int64_t)H * I; a.n_groups = E;
+      a.tile_g = w.tile_g; a.tile_m0 = w.tile_m0; a.n_tiles = w.n_tiles; a.max_mtiles = w.max_mtiles;
+      MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
+      // this rank's slice of the shared expert (column-parallel gate/up, row-parallel down)  (:599-606)
+      int nzs = 0;
+      if (SI) {
+        a = g256_hilo(w.yh, H, (int64_t)M * H, tp->ws_gate_up[l], H, nullptr, tw.ysh, SI, M, SI, H);
+        a.w_pair_rows = SI; a.c_lo_off = (int64_t)M * SI;
+        MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
+        a = g256_hilo(tw.ysh, SI, (int64_t)M * SI, tp->ws_down[l], SI, nullptr, psh, H, M, H, SI);
+        a.c_zstride = (int64_t)M * H;
+        nzs = mn_gemm256_ex(&a, MN_G256_F32, tw.ks_sh3, stream);
+        if (nzs < 0) return nzs;
+      }
+      TpPush p;                                     // all-reduce 2: local experts' weighted sum + shared slice
+      memset(&p, 0, sizeof(p));
+      if (SI) { p.P = psh; p.nz = nzs; p.slab = (int64_t)M * H; }
+      p.cy = w.yg; p.cpos = w.slot_of; p.cw = w.tw; p.ci = w.ti; p.n_slot = n_slot; p.e0 = e0; p.e1 = e1;
+      tp_push(comm, ep + 1, p, M, H, st);
+    }
+    ++seg; ++ep;
+  }
+  if (seg_end == n_seg) comm->epoch += 2u * (uint32_t)m->n_layers;
+  MN_CHECK_LAUNCH("mn_llm_step_tp");
+  return MN_OK;
+}
+
+// ===========================================================================================
+// Rectified-flow head, tensor parallel over the SwiGLU hidden width
+// ===========================================================================================
+extern "C" int mn_rf_tp_segments(const mn_rf_head* h) { return h->steps * h->depth + 1; }
+
+extern "C" size_t mn_rf_tp_workspace_bytes(const mn_rf_head* h, int rows) {
+  RfWideWs w;
+  return rf_wide_carve(h, rows, nullptr, 0, &w);
+}
+
+// h: the rank's shard — hidden = its share of the SwiGLU width (w12 [2 * hidden, w] gate rows then up rows, b12 [2 * hidden],
+// w3 [w, hidden]); b3 and every other tensor are the full (replicated) ones.  Same arguments as mn_rf_sample otherwise.
+extern "C" int mn_rf_sample_tp(const mn_rf_head* h, mn_tp_comm* comm, const float* hidden, int64_t ld_hidden, int rows, int n_images,
+                               const float* noise, float temperature, float text_cfg, float image_cfg, float* latent_out,
+                               void* workspace, size_t workspace_bytes, int seg_begin, int seg_end, void* stream) {
+  MN_CHECK_ARG(h && comm && hidden && noise && latent_out && workspace && rows >= 1 && n_images >= 1 && rows % n_images == 0,
+               "mn_rf_sample_tp: bad args");
+  MN_CHECK_ARG(rows <= 2048 && wide_glue_ok(h->w) && wide_glue_ok(h->z_dim) && wide_glue_ok(h->llm_hidden) && (h->w % 64) == 0 &&
+                   (h->hidden % 64) == 0 && (h->z_dim % 64) == 0 && (h->llm_hidden % 64) == 0 && h->target <= 64 && (h->target % 4) == 0 &&
+                   tp_comm_ok(comm, rows, h->w), "mn_rf_sample_tp: unsupported widths / communicator");
+  const int n_seg = h->steps * h->depth + 1;
+  MN_CHECK_ARG(seg_begin >= 0 && seg_begin < seg_end && seg_end <= n_seg, "mn_rf_sample_tp: segments [%d, %d) of %d", seg_begin, seg_end, n_seg);
+  RfWideWs w;
+  const size_t need = rf_wide_carve(h, rows, workspace, workspace_bytes, &w);
+  if (need > workspace_bytes) { mn_set_error("mn_rf_sample_tp: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
+  hipStream_t st = mn_stream(stream);
+  const int W = h->w, HID = h->hidden, T = h->target, A = h->depth * 3 * W + 2 * W, rpi = rows / n_images;
+  const int64_t SR = (int64_t)h->steps * rows;
+  const int64_t lo_a = (int64_t)rows * W, lo_b = (int64_t)rows * HID;
+  const float step = 1.0f / (float)h->steps;
+  int seg = 0;
+  uint32_t ep = comm->epoch;
+  auto on = [&]() { return seg >= seg_begin && seg < seg_end; };
+  WideGlue g;
+  mn_g256 a;
+  // block b of a step on this rank's hidden units: w12 (SwiGLU in the epilogue or split-K + slab SwiGLU) -> w3 slabs -> push
+  auto block_gemms = [&](int b) -> int {
+    if (w.ks12 > 1) {
+      a = g256_hilo(w.ya, W, lo_a, h->w12[b], W, nullptr, w.pbuf, 2 * HID, rows, 2 * HID, W);
+      a.c_zstride = (int64_t)rows * 2 * HID;
+      const int nz12 = mn_gemm256_ex(&a, MN_G256_F32, w.ks12, stream);
+      if (nz12 < 0) return nz12;
+      hipLaunchKernelGGL(rf_swiglu_slabs_kernel, dim3(mn_cdiv((int64_t)rows * (HID / 4), 256)), dim3(256), 0, st, w.pbuf, nz12,
+                         (int64_t)rows * 2 * HID, h->b12[b], w.yb, lo_b, rows, HID);
+    } else {
+      a = g256_hilo(w.ya, W, lo_a, h->w12[b], W, h->b12[b], w.yb, HID, rows, HID, W);
+      a.w_pair_rows = HID; a.c_lo_off = lo_b;
+      MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
+    }
+    a = g256_hilo(w.yb, HID, lo_b, h->w3[b], HID, nullptr, w.pbuf, W, rows, W, HID);
+    a.c_zstride = (int64_t)rows * W;
+    const int nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks3, stream);
+    if (nz < 0) return nz;
+    TpPush p;
+    memset(&p, 0, sizeof(p));
+    p.P = w.pbuf; p.nz = nz; p.slab = (int64_t)rows * W;
+    tp_push(comm, ep + 1, p, rows, W, st);
+    return 0;
+  };
+  if (on()) {
+    // replicated prologue: z = vis_head(hidden); c = cond_embed(LN(z)); adaLN of all Euler steps; x0 = noise * temperature
+    memset(&g, 0, sizeof(g));
+    g.h = hidden; g.ldh = ld_hidden; g.Y = w.hs; g.ldy = h->llm_hidden; g.y_lo_off = (int64_t)rows * h->llm_hidden;
+    g.M = rows; g.D = h->llm_hidden;
+    wide_glue(g, st);
+    a = g256_hilo(w.hs, h->llm_hidden, (int64_t)rows * h->llm_hidden, h->vis_w, h->llm_hidden, h->vis_b, w.z, h->z_dim, rows, h->z_dim,
+                  h->llm_hidden);
+    MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
+    memset(&g, 0, sizeof(g));
+    g.h = w.z; g.ldh = h->z_dim; g.norm = 2; g.ng = h->vis_ln_g; g.nb = h->vis_ln_b; g.eps = 1e-6f;
+    g.Y = w.zs; g.ldy = h->z_dim; g.y_lo_off = (int64_t)rows * h->z_dim; g.M = rows; g.D = h->z_dim;
+    wide_glue(g, st);
+    a = g256_hilo(w.zs, h->z_dim, (int64_t)rows * h->z_dim, h->cond_w, h->z_dim, h->cond_b, w.c, W, rows, W, h->z_dim);
+    MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
+    hipLaunchKernelGGL(rf_init_x_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, noise, temperature, w.x, rows, T, rpi);
+    hipLaunchKernelGGL(rf_build_y_kernel, dim3(mn_cdiv(SR * W, 256)), dim3(256), 0, st, h->temb, w.c, w.y, h->steps, rows, W);
+    a = g256_hilo(w.y, W, SR * W, h->ada_w, W, h->ada_b, w.ada, A, (int)SR, A, W);
+    MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
+  }
+  for (int s = 0; s < h->steps; ++s) {
+    const float* ada = w.ada + (int64_t)s * rows * A;
+    if (on()) {
+      // h = input_proj(x); ya = split(in_ln_0(h) * (1 + scale_0) + shift_0); then block 0 on this rank's hidden units
+      memset(&g, 0, sizeof(g));
+      g.xin = w.x; g.kin = T; g.win = h->in_w; g.bin = h->in_b; g.h_out = w.hh; g.ldho = W;
+      g.norm = 2; g.ng = h->ln_g[0]; g.nb = h->ln_b[0]; g.eps = 1e-6f; g.shift = ada; g.scale = ada + W; g.ldmod = A;
+      g.Y = w.ya; g.ldy = W; g.y_lo_off = lo_a; g.M = rows; g.D = W;
+      wide_glue(g, st);
+      MN_TRYZ(block_gemms(0));
+    }
+    ++seg; ++ep;
+    for (int b = 0; b < h->depth; ++b) {
+      const float* mod = ada + (int64_t)b * 3 * W;
+      const bool last = b + 1 == h->depth;
+      if (on()) {
+        // hh += gate * (all-reduced w3 partials + b3); next in_ln / final LN + modulate  (diff_loss:270-272, 290)
+        const float* nmod = last ? ada + (int64_t)h->depth * 3 * W : ada + (int64_t)(b + 1) * 3 * W;
+        memset(&g, 0, sizeof(g));
+        g.h = w.hh; g.ldh = W; tp_consume(g, comm, ep); g.pbias = h->b3[b];
+        g.gate = mod + 2 * W; g.ldgate = A; g.h_out = w.hh; g.ldho = W;
+        g.norm = 2; g.ng = last ? nullptr : h->ln_g[b + 1]; g.nb = last ? nullptr : h->ln_b[b + 1]; g.eps = 1e-6f;
+        g.shift = nmod; g.scale = nmod + W; g.ldmod = A;
+        g.Y = w.ya; g.ldy = W; g.y_lo_off = lo_a; g.M = rows; g.D = W;
+        wide_glue(g, st);
+        if (!last) {
+          MN_TRYZ(block_gemms(b + 1));
+        } else {
+          // replicated tail of the step: final Linear -> bias -> CFG combine + Euler step  (diff_loss:144-179, 291)
+          a = g256_hilo(w.ya, W, lo_a, h->fin_w, W, nullptr, w.pbuf, T, rows, T, W);
+          a.c_zstride = (int64_t)rows * T;
+          const int nz = mn_gemm256_ex(&a, MN_G256_F32, w.ksf, stream);
+          if (nz < 0) return nz;
+          hipLaunchKernelGGL(rf_glue_bias_out_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, w.pbuf, nz, rows, T, h->fin_b, w.v);
+          hipLaunchKernelGGL(rf_euler_kernel, dim3(n_images), dim3(256), 0, st, w.v, w.x, rpi, T, text_cfg, image_cfg, step);
+          if (s + 1 == h->steps)
+            hipLaunchKernelGGL(rf_gather_latent_kernel, dim3(mn_cdiv(n_images * T, 256)), dim3(256), 0, st, w.x, latent_out, n_images, rpi, T);
+        }
+      }
+      if (!last) { ++seg; ++ep; }
+    }
+  }
+  if (seg_end == n_seg) comm->epoch += (uint32_t)(h->steps * h->depth);
+  MN_CHECK_LAUNCH("mn_rf_sample_tp");
+  return MN_OK;
+}

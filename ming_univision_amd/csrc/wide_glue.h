@@ -27,6 +27,9 @@ struct WideGlue {
   float* out; int64_t ldo;                             // fp32 result, or NULL
   bf16_t* Y; int64_t ldy; int64_t y_lo_off;            // bf16 hi rows at Y, lo rows y_lo_off elements further (0: plain bf16, no lo rows), or NULL
   int M, D;
+  // ---- tensor-parallel all-reduce, consumer side (tp.inl): before reading P (= this rank's inbox: nz = world slabs, one per
+  // sender), row m waits until sender s's arrival flag wait_flags[s * wait_stride + m] reached wait_epoch (bounded spin).
+  const uint32_t* wait_flags; int wait_n; int64_t wait_stride; uint32_t wait_epoch; uint32_t* wait_err;
 };
 
 namespace {
@@ -38,6 +41,20 @@ __global__ __launch_bounds__(1024) void wide_glue_kernel(const WideGlue p) {
   typedef uint32_t u2 __attribute__((ext_vector_type(2)));
   const int m = blockIdx.x, col = threadIdx.x * 4, D = p.D;
   const bool act = col < D;
+  if (p.wait_flags) {                                    // uniform per launch
+    if ((int)threadIdx.x < p.wait_n) {
+      const uint32_t* f = p.wait_flags + (int64_t)threadIdx.x * p.wait_stride + m;
+      int spins = 0;
+      while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - p.wait_epoch) < 0) {
+        if (++spins > (1 << 24)) {                       // ~ seconds: a peer died or the launch orders diverged — fail loudly, never hang
+          if (p.wait_err) atomicExch(p.wait_err, 0x100u | (unsigned)threadIdx.x);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    __syncthreads();
+  }
   if (p.xin) {                                           // stage the row of the tiny-K projection
     if (threadIdx.x < p.kin) xs[threadIdx.x] = p.xin[(int64_t)m * p.kin + threadIdx.x];
     __syncthreads();
@@ -80,8 +97,9 @@ __global__ __launch_bounds__(1024) void wide_glue_kernel(const WideGlue p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int sj = s + j < p.n_slot ? s + j : s;
-          y[j] = *reinterpret_cast<const f4*>(p.cy + (int64_t)p.cpos[(int64_t)m * p.n_slot + sj] * D + col);
           wv[j] = s + j < p.n_slot ? p.cw[(int64_t)m * p.n_slot + sj] : 0.f;
+          y[j] = f4{0.f, 0.f, 0.f, 0.f};
+          if (wv[j] != 0.f) y[j] = *reinterpret_cast<const f4*>(p.cy + (int64_t)p.cpos[(int64_t)m * p.n_slot + sj] * D + col);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) v += wv[j] * y[j];

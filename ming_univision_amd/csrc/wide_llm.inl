@@ -10,11 +10,14 @@ extern "C" int mn_moe_sort_tiles(const int32_t* topk_idx, int T, int n_slot, int
 
 // Router tail for many rows: one wave per row sums the gate GEMM's split-K slabs, fp32 softmax, iterative arg-max top-k
 // (ties -> lowest expert), renormalise, append the shared pseudo-experts  (BailingMoeGate.forward :505-520).
-__global__ __launch_bounds__(256) void moe_topk_partials_kernel(const float* __restrict__ P, int nz, int64_t slab, int M, int E,
+// Rows flagged by image_mask take their logits from the image gate's slabs P_img (multi-gate blend, :565-592).
+__global__ __launch_bounds__(256) void moe_topk_partials_kernel(const float* __restrict__ P, const float* __restrict__ P_img,
+                                                                const uint8_t* __restrict__ image_mask, int nz, int64_t slab, int M, int E,
                                                                 int top_k, int norm_topk_prob, int n_shared,
                                                                 int32_t* __restrict__ topk_idx, float* __restrict__ topk_w) {
   const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
+  if (P_img && image_mask && image_mask[m]) P = P_img;      // wave-uniform
   float s = -INFINITY;
   if (lane < E) {
     s = 0.f;
@@ -69,7 +72,7 @@ static size_t llm_wide_carve(const mn_llm* m, int rows, int64_t t_max, void* ws,
   o->ks_gate = rf_wide_ksplit(rows, m->n_experts, H);
   size_t pmax = (size_t)mn_gemm256_slices(H, o->ks_qkv) * rows * qkv_dim;
   const size_t p2 = (size_t)mn_gemm256_slices(ad, o->ks_dense) * rows * H;
-  const size_t p3 = (size_t)mn_gemm256_slices(H, o->ks_gate) * rows * m->n_experts;
+  const size_t p3 = (size_t)2 * mn_gemm256_slices(H, o->ks_gate) * rows * m->n_experts;    // text gate slabs + image gate slabs
   if (p2 > pmax) pmax = p2;
   if (p3 > pmax) pmax = p3;
   o->h = cv.take<float>((size_t)rows * H);
@@ -94,7 +97,7 @@ static size_t llm_wide_carve(const mn_llm* m, int rows, int64_t t_max, void* ws,
   return cv.off;
 }
 
-static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int M, const int32_t* row_seq,
+static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int M, const uint8_t* image_mask, const int32_t* row_seq,
                          const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len, const uint8_t* key_mask,
                          int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max, float* hidden_out, void* workspace,
                          size_t workspace_bytes, void* stream) {
@@ -123,7 +126,7 @@ static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row
     if (fin) break;
     float* kv_l = kv_cache + (int64_t)l * layer_kv;
     // QKV (split-K slabs) -> RoPE + KV append reduce them  (:743-789)
-    mn_g256 a = g256_hilo(w.yh, H, (int64_t)M * H, m->wqkv[l], H, nullptr, w.pp, qkv_dim, M, qkv_dim, H);
+    mn_g256 a = g256_hilo(w.yh, H, lo_at(LO_LLM_QKV, (int64_t)M * H), m->wqkv[l], H, nullptr, w.pp, qkv_dim, M, qkv_dim, H);
     a.c_zstride = (int64_t)M * qkv_dim;
     int nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks_qkv, stream);
     if (nz < 0) return nz;
@@ -132,7 +135,7 @@ static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row
     // masked GQA against the cache; the combine writes the dense projection's hi/lo operand  (:791-812)
     MN_TRY(mn_attn_decode_split(w.q, M, nq, nkv, hd, kv_l, t_max, row_seq, row_len, key_mask, ld_mask, nullptr, w.ya, w.attn_ws,
                                 w.attn_ws_bytes, stream));
-    a = g256_hilo(w.ya, ad, (int64_t)M * ad, m->wdense[l], ad, nullptr, w.pp, H, M, H, ad);
+    a = g256_hilo(w.ya, ad, lo_at(LO_LLM_DENSE, (int64_t)M * ad), m->wdense[l], ad, nullptr, w.pp, H, M, H, ad);
     a.c_zstride = (int64_t)M * H;
     nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks_dense, stream);
     if (nz < 0) return nz;
@@ -142,20 +145,30 @@ static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row
     g.norm = 1; g.ng = m->ln2[l]; g.eps = m->rms_eps; g.Y = w.yh; g.ldy = H; g.y_lo_off = (int64_t)M * H; g.M = M; g.D = H;
     wide_glue(g, st);
     // router: gate logits (split-K slabs) -> softmax / top-k -> expert sort  (:505-520, 608-616)
-    a = g256_hilo(w.yh, H, (int64_t)M * H, m->gate[l], H, nullptr, w.pp, E, M, E, H);
+    a = g256_hilo(w.yh, H, lo_at(LO_LLM_GATE, (int64_t)M * H), m->gate[l], H, nullptr, w.pp, E, M, E, H);
     a.c_zstride = (int64_t)M * E;
     nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks_gate, stream);
     if (nz < 0) return nz;
-    hipLaunchKernelGGL(moe_topk_partials_kernel, dim3(mn_cdiv(M, 4)), dim3(256), 0, st, (const float*)w.pp, nz, (int64_t)M * E, M, E,
-                       m->top_k, m->norm_topk_prob, m->n_shared_slots, w.ti, w.tw);
-    MN_TRY(mn_moe_sort_tiles(w.ti, M, n_slot, G, w.cnt, w.off, w.perm, w.slot_of, 128, w.tile_g, w.tile_m0, w.n_tiles, stream));
+    const float* p_img = nullptr;
+    if (image_mask && m->image_gate && m->image_gate[l]) {      // image-gate logits of all rows, chosen per row by the mask (:565-592)
+      float* pi = w.pp + (int64_t)nz * M * E;
+      a = g256_hilo(w.yh, H, (int64_t)M * H, m->image_gate[l], H, nullptr, pi, E, M, E, H);
+      a.c_zstride = (int64_t)M * E;
+      const int nzi = mn_gemm256_ex(&a, MN_G256_F32, w.ks_gate, stream);
+      if (nzi < 0) return nzi;
+      p_img = pi;
+    }
+    hipLaunchKernelGGL(moe_topk_partials_kernel, dim3(mn_cdiv(M, 4)), dim3(256), 0, st, (const float*)w.pp, p_img, image_mask, nz,
+                       (int64_t)M * E, M, E, m->top_k, m->norm_topk_prob, m->n_shared_slots, w.ti, w.tw);
+    MN_TRY(mn_moe_sort_tiles(w.ti, M, n_slot, G, w.cnt, w.off, w.perm, w.slot_of, lo_at(LO_LLM_EXPERTS, 1) ? 128 : 256, w.tile_g, w.tile_m0,
+                             w.n_tiles, stream));
     // experts: grouped gate/up (rows gathered by perm, SwiGLU + split epilogue), grouped down -> yg [P, H]  (:617-628, 483-484)
-    a = g256_hilo(w.yh, H, (int64_t)M * H, m->w_gate_up[l], H, nullptr, w.y2, I, M, I, H);
+    a = g256_hilo(w.yh, H, lo_at(LO_LLM_EXPERTS, (int64_t)M * H), m->w_gate_up[l], H, nullptr, w.y2, I, M, I, H);
     a.w_pair_rows = I; a.c_lo_off = P * I;
     a.g_off = w.off; a.g_cnt = w.cnt; a.w_gstride = (int64_t)2 * I * H; a.a_rows = w.perm; a.n_groups = G;
     a.tile_g = w.tile_g; a.tile_m0 = w.tile_m0; a.n_tiles = w.n_tiles; a.max_mtiles = w.max_mtiles;
     MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
-    a = g256_hilo(w.y2, I, P * I, m->w_down[l], I, nullptr, w.yg, H, M, H, I);
+    a = g256_hilo(w.y2, I, lo_at(LO_LLM_EXPERTS, P * I), m->w_down[l], I, nullptr, w.yg, H, M, H, I);
     a.g_off = w.off; a.g_cnt = w.cnt; a.w_gstride = (int64_t)H * I; a.n_groups = G;
     a.tile_g = w.tile_g; a.tile_m0 = w.tile_m0; a.n_tiles = w.n_tiles; a.max_mtiles = w.max_mtiles;
     MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
@@ -227,7 +240,7 @@ static int semdec_step_wide(const mn_semdec* s, const float* latent_norm, int M,
   for (int l = 0; l < s->depth; ++l) {
     float* kv_l = kv_cache + (int64_t)l * layer_kv;
     // CausalBlock (layers/block.py:301-327): attention
-    mn_g256 a = g256_hilo(w.yd, D, loD, s->wqkv[l], D, s->bqkv[l], w.pp, 3 * D, M, 3 * D, D);
+    mn_g256 a = g256_hilo(w.yd, D, lo_at(LO_SEM_QKV, loD), s->wqkv[l], D, s->bqkv[l], w.pp, 3 * D, M, 3 * D, D);
     a.c_zstride = (int64_t)M * 3 * D;
     int nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks_qkv, stream);            // bias rides slice 0
     if (nz < 0) return nz;
@@ -235,7 +248,7 @@ static int semdec_step_wide(const mn_semdec* s, const float* latent_norm, int M,
                                     0, 0, 0.125f, w.q, kv_l, t_max, stream));
     MN_TRY(mn_attn_decode_split(w.q, M, nh, nh, 64, kv_l, t_max, row_seq, row_len, nullptr, 0, nullptr, w.ya, w.attn_ws,
                                 w.attn_ws_bytes, stream));
-    a = g256_hilo(w.ya, D, loD, s->wproj[l], D, s->bproj[l], w.pp, D, M, D, D);
+    a = g256_hilo(w.ya, D, lo_at(LO_SEM_PROJ, loD), s->wproj[l], D, s->bproj[l], w.pp, D, M, D, D);
     a.c_zstride = loD;
     nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks_proj, stream);
     if (nz < 0) return nz;
@@ -244,10 +257,10 @@ static int semdec_step_wide(const mn_semdec* s, const float* latent_norm, int M,
     g.norm = 2; g.ng = s->ln2_g[l]; g.nb = s->ln2_b[l]; g.eps = 1e-6f; g.Y = w.yd; g.ldy = D; g.y_lo_off = loD; g.M = M; g.D = D;
     wide_glue(g, st);
     // SwiGLU FFN on the zero-padded hidden width
-    a = g256_hilo(w.yd, D, loD, s->w12p[l], D, s->b12p[l], w.yb, HP, M, HP, D);
+    a = g256_hilo(w.yd, D, lo_at(LO_SEM_W12, loD), s->w12p[l], D, s->b12p[l], w.yb, HP, M, HP, D);
     a.w_pair_rows = HP; a.c_lo_off = (int64_t)M * HP;
     MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
-    a = g256_hilo(w.yb, HP, (int64_t)M * HP, s->w3p[l], HP, s->b3[l], w.pp, D, M, D, HP);
+    a = g256_hilo(w.yb, HP, lo_at(LO_SEM_W3, (int64_t)M * HP), s->w3p[l], HP, s->b3[l], w.pp, D, M, D, HP);
     a.c_zstride = loD;
     nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks_w3, stream);
     if (nz < 0) return nz;
@@ -263,13 +276,13 @@ static int semdec_step_wide(const mn_semdec* s, const float* latent_norm, int M,
   if (embed_out) {
     // linear_proj = Linear [GELU Linear]  (modeling_bailingmm.py:111-115)
     const int PD = s->proj_dim;
-    mn_g256 a = g256_hilo(w.ys, D, loD, s->proj_w[0], D, s->proj_b[0], s->proj_depth == 1 ? embed_out : w.p0, PD, M, PD, D);
+    mn_g256 a = g256_hilo(w.ys, D, lo_at(LO_SEM_LP, loD), s->proj_w[0], D, s->proj_b[0], s->proj_depth == 1 ? embed_out : w.p0, PD, M, PD, D);
     MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
     if (s->proj_depth == 2) {
       memset(&g, 0, sizeof(g));
       g.h = w.p0; g.ldh = PD; g.act = 1; g.Y = w.yp; g.ldy = PD; g.y_lo_off = (int64_t)M * PD; g.M = M; g.D = PD;
       wide_glue(g, st);
-      a = g256_hilo(w.yp, PD, (int64_t)M * PD, s->proj_w[1], PD, s->proj_b[1], embed_out, PD, M, PD, PD);
+      a = g256_hilo(w.yp, PD, lo_at(LO_SEM_LP, (int64_t)M * PD), s->proj_w[1], PD, s->proj_b[1], embed_out, PD, M, PD, PD);
       MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
     }
   }

@@ -20,6 +20,16 @@ extern "C" MN_DEV_API void mn_wide_tune(int llm_min_rows, int rf_min_rows, int s
 }
 #endif
 
+// Per-site single-pass switch (measurement only, DESIGN.md §2 "lo-pass map"): bit s set = the activation operand of site s enters
+// its GEMM as plain bf16 (hi rows only).  The product build has no way to set it; tools/exp/lo_map.py does through the dev library.
+enum { LO_RF_VIS = 0, LO_RF_COND, LO_RF_ADA, LO_RF_W12, LO_RF_W3, LO_RF_FIN, LO_LLM_QKV, LO_LLM_DENSE, LO_LLM_GATE, LO_LLM_EXPERTS,
+       LO_SEM_QKV, LO_SEM_PROJ, LO_SEM_W12, LO_SEM_W3, LO_SEM_LP };
+static unsigned g_lo_drop = 0;
+#ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_lo_drop_mask(unsigned mask) { g_lo_drop = mask; }
+#endif
+static inline int64_t lo_at(int site, int64_t off) { return ((g_lo_drop >> site) & 1u) ? 0 : off; }
+
 struct RfWideWs {
   float *z, *c, *ada, *hh, *v, *x, *pbuf;
   bf16_t *hs, *zs, *y, *ya, *yb;
@@ -134,20 +144,20 @@ static int rf_sample_wide(const mn_rf_head* h, const float* hidden, int64_t ld_h
   g.h = hidden; g.ldh = ld_hidden; g.Y = w.hs; g.ldy = h->llm_hidden; g.y_lo_off = (int64_t)rows * h->llm_hidden;
   g.M = rows; g.D = h->llm_hidden;
   wide_glue(g, st);
-  mn_g256 a = g256_hilo(w.hs, h->llm_hidden, (int64_t)rows * h->llm_hidden, h->vis_w, h->llm_hidden, h->vis_b, w.z, h->z_dim, rows,
+  mn_g256 a = g256_hilo(w.hs, h->llm_hidden, lo_at(LO_RF_VIS, (int64_t)rows * h->llm_hidden), h->vis_w, h->llm_hidden, h->vis_b, w.z, h->z_dim, rows,
                         h->z_dim, h->llm_hidden);
   MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
   memset(&g, 0, sizeof(g));
   g.h = w.z; g.ldh = h->z_dim; g.norm = 2; g.ng = h->vis_ln_g; g.nb = h->vis_ln_b; g.eps = 1e-6f;
   g.Y = w.zs; g.ldy = h->z_dim; g.y_lo_off = (int64_t)rows * h->z_dim; g.M = rows; g.D = h->z_dim;
   wide_glue(g, st);
-  a = g256_hilo(w.zs, h->z_dim, (int64_t)rows * h->z_dim, h->cond_w, h->z_dim, h->cond_b, w.c, W, rows, W, h->z_dim);
+  a = g256_hilo(w.zs, h->z_dim, lo_at(LO_RF_COND, (int64_t)rows * h->z_dim), h->cond_w, h->z_dim, h->cond_b, w.c, W, rows, W, h->z_dim);
   MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
 
   hipLaunchKernelGGL(rf_init_x_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, noise, temperature, w.x, rows, T, rpi);
   // modulations of every Euler step: [steps * rows, w] x [w, depth*3w + 2w], adaLN weights read once per token
   hipLaunchKernelGGL(rf_build_y_kernel, dim3(mn_cdiv(SR * W, 256)), dim3(256), 0, st, h->temb, w.c, w.y, h->steps, rows, W);
-  a = g256_hilo(w.y, W, SR * W, h->ada_w, W, h->ada_b, w.ada, A, (int)SR, A, W);
+  a = g256_hilo(w.y, W, lo_at(LO_RF_ADA, SR * W), h->ada_w, W, h->ada_b, w.ada, A, (int)SR, A, W);
   MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
 
   const float step = 1.0f / (float)h->steps;
@@ -163,18 +173,18 @@ static int rf_sample_wide(const mn_rf_head* h, const float* hidden, int64_t ld_h
     for (int b = 0; b < h->depth; ++b) {
       const float* mod = ada + (int64_t)b * 3 * W;
       if (w.ks12 > 1) {
-        a = g256_hilo(w.ya, W, lo_a, h->w12[b], W, nullptr, w.pbuf, 2 * HID, rows, 2 * HID, W);
+        a = g256_hilo(w.ya, W, lo_at(LO_RF_W12, lo_a), h->w12[b], W, nullptr, w.pbuf, 2 * HID, rows, 2 * HID, W);
         a.c_zstride = (int64_t)rows * 2 * HID;
         const int nz12 = mn_gemm256_ex(&a, MN_G256_F32, w.ks12, stream);
         if (nz12 < 0) return nz12;
         hipLaunchKernelGGL(rf_swiglu_slabs_kernel, dim3(mn_cdiv((int64_t)rows * (HID / 4), 256)), dim3(256), 0, st, w.pbuf, nz12,
                            (int64_t)rows * 2 * HID, h->b12[b], w.yb, lo_b, rows, HID);
       } else {
-        a = g256_hilo(w.ya, W, lo_a, h->w12[b], W, h->b12[b], w.yb, HID, rows, HID, W);
+        a = g256_hilo(w.ya, W, lo_at(LO_RF_W12, lo_a), h->w12[b], W, h->b12[b], w.yb, HID, rows, HID, W);
         a.w_pair_rows = HID; a.c_lo_off = lo_b;
         MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
       }
-      a = g256_hilo(w.yb, HID, lo_b, h->w3[b], HID, nullptr, w.pbuf, W, rows, W, HID);
+      a = g256_hilo(w.yb, HID, lo_at(LO_RF_W3, lo_b), h->w3[b], HID, nullptr, w.pbuf, W, rows, W, HID);
       a.c_zstride = (int64_t)rows * W;
       const int nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks3, stream);
       if (nz < 0) return nz;
@@ -188,7 +198,7 @@ static int rf_sample_wide(const mn_rf_head* h, const float* hidden, int64_t ld_h
       g.Y = w.ya; g.ldy = W; g.y_lo_off = lo_a; g.M = rows; g.D = W;
       wide_glue(g, st);
     }
-    a = g256_hilo(w.ya, W, lo_a, h->fin_w, W, nullptr, w.pbuf, T, rows, T, W);
+    a = g256_hilo(w.ya, W, lo_at(LO_RF_FIN, lo_a), h->fin_w, W, nullptr, w.pbuf, T, rows, T, W);
     a.c_zstride = (int64_t)rows * T;
     const int nz = mn_gemm256_ex(&a, MN_G256_F32, w.ksf, stream);
     if (nz < 0) return nz;

@@ -40,10 +40,16 @@ class SemDecodeState:
 class MingTok:
     config_class = MingTokConfig
 
-    def __init__(self, config: MingTokConfig, state_dict=None, device="cuda", seed=0, linear_proj=None):
+    def __init__(self, config: MingTokConfig, state_dict=None, device="cuda", seed=0, linear_proj=None, precision="bf16"):
         """state_dict: reference-named tensors (any float dtype; stored as bf16 in HBM); None -> synthetic.
         linear_proj: optional list of (weight, bias) bf16 CUDA tensors (modeling_bailingmm.py:111-115)
-        fused behind the decode step."""
+        fused behind the decode step.
+        precision: regime of the BATCHED passes (encode, semantic-decoder prefill, pixel decoder); every method takes an override.
+          "bf16" — bf16 activations on the MFMA, flash attention (the reference's own autocast precision: ~1e-2 of the fp32 result);
+          "fp32" — fp32-class: every Linear a gemm256 launch on bf16 hi/lo activation pairs (2^-17), attention on the fp32 decode
+                   kernels against a scratch K/V arena; matches the fp32 oracle to 1e-3 (what feeds the LLM in understanding / editing)."""
+        assert precision in ("bf16", "fp32")
+        self.precision = precision
         self.config = config
         enc, sem, pix = config.low_level_encoder, config.semantic_decoder, config.pixel_decoder
         self.latent_dim = enc.get("out_dim", 32)
@@ -147,18 +153,82 @@ class MingTok:
         self._pos_cache[key] = pe
         return pe
 
+    # ---- fp32-class ("precise") regime: hi/lo GEMMs + fp32 attention ----------------------------------------------
+    def _swiglu_padded(self, prefix):
+        """(w12p, b12p, w3p): the block's SwiGLU weights with the hidden width zero-padded to a multiple of 64 (whole K-tiles for
+        w3; the padded units are silu(0) * 0 against zero w3 columns) — load-time copies, cached."""
+        if prefix.startswith("semantic_decoder.blocks.0."):       # the cached-decode struct already holds these copies
+            self._semdec()
+            li = int(prefix.rsplit(".", 1)[1])
+            return self._sem_pad[0][li], self._sem_pad[1][li], self._sem_pad[2][li]
+        key = ("pad", prefix)
+        if key not in self._pos_cache:
+            w12, b12, w3 = self._w(prefix + ".mlp.w12.weight"), self._w(prefix + ".mlp.w12.bias"), self._w(prefix + ".mlp.w3.weight")
+            hid, D = w12.shape[0] // 2, w12.shape[1]
+            hp = (hid + 63) // 64 * 64
+            if hp == hid:
+                self._pos_cache[key] = (w12, b12, w3)
+            else:
+                a = torch.zeros(2 * hp, D, dtype=torch.bfloat16, device=self.device)
+                a[:hid], a[hp:hp + hid] = w12[:hid], w12[hid:]
+                bb = torch.zeros(2 * hp, dtype=torch.bfloat16, device=self.device)
+                bb[:hid], bb[hp:hp + hid] = b12[:hid], b12[hid:]
+                c = torch.zeros(w3.shape[0], hp, dtype=torch.bfloat16, device=self.device)
+                c[:, :hid] = w3
+                self._pos_cache[key] = (a, bb, c)
+        return self._pos_cache[key]
+
+    def _attention_fp32(self, qkv, B, T, nh, causal):
+        """softmax(q k^T / 8) v per (image, head) on the fp32 decode kernels: K / V go to a scratch arena [B, 2, nh, T, 64] (one
+        cache sequence per image), then every row attends keys [0, t] (causal) or [0, T) of its sequence.  qkv fp32 [B*T, 3*nh*64]
+        in the reshape of attention.py:83 -> fp32 [B*T, nh*64]."""
+        dev = self.device
+        key = ("attn", B, T, nh)
+        if key not in self._ws:
+            seq = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(T)
+            slot = torch.arange(T, dtype=torch.int32, device=dev).repeat(B)
+            self._ws[key] = (seq, slot, (slot + 1).contiguous(), torch.full((B * T,), T, dtype=torch.int32, device=dev),
+                             torch.empty(B, 2, nh, T, 64, dtype=torch.float32, device=dev))
+        seq, slot, len_causal, len_full, kv = self._ws[key]
+        q = ops.rope_kv_append(qkv, nh, nh, 64, kv, seq, slot, q_scale=0.125)
+        return ops.attn_decode(q, nh, nh, 64, kv, seq, len_causal if causal else len_full)
+
+    def _block_fp32(self, x, prefix, D, B, T, causal):
+        """Block.forward / CausalBlock.forward (layers/block.py:80-105, 301-327) on the fp32 residual x [B*T, D], fp32-class."""
+        nh = D // 64
+        xn, _ = ops.norm_act_split(x, "ln", self._w(prefix + ".norm1.weight"), self._w(prefix + ".norm1.bias"))
+        qkv = ops.linear_hilo(xn, self._w(prefix + ".attn.qkv.weight"), self._w(prefix + ".attn.qkv.bias"))
+        att = self._attention_fp32(qkv, B, T, nh, causal)
+        ops.linear_hilo(ops.split_hilo(att), self._w(prefix + ".attn.proj.weight"), self._w(prefix + ".attn.proj.bias"), out=x, resid=True)
+        xn, _ = ops.norm_act_split(x, "ln", self._w(prefix + ".norm2.weight"), self._w(prefix + ".norm2.bias"))
+        if (prefix + ".mlp.w12.weight") in self.sd:
+            w12, b12, w3 = self._swiglu_padded(prefix)
+            h = ops.gemm256_swiglu_split(xn, w12, b12)
+            ops.linear_hilo(h, w3, self._w(prefix + ".mlp.w3.bias"), out=x, resid=True)
+        else:
+            h = ops.linear_hilo(xn, self._w(prefix + ".mlp.fc1.weight"), self._w(prefix + ".mlp.fc1.bias"))
+            hs, _ = ops.norm_act_split(h, "none", gelu=True)
+            ops.linear_hilo(hs, self._w(prefix + ".mlp.fc2.weight"), self._w(prefix + ".mlp.fc2.bias"), out=x, resid=True)
+
+    def _blocks_fp32(self, x, stem, depth, D, B, T, causal):
+        for i in range(depth):
+            self._block_fp32(x, f"{stem}.{i}", D, B, T, causal)
+
     # ---- encoder ---------------------------------------------------------------------------
-    def encode(self, x):
+    def encode(self, x, precision=None):
         """low_level_encoder(x) -> RAW latent fp32 [B, N+1, latent_dim] (vision_transformer.py:225-233)."""
+        fp32 = (precision or self.precision) == "fp32"
         B, _, W, H = x.shape
         P, D = self.patch_size, self.enc_dim
         gh, gw = W // P, H // P
         N = gh * gw
         # im2col (view/permute only): conv k=s=P == GEMM over (c, ph, pw)  (patch_embed.py:76-78)
         cols = x.to(self.device, torch.float32).reshape(B, 3, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B * N, 3 * P * P)
-        cols = ops.f32_to_bf16(cols.contiguous())
         wpe = self._w("low_level_encoder.patch_embed.proj.weight").reshape(D, 3 * P * P)
-        tok = ops.gemm_bf16(cols, wpe, self._w("low_level_encoder.patch_embed.proj.bias"), "f32")
+        if fp32:
+            tok = ops.linear_hilo(ops.split_hilo(cols.contiguous()), wpe, self._w("low_level_encoder.patch_embed.proj.bias"))
+        else:
+            tok = ops.gemm_bf16(ops.f32_to_bf16(cols.contiguous()), wpe, self._w("low_level_encoder.patch_embed.proj.bias"), "f32")
         cls = ops.bf16_to_f32(self._w("low_level_encoder.cls_token").reshape(1, D))
         xt = torch.cat((tok.reshape(B, N, D), cls.reshape(1, 1, D).expand(B, 1, D)), dim=1).contiguous()  # cls LAST (:221)
         T = N + 1
@@ -166,55 +236,79 @@ class MingTok:
         xf = xt.reshape(B * T, D)
         check(lib().mn_add_bcast_f32(ptr(xf), ptr(pe), ptr(xf), xf.numel(), pe.numel(), current_stream()), "mn_add_bcast_f32")
         # blocks, then forward_out_layer (:173-178) whose LayerNorm + GELU rides the last block's tail
-        xn = self._blocks(xf, "low_level_encoder.blocks.0", self.enc_depth, D, B, T, False,
-                          (self._w("low_level_encoder.out_norm.weight"), self._w("low_level_encoder.out_norm.bias"), True))
-        y = ops.gemm_bf16(xn, self._w("low_level_encoder.out_proj.weight"), self._w("low_level_encoder.out_proj.bias"), "f32")
+        if fp32:
+            self._blocks_fp32(xf, "low_level_encoder.blocks.0", self.enc_depth, D, B, T, False)
+            xn, _ = ops.norm_act_split(xf, "ln", self._w("low_level_encoder.out_norm.weight"), self._w("low_level_encoder.out_norm.bias"), gelu=True)
+            y = ops.linear_hilo(xn, self._w("low_level_encoder.out_proj.weight"), self._w("low_level_encoder.out_proj.bias"))
+        else:
+            xn = self._blocks(xf, "low_level_encoder.blocks.0", self.enc_depth, D, B, T, False,
+                              (self._w("low_level_encoder.out_norm.weight"), self._w("low_level_encoder.out_norm.bias"), True))
+            y = ops.gemm_bf16(xn, self._w("low_level_encoder.out_proj.weight"), self._w("low_level_encoder.out_proj.bias"), "f32")
         out = torch.empty_like(y)
         check(lib().mn_group_mean_add(ptr(y), ptr(xf), ptr(out), B * T, D, self.latent_dim, current_stream()), "mn_group_mean_add")
         return out.reshape(B, T, self.latent_dim)
 
     # ---- semantic decoder, full causal pass -----------------------------------------------
-    def _semantic_decoder_full(self, latent_raw):
-        """forward_features without cache (vision_transformer.py:382-451): [B,T,in] RAW latent -> x_norm bf16->fp32 [B,T,D]."""
+    def _semantic_decoder_full(self, latent_raw, precision=None):
+        """forward_features without cache (vision_transformer.py:382-451): [B,T,in] RAW latent -> x_norm fp32 [B,T,D]
+        (rounded to bf16 in the bf16 regime, like the reference's autocast output)."""
+        fp32 = (precision or self.precision) == "fp32"
         B, T, Cin = latent_raw.shape
         D = self.feature_dim
         lat = latent_raw.reshape(B * T, Cin).contiguous()
-        y = ops.gemm_bf16(ops.f32_to_bf16(lat), self._w("semantic_decoder.in_proj.weight"),
-                          self._w("semantic_decoder.in_proj.bias"), "f32")
+        if fp32:
+            y = ops.linear_hilo(ops.split_hilo(lat), self._w("semantic_decoder.in_proj.weight"), self._w("semantic_decoder.in_proj.bias"))
+        else:
+            y = ops.gemm_bf16(ops.f32_to_bf16(lat), self._w("semantic_decoder.in_proj.weight"),
+                              self._w("semantic_decoder.in_proj.bias"), "f32")
         x = torch.empty_like(y)
         check(lib().mn_repeat_add(ptr(y), ptr(lat), ptr(x), B * T, D, Cin, 1.0, 0.0, current_stream()), "mn_repeat_add")
+        if fp32:
+            self._blocks_fp32(x, "semantic_decoder.blocks.0", self.sem_depth, D, B, T, True)
+            _, out = ops.norm_act_split(x, "ln", self._w("semantic_decoder.norm.weight"), self._w("semantic_decoder.norm.bias"),
+                                        want_split=False, want_f32=True)
+            return out.reshape(B, T, D)
         xn = self._blocks(x, "semantic_decoder.blocks.0", self.sem_depth, D, B, T, True,
                           (self._w("semantic_decoder.norm.weight"), self._w("semantic_decoder.norm.bias"), False))
         return ops.bf16_to_f32(xn).reshape(B, T, D)
 
-    def forward(self, x):
+    def forward(self, x, precision=None):
         """MingTok.forward (modeling_mingtok.py:156-163)."""
-        latent = self.encode(x)
-        x_norm = self._semantic_decoder_full(latent)
+        latent = self.encode(x, precision)
+        x_norm = self._semantic_decoder_full(latent, precision)
         return {"x_norm_patchtokens": x_norm[:, :-1], "latent": (latent - self.mean) / self.scaling_factor}
 
     __call__ = forward
 
-    def forward_feature_decoder_wo_cache(self, hidden_states):
+    def forward_feature_decoder_wo_cache(self, hidden_states, precision=None):
         """(modeling_mingtok.py:176-177): RAW latent in, dict out."""
-        x_norm = self._semantic_decoder_full(hidden_states.to(self.device, torch.float32))
+        x_norm = self._semantic_decoder_full(hidden_states.to(self.device, torch.float32), precision)
         return {"x_norm_patchtokens": x_norm[:, :-1] if x_norm.shape[1] > 1 else x_norm, "x_norm": x_norm}
 
     # ---- pixel decoder ----------------------------------------------------------------------
-    def forward_pixel_decoder(self, sem):
+    def forward_pixel_decoder(self, sem, precision=None):
         """MingTok.forward_pixel_decoder (modeling_mingtok.py:179-196): sem [B,N,Dsem] -> image [B,3,R,R] fp32 in [-1,1]."""
+        fp32 = (precision or self.precision) == "fp32"
         B, N, Ds = sem.shape
         r = self.sem_patch // self.pix_patch
         Dp = self.pix_dim
-        s = ops.f32_to_bf16(sem.to(self.device, torch.float32).reshape(B * N, Ds).contiguous())
-        y = ops.gemm_bf16(s, self._w("sem_to_pix.weight"), self._w("sem_to_pix.bias"), "f32")
+        s32 = sem.to(self.device, torch.float32).reshape(B * N, Ds).contiguous()
+        if fp32:
+            y = ops.linear_hilo(ops.split_hilo(s32), self._w("sem_to_pix.weight"), self._w("sem_to_pix.bias"))
+        else:
+            y = ops.gemm_bf16(ops.f32_to_bf16(s32), self._w("sem_to_pix.weight"), self._w("sem_to_pix.bias"), "f32")
         h = w = int(math.sqrt(N))
         # rearrange "b (h w) (x y c) -> b (h x w y) c" (view/permute only)
         x = y.reshape(B, h, w, r, r, Dp).permute(0, 1, 3, 2, 4, 5).reshape(B * h * r * w * r, Dp).contiguous()
         T = N * r * r
-        xn = self._blocks(x, "pixel_decoder.blocks.0", self.pix_depth, Dp, B, T, False,
-                          (self._w("pixel_decoder.norm.weight"), self._w("pixel_decoder.norm.bias"), False))
-        o = ops.gemm_bf16(xn, self._w("pixel_decoder.head.weight"), self._w("pixel_decoder.head.bias"), "f32")
+        if fp32:
+            self._blocks_fp32(x, "pixel_decoder.blocks.0", self.pix_depth, Dp, B, T, False)
+            xn, _ = ops.norm_act_split(x, "ln", self._w("pixel_decoder.norm.weight"), self._w("pixel_decoder.norm.bias"))
+            o = ops.linear_hilo(xn, self._w("pixel_decoder.head.weight"), self._w("pixel_decoder.head.bias"))
+        else:
+            xn = self._blocks(x, "pixel_decoder.blocks.0", self.pix_depth, Dp, B, T, False,
+                              (self._w("pixel_decoder.norm.weight"), self._w("pixel_decoder.norm.bias"), False))
+            o = ops.gemm_bf16(xn, self._w("pixel_decoder.head.weight"), self._w("pixel_decoder.head.bias"), "f32")
         p = self.pix_patch
         hh = ww = int(math.sqrt(T))
         # unpatchify (vision_transformer.py:515-527): 'nhwpqc->nchpwq' (view/permute only)
@@ -222,9 +316,9 @@ class MingTok:
         check(lib().mn_clamp_f32(ptr(img), img.numel(), -1.0, 1.0, current_stream()), "mn_clamp_f32")
         return img
 
-    def forward_enc_dec(self, x):
+    def forward_enc_dec(self, x, precision=None):
         """MingTok.forward_enc_dec (modeling_mingtok.py:150-153)."""
-        return self.forward_pixel_decoder(self.forward(x)["x_norm_patchtokens"])
+        return self.forward_pixel_decoder(self.forward(x, precision)["x_norm_patchtokens"], precision)
 
     # ---- cached decode -----------------------------------------------------------------------
     def _semdec(self):

@@ -67,7 +67,12 @@ class MingUniVisionForConditionalGeneration:
             rf_sd = {k: v for k, v in llm_sd.items() if k.startswith("vis_head") or k.startswith("diffloss")}
         self.rf = RectifiedFlowHead(rf_sd, cfg.hidden_size, config.vishead_diffloss_config, self.vision.latent_dim)
         self.tokenizer = None
-        self.mfma_prefill_threshold = 64   # prompts longer than this prefill on the MFMA path
+        self.mfma_prefill_threshold = 64   # prompts longer than this prefill as GEMMs (prefill_wide / prefill_mfma)
+        # Numerics of what feeds the LLM in understanding / editing (MingTok encode + linear_proj, long-prompt prefill):
+        #   "fp32" (default): fp32-class — hi/lo GEMMs, fp32 attention; within 1e-3 of the fp32 reference path (north_star);
+        #   "bf16": bf16 activations like the reference's own torch.autocast path (modeling_bailingmm.py:132, 243): ~2x faster
+        #           prefill, ~1e-2 of the fp32 result (DESIGN.md §2 has both measured).
+        self.understanding_precision = "fp32"
         self.decode_chunk = 8              # greedy text tokens per host round trip
         self.noise_generator = torch.Generator(device=self.device)
         self.noise_generator.manual_seed(seed)
@@ -82,11 +87,18 @@ class MingUniVisionForConditionalGeneration:
         self.past_uncond_attention_mask = None
 
     # ---- vision ----------------------------------------------------------------------------------
-    def extract_image_feature(self, pixel_values, grid_thw=None):
+    def extract_image_feature(self, pixel_values, grid_thw=None, precision=None):
         """MingTok.forward -> x_norm_patchtokens -> linear_proj (modeling_bailingmm.py:131-138) -> [B*N, H] fp32."""
-        feat = self.vision.forward(pixel_values)["x_norm_patchtokens"]
-        x = ops.f32_to_bf16(feat.reshape(-1, feat.shape[-1]).contiguous())
+        precision = precision or self.understanding_precision
+        feat = self.vision.forward(pixel_values, precision=precision)["x_norm_patchtokens"]
+        x32 = feat.reshape(-1, feat.shape[-1]).contiguous()
         n = len(self.linear_proj)
+        if precision == "fp32":
+            for i, (w, b) in enumerate(self.linear_proj):               # Linear [GELU Linear]* on hi/lo operands
+                a2, _ = ops.norm_act_split(x32, "none", gelu=i > 0)
+                x32 = ops.linear_hilo(a2, w, b)
+            return x32
+        x = ops.f32_to_bf16(x32)
         for i, (w, b) in enumerate(self.linear_proj):
             last = i == n - 1
             x = ops.gemm_bf16(x, w, b, "f32" if last else "bf16_gelu")
@@ -237,9 +249,14 @@ class MingUniVisionForConditionalGeneration:
                 for j, b in enumerate(chunk):
                     embeds[b], m = self.prompt_wrap_vision(ids_l[b], embeds[b], feats[j])
                     masks[b] = m.reshape(-1)
-        # prompts: long ones on the bf16 MFMA path, stacked up to 8192 tokens per pass; short ones through the decode kernels
+        # prompts, fp32-class (default): all of them in shared passes of <= max_rows() rows through the stack (decode-path numerics)
+        # bf16 regime: long ones on the bf16 MFMA path, stacked up to 8192 tokens per pass; short ones through the decode kernels
         last = [None] * B
         long_ = [b for b in range(B) if lens[b] > self.mfma_prefill_threshold and cfg.head_dim == 128]
+        if self.understanding_precision == "fp32" and self.model.max_rows() > 64:
+            hs = self.model.prefill_ragged(embeds, [s0 + b for b in range(B)], past=0, image_masks=masks)
+            last = [hs[b:b + 1] for b in range(B)]
+            long_ = []
         c0 = 0
         while c0 < len(long_):
             c1, tot = c0, 0
@@ -319,8 +336,11 @@ class MingUniVisionForConditionalGeneration:
         if past + T > self.model.t_max:
             raise ValueError(f"{past} cached + {T} prompt tokens exceed the KV arena (t_max = {self.model.t_max}); "
                              "call reset_inner_state() or build the model with a larger t_max")
-        if T > self.mfma_prefill_threshold and self.config.llm_config.head_dim == 128:
-            # long prompts (image understanding: 256-1024 image tokens): bf16 MFMA prefill with grouped-GEMM MoE
+        if T > self.mfma_prefill_threshold and self.understanding_precision == "fp32" and self.model.max_rows() > 64:
+            # long prompts (image understanding: 256-1024 image tokens), fp32-class: the decode path's numerics at MFMA rate
+            hidden = self.model.prefill_wide(embeds, seq=0, past=past, image_mask=image_mask)[-1:]
+        elif T > self.mfma_prefill_threshold and self.config.llm_config.head_dim == 128:
+            # bf16 activations (the reference's autocast precision): bf16 MFMA prefill with grouped-GEMM MoE, flash attention
             hidden = self.model.prefill_mfma(embeds, seq=0, past=past, image_mask=image_mask)
         else:
             hidden = self.model.prefill(embeds, seq=0, past=past, image_mask=image_mask)[-1:]
@@ -339,9 +359,12 @@ class MingUniVisionForConditionalGeneration:
             # every token of a chunk is fed (cache slot + rotary position cache_len + j) before the host looks at it: the
             # chunk must end inside the arena, also when the conversation stops a few slots short of t_max
             room = self.model.t_max - cache_len
-            if room <= 0:
-                raise ValueError(f"the conversation filled the KV arena (t_max = {self.model.t_max}) after {len(new_ids)} new tokens")
-            n = min(self.decode_chunk, max_new_tokens - len(new_ids), room)
+            remaining = max_new_tokens - len(new_ids)
+            n = min(self.decode_chunk, remaining)
+            if (n if n < remaining else n - 1) > room:                   # tokens this chunk feeds (the call's last token is not fed)
+                if room <= 0:
+                    raise ValueError(f"the conversation filled the KV arena (t_max = {self.model.t_max}) after {len(new_ids)} new tokens")
+                n = room
             slot = torch.tensor([cache_len], dtype=torch.int32, device=dev)
             ln = slot + 1
             toks_dev = []

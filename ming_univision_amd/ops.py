@@ -166,6 +166,42 @@ def split_hilo(x):
     return y
 
 
+NORM = dict(none=0, rms=1, ln=2)
+
+
+def norm_act_split(x, norm="none", g=None, b=None, eps=1e-6, gelu=False, want_split=True, want_f32=False):
+    """fp32 [M, D] -> act(norm(x)) as the bf16 hi/lo pair [2, M, D] of a hi/lo GEMM and / or as fp32 [M, D].
+    Returns (pair | None, f32 | None)."""
+    _req(x, torch.float32, "x"); _req(g, torch.bfloat16, "g"); _req(b, torch.bfloat16, "b")
+    M, D = x.shape
+    assert x.stride(1) == 1
+    y = torch.empty(2, M, D, dtype=torch.bfloat16, device=x.device) if want_split else None
+    o = torch.empty(M, D, dtype=torch.float32, device=x.device) if want_f32 else None
+    check(lib().mn_norm_act_split(ptr(x), x.stride(0), NORM[norm], ptr(g), ptr(b), eps, int(gelu), ptr(y), D,
+                                  0 if y is None else y.stride(0), ptr(o), D, M, D, current_stream()), "mn_norm_act_split")
+    return y, o
+
+
+def linear_hilo(a2, w, bias=None, out=None, resid=False):
+    """fp32-class Linear on the bf16 MFMA: a2 bf16 [2, M, K] hi/lo pair, w bf16 [N, K] -> fp32 [M, N] (resid: out += ...).
+    gemm256 when the shape allows (K % 64 == 0, N % 4 == 0), else the 128-tile hi/lo kernel (any K % 8 == 0; no resid form)."""
+    _req(a2, torch.bfloat16, "a2"); _req(w, torch.bfloat16, "w"); _req(bias, torch.bfloat16, "bias")
+    _, M, K = a2.shape
+    N = w.shape[0]
+    assert a2.is_contiguous() and w.shape[1] == K and w.stride(1) == 1
+    if out is None:
+        assert not resid
+        out = torch.empty(M, N, dtype=torch.float32, device=a2.device)
+    _req(out, torch.float32, "out")
+    if lib().mn_gemm256_supported(K, a2.stride(0), w.stride(0), N, M, N, K) and out.stride(0) % 4 == 0:
+        return gemm256(a2, w, bias, "f32_resid" if resid else "f32", out=out)
+    if resid:
+        raise RuntimeError(f"linear_hilo: residual form needs K % 64 == 0 and N % 4 == 0 (K={K}, N={N})")
+    check(lib().mn_gemm_bf16_hilo(ptr(a2[0]), K, a2.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(out), out.stride(0), M, N, K,
+                                  current_stream()), "mn_gemm_bf16_hilo")
+    return out
+
+
 def gemm256(a, w, bias=None, epilogue="bf16", out=None):
     """Wide-row GEMM (256 x 256 tiles).  a: bf16 [M, K], or a hi/lo pair bf16 [2, M, K] (fp32-class products).
     w bf16 [N, K] -> bf16 or fp32 [M, N] (f32_resid accumulates into `out`)."""
