@@ -454,6 +454,94 @@ MN_API int mn_semdec_step(const mn_semdec* s, const float* latent_norm, int M,
                    float* kv_cache, int n_seq, int64_t t_max, float* sem_out, float* embed_out,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * 6. Tensor / expert parallelism of the decode path over one xGMI node (BASELINE configs[4]; SURVEY.md §8e — no reference
+ *    counterpart: the reference runs the model on one device).  One process per GPU; every rank calls the same composites on its
+ *    SHARD with the same arguments.  Partitioning, the one-shot all-reduce and the segment mechanism: csrc/tp.inl, DESIGN.md §7.
+ * ------------------------------------------------------------------------------------------ */
+#define MN_TP_MAX_WORLD 16
+
+/* Communicator: every rank owns an inbox fp32 [2 (epoch parity)][world (sender)][cap] and arrival flags uint32
+ * [world (sender)][rows_cap] in fine-grained device memory (mn_tp_alloc), mapped on every other rank (mn_tp_ipc_*).  inbox[p] /
+ * flags[p] are the DEVICE addresses of rank p's arrays as seen from THIS rank (host arrays of `world` pointers).  epoch counts the
+ * all-reduces completed on the communicator; it is advanced by the calls below, identically on every rank.  err: a local device
+ * word that a bounded flag wait sets non-zero when it gives up (a dead peer / diverged launch order never hangs the GPU). */
+typedef struct mn_tp_comm {
+  int32_t rank, world;
+  float* const* inbox;
+  uint32_t* const* flags;
+  int64_t cap;          /* floats per (parity, sender) slab: >= rows * widest reduced row (3072 for the 16B-A3B RF head) */
+  int32_t rows_cap;
+  uint32_t epoch;
+  uint32_t* err;
+} mn_tp_comm;
+
+/* Host-side setup (these DO allocate / map; they are not launchers): fine-grained (uncached, system-coherent) device memory, its
+ * IPC handle (64 bytes) for the other ranks, and the mapping of a peer's handle.  bytes for one rank's inbox = 2 * world * cap * 4,
+ * flags = world * rows_cap * 4 (zero-filled by the caller). */
+MN_API int mn_tp_alloc(size_t bytes, void** dptr);
+MN_API int mn_tp_free(void* dptr);
+MN_API int mn_tp_ipc_handle(void* dptr, void* handle_out_64);
+MN_API int mn_tp_ipc_open(const void* handle_64, void** dptr);
+MN_API int mn_tp_ipc_close(void* dptr);
+
+/* out[m] = sum over the ranks of x[m]: x fp32 [M, D] (ldx == D) is this rank's partial, out fp32 [M, D] (ldo).  One-shot: the rank
+ * pushes its rows into every rank's inbox over xGMI and sets their arrival flags; the reduce kernel waits on its LOCAL flags only.
+ * 64 <= D <= 4096, D % 4 == 0, M <= rows_cap, M * D <= cap.  (latency-bound 4-18 KB payloads.) */
+enum { MN_TP_PUSH = 1, MN_TP_REDUCE = 2 };   /* phase bits: both = the whole all-reduce in one call; split = work between them */
+MN_API int mn_allreduce_oneshot(mn_tp_comm* comm, const float* x, int64_t ldx, float* out, int64_t ldo, int M, int D, int phase,
+                                void* stream);
+
+/* Expert parallelism, replicate-and-reduce: every rank holds all rows and the global routing (topk_idx [T, n_slot]
+ * GLOBAL expert ids).  dispatch = moe_infer's count / argsort bookkeeping (modeling_bailing_moe.py:608-616) restricted to the experts
+ * [expert0, expert0 + n_local) this rank owns: mn_moe_sort_tiles' outputs, the row-tile list only for those experts.
+ * combine = the weighted un-permute (:630-639) across ranks: part[m] = sum over the LOCAL picks of topk_w * yg[slot_of] (+ optional
+ * slabs P: the rank's slice of the shared expert), all-reduced; out[m] = h[m] + sum over ranks. */
+MN_API int mn_ep_dispatch(const int32_t* topk_idx, int T, int n_slot, int n_experts, int expert0, int n_local, int32_t* counts,
+                          int32_t* offsets, int32_t* perm, int32_t* slot_of, int tile_rows, int32_t* tile_g, int32_t* tile_m0,
+                          int32_t* n_tiles, void* stream);
+MN_API int mn_ep_combine(mn_tp_comm* comm, const float* yg, const int32_t* slot_of, const int32_t* topk_idx, const float* topk_w,
+                         int n_slot, int expert0, int n_local, const float* P, int nz, int64_t slab, const float* h, int64_t ldh,
+                         float* out, int64_t ldo, int M, int D, void* stream);
+
+/* Decoder-stack step on a shard.  m describes the rank's shard as an mn_llm: n_q / n_kv = its local head counts, wqkv[l] =
+ * [(n_q + 2 n_kv) * hd, H] (its q heads, then its K, then its V rows), wdense[l] = [H, n_q * hd] (its columns), n_experts = the
+ * GLOBAL expert count with gate / image_gate replicated, n_shared_slots = 0, w_gate_up[l] / w_down[l] = its n_local_experts routed
+ * experts; the KV arena holds its KV heads only.  tp adds the expert window and the rank's slice of the shared expert
+ * (gate rows then up rows of shared_inter units, zero-padded to a multiple of 64; 0 = none).
+ * Segments (mn_llm_tp_segments = 2 * n_layers + 1): [seg_begin, seg_end) selects the launch ranges between all-reduces; a rank
+ * in production passes (0, n_segments).  Rows 1..2048; workspace mn_llm_tp_workspace_bytes.  Other arguments as mn_llm_step. */
+typedef struct mn_llm_tp {
+  int32_t expert0, n_local_experts;
+  int32_t shared_inter;
+  const uint16_t* const* ws_gate_up;   /* [L] [2 * shared_inter, H] */
+  const uint16_t* const* ws_down;      /* [L] [H, shared_inter] */
+} mn_llm_tp;
+MN_API size_t mn_llm_tp_workspace_bytes(const mn_llm* m, const mn_llm_tp* tp, int rows, int64_t t_max);
+MN_API int mn_llm_tp_segments(const mn_llm* m);
+MN_API int mn_llm_step_tp(const mn_llm* m, const mn_llm_tp* tp, mn_tp_comm* comm, const float* x, int64_t ldx, int x_row_div, int M,
+                          const uint8_t* image_mask, const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_pos,
+                          const int32_t* row_len, const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
+                          float* hidden_out, void* workspace, size_t workspace_bytes, int seg_begin, int seg_end, void* stream);
+
+/* RectifiedFlowLoss.sample on a shard: h->hidden = the rank's share of the SwiGLU width, w12[b] = [2 * hidden, w] (its gate rows,
+ * then its up rows), b12[b] likewise, w3[b] = [w, hidden] (its columns); b3 and all other tensors are the full replicated ones.
+ * One all-reduce per ResBlock per Euler step; segments = steps * depth + 1.  Other arguments as mn_rf_sample; rows 1..2048. */
+MN_API size_t mn_rf_tp_workspace_bytes(const mn_rf_head* h, int rows);
+MN_API int mn_rf_tp_segments(const mn_rf_head* h);
+MN_API int mn_rf_sample_tp(const mn_rf_head* h, mn_tp_comm* comm, const float* hidden, int64_t ld_hidden, int rows, int n_images,
+                           const float* noise, float temperature, float text_cfg, float image_cfg, float* latent_out,
+                           void* workspace, size_t workspace_bytes, int seg_begin, int seg_end, void* stream);
+
+/* lm_head + greedy pick (compute_logit, modeling_bailing_moe.py:1604-1620, + the argmax of greedy decoding):
+ * idx[m] = vocab_offset + argmax_v hidden[m] . W[v] (ties -> lowest index, torch.argmax's rule), val[m] = that logit (optional).
+ * W bf16 [V, H]: the whole lm_head, or a rank's vocabulary slice starting at vocab_offset.  The fp32 logits [M, V] are left in the
+ * first bytes of the workspace (mn_lmhead_argmax_workspace_bytes). */
+MN_API size_t mn_lmhead_argmax_workspace_bytes(int M, int V, int H);
+MN_API int mn_lmhead_argmax(const float* hidden, int64_t ld_hidden, int M, const uint16_t* W, int64_t ldw, int V, int H,
+                            int64_t vocab_offset, int64_t* idx, float* val, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,22 @@ class SemDec(C.Structure):
     ]
 
 
+class TpComm(C.Structure):
+    _fields_ = [
+        ("rank", C.c_int32), ("world", C.c_int32),
+        ("inbox", PP), ("flags", PP),
+        ("cap", C.c_int64), ("rows_cap", C.c_int32), ("epoch", C.c_uint32),
+        ("err", C.c_void_p),
+    ]
+
+
+class LlmTp(C.Structure):
+    _fields_ = [
+        ("expert0", C.c_int32), ("n_local_experts", C.c_int32), ("shared_inter", C.c_int32),
+        ("ws_gate_up", PP), ("ws_down", PP),
+    ]
+
+
 _lib = None
 
 # every symbol include/mingnative.h declares: (name, restype, argtypes)
@@ -146,6 +162,23 @@ SYMBOLS = {
     "mn_group_mean_add": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "mn_repeat_add": (_i, [_p, _p, _p, _i, _i, _i, _f, _f, _p]),
     "mn_clamp_f32": (_i, [_p, _i64, _f, _f, _p]),
+    "mn_tp_alloc": (_i, [_sz, C.POINTER(C.c_void_p)]),
+    "mn_tp_free": (_i, [_p]),
+    "mn_tp_ipc_handle": (_i, [_p, _p]),
+    "mn_tp_ipc_open": (_i, [_p, C.POINTER(C.c_void_p)]),
+    "mn_tp_ipc_close": (_i, [_p]),
+    "mn_allreduce_oneshot": (_i, [C.POINTER(TpComm), _p, _i64, _p, _i64, _i, _i, _i, _p]),
+    "mn_ep_dispatch": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
+    "mn_ep_combine": (_i, [C.POINTER(TpComm), _p, _p, _p, _p, _i, _i, _i, _p, _i, _i64, _p, _i64, _p, _i64, _i, _i, _p]),
+    "mn_llm_tp_workspace_bytes": (_sz, [C.POINTER(Llm), C.POINTER(LlmTp), _i, _i64]),
+    "mn_llm_tp_segments": (_i, [C.POINTER(Llm)]),
+    "mn_llm_step_tp": (_i, [C.POINTER(Llm), C.POINTER(LlmTp), C.POINTER(TpComm), _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _i,
+                            _i64, _p, _p, _sz, _i, _i, _p]),
+    "mn_rf_tp_workspace_bytes": (_sz, [C.POINTER(RfHead), _i]),
+    "mn_rf_tp_segments": (_i, [C.POINTER(RfHead)]),
+    "mn_rf_sample_tp": (_i, [C.POINTER(RfHead), C.POINTER(TpComm), _p, _i64, _i, _i, _p, _f, _f, _f, _p, _p, _sz, _i, _i, _p]),
+    "mn_lmhead_argmax_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mn_lmhead_argmax": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _i64, _p, _p, _p, _sz, _p]),
     "mn_semdec_workspace_bytes": (_sz, [C.POINTER(SemDec), _i, _i64]),
     "mn_semdec_step": (_i, [C.POINTER(SemDec), _p, _i, _p, _p, _p, _p, _i, _i64, _p, _p, _p, _sz, _p]),
 }

@@ -265,6 +265,10 @@ class BailingMoeDecoder:
         kv[:, :self.n_seq] = self.kv_cache
         self.kv_cache, self.n_seq = kv, n_seq
 
+    def copy_sequence(self, src, dst, n):
+        """Cache sequence dst[:n] = src[:n] (KV replicate of generate_image, modeling_bailing_moe.py:1891-1902)."""
+        self.kv_cache[:, dst, :, :, :n].copy_(self.kv_cache[:, src, :, :, :n])
+
     def release_sequences(self, n_keep):
         """Shrink the KV arena back to its first `n_keep` sequences (after a batch call: the batch sequences are dead)."""
         if n_keep >= self.n_seq:
@@ -586,7 +590,7 @@ def generate_images(dec: BailingMoeDecoder, rf, tok, start_embed, past_lens, att
     if rpi > 1:   # replicate each prompt's KV to its CFG rows (:1891-1902) — device memcpy
         for i, past in enumerate(past_lens):
             for r in range(1, rpi):
-                dec.kv_cache[:, seq0 + i * rpi + r, :, :, :past].copy_(dec.kv_cache[:, seq0 + i * rpi, :, :, :past])
+                dec.copy_sequence(seq0 + i * rpi, seq0 + i * rpi + r, past)
     noises = noises.reshape(B, -1, rf.target)
     kw = dict(temperature=temperature, text_cfg=text_cfg, image_cfg=image_cfg)
     main = torch.cuda.current_stream()

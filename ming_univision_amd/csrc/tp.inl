@@ -78,27 +78,33 @@ static void tp_consume(WideGlue& g, const mn_tp_comm* c, uint32_t epoch) {
   g.wait_flags = c->flags[c->rank]; g.wait_n = c->world; g.wait_stride = c->rows_cap; g.wait_epoch = epoch; g.wait_err = c->err;
 }
 
-// out[m] = sum over ranks of x[m] (fp32 [M, D] partial per rank).  Stand-alone form of the mechanism above (push + reduce).
-extern "C" int mn_allreduce_oneshot(mn_tp_comm* comm, const float* x, int64_t ldx, float* out, int64_t ldo, int M, int D, void* stream) {
-  MN_CHECK_ARG(x && out && M >= 1 && tp_comm_ok(comm, M, D) && ldx == D && (ldo % 4) == 0,
+// out[m] = sum over ranks of x[m] (fp32 [M, D] partial per rank).  Stand-alone form of the mechanism above.  phase: MN_TP_PUSH
+// (publish x to every rank), MN_TP_REDUCE (wait for the row's arrivals, sum into out; completes the all-reduce and advances the
+// epoch) or both; split phases let the caller put other work between them (or run several ranks from one process).
+extern "C" int mn_allreduce_oneshot(mn_tp_comm* comm, const float* x, int64_t ldx, float* out, int64_t ldo, int M, int D, int phase,
+                                    void* stream) {
+  MN_CHECK_ARG(M >= 1 && tp_comm_ok(comm, M, D) && (phase & ~3) == 0 && phase != 0 && (!(phase & MN_TP_PUSH) || (x && ldx == D)) &&
+                   (!(phase & MN_TP_REDUCE) || (out && (ldo % 4) == 0)),
                "mn_allreduce_oneshot: bad args (rows <= rows_cap, rows * D <= cap, D %% 4 == 0, 64 <= D <= 4096, ldx == D)");
   hipStream_t st = mn_stream(stream);
   const uint32_t ep = comm->epoch + 1;
-  TpPush p;
-  memset(&p, 0, sizeof(p));
-  p.P = x; p.nz = 1; p.slab = 0;
-  tp_push(comm, ep, p, M, D, st);
-  WideGlue g;
-  memset(&g, 0, sizeof(g));
-  g.xin = nullptr; g.h = nullptr;
-  tp_consume(g, comm, ep);
-  g.out = out; g.ldo = ldo; g.M = M; g.D = D;
-  g.x = nullptr;
-  // v starts from the (zero) source: give the glue a zero row source by pointing h at slab 0 and skipping it in the sum
-  g.h = g.P; g.ldh = D; g.P += g.slab; g.nz -= 1;
-  if (g.nz == 0) g.P = nullptr;
-  wide_glue(g, st);
-  comm->epoch = ep;
+  if (phase & MN_TP_PUSH) {
+    TpPush p;
+    memset(&p, 0, sizeof(p));
+    p.P = x; p.nz = 1; p.slab = 0;
+    tp_push(comm, ep, p, M, D, st);
+  }
+  if (phase & MN_TP_REDUCE) {
+    WideGlue g;
+    memset(&g, 0, sizeof(g));
+    tp_consume(g, comm, ep);
+    // the glue adds the slabs P[0 .. nz) to a source row: take sender 0's slab as the source and sum the other world - 1
+    g.h = g.P; g.ldh = D; g.P += g.slab; g.nz -= 1;
+    if (g.nz == 0) g.P = nullptr;
+    g.out = out; g.ldo = ldo; g.M = M; g.D = D;
+    wide_glue(g, st);
+    comm->epoch = ep;
+  }
   MN_CHECK_LAUNCH("mn_allreduce_oneshot");
   return MN_OK;
 }

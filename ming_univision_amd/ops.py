@@ -354,3 +354,19 @@ def f32_split_bf16(x):
     lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     check(lib().mn_f32_split_bf16(ptr(x), ptr(hi), ptr(lo), x.numel(), current_stream()), "mn_f32_split_bf16")
     return hi, lo
+
+
+def lmhead_argmax(hidden, w, vocab_offset=0):
+    """Greedy pick: (idx int64 [M], val fp32 [M]) = arg-max / max over v of hidden[m] . w[v], idx offset by vocab_offset
+    (w may be a vocabulary slice).  hidden fp32 [M, H], w bf16 [V, H]."""
+    _req(hidden, torch.float32, "hidden"); _req(w, torch.bfloat16, "w")
+    M, H = hidden.shape
+    V = w.shape[0]
+    assert hidden.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == H
+    n = lib().mn_lmhead_argmax_workspace_bytes(M, V, H)
+    ws = torch.empty(n, dtype=torch.uint8, device=hidden.device)
+    idx = torch.empty(M, dtype=torch.int64, device=hidden.device)
+    val = torch.empty(M, dtype=torch.float32, device=hidden.device)
+    check(lib().mn_lmhead_argmax(ptr(hidden), hidden.stride(0), M, ptr(w), w.stride(0), V, H, vocab_offset, ptr(idx), ptr(val), ptr(ws), n,
+                                 current_stream()), "mn_lmhead_argmax")
+    return idx, val

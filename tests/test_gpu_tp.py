@@ -1,0 +1,330 @@
+"""Tensor / expert parallel decode path (BASELINE configs[4]) on ONE GPU: every rank's shard, KV arena, workspace and communicator
+live in one process and advance segment by segment (ming_univision_amd.tp.TpSimGroup) — the same kernels, the same push / arrival-flag
+protocol as one process per GPU; the cross-device memory path itself needs the 8-GPU node (unmeasured on hardware).
+Parity: the sum over the shards must be the unsharded path (<= 2e-4: summation order) and the fp32 oracle (<= 1e-3)."""
+import pytest
+import torch
+
+from ming_univision_amd import configuration as C
+from ming_univision_amd.synth import synth_state_dict
+from tests.util import llm_sd, load_golden, mingtok_sd, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+def _dev(sd):
+    return {k: v.to("cuda", torch.bfloat16).contiguous() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_allreduce_oneshot_phases(world):
+    """mn_allreduce_oneshot: every rank pushes, then every rank reduces — three rounds on one communicator (epoch parity, flags never
+    reset), ragged row counts; the result is the fp32 sum over the ranks, bit-identical on every rank (same order of additions)."""
+    from ming_univision_amd.tp import TpCommunicator
+    comms = TpCommunicator.simulated(world, rows_cap=40, width=512)
+    g = torch.Generator().manual_seed(world)
+    for rnd, (M, D) in enumerate([(3, 512), (40, 256), (1, 64)]):
+        xs = [torch.randn(M, D, generator=g).cuda() for _ in range(world)]
+        for r in range(world):
+            comms[r].all_reduce(xs[r], phase=TpCommunicator.PUSH)
+        outs = [comms[r].all_reduce(xs[r], phase=TpCommunicator.REDUCE) for r in range(world)]
+        ref = torch.stack(xs).double().sum(0)
+        for r in range(world):
+            assert rel_err(outs[r], ref) < 1e-6, (rnd, r)
+            assert torch.equal(outs[r], outs[0])                  # same order of additions on every rank: bit-identical
+            assert comms[r].struct.epoch == rnd + 1
+            comms[r].check_err()
+
+
+def test_allreduce_oneshot_concurrent_ranks_really_wait():
+    """Two ranks on two HIP streams, each enqueuing push + reduce in ONE call: rank 0's reduce is on the GPU before rank 1's push
+    exists, so its rows spin on their arrival flags until the other stream delivers.  (A wait that never completes sets the
+    communicator's error word after a bounded spin instead of hanging the GPU.)"""
+    from ming_univision_amd.tp import TpCommunicator
+    comms = TpCommunicator.simulated(2, rows_cap=8, width=256)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    g = torch.Generator().manual_seed(3)
+    for _ in range(5):
+        xs = [torch.randn(8, 256, generator=g).cuda() for _ in range(2)]
+        torch.cuda.synchronize()
+        outs = [None, None]
+        for r in (0, 1):
+            with torch.cuda.stream(streams[r]):
+                outs[r] = comms[r].all_reduce(xs[r])
+        torch.cuda.synchronize()
+        for r in (0, 1):
+            comms[r].check_err()
+            assert torch.equal(outs[r], xs[0] + xs[1])
+
+
+def test_ep_dispatch_and_combine_match_the_full_expert_sum():
+    """mn_ep_dispatch / mn_ep_combine: 4 ranks x 2 experts; the tile list of a rank names only its experts, the combine over the
+    ranks is the weighted un-permute of ALL picks."""
+    import ctypes as Ct
+    from ming_univision_amd._lib import check, current_stream, lib, ptr
+    from ming_univision_amd.tp import TpCommunicator
+    world, E, k, M, D = 4, 8, 3, 37, 128
+    g = torch.Generator().manual_seed(0)
+    ti = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(M)]).to(torch.int32).cuda()
+    tw = torch.rand(M, k, generator=g).cuda()
+    h = torch.randn(M, D, generator=g).cuda()
+    comms = TpCommunicator.simulated(world, rows_cap=64, width=D)
+    L = lib()
+    # expert e's "MLP output" for sorted position p is a known function of (e, p): yg[p] = (e + 1) * base[p]
+    base = torch.randn(M * k, D, generator=g).cuda()
+    outs, P = [], M * k
+    state = []
+    for r in range(world):
+        cnt = torch.empty(E, dtype=torch.int32, device="cuda"); off = torch.empty(E + 1, dtype=torch.int32, device="cuda")
+        perm = torch.empty(P, dtype=torch.int32, device="cuda"); slot_of = torch.empty(P, dtype=torch.int32, device="cuda")
+        tg = torch.full((P // 16 + E,), -1, dtype=torch.int32, device="cuda"); tm = torch.empty_like(tg)
+        nt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        check(L.mn_ep_dispatch(ptr(ti), M, k, E, 2 * r, 2, ptr(cnt), ptr(off), ptr(perm), ptr(slot_of), 16, ptr(tg), ptr(tm), ptr(nt),
+                               current_stream()), "mn_ep_dispatch")
+        n = int(nt.item())
+        assert set(tg[:n].tolist()) <= {2 * r, 2 * r + 1}
+        assert n == sum(-(-int(cnt[e]) // 16) for e in (2 * r, 2 * r + 1))
+        assert int(cnt.sum()) == P and sorted(slot_of.tolist()) == list(range(P))
+        assert torch.equal(perm[slot_of.long()].reshape(M, k), torch.arange(M, device="cuda", dtype=torch.int32).unsqueeze(1).expand(M, k))
+        exp_of_pos = torch.empty(P, dtype=torch.long, device="cuda")
+        exp_of_pos[slot_of.long()] = ti.reshape(-1).long()
+        yg = base * (exp_of_pos + 1).unsqueeze(1).float()
+        local = (exp_of_pos >= 2 * r) & (exp_of_pos < 2 * r + 2)
+        yg[~local] = float("nan")                                   # rows of other ranks' experts are never written: must not be read
+        state.append((slot_of, yg))
+    extra = [torch.randn(2, M, D, generator=g).cuda() for _ in range(world)]     # each rank's "shared slice" slabs
+    # mn_ep_combine is push + reduce in one call; with all ranks in one process the local weighted sums are taken through one-rank
+    # communicators and summed across ranks with the two phases of the public all-reduce
+    parts = []
+    zero = torch.zeros(M, D, device="cuda")
+    for r in range(world):
+        one = TpCommunicator.simulated(1, rows_cap=64, width=D)[0]
+        part = torch.empty(M, D, device="cuda")
+        slot_of, yg = state[r]
+        check(L.mn_ep_combine(Ct.byref(one.struct), ptr(yg), ptr(slot_of), ptr(ti), ptr(tw), k, 2 * r, 2, ptr(extra[r]), 2, M * D,
+                              ptr(zero), D, ptr(part), D, M, D, current_stream()), "mn_ep_combine")
+        one.check_err()
+        parts.append(part)
+    for r in range(world):
+        comms[r].all_reduce(parts[r], phase=TpCommunicator.PUSH)
+    total = comms[0].all_reduce(parts[0], phase=TpCommunicator.REDUCE) + h
+    ref = h.double().cpu().clone()
+    for r in range(world):
+        ref += extra[r].double().cpu().sum(0)
+    tic, twc, basec = ti.cpu(), tw.double().cpu(), base.double().cpu()
+    for m in range(M):
+        for s_ in range(k):
+            e = int(tic[m, s_])
+            pos = int(state[e // 2][0][m * k + s_])                 # the owner rank's sorted position of this pick
+            ref[m] += twc[m, s_] * (e + 1) * basec[pos]
+    assert torch.isfinite(total).all()
+    assert rel_err(total, ref) < 1e-5
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tp_llm_step_tiny_matches_unsharded_and_reference(world):
+    """Tiny decoder (4 q / 2 KV heads, 8 experts + 2 shared, multi-gate) split 2 and 4 ways: a 12-token prefill with image-gate rows,
+    then 3-row CFG decode steps with holey masks — against the unsharded path, the reference's golden hidden states, and rank against
+    rank (bit-identical: every rank sums the same slabs in the same order)."""
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder
+    from ming_univision_amd.tp import TpSimGroup
+    g = load_golden("llm_tiny")
+    sd = llm_sd(g["config"], g["rf_config"], g["seed"])
+    cfg = C.BailingMoeConfig(**g["config"])
+    if cfg.num_key_value_heads % world and world % cfg.num_key_value_heads:
+        pytest.skip("KV heads do not split")
+    dec = BailingMoeDecoder.from_state_dict(cfg, _dev(sd), t_max=64, n_seq=3)
+    grp = TpSimGroup(dec, None, world, rows_cap=64)
+    emb = g["emb"][0].cuda()
+    T = emb.shape[0]
+    h_tp = grp.prefill(emb, seq=0, past=0, image_mask=g["image_mask"][0])
+    h_full = dec.prefill(emb, seq=0, past=0, image_mask=g["image_mask"][0])
+    grp.check_err()
+    assert rel_err(h_tp, g["hidden"][0]) < TOL
+    assert rel_err(h_tp, h_full) < 2e-4
+    for o in grp.last_rank_outputs[1:]:
+        assert torch.equal(o, grp.last_rank_outputs[0])
+    # every rank's KV arena holds its KV heads of the full arena
+    for r, sh in enumerate(grp.shards):
+        kv0 = (r * sh.plan["n_q"] * cfg.num_key_value_heads) // cfg.num_attention_heads
+        assert rel_err(sh.kv_cache[:, 0, :, :, :T], dec.kv_cache[:, 0, :, kv0:kv0 + sh.plan["n_kv"], :T]) < 2e-4
+    # CFG decode: replicate the prompt to 3 rows, then the golden decode inputs
+    for s in (1, 2):
+        grp.copy_sequence(0, s, T); dec.copy_sequence(0, s, T)
+    from ming_univision_amd.bailing_moe import ImageGenState
+    st = ImageGenState(grp, [g["dec_mask0"]], [T])
+    for i in range(g["dec_in"].shape[0]):
+        x = g["dec_in"][i][:, 0].cuda().contiguous()
+        h1 = grp.step(x, st.row_seq, st.row_slot, st.row_pos, st.row_len, st.key_mask)
+        h2 = dec.step(x, st.row_seq, st.row_slot, st.row_pos, st.row_len, st.key_mask)
+        assert rel_err(h1, g["dec_hidden"][i][:, 0]) < TOL, i
+        assert rel_err(h1, h2) < 2e-4
+        st.advance()
+    grp.check_err()
+
+
+def test_tp_relayed_transport_matches_unsharded():
+    """The RCCL fallback transport (TpCommunicator.relayed: pushes stay local, an all-gather over the process group delivers them
+    between two segments) with a loop-back process group standing in for RCCL: two ranks of the tiny decoder, prefill + decode."""
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder
+    from ming_univision_amd.tp import TpCommunicator, TpDecoderShard
+    g = load_golden("llm_tiny")
+    cfg = C.BailingMoeConfig(**g["config"])
+    dec = BailingMoeDecoder.from_state_dict(cfg, _dev(llm_sd(g["config"], g["rf_config"], g["seed"])), t_max=64, n_seq=3)
+    world = 2
+    comms = []
+
+    class Loopback:                                   # all_gather of the in-process "ranks": slab p comes from rank p's own inbox
+        def __init__(self, rank):
+            self.rank = rank
+
+        def get_rank(self):
+            return self.rank
+
+        def get_world_size(self):
+            return world
+
+        def all_gather(self, outs, mine):
+            for p_, o in enumerate(outs):
+                src = comms[p_]._relay[1].reshape(-1)[o.storage_offset():o.storage_offset() + o.numel()]
+                if p_ != self.rank:
+                    o.copy_(src)
+
+    comms.extend(TpCommunicator.relayed(Loopback(r), 64, cfg.hidden_size, "cuda") for r in range(world))
+    shards = [TpDecoderShard(dec, r, world) for r in range(world)]
+    emb = g["emb"][0].cuda()
+    T = emb.shape[0]
+    slot = torch.arange(T, dtype=torch.int32).cuda()
+    seq = torch.zeros(T, dtype=torch.int32).cuda()
+    im = g["image_mask"][0].to(torch.uint8).cuda()
+    outs = [torch.empty(T, cfg.hidden_size, device="cuda") for _ in range(world)]
+    n_seg = shards[0].n_segments()
+    base = comms[0].struct.epoch
+    for s_ in range(n_seg):
+        for r in range(world):
+            shards[r].step_tp(comms[r], emb, seq, slot, slot, slot + 1, None, im, out=outs[r], seg_begin=s_, seg_end=s_ + 1)
+        if s_ + 1 < n_seg:
+            for r in range(world):
+                comms[r].relay(base + s_ + 1, T * cfg.hidden_size)
+    for c in comms:
+        c.check_err()
+    assert rel_err(outs[0], g["hidden"][0]) < TOL and torch.equal(outs[0], outs[1])
+
+
+def test_tp_rf_sampler_full_size_matches_unsharded():
+    """The full RF head (w = 3072, 12 blocks, hidden 8192, 16 Euler steps: 192 all-reduces per token) split 8 ways, 2 and 6 CFG rows."""
+    from ming_univision_amd.rf_head import RectifiedFlowHead
+    from ming_univision_amd.synth import synth_tensor
+    from ming_univision_amd.tp import TpCommunicator, TpRfShard
+    cfg = C.BailingMoeConfig.ming_univision_16b_a3b()
+    rf_cfg = dict(C.DEFAULT_VISHEAD_DIFFLOSS)
+    shapes = C.llm_param_shapes(cfg, rf_cfg, 32)
+    sd = {k: synth_tensor(k, s_, 7, "cuda", torch.bfloat16) for k, s_ in shapes.items() if k.startswith("vis_head") or k.startswith("diffloss")}
+    rf = RectifiedFlowHead(sd, cfg.hidden_size, rf_cfg)
+    world = 8
+    shards = [TpRfShard(rf, r, world) for r in range(world)]
+    assert shards[0].hidden == 1024 and shards[0].n_segments() == 193
+    comms = TpCommunicator.simulated(world, rows_cap=8, width=rf.w)
+    g = torch.Generator().manual_seed(5)
+    for n_images, rpi in ((1, 2), (2, 3)):
+        hidden = torch.randn(n_images * rpi, cfg.hidden_size, generator=g).cuda()
+        noise = torch.randn(n_images, 32, generator=g).cuda()
+        ref = rf.sample(hidden, noise, n_images=n_images)
+        outs = [torch.empty_like(ref) for _ in range(world)]
+        for seg in range(193):
+            for r in range(world):
+                shards[r].sample_tp(comms[r], hidden, noise, out=outs[r], n_images=n_images, seg_begin=seg, seg_end=seg + 1)
+        for r in range(world):
+            comms[r].check_err()
+            assert torch.equal(outs[r], outs[0])
+        err = (outs[0] - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)
+        assert float(err.max()) < 2e-4, float(err.max())
+    assert comms[0].struct.epoch == 2 * 192
+
+
+def test_tp8_full_width_generate_image_vs_oracle():
+    """BASELINE configs[4] shapes on one GPU: the 16B-A3B layer shapes (16 q / 4 KV heads -> 2 + 1 per rank, 64 experts -> 8 per rank,
+    shared width 2816 -> 352 (+32 zero units) per rank), the full RF head (hidden 8192 -> 1024 per rank), 2 LLM layers, 3 visual tokens,
+    3 CFG rows, TP = 8: prompt prefill, the AR loop with the sharded decoder stack and sampler, the replicated semantic decoder —
+    image 0 against the fp32 oracle <= 1e-3 and against the unsharded HIP path."""
+    from oracle import bailing_ref, mingtok_ref
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder, generate_image
+    from ming_univision_amd.mingtok import MingTok
+    from ming_univision_amd.rf_head import RectifiedFlowHead
+    from ming_univision_amd.tp import TpSimGroup, shard_plan
+    seed = 5
+    d = C.BailingMoeConfig.ming_univision_16b_a3b().to_dict()
+    d.pop("model_type", None)
+    d.update(num_hidden_layers=2, vocab_size=1024, num_image_tokens_for_gen=3, image_start_token=1000, pad_token_id=0)
+    rf_cfg = dict(C.DEFAULT_VISHEAD_DIFFLOSS)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    sd = llm_sd(d, rf_cfg, seed)
+    ocfg = bailing_ref.LLMConfig(**{k: v for k, v in d.items() if k in bailing_ref.LLMConfig.__dataclass_fields__})
+    cfg = C.BailingMoeConfig(**d)
+    pl = shard_plan(cfg, 8, rf_hidden=8192)
+    assert (pl["n_q"], pl["n_kv"], pl["n_experts"], pl["shared"], pl["shared_pad"], pl["rf_hidden"]) == (2, 1, 8, 352, 384, 1024)
+    dsd = _dev(sd)
+    dec = BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=32, n_seq=3)
+    rf = RectifiedFlowHead(dsd, cfg.hidden_size, rf_cfg)
+    lsd = synth_state_dict(C.linear_proj_param_shapes(1024, cfg.hidden_size, 2), seed)
+    dl = _dev(lsd)
+    tok = MingTok(C.MingTokConfig(), device="cuda", seed=seed,
+                  linear_proj=[(dl["linear_proj.0.weight"], dl["linear_proj.0.bias"]), (dl["linear_proj.2.weight"], dl["linear_proj.2.bias"])])
+    tsd = {k: v.float().cpu() for k, v in tok.sd.items()}
+    g = torch.Generator().manual_seed(1)
+    T = 12
+    ids = torch.randint(0, 900, (1, T), generator=g)
+    noises = torch.randn(cfg.num_image_tokens_for_gen + 1, 32, generator=g)
+    am = torch.ones(1, T + 1, dtype=torch.long)
+    un = am.clone(); un[0, 2:T - 2] = 0
+    tu = am.clone(); tu[0, 2:5] = 0
+    kvs = bailing_ref.new_kv(ocfg)
+    bailing_ref.model_forward(sd["model.word_embeddings.weight"][ids], sd, ocfg, torch.ones(1, T, dtype=torch.long), None, kvs)
+    caches = mingtok_ref.semdec_new_cache(tsd)
+    ref = bailing_ref.generate_image(
+        sd["model.word_embeddings.weight"][torch.tensor([[cfg.image_start_token]])], kvs, am, un, tu, sd, ocfg, noises,
+        latent_to_sem=lambda lat: mingtok_ref.mingtok_feature_decoder_step(lat, tsd, caches),
+        linear_proj=lambda s: bailing_ref.linear_proj(s, lsd), sem_to_pix=lambda s: None, steps=16)
+    assert ref["last_hidden"].shape[0] == 3
+    grp = TpSimGroup(dec, rf, 8, rows_cap=16)
+    grp.prefill(dec.embed(ids[0].cuda()), seq=0, past=0)
+    start = dec.embed(torch.tensor([cfg.image_start_token]).cuda())
+    out = generate_image(grp, grp.sampler(), tok, start, T, am, un, tu, noises.cuda(), decode_pixels=False)
+    grp.check_err()
+    errs = (rel_err(out["latents"], ref["latents"][:, 0]), rel_err(out["sem"], ref["sem"][0]), rel_err(out["last_hidden"], ref["last_hidden"][:, 0]))
+    print("TP = 8 (simulated on one GPU) vs oracle: latents %.2e sem %.2e hidden %.2e" % errs)
+    assert max(errs) < TOL, errs
+    dec.prefill(dec.embed(ids[0].cuda()), seq=0, past=0)
+    one = generate_image(dec, rf, tok, start, T, am, un, tu, noises.cuda(), decode_pixels=False)
+    assert rel_err(out["latents"], one["latents"]) < 5e-4
+    # bytes a rank streams per visual token at TP = 8 vs the unsharded path (the point of TP: batch-1 latency)
+    print("decoder-stack weight bytes per rank: %.2f GB of %.2f GB" % (grp.shards[0].weight_bytes() / 1e9,
+          sum(t.numel() * 2 for ly in dec.layers for k, t in ly.items() if t is not None and k not in ("ln1", "ln2")) / 1e9))
+
+
+def test_lmhead_argmax_matches_logits_argmax():
+    """mn_lmhead_argmax (1, 7, 40 and 130 rows: skinny and MFMA routes) against torch.argmax of mn logits; vocabulary slices with an
+    offset (the TP form) reduce to the same pick; ties go to the lowest index."""
+    import ctypes as Ct
+    from ming_univision_amd import ops
+    from ming_univision_amd._lib import check, current_stream, lib, ptr
+    g = torch.Generator().manual_seed(0)
+    V, H = 5000, 256
+    W = (torch.randn(V, H, generator=g) * H ** -0.5).to(torch.bfloat16).cuda()
+    for M in (1, 7, 40, 130):
+        x = torch.randn(M, H, generator=g).cuda()
+        idx, val = ops.lmhead_argmax(x, W)
+        ref_logits = x.double().cpu() @ W.double().cpu().T
+        assert idx.tolist() == ref_logits.argmax(-1).tolist()
+        assert rel_err(val, ref_logits.max(-1).values) < 1e-4
+        # two vocabulary slices (TP = 2): the better (val, idx) pair is the global pick
+        i0, v0 = ops.lmhead_argmax(x, W[:2500], vocab_offset=0)
+        i1, v1 = ops.lmhead_argmax(x, W[2500:], vocab_offset=2500)
+        pick = torch.where(v1 > v0, i1, i0)
+        assert pick.tolist() == idx.tolist()
+    W2 = W.clone(); W2[77] = W2[4000]                              # a tie: rows 77 and 4000 are the same vector
+    x = W2[4000].float().unsqueeze(0) * 10
+    idx, _ = ops.lmhead_argmax(x.contiguous(), W2)
+    assert int(idx[0]) == 77

@@ -216,3 +216,124 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True,
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+TP_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from ming_univision_amd import configuration as C
+from ming_univision_amd.bailing_moe import pack_experts
+from ming_univision_amd.tp import shard_attention, shard_experts, shard_plan, shard_rf_block
+from oracle import bailing_ref, rf_ref
+from tests.util import llm_sd, load_golden
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+g = load_golden("llm_tiny")
+sd = llm_sd(g["config"], g["rf_config"], g["seed"])            # every rank synthesises the same full weights, keeps its shard
+cfg = C.BailingMoeConfig(**g["config"])
+ocfg = bailing_ref.LLMConfig(**{k: v for k, v in g["config"].items() if k in bailing_ref.LLMConfig.__dataclass_fields__})
+pl = shard_plan(cfg, world)
+H, hd, nq, nkv = cfg.hidden_size, cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads
+gen = torch.Generator().manual_seed(7)
+M = 5
+x = torch.randn(1, M, H, generator=gen)
+p = "model.layers.0"
+err = {}
+
+# ---- attention: this rank's q heads + its KV head, dense over its columns; all-reduce = BailingMoeAttention.forward
+wqkv_l, wdense_l = shard_attention(sd[p + ".attention.query_key_value.weight"], sd[p + ".attention.dense.weight"], cfg, rank, world)
+assert wqkv_l.shape == ((pl["n_q"] + 2 * pl["n_kv"]) * hd, H) and wdense_l.shape == (H, pl["n_q"] * hd)
+qkv = F.linear(x, wqkv_l).view(1, M, pl["n_q"] + 2 * pl["n_kv"], hd)
+q, k, v = (t.transpose(1, 2) for t in qkv.split([pl["n_q"], pl["n_kv"], pl["n_kv"]], dim=-2))
+pos = torch.arange(M).unsqueeze(0)
+cos, sin = bailing_ref.rope_cos_sin(hd, cfg.rope_theta, M)
+q, k = bailing_ref.apply_rope(q, k, cos, sin, pos)
+rep = pl["n_q"] // pl["n_kv"]
+kk, vv = k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1)
+w = torch.matmul(q / hd ** 0.5, kk.transpose(2, 3)) + bailing_ref.build_4d_mask(torch.ones(1, M, dtype=torch.long), M, 0)
+o = torch.matmul(F.softmax(w, dim=-1, dtype=torch.float32), vv).transpose(1, 2).reshape(1, M, pl["n_q"] * hd)
+part = F.linear(o, wdense_l)
+dist.all_reduce(part)
+full = bailing_ref.attention(x, sd, p + ".attention", ocfg, bailing_ref.build_4d_mask(torch.ones(1, M, dtype=torch.long), M, 0), pos,
+                             dict(k=None, v=None))
+err["attention"] = float((part - full).abs().max() / full.abs().max())
+
+# ---- experts: its E / world routed experts on the rows routed to them + its slice of the shared expert; all-reduce = moe block
+gu, dn = (t.float() for t in pack_experts(sd, p + ".mlp", cfg))      # packs into bf16: lossless, the values are bf16-rounded
+gu_l, dn_l, ws_gu, ws_dn = shard_experts(gu, dn, cfg, rank, world)
+x2 = x.reshape(M, H)
+ti, tw, _ = bailing_ref.gate(x2, sd[p + ".mlp.gate.weight"], ocfg)       # routing replicated on every rank
+e0, I = rank * pl["n_experts"], cfg.moe_intermediate_size
+part = torch.zeros(M, H)
+n_local = 0
+for m in range(M):
+    for s in range(cfg.num_experts_per_tok):
+        e = int(ti[m, s])
+        if e0 <= e < e0 + pl["n_experts"]:
+            n_local += 1
+            y = F.linear(x2[m:m + 1], gu_l[e - e0])
+            part[m] += tw[m, s] * F.linear(F.silu(y[:, :I]) * y[:, I:], dn_l[e - e0])[0]
+pad = pl["shared_pad"]
+y = F.linear(x2, ws_gu)
+part += F.linear(F.silu(y[:, :pad]) * y[:, pad:], ws_dn)
+dist.all_reduce(part)
+full, _ = bailing_ref.moe_block(x, sd, p + ".mlp", ocfg, None)
+err["moe"] = float((part - full[0]).abs().max() / full.abs().max())
+cnt = torch.tensor([float(n_local)])
+dist.all_reduce(cnt)
+assert int(cnt.item()) == M * cfg.num_experts_per_tok          # every pick has exactly one owner
+
+# ---- RF ResBlock MLP: its hidden units; all-reduce (+ b3 once) = SwiGLUFFNFused
+gen2 = torch.Generator().manual_seed(11)
+wd, hid = 64, 128
+w12, b12 = torch.randn(2 * hid, wd, generator=gen2) * 0.1, torch.randn(2 * hid, generator=gen2) * 0.1
+w3, b3 = torch.randn(wd, hid, generator=gen2) * 0.1, torch.randn(wd, generator=gen2) * 0.1
+xr = torch.randn(3, wd, generator=gen2)
+a, bb, c = shard_rf_block(w12, b12, w3, rank, world)
+n = hid // world
+y = F.linear(xr, a, bb)
+part = F.linear(F.silu(y[:, :n]) * y[:, n:], c)
+dist.all_reduce(part)
+yf = F.linear(xr, w12, b12)
+full = F.linear(F.silu(yf[:, :hid]) * yf[:, hid:], w3, b3)
+err["rf_block"] = float((part + b3 - full).abs().max() / full.abs().max())
+if rank == 0:
+    print(json.dumps(err))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_tp_partitioning_world2_gloo(tmp_path):
+    """The tensor / expert-parallel partitioning (ming_univision_amd.tp.shard_*: heads, KV replication, expert window, shared-expert
+    slice with zero padding, RF hidden split) on two gloo ranks: each rank computes its partial with plain fp32 math on ITS shard,
+    the all-reduce over the process group must equal the oracle's unsharded attention / MoE block / SwiGLU block."""
+    script = tmp_path / "tp_worker.py"
+    script.write_text(TP_WORKER % ROOT)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    err = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert set(err) == {"attention", "moe", "rf_block"} and max(err.values()) < 1e-5, err
+
+
+def test_tp_shard_plan_16b_a3b():
+    from ming_univision_amd.tp import shard_plan
+    cfg = C.BailingMoeConfig.ming_univision_16b_a3b()
+    assert shard_plan(cfg, 8, rf_hidden=8192) == dict(n_q=2, n_kv=1, n_experts=8, shared=352, shared_pad=384, rf_hidden=1024)
+    assert shard_plan(cfg, 4, rf_hidden=8192) == dict(n_q=4, n_kv=1, n_experts=16, shared=704, shared_pad=704, rf_hidden=2048)
+    assert shard_plan(cfg, 2)["n_kv"] == 2 and shard_plan(cfg, 1)["shared_pad"] == 2816
+    with pytest.raises(ValueError):
+        shard_plan(cfg, 3)
+    with pytest.raises(ValueError):
+        shard_plan(cfg, 32)                                        # 16 q heads do not split 32 ways
