@@ -212,8 +212,17 @@ def dominant_kernel_roofline_wide(rf, rows, iters=48):
     pmc = os.path.join(ROOT, "profiles", "r02_pmc_gemm256_w12_rows%d.json" % rows)
     if os.path.exists(pmc) and hid == 8192 and w == 3072:
         traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+    # the same call site inside a whole bench step, from the committed rocprofv3 kernel trace of `bench.py --steps 1` reduced per
+    # (kernel, grid) by tools/site_stats.py (profiles/r03_bench_default_site_stats.csv): what the launch costs IN the step
+    in_step = None
+    site = os.path.join(ROOT, "profiles", "r03_bench_default_site_stats.csv")
+    if os.path.exists(site) and hid == 8192 and w == 3072 and rows == 1536:
+        import csv
+        for r in csv.DictReader(open(site)):
+            if r["site"].startswith("RF w12"):
+                in_step = dict(us=float(r["avg_us"]), calls=int(r["calls"]))
     return dict(traffic=traffic, kernel="gemm256_kernel<SWIGLU_SPLIT,2-phase,hi/lo> (RF w12: N=2x%d, K=%d, rows=%d)" % (hid, w, rows),
-                us=us, flops=flops, tflops=flops / us * 1e-6)
+                us=us, flops=flops, tflops=flops / us * 1e-6, in_step=in_step)
 
 
 def cpu_baseline(args, rows=2):
@@ -355,7 +364,12 @@ def main():
             roof = {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": dom["tflops"] / MFMA_PEAK_TFLOPS, "traffic": dom["traffic"], "kernel": dom["kernel"],
                     "flops_per_launch": dom["flops"], "us_per_launch": dom["us"],
-                    "mfma_issued_tflops": 2 * dom["tflops"]}
+                    "mfma_issued_tflops": 2 * dom["tflops"],
+                    "timing": "HIP events over 48 back-to-back launches of this call site alone, on the launch stream"}
+            if dom.get("in_step"):      # the same call site inside a full step (rocprofv3 kernel trace, per-site reduction)
+                roof["us_per_launch_in_step_rocprof"] = dom["in_step"]["us"]
+                roof["launches_in_step_rocprof"] = dom["in_step"]["calls"]
+                roof["frac_in_step_rocprof"] = dom["flops"] / dom["in_step"]["us"] * 1e-6 / MFMA_PEAK_TFLOPS
         else:
             dom = (dominant_kernel_roofline_stream(rf, rows * per_group) if rows * per_group >= 2   # matrix-core route
                    else dominant_kernel_roofline(rf, rows))

@@ -445,6 +445,11 @@ class BailingMoeDecoder:
         outs = [ops.skinny_gemm(hidden[i:i + 8].contiguous(), self.lm_head) for i in range(0, hidden.shape[0], 8)]
         return torch.cat(outs, 0)
 
+    def greedy(self, hidden):
+        """Greedy pick of every row: lm_head + arg-max in ONE C call (mn_lmhead_argmax: compute_logit, :1604-1620, + the argmax
+        of greedy decoding; ties -> lowest id like torch.argmax).  hidden fp32 [M, H] -> int64 [M] on the device."""
+        return ops.lmhead_argmax(hidden.contiguous(), self.lm_head)[0]
+
     def embed(self, ids):
         """word_embeddings lookup -> fp32 rows (gather = memory plumbing)."""
         return ops.bf16_to_f32(self.word_embeddings[ids.reshape(-1)])

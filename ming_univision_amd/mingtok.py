@@ -47,7 +47,7 @@ class MingTok:
         precision: regime of the BATCHED passes (encode, semantic-decoder prefill, pixel decoder); every method takes an override.
           "bf16" — bf16 activations on the MFMA, flash attention (the reference's own autocast precision: ~1e-2 of the fp32 result);
           "fp32" — fp32-class: every Linear a gemm256 launch on bf16 hi/lo activation pairs (2^-17), attention on the fp32 decode
-                   kernels against a scratch K/V arena; matches the fp32 oracle to 1e-3 (what feeds the LLM in understanding / editing)."""
+                   kernels against a scratch K/V arena; within 1e-3 of the fp32 reference path (what feeds the LLM in understanding / editing)."""
         assert precision in ("bf16", "fp32")
         self.precision = precision
         self.config = config

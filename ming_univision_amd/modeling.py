@@ -174,7 +174,7 @@ class MingUniVisionForConditionalGeneration:
         s0 = self.BATCH_SEQ0            # the multi-round conversation keeps its cache sequences
         self.model.ensure_sequences(s0 + rpi * B)
         hidden = self.model.prefill_ragged([self.model.embed(i[0].to(dev)) for i in ids], [s0 + rpi * b for b in range(B)])
-        first = torch.argmax(self.model.logits(hidden), dim=-1).tolist()
+        first = self.model.greedy(hidden).tolist()
         if forced_first_token is not None:
             first = [int(forced_first_token)] * B
         bad = [b for b, t in enumerate(first) if t != cfg.image_start_token]
@@ -282,7 +282,7 @@ class MingUniVisionForConditionalGeneration:
         finished = torch.zeros(B, dtype=torch.bool, device=dev)
         toks = []
         for step in range(max_new_tokens):
-            tok = torch.argmax(self.model.logits(hidden), dim=-1)
+            tok = self.model.greedy(hidden)
             toks.append(tok)
             finished |= tok == cfg.eos_token_id
             if step + 1 == max_new_tokens:
@@ -369,7 +369,7 @@ class MingUniVisionForConditionalGeneration:
             ln = slot + 1
             toks_dev = []
             for j in range(n):
-                tok_dev = torch.argmax(self.model.logits(hidden)[0]).reshape(1)
+                tok_dev = self.model.greedy(hidden[0:1])
                 if not new_ids and j == 0 and forced_first_token is not None:
                     tok_dev = torch.tensor([int(forced_first_token)], device=dev)
                 toks_dev.append(tok_dev)

@@ -362,6 +362,9 @@ class _TpDecoderBase:
     def logits(self, hidden):
         return self.full.logits(hidden)            # lm_head replicated (vocabulary split: next step)
 
+    def greedy(self, hidden):
+        return self.full.greedy(hidden)
+
     def prefill(self, embeds, seq=0, past=0, image_mask=None, chunk=None):
         T = embeds.shape[0]
         assert past + T <= self.t_max
