@@ -737,12 +737,6 @@ static size_t llm_carve(const mn_llm* m, int rows, int64_t t_max, void* ws, size
   return cv.off;
 }
 
-// Largest row count one call of each composite accepts for this configuration: 2048 when the wide route applies
-// (64-aligned widths), else 64.
-// Tail of a split-K nn.Linear whose result joins the fp32 residual stream (MingTok Block.forward, layers/block.py:80-105: x = x +
-// proj(attn) / x = x + mlp(...)), fused with the LayerNorm of the NEXT consumer: h[m] += sum_z P[z][m][:] (the bias rides slab 0);
-// if y: y[m] = bf16(LayerNorm(h[m]) (ln_g, ln_b optional), GELU after it when gelu != 0).  One launch instead of a reduce pass
-// and a LayerNorm pass; used when the row count leaves a 256 x 256-tile GEMM without split-K on a fraction of the chip.
 // Y (bf16 hi rows, lo rows y_lo_off elements further; y_lo_off = 0: plain bf16) = act(norm(x)): the operand of a hi/lo gemm256
 // launch from an fp32 row block.  norm 0: none, 1: RMSNorm(g), 2: LayerNorm(g?, b?); act 1: exact-erf GELU.
 extern "C" int mn_norm_act_split(const float* x, int64_t ldx, int norm, const uint16_t* g, const uint16_t* b, float eps, int act,
@@ -760,6 +754,10 @@ extern "C" int mn_norm_act_split(const float* x, int64_t ldx, int norm, const ui
   return MN_OK;
 }
 
+// Tail of a split-K nn.Linear whose result joins the fp32 residual stream (MingTok Block.forward, layers/block.py:80-105: x = x +
+// proj(attn) / x = x + mlp(...)), fused with the LayerNorm of the NEXT consumer: h[m] += sum_z P[z][m][:] (the bias rides slab 0);
+// if y: y[m] = bf16(LayerNorm(h[m]) (ln_g, ln_b optional), GELU after it when gelu != 0).  One launch instead of a reduce pass
+// and a LayerNorm pass; used when the row count leaves a 256 x 256-tile GEMM without split-K on a fraction of the chip.
 extern "C" int mn_slab_resid_norm(const float* P, int nz, int64_t slab, float* h, int64_t ldh, const uint16_t* ln_g, const uint16_t* ln_b,
                                   float eps, int gelu, uint16_t* y, int64_t ldy, int M, int D, void* stream) {
   MN_CHECK_ARG(P && h && nz >= 1 && M >= 1 && wide_glue_ok(D) && (ldh % 4) == 0 && (!y || (ldy % 4) == 0), "mn_slab_resid_norm: bad args");
@@ -790,6 +788,8 @@ extern "C" int mn_moe_combine_norm(const float* yg, const int32_t* slot_of, cons
 }
 
 extern "C" int mn_llm_max_rows(const mn_llm* m) { return llm_wide_ok(m, 2048) ? 2048 : 64; }
+// Largest row count one call of each composite accepts for this configuration: 2048 when the wide route applies
+// (64-aligned widths), else 64.
 extern "C" int mn_rf_max_rows(const mn_rf_head* h) { return rf_wide_ok(h, 2048) ? 2048 : 64; }
 extern "C" int mn_semdec_max_rows(const mn_semdec* s) { return sem_wide_ok(s, 2048) ? 2048 : 64; }
 

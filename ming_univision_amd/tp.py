@@ -365,6 +365,22 @@ class _TpDecoderBase:
     def greedy(self, hidden):
         return self.full.greedy(hidden)
 
+    def prefill_many(self, embeds, seqs, past=0):
+        """B prompts of equal length in lock-step (BailingMoeDecoder.prefill_many): embeds fp32 [B, T, H] -> hidden [B, T, H]."""
+        B, T, H = embeds.shape
+        assert past + T <= self.t_max and len(seqs) == B
+        dev = self.device
+        x = embeds.reshape(B * T, H).contiguous()
+        seq = torch.tensor(list(seqs), dtype=torch.int32, device=dev).repeat_interleave(T)
+        slot = (torch.arange(T, dtype=torch.int32, device=dev) + past).repeat(B)
+        out = torch.empty(B * T, H, dtype=torch.float32, device=dev)
+        step = self.max_rows()
+        for r0 in range(0, B * T, step):
+            r1 = min(B * T, r0 + step)
+            sl = slot[r0:r1].contiguous()
+            self.step(x[r0:r1], seq[r0:r1].contiguous(), sl, sl, (sl + 1).contiguous(), None, None, out=out[r0:r1])
+        return out.reshape(B, T, H)
+
     def prefill(self, embeds, seq=0, past=0, image_mask=None, chunk=None):
         T = embeds.shape[0]
         assert past + T <= self.t_max

@@ -68,6 +68,33 @@ def test_image_transforms():
     assert MingTokUndProcessor(32)(im).shape == (3, 32, 32)
 
 
+def test_image_transforms_geometry_and_values():
+    """MingTokCenterCropProcessor / MingTokUndProcessor (processing_bailingmm.py:80-123; mingtok/utils/processor.py:8-30) on a
+    non-trivial image: torchvision's Resize(int) maps the SHORTER side to S keeping the aspect (long side int(S * long / short)),
+    CenterCrop rounds the offset half-away-from-zero, ToTensor scales by 1/255, Normalize(0.5, 0.5) maps to [-1, 1].  torchvision is
+    not installed here, so the expected tensor is assembled from PIL's own resize (what torchvision calls for PIL inputs) with the
+    documented geometry; odd sizes exercise both rounding rules."""
+    import numpy as np
+    from PIL import Image
+    from ming_univision_amd.processing import MingTokCenterCropProcessor, MingTokUndProcessor
+    rng = np.random.RandomState(0)
+    for (w, h, S) in ((301, 200, 64), (97, 233, 32), (64, 64, 48)):
+        arr = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        im = Image.fromarray(arr)
+        t = MingTokCenterCropProcessor(S)(im)
+        nw, nh = (S, int(S * h / w)) if w <= h else (int(S * w / h), S)
+        rs = np.asarray(im.resize((nw, nh), Image.BICUBIC), dtype=np.float32)
+        left, top = int(round((nw - S) / 2.0)), int(round((nh - S) / 2.0))
+        exp = torch.from_numpy(rs[top:top + S, left:left + S]).permute(2, 0, 1) / 255.0
+        exp = (exp - 0.5) / 0.5
+        assert t.shape == (3, S, S) and t.dtype == torch.float32
+        assert torch.equal(t, exp), (w, h, S)
+        u = MingTokUndProcessor(S)(im)
+        expu = (torch.from_numpy(np.asarray(im.resize((S, S), Image.BICUBIC), dtype=np.float32)).permute(2, 0, 1) / 255.0 - 0.5) / 0.5
+        assert torch.equal(u, expu)
+        assert float(t.min()) >= -1.0 and float(t.max()) <= 1.0
+
+
 def test_build_cfg_rows_matches_reference_masks():
     from ming_univision_amd.bailing_moe import build_cfg_rows
     from tests.util import load_golden
