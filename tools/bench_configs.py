@@ -37,6 +37,7 @@ def c1_c2(args):
         mse_in = lambda x: float(((x.double().cpu() - img.double()) ** 2).mean())
         out["psnr_vs_input_db"] = {"hip": 10 * torch.log10(torch.tensor(4.0 / mse_in(rec))).item(),
                                    "oracle": 10 * torch.log10(torch.tensor(4.0 / mse_in(ref))).item()}
+    out["ms_fp32_class"] = timeit(lambda: tok.forward_enc_dec(img.cuda(), precision="fp32"), 3) * 1e3
     print(json.dumps(out), flush=True)
     B = 64
     imgs = (torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).cuda()
@@ -44,6 +45,8 @@ def c1_c2(args):
     print(json.dumps({"config": "C2 MingTok enc->dec 64x256^2", "ms_per_batch": dt * 1e3, "images_per_s": B / dt,
                       "achieved_TFLOPs": 213e9 * B / dt / 1e12, "mfma_bf16_peak_TFLOPs": 2500.0,
                       "frac_of_mfma_peak": 213e9 * B / dt / 2.5e15}), flush=True)
+    dt32 = timeit(lambda: tok.forward_enc_dec(imgs, precision="fp32"), 1)
+    print(json.dumps({"config": "C2 fp32-class regime (hi/lo GEMMs, fp32 attention)", "ms_per_batch": dt32 * 1e3, "images_per_s": B / dt32}), flush=True)
     dt = timeit(lambda: tok.forward(imgs), 3)
     dtp = timeit(lambda: tok.forward_pixel_decoder(tok.forward(imgs)["x_norm_patchtokens"]), 1)
     print(json.dumps({"config": "C2 split", "enc+sem_ms": dt * 1e3, "enc+sem+pix_ms": dtp * 1e3}), flush=True)
@@ -58,21 +61,26 @@ def c3(args):
     ids[0, 13:13 + 1024] = cfg.llm_config.image_patch_token
     ids[0, 13 + 1024] = 126348
     px = torch.rand(1, 3, 1024, 1024) * 2 - 1
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    feats = model.extract_image_feature(px.cuda())
-    torch.cuda.synchronize(); t_img = time.perf_counter() - t0
-    model.generate(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values=px, max_new_tokens=3)   # warm-up
-    torch.cuda.synchronize(); model.reset_inner_state()
-    t0 = time.perf_counter()
-    seq = model.generate(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values=px, max_new_tokens=1)
-    torch.cuda.synchronize(); t_prefill = time.perf_counter() - t0
-    model.reset_inner_state()
-    t0 = time.perf_counter()
-    seq = model.generate(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values=px, max_new_tokens=65)
-    torch.cuda.synchronize(); t_all = time.perf_counter() - t0
-    print(json.dumps({"config": "C3 16B-A3B image(1024^2)->text", "prompt_tokens": ids.shape[1], "mingtok_1024_ms": t_img * 1e3,
-                      "prefill_incl_vision_s": t_prefill, "decode_tokens_per_s": 64 / max(1e-9, t_all - t_prefill), "new_tokens": int(seq.shape[1] - ids.shape[1]),
-                      "note": "prompts > 64 tokens prefill on the bf16 MFMA path (GQA flash attention + grouped-GEMM MoE)"}), flush=True)
+    for regime in ("fp32", "bf16"):
+        model.understanding_precision = regime
+        model.reset_inner_state()
+        model.extract_image_feature(px.cuda())
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        model.extract_image_feature(px.cuda())
+        torch.cuda.synchronize(); t_img = time.perf_counter() - t0
+        model.generate(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values=px, max_new_tokens=3)   # warm-up
+        torch.cuda.synchronize(); model.reset_inner_state()
+        t0 = time.perf_counter()
+        seq = model.generate(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values=px, max_new_tokens=1)
+        torch.cuda.synchronize(); t_prefill = time.perf_counter() - t0
+        model.reset_inner_state()
+        t0 = time.perf_counter()
+        seq = model.generate(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values=px, max_new_tokens=65)
+        torch.cuda.synchronize(); t_all = time.perf_counter() - t0
+        print(json.dumps({"config": "C3 16B-A3B image(1024^2)->text, %s regime" % ("fp32-class (default)" if regime == "fp32" else "bf16 (autocast-like)"),
+                          "prompt_tokens": ids.shape[1], "mingtok_1024_plus_linear_proj_ms": t_img * 1e3, "prefill_incl_vision_s": t_prefill,
+                          "decode_tokens_per_s": 64 / max(1e-9, t_all - t_prefill), "new_tokens": int(seq.shape[1] - ids.shape[1])}), flush=True)
+    model.understanding_precision = "fp32"
     # B conversations in lock-step (generate_text_batch): same prompt shape per conversation, different token ids
     for B in args.c3_batches:
         del model
