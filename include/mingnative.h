@@ -156,7 +156,8 @@ MN_API int mn_rope_kv_append_3d(const float* qkv, int64_t ldqkv, int M, int n_q,
                          float q_scale, float* q_out, float* kv_cache, int64_t t_max, void* stream);
 
 /*    out[m] = softmax(q[m] . K[seq]^T + mask) V[seq] over keys j < row_len[m] with
- *    key_mask[m*ld_mask + j] != 0 (key_mask NULL = all ones; a row with every key masked is undefined).
+ *    key_mask[m*ld_mask + j] != 0 (key_mask NULL = all ones).  A row with every key masked gets the mean of V over its keys
+ *    [0, row_len): what the reference's additive finfo.min mask degenerates to (uniform softmax, modeling_bailing_moe.py:1466).
  *    q is pre-scaled.  out [M, n_q*hd] fp32.  The key range is split over workgroups
  *    (flash-decoding); workspace holds the per-split partials. */
 MN_API size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t t_max);

@@ -472,7 +472,8 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(
 // out (fp32 [M, n_q*HD]) and / or split (bf16 [2][M][n_q*HD]: hi rows then lo rows, the next GEMV's MFMA operand)
 template <int HD>
 __global__ void attn_decode_combine_kernel(const float* __restrict__ partial, int n_q, int S, float* __restrict__ out,
-                                           bf16_t* __restrict__ split, int M) {
+                                           bf16_t* __restrict__ split, int M, const float* __restrict__ kv_cache, int n_kv,
+                                           int64_t t_max, const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_len) {
   const int m = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
   const float* p = partial + (((int64_t)m * n_q + h) * S) * (HD + 2);
   float l = 0.f, acc = 0.f;
@@ -502,7 +503,20 @@ __global__ void attn_decode_combine_kernel(const float* __restrict__ partial, in
       acc = fmaf(f, p[s * (HD + 2) + d], acc);
     }
   }
-  const float v = l > 0.f ? acc / l : 0.f;     // a row with no attended key yields 0, not NaN (precondition: see mingnative.h)
+  float v;
+  if (l > 0.f) {
+    v = acc / l;
+  } else {
+    // No attended key among the row's keys: the reference's additive finfo.min mask (modeling_bailing_moe.py:1466, :802-806) then
+    // absorbs every score (s + finfo.min == finfo.min in fp32), the softmax is UNIFORM over the row's keys [0, len) and the output
+    // is the mean of their V rows.  Degenerate (no caller builds such a row); computed here, off the fast path, for parity.
+    const int len = row_len[m];
+    const int kvh = h / (n_q / n_kv);
+    const float* Vb = kv_cache + (((int64_t)row_seq[m] * 2 + 1) * n_kv + kvh) * t_max * HD;
+    float sum = 0.f;
+    for (int j = 0; j < len; ++j) sum += Vb[(int64_t)j * HD + d];
+    v = len > 0 ? sum / (float)len : 0.f;
+  }
   const int64_t o = ((int64_t)m * n_q + h) * HD + d;
   if (out) out[o] = v;
   if (split) {
@@ -549,15 +563,18 @@ extern "C" int mn_attn_decode_split(const float* q, int M, int n_q, int n_kv, in
   if (attn_use_gqa(M, n_q, n_kv, hd)) {
     hipLaunchKernelGGL((attn_decode_gqa_kernel<128, 4>), dim3(M, (n_kv + 3) / 4, S), dim3(256), lds * 4, st, q, n_q, n_kv, kv_cache,
                        t_max, row_seq, row_len, key_mask, ld_mask, S, chunk_cap, partial);
-    hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(M, n_q), dim3(128), 0, st, partial, n_q, S, out, split, M);
+    hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(M, n_q), dim3(128), 0, st, partial, n_q, S, out, split, M, kv_cache, n_kv, t_max,
+                       row_seq, row_len);
   } else if (hd == 128) {
     hipLaunchKernelGGL(attn_decode_split_kernel<128>, grid, dim3(256), lds, st, q, n_q, n_kv, kv_cache, t_max, row_seq,
                        row_len, key_mask, ld_mask, S, chunk_cap, partial);
-    hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(M, n_q), dim3(128), 0, st, partial, n_q, S, out, split, M);
+    hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(M, n_q), dim3(128), 0, st, partial, n_q, S, out, split, M, kv_cache, n_kv, t_max,
+                       row_seq, row_len);
   } else {
     hipLaunchKernelGGL(attn_decode_split_kernel<64>, grid, dim3(256), lds, st, q, n_q, n_kv, kv_cache, t_max, row_seq,
                        row_len, key_mask, ld_mask, S, chunk_cap, partial);
-    hipLaunchKernelGGL(attn_decode_combine_kernel<64>, dim3(M, n_q), dim3(64), 0, st, partial, n_q, S, out, split, M);
+    hipLaunchKernelGGL(attn_decode_combine_kernel<64>, dim3(M, n_q), dim3(64), 0, st, partial, n_q, S, out, split, M, kv_cache, n_kv, t_max,
+                       row_seq, row_len);
   }
   MN_CHECK_LAUNCH("mn_attn_decode");
   return MN_OK;

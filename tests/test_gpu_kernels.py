@@ -159,6 +159,38 @@ def test_rope_kv_attn_decode(ops, hd, nq, nkv, rope):
             assert rel(out[m].view(nq, hd)[h], sc @ V[h // rep]) < 1e-5, (m, h)
 
 
+@pytest.mark.parametrize("M,hd,nq,nkv", [(3, 128, 16, 4), (70, 128, 16, 4), (5, 64, 16, 16)])
+def test_attn_decode_fully_masked_row_follows_the_reference_mask(ops, M, hd, nq, nkv):
+    """A row whose keys are ALL masked: the reference's additive finfo.min mask (modeling_bailing_moe.py:1466) absorbs every score in
+    fp32, the softmax degenerates to uniform over the row's keys and the output is their mean V — restated exactly as the reference
+    computes it (scores + finfo.min, fp32 softmax).  Rows 0 and M-1 are fully masked, the others keep their holey masks; 3 and 5
+    rows take the per-head kernel, 70 rows the GQA kernel of the wide route."""
+    n_seq, t_max = M, 96
+    kv = rnd(n_seq, 2, nkv, t_max, hd, seed=40)
+    q = rnd(M, nq * hd, seed=41) * (1.0 / math.sqrt(hd))
+    g = torch.Generator().manual_seed(42)
+    lens = torch.randint(1, t_max + 1, (M,), generator=g).to(torch.int32)
+    mask = (torch.rand(M, t_max, generator=g) > 0.4).to(torch.uint8)
+    for m in range(M):
+        mask[m, lens[m] - 1] = 1
+    mask[0] = 0
+    mask[M - 1] = 0
+    seqs = torch.arange(M, dtype=torch.int32)
+    out = ops.attn_decode(q.cuda(), nq, nkv, hd, kv.cuda(), seqs.cuda(), lens.cuda(), mask.cuda())
+    assert torch.isfinite(out).all()
+    neg = torch.finfo(torch.float32).min
+    rep = nq // nkv
+    for m in range(M):
+        L = int(lens[m])
+        K, V = kv[m, 0, :, :L].float(), kv[m, 1, :, :L].float()
+        add = torch.where(mask[m, :L] == 0, torch.tensor(neg), torch.tensor(0.0))
+        for h in (0, nq // 2, nq - 1):
+            w = (K[h // rep] @ q[m].view(nq, hd)[h]) + add                       # fp32, like the reference's eager path
+            ref = torch.softmax(w, dim=-1, dtype=torch.float32) @ V[h // rep]
+            assert rel(out[m].view(nq, hd)[h], ref) < 2e-5, (m, h)
+    assert rel(out[0].view(nq, hd)[0], kv[0, 1, 0, :int(lens[0])].mean(0)) < 2e-5   # = the mean of V over the row's keys
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 344), (4160, 2304, 768), (96, 1000, 3072), (70, 32, 32)])
 def test_gemm_bf16(ops, M, N, K):
     a = rnd(M, K, seed=40).to(torch.bfloat16)
