@@ -27,6 +27,7 @@
 struct TpPush {
   const float* P; int nz; int64_t slab;                                    // local split-K slabs [nz][M][D] (or NULL)
   const float* cy; const int32_t* cpos; const float* cw; const int32_t* ci; int n_slot; int e0, e1;   // local experts' outputs (or NULL)
+  int cy_nz; int64_t cy_slab;                                              // ... as cy_nz K-slice slabs (0 / 1: one array)
   float* inbox[MN_TP_MAX_WORLD];
   uint32_t* flags[MN_TP_MAX_WORLD];
   int world, rank, rows_cap, M, D;
@@ -47,8 +48,12 @@ __global__ __launch_bounds__(1024) void tp_push_kernel(const TpPush p) {
     if (p.cy) {
       for (int s = 0; s < p.n_slot; ++s) {
         const int e = p.ci[(int64_t)m * p.n_slot + s];
-        if (e >= p.e0 && e < p.e1)
-          v += p.cw[(int64_t)m * p.n_slot + s] * *reinterpret_cast<const f4*>(p.cy + (int64_t)p.cpos[(int64_t)m * p.n_slot + s] * D + col);
+        if (e >= p.e0 && e < p.e1) {
+          const float* yr = p.cy + (int64_t)p.cpos[(int64_t)m * p.n_slot + s] * D + col;
+          f4 y = *reinterpret_cast<const f4*>(yr);
+          for (int z = 1; z < p.cy_nz; ++z) y += *reinterpret_cast<const f4*>(yr + z * p.cy_slab);
+          v += p.cw[(int64_t)m * p.n_slot + s] * y;
+        }
       }
     }
     const int64_t off = ((int64_t)(p.epoch & 1u) * p.world + p.rank) * p.cap + (int64_t)m * D + col;
@@ -123,7 +128,7 @@ extern "C" int mn_ep_combine(mn_tp_comm* comm, const float* yg, const int32_t* s
   TpPush p;
   memset(&p, 0, sizeof(p));
   p.P = P; p.nz = nz; p.slab = slab;
-  p.cy = yg; p.cpos = slot_of; p.cw = topk_w; p.ci = topk_idx; p.n_slot = n_slot; p.e0 = expert0; p.e1 = expert0 + n_local;
+  p.cy = yg; p.cy_nz = 1; p.cpos = slot_of; p.cw = topk_w; p.ci = topk_idx; p.n_slot = n_slot; p.e0 = expert0; p.e1 = expert0 + n_local;
   tp_push(comm, ep, p, M, D, st);
   WideGlue g;
   memset(&g, 0, sizeof(g));
@@ -144,6 +149,8 @@ struct LlmTpWs {
   bf16_t* ysh;          // hi/lo operand of the shared slice's down projection [2][rows][shared_inter]
   float* psh;           // its split-K slabs
   int ks_sh3;
+  // <= 64 rows: K-slice slabs of the weight-streaming kernels (QKV / dense / gate x 2 / shared gate-up), grouped expert slabs
+  float *pps, *p1, *p2;
 };
 
 static bool llm_tp_ok(const mn_llm* m, const mn_llm_tp* tp, const mn_tp_comm* c, int rows) {
@@ -163,7 +170,25 @@ static size_t llm_tp_carve(const mn_llm* m, const mn_llm_tp* tp, int rows, int64
   // ... + the shared slice: its down projection's slabs share pp (sized below), its operand is ysh
   o->ks_sh3 = tp->shared_inter ? rf_wide_ksplit(rows, m->hidden, tp->shared_inter) : 1;
   o->ysh = cv.take<bf16_t>((size_t)2 * rows * (tp->shared_inter ? tp->shared_inter : 64));
-  o->psh = cv.take<float>((size_t)mn_gemm256_slices(tp->shared_inter ? tp->shared_inter : 64, o->ks_sh3) * rows * m->hidden);
+  const int SIc = tp->shared_inter ? tp->shared_inter : 64;
+  size_t psh = (size_t)mn_gemm256_slices(SIc, o->ks_sh3) * rows * m->hidden;
+  o->pps = o->p1 = o->p2 = nullptr;
+  if (rows <= 64) {
+    const int H = m->hidden, ad = m->n_q * m->head_dim, qkv_dim = (m->n_q + 2 * m->n_kv) * m->head_dim, I = m->moe_inter;
+    const size_t Pn = (size_t)rows * m->top_k;
+    size_t pmax = (size_t)mn_stream_mfma_slices(rows, qkv_dim, H) * qkv_dim;
+    const size_t c2 = (size_t)mn_stream_mfma_slices(rows, H, ad) * H, c3 = (size_t)2 * mn_stream_mfma_slices(rows, m->n_experts, H) * m->n_experts;
+    const size_t c4 = (size_t)mn_stream_mfma_slices(rows, 2 * SIc, H) * 2 * SIc;
+    if (c2 > pmax) pmax = c2;
+    if (c3 > pmax) pmax = c3;
+    if (c4 > pmax) pmax = c4;
+    const size_t s3 = (size_t)mn_stream_mfma_slices(rows, H, SIc) * rows * H;
+    if (s3 > psh) psh = s3;
+    o->pps = cv.take<float>(pmax * rows);
+    o->p1 = cv.take<float>((size_t)mn_stream_mfma_grouped_slices(m->n_experts, rows, 2 * I, H) * Pn * 2 * I);
+    o->p2 = cv.take<float>((size_t)mn_stream_mfma_grouped_slices(m->n_experts, rows, H, I) * Pn * H);
+  }
+  o->psh = cv.take<float>(psh);
   return off + cv.off;
 }
 
@@ -197,6 +222,7 @@ extern "C" int mn_llm_step_tp(const mn_llm* m, const mn_llm_tp* tp, mn_tp_comm* 
   int seg = 0;
   uint32_t ep = comm->epoch;                       // epoch of the all-reduce the NEXT consumer waits for
   auto on = [&]() { return seg >= seg_begin && seg < seg_end; };
+  const bool streaming = M <= 64 && (I % 8) == 0 && (SI % 8) == 0;
   WideGlue g;
   for (int l = 0; l <= m->n_layers; ++l) {
     const bool fin = l == m->n_layers;
@@ -216,21 +242,32 @@ extern "C" int mn_llm_step_tp(const mn_llm* m, const mn_llm_tp* tp, mn_tp_comm* 
     float* kv_l = kv_cache + (int64_t)l * layer_kv;
     if (on()) {
       // local heads: QKV rows of this rank -> RoPE + KV append (its KV head) -> masked GQA -> dense over its columns  (:743-829)
-      mn_g256 a = g256_hilo(w.yh, H, (int64_t)M * H, m->wqkv[l], H, nullptr, w.pp, qkv_dim, M, qkv_dim, H);
-      a.c_zstride = (int64_t)M * qkv_dim;
-      int nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks_qkv, stream);
+      mn_g256 a;
+      int nz;
+      float* pp = streaming ? tw.pps : w.pp;        // <= 64 rows: the weight-streaming MFMA kernels on the shard's slices
+      if (streaming) {
+        nz = mn_stream_mfma(w.yh, m->wqkv[l], pp, M, qkv_dim, H, stream);
+      } else {
+        a = g256_hilo(w.yh, H, (int64_t)M * H, m->wqkv[l], H, nullptr, pp, qkv_dim, M, qkv_dim, H);
+        a.c_zstride = (int64_t)M * qkv_dim;
+        nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks_qkv, stream);
+      }
       if (nz < 0) return nz;
-      MN_TRY(mn_rope_kv_from_partials(w.pp, qkv_dim, nz, (int64_t)M * qkv_dim, M, nq, nkv, hd, 1, m->cos_tab, m->sin_tab, row_seq,
+      MN_TRY(mn_rope_kv_from_partials(pp, qkv_dim, nz, (int64_t)M * qkv_dim, M, nq, nkv, hd, 1, m->cos_tab, m->sin_tab, row_seq,
                                       row_slot, row_pos, m->mrope_sec_t, m->mrope_sec_h, q_scale, w.q, kv_l, t_max, stream));
       MN_TRY(mn_attn_decode_split(w.q, M, nq, nkv, hd, kv_l, t_max, row_seq, row_len, key_mask, ld_mask, nullptr, w.ya, w.attn_ws,
                                   w.attn_ws_bytes, stream));
-      a = g256_hilo(w.ya, ad, (int64_t)M * ad, m->wdense[l], ad, nullptr, w.pp, H, M, H, ad);
-      a.c_zstride = (int64_t)M * H;
-      nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks_dense, stream);
+      if (streaming) {
+        nz = mn_stream_mfma(w.ya, m->wdense[l], pp, M, H, ad, stream);
+      } else {
+        a = g256_hilo(w.ya, ad, (int64_t)M * ad, m->wdense[l], ad, nullptr, pp, H, M, H, ad);
+        a.c_zstride = (int64_t)M * H;
+        nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks_dense, stream);
+      }
       if (nz < 0) return nz;
       TpPush p;                                     // all-reduce 1: the dense partial of this rank's heads
       memset(&p, 0, sizeof(p));
-      p.P = w.pp; p.nz = nz; p.slab = (int64_t)M * H;
+      p.P = pp; p.nz = nz; p.slab = (int64_t)M * H;
       tp_push(comm, ep + 1, p, M, H, st);
     }
     ++seg; ++ep;
@@ -240,47 +277,83 @@ extern "C" int mn_llm_step_tp(const mn_llm* m, const mn_llm_tp* tp, mn_tp_comm* 
       g.h = w.h; g.ldh = H; tp_consume(g, comm, ep); g.h_out = w.h; g.ldho = H;
       g.norm = 1; g.ng = m->ln2[l]; g.eps = m->rms_eps; g.Y = w.yh; g.ldy = H; g.y_lo_off = (int64_t)M * H; g.M = M; g.D = H;
       wide_glue(g, st);
-      mn_g256 a = g256_hilo(w.yh, H, (int64_t)M * H, m->gate[l], H, nullptr, w.pp, E, M, E, H);
-      a.c_zstride = (int64_t)M * E;
-      int nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks_gate, stream);
+      mn_g256 a;
+      int nz;
+      float* pp = streaming ? tw.pps : w.pp;
+      if (streaming) {
+        nz = mn_stream_mfma(w.yh, m->gate[l], pp, M, E, H, stream);
+      } else {
+        a = g256_hilo(w.yh, H, (int64_t)M * H, m->gate[l], H, nullptr, pp, E, M, E, H);
+        a.c_zstride = (int64_t)M * E;
+        nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks_gate, stream);
+      }
       if (nz < 0) return nz;
       const float* p_img = nullptr;
       if (image_mask && m->image_gate && m->image_gate[l]) {
-        float* pi = w.pp + (int64_t)nz * M * E;
-        a = g256_hilo(w.yh, H, (int64_t)M * H, m->image_gate[l], H, nullptr, pi, E, M, E, H);
-        a.c_zstride = (int64_t)M * E;
-        const int nzi = mn_gemm256_ex(&a, MN_G256_F32, w.ks_gate, stream);
+        float* pi = pp + (int64_t)nz * M * E;
+        int nzi;
+        if (streaming) {
+          nzi = mn_stream_mfma(w.yh, m->image_gate[l], pi, M, E, H, stream);
+        } else {
+          a = g256_hilo(w.yh, H, (int64_t)M * H, m->image_gate[l], H, nullptr, pi, E, M, E, H);
+          a.c_zstride = (int64_t)M * E;
+          nzi = mn_gemm256_ex(&a, MN_G256_F32, w.ks_gate, stream);
+        }
         if (nzi < 0) return nzi;
+        if (nzi != nz) { mn_set_error("mn_llm_step_tp: gate / image gate slab counts differ"); return MN_EINVAL; }
         p_img = pi;
       }
-      hipLaunchKernelGGL(moe_topk_partials_kernel, dim3(mn_cdiv(M, 4)), dim3(256), 0, st, (const float*)w.pp, p_img, image_mask, nz,
+      hipLaunchKernelGGL(moe_topk_partials_kernel, dim3(mn_cdiv(M, 4)), dim3(256), 0, st, (const float*)pp, p_img, image_mask, nz,
                          (int64_t)M * E, M, E, m->top_k, m->norm_topk_prob, 0, w.ti, w.tw);
       MN_TRY(mn_ep_dispatch(w.ti, M, n_slot, E, e0, e1 - e0, w.cnt, w.off, w.perm, w.slot_of, 128, w.tile_g, w.tile_m0, w.n_tiles, stream));
-      // local experts (weights biased by -e0 groups: only local group ids appear in the tile list)  (:617-628, 483-484)
-      a = g256_hilo(w.yh, H, (int64_t)M * H, m->w_gate_up[l] - (int64_t)e0 * 2 * I * H, H, nullptr, w.y2, I, M, I, H);
-      a.w_pair_rows = I; a.c_lo_off = P * I;
-      a.g_off = w.off; a.g_cnt = w.cnt; a.w_gstride = (int64_t)2 * I * H; a.a_rows = w.perm; a.n_groups = E;
-      a.tile_g = w.tile_g; a.tile_m0 = w.tile_m0; a.n_tiles = w.n_tiles; a.max_mtiles = w.max_mtiles;
-      MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
-      a = g256_hilo(w.y2, I, P * I, m->w_down[l] - (int64_t)e0 * H * I, I, nullptr, w.yg, H, M, H, I);
-      a.g_off = w.off; a.g_cnt = w.cnt; a.w_gstride = (int64_t)H * I; a.n_groups = E;
-      a.tile_g = w.tile_g; a.tile_m0 = w.tile_m0; a.n_tiles = w.n_tiles; a.max_mtiles = w.max_mtiles;
-      MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
-      // this rank's slice of the shared expert (column-parallel gate/up, row-parallel down)  (:599-606)
-      int nzs = 0;
-      if (SI) {
-        a = g256_hilo(w.yh, H, (int64_t)M * H, tp->ws_gate_up[l], H, nullptr, tw.ysh, SI, M, SI, H);
-        a.w_pair_rows = SI; a.c_lo_off = (int64_t)M * SI;
-        MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
-        a = g256_hilo(tw.ysh, SI, (int64_t)M * SI, tp->ws_down[l], SI, nullptr, psh, H, M, H, SI);
-        a.c_zstride = (int64_t)M * H;
-        nzs = mn_gemm256_ex(&a, MN_G256_F32, tw.ks_sh3, stream);
-        if (nzs < 0) return nzs;
-      }
       TpPush p;                                     // all-reduce 2: local experts' weighted sum + shared slice
       memset(&p, 0, sizeof(p));
+      int nzs = 0;
+      if (streaming) {
+        // local experts on the grouped K-loop kernel: group g of the window = expert e0 + g, its rows are the sorted positions
+        // [off[e0 + g], off[e0 + g + 1]) of the GLOBAL sort (gathered through perm); every distinct local expert is streamed once
+        int nz1 = mn_stream_mfma_grouped(w.yh, M, m->w_gate_up[l], (int64_t)2 * I * H, tw.p1, (int)P, w.off + e0, w.perm, e1 - e0, M,
+                                         2 * I, H, stream);
+        if (nz1 < 0) return nz1;
+        hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv(P * I, 1024)), dim3(256), 0, st, (const float*)tw.p1, nz1, (int)P, I,
+                           (const bf16_t*)nullptr, w.y2);
+        const int nz2 = mn_stream_mfma_grouped(w.y2, (int)P, m->w_down[l], (int64_t)H * I, tw.p2, (int)P, w.off + e0, nullptr, e1 - e0, M,
+                                               H, I, stream);
+        if (nz2 < 0) return nz2;
+        p.cy = tw.p2; p.cy_nz = nz2; p.cy_slab = P * H;
+        if (SI) {
+          int nzg = mn_stream_mfma(w.yh, tp->ws_gate_up[l], pp, M, 2 * SI, H, stream);
+          if (nzg < 0) return nzg;
+          hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)M * SI, 1024)), dim3(256), 0, st, (const float*)pp, nzg, M,
+                             SI, (const bf16_t*)nullptr, tw.ysh);
+          nzs = mn_stream_mfma(tw.ysh, tp->ws_down[l], psh, M, H, SI, stream);
+          if (nzs < 0) return nzs;
+        }
+      } else {
+        // local experts (weights biased by -e0 groups: only local group ids appear in the tile list)  (:617-628, 483-484)
+        a = g256_hilo(w.yh, H, (int64_t)M * H, m->w_gate_up[l] - (int64_t)e0 * 2 * I * H, H, nullptr, w.y2, I, M, I, H);
+        a.w_pair_rows = I; a.c_lo_off = P * I;
+        a.g_off = w.off; a.g_cnt = w.cnt; a.w_gstride = (int64_t)2 * I * H; a.a_rows = w.perm; a.n_groups = E;
+        a.tile_g = w.tile_g; a.tile_m0 = w.tile_m0; a.n_tiles = w.n_tiles; a.max_mtiles = w.max_mtiles;
+        MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
+        a = g256_hilo(w.y2, I, P * I, m->w_down[l] - (int64_t)e0 * H * I, I, nullptr, w.yg, H, M, H, I);
+        a.g_off = w.off; a.g_cnt = w.cnt; a.w_gstride = (int64_t)H * I; a.n_groups = E;
+        a.tile_g = w.tile_g; a.tile_m0 = w.tile_m0; a.n_tiles = w.n_tiles; a.max_mtiles = w.max_mtiles;
+        MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
+        p.cy = w.yg; p.cy_nz = 1;
+        // this rank's slice of the shared expert (column-parallel gate/up, row-parallel down)  (:599-606)
+        if (SI) {
+          a = g256_hilo(w.yh, H, (int64_t)M * H, tp->ws_gate_up[l], H, nullptr, tw.ysh, SI, M, SI, H);
+          a.w_pair_rows = SI; a.c_lo_off = (int64_t)M * SI;
+          MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
+          a = g256_hilo(tw.ysh, SI, (int64_t)M * SI, tp->ws_down[l], SI, nullptr, psh, H, M, H, SI);
+          a.c_zstride = (int64_t)M * H;
+          nzs = mn_gemm256_ex(&a, MN_G256_F32, tw.ks_sh3, stream);
+          if (nzs < 0) return nzs;
+        }
+      }
       if (SI) { p.P = psh; p.nz = nzs; p.slab = (int64_t)M * H; }
-      p.cy = w.yg; p.cpos = w.slot_of; p.cw = w.tw; p.ci = w.ti; p.n_slot = n_slot; p.e0 = e0; p.e1 = e1;
+      p.cpos = w.slot_of; p.cw = w.tw; p.ci = w.ti; p.n_slot = n_slot; p.e0 = e0; p.e1 = e1;
       tp_push(comm, ep + 1, p, M, H, st);
     }
     ++seg; ++ep;
@@ -295,9 +368,21 @@ extern "C" int mn_llm_step_tp(const mn_llm* m, const mn_llm_tp* tp, mn_tp_comm* 
 // ===========================================================================================
 extern "C" int mn_rf_tp_segments(const mn_rf_head* h) { return h->steps * h->depth + 1; }
 
+// the wide route's carve on the shard + room in pbuf for the streaming kernels' K-slice slabs (<= 64 rows)
+static size_t rf_tp_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, RfWideWs* o) {
+  const size_t off = rf_wide_carve(h, rows, ws, cap, o);
+  if (rows > 64) return off;
+  const size_t p12 = (size_t)mn_stream_mfma_slices(rows, 2 * h->hidden, h->w) * 2 * h->hidden * rows;
+  const size_t p3 = (size_t)mn_stream_mfma_slices(rows, h->w, h->hidden) * h->w * rows;
+  Carver cv(ws ? (char*)ws + off : nullptr, cap > off ? cap - off : 0, ws == nullptr);
+  float* pb = cv.take<float>(p12 > p3 ? p12 : p3);
+  if (ws) o->pbuf_stream = pb;
+  return off + cv.off;
+}
+
 extern "C" size_t mn_rf_tp_workspace_bytes(const mn_rf_head* h, int rows) {
   RfWideWs w;
-  return rf_wide_carve(h, rows, nullptr, 0, &w);
+  return rf_tp_carve(h, rows, nullptr, 0, &w);
 }
 
 // h: the rank's shard — hidden = its share of the SwiGLU width (w12 [2 * hidden, w] gate rows then up rows, b12 [2 * hidden],
@@ -313,8 +398,10 @@ extern "C" int mn_rf_sample_tp(const mn_rf_head* h, mn_tp_comm* comm, const floa
   const int n_seg = h->steps * h->depth + 1;
   MN_CHECK_ARG(seg_begin >= 0 && seg_begin < seg_end && seg_end <= n_seg, "mn_rf_sample_tp: segments [%d, %d) of %d", seg_begin, seg_end, n_seg);
   RfWideWs w;
-  const size_t need = rf_wide_carve(h, rows, workspace, workspace_bytes, &w);
+  const size_t need = rf_tp_carve(h, rows, workspace, workspace_bytes, &w);
   if (need > workspace_bytes) { mn_set_error("mn_rf_sample_tp: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
+  float* pbuf_wide = w.pbuf;                        // the replicated final Linear keeps the wide route's slab area
+  if (rows <= 64) w.pbuf = w.pbuf_stream;
   hipStream_t st = mn_stream(stream);
   const int W = h->w, HID = h->hidden, T = h->target, A = h->depth * 3 * W + 2 * W, rpi = rows / n_images;
   const int64_t SR = (int64_t)h->steps * rows;
@@ -325,24 +412,37 @@ extern "C" int mn_rf_sample_tp(const mn_rf_head* h, mn_tp_comm* comm, const floa
   auto on = [&]() { return seg >= seg_begin && seg < seg_end; };
   WideGlue g;
   mn_g256 a;
-  // block b of a step on this rank's hidden units: w12 (SwiGLU in the epilogue or split-K + slab SwiGLU) -> w3 slabs -> push
+  // block b of a step on this rank's hidden units: w12 -> SwiGLU -> w3 partial slabs -> push.  Up to 64 rows the two GEMMs are the
+  // weight-streaming MFMA kernels of the <= 64-row route (the shard's bytes are what a launch costs there: 12.6 + 6.3 MB per block at
+  // TP = 8 against 100.7 + 50.3 unsharded); above, gemm256 like the wide route.
+  const bool streaming = rows <= 64;
   auto block_gemms = [&](int b) -> int {
-    if (w.ks12 > 1) {
-      a = g256_hilo(w.ya, W, lo_a, h->w12[b], W, nullptr, w.pbuf, 2 * HID, rows, 2 * HID, W);
-      a.c_zstride = (int64_t)rows * 2 * HID;
-      const int nz12 = mn_gemm256_ex(&a, MN_G256_F32, w.ks12, stream);
-      if (nz12 < 0) return nz12;
-      hipLaunchKernelGGL(rf_swiglu_slabs_kernel, dim3(mn_cdiv((int64_t)rows * (HID / 4), 256)), dim3(256), 0, st, w.pbuf, nz12,
-                         (int64_t)rows * 2 * HID, h->b12[b], w.yb, lo_b, rows, HID);
+    int nz;
+    if (streaming) {
+      nz = mn_stream_mfma(w.ya, h->w12[b], w.pbuf, rows, 2 * HID, W, stream);
+      if (nz < 0) return nz;
+      hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)rows * HID, 1024)), dim3(256), 0, st, (const float*)w.pbuf, nz,
+                         rows, HID, h->b12[b], w.yb);
+      nz = mn_stream_mfma(w.yb, h->w3[b], w.pbuf, rows, W, HID, stream);
+      if (nz < 0) return nz;
     } else {
-      a = g256_hilo(w.ya, W, lo_a, h->w12[b], W, h->b12[b], w.yb, HID, rows, HID, W);
-      a.w_pair_rows = HID; a.c_lo_off = lo_b;
-      MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
+      if (w.ks12 > 1) {
+        a = g256_hilo(w.ya, W, lo_a, h->w12[b], W, nullptr, w.pbuf, 2 * HID, rows, 2 * HID, W);
+        a.c_zstride = (int64_t)rows * 2 * HID;
+        const int nz12 = mn_gemm256_ex(&a, MN_G256_F32, w.ks12, stream);
+        if (nz12 < 0) return nz12;
+        hipLaunchKernelGGL(rf_swiglu_slabs_kernel, dim3(mn_cdiv((int64_t)rows * (HID / 4), 256)), dim3(256), 0, st, w.pbuf, nz12,
+                           (int64_t)rows * 2 * HID, h->b12[b], w.yb, lo_b, rows, HID);
+      } else {
+        a = g256_hilo(w.ya, W, lo_a, h->w12[b], W, h->b12[b], w.yb, HID, rows, HID, W);
+        a.w_pair_rows = HID; a.c_lo_off = lo_b;
+        MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
+      }
+      a = g256_hilo(w.yb, HID, lo_b, h->w3[b], HID, nullptr, w.pbuf, W, rows, W, HID);
+      a.c_zstride = (int64_t)rows * W;
+      nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks3, stream);
+      if (nz < 0) return nz;
     }
-    a = g256_hilo(w.yb, HID, lo_b, h->w3[b], HID, nullptr, w.pbuf, W, rows, W, HID);
-    a.c_zstride = (int64_t)rows * W;
-    const int nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks3, stream);
-    if (nz < 0) return nz;
     TpPush p;
     memset(&p, 0, sizeof(p));
     p.P = w.pbuf; p.nz = nz; p.slab = (int64_t)rows * W;
@@ -398,11 +498,11 @@ extern "C" int mn_rf_sample_tp(const mn_rf_head* h, mn_tp_comm* comm, const floa
           MN_TRYZ(block_gemms(b + 1));
         } else {
           // replicated tail of the step: final Linear -> bias -> CFG combine + Euler step  (diff_loss:144-179, 291)
-          a = g256_hilo(w.ya, W, lo_a, h->fin_w, W, nullptr, w.pbuf, T, rows, T, W);
+          a = g256_hilo(w.ya, W, lo_a, h->fin_w, W, nullptr, pbuf_wide, T, rows, T, W);
           a.c_zstride = (int64_t)rows * T;
           const int nz = mn_gemm256_ex(&a, MN_G256_F32, w.ksf, stream);
           if (nz < 0) return nz;
-          hipLaunchKernelGGL(rf_glue_bias_out_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, w.pbuf, nz, rows, T, h->fin_b, w.v);
+          hipLaunchKernelGGL(rf_glue_bias_out_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, pbuf_wide, nz, rows, T, h->fin_b, w.v);
           hipLaunchKernelGGL(rf_euler_kernel, dim3(n_images), dim3(256), 0, st, w.v, w.x, rpi, T, text_cfg, image_cfg, step);
           if (s + 1 == h->steps)
             hipLaunchKernelGGL(rf_gather_latent_kernel, dim3(mn_cdiv(n_images * T, 256)), dim3(256), 0, st, w.x, latent_out, n_images, rpi, T);

@@ -32,6 +32,7 @@ static inline int64_t lo_at(int site, int64_t off) { return ((g_lo_drop >> site)
 
 struct RfWideWs {
   float *z, *c, *ada, *hh, *v, *x, *pbuf;
+  float* pbuf_stream;    // tp.inl, <= 64 rows: K-slice slabs of the weight-streaming kernels
   bf16_t *hs, *zs, *y, *ya, *yb;
   int ks12, ks3, ksf;    // split-K requests of the w12 (1 = SwiGLU in the GEMM epilogue), w3 and final GEMMs
 };

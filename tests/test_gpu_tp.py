@@ -165,6 +165,60 @@ def test_tp_llm_step_tiny_matches_unsharded_and_reference(world):
     grp.check_err()
 
 
+def test_tp_wide_rows_match_unsharded():
+    """Above 64 rows the TP composites run on gemm256 (the wide route's kernels) instead of the weight-streaming ones: 70 rows of
+    the tiny decoder (ragged cache lengths, holey masks, image-gate rows) on 2 ranks, and 66 rows of a small RF head on 4 ranks,
+    against the unsharded path."""
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder
+    from ming_univision_amd.rf_head import RectifiedFlowHead
+    from ming_univision_amd.synth import synth_tensor
+    from ming_univision_amd.tp import TpCommunicator, TpRfShard, TpSimGroup
+    g = load_golden("llm_tiny")
+    cfg = C.BailingMoeConfig(**g["config"])
+    dec = BailingMoeDecoder.from_state_dict(cfg, _dev(llm_sd(g["config"], g["rf_config"], g["seed"])), t_max=48, n_seq=70)
+    grp = TpSimGroup(dec, None, 2, rows_cap=128)
+    gen = torch.Generator().manual_seed(0)
+    M = 70
+    kv0 = torch.randn(dec.kv_cache.shape, generator=gen).cuda() * 0.5
+    dec.kv_cache.copy_(kv0)
+    for r, sh in enumerate(grp.shards):
+        k0 = (r * sh.plan["n_q"] * cfg.num_key_value_heads) // cfg.num_attention_heads
+        sh.kv_cache.copy_(kv0[:, :, :, k0:k0 + sh.plan["n_kv"]])
+    x = torch.randn(M, cfg.hidden_size, generator=gen).cuda()
+    slot = torch.randint(5, 40, (M,), generator=gen).to(torch.int32).cuda()
+    seq = torch.arange(M, dtype=torch.int32).cuda()
+    km = (torch.rand(M, 48, generator=gen) > 0.2).to(torch.uint8)
+    km[torch.arange(M), slot.cpu().long()] = 1
+    km = km.cuda()
+    im = (torch.arange(M) % 3 == 0).to(torch.uint8).cuda()
+    h_tp = grp.step(x, seq, slot, slot, slot + 1, km, im)
+    h_full = dec.step(x, seq, slot, slot, slot + 1, km, im)
+    grp.check_err()
+    assert rel_err(h_tp, h_full) < 2e-4
+    for o in grp.last_rank_outputs[1:]:
+        assert torch.equal(o, grp.last_rank_outputs[0])
+    # RF head: w = 384, hidden 1024 -> 256 per rank, 66 rows (33 images x 2 CFG rows)
+    rf_cfg = dict(diffloss_w=384, diffloss_d=2, num_sampling_steps="3", gen_method="flow_matching_swiglu-4")
+    shapes = C.rf_param_shapes(384, 2, 384, 32, 4)
+    shapes.update({"vis_head.0.weight": (384, 256), "vis_head.0.bias": (384,), "vis_head.1.weight": (384,), "vis_head.1.bias": (384,)})
+    sd = {k: synth_tensor(k, s_, 3, "cuda", torch.bfloat16) for k, s_ in shapes.items()}
+    rf = RectifiedFlowHead(sd, 256, rf_cfg)
+    world = 4
+    shards = [TpRfShard(rf, r, world) for r in range(world)]
+    comms = TpCommunicator.simulated(world, rows_cap=128, width=rf.w)
+    hidden = torch.randn(66, 256, generator=gen).cuda()
+    noise = torch.randn(33, 32, generator=gen).cuda()
+    ref = rf.sample(hidden, noise, n_images=33)
+    outs = [torch.empty_like(ref) for _ in range(world)]
+    for seg in range(shards[0].n_segments()):
+        for r in range(world):
+            shards[r].sample_tp(comms[r], hidden, noise, out=outs[r], n_images=33, seg_begin=seg, seg_end=seg + 1)
+    for r in range(world):
+        comms[r].check_err()
+    err = (outs[0] - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)
+    assert float(err.max()) < 2e-4, float(err.max())
+
+
 def test_tp_relayed_transport_matches_unsharded():
     """The RCCL fallback transport (TpCommunicator.relayed: pushes stay local, an all-gather over the process group delivers them
     between two segments) with a loop-back process group standing in for RCCL: two ranks of the tiny decoder, prefill + decode."""
