@@ -346,6 +346,31 @@ class TpRfShard:
         return out
 
 
+def ops_lmhead(hidden, lm_slice, vocab0):
+    from . import ops
+    idx, val = ops.lmhead_argmax(hidden.contiguous(), lm_slice, vocab_offset=vocab0)
+    return idx, val
+
+
+def vocab_parallel_pick(dist, pair):
+    """(idx int64 [M], val fp32 [M]) of this rank's vocabulary slice -> the global greedy ids [M]: the pair with the largest logit,
+    the lowest id among equals (selection over `world` candidates per row; the logits themselves come from mn_lmhead_argmax)."""
+    idx, val = pair
+    world = dist.get_world_size()
+    idxs = [torch.empty_like(idx) for _ in range(world)]
+    vals = [torch.empty_like(val) for _ in range(world)]
+    dist.all_gather(idxs, idx)
+    dist.all_gather(vals, val)
+    return pick_best(torch.stack(idxs), torch.stack(vals))
+
+
+def pick_best(idxs, vals):
+    """idxs / vals [world, M] -> [M]: max logit, ties -> lowest id."""
+    best = vals.max(dim=0).values
+    cand = torch.where(vals == best.unsqueeze(0), idxs, torch.full_like(idxs, torch.iinfo(torch.int64).max))
+    return cand.min(dim=0).values
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # one rank of a real TP group / all ranks simulated on one GPU — both expose the decoder + sampler interface of generate_images
 # ------------------------------------------------------------------------------------------------------------------------
@@ -426,6 +451,14 @@ class TpSimGroup(_TpDecoderBase):
         for sh in self.shards:
             sh.kv_cache[:, dst, :, :, :n].copy_(sh.kv_cache[:, src, :, :, :n])
 
+    def greedy(self, hidden):
+        """The vocabulary-parallel greedy pick of TpRank.greedy with every rank's slice computed in this process."""
+        lm = self.full.lm_head
+        V = lm.shape[0]
+        n = -(-V // self.world)
+        pairs = [ops_lmhead(hidden, lm[min(V, r * n):min(V, (r + 1) * n)], min(V, r * n)) for r in range(self.world) if r * n < V]
+        return pick_best(torch.stack([p[0] for p in pairs]), torch.stack([p[1] for p in pairs]))
+
     # -- RF sampler ----------------------------------------------------------------------------------------------
     def rf_max_rows(self):
         return min(2048, self.rows_cap)
@@ -468,6 +501,7 @@ class TpRank(_TpDecoderBase):
         """dec: the full decoder (its weights are sliced) or None with a prebuilt `shard` (TpDecoderShard.synthetic) plus the
         replicated embed / logits callables."""
         self.full, self.rf_full, self.rows_cap, self.transport = dec, rf, rows_cap, transport
+        self._dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.shard = shard if shard is not None else TpDecoderShard(dec, self.rank, self.world)
         src = dec if dec is not None else self.shard
@@ -484,6 +518,16 @@ class TpRank(_TpDecoderBase):
 
     def logits(self, hidden):
         return self._logits(hidden) if self._logits is not None else self.full.logits(hidden)
+
+    def greedy(self, hidden):
+        """Greedy pick with the lm_head split over the vocabulary (each rank streams V / world rows of it): mn_lmhead_argmax on the
+        rank's slice with its vocabulary offset, then the ranks' (logit, id) pairs are gathered over the process group and the
+        best pair wins — ties to the lowest id, like the unsharded arg-max."""
+        lm = self.full.lm_head
+        V = lm.shape[0]
+        n = -(-V // self.world)
+        v0, v1 = min(V, self.rank * n), min(V, (self.rank + 1) * n)
+        return vocab_parallel_pick(self._dist, ops_lmhead(hidden, lm[v0:v1], v0))
 
     def _segmented(self, call, n_seg, n_floats):
         """Relayed transport: run the composite one segment at a time, delivering each all-reduce through the process group."""

@@ -78,9 +78,9 @@ def full_ref():
     return dict(cfg=cfg, dsd=dsd, rf=rf, tok=tok, ids=ids, noises=noises, am=am, un=un, ref=ref, T=T, g=g)
 
 
-@pytest.mark.parametrize("n_images", [200, 768])
+@pytest.mark.parametrize("n_images", [200, 768, 1024])
 def test_full_width_bench_operating_point_vs_oracle(full_ref, n_images):
-    """400 and 1536 CFG rows in one lock-step group — bench.py's default is 768 images = 1536 rows: w12 with the SwiGLU epilogue
+    """400, 1536 and 2048 (the maximum) CFG rows in one lock-step group — bench.py's default is 768 images = 1536 rows: w12 with the SwiGLU epilogue
     (>= 385 rows), w3 split-K, grouped experts with full and remainder row tiles, prompts prefilled in lock-step on the wide route.
     Image 0 carries the oracle's prompt and noise; the other images have their own noise."""
     from ming_univision_amd.bailing_moe import BailingMoeDecoder, generate_images

@@ -142,6 +142,7 @@ def test_tp_llm_step_tiny_matches_unsharded_and_reference(world):
     h_tp = grp.prefill(emb, seq=0, past=0, image_mask=g["image_mask"][0])
     h_full = dec.prefill(emb, seq=0, past=0, image_mask=g["image_mask"][0])
     grp.check_err()
+    assert grp.greedy(h_tp).tolist() == dec.greedy(h_full).tolist()          # lm_head split over the vocabulary: same greedy ids
     assert rel_err(h_tp, g["hidden"][0]) < TOL
     assert rel_err(h_tp, h_full) < 2e-4
     for o in grp.last_rank_outputs[1:]:

@@ -364,3 +364,11 @@ def test_tp_shard_plan_16b_a3b():
         shard_plan(cfg, 3)
     with pytest.raises(ValueError):
         shard_plan(cfg, 32)                                        # 16 q heads do not split 32 ways
+
+
+def test_tp_vocab_parallel_pick_rule():
+    """The reduce of the ranks' (logit, id) pairs of a vocabulary-split lm_head: largest logit, lowest id among equals."""
+    from ming_univision_amd.tp import pick_best
+    vals = torch.tensor([[1.0, 5.0, 2.0], [3.0, 5.0, 2.0], [3.0, 4.0, -1.0]])
+    idxs = torch.tensor([[7, 900, 11], [1000, 20, 12], [40, 30, 13]])
+    assert pick_best(idxs, vals).tolist() == [40, 20, 11]
