@@ -60,6 +60,17 @@ __global__ __launch_bounds__(1024) void wide_glue_kernel(const WideGlue p) {
     __syncthreads();
   }
   f4 v = {0.f, 0.f, 0.f, 0.f};
+  // modulation and norm parameters of this thread's columns are requested with the row, not behind the reductions' barriers
+  f4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  u2 ng2 = {0u, 0u}, nb2 = {0u, 0u};
+  if (act) {
+    if (p.scale) {
+      sc = *reinterpret_cast<const f4*>(p.scale + (int64_t)m * p.ldmod + col);
+      sh = *reinterpret_cast<const f4*>(p.shift + (int64_t)m * p.ldmod + col);
+    }
+    if (p.norm && p.ng) ng2 = *reinterpret_cast<const u2*>(p.ng + col);
+    if (p.norm == 2 && p.nb) nb2 = *reinterpret_cast<const u2*>(p.nb + col);
+  }
   if (act) {
     if (p.xin) {
       float o[4];
@@ -110,8 +121,8 @@ __global__ __launch_bounds__(1024) void wide_glue_kernel(const WideGlue p) {
   if (p.norm == 1) {
     const float ss = block_sum(act ? v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w : 0.f, red);
     const float rstd = rsqrtf(ss / (float)D + p.eps);
-    if (act) v = f4{v.x * rstd * bf16_to_f32(p.ng[col]), v.y * rstd * bf16_to_f32(p.ng[col + 1]),
-                    v.z * rstd * bf16_to_f32(p.ng[col + 2]), v.w * rstd * bf16_to_f32(p.ng[col + 3])};
+    if (act) v = f4{v.x * rstd * bf16lo_to_f32(ng2.x), v.y * rstd * bf16hi_to_f32(ng2.x),
+                    v.z * rstd * bf16lo_to_f32(ng2.y), v.w * rstd * bf16hi_to_f32(ng2.y)};
   } else if (p.norm == 2) {
     const float mean = block_sum(act ? (v.x + v.y) + (v.z + v.w) : 0.f, red) / (float)D;
     float ss = 0.f;
@@ -119,20 +130,18 @@ __global__ __launch_bounds__(1024) void wide_glue_kernel(const WideGlue p) {
     const float rstd = rsqrtf(block_sum(ss, red) / (float)D + p.eps);
     if (act) {
       float o[4] = {(v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd};
+      const float gq[4] = {bf16lo_to_f32(ng2.x), bf16hi_to_f32(ng2.x), bf16lo_to_f32(ng2.y), bf16hi_to_f32(ng2.y)};
+      const float bq[4] = {bf16lo_to_f32(nb2.x), bf16hi_to_f32(nb2.x), bf16lo_to_f32(nb2.y), bf16hi_to_f32(nb2.y)};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (p.ng) o[j] *= bf16_to_f32(p.ng[col + j]);
-        if (p.nb) o[j] += bf16_to_f32(p.nb[col + j]);
+        if (p.ng) o[j] *= gq[j];
+        if (p.nb) o[j] += bq[j];
       }
       v = f4{o[0], o[1], o[2], o[3]};
     }
   }
   if (!act) return;
-  if (p.scale) {
-    const f4 sc = *reinterpret_cast<const f4*>(p.scale + (int64_t)m * p.ldmod + col);
-    const f4 sh = *reinterpret_cast<const f4*>(p.shift + (int64_t)m * p.ldmod + col);
-    v = v * (1.0f + sc) + sh;
-  }
+  if (p.scale) v = v * (1.0f + sc) + sh;
   if (p.act == 1) v = f4{gelu_erf_f(v.x), gelu_erf_f(v.y), gelu_erf_f(v.z), gelu_erf_f(v.w)};
   if (p.out) *reinterpret_cast<f4*>(p.out + (int64_t)m * p.ldo + col) = v;
   if (p.Y) {
