@@ -21,7 +21,7 @@ extern "C" MN_DEV_API void mn_wide_tune(int llm_min_rows, int rf_min_rows, int s
 #endif
 
 // Per-site single-pass switch (measurement only, DESIGN.md §2 "lo-pass map"): bit s set = the activation operand of site s enters
-// its GEMM as plain bf16 (hi rows only).  The product build has no way to set it; tools/exp/lo_map.py does through the dev library.
+// its GEMM as plain bf16 (hi rows only).  The product build has no way to set it; tests/measure/lo_map.py does through the dev library.
 enum { LO_RF_VIS = 0, LO_RF_COND, LO_RF_ADA, LO_RF_W12, LO_RF_W3, LO_RF_FIN, LO_LLM_QKV, LO_LLM_DENSE, LO_LLM_GATE, LO_LLM_EXPERTS,
        LO_SEM_QKV, LO_SEM_PROJ, LO_SEM_W12, LO_SEM_W3, LO_SEM_LP };
 static unsigned g_lo_drop = 0;

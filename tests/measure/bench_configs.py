@@ -4,7 +4,7 @@
   C3  16B-A3B image->text understanding: 1024^2 image -> 1024 image tokens, ~1060-token prefill + 64 greedy decode steps
 Prints one JSON object per config."""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ming_univision_amd import configuration as C
 from ming_univision_amd.mingtok import MingTok
