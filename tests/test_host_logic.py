@@ -372,3 +372,41 @@ def test_tp_vocab_parallel_pick_rule():
     vals = torch.tensor([[1.0, 5.0, 2.0], [3.0, 5.0, 2.0], [3.0, 4.0, -1.0]])
     idxs = torch.tensor([[7, 900, 11], [1000, 20, 12], [40, 30, 13]])
     assert pick_best(idxs, vals).tolist() == [40, 20, 11]
+
+
+def test_hf_tokenizer_adapter_with_a_real_tokenizer_json(tmp_path):
+    """infer.HFTokenizerAdapter over a `tokenizers` tokenizer.json (what MingUniVisionInfer loads next to a checkpoint): a small
+    WordLevel tokenizer that carries the reference's special tokens at the reference's ids (tokenizer_config.json: 126340 / 126341
+    `<role>` / `</role>`, 126346-126348).  The processor's chat template, image-token expansion and CFG masks
+    (processing_bailingmm.py:282-361) must behave through it exactly as through the stand-in tokenizer: the uncond mask is zero
+    strictly between the last HUMAN tag and the next ASSISTANT tag, the text-uncond mask keeps the image tokens there."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from ming_univision_amd.infer import HFTokenizerAdapter
+    from ming_univision_amd.processing import SPECIAL_TOKEN_IDS
+    words = ["[UNK]", "HUMAN", "ASSISTANT", "SYSTEM", "describe", "this", "picture", "please", "a", "cat", "hello", "You", "are", "."]
+    vocab = {w: i for i, w in enumerate(words)}
+    vocab.update(SPECIAL_TOKEN_IDS)
+    tk = Tokenizer(models.WordLevel(vocab=vocab, unk_token="[UNK]"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    tk.add_special_tokens(list(SPECIAL_TOKEN_IDS))
+    path = tmp_path / "tokenizer.json"
+    tk.save(str(path))
+    ad = HFTokenizerAdapter(str(path))
+    assert ad.convert_tokens_to_ids("<imagePatch>") == 126346 and ad.convert_tokens_to_ids("<role>") == 126340
+    assert ad.encode("<role>HUMAN</role>") == [126340, vocab["HUMAN"], 126341]
+    proc = BailingMMProcessor(tokenizer=ad)
+    conv = [{"role": "HUMAN", "content": [{"type": "image", "image": "x.png"}, {"type": "text", "text": "describe this picture please"}]}]
+    text = proc.apply_chat_template(conv, add_generation_prompt=True)
+    out = proc(images=[torch.zeros(3, 64, 64)], text=[text], image_patch_size=32)
+    ids = out["input_ids"][0].tolist()
+    assert ids.count(126346) == 4 and ids.count(126347) == 1 and ids.count(126348) == 1
+    h = [i for i in range(len(ids) - 2) if ids[i:i + 3] == [126340, vocab["HUMAN"], 126341]][-1]
+    a = [i for i in range(len(ids) - 2) if ids[i:i + 3] == [126340, vocab["ASSISTANT"], 126341]][-1]
+    unc, tunc = out["uncond_attention_mask"][0].tolist(), out["text_uncond_attention_mask"][0].tolist()
+    for i, t in enumerate(ids):
+        inside = h + 3 <= i < a
+        assert unc[i] == (0 if inside else 1), i
+        assert tunc[i] == (0 if inside and t not in (126346, 126347, 126348) else 1), i
+    assert any(inside for inside in (h + 3 <= i < a for i in range(len(ids))))
+    assert ad.decode([vocab["a"], vocab["cat"], 126081], skip_special_tokens=True).split() == ["a", "cat"]
+    assert ad.batch_decode([[vocab["hello"]], [vocab["cat"], vocab["."]]]) == ["hello", "cat ."]
