@@ -406,6 +406,7 @@ class MingUniVisionForConditionalGeneration:
                             break
                     n_img += 1
                     self.last_image = out["image"]
+                    self.last_generation = out                           # latents / sem / last_hidden of the image (inspection, tests)
                     break                                                # speculative tokens behind `<image>` are dropped
             else:
                 cache_len += n                                           # every token of the chunk was fed

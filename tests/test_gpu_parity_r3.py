@@ -222,6 +222,69 @@ def test_image_to_text_full_width_vs_oracle():
     print("bf16 regime greedy tokens equal to the oracle's: %d of %d" % (n_same, n_new))
 
 
+def test_edit_round_image_in_image_out_vs_oracle(tmp_path):
+    """The editing round of BASELINE configs[4] on one GPU (tiny model): an input image (4 `<imagePatch>` tokens through MingTok +
+    linear_proj, image-gate rows in the prefill) and an instruction, processor-style CFG masks — uncond hides the whole user turn,
+    text-uncond keeps its image tokens, so generate_image runs THREE distinct CFG rows (:1867-1889) — then the generated image.
+    Latents, semantic tokens and the last hidden states against the oracle driven the way modeling_bailingmm.py:206-301 drives the
+    reference; then a follow-up text round on top of the cache (multi-round state)."""
+    from oracle import bailing_ref, mingtok_ref
+    from ming_univision_amd.processing import cfg_attention_masks
+    g = load_golden("genimg_tiny")
+    llm_cfg = dict(g["llm_config"]); llm_cfg.update(eos_token_id=1, image_patch_token=498)
+    sd = llm_sd(g["llm_config"], g["rf_config"], g["seed"])
+    tsd = mingtok_sd(g["mingtok_config"], g["seed"])
+    lsd = synth_state_dict(C.linear_proj_param_shapes(128, 256, 2), g["seed"])
+    sd_r, tsd_r, lsd_r = ({k: v.to(torch.bfloat16).float() for k, v in d.items()} for d in (sd, tsd, lsd))
+    model = _facade(llm_cfg, g["rf_config"], g["mingtok_config"], g["seed"], 64, 128, sd, tsd, lsd)
+    ocfg = bailing_ref.LLMConfig(**{k: v for k, v in llm_cfg.items() if k in bailing_ref.LLMConfig.__dataclass_fields__})
+    gen = torch.Generator().manual_seed(11)
+    px = torch.rand(1, 3, 64, 64, generator=gen) * 2 - 1
+    # <role>HUMAN</role> <image> 4 x <imagePatch> </image> text... <role>ASSISTANT</role>   (ids of a 512-word toy vocabulary)
+    ROLE, ROLE_E, HUMAN, ASSIST, IMG, IMG_E, PATCH = 490, 491, 300, 301, 496, 497, 498
+    ids = [ROLE, HUMAN, ROLE_E, IMG, PATCH, PATCH, PATCH, PATCH, IMG_E, 21, 22, 23, 24, ROLE, ASSIST, ROLE_E]
+    unc, tunc = cfg_attention_masks(ids, [ROLE, HUMAN, ROLE_E], [ROLE, ASSIST, ROLE_E], {IMG, IMG_E, PATCH})
+    assert unc != tunc and sum(tunc) > sum(unc)
+    ids_t = torch.tensor([ids]); T = len(ids)
+    am = torch.ones(1, T, dtype=torch.long)
+    unc_t, tunc_t = torch.tensor([unc]), torch.tensor([tunc])
+    n_tok = llm_cfg["num_image_tokens_for_gen"]
+    # the noise generate() will draw (torch.randn on its generator, diff_loss_rf_swiglu.py:117-122) is replayed for the oracle
+    model.noise_generator.manual_seed(123)
+    noises = torch.randn(n_tok + 1, 32, generator=model.noise_generator, device="cuda").cpu()
+    model.noise_generator.manual_seed(123)
+    # ---- oracle, driven like the reference: features -> scatter -> prefill with image_mask -> generate_image (3 rows) ----
+    feat = mingtok_ref.mingtok_forward(px, tsd_r)["x_norm_patchtokens"]
+    img = bailing_ref.linear_proj(feat.float(), lsd_r).reshape(-1, ocfg.hidden_size)
+    emb = sd_r["model.word_embeddings.weight"][ids_t].clone()
+    mask = ids_t == PATCH
+    emb[mask] = img
+    kvs = bailing_ref.new_kv(ocfg)
+    bailing_ref.model_forward(emb, sd_r, ocfg, None, None, kvs, image_mask=mask)
+    caches = mingtok_ref.semdec_new_cache(tsd_r)
+    one = torch.ones(1, 1, dtype=torch.long)
+    ref = bailing_ref.generate_image(
+        sd_r["model.word_embeddings.weight"][torch.tensor([[llm_cfg["image_start_token"]]])], kvs, torch.cat((am, one), 1), unc_t, tunc_t,
+        sd_r, ocfg, noises, latent_to_sem=lambda lat: mingtok_ref.mingtok_feature_decoder_step(lat, tsd_r, caches),
+        linear_proj=lambda s_: bailing_ref.linear_proj(s_, lsd_r),
+        sem_to_pix=lambda s_: mingtok_ref.pixel_decoder_forward(s_, tsd_r), steps=int(g["rf_config"]["num_sampling_steps"]))
+    assert ref["last_hidden"].shape[0] == 3
+    # ---- HIP path through the facade ----
+    seqs = model.generate(input_ids=ids_t, attention_mask=am, uncond_attention_mask=unc_t, text_uncond_attention_mask=tunc_t, pixel_values=px,
+                          max_new_tokens=2, forced_first_token=llm_cfg["image_start_token"], output_image_prefix=str(tmp_path / "edit"))
+    out = model.last_generation
+    assert out["last_hidden"].shape[0] == 3
+    errs = (rel_err(out["latents"], ref["latents"][:, 0]), rel_err(out["sem"], ref["sem"][0]), rel_err(out["last_hidden"], ref["last_hidden"][:, 0]))
+    print("edit round (image in, 3 CFG rows, image out) vs oracle: latents %.2e sem %.2e hidden %.2e" % errs)
+    assert max(errs) < TOL, errs
+    assert psnr(model.last_image[0], ref["image"][0]) > 40.0            # the pixel decoder of generate_image runs in the bf16 regime
+    assert os.path.exists(str(tmp_path / "edit.png"))
+    assert model.past_len == T + 1 + n_tok and seqs.shape[1] == T + 2
+    # follow-up text round on the cache the edit left (DROP policy: the uncond row forgets the generated tokens)
+    nxt = model.generate(input_ids=torch.tensor([[ROLE, HUMAN, ROLE_E, 31, 32, ROLE, ASSIST, ROLE_E]]), max_new_tokens=3)
+    assert nxt.shape[1] == 8 + 3 and model.past_len == T + 1 + n_tok + 8 + 2
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # (d) fp32-class regime of the batched paths on the reference's golden vectors
 # ------------------------------------------------------------------------------------------------------------------------
