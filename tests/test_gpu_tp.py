@@ -447,3 +447,32 @@ def test_tp_two_processes_one_gpu_over_ipc(tmp_path):
     n_ar = 2 * g["config"]["num_hidden_layers"]
     assert res["max_err"] < TOL, res
     assert res["epoch"] == n_ar * (1 + g["dec_in"].shape[0]), res      # one prefill pass + the decode steps, 2 all-reduces per layer
+
+
+@pytest.mark.parametrize("mode", ["tp-xgmi", "tp-rccl", "replicas"])
+def test_bench_two_ranks_on_one_gpu(mode):
+    """bench.py's multi-rank paths with TWO real ranks on this box's single GPU (MING_BENCH_SINGLE_GPU=1: gloo process group, both
+    ranks on cuda:0; a plumbing check, not a result): `--gpus 2` starts the ranks itself; `--tp` builds each rank's shard of a
+    2-layer 16B-A3B stack + the RF head, maps the inboxes over IPC (or relays them through the process group) and generates the
+    images as one TP group (`scaling` strong); the default is two replicas (`scaling` weak, twice the tokens)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MING_BENCH_SINGLE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--layers", "2", "--tokens", "16", "--images", "2", "--steps", "1",
+           "--warmup", "1", "--no-cpu-baseline", "--no-batch1"]
+    if mode.startswith("tp"):
+        cmd += ["--tp", "--tp-transport", mode.split("-")[1]]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["outputs_finite"] is True and res["value"] > 0
+    assert res["config"]["single_gpu_plumbing_check"] is True
+    if mode.startswith("tp"):
+        assert res["scaling"] == "strong" and res["config"]["parallelism"].startswith("tp2+ep2")
+        assert abs(res["value"] - 16 * 2 / (res["ms_per_step"] / 1e3)) < 1e-6 * res["value"]          # the group's images, counted once
+    else:
+        assert res["scaling"] == "weak" and res["config"]["parallelism"] == "replicas x2"
+        assert abs(res["value"] - 2 * 16 * 2 / (res["ms_per_step"] / 1e3)) < 1e-6 * res["value"]      # both replicas' images
