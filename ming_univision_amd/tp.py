@@ -148,7 +148,26 @@ class TpCommunicator:
                     out.append(p.value)
         dist.barrier()
         err = torch.zeros(1, dtype=torch.int32, device=device)
-        return TpCommunicator(rank, world, inbox_ptrs, flag_ptrs, cap, rows_cap, err)
+        c = TpCommunicator(rank, world, inbox_ptrs, flag_ptrs, cap, rows_cap, err)
+        c._ipc = (dist, [p for r, p in enumerate(inbox_ptrs + flag_ptrs) if r % world != rank], [p for p, _ in mine])
+        return c
+
+    def close(self):
+        """Unmap the peers' buffers and free this rank's (communicators made by from_process_group; a collective: every rank calls
+        it, after its last composite has completed)."""
+        ipc = getattr(self, "_ipc", None)
+        if ipc is None:
+            return
+        dist, mapped, own = ipc
+        torch.cuda.synchronize()
+        dist.barrier()                                   # nobody unmaps while a peer may still push
+        L = lib()
+        for p in mapped:
+            L.mn_tp_ipc_close(C.c_void_p(p))
+        dist.barrier()
+        for p in own:
+            L.mn_tp_free(C.c_void_p(p))
+        self._ipc = None
 
     @staticmethod
     def relayed(dist, rows_cap, width, device):

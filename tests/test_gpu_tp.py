@@ -421,6 +421,7 @@ t = torch.tensor([max(errs)], dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 if rank == 0:
     print(json.dumps({"max_err": float(t.item()), "epoch": int(tp.comm.struct.epoch)}))
+tp.comm.close()                                      # unmap the peer's inbox / flags, free this rank's
 dist.barrier()
 dist.destroy_process_group()
 """
