@@ -103,13 +103,18 @@ __global__ void rf_build_y_kernel(const float* __restrict__ temb, const float* _
 // ---- glue kernels of the matrix-core RF chain (rows >= 5): they sit between two weight-streaming launches and
 // fuse "reduce the K-slice partials + bias + epilogue of GEMV i" with "prologue + bf16 hi/lo split of GEMV i+1".
 // P: [nz][M][Ntot] fp32 partials (stream_mfma.hip); Y: [2][M][K] bf16 (hi rows, lo rows).
+// row_range (optional, device): only rows [row_range[0], row_range[1]) are live (expert parallelism: the sorted positions of the
+// rank's own experts; the other rows of P were never written and are not touched).
 __global__ __launch_bounds__(256) void rf_glue_swiglu_split_kernel(const float* __restrict__ P, int nz, int M, int hidden,
-                                                                   const bf16_t* __restrict__ b12, bf16_t* __restrict__ Y) {
+                                                                   const bf16_t* __restrict__ b12, bf16_t* __restrict__ Y,
+                                                                   const int32_t* __restrict__ row_range = nullptr,
+                                                                   const int32_t* __restrict__ row_range_end = nullptr) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef uint32_t u2 __attribute__((ext_vector_type(2)));
   const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;    // 4 consecutive columns per thread (hidden % 4 == 0)
   if (i >= (int64_t)M * hidden) return;
   const int m = (int)(i / hidden), n = (int)(i % hidden);
+  if (row_range && (m < *row_range || m >= *row_range_end)) return;
   const int64_t slab = (int64_t)M * 2 * hidden;
   f4 y1 = {0.f, 0.f, 0.f, 0.f}, y2 = {0.f, 0.f, 0.f, 0.f};
   if (b12) {

@@ -316,7 +316,7 @@ extern "C" int mn_llm_step_tp(const mn_llm* m, const mn_llm_tp* tp, mn_tp_comm* 
                                          2 * I, H, stream);
         if (nz1 < 0) return nz1;
         hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv(P * I, 1024)), dim3(256), 0, st, (const float*)tw.p1, nz1, (int)P, I,
-                           (const bf16_t*)nullptr, w.y2);
+                           (const bf16_t*)nullptr, w.y2, (const int32_t*)(w.off + e0), (const int32_t*)(w.off + e1));
         const int nz2 = mn_stream_mfma_grouped(w.y2, (int)P, m->w_down[l], (int64_t)H * I, tw.p2, (int)P, w.off + e0, nullptr, e1 - e0, M,
                                                H, I, stream);
         if (nz2 < 0) return nz2;
