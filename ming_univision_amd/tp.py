@@ -542,6 +542,8 @@ class TpRank(_TpDecoderBase):
         """Greedy pick with the lm_head split over the vocabulary (each rank streams V / world rows of it): mn_lmhead_argmax on the
         rank's slice with its vocabulary offset, then the ranks' (logit, id) pairs are gathered over the process group and the
         best pair wins — ties to the lowest id, like the unsharded arg-max."""
+        if self.full is None or self.full.lm_head is None:
+            raise RuntimeError("TpRank.greedy needs the lm_head (build the rank from a full decoder with vocabulary weights)")
         lm = self.full.lm_head
         V = lm.shape[0]
         n = -(-V // self.world)
