@@ -192,7 +192,7 @@ __global__ void rope_kv_append_kernel(const float* __restrict__ qkv, int64_t ldq
                                       int rope, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
                                       const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_slot,
                                       const int32_t* __restrict__ row_pos, int M, int sec_t, int sec_h, float q_scale,
-                                      float* __restrict__ q_out, float* __restrict__ kv_cache, int64_t t_max) {
+                                      float* __restrict__ q_out, float* __restrict__ kv_cache, int64_t t_max, int round_kv) {
   const int m = blockIdx.x, h = blockIdx.y, i = threadIdx.x, half = hd >> 1;
   const float* src = qkv + (int64_t)m * ldqkv + (int64_t)h * hd;
   float x1 = src[i], x2 = src[i + half];
@@ -215,10 +215,19 @@ __global__ void rope_kv_append_kernel(const float* __restrict__ qkv, int64_t ldq
     const int kvh = is_k ? h - n_q : h - n_q - n_kv;
     const int64_t seq = row_seq[m], slot = row_slot[m];
     float* dst = kv_cache + (((seq * 2 + (is_k ? 0 : 1)) * n_kv + kvh) * t_max + slot) * hd;
+    if (round_kv) {     // measurement only (dev library, tests/measure/kv_bf16_error.py): what a bf16 KV cache would hold
+      x1 = bf16_to_f32(f32_to_bf16(x1));
+      x2 = bf16_to_f32(f32_to_bf16(x2));
+    }
     dst[i] = x1;
     dst[i + half] = x2;
   }
 }
+
+static int g_kv_round_bf16 = 0;
+#ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_kv_round_bf16(int on) { g_kv_round_bf16 = on; }
+#endif
 
 // Internal (engine.hip): as mn_rope_kv_append_3d, reading the QKV projection as nz partial slabs.
 extern "C" int mn_rope_kv_from_partials(const float* qkv, int64_t ldqkv, int nz, int64_t slab, int M, int n_q, int n_kv, int hd,
@@ -231,7 +240,7 @@ extern "C" int mn_rope_kv_from_partials(const float* qkv, int64_t ldqkv, int nz,
   MN_CHECK_ARG(sec_t >= 0 && sec_h >= 0 && sec_t + sec_h <= hd / 2, "mn_rope_kv_append: bad rotary sections %d/%d", sec_t, sec_h);
   hipLaunchKernelGGL(rope_kv_append_kernel, dim3(M, n_q + 2 * n_kv), dim3(hd / 2), 0, mn_stream(stream), qkv, ldqkv, nz, slab,
                      n_q, n_kv, hd, rope, cos_tab, sin_tab, row_seq, row_slot, row_pos, M, sec_t, sec_h, q_scale, q_out,
-                     kv_cache, t_max);
+                     kv_cache, t_max, g_kv_round_bf16);
   MN_CHECK_LAUNCH("mn_rope_kv_append");
   return MN_OK;
 }
