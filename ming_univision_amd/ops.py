@@ -270,6 +270,35 @@ def gemm256_grouped(a2, a_rows, w, off, cnt, n_pos, m_max, swiglu):
     return out
 
 
+def gemm256_grouped_tiles(a2, topk_idx, w, n_groups, swiglu):
+    """Grouped form over a device-built row-tile list, as the lock-step decoder step runs its experts (modeling_bailing_moe.py:605-639):
+    a2 bf16 [2, T, K] hi/lo pair, topk_idx int32 [T, n_slot] group id of every (row, pick); w bf16 [G, N or 2N, K].  Returns (out, off, cnt, perm): out fp32 [T * n_slot, N] or the bf16 hi/lo pair
+    [2, T * n_slot, N] (swiglu) in group-sorted order; perm[position] = source row."""
+    _req(a2, torch.bfloat16, "a2"); _req(w, torch.bfloat16, "w"); _req(topk_idx, torch.int32, "topk_idx")
+    tile_rows = 128
+    T, n_slot = topk_idx.shape
+    G, NW, K = w.shape
+    assert G == n_groups
+    N = NW // 2 if swiglu else NW
+    dev, n_pos = a2.device, T * n_slot
+    i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
+    cnt, off, perm, slot_of = i32(G), i32(G + 1), i32(n_pos), i32(n_pos)
+    max_mtiles = n_pos // tile_rows + G
+    tile_g, tile_m0, n_tiles = i32(max_mtiles), i32(max_mtiles), i32(1)
+    st = current_stream()
+    check(lib().mn_moe_sort_tiles(ptr(topk_idx), T, n_slot, G, ptr(cnt), ptr(off), ptr(perm), ptr(slot_of), tile_rows, ptr(tile_g), ptr(tile_m0),
+                                  ptr(n_tiles), st), "mn_moe_sort_tiles")
+    if swiglu:
+        out = torch.zeros(2, n_pos, N, dtype=torch.bfloat16, device=dev)
+        lo_off = out.stride(0)
+    else:
+        out = torch.zeros(n_pos, N, dtype=torch.float32, device=dev)
+        lo_off = 0
+    check(lib().mn_gemm256_grouped_tiles(ptr(a2), K, a2.stride(0), a2.shape[1], ptr(perm), ptr(w), K, w.stride(0), ptr(off), ptr(cnt), G, ptr(tile_g), ptr(tile_m0), ptr(n_tiles),
+             max_mtiles, ptr(out), N, lo_off, N, K, 4 if swiglu else 0, st), "mn_gemm256_grouped_tiles")
+    return out, off, cnt, perm
+
+
 def gemm256_splitk_bf16(a, w, bias, ksplit):
     """Split-K form on plain bf16 activations a [M, K]: fp32 partial slabs [nz, M, N] (bias in slab 0)."""
     _req(a, torch.bfloat16, "a"); _req(w, torch.bfloat16, "w"); _req(bias, torch.bfloat16, "bias")

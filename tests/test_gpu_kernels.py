@@ -468,6 +468,38 @@ def test_gemm256_grouped(ops, gather):
         assert rel(got, ref) < 3e-5
 
 
+def test_gemm256_grouped_tile_list(ops):
+    """The expert GEMMs of the lock-step decoder step: device-built row-tile list (hi/lo rows: 128-row tiles), rows gathered while
+    staging, the XCD-aware order ranging over the live tiles of a grid sized for the worst case.  Group sizes straddle the tile edges."""
+    G, K, N = 9, 320, 136
+    counts = [0, 1, 16, 17, 127, 128, 129, 144, 400]                 # empty, one row, one fragment, +1, tile edges, the bench's size, 4 tiles
+    T = sum(counts)
+    g = torch.Generator().manual_seed(51)
+    ids = torch.cat([torch.full((c,), gi, dtype=torch.int32) for gi, c in enumerate(counts)])[torch.randperm(T, generator=g)].reshape(T, 1)
+    x = rnd(T, K, seed=52)
+    a2 = ops.split_hilo(x.cuda())
+    xr = a2[0].double().cpu() + a2[1].double().cpu()
+    for swiglu in (False, True):
+        w, wf = bw(G, 2 * N if swiglu else N, K, seed=53 + swiglu, scale=K ** -0.5)
+        out, off, cnt, perm = ops.gemm256_grouped_tiles(a2, ids.cuda(), w, G, swiglu)
+        assert cnt.cpu().tolist() == counts
+        off, perm = off.cpu(), perm.cpu().long()
+        assert torch.equal(ids[perm, 0].long(), torch.repeat_interleave(torch.arange(G), torch.tensor(counts)))
+        ref = torch.zeros(T, N, dtype=torch.float64)
+        for gi in range(G):
+            lo, hi = int(off[gi]), int(off[gi]) + counts[gi]
+            r = xr[perm[lo:hi]] @ wf[gi].double().T
+            ref[lo:hi] = F.silu(r[:, :N]) * r[:, N:] if swiglu else r
+        got = out[0].double() + out[1].double() if swiglu else out
+        assert rel(got, ref) < 3e-5
+        # the order inside a group is arbitrary (LDS atomics of the sort), a row's result does not depend on its position
+        out2, _, _, perm2 = ops.gemm256_grouped_tiles(a2, ids.cuda(), w, G, swiglu)
+        by_row, by_row2 = torch.empty_like(out), torch.empty_like(out2)
+        by_row[..., perm.cuda(), :] = out
+        by_row2[..., perm2.long(), :] = out2
+        assert torch.equal(by_row, by_row2)
+
+
 def test_gemm256_race_screen(ops):
     """The counted-vmcnt pipeline has no hardware interlock between LDS-DMA writes and fragment reads: a schedule error shows
     as RARE wrong tiles.  Screen: many launches of production shapes under load must be bitwise identical and right."""
