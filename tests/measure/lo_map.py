@@ -1,6 +1,7 @@
 """Per-site lo-pass map: the full-width generation case of tests/test_gpu_fullwidth.py (16B-A3B widths, 2 LLM layers,
 3 visual tokens, 2 CFG rows, 96 rows on the wide route) with ONE Linear site at a time multiplying plain bf16 activations instead of
-the hi/lo pair; error of image 0 against the fp32 oracle.  Uses the dev library (mn_lo_drop_mask).  Prints one line per site."""
+the hi/lo pair; error of image 0 against the fp32 oracle.  Uses the dev library (mn_lo_drop_mask).  Prints one line per site.
+usage: lo_map.py [images (48; the semantic decoder takes the wide route — where the switch acts — from 65 images on)] [site prefix]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -45,7 +46,8 @@ caches = mingtok_ref.semdec_new_cache(tsd)
 ref = bailing_ref.generate_image(sd["model.word_embeddings.weight"][torch.tensor([[cfg.image_start_token]])], kvs, am, un, un.clone(), sd, ocfg,
                                  noises, latent_to_sem=lambda lat: mingtok_ref.mingtok_feature_decoder_step(lat, tsd, caches),
                                  linear_proj=lambda s: bailing_ref.linear_proj(s, lsd), sem_to_pix=lambda s: None, steps=16)
-B, R = 48, 2
+B, R = (int(sys.argv[1]) if len(sys.argv) > 1 else 48), 2
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
 dec = BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=32, n_seq=R * B)
 nb = torch.randn(B, cfg.num_image_tokens_for_gen + 1, 32, generator=g); nb[0] = noises
 emb = dec.embed(ids[0].cuda())
@@ -64,6 +66,7 @@ def run(mask):
 print("site                 latents    sem        hidden   (rel. to the fp32 oracle; bar 1e-3, shipping bar 5e-4)")
 print("%-20s %.2e   %.2e   %.2e" % (("none (all hi/lo)",) + run(0)))
 for i, name in enumerate(SITES):
+    if not name.startswith(ONLY): continue
     print("%-20s %.2e   %.2e   %.2e" % ((name,) + run(1 << i)), flush=True)
 print("%-20s %.2e   %.2e   %.2e" % (("ALL sites",) + run((1 << len(SITES)) - 1)))
 L.mn_lo_drop_mask(0)
