@@ -160,3 +160,58 @@ def test_lmhead_argmax_random(ops, M, V, H, off):
     # the index may differ from float64's only where two logits tie within the fp32 error of the product
     picked = logits.gather(1, (idx.cpu().long() - off).view(-1, 1)).squeeze(1)
     assert torch.all(best.values - picked <= 3e-5 * best.values.abs().max())
+
+
+# ---- the decoder step over random small configurations (both routes) ---------------------------------------------------------
+def _llm_cases():
+    r = random.Random(900)
+    cases = []
+    for i in range(6):
+        hd = r.choice([64, 128])
+        n_kv = r.choice([1, 2, 4])
+        n_q = n_kv * r.choice([1, 2, 4])
+        cases.append(dict(hidden_size=64 * r.randint(1, 5), num_attention_heads=n_q, num_key_value_heads=n_kv, head_dim=hd,
+                          num_experts=r.choice([4, 8, 16]), num_experts_per_tok=r.choice([1, 2, 4]), num_shared_experts=r.choice([0, 1, 2]),
+                          moe_intermediate_size=64 * r.randint(1, 3), norm_topk_prob=r.random() < 0.7, multi_gate=r.random() < 0.5,
+                          num_hidden_layers=2, rows=r.choice([1, 2, 5, 33, 70, 130]), seed=i))
+    return cases
+
+
+@pytest.mark.parametrize("case", _llm_cases(), ids=lambda c: "h%d_q%dkv%dx%d_e%dk%ds%d_rows%d" % (
+    c["hidden_size"], c["num_attention_heads"], c["num_key_value_heads"], c["head_dim"], c["num_experts"], c["num_experts_per_tok"],
+    c["num_shared_experts"], c["rows"]))
+def test_decoder_step_random_configs_vs_oracle(case):
+    """Cached decode steps (modeling_bailing_moe.py:1214-1218, 656-829, 505-639) of random small Bailing-MoE configurations — head
+    counts, GQA ratios, expert counts, top-k, 0 / 1 / 2 shared experts, image gate on or off — at row counts on the weight-streaming
+    route (<= 64) and on the wide route, with holey key masks, against the fp32 oracle."""
+    from ming_univision_amd import configuration as C
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder
+    from oracle import bailing_ref
+    from tests.util import llm_sd, rel_err
+    rows, seed = case["rows"], case["seed"]
+    d = dict(vocab_size=128, use_qkv_bias=False, use_bias=False, rms_norm_eps=1e-5, rope_theta=600000.0, first_k_dense_replace=0,
+             num_image_tokens_for_gen=4, image_start_token=100, image_patch_token=99, embedding_dropout=0.0, attention_dropout=0.0,
+             output_dropout=0.0, pad_token_id=0)
+    d.update({k: v for k, v in case.items() if k not in ("rows", "seed")})
+    rf_cfg = dict(diffloss_w=64, diffloss_d=1, num_sampling_steps="2", gen_method="flow_matching_swiglu-4", vis_head_arch="linear2-norm")
+    sd = llm_sd(d, rf_cfg, 40 + seed)
+    cfg = C.BailingMoeConfig(**d)
+    dec = BailingMoeDecoder.from_state_dict(cfg, {k: v.to("cuda", torch.bfloat16).contiguous() for k, v in sd.items()}, t_max=8, n_seq=rows)
+    sdr = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}          # the oracle multiplies the same bf16-rounded weights
+    ocfg = bailing_ref.LLMConfig(**{k: v for k, v in d.items() if k in bailing_ref.LLMConfig.__dataclass_fields__})
+    kvs = bailing_ref.new_kv(ocfg)
+    gen = torch.Generator().manual_seed(seed)
+    seq = torch.arange(rows, dtype=torch.int32).cuda()
+    keep = torch.ones(rows, 8, dtype=torch.long)
+    for step in range(3):
+        x = torch.randn(rows, 1, cfg.hidden_size, generator=gen)
+        img = (torch.rand(rows, 1, generator=gen) < 0.5) if case["multi_gate"] else None
+        if step == 1:
+            keep[::2, 0] = 0                                                # from step 1 on every other row stops seeing key 0
+        am = keep[:, :step + 1]
+        pos = torch.full((rows, 1), step, dtype=torch.long)
+        ref = bailing_ref.model_forward(x, sdr, ocfg, am, pos, kvs, image_mask=img)
+        slot = torch.full((rows,), step, dtype=torch.int32).cuda()
+        out = dec.step(x[:, 0].cuda().contiguous(), seq, slot, slot, slot + 1, keep.to(torch.uint8).cuda(),
+                       image_mask=None if img is None else img[:, 0].to(torch.uint8).cuda())
+        assert rel_err(out, ref[:, 0]) < 1e-3, step
