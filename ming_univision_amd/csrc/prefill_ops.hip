@@ -312,25 +312,42 @@ __global__ __launch_bounds__(1024) void moe_sort_kernel(const int32_t* __restric
                                                         int n_slot, int tile_rows, int32_t* __restrict__ tile_g,
                                                         int32_t* __restrict__ tile_m0, int32_t* __restrict__ n_tiles,
                                                         int g_lo, int g_hi) {
-  __shared__ int cnt[128], off[129], cur[128];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < n_groups; i += 1024) { cnt[i] = 0; cur[i] = 0; }
+  __shared__ int cnt[128], off[129], cur[128], toff[129], wtot[2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid < 128) { cnt[tid] = 0; cur[tid] = 0; }
   __syncthreads();
   for (int i = tid; i < n_pairs; i += 1024) atomicAdd(&cnt[topk_idx[i]], 1);
   __syncthreads();
-  if (tid == 0) {
-    int a = 0;
-    for (int e = 0; e < n_groups; ++e) { off[e] = a; a += cnt[e]; }
-    off[n_groups] = a;
+  // exclusive scans over the <= 128 groups — rows per group, and row tiles of the groups in [g_lo, g_hi) — by the first two waves:
+  // inclusive scan inside a wave by shuffles, the second wave adds the first one's totals
+  int c = 0, t = 0, sc = 0, stl = 0;
+  if (tid < 128) {
+    c = tid < n_groups ? cnt[tid] : 0;
+    t = (tile_g && tid >= g_lo && tid < g_hi) ? (c + tile_rows - 1) / tile_rows : 0;
+    sc = c; stl = t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int a = __shfl_up(sc, d, 64), b = __shfl_up(stl, d, 64);
+      if (lane >= d) { sc += a; stl += b; }
+    }
+    if (tid == 63) { wtot[0] = sc; wtot[1] = stl; }
   }
   __syncthreads();
-  for (int i = tid; i < n_groups; i += 1024) { counts[i] = cnt[i]; offsets[i] = off[i]; }
+  if (tid < 128) {
+    if (tid >= 64) { sc += wtot[0]; stl += wtot[1]; }
+    off[tid] = sc - c;
+    toff[tid] = stl - t;
+    if (tid == 127) { off[128] = sc; toff[128] = stl; }      // totals (groups past n_groups count 0, so off[n_groups] is the total too)
+  }
+  __syncthreads();
+  if (tid < n_groups) { counts[tid] = c; offsets[tid] = off[tid]; }
   if (tid == 0) offsets[n_groups] = off[n_groups];
-  if (tile_g && tid == 0) {        // live row tiles of the grouped GEMMs, in group order
-    int t = 0;
-    for (int e = g_lo; e < g_hi; ++e)           // expert parallelism: only the groups this rank holds get tiles
-      for (int m0 = 0; m0 < cnt[e]; m0 += tile_rows) { tile_g[t] = e; tile_m0[t] = m0; ++t; }
-    *n_tiles = t;
+  if (tile_g) {        // live row tiles of the grouped GEMMs, in group order; expert parallelism: only the groups this rank holds get tiles
+    if (tid >= g_lo && tid < g_hi) {
+      int k = toff[tid];
+      for (int m0 = 0; m0 < c; m0 += tile_rows) { tile_g[k] = tid; tile_m0[k] = m0; ++k; }
+    }
+    if (tid == 0) *n_tiles = toff[128];
   }
   for (int i = tid; i < n_pairs; i += 1024) {
     const int e = topk_idx[i];
