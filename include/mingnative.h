@@ -140,6 +140,8 @@ MN_API int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w, fl
  *    row_seq[m]: cache sequence of row m; row_slot[m]: cache slot to write; row_pos[m]: rotary
  *    position (cumsum(mask)-1, :1905).  cos/sin tables fp32 [n_pos, hd/2].
  *    q_out [M, n_q*hd] fp32 receives rotated (and scaled by q_scale) queries.
+ *    A row whose slot is outside [0, t_max) writes no K / V (the Python surface raises before a cache fills up; the kernel
+ *    never stores outside the sequence's rows of the arena).
  * ------------------------------------------------------------------------------------------ */
 MN_API int mn_rope_kv_append(const float* qkv, int64_t ldqkv, int M, int n_q, int n_kv, int hd,
                       int rope, const float* cos_tab, const float* sin_tab,

@@ -214,6 +214,7 @@ __global__ void rope_kv_append_kernel(const float* __restrict__ qkv, int64_t ldq
   } else {
     const int kvh = is_k ? h - n_q : h - n_q - n_kv;
     const int64_t seq = row_seq[m], slot = row_slot[m];
+    if ((uint64_t)slot >= (uint64_t)t_max) return;      // never write outside the sequence's arena rows (the host raises before a cache fills up)
     float* dst = kv_cache + (((seq * 2 + (is_k ? 0 : 1)) * n_kv + kvh) * t_max + slot) * hd;
     if (round_kv) {     // measurement only (dev library, tests/measure/kv_bf16_error.py): what a bf16 KV cache would hold
       x1 = bf16_to_f32(f32_to_bf16(x1));
