@@ -45,13 +45,15 @@ __global__ __launch_bounds__(1024) void wide_glue_kernel(const WideGlue p) {
     if ((int)threadIdx.x < p.wait_n) {
       const uint32_t* f = p.wait_flags + (int64_t)threadIdx.x * p.wait_stride + m;
       int spins = 0;
-      while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - p.wait_epoch) < 0) {
+      // relaxed polls, ONE acquire once the flag is there (an acquire load per poll would drop this CU's L1 on every iteration)
+      while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - p.wait_epoch) < 0) {
         if (++spins > (1 << 24)) {                       // ~ seconds: a peer died or the launch orders diverged — fail loudly, never hang
           if (p.wait_err) atomicExch(p.wait_err, 0x100u | (unsigned)threadIdx.x);
           break;
         }
         __builtin_amdgcn_s_sleep(4);
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope: the senders may be other GPUs
     }
     __syncthreads();
   }
