@@ -59,10 +59,16 @@ __global__ __launch_bounds__(1024) void tp_push_kernel(const TpPush p) {
     const int64_t off = ((int64_t)(p.epoch & 1u) * p.world + p.rank) * p.cap + (int64_t)m * D + col;
     for (int r = 0; r < p.world; ++r) *reinterpret_cast<f4*>(p.inbox[r] + off) = v;
   }
-  __threadfence_system();          // the row is visible on every rank before any of its flags
+  // The row is visible on every rank before any of its flags (cdna_hip_programming.md §6 Guideline 16, flag form): every wave drains
+  // its stores, barrier, then the flag lanes alone release at system scope — the wait restated after the fence, where the compiler
+  // cannot drop it — and raise the flags with relaxed stores.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if ((int)threadIdx.x < p.world)
-    __hip_atomic_store(p.flags[threadIdx.x] + (int64_t)p.rank * p.rows_cap + m, p.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if ((int)threadIdx.x < p.world) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(p.flags[threadIdx.x] + (int64_t)p.rank * p.rows_cap + m, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 static bool tp_comm_ok(const mn_tp_comm* c, int rows, int D) {
