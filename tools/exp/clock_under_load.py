@@ -1,0 +1,54 @@
+"""Shader clock and socket power while the roofline kernel (gemm256 SwiGLU-split on RF w12, 1536 rows) runs back to back, on random and
+on zero operands, against an HBM-bound kernel (a device copy): `rocm-smi` sampled from a thread while the launches are queued.
+What "power-limited" means for the 0.26 / 0.29 roofline fraction."""
+import os, sys, re, subprocess, threading, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from ming_univision_amd._lib import lib, ptr, check, current_stream
+L = lib()
+rows, K, hid = 1536, 3072, 8192
+dev = "cuda"
+g = torch.Generator().manual_seed(0)
+def split(x):
+    hi = x.to(torch.bfloat16); lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo]).contiguous()
+a_rand = split(torch.randn(rows, K, generator=g).to(dev))
+w_rand = [(torch.randn(2 * hid, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev) for _ in range(4)]
+a_zero, w_zero = torch.zeros_like(a_rand), [torch.zeros_like(w_rand[0])]
+y = torch.empty(2, rows, hid, dtype=torch.bfloat16, device=dev)
+big = torch.empty(1 << 28, dtype=torch.float32, device=dev); big2 = torch.empty_like(big)
+def w12(a2, ws):
+    return lambda i: check(L.mn_gemm256_swiglu_split(ptr(a2), K, a2.stride(0), ptr(ws[i % len(ws)]), K, None, ptr(y), hid, y.stride(0), rows, hid, K, current_stream()), "x")
+def smi():
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+    except Exception as e:
+        return None, None
+    sclk = re.search(r"sclk clock level.*?\((\d+)Mhz\)", out)
+    pw = re.search(r"(?:Average|Current Socket) Graphics Package Power \(W\): ([\d.]+)", out)
+    return (int(sclk.group(1)) if sclk else None), (float(pw.group(1)) if pw else None)
+def measure(name, fn, seconds=6.0, per_launch_flop=None):
+    samples, stop = [], False
+    def sampler():
+        while not stop:
+            samples.append(smi()); time.sleep(0.15)
+    for i in range(20): fn(i)
+    torch.cuda.synchronize()
+    th = threading.Thread(target=sampler); th.start()
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < seconds:
+        for i in range(200): fn(n + i)
+        n += 200
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stop = True; th.join()
+    s = [x for x in samples[2:] if x[0]]
+    clk = sum(x[0] for x in s) / max(1, len(s)); pw = [x[1] for x in s if x[1]]
+    extra = f", {per_launch_flop * n / dt / 1e12:.0f} TFLOP/s algorithmic" if per_launch_flop else ""
+    print(f"{name}: {dt / n * 1e6:.1f} us per launch{extra}; sclk {clk:.0f} MHz over {len(s)} samples" +
+          (f", power {sum(pw) / len(pw):.0f} W" if pw else ""), flush=True)
+print("idle:", smi(), flush=True)
+fl = 2.0 * rows * 2 * hid * K
+measure("w12 on random operands, back to back", w12(a_rand, w_rand), per_launch_flop=fl)
+measure("w12 on zero operands, back to back", w12(a_zero, w_zero), per_launch_flop=fl)
+measure("1 GiB device copy (HBM-bound)", lambda i: big2.copy_(big))
