@@ -53,7 +53,22 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(mn_f2_t{lo, hi}, mn_b2_t));
 }
 // (a, b) -> packed bf16 hi parts and packed bf16 lo parts: a = hi.a + lo.a to 2^-17
+#ifdef MN_EMUL_F16F8
+// Measurement only (never in the product or the dev library: `make dev EXTRA=-DMN_EMUL_F16F8=3` builds a one-off copy): the operand
+// an fp16 hi pass + an fp8 lo pass would multiply — x16 = fp16(x) plus the residual rounded to MN_EMUL_F16F8 mantissa bits (3 = e4m3)
+// — carried through the existing bf16 hi/lo pair (16 bits hold it to 2^-18).  DESIGN.md §9-1, tests/measure/f16f8_error.py.
+__device__ __forceinline__ float emul_f16f8(float a) {
+  const float a16 = (float)(_Float16)a;
+  uint32_t u = __builtin_bit_cast(uint32_t, a - a16);
+  constexpr int drop = 23 - MN_EMUL_F16F8;
+  u = (u + (1u << (drop - 1))) & ~((1u << drop) - 1u);
+  return a16 + __builtin_bit_cast(float, u);
+}
+#endif
 __device__ __forceinline__ void split_pk_bf16(float a, float b, uint32_t& hi, uint32_t& lo) {
+#ifdef MN_EMUL_F16F8
+  a = emul_f16f8(a); b = emul_f16f8(b);
+#endif
   hi = cvt_pk_bf16(a, b);
   lo = cvt_pk_bf16(a - bf16lo_to_f32(hi), b - bf16hi_to_f32(hi));
 }
