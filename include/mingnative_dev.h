@@ -29,6 +29,8 @@ MN_DEV_API void mn_wide_tune(int llm_min_rows, int rf_min_rows, int sem_min_rows
  * rows only).  Sites: 0 vis_head, 1 cond_embed, 2 adaLN, 3 RF w12, 4 RF w3, 5 RF final, 6 QKV, 7 dense, 8 gate, 9 experts (gate/up +
  * down), 10 semdec qkv, 11 semdec proj, 12 semdec w12, 13 semdec w3, 14 linear_proj. */
 MN_DEV_API void mn_lo_drop_mask(unsigned mask);
+/* Tile lists (expert GEMMs): skip the MFMAs and fragment reads of M-fragments without a live row (1, shipped) or run them all (0). */
+MN_DEV_API void mn_gemm256_tune_thin(int on);
 /* Measurement only: K / V rows are rounded to bf16 when appended to the (fp32) cache — the values a bf16 KV cache would hold. */
 MN_DEV_API void mn_kv_round_bf16(int on);
 

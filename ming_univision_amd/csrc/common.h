@@ -131,6 +131,7 @@ typedef struct mn_g256 {
   // [tile_m0[t], +128 or 256) of group tile_g[t], *n_tiles entries, at most max_mtiles; the grid then has no empty groups
   const int32_t* tile_g; const int32_t* tile_m0; const int32_t* n_tiles; int max_mtiles;
   int group_m;                                           // set by the launcher: M-tiles per band of the tile order (0: tm fastest over all M-tiles)
+  int thin;                                              // set by the launcher: tile lists skip the MFMAs / fragment reads of M-fragments without a live row
 } mn_g256;
 enum { MN_G256_F32 = 0, MN_G256_BF16 = 1, MN_G256_BF16_GELU = 2, MN_G256_F32_RESID = 3, MN_G256_SWIGLU_SPLIT = 4,
        MN_G256_F32_RESID_GATE = 5, MN_G256_SWIGLU_BF16 = 6 };

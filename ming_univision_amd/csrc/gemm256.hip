@@ -249,6 +249,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   // ---- staging: wave w fills LDS rows [16w, 16w+16) of a half-tile with two instructions of 8 rows x 8 slots ----
   uint32_t srcA[2][2], srcW[2][2];
   g256_src_offsets<hilo, paired>(p, wave, lane, m0, n0, row0, Mg, kbeg, srcA, srcW);
+  // Row tiles of a tile list (the expert GEMMs) are often mostly padding — 144 rows per expert = a full tile + a 16-row one —, and
+  // a power-limited chip pays for the MFMAs and fragment reads of clamped rows in clock: M-fragments of this wave row without a live
+  // row are skipped (wave-uniform count, one copy of the K loop per count so that no branch sits inside an MFMA cluster).
+  constexpr bool thin = HILO && (EPI == E_F32 || EPI == E_SWIGLU_SPLIT);
+  const int live_f = (thin && p.tile_g && p.thin) ? __builtin_amdgcn_readfirstlane(min(4, max(0, (Mg - m0 - wr * 64 + 15) >> 4))) : 4;
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Wb = reinterpret_cast<const char*>(p.W) + (int64_t)grp * p.w_gstride * 2;
   auto stage = [&](int op, int h, int kt, int buf) {   // op 0 = A, 1 = W; all arguments compile-time or wave-uniform
@@ -269,10 +274,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   for (int kk = 0; kk < 2; ++kk) lane_off[kk] = fr * 128 + (((4 * kk + fq) ^ ((fr >> 1) & 7)) << 4);
   const int a_wave = wr * 64 * 128, w_wave = wc * 32 * 128;
   bf16x8 af[8], wf0[4], wf1[4];
-  auto read_a = [&](int buf, int h) {
+  auto read_a = [&](int buf, int h, auto LVc) {   // LV = live M-fragments of this wave row
+    constexpr int LV = decltype(LVc)::value;
     const char* base = &lds[lds_off(buf, 0, h) + a_wave];
 #pragma unroll
-    for (int x = 0; x < 8; ++x) af[x] = *reinterpret_cast<const bf16x8*>(base + (x >> 1) * 2048 + lane_off[x & 1]);   // x = 2 i + kk
+    for (int x = 0; x < 2 * LV; ++x) af[x] = *reinterpret_cast<const bf16x8*>(base + (x >> 1) * 2048 + lane_off[x & 1]);   // x = 2 i + kk
   };
   auto read_w = [&](int buf, int h, bf16x8 (&wf)[4]) {
     const char* base = &lds[lds_off(buf, 1, h) + w_wave];
@@ -285,11 +291,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // quadrant (mh, nh): D[n][m] += W-frag (as A operand) x activation frag (as B operand)
-  auto quad = [&](int mh, int nh, bf16x8 (&wf)[4]) {
+  auto quad = [&](int mh, int nh, bf16x8 (&wf)[4], auto LVc) {
+    constexpr int LV = decltype(LVc)::value;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < LV; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[mh * 4 + i][nh * 2 + j] =
@@ -304,11 +311,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   //   RAW: X.A1(T) issued (T-1).1, retired by the vmcnt(8) of T.1 (8 = Y.A1 + the three half-tiles of (T-1).2), read T.2;
   //        Y.{A0,W0,W1}(T+1) issued (T-1).2, retired by the vmcnt(8) of T.2, read (T+1).1 — always one phase after the wait.
   //   WAR: one phase, safe because every wave's reads completed before the barrier that precedes the re-issue.
-  auto phase2 = [&](auto Xc, auto PHc, int T) {
+  auto phase2 = [&](auto Xc, auto PHc, int T, auto LVc) {
     constexpr int X = decltype(Xc)::value, PH = decltype(PHc)::value, Y = X ^ 1;
     const int tgt = PH == 0 ? T + 1 : T + 2;
-    if (PH == 0) { read_w(X, 0, wf0); read_w(X, 1, wf1); __builtin_amdgcn_sched_barrier(0); read_a(X, 0); }
-    else read_a(X, 1);
+    constexpr bool any = decltype(LVc)::value > 0;        // a wave row without live rows reads no fragments at all
+    if (PH == 0) { if (any) { read_w(X, 0, wf0); read_w(X, 1, wf1); } __builtin_amdgcn_sched_barrier(0); read_a(X, 0, LVc); }
+    else read_a(X, 1, LVc);
     if (tgt < nk) {   // (issuing the LDS-DMA before the fragment reads instead measured within +-1 %)
       if (PH == 0) stage(0, 1, tgt, Y);
       else { stage(0, 0, tgt, X); stage(1, 0, tgt, X); stage(1, 1, tgt, X); }
@@ -319,8 +327,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-    if (PH == 0) { quad(0, 0, wf0); quad(0, 1, wf1); }
-    else { quad(1, 1, wf1); quad(1, 0, wf0); }
+    if (PH == 0) { quad(0, 0, wf0, LVc); quad(0, 1, wf1, LVc); }
+    else { quad(1, 1, wf1, LVc); quad(1, 0, wf0, LVc); }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -332,9 +340,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   else wait_vm<0>();
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();
-  for (int t = 0; t < nk; t += 2) {
-    phase2(I0{}, I0{}, t); phase2(I0{}, I1{}, t);
-    if (t + 1 < nk) { phase2(I1{}, I0{}, t + 1); phase2(I1{}, I1{}, t + 1); }
+  auto kloop = [&](auto LVc) {
+    for (int t = 0; t < nk; t += 2) {
+      phase2(I0{}, I0{}, t, LVc); phase2(I0{}, I1{}, t, LVc);
+      if (t + 1 < nk) { phase2(I1{}, I0{}, t + 1, LVc); phase2(I1{}, I1{}, t + 1, LVc); }
+    }
+  };
+  if constexpr (thin) {
+    switch (live_f) {
+      case 0: kloop(std::integral_constant<int, 0>{}); break;
+      case 1: kloop(std::integral_constant<int, 1>{}); break;
+      case 2: kloop(std::integral_constant<int, 2>{}); break;
+      case 3: kloop(std::integral_constant<int, 3>{}); break;
+      default: kloop(std::integral_constant<int, 4>{}); break;
+    }
+  } else {
+    kloop(std::integral_constant<int, 4>{});
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
 
@@ -347,8 +368,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
 
 // Tile order: dense problems run in bands of 4 M-tiles inside an XCD's tile range; tile lists keep the N-tiles of a row tile together
 // (bands of 2-8 row tiles measured 0.7 % slower end to end).
-static int g_g256_groupm = 4, g_g256_groupb = 1;
+static int g_g256_groupm = 4, g_g256_groupb = 1, g_g256_thin = 1;
 #ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_gemm256_tune_thin(int on) { g_g256_thin = on; }   // A/B hook: skip the MFMAs of dead M-fragments in tile lists
 extern "C" MN_DEV_API void mn_gemm256_tune_order(int group_m, int group_list) {   // A/B hook (tools/, libmingnative_dev.so only)
   g_g256_groupm = group_m;
   g_g256_groupb = group_list;
@@ -362,6 +384,7 @@ static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {
   const int tiles = (int)((a.tile_g ? a.max_mtiles : mn_cdiv(a.M, hilo ? 128 : 256)) * mn_cdiv(a.N, paired ? 128 : 256));
   G256 p = a;
   p.group_m = a.tile_g ? g_g256_groupb : g_g256_groupm;
+  p.thin = g_g256_thin;
   p.Kc = p.K;
   if (ksplit > 1) p.Kc = (int)(mn_cdiv(mn_cdiv(p.K, ksplit), 2 * BK) * 2 * BK);   // even number of K-tiles per slice
   const int nz = (int)mn_cdiv(p.K, p.Kc);
