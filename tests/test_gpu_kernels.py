@@ -470,9 +470,11 @@ def test_gemm256_grouped(ops, gather):
 
 def test_gemm256_grouped_tile_list(ops):
     """The expert GEMMs of the lock-step decoder step: device-built row-tile list (hi/lo rows: 128-row tiles), rows gathered while
-    staging, the XCD-aware order ranging over the live tiles of a grid sized for the worst case.  Group sizes straddle the tile edges."""
-    G, K, N = 9, 320, 136
-    counts = [0, 1, 16, 17, 127, 128, 129, 144, 400]                 # empty, one row, one fragment, +1, tile edges, the bench's size, 4 tiles
+    staging, the XCD-aware order ranging over the live tiles of a grid sized for the worst case, dead M-fragments skipped."""
+    G, K, N = 13, 320, 136
+    # empty, one row, one fragment, +1, every live-fragment count of either wave row (33 / 40: 3 of 4; 70 / 90 / 110: second wave row
+    # with 1 / 2 / 3), tile edges, the bench's size, 4 tiles — the kernel runs a different copy of its K loop per live-fragment count
+    counts = [0, 1, 16, 17, 40, 70, 90, 110, 127, 128, 129, 144, 400]
     T = sum(counts)
     g = torch.Generator().manual_seed(51)
     ids = torch.cat([torch.full((c,), gi, dtype=torch.int32) for gi, c in enumerate(counts)])[torch.randperm(T, generator=g)].reshape(T, 1)
