@@ -251,9 +251,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   g256_src_offsets<hilo, paired>(p, wave, lane, m0, n0, row0, Mg, kbeg, srcA, srcW);
   // Row tiles of a tile list (the expert GEMMs) are often mostly padding — 144 rows per expert = a full tile + a 16-row one —, and
   // a power-limited chip pays for the MFMAs and fragment reads of clamped rows in clock: M-fragments of this wave row without a live
-  // row are skipped (wave-uniform count, one copy of the K loop per count so that no branch sits inside an MFMA cluster).
+  // row are skipped (wave-uniform count, one copy of the K loop per count so that no branch sits inside an MFMA cluster).  The last
+  // row tile of a dense problem whose row count is not a multiple of 128 takes the same path.
   constexpr bool thin = HILO && (EPI == E_F32 || EPI == E_SWIGLU_SPLIT);
-  const int live_f = (thin && p.tile_g && p.thin) ? __builtin_amdgcn_readfirstlane(min(4, max(0, (Mg - m0 - wr * 64 + 15) >> 4))) : 4;
+  const int live_f = (thin && p.thin) ? __builtin_amdgcn_readfirstlane(min(4, max(0, (Mg - m0 - wr * 64 + 15) >> 4))) : 4;
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Wb = reinterpret_cast<const char*>(p.W) + (int64_t)grp * p.w_gstride * 2;
   auto stage = [&](int op, int h, int kt, int buf) {   // op 0 = A, 1 = W; all arguments compile-time or wave-uniform
