@@ -1,6 +1,7 @@
 """Shader clock and socket power while the roofline kernel (gemm256 SwiGLU-split on RF w12, 1536 rows) runs back to back, on random and
 on zero operands, against an HBM-bound kernel (a device copy): `rocm-smi` sampled from a thread while the launches are queued.
-What "power-limited" means for the 0.26 / 0.29 roofline fraction."""
+What "power-limited" means for the 0.26 / 0.29 roofline fraction.  `clock_under_load.py loop`: the same sampling over the
+lock-step token loop (768 images, 16 tokens)."""
 import os, sys, re, subprocess, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -47,6 +48,31 @@ def measure(name, fn, seconds=6.0, per_launch_flop=None):
     extra = f", {per_launch_flop * n / dt / 1e12:.0f} TFLOP/s algorithmic" if per_launch_flop else ""
     print(f"{name}: {dt / n * 1e6:.1f} us per launch{extra}; sclk {clk:.0f} MHz over {len(s)} samples" +
           (f", power {sum(pw) / len(pw):.0f} W" if pw else ""), flush=True)
+if len(sys.argv) > 1 and sys.argv[1] == "loop":
+    # the lock-step token loop itself (768 images, 16 visual tokens): average clock and power over the whole run
+    import argparse
+    import bench
+    B, NT = 768, 16
+    a = argparse.Namespace(tiny=False, tokens=NT, layers=None, prompt_len=40, images=B, cfg_rows=2)
+    cfg, dec, rf, tok = bench.build_models(a, torch.device("cuda"), 0)
+    gg = torch.Generator(device="cuda").manual_seed(0)
+    prompt = torch.randint(0, 100000, (B, 40), generator=gg, device="cuda")
+    noises = torch.randn(B, NT + 1, 32, generator=gg, device="cuda")
+    bench.one_image(cfg, dec, rf, tok, prompt, noises, 1, 2); torch.cuda.synchronize()
+    samples, stop = [], False
+    def sampler():
+        while not stop:
+            samples.append(smi()); time.sleep(0.1)
+    th = threading.Thread(target=sampler); th.start()
+    t0 = time.perf_counter()
+    for _ in range(3): bench.one_image(cfg, dec, rf, tok, prompt, noises, 1, 2)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+    stop = True; th.join()
+    sm = [x for x in samples[2:] if x[0]]
+    pw = [x[1] for x in sm if x[1]]
+    print(f"token loop, {B} images x {NT} tokens: {dt:.3f} s = {B * NT / dt:.0f} tokens/s; sclk mean {sum(x[0] for x in sm) / len(sm):.0f} MHz "
+          f"(min {min(x[0] for x in sm)}, max {max(x[0] for x in sm)}), power mean {sum(pw) / len(pw):.0f} W (max {max(pw):.0f}) over {len(sm)} samples", flush=True)
+    sys.exit(0)
 print("idle:", smi(), flush=True)
 fl = 2.0 * rows * 2 * hid * K
 measure("w12 on random operands, back to back", w12(a_rand, w_rand), per_launch_flop=fl)
