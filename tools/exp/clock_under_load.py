@@ -73,6 +73,42 @@ if len(sys.argv) > 1 and sys.argv[1] == "loop":
     print(f"token loop, {B} images x {NT} tokens: {dt:.3f} s = {B * NT / dt:.0f} tokens/s; sclk mean {sum(x[0] for x in sm) / len(sm):.0f} MHz "
           f"(min {min(x[0] for x in sm)}, max {max(x[0] for x in sm)}), power mean {sum(pw) / len(pw):.0f} W (max {max(pw):.0f}) over {len(sm)} samples", flush=True)
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "energy":
+    # energy per launch (mean socket power x time, static power included) of the token loop's main call shapes at 1536 rows
+    from ming_univision_amd import ops
+    W_, HID = 3072, 8192
+    yb = split(torch.randn(rows, HID, generator=g).to(dev))
+    w3s = [(torch.randn(W_, HID, generator=g) * HID ** -0.5).to(torch.bfloat16).to(dev) for _ in range(4)]
+    P3 = torch.empty(3, rows, W_, dtype=torch.float32, device=dev)
+    def w3(i): L.mn_gemm256_splitk(ptr(yb), HID, yb.stride(0), ptr(w3s[i % 4]), HID, None, ptr(P3), rows, W_, HID, 3, current_stream())
+    xg = torch.randn(rows, W_, device=dev); gg_ = torch.ones(W_, dtype=torch.bfloat16, device=dev); bb_ = torch.zeros(W_, dtype=torch.bfloat16, device=dev)
+    def glue(i): ops.slab_resid_norm(P3, xg, gg_, bb_)
+    M_, nq, nkv, hd, t_max = rows, 16, 4, 128, 304
+    kvc = torch.randn(M_, 2, nkv, t_max, hd, device=dev); qq = torch.randn(M_, nq * hd, device=dev)
+    seqs = torch.arange(M_, dtype=torch.int32, device=dev); lens = torch.full((M_,), 170, dtype=torch.int32, device=dev)
+    def attn(i): ops.attn_decode(qq, nq, nkv, hd, kvc, seqs, lens)
+    def energy(name, fn, flop=None, seconds=5.0):
+        samples, stop = [], False
+        def sampler():
+            while not stop:
+                samples.append(smi()); time.sleep(0.15)
+        for i in range(20): fn(i)
+        torch.cuda.synchronize()
+        th = threading.Thread(target=sampler); th.start()
+        t0 = time.perf_counter(); n = 0
+        while time.perf_counter() - t0 < seconds:
+            for i in range(100): fn(n + i)
+            n += 100; torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        stop = True; th.join()
+        s_ = [x for x in samples[2:] if x[0] and x[1]]
+        pw = sum(x[1] for x in s_) / len(s_); clk = sum(x[0] for x in s_) / len(s_)
+        print(f"{name}: {dt / n * 1e6:.1f} us, {pw:.0f} W at {clk:.0f} MHz -> {pw * dt / n * 1e3:.1f} mJ per launch", flush=True)
+    energy("RF w12 (SwiGLU-split hi/lo)", w12(a_rand, w_rand))
+    energy("RF w3 (split-K 3 slabs)", w3)
+    energy("row kernel (3 slabs + residual + LN, bf16 out: mn_slab_resid_norm)", glue)
+    energy("GQA decode attention, 170 keys (split + combine)", attn)
+    sys.exit(0)
 print("idle:", smi(), flush=True)
 fl = 2.0 * rows * 2 * hid * K
 measure("w12 on random operands, back to back", w12(a_rand, w_rand), per_launch_flop=fl)
