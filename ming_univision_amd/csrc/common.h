@@ -78,15 +78,39 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // ---- wave / block reductions -------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions on DPP operands: `__shfl_xor` compiles to ds_bpermute_b32 here — one trip through the LDS crossbar per step
+// (64 of them in the GQA decode-attention kernel) — where a VALU instruction with a DPP-permuted operand does the same for nothing.
+// A row of 16 lanes is reduced by four symmetric pairings (row_mirror, row_half_mirror, quad_perm [2,3,0,1], quad_perm [1,0,3,2]):
+// every lane of the row ends with the bitwise same value.  The four rows of a wave are combined from one lane each (v_readlane),
+// in a fixed order, so the whole wave holds one value.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_f(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0x140>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0xB1>(v);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f<0x140>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0xB1>(v));
   return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = row16_max(v);
+  return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
 }
 // Block-wide sum; `red` is LDS scratch of >= blockDim.x/64 floats. All threads get the result.
 __device__ __forceinline__ float block_sum(float v, float* red) {

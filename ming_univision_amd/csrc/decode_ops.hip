@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(
         d = fmaf(kv.x, qv[i], d); d = fmaf(kv.y, qv[i + 1], d); d = fmaf(kv.z, qv[i + 2], d); d = fmaf(kv.w, qv[i + 3], d);
       }
     }
-    d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 1, 64);
+    d = row16_sum(d);           // the 16 lanes of a key are one DPP row
     const bool keep = ok && (!mk || mk[j] != 0);
     const float sv = keep ? d : -INFINITY;
     if (sub == 0 && (j - j0) < chunk_cap) sc[j - j0] = sv;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       float v = d[g];
-      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+      v = row16_sum(v);         // the 16 lanes of a key are one DPP row
       const float sv = keep ? v : -INFINITY;
       if (sub == 0 && (j - j0) < chunk_cap) sc[g * chunk_cap + (j - j0)] = sv;
       mx[g] = fmaxf(mx[g], sv);
