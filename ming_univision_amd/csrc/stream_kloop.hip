@@ -232,12 +232,16 @@ template <int MT>
 void kloop_launch_d(int nt, int G, int nz, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab, int M,
                     int Ntot, int K, const KGroups& g, hipStream_t st) {
   const int depth = g_kl_depth > 0 ? g_kl_depth : (nt == 2 ? 2 : 4);
-  const int ck = kloop_ck();
+  const int ck = kloop_ck(); (void)ck;
+#ifdef MN_DEV_HOOKS      // the 128-k chunk form exists for the A/B hook only (it spills at four row tiles): not in the product library
 #define MN_KL(NT_, D_)                                                                                      \
   do {                                                                                                      \
     if (ck == 64) kloop_launch<MT, NT_, D_, 64>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);           \
     else kloop_launch<MT, NT_, D_, 128>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);                   \
   } while (0)
+#else
+#define MN_KL(NT_, D_) kloop_launch<MT, NT_, D_, 64>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st)
+#endif
   if (nt == 2) { if (depth == 2) MN_KL(2, 2); else MN_KL(2, 4); }
   else { if (depth == 2) MN_KL(1, 2); else MN_KL(1, 4); }
 #undef MN_KL
