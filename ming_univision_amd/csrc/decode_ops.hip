@@ -501,7 +501,7 @@ __global__ void attn_decode_combine_kernel(const float* __restrict__ partial, in
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = s0 + j < S ? p[(s0 + j) * (HD + 2) + d] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc = fmaf(__shfl(f, (s0 + j) & 63, 64), v[j], acc);
+      for (int j = 0; j < 8; ++j) acc = fmaf(lane_f(f, (s0 + j) & 63), v[j], acc);      // uniform source lane: v_readlane, not ds_bpermute
     }
   } else {
     float mx = -INFINITY;
