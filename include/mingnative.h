@@ -28,8 +28,9 @@
 extern "C" {
 #endif
 
-#define MN_VERSION 110 /* 0.1.10: hidden visibility + MN_API, tune hooks out of the product library, mn_gemm256_grouped takes
-                          the row count of A, TP/EP entry points, mn_lmhead_argmax */
+#define MN_VERSION 120 /* 0.1.20: fp8 weight mode (section 7): wfmt / row-scale fields at the END of mn_skinny_args, mn_rf_head,
+                          mn_llm and mn_llm_tp (zero = bf16: callers of 0.1.10 that zero-fill the structs are unchanged),
+                          mn_quant_fp8_rows / mn_dequant_fp8_rows / mn_stream_mfma_w8 / mn_stream_mfma_grouped_w8 */
 
 /* Only the entry points declared here are exported (the library is built with -fvisibility=hidden; tests/test_host_logic.py
  * holds `nm -D` to exactly this list).  The launchers keep no mutable process state: launch plans are pure functions of the
@@ -103,11 +104,16 @@ typedef struct mn_skinny_args {
    * split into bf16 hi + lo) -> weight-streaming MFMA kernel over K slices -> reduce + epilogue, and need
    * mn_skinny_workspace_bytes(M, N, K, epilogue) bytes.  May be NULL for M <= 8 (fp32-FMA kernel is used). */
   void* ws; size_t ws_bytes;
+  /* fp8 weights (section 7): wfmt = MN_W_FP8_E4M3 -> `w` points to e4m3 bytes [N or 2N, K] (ldw == K, K % 16 == 0) and wscale to one
+   * fp32 scale per weight row.  Every row count (1..64) then takes the matrix-core route: ws is required
+   * (mn_skinny_workspace_bytes_w8), batch / nseg forms are not available. */
+  int32_t wfmt; const float* wscale;
 } mn_skinny_args;
 
 /* 1 <= M <= 64 (batch / nseg forms: M <= 8). */
 MN_API int mn_skinny_gemm(const mn_skinny_args* args, void* stream);
 MN_API size_t mn_skinny_workspace_bytes(int M, int N, int K, int epilogue);
+MN_API size_t mn_skinny_workspace_bytes_w8(int M, int N, int K, int epilogue);
 
 /* ------------------------------------------------------------------------------------------
  * 2. MoE router: RMSNorm + gate GEMV + fp32 softmax + top-k + renormalise, with the
@@ -375,6 +381,11 @@ typedef struct mn_rf_head {
   const uint16_t* const* w12;   const uint16_t* const* b12;    /* [depth] [2*hidden, w] */
   const uint16_t* const* w3;    const uint16_t* const* b3;     /* [depth] [w, hidden] */
   const uint16_t *fin_w, *fin_b;          /* final_layer.linear [target, w] */
+  /* fp8 weight mode (section 7; 0 = bf16).  wfmt = MN_W_FP8_E4M3: w12[b] / w3[b] point to e4m3 BYTES in the same [out, in] layout and
+   * w12_scale[b] [2*hidden] / w3_scale[b] [w] hold one fp32 scale per output row; every other tensor stays bf16.  Calls then take
+   * the weight-streaming route only (rows <= 64: that route is HBM-bound, fp8 halves its bytes; mn_rf_max_rows returns 64). */
+  int32_t wfmt;
+  const float* const* w12_scale; const float* const* w3_scale;
 } mn_rf_head;
 
 /* hidden [rows, llm_hidden] fp32 (last hidden states of the LLM step), rows = n_images x R image-major with
@@ -407,6 +418,12 @@ typedef struct mn_llm {
   const float *cos_tab, *sin_tab;    /* [n_pos, hd/2] */
   int32_t n_pos;
   int32_t mrope_sec_t, mrope_sec_h;  /* 0, 0: Legacy rotary, row_pos [M]; else 3D rotary sections, row_pos [3][M] (t, h, w) */
+  /* fp8 weight mode (section 7; 0 = bf16).  wfmt = MN_W_FP8_E4M3: w_gate_up[l] / w_down[l] point to e4m3 BYTES in the same packed
+   * layout, w_gate_up_scale[l] [E + S, 2I] / w_down_scale[l] [E + S, H] hold one fp32 scale per output row of every expert;
+   * attention, router and norm weights stay bf16.  Steps then take the weight-streaming route only (rows <= 64; every row count
+   * runs the grouped expert kernels; mn_llm_max_rows returns 64). */
+  int32_t wfmt;
+  const float* const* w_gate_up_scale; const float* const* w_down_scale;
 } mn_llm;
 
 MN_API size_t mn_llm_workspace_bytes(const mn_llm* m, int rows, int64_t t_max);
@@ -469,7 +486,11 @@ MN_API int mn_semdec_step(const mn_semdec* s, const float* latent_norm, int M,
  * [world (sender)][rows_cap] in fine-grained device memory (mn_tp_alloc), mapped on every other rank (mn_tp_ipc_*).  inbox[p] /
  * flags[p] are the DEVICE addresses of rank p's arrays as seen from THIS rank (host arrays of `world` pointers).  epoch counts the
  * all-reduces completed on the communicator; it is advanced by the calls below, identically on every rank.  err: a local device
- * word that a bounded flag wait sets non-zero when it gives up (a dead peer / diverged launch order never hangs the GPU). */
+ * word that a bounded flag wait sets non-zero when it gives up (a dead peer / diverged launch order never hangs the GPU).  The
+ * wait is bounded in WALL time — wait_ms milliseconds on the GPU's constant 100 MHz clock, 0 = the default of 30 s: host-side skew
+ * between ranks (first-launch code loading, an allocator stall) is legitimate and can be long — and a row whose wait expired
+ * POISONS its outputs with NaN instead of summing stale slabs: callers check err at their next host sync (TpRank does), and a
+ * result can never silently miss an all-reduce. */
 typedef struct mn_tp_comm {
   int32_t rank, world;
   float* const* inbox;
@@ -478,6 +499,7 @@ typedef struct mn_tp_comm {
   int32_t rows_cap;
   uint32_t epoch;
   uint32_t* err;
+  uint32_t wait_ms;     /* 0 = 30 000 */
 } mn_tp_comm;
 
 /* Host-side setup (these DO allocate / map; they are not launchers): fine-grained (uncached, system-coherent) device memory, its
@@ -520,6 +542,8 @@ typedef struct mn_llm_tp {
   int32_t shared_inter;
   const uint16_t* const* ws_gate_up;   /* [L] [2 * shared_inter, H] */
   const uint16_t* const* ws_down;      /* [L] [H, shared_inter] */
+  /* m->wfmt = MN_W_FP8_E4M3: ws_gate_up / ws_down are e4m3 bytes with these row scales ([2 * shared_inter] / [H] per layer) */
+  const float* const* ws_gate_up_scale; const float* const* ws_down_scale;
 } mn_llm_tp;
 MN_API size_t mn_llm_tp_workspace_bytes(const mn_llm* m, const mn_llm_tp* tp, int rows, int64_t t_max);
 MN_API int mn_llm_tp_segments(const mn_llm* m);
@@ -544,6 +568,34 @@ MN_API int mn_rf_sample_tp(const mn_rf_head* h, mn_tp_comm* comm, const float* h
 MN_API size_t mn_lmhead_argmax_workspace_bytes(int M, int V, int H);
 MN_API int mn_lmhead_argmax(const float* hidden, int64_t ld_hidden, int M, const uint16_t* W, int64_t ldw, int V, int H,
                             int64_t vocab_offset, int64_t* idx, float* val, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 7. fp8 weight mode (BASELINE configs[4] "fp8").
+ *    No arithmetic counterpart in the reference: its reduced-byte surface is the `dtype` switch of MingUniVisionInfer
+ *    (mingunivision/mingunivisioninfer.py:46-70, int8 / int4 weight-only through quanto / bitsandbytes); the only fp8 trace is
+ *    vllm/ming_lite.patch:171-190.  This mode is weight-only too: OCP e4m3fn bytes + one fp32 scale per OUTPUT ROW,
+ *        W[n, k] = e4m3(Wq[n, k]) * scale[n],
+ *    for the tensors that carry the bytes of the HBM-bound decode route — RF w12 / w3 and the routed + shared experts.
+ *    Activations stay fp32 / bf16 hi+lo pairs and the MFMAs stay bf16: the kernels convert e4m3 -> bf16 in registers (exact)
+ *    and apply the row scale to the fp32 accumulators, so the result is that of the DEQUANTISED weights to fp32 rounding —
+ *    parity is defined against the oracle fed those (tests/test_gpu_fp8.py); the distance between the quantised and the bf16
+ *    model is reported separately.  mn_quant_fp8_rows emits power-of-two scales, for which the dequantised weights are exactly
+ *    representable in bf16 (mn_dequant_fp8_rows): the same model can be run through every bf16 route.
+ * ------------------------------------------------------------------------------------------ */
+enum { MN_W_BF16 = 0, MN_W_FP8_E4M3 = 1 };
+/* Row-wise quantisation at load: scale[n] = 2^ceil(log2(amax_n / 448)) (1 for an all-zero row), Wq[n, k] = e4m3_rne(W[n, k] / scale[n]).
+ * W bf16 [n_rows, K] (row stride ldw), Wq bytes (row stride ldq), K % 4 == 0. */
+MN_API int mn_quant_fp8_rows(const uint16_t* W, int64_t ldw, uint8_t* Wq, int64_t ldq, float* scale, int64_t n_rows, int K, void* stream);
+/* W[n, k] = bf16_rne(e4m3(Wq[n, k]) * scale[n]) — exact for power-of-two scales. */
+MN_API int mn_dequant_fp8_rows(const uint8_t* Wq, int64_t ldq, const float* scale, uint16_t* W, int64_t ldw, int64_t n_rows, int K,
+                               void* stream);
+/* mn_stream_mfma / mn_stream_mfma_grouped on fp8 weights: Wq e4m3 [Ntot, K] dense (K % 16 == 0, 16-byte aligned), wscale fp32
+ * [Ntot]; grouped: group g reads Wq + g * w_stride bytes and wscale + g * s_stride floats.  Half the HBM bytes per launch. */
+MN_API int mn_stream_mfma_w8(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, void* stream);
+MN_API int mn_stream_mfma_w8_slices(int M, int Ntot, int K);
+MN_API int mn_stream_mfma_grouped_w8(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale,
+                                     int64_t s_stride, float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G,
+                                     int max_rows, int Ntot, int K, void* stream);
 
 #ifdef __cplusplus
 }

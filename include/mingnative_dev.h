@@ -17,6 +17,7 @@ extern "C" {
 
 MN_DEV_API void mn_skinny_tune(int R, int nt, int bpc);                 /* skinny_gemm.hip launch plan */
 MN_DEV_API void mn_stream_tune_plan(int kch, int nw);                   /* stream_mfma.hip K-slice length / waves */
+MN_DEV_API void mn_stream_tune_w8(int depth);                           /* stream_mfma.hip fp8 form: weight chunks in flight per wave (1 or 2) */
 MN_DEV_API void mn_stream_kloop_tune(int nz, int depth, int nt);        /* stream_kloop.hip */
 MN_DEV_API void mn_stream_kloop_tune_small(int div);
 MN_DEV_API void mn_moe_router_tune(int max_rows);                       /* one-launch router up to this many rows */

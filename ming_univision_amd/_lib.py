@@ -36,6 +36,7 @@ class SkinnyArgs(C.Structure):
         ("res_batch_stride", C.c_int64),
         ("nseg", C.c_int32), ("seg_index", C.c_void_p), ("seg_scale", C.c_void_p), ("seg_w_stride", C.c_int64),
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+        ("wfmt", C.c_int32), ("wscale", C.c_void_p),
     ]
 
 
@@ -53,6 +54,7 @@ class RfHead(C.Structure):
         ("ada_w", C.c_void_p), ("ada_b", C.c_void_p),
         ("ln_g", PP), ("ln_b", PP), ("w12", PP), ("b12", PP), ("w3", PP), ("b3", PP),
         ("fin_w", C.c_void_p), ("fin_b", C.c_void_p),
+        ("wfmt", C.c_int32), ("w12_scale", PP), ("w3_scale", PP),
     ]
 
 
@@ -68,6 +70,7 @@ class Llm(C.Structure):
         ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p),
         ("n_pos", C.c_int32),
         ("mrope_sec_t", C.c_int32), ("mrope_sec_h", C.c_int32),
+        ("wfmt", C.c_int32), ("w_gate_up_scale", PP), ("w_down_scale", PP),
     ]
 
 
@@ -90,7 +93,7 @@ class TpComm(C.Structure):
         ("rank", C.c_int32), ("world", C.c_int32),
         ("inbox", PP), ("flags", PP),
         ("cap", C.c_int64), ("rows_cap", C.c_int32), ("epoch", C.c_uint32),
-        ("err", C.c_void_p),
+        ("err", C.c_void_p), ("wait_ms", C.c_uint32),
     ]
 
 
@@ -98,8 +101,12 @@ class LlmTp(C.Structure):
     _fields_ = [
         ("expert0", C.c_int32), ("n_local_experts", C.c_int32), ("shared_inter", C.c_int32),
         ("ws_gate_up", PP), ("ws_down", PP),
+        ("ws_gate_up_scale", PP), ("ws_down_scale", PP),
     ]
 
+
+W_BF16, W_FP8_E4M3 = 0, 1          # mingnative.h section 7: weight formats of the streaming route
+WFMT = {"bf16": W_BF16, "fp8": W_FP8_E4M3}
 
 _lib = None
 
@@ -111,6 +118,12 @@ SYMBOLS = {
     "mn_num_cus": (_i, []),
     "mn_skinny_gemm": (_i, [C.POINTER(SkinnyArgs), _p]),
     "mn_skinny_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "mn_skinny_workspace_bytes_w8": (_sz, [_i, _i, _i, _i]),
+    "mn_quant_fp8_rows": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _p]),
+    "mn_dequant_fp8_rows": (_i, [_p, _i64, _p, _p, _i64, _i64, _i, _p]),
+    "mn_stream_mfma_w8": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "mn_stream_mfma_w8_slices": (_i, [_i, _i, _i]),
+    "mn_stream_mfma_grouped_w8": (_i, [_p, _i, _p, _i64, _p, _i64, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "mn_gemm_bf16_hilo": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _i, _i, _i, _p]),
     "mn_gemm_bf16_splitk": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _i, _i, _p]),
     "mn_stream_mfma": (_i, [_p, _p, _p, _i, _i, _i, _p]),
@@ -198,7 +211,7 @@ def lib():
         fn = getattr(handle, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if handle.mn_version() < 110:
+    if handle.mn_version() < 120:
         raise RuntimeError("libmingnative.so is too old")
     _lib = handle
     return _lib

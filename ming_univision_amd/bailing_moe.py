@@ -16,6 +16,11 @@ All arithmetic runs in libmingnative; this module owns HBM residency:
     reference's torch.cat per layer per step (DynamicCache.update, :789).
   * per-row bookkeeping (cache slot, rotary position, length, key mask) lives in device
     int32/uint8 arrays that the kernels read, so the AR loop never syncs with the host.
+  * `weights="fp8"` (mingnative.h section 7; the reference's reduced-byte surface is the `dtype` switch of
+    mingunivisioninfer.py:46-70): the packed experts — 15.5 of the stack's 16.2 B parameters, 87-92 % of the bytes a decode step
+    streams — are quantised once at load to OCP e4m3 with one power-of-two scale per output row of every expert and streamed
+    as bytes; attention, router, norms, embeddings and lm_head stay bf16.  The stack then serves <= 64 rows per step (the
+    HBM-bound route) and long prompts prefill in 64-row passes.
 """
 import ctypes as C
 
@@ -52,6 +57,13 @@ def pack_experts(sd, prefix, cfg):
     return gu, dn
 
 
+def quantize_layer_experts(ly):
+    """fp8 weight mode: replace a layer's packed bf16 experts by e4m3 bytes + row scales [E + S, 2I] / [E + S, H] (in place)."""
+    for k in ("w_gate_up", "w_down"):
+        ly[k], ly[k + "_scale"] = ops.quant_fp8_rows(ly[k])
+    return ly
+
+
 MAX_ROWS = 64        # rows of one pass through the weight-streaming decode kernels (four 16-row MFMA tiles)
 MAX_ROWS_WIDE = 2048 # rows of one pass through the wide route (every Linear a 256 x 256-tile MFMA GEMM on hi/lo operands)
 
@@ -60,9 +72,17 @@ class BailingMoeDecoder:
     """Weights + KV arena + C-ABI pointer table of the decoder stack."""
 
     def __init__(self, cfg: BailingMoeConfig, layers, final_norm, word_embeddings=None, lm_head=None,
-                 t_max=2048, n_seq=3, n_pos=None):
+                 t_max=2048, n_seq=3, n_pos=None, weights="bf16"):
         """layers: list of dicts with bf16 CUDA tensors: ln1, wqkv, wdense, ln2, gate, image_gate (or None),
-        w_gate_up, w_down (see pack_experts).  Use `from_state_dict` / `synthetic` to build them."""
+        w_gate_up, w_down (see pack_experts).  Use `from_state_dict` / `synthetic` to build them.
+        weights="fp8": w_gate_up / w_down are e4m3 bytes (uint8) with `w_gate_up_scale` / `w_down_scale` (quantize_layer_experts;
+        bf16 experts are quantised here)."""
+        assert weights in _lib.WFMT, f"weights={weights!r}: 'bf16' or 'fp8'"
+        self.weights = weights
+        if weights == "fp8":
+            for ly in layers:
+                if ly["w_gate_up"].dtype != torch.uint8:
+                    quantize_layer_experts(ly)
         rs = cfg.rope_scaling
         assert rs is None or rs.get("type") == "3D", "Legacy or 3D rotary only (linear / NTK / YaRN are dead code, SURVEY.md a27)"
         # 3D rotary (:413-425, 463-469): same tables, per-frequency choice among the t / h / w position streams.
@@ -90,6 +110,11 @@ class BailingMoeDecoder:
         s.moe_inter, s.norm_topk_prob, s.rms_eps = cfg.moe_intermediate_size, int(cfg.norm_topk_prob), cfg.rms_norm_eps
         for k in keys:
             setattr(s, k, C.cast(self._arrays[k], _lib.PP))
+        s.wfmt = _lib.WFMT[weights]
+        if weights == "fp8":
+            for k in ("w_gate_up_scale", "w_down_scale"):
+                self._arrays[k] = ptr_array([ly[k] for ly in layers])
+                setattr(s, k, C.cast(self._arrays[k], _lib.PP))
         if not cfg.multi_gate:
             s.image_gate = None
         s.final_norm = ptr(final_norm)
@@ -136,7 +161,9 @@ class BailingMoeDecoder:
                 gate=sd[p + ".mlp.gate.weight"],
                 image_gate=sd.get(p + ".mlp.image_gate.weight") if cfg.multi_gate else None,
                 w_gate_up=gu, w_down=dn))
-            del sd
+            if kw.get("weights") == "fp8":          # layer by layer: the bf16 experts of one layer at a time
+                quantize_layer_experts(layers[-1])
+            del sd, gu, dn
         H, V = cfg.hidden_size, cfg.vocab_size
         fn = synth_tensor("model.norm.weight", (H,), seed, device, torch.bfloat16)
         emb = lm = None
@@ -145,12 +172,53 @@ class BailingMoeDecoder:
             lm = synth_tensor("lm_head.weight", (V, H), seed, device, torch.bfloat16)
         return cls(cfg, layers, fn, emb, lm, **kw)
 
+    def view(self, t_max, n_seq, n_pos=None):
+        """A second decoder on the SAME weights with its own KV arena / rotary tables (e.g. long-context understanding next to an
+        image batch's arena)."""
+        return BailingMoeDecoder(self.cfg, self.layers, self.final_norm, self.word_embeddings, self.lm_head, t_max=t_max, n_seq=n_seq,
+                                 n_pos=n_pos, weights=self.weights)
+
+    def to_fp8(self, t_max=None, n_seq=None):
+        """A second decoder whose experts are e4m3 copies of this one's (attention / router / vocabulary tensors shared; this bf16
+        decoder stays usable): + 0.5 bytes per expert parameter of HBM."""
+        assert self.weights == "bf16"
+        layers = [quantize_layer_experts(dict(ly)) for ly in self.layers]
+        return BailingMoeDecoder(self.cfg, layers, self.final_norm, self.word_embeddings, self.lm_head, t_max=t_max or self.t_max,
+                                 n_seq=n_seq or self.n_seq, weights="fp8")
+
     def weight_bytes_active(self, distinct_experts_per_layer):
+        """Weight bytes one decode step streams: attention + router (bf16) + the distinct routed and the shared experts
+        (bf16, or e4m3 bytes + fp32 row scales)."""
         cfg = self.cfg
         H, I = cfg.hidden_size, cfg.moe_intermediate_size
         attn = (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim * H + H * cfg.num_attention_heads * cfg.head_dim
-        per_expert = 3 * I * H
-        return 2 * cfg.num_hidden_layers * (attn + cfg.num_experts * H + (distinct_experts_per_layer + self.n_shared) * per_expert)
+        per_expert = 2 * 3 * I * H if self.weights == "bf16" else 3 * I * H + (2 * I + H) * 4
+        return cfg.num_hidden_layers * (2 * (attn + cfg.num_experts * H) + (distinct_experts_per_layer + self.n_shared) * per_expert)
+
+    def dequantized_state_dict(self, prefix="model."):
+        """fp8 mode: {reference parameter name: bf16 tensor} of every expert / shared-expert projection as the kernels see it —
+        the inverse of pack_experts on the dequantised packed tensors.  What the oracle is fed in the parity tests."""
+        cfg = self.cfg
+        E, S, I = cfg.num_experts, self.n_shared, cfg.moe_intermediate_size
+        out = {}
+        for li in range(cfg.num_hidden_layers):
+            gu, dn = self.dequantized_experts(li)
+            p = f"{prefix}layers.{li}.mlp"
+            for e in range(E):
+                out[f"{p}.experts.{e}.gate_proj.weight"] = gu[e, :I]
+                out[f"{p}.experts.{e}.up_proj.weight"] = gu[e, I:]
+                out[f"{p}.experts.{e}.down_proj.weight"] = dn[e]
+            if S:
+                out[f"{p}.shared_experts.gate_proj.weight"] = torch.cat([gu[E + s, :I] for s in range(S)], 0)
+                out[f"{p}.shared_experts.up_proj.weight"] = torch.cat([gu[E + s, I:] for s in range(S)], 0)
+                out[f"{p}.shared_experts.down_proj.weight"] = torch.cat([dn[E + s] for s in range(S)], 1)
+        return out
+
+    def dequantized_experts(self, li):
+        """fp8 mode: layer li's packed experts as the kernels see them (e4m3 * row scale, exact in bf16): (w_gate_up, w_down)."""
+        assert self.weights == "fp8"
+        ly = self.layers[li]
+        return (ops.dequant_fp8_rows(ly["w_gate_up"], ly["w_gate_up_scale"]), ops.dequant_fp8_rows(ly["w_down"], ly["w_down_scale"]))
 
     # ---- stepping -------------------------------------------------------------------------
     def _workspace(self, rows):
@@ -318,6 +386,10 @@ class BailingMoeDecoder:
         embeds_list[i] fp32 [T_i,H] goes to cache sequence seqs[i] from slot `past`.  Returns the final-norm hidden state of
         the LAST token of each sequence [B,H] fp32 (what the next-token logits need)."""
         import math
+        if self.weights != "bf16":
+            # fp8 experts exist for the <= 64-row streaming route only: shared 64-row passes through the decode kernels instead
+            assert positions is None and key_masks is None, "fp8 weight mode: default positions / masks only"
+            return self.prefill_ragged(embeds_list, seqs, past=past, image_masks=image_masks)
         cfg, L_ = self.cfg, lib()
         lens = [int(e.shape[0]) for e in embeds_list]
         H = embeds_list[0].shape[1]
@@ -590,6 +662,9 @@ def generate_images(dec: BailingMoeDecoder, rf, tok, start_embed, past_lens, att
     n_tok = cfg.num_image_tokens_for_gen
     groups = split_groups(B, n_groups)
     n_groups, per = len(groups), groups[0][1]
+    if n_groups > 1 and getattr(dec, "single_stream", False):
+        # a TP communicator is one epoch counter + a two-parity inbox: its all-reduces must be strictly sequential on ONE stream
+        raise ValueError("tensor-parallel decoders run one lock-step group (n_groups = 1): the communicator serves a single stream")
     row_cap = min(dec.max_rows(), rf.max_rows(), tok.max_decode_rows() * rpi)
     assert max(past_lens) + n_tok + 1 <= dec.t_max and per * rpi <= row_cap, f"{per * rpi} rows per group > {row_cap}"
     if rpi > 1:   # replicate each prompt's KV to its CFG rows (:1891-1902) — device memcpy
@@ -612,6 +687,8 @@ def generate_images(dec: BailingMoeDecoder, rf, tok, start_embed, past_lens, att
                 run.token(ti)
     for s in streams:
         main.wait_stream(s)
+    if hasattr(dec, "check_err"):        # tensor-parallel decoders: an all-reduce wait that expired (NaN-poisoned rows) raises here
+        dec.check_err()
     if n_groups > 1:      # side-stream allocations are consumed on the caller's stream below
         for r in runs:
             for t in (r.latents, r.sems, r.hidden):

@@ -73,6 +73,22 @@ __device__ __forceinline__ void split_pk_bf16(float a, float b, uint32_t& hi, ui
   lo = cvt_pk_bf16(a - bf16lo_to_f32(hi), b - bf16hi_to_f32(hi));
 }
 
+// ---- fp8 weights (OCP e4m3fn) -----------------------------------------------------------------------
+// Four e4m3 bytes of one dword -> four bf16 (two packed dwords), exact: every e4m3 value is a bf16 value.  v_cvt_scalef32_pk_bf16_fp8
+// converts the two bytes of the selected 16-bit half in one instruction; the scale operand stays 1.0 (row scales are applied to the
+// fp32 accumulators, so any fp32 scale is allowed).
+typedef uint32_t mn_u2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t mn_u4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mn_u2_t fp8x4_to_bf16(uint32_t q) {
+  return mn_u2_t{__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q, 1.0f, false)),
+                 __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q, 1.0f, true))};
+}
+// eight e4m3 bytes (k ascending) -> eight bf16 = one MFMA fragment / one 16-byte LDS slot
+__device__ __forceinline__ mn_u4_t fp8x8_to_bf16(uint32_t q0, uint32_t q1) {
+  const mn_u2_t a = fp8x4_to_bf16(q0), b = fp8x4_to_bf16(q1);
+  return mn_u4_t{a.x, a.y, b.x, b.y};
+}
+
 // ---- activations ----------------------------------------------------------------------------
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

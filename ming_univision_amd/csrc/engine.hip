@@ -27,6 +27,26 @@ extern "C" int mn_attn_decode_split(const float* q, int M, int n_q, int n_kv, in
 extern "C" int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P,
                                       int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows,
                                       int Ntot, int K, void* stream);
+extern "C" size_t mn_skinny_workspace_bytes_w8(int M, int N, int K, int epilogue);
+
+// ---- weight-format dispatch of the streaming launches (mingnative.h section 7): wfmt != 0 -> e4m3 bytes + fp32 row scales ----
+static inline int stream_slices(int wfmt, int M, int Ntot, int K) {
+  return wfmt ? mn_stream_mfma_w8_slices(M, Ntot, K) : mn_stream_mfma_slices(M, Ntot, K);
+}
+static inline int stream_dense(int wfmt, const uint16_t* Y, const void* W, const float* wscale, float* P, int M, int Ntot, int K, void* stream) {
+  return wfmt ? mn_stream_mfma_w8(Y, reinterpret_cast<const uint8_t*>(W), wscale, P, M, Ntot, K, stream)
+              : mn_stream_mfma(Y, reinterpret_cast<const uint16_t*>(W), P, M, Ntot, K, stream);
+}
+// grouped: w_stride counts weight ELEMENTS (= bytes for fp8), s_stride the row scales per group
+static inline int stream_grouped(int wfmt, const uint16_t* Y, int y_rows, const void* W, int64_t w_stride, const float* wscale, int64_t s_stride,
+                                 float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows, int Ntot, int K,
+                                 void* stream) {
+  return wfmt ? mn_stream_mfma_grouped_w8(Y, y_rows, reinterpret_cast<const uint8_t*>(W), w_stride, wscale, s_stride, P, p_rows, off, xrows,
+                                          G, max_rows, Ntot, K, stream)
+              : mn_stream_mfma_grouped(Y, y_rows, reinterpret_cast<const uint16_t*>(W), w_stride, P, p_rows, off, xrows, G, max_rows, Ntot,
+                                       K, stream);
+}
+
 namespace {
 
 struct Carver {  // carve 256-byte aligned pieces out of a caller-provided workspace
@@ -340,7 +360,11 @@ size_t sk_ws_need(int M, std::initializer_list<std::array<int, 3>> shapes) {   /
 // ===========================================================================================
 // rows >= 5 run the RF blocks as the matrix-core chain; its glue kernels move 4 columns (16 bytes) per thread
 static bool rf_chain_ok(const mn_rf_head* h, int rows) {
-  return mn_skinny_workspace_bytes(rows, h->w, h->w, 0) > 0 && h->w <= 4096 && (h->w % 4) == 0 && (h->hidden % 4) == 0;
+  return (h->wfmt || mn_skinny_workspace_bytes(rows, h->w, h->w, 0) > 0) && h->w <= 4096 && (h->w % 4) == 0 && (h->hidden % 4) == 0;
+}
+// fp8 weight mode: the RF blocks must be able to run as the matrix-core chain (the fp32-FMA kernels read bf16 rows)
+static bool rf_fp8_ok(const mn_rf_head* h) {
+  return h->wfmt == MN_W_FP8_E4M3 && h->w12_scale && h->w3_scale && h->w <= 4096 && (h->w % 16) == 0 && (h->hidden % 16) == 0;
 }
 
 static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, float** z, float** c, float** ada,
@@ -362,8 +386,8 @@ static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, floa
   *skws = cv.take<char>(*skws_bytes);
   // matrix-core chain (rows >= 5): split activations of both GEMVs and the K-slice partial slabs
   const bool chain = rf_chain_ok(h, rows);
-  const size_t p12 = (size_t)mn_stream_mfma_slices(rows, 2 * h->hidden, h->w) * 2 * h->hidden;
-  const size_t p3 = (size_t)mn_stream_mfma_slices(rows, h->w, h->hidden) * h->w;
+  const size_t p12 = (size_t)stream_slices(h->wfmt, rows, 2 * h->hidden, h->w) * 2 * h->hidden;
+  const size_t p3 = (size_t)stream_slices(h->wfmt, rows, h->w, h->hidden) * h->w;
   const size_t pf = (size_t)mn_stream_mfma_slices(rows, h->target, h->w) * h->target;
   const size_t pmax = p12 > p3 ? (p12 > pf ? p12 : pf) : (p3 > pf ? p3 : pf);
   *ya = cv.take<bf16_t>(chain ? (size_t)2 * rows * h->w : 0);
@@ -391,6 +415,7 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   MN_CHECK_ARG(n_images >= 1 && rows >= n_images && rows % n_images == 0 && rows / n_images <= 3 && (rows <= 64 || rf_wide_ok(h, rows)),
                "mn_rf_sample: rows=%d n_images=%d (1..3 CFG rows per image; <= 64 rows, or <= 2048 with 64-aligned widths)", rows, n_images);
   MN_CHECK_ARG(h->target <= 256, "mn_rf_sample: target too large");
+  MN_CHECK_ARG(h->wfmt == MN_W_BF16 || rf_fp8_ok(h), "mn_rf_sample: bad fp8 weight description (wfmt %d: row scales, widths %% 16)", h->wfmt);
   if (rf_wide_ok(h, rows))
     return rf_sample_wide(h, hidden, ld_hidden, rows, n_images, noise, temperature, text_cfg, image_cfg, latent_out, workspace,
                           workspace_bytes, stream);
@@ -440,11 +465,11 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
                          (const bf16_t*)nullptr, (const float*)nullptr, hh, h->ln_g[0], h->ln_b[0], ada, ada + w, (int64_t)A, ya);
       for (int b = 0; b < h->depth; ++b) {
         const float* mod = ada + (int64_t)b * 3 * w;
-        int nz = mn_stream_mfma(ya, h->w12[b], pbuf, rows, 2 * hid_n, w, stream);
+        int nz = stream_dense(h->wfmt, ya, h->w12[b], h->wfmt ? h->w12_scale[b] : nullptr, pbuf, rows, 2 * hid_n, w, stream);
         if (nz < 0) return nz;
         hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)rows * hid_n, 1024)), dim3(256), 0, st, pbuf, nz,
                            rows, hid_n, h->b12[b], yb);
-        nz = mn_stream_mfma(yb, h->w3[b], pbuf, rows, w, hid_n, stream);
+        nz = stream_dense(h->wfmt, yb, h->w3[b], h->wfmt ? h->w3_scale[b] : nullptr, pbuf, rows, w, hid_n, stream);
         if (nz < 0) return nz;
         const bool last = b + 1 == h->depth;
         const float* nmod = last ? ada + (int64_t)h->depth * 3 * w : ada + (int64_t)(b + 1) * 3 * w;
@@ -701,7 +726,7 @@ static size_t moe_carve(Carver& cv, int rows, int H, int I, int G, int n_slot, M
 // grouped-expert route from 3 rows (3 rows: 74.2 vs 70.6 tokens/s against the fp32-FMA pair kernels; 2 rows: 75.1 vs 76.8)
 constexpr int MOE_MFMA_MIN_ROWS = 3;
 static bool moe_mfma_ok(const mn_llm* m, int rows) {
-  return rows >= MOE_MFMA_MIN_ROWS && rows * (m->top_k + m->n_shared_slots) <= 1024 &&
+  return (rows >= MOE_MFMA_MIN_ROWS || m->wfmt) && rows * (m->top_k + m->n_shared_slots) <= 1024 &&
          m->n_experts + m->n_shared_slots <= 256 && (m->hidden % 8) == 0 && (m->moe_inter % 8) == 0;   // % 4: vector glue
 }
 
@@ -845,6 +870,10 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
                "mn_llm_step: null pointer");
   MN_CHECK_ARG(M >= 1 && (M <= 64 || llm_wide_ok(m, M)) && x_row_div >= 1,
                "mn_llm_step: M=%d (1..64, or up to 2048 rows with 64-aligned widths)", M);
+  // fp8 experts: every row count runs the grouped streaming kernels (the fp32-FMA pair kernels read bf16 rows)
+  MN_CHECK_ARG(m->wfmt == MN_W_BF16 || (m->wfmt == MN_W_FP8_E4M3 && m->w_gate_up_scale && m->w_down_scale && (m->hidden % 16) == 0 &&
+                                        (m->moe_inter % 16) == 0 && M <= 64 && moe_mfma_ok(m, M)),
+               "mn_llm_step: fp8 experts need row scales, widths %% 16 == 0 and <= 64 rows (M = %d)", M);
   if (llm_wide_ok(m, M))
     return llm_step_wide(m, x, ldx, x_row_div, M, image_mask, row_seq, row_slot, row_pos, row_len, key_mask, ld_mask, kv_cache, n_seq, t_max,
                          hidden_out, workspace, workspace_bytes, stream);
@@ -896,13 +925,13 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
                          m->norm_topk_prob, S, w.tw, w.ti, G, grouped ? w.moe.off : (int32_t*)nullptr, w.moe.xrows,
                          w.moe.pair_pos);
       if (grouped) {
-        nz = mn_stream_mfma_grouped(w.yh, M, m->w_gate_up[l], (int64_t)2 * I * H, w.moe.p1, P, w.moe.off, w.moe.xrows, G, M,
-                                    2 * I, H, stream);
+        nz = stream_grouped(m->wfmt, w.yh, M, m->w_gate_up[l], (int64_t)2 * I * H, m->wfmt ? m->w_gate_up_scale[l] : nullptr, 2 * I,
+                            w.moe.p1, P, w.moe.off, w.moe.xrows, G, M, 2 * I, H, stream);
         if (nz < 0) return nz;
         hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)P * I, 1024)), dim3(256), 0, st, w.moe.p1, nz, P,
                            I, (const bf16_t*)nullptr, w.moe.y2);
-        nz2 = mn_stream_mfma_grouped(w.moe.y2, P, m->w_down[l], (int64_t)H * I, w.moe.p2, P, w.moe.off, nullptr, G, M, H, I,
-                                     stream);
+        nz2 = stream_grouped(m->wfmt, w.moe.y2, P, m->w_down[l], (int64_t)H * I, m->wfmt ? m->w_down_scale[l] : nullptr, H, w.moe.p2, P,
+                             w.moe.off, nullptr, G, M, H, I, stream);
         if (nz2 < 0) return nz2;
       } else {   // 2 rows: (row, expert) pairs on the fp32-FMA kernels, accumulated straight into h
         mn_skinny_args a = sk(w.xn, H, m->w_gate_up[l], H, nullptr, w.hmid, I, 1, I, H);
@@ -947,12 +976,13 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
       const int G = m->n_experts + m->n_shared_slots, P = M * n_slot;
       hipLaunchKernelGGL(moe_group_split_kernel, dim3(M + 1), dim3(256), 0, st, w.ti, M, n_slot, G, w.moe.off, w.moe.xrows,
                          w.moe.pair_pos, w.xn, H, w.moe.y1);
-      int nz = mn_stream_mfma_grouped(w.moe.y1, M, m->w_gate_up[l], (int64_t)2 * I * H, w.moe.p1, P, w.moe.off, w.moe.xrows,
-                                      G, M, 2 * I, H, stream);
+      int nz = stream_grouped(m->wfmt, w.moe.y1, M, m->w_gate_up[l], (int64_t)2 * I * H, m->wfmt ? m->w_gate_up_scale[l] : nullptr,
+                              2 * I, w.moe.p1, P, w.moe.off, w.moe.xrows, G, M, 2 * I, H, stream);
       if (nz < 0) return nz;
       hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)P * I, 1024)), dim3(256), 0, st, w.moe.p1, nz, P, I,
                          (const bf16_t*)nullptr, w.moe.y2);
-      nz = mn_stream_mfma_grouped(w.moe.y2, P, m->w_down[l], (int64_t)H * I, w.moe.p2, P, w.moe.off, nullptr, G, M, H, I, stream);
+      nz = stream_grouped(m->wfmt, w.moe.y2, P, m->w_down[l], (int64_t)H * I, m->wfmt ? m->w_down_scale[l] : nullptr, H, w.moe.p2, P,
+                          w.moe.off, nullptr, G, M, H, I, stream);
       if (nz < 0) return nz;
       hipLaunchKernelGGL(moe_combine_resid_kernel, dim3(mn_cdiv((int64_t)M * H, 1024)), dim3(256), 0, st, w.moe.p2, nz,
                          (int64_t)P * H, M, H, n_slot, w.moe.pair_pos, w.tw, w.h);
@@ -1083,23 +1113,31 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* __restri
   __shared__ int si[16];
   const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* r = logits + (int64_t)m * ld;
+  // torch.argmax's order: NaN is the maximum, equal values (NaN among NaN too) resolve to the lowest index — a row of NaN logits
+  // yields a VALID id (the first NaN), never an out-of-range one
+  auto better = [](float v, int j, float bv, int bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn || bn) return vn && (!bn || j < bi);
+    return v > bv || (v == bv && j < bi);
+  };
   float bv = -INFINITY;
   int bi = 0x7fffffff;
   for (int j = threadIdx.x; j < V; j += 1024) {
     const float v = r[j];
-    if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; }
+    if (better(v, j, bv, bi)) { bv = v; bi = j; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float ov = __shfl_xor(bv, o, 64);
     const int oi = __shfl_xor(bi, o, 64);
-    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
   }
   if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w2 = 1; w2 < 16; ++w2)
-      if (sv[w2] > bv || (sv[w2] == bv && si[w2] < bi)) { bv = sv[w2]; bi = si[w2]; }
+      if (better(sv[w2], si[w2], bv, bi)) { bv = sv[w2]; bi = si[w2]; }
+    if (bi >= V) bi = 0;                               // V >= 1: unreachable, kept as the last line of defence for the gather that follows
     idx[m] = (int64_t)bi + vocab_offset;
     if (val) val[m] = bv;
   }

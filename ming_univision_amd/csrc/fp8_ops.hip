@@ -1,0 +1,77 @@
+// fp8_ops.hip — load-time row-wise quantisation of bf16 weights to OCP e4m3fn + one power-of-two fp32 scale per output row
+// (mingnative.h section 7), and the inverse.  HBM-bound elementwise work, run once per tensor when a model is loaded in fp8 mode.
+//
+// Why power-of-two scales: e4m3 is a floating-point format, so a scale that maps a row's amax into (224, 448] instead of exactly
+// onto 448 costs no relative precision on normal values (at most one binade of range at the subnormal end), and it makes
+// e4m3(q) * scale exactly representable in bf16 — the dequantised model is a bf16 model, runnable through every bf16 route and
+// through the fp32 oracle with bit-identical weights.
+#include "common.h"
+
+namespace {
+
+// scale = 2^es with amax / 2^es in (224, 448]:  amax = ma * 2^ea (1 <= ma < 2), 448 = 1.75 * 2^8  ->  es = ea - 8 (+1 if ma > 1.75)
+__device__ __forceinline__ float pow2_scale_for(float amax) {
+  const uint32_t u = __float_as_uint(amax);
+  if ((u & 0x7fffffffu) == 0u) return 1.0f;
+  int es = (int)(u >> 23) - 127 - 8 + ((u & 0x7fffffu) > 0x600000u ? 1 : 0);
+  es = es < -126 ? -126 : (es > 127 ? 127 : es);
+  return __uint_as_float((uint32_t)(es + 127) << 23);
+}
+
+// one workgroup per row; K % 4 == 0
+__global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __restrict__ W, int64_t ldw, uint8_t* __restrict__ Q, int64_t ldq,
+                                                             float* __restrict__ scale, int K) {
+  __shared__ float red[4];
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  const int64_t n = blockIdx.x;
+  const bf16_t* wr = W + n * ldw;
+  float amax = 0.f;
+  for (int k = threadIdx.x * 4; k < K; k += 1024) {
+    const u2 v = *reinterpret_cast<const u2*>(wr + k);
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(bf16lo_to_f32(v.x)), fabsf(bf16hi_to_f32(v.x))), fmaxf(fabsf(bf16lo_to_f32(v.y)), fabsf(bf16hi_to_f32(v.y)))));
+  }
+  amax = block_max(amax, red);
+  const float s = pow2_scale_for(amax);
+  const float inv = 1.0f / s;                          // exact: s is a power of two
+  if (threadIdx.x == 0) scale[n] = s;
+  for (int k = threadIdx.x * 4; k < K; k += 1024) {
+    const u2 v = *reinterpret_cast<const u2*>(wr + k);
+    int q = 0;
+    q = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo_to_f32(v.x) * inv, bf16hi_to_f32(v.x) * inv, q, false);   // v_cvt_pk_fp8_f32: RNE
+    q = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo_to_f32(v.y) * inv, bf16hi_to_f32(v.y) * inv, q, true);
+    *reinterpret_cast<uint32_t*>(Q + n * ldq + k) = (uint32_t)q;
+  }
+}
+
+__global__ __launch_bounds__(256) void dequant_fp8_rows_kernel(const uint8_t* __restrict__ Q, int64_t ldq, const float* __restrict__ scale,
+                                                               bf16_t* __restrict__ W, int64_t ldw, int K) {
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  const int64_t n = blockIdx.x;
+  const float s = scale[n];
+  for (int k = threadIdx.x * 4; k < K; k += 1024) {
+    const uint32_t q = *reinterpret_cast<const uint32_t*>(Q + n * ldq + k);
+    const mn_f2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(q, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(q, true);
+    *reinterpret_cast<u2*>(W + n * ldw + k) = u2{cvt_pk_bf16(a.x * s, a.y * s), cvt_pk_bf16(b.x * s, b.y * s)};
+  }
+}
+
+}  // namespace
+
+extern "C" int mn_quant_fp8_rows(const uint16_t* W, int64_t ldw, uint8_t* Wq, int64_t ldq, float* scale, int64_t n_rows, int K, void* stream) {
+  MN_CHECK_ARG(W && Wq && scale && n_rows >= 1 && n_rows < ((int64_t)1 << 31) && K >= 4 && (K % 4) == 0 && (ldw % 4) == 0 && (ldq % 4) == 0 &&
+                   (((uintptr_t)W) & 7) == 0 && (((uintptr_t)Wq) & 3) == 0,
+               "mn_quant_fp8_rows: bad args (K, ldw, ldq multiples of 4)");
+  hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, mn_stream(stream), W, ldw, Wq, ldq, scale, K);
+  MN_CHECK_LAUNCH("mn_quant_fp8_rows");
+  return MN_OK;
+}
+
+extern "C" int mn_dequant_fp8_rows(const uint8_t* Wq, int64_t ldq, const float* scale, uint16_t* W, int64_t ldw, int64_t n_rows, int K,
+                                   void* stream) {
+  MN_CHECK_ARG(W && Wq && scale && n_rows >= 1 && n_rows < ((int64_t)1 << 31) && K >= 4 && (K % 4) == 0 && (ldw % 4) == 0 && (ldq % 4) == 0 &&
+                   (((uintptr_t)W) & 7) == 0 && (((uintptr_t)Wq) & 3) == 0,
+               "mn_dequant_fp8_rows: bad args (K, ldw, ldq multiples of 4)");
+  hipLaunchKernelGGL(dequant_fp8_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, mn_stream(stream), Wq, ldq, scale, W, ldw, K);
+  MN_CHECK_LAUNCH("mn_dequant_fp8_rows");
+  return MN_OK;
+}

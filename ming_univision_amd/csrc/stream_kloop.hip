@@ -31,6 +31,7 @@ struct KGroups {
   const int32_t* xrows;    // [total] x row of each sorted row; nullptr = identity (off[g] + r)
   int64_t w_stride;        // elements between consecutive groups' weight matrices
   int row_lo, row_hi;      // only groups with row_lo < rows <= row_hi are processed by this launch
+  int64_t s_stride;        // fp8 weights: floats between consecutive groups' row scales
 };
 
 // byte offset of 16-byte slot `slot` of chunk row `row` (CK k per chunk = CK/8 slots per row): the XOR swizzle makes
@@ -38,10 +39,22 @@ struct KGroups {
 template <int CK>
 __device__ __forceinline__ int cslot(int row, int slot) { return row * (CK * 2) + ((slot ^ (row & (CK / 8 - 1))) << 4); }
 
-template <int MT, int NT, int D, int CK>
+// W8: the weights are OCP e4m3 bytes with one fp32 scale per output row (group g: Wq + g * w_stride bytes, scales
+// wscale + g * s_stride).  A wave's weight load then covers a PIECE of 128 k (16 NT rows x 128 B: whole lines, 16 bytes = 16 k per
+// lane) that serves TWO 64-k chunks.  The sum over k may run in any order, so inside a piece the chunks are interleaved: chunk
+// 2p takes the first 8 k of every lane's 16, chunk 2p + 1 the second 8 — every lane converts 8 bytes to one 16-byte bf16 slot
+// (exact) and parks it at each chunk, full-wave stores into the SAME 64-k bf16 tile the bf16 form uses, and the x pieces are
+// gathered with the matching stride (slot j of chunk 2p + h = k 16 j + 8 h .. + 8 of the piece).  The MFMA loop, the LDS
+// footprint (two workgroups per CU) and the barriers are those of the bf16 form; HBM bytes halve; the row scale multiplies the
+// fp32 accumulators at the partial store.  CK must be 64, D = 4 (two pieces in flight).
+template <int MT, int NT, int D, int CK, bool W8>
 __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
-                                                               const bf16_t* __restrict__ W, float* __restrict__ P,
-                                                               int64_t p_slab, int M, int Ntot, int K, int nz, KGroups g) {
+                                                               const void* __restrict__ Wv, const float* __restrict__ wscale,
+                                                               float* __restrict__ P, int64_t p_slab, int M, int Ntot, int K,
+                                                               int nz, KGroups g) {
+  static_assert(!W8 || (CK == 64 && D == 4), "fp8 weight pieces span two 64-k chunks, two pieces in flight");
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(Wv);
+  const uint8_t* __restrict__ Wq = reinterpret_cast<const uint8_t*>(Wv);
   extern __shared__ __attribute__((aligned(16))) char lds[];          // x: [2 bufs][2 x 16MT rows][256 B]; w: [KW][16 NT][256 B]
   constexpr int ROWB = CK * 2;                                        // bytes per LDS row of a chunk
   constexpr int SPR = CK / 8;                                         // 16-byte slots per row (16 or 8)
@@ -54,14 +67,25 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
     nrows = g.off[blockIdx.z + 1] - row0;
     if (nrows <= g.row_lo || nrows > g.row_hi) return;
     W += (int64_t)blockIdx.z * g.w_stride;
+    Wq += (int64_t)blockIdx.z * g.w_stride;
+    if constexpr (W8) wscale += (int64_t)blockIdx.z * g.s_stride;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   char* wt = lds + 2 * XB + wave * (16 * NT) * ROWB;
   // K-range of this workgroup: chunks [c0, c0 + nc), balanced over the nz ranges
   const int nch = (K + CK - 1) / CK;
-  const int z = blockIdx.y, base = nch / nz, rem = nch % nz;
-  const int c0 = z * base + min(z, rem), nc = base + (z < rem ? 1 : 0);
+  const int z = blockIdx.y;
+  int c0, nc;
+  if constexpr (W8) {                                                 // ranges of whole chunk PAIRS: weight pieces stay line-aligned
+    const int np = (nch + 1) / 2, base = np / nz, rem = np % nz;
+    c0 = 2 * (z * base + min(z, rem));
+    nc = min(2 * (base + (z < rem ? 1 : 0)), nch - c0);
+  } else {
+    const int base = nch / nz, rem = nch % nz;
+    c0 = z * base + min(z, rem);
+    nc = base + (z < rem ? 1 : 0);
+  }
   const int ntiles = (Ntot + 15) >> 4;
   const int t = (blockIdx.x * KW + wave) * NT;                        // first of this wave's NT adjacent tiles
   const bool active = t < ntiles;                                     // idle waves still help with x and the barriers
@@ -79,35 +103,47 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
     xp[j] = nullptr;
     if (rr < 2 * XR && m < nrows) {
       const int xr = g.xrows ? g.xrows[row0 + m] : row0 + m;
-      xp[j] = Y + h * y_lo + (int64_t)xr * K + slot * 8;
+      xp[j] = Y + h * y_lo + (int64_t)xr * K + slot * (W8 ? 16 : 8);   // fp8: slot j of a chunk = k 16 j (+ 8 for odd chunks) of its piece
     }
   }
   // ---- weight pieces of this wave: instruction i -> row i * RPI + lane / SPR of its 16 NT rows, slot lane % SPR
+  // (fp8: 16 bytes per lane = slot lane % 8 of BOTH chunks of the piece)
   constexpr int RPI = 64 / SPR;                                       // rows per instruction (4 x 256 B or 8 x 128 B)
   constexpr int WI = 16 * NT / RPI;
+  constexpr int DW = W8 ? D / 2 : D;                                  // ring depth in weight loads
   const bf16_t* wp[WI];
+  const uint8_t* wq[WI];
   int wo[WI];
-  const int wslot_k = (lane % SPR) * 8;
+  const int wslot_k = (lane % SPR) * (W8 ? 16 : 8);
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
     const int row = i * RPI + lane / SPR;
     const int n = min(t * 16 + row, Ntot - 1);
     wp[i] = W + (int64_t)n * K;
+    wq[i] = Wq + (int64_t)n * K;
     wo[i] = cslot<CK>(row, lane % SPR);
   }
-  u32x4 xr_[D][XJ], wr_[D][WI];
+  u32x4 xr_[D][XJ], wr_[DW][WI];
   auto load_x = [&](u32x4 (&dst)[XJ], int c) {
-    const int k = (c0 + c) * CK;
+    // bf16: chunk c = k [(c0 + c) 64, + 64); fp8: piece (c0 + c) / 2 (c0 is even), the lanes' first / second 8 k for even / odd c
+    const int k = W8 ? (c0 + (c & ~1)) * CK + (c & 1) * 8 : (c0 + c) * CK;
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
       dst[j] = u32x4{0u, 0u, 0u, 0u};                                  // rows >= nrows and k >= K stay zero
-      if (xp[j] && k + ((tid + j * (KW * 64)) % SPR) * 8 < K) dst[j] = *reinterpret_cast<const u32x4*>(xp[j] + k);
+      if (xp[j] && k + ((tid + j * (KW * 64)) % SPR) * (W8 ? 16 : 8) < K) dst[j] = *reinterpret_cast<const u32x4*>(xp[j] + k);
     }
   };
+  // bf16: chunk c of the K-range; fp8: piece c = chunks 2c, 2c + 1
   auto load_w = [&](u32x4 (&dst)[WI], int c) {
-    const int k = min((c0 + c) * CK + wslot_k, K - 8);                // beyond K the x image is zero: any finite value will do
+    if constexpr (W8) {
+      const int k = min((c0 + 2 * c) * CK + wslot_k, K - 16);         // beyond K the x image is zero: any finite value will do
 #pragma unroll
-    for (int i = 0; i < WI; ++i) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[i] + k));
+      for (int i = 0; i < WI; ++i) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wq[i] + k));
+    } else {
+      const int k = min((c0 + c) * CK + wslot_k, K - 8);              // beyond K the x image is zero: any finite value will do
+#pragma unroll
+      for (int i = 0; i < WI; ++i) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[i] + k));
+    }
   };
   auto store_x = [&](const u32x4 (&src)[XJ], int buf) {
 #pragma unroll
@@ -118,10 +154,11 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (d < nc) load_x(xr_[d], d);
+  const int nwl = W8 ? (nc + 1) / 2 : nc;                            // weight loads of this K-range
   if (active) {
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-      if (d < nc) load_w(wr_[d], d);
+    for (int d = 0; d < DW; ++d)
+      if (d < nwl) load_w(wr_[d], d);
   }
   store_x(xr_[0], 0);
   if (D < nc) load_x(xr_[0], D);
@@ -140,9 +177,20 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
         const int buf = d & 1;                                        // D is even: chunk parity == d parity
         if (active) {
           // park the landed weight chunk, refill its registers with the chunk D ahead
+          if constexpr (W8) {
+            // piece c / 2 sits in ring slot d / 2 (cb is a multiple of D): its first 8 k per lane for the even chunk, the second
+            // 8 for the odd one, converted to one bf16 slot; after the odd chunk the registers take the piece DW ahead
 #pragma unroll
-          for (int i = 0; i < WI; ++i) *reinterpret_cast<u32x4*>(wt + wo[i]) = wr_[d][i];
-          if (c + D < nc) load_w(wr_[d], c + D);
+            for (int i = 0; i < WI; ++i) {
+              const u32x4 q = wr_[d >> 1][i];
+              *reinterpret_cast<u32x4*>(wt + wo[i]) = (d & 1) ? fp8x8_to_bf16(q.z, q.w) : fp8x8_to_bf16(q.x, q.y);
+            }
+            if ((d & 1) && (c >> 1) + DW < nwl) load_w(wr_[d >> 1], (c >> 1) + DW);
+          } else {
+#pragma unroll
+            for (int i = 0; i < WI; ++i) *reinterpret_cast<u32x4*>(wt + wo[i]) = wr_[d][i];
+            if (c + D < nc) load_w(wr_[d], c + D);
+          }
           // CK / 32 MFMA steps of 32 k against every populated x tile (hi and lo)
 #pragma unroll
           for (int s = 0; s < CK / 32; ++s) {
@@ -179,12 +227,14 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
     for (int nt = 0; nt < NT; ++nt) {
       const int nn = (t + nt) * 16 + fr;
       if (nn < Ntot) {
+        float rs = 1.0f;
+        if constexpr (W8) rs = wscale[nn];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = mt * 16 + fq * 4 + r;
-            if (m < nrows) P[(int64_t)z * p_slab + (int64_t)(row0 + m) * Ntot + nn] = acc[mt][nt][r];
+            if (m < nrows) P[(int64_t)z * p_slab + (int64_t)(row0 + m) * Ntot + nn] = W8 ? acc[mt][nt][r] * rs : acc[mt][nt][r];
           }
         }
       }
@@ -201,58 +251,64 @@ int kloop_ck() { return g_kl_ck > 0 ? g_kl_ck : 64; }
 // weight tiles per wave: two above 32 rows (halves the x fragment reads per weight byte, which bound the 64-row regime)
 int kloop_nt(int max_rows) { return g_kl_nt > 0 ? g_kl_nt : (max_rows > 32 ? 2 : 1); }
 
-// number of K-ranges: enough workgroups to fill `slots` CUs-worth of residency, never more ranges than chunks
-int kloop_nz(int Ntot, int K, int slots, int nt) {
-  if (g_kl_nz > 0) return g_kl_nz;
+// number of K-ranges: enough workgroups to fill `slots` CUs-worth of residency, never more ranges than chunks (fp8: chunk pairs)
+int kloop_nz(int Ntot, int K, int slots, int nt, bool w8 = false) {
   const int tb = (int)mn_cdiv(mn_cdiv(Ntot, 16), KW * nt);
-  const int nch = (int)mn_cdiv(K, kloop_ck());
+  int nch = (int)mn_cdiv(K, w8 ? 64 : kloop_ck());
+  if (w8) nch = (nch + 1) / 2;
+  if (g_kl_nz > 0) return g_kl_nz < nch ? g_kl_nz : nch;
   int nz = slots / tb;
   if (nz < 1) nz = 1;
   if (nz > nch) nz = nch;
   return nz;
 }
 
-template <int MT, int NT, int D, int CK>
-void kloop_launch(int G, int nz, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab, int M, int Ntot,
-                  int K, const KGroups& g, hipStream_t st) {
+template <int MT, int NT, int D, int CK, bool W8>
+void kloop_launch(int G, int nz, const bf16_t* Y, int64_t y_lo, const void* W, const float* wscale, float* P, int64_t p_slab, int M,
+                  int Ntot, int K, const KGroups& g, hipStream_t st) {
   constexpr int ROWB = CK * 2;
   const size_t lds = (size_t)2 * 2 * 16 * MT * ROWB + (size_t)KW * 16 * NT * ROWB;
   static bool opted = false;
   if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_kloop_kernel<MT, NT, D, CK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_kloop_kernel<MT, NT, D, CK, W8>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     opted = true;
   }
   const int tb = (int)mn_cdiv(mn_cdiv(Ntot, 16), KW * NT);
-  hipLaunchKernelGGL((stream_kloop_kernel<MT, NT, D, CK>), dim3(tb, nz, G), dim3(KW * 64), lds, st, Y, y_lo, W, P, p_slab, M, Ntot,
-                     K, nz, g);
+  hipLaunchKernelGGL((stream_kloop_kernel<MT, NT, D, CK, W8>), dim3(tb, nz, G), dim3(KW * 64), lds, st, Y, y_lo, W, wscale, P, p_slab,
+                     M, Ntot, K, nz, g);
 }
 
 template <int MT>
-void kloop_launch_d(int nt, int G, int nz, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab, int M,
-                    int Ntot, int K, const KGroups& g, hipStream_t st) {
+void kloop_launch_d(int nt, int G, int nz, const bf16_t* Y, int64_t y_lo, const void* W, const float* wscale, float* P, int64_t p_slab,
+                    int M, int Ntot, int K, const KGroups& g, hipStream_t st) {
+  if (wscale) {     // fp8 weights: 64-k x chunks, 128-k weight pieces, two pieces (= four chunks) in flight per wave
+    if (nt == 2) kloop_launch<MT, 2, 4, 64, true>(G, nz, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, g, st);
+    else kloop_launch<MT, 1, 4, 64, true>(G, nz, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, g, st);
+    return;
+  }
   const int depth = g_kl_depth > 0 ? g_kl_depth : (nt == 2 ? 2 : 4);
   const int ck = kloop_ck(); (void)ck;
 #ifdef MN_DEV_HOOKS      // the 128-k chunk form exists for the A/B hook only (it spills at four row tiles): not in the product library
 #define MN_KL(NT_, D_)                                                                                      \
   do {                                                                                                      \
-    if (ck == 64) kloop_launch<MT, NT_, D_, 64>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);           \
-    else kloop_launch<MT, NT_, D_, 128>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);                   \
+    if (ck == 64) kloop_launch<MT, NT_, D_, 64, false>(G, nz, Y, y_lo, W, nullptr, P, p_slab, M, Ntot, K, g, st);           \
+    else kloop_launch<MT, NT_, D_, 128, false>(G, nz, Y, y_lo, W, nullptr, P, p_slab, M, Ntot, K, g, st);                   \
   } while (0)
 #else
-#define MN_KL(NT_, D_) kloop_launch<MT, NT_, D_, 64>(G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st)
+#define MN_KL(NT_, D_) kloop_launch<MT, NT_, D_, 64, false>(G, nz, Y, y_lo, W, nullptr, P, p_slab, M, Ntot, K, g, st)
 #endif
   if (nt == 2) { if (depth == 2) MN_KL(2, 2); else MN_KL(2, 4); }
   else { if (depth == 2) MN_KL(1, 2); else MN_KL(1, 4); }
 #undef MN_KL
 }
 
-int kloop_dispatch(int G, int max_rows, int nz, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab,
-                   int M, int Ntot, int K, const KGroups& g, hipStream_t st) {
+int kloop_dispatch(int G, int max_rows, int nz, const bf16_t* Y, int64_t y_lo, const void* W, const float* wscale, float* P,
+                   int64_t p_slab, int M, int Ntot, int K, const KGroups& g, hipStream_t st) {
   const int nt = kloop_nt(max_rows);
-  if (max_rows <= 16) kloop_launch_d<1>(nt, G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
-  else if (max_rows <= 32) kloop_launch_d<2>(nt, G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
-  else kloop_launch_d<4>(nt, G, nz, Y, y_lo, W, P, p_slab, M, Ntot, K, g, st);
+  if (max_rows <= 16) kloop_launch_d<1>(nt, G, nz, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, g, st);
+  else if (max_rows <= 32) kloop_launch_d<2>(nt, G, nz, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, g, st);
+  else kloop_launch_d<4>(nt, G, nz, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, g, st);
   return nz;
 }
 
@@ -266,22 +322,33 @@ extern "C" MN_DEV_API void mn_stream_kloop_tune(int nz, int depth, int nt) { g_k
 // K-ranges to reduce, and other streams' kernels run beside them (end to end +3 % with three stream groups; a third or a
 // quarter of the chip, or narrowing RF w12 as well, measured worse)
 int g_kl_small_div = 2, g_kl_small_mb = 64;
-int kloop_dense_slots(int Ntot, int K) {
+int kloop_dense_slots(int Ntot, int K, int wbytes = 2) {
   const int cus = mn_num_cus();
-  return ((int64_t)Ntot * K * 2 < ((int64_t)g_kl_small_mb << 20) && g_kl_small_div > 1) ? cus / g_kl_small_div : cus;
+  return ((int64_t)Ntot * K * wbytes < ((int64_t)g_kl_small_mb << 20) && g_kl_small_div > 1) ? cus / g_kl_small_div : cus;
 }
 #ifdef MN_DEV_HOOKS
 extern "C" MN_DEV_API void mn_stream_kloop_tune_small(int div) { g_kl_small_div = div & 15; if (div >> 4) g_kl_small_mb = div >> 4; }
 #endif
 extern "C" int mn_stream_kloop_slices(int M, int Ntot, int K) { return kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K), kloop_nt(M)); }
+extern "C" int mn_stream_kloop_w8_slices(int M, int Ntot, int K) { return kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K, 1), kloop_nt(M), true); }
 
 // Dense: Y [2][M][K] bf16 (hi rows then lo rows), W [Ntot][K], P [nz][M][Ntot].  Returns nz (< 0: error).  M <= 64.
 extern "C" int mn_stream_kloop(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream) {
   MN_CHECK_ARG(Y && W && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0, "mn_stream_kloop: bad args");
   const int nz = kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K), kloop_nt(M));
-  const KGroups g{nullptr, nullptr, 0, 0, 1 << 30};
-  kloop_dispatch(1, M, nz, Y, (int64_t)M * K, W, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
+  const KGroups g{nullptr, nullptr, 0, 0, 1 << 30, 0};
+  kloop_dispatch(1, M, nz, Y, (int64_t)M * K, W, nullptr, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
   MN_CHECK_LAUNCH("mn_stream_kloop");
+  return nz;
+}
+
+// Dense on fp8 weights: Wq e4m3 [Ntot][K] (K % 16 == 0), wscale fp32 [Ntot].  nz = mn_stream_kloop_w8_slices(M, Ntot, K).
+extern "C" int mn_stream_kloop_w8(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, void* stream) {
+  MN_CHECK_ARG(Y && Wq && wscale && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 16 && (K % 16) == 0, "mn_stream_kloop_w8: bad args");
+  const int nz = kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K, 1), kloop_nt(M), true);
+  const KGroups g{nullptr, nullptr, 0, 0, 1 << 30, 0};
+  kloop_dispatch(1, M, nz, Y, (int64_t)M * K, Wq, wscale, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
+  MN_CHECK_LAUNCH("mn_stream_kloop_w8");
   return nz;
 }
 
@@ -293,8 +360,21 @@ extern "C" int mn_stream_kloop_grouped(const uint16_t* Y, int y_rows, const uint
   MN_CHECK_ARG(Y && W && P && off && G >= 1 && max_rows >= 1 && max_rows <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0 &&
                    nz >= 1 && nz <= (K + kloop_ck() - 1) / kloop_ck(),
                "mn_stream_kloop_grouped: bad args");
-  const KGroups g{off, xrows, w_stride, row_lo, max_rows};
-  kloop_dispatch(G, max_rows, nz, Y, (int64_t)y_rows * K, W, P, (int64_t)p_rows * Ntot, 0, Ntot, K, g, mn_stream(stream));
+  const KGroups g{off, xrows, w_stride, row_lo, max_rows, 0};
+  kloop_dispatch(G, max_rows, nz, Y, (int64_t)y_rows * K, W, nullptr, P, (int64_t)p_rows * Ntot, 0, Ntot, K, g, mn_stream(stream));
   MN_CHECK_LAUNCH("mn_stream_kloop_grouped");
+  return nz;
+}
+
+// Grouped form on fp8 weights (group g: Wq + g * w_stride bytes, wscale + g * s_stride floats).
+extern "C" int mn_stream_kloop_grouped_w8(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale,
+                                          int64_t s_stride, float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G,
+                                          int max_rows, int nz, int Ntot, int K, void* stream) {
+  MN_CHECK_ARG(Y && Wq && wscale && P && off && G >= 1 && max_rows >= 1 && max_rows <= 64 && Ntot >= 1 && K >= 16 && (K % 16) == 0 &&
+                   (w_stride % 16) == 0 && nz >= 1 && nz <= (K + 127) / 128,
+               "mn_stream_kloop_grouped_w8: bad args");
+  const KGroups g{off, xrows, w_stride, 0, max_rows, s_stride};
+  kloop_dispatch(G, max_rows, nz, Y, (int64_t)y_rows * K, Wq, wscale, P, (int64_t)p_rows * Ntot, 0, Ntot, K, g, mn_stream(stream));
+  MN_CHECK_LAUNCH("mn_stream_kloop_grouped_w8");
   return nz;
 }

@@ -34,6 +34,12 @@ extern "C" int mn_stream_kloop_slices(int M, int Ntot, int K);
 extern "C" int mn_stream_kloop_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P,
                                        int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows, int row_lo,
                                        int nz, int Ntot, int K, void* stream);
+// ... and on fp8 weights (e4m3 bytes + one fp32 scale per output row)
+extern "C" int mn_stream_kloop_w8(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, void* stream);
+extern "C" int mn_stream_kloop_w8_slices(int M, int Ntot, int K);
+extern "C" int mn_stream_kloop_grouped_w8(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale,
+                                          int64_t s_stride, float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G,
+                                          int max_rows, int nz, int Ntot, int K, void* stream);
 
 namespace {
 
@@ -46,10 +52,15 @@ __device__ __forceinline__ int wslot(int row, int slot) { return row * (WCH * 2)
 __device__ __forceinline__ int xslot(int row, int srow, int slot) { return row * srow + ((slot ^ (row & 15)) << 3); }
 
 // Y: bf16, hi rows at Y, lo rows at Y + y_lo (row stride K).  P: [nz][p_rows][Ntot] fp32, p_slab = p_rows * Ntot.
-template <int MT, int DEPTH, int MAXT>
+// W8: the weights are OCP e4m3 bytes [Ntot][K] with one fp32 scale per output row (W[n,k] = e4m3(Wq[n,k]) * wscale[n]): a chunk
+// is 4 KiB of HBM traffic instead of 8, converted to bf16 (exact) in registers on its way into the wave's LDS tile, so the MFMA
+// loop is the bf16 one; the row scale multiplies the fp32 accumulators when a tile's partials are stored.
+template <int MT, int DEPTH, int MAXT, bool W8>
 __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
-                                                               const bf16_t* __restrict__ W, float* __restrict__ P,
-                                                               int64_t p_slab, int M, int Ntot, int K, int ks) {
+                                                               const void* __restrict__ Wv, const float* __restrict__ wscale,
+                                                               float* __restrict__ P, int64_t p_slab, int M, int Ntot, int K, int ks) {
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(Wv);
+  const uint8_t* __restrict__ Wq = reinterpret_cast<const uint8_t*>(Wv);
   extern __shared__ __attribute__((aligned(16))) bf16_t xs_raw[];      // [2][16*MT][ks] x image, then nw x 8 KiB weight tiles
   const int row0 = 0, nrows = M;
   constexpr int XR = 16 * MT;
@@ -94,17 +105,25 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
   };
   load_x();   // before the weights: loads retire in order, so the x image never waits behind a weight chunk
   // ---- weight ring: one chunk (8 KiB per wave) in flight in registers
-  u32x4 ring[DEPTH][8];
+  constexpr int NI = W8 ? 4 : 8;                    // 16-byte loads per lane and chunk
+  u32x4 ring[DEPTH][NI];
   int it = t0, ich = 0;                             // issue cursor (tile, chunk), tile-major
-  // instruction i of a chunk: rows (i & 1) * 8 + r8, 16-byte slot (i >> 1) * 8 + c8 — whole 128-byte lines
-  auto issue = [&](u32x4 (&dst)[8]) {
+  // bf16: instruction i of a chunk: rows (i & 1) * 8 + r8, 16-byte slot (i >> 1) * 8 + c8 — whole 128-byte lines
+  // fp8:  instruction i: rows i * 4 + fq, bytes fr * 16 .. + 16 of the row's 256 (two whole lines per row)
+  auto issue = [&](u32x4 (&dst)[NI]) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = (i & 1) * 8 + r8;
-      const int n = min(it * 16 + row, Ntot - 1);
-      const int k = min(ich * WCH + ((i >> 1) * 8 + c8) * 8, klen - 8);
-      // nontemporal: every weight byte is used once (21.7 vs 23.4 us on RF w12 at 16 rows)
-      dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (int64_t)n * K + k0 + k));
+    for (int i = 0; i < NI; ++i) {
+      if constexpr (W8) {
+        const int n = min(it * 16 + i * 4 + fq, Ntot - 1);
+        const int k = min(ich * WCH + fr * 16, klen - 16);
+        dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wq + (int64_t)n * K + k0 + k));
+      } else {
+        const int row = (i & 1) * 8 + r8;
+        const int n = min(it * 16 + row, Ntot - 1);
+        const int k = min(ich * WCH + ((i >> 1) * 8 + c8) * 8, klen - 8);
+        // nontemporal: every weight byte is used once (21.7 vs 23.4 us on RF w12 at 16 rows)
+        dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (int64_t)n * K + k0 + k));
+      }
     }
     if (++ich == nch) { ich = 0; it += twaves; }
   };
@@ -132,9 +151,21 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
       const int q = q0 + d;
       if (q < total) {
         // park the landed chunk in the wave's LDS tile ...
+        if constexpr (W8) {                          // 16 e4m3 -> 16 bf16 = the row's slots 2 fr and 2 fr + 1
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          *reinterpret_cast<u32x4*>(wbuf + wslot((i & 1) * 8 + r8, (i >> 1) * 8 + c8)) = ring[d][i];
+          for (int i = 0; i < NI; ++i) {
+            const u32x4 a = fp8x8_to_bf16(ring[d][i].x, ring[d][i].y), b = fp8x8_to_bf16(ring[d][i].z, ring[d][i].w);
+            // every other quad of lanes stores its odd slot first: the 8 lanes of one LDS write group (same row) then cover
+            // slots {0, 2, 4, 6, 9, 11, 13, 15} (mod 16) = 8 distinct 16-byte bank groups
+            const int row = i * 4 + fq, sw = (fr >> 2) & 1;
+            *reinterpret_cast<u32x4*>(wbuf + wslot(row, 2 * fr + sw)) = sw ? b : a;
+            *reinterpret_cast<u32x4*>(wbuf + wslot(row, 2 * fr + 1 - sw)) = sw ? a : b;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<u32x4*>(wbuf + wslot((i & 1) * 8 + r8, (i >> 1) * 8 + c8)) = ring[d][i];
+        }
         // ... refill its registers with the chunk DEPTH ahead ...
         if (q + DEPTH < total) issue(ring[d]);
         // ... and multiply: 8 MFMA steps of 32 k (columns >= klen of x are zero in LDS)
@@ -154,13 +185,15 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
         }
         if (++ch == nch) {                          // tile done: D layout row m = fq*4 + r, col n = t*16 + fr
           const int nn = t * 16 + fr;
+          float rs = 1.0f;
+          if constexpr (W8) rs = wscale[min(nn, Ntot - 1)];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             if (nn < Ntot) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int m = mt * 16 + fq * 4 + r;
-                if (m < nrows) P[(int64_t)z * p_slab + (int64_t)(row0 + m) * Ntot + nn] = acc[mt][r];
+                if (m < nrows) P[(int64_t)z * p_slab + (int64_t)(row0 + m) * Ntot + nn] = W8 ? acc[mt][r] * rs : acc[mt][r];
               }
             }
             acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -177,15 +210,16 @@ struct StreamPlan { int ks, nw, gx, nz; size_t lds; };
 
 // Tuning knobs for in-process A/B (not part of the stable ABI): force the slice length (in 256-k chunks) and the
 // waves per workgroup.
-int g_kch = 0, g_nw = 0;
+int g_kch = 0, g_nw = 0, g_w8_depth = 1;      // fp8: one 4 KiB chunk in flight per wave measured faster than two (13.0 vs 13.3 us on RF w12, 8.1 vs 9.3 on w3)
 
 // Launch shape for one [Ntot, K] matrix that has `slots` CUs to itself (dense: the whole chip; grouped: the chip's
 // share of one group).  One workgroup per CU (LDS-bound); the cost is the bytes a CU moves: weight chunks of its
 // waves + its x image + its share of the partial slabs (written here, read back by the reducing kernel).
 // E.g. RF w12 (1024 tiles x 12 chunks) runs as 4 slices of 768 x 64 workgroups x 8 waves = exactly 2 tiles per wave,
 // RF w3 (192 tiles x 32 chunks) as 16 slices of 512 x 16 workgroups x 12 waves = exactly 1 tile per wave.
-StreamPlan stream_plan(int mt, int Ntot, int K, int slots) {
+StreamPlan stream_plan(int mt, int Ntot, int K, int slots, bool w8 = false) {
   const int ntiles = (Ntot + 15) / 16;
+  const double chunk_bytes = w8 ? 4096.0 : 8192.0;  // HBM bytes of one 16-row x 256-k weight chunk
   StreamPlan best{};
   double best_cost = 1e30;
   for (int kch = 1; kch <= MAX_KCH; ++kch) {
@@ -199,7 +233,7 @@ StreamPlan stream_plan(int mt, int Ntot, int K, int slots) {
       const int gxmax = slots / nz > 0 ? slots / nz : 1;
       if (gx > gxmax) gx = gxmax;
       const int tiles_w = (int)mn_cdiv(ntiles, (int64_t)gx * nw);
-      const double cost = (double)nw * tiles_w * kch * 8192.0 + kch * 16384.0 * mt +
+      const double cost = (double)nw * tiles_w * kch * chunk_bytes + kch * 16384.0 * mt +
                           (double)nz * 16 * mt * Ntot * 8.0 / slots + (nz > slots ? 1e12 : 0.0);
       if (cost < best_cost) { best_cost = cost; best = StreamPlan{ks, nw, gx, nz, lds}; }
     }
@@ -207,37 +241,47 @@ StreamPlan stream_plan(int mt, int Ntot, int K, int slots) {
   return best;
 }
 
-template <int MT, int DEPTH, int MAXT>
-void stream_launch_d(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab,
-                     int M, int Ntot, int K, hipStream_t st) {
+template <int MT, int DEPTH, int MAXT, bool W8>
+void stream_launch_d(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, const void* W, const float* wscale, float* P,
+                     int64_t p_slab, int M, int Ntot, int K, hipStream_t st) {
   static bool opted = false;
   if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_lds_kernel<MT, DEPTH, MAXT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_lds_kernel<MT, DEPTH, MAXT, W8>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP);
     opted = true;
   }
-  hipLaunchKernelGGL((stream_mfma_lds_kernel<MT, DEPTH, MAXT>), dim3(pl.gx, pl.nz, G), dim3(pl.nw * 64), pl.lds, st, Y, y_lo, W, P,
-                     p_slab, M, Ntot, K, pl.ks);
+  hipLaunchKernelGGL((stream_mfma_lds_kernel<MT, DEPTH, MAXT, W8>), dim3(pl.gx, pl.nz, G), dim3(pl.nw * 64), pl.lds, st, Y, y_lo, W,
+                     wscale, P, p_slab, M, Ntot, K, pl.ks);
 }
 
-template <int MT>
-void stream_launch(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, const bf16_t* W, float* P, int64_t p_slab,
-                   int M, int Ntot, int K, hipStream_t st) {
+template <int MT, bool W8>
+void stream_launch(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, const void* W, const float* wscale, float* P,
+                   int64_t p_slab, int M, int Ntot, int K, hipStream_t st) {
   // 8-wave workgroups compile for 512 threads, larger ones for 1024
   // (a 2-deep ring measured 2-4 % slower at every shape: 20.4 vs 20.0 us on RF w12 at 16 rows, 24.6 vs 23.8 at 32)
-  if (pl.nw <= 8) stream_launch_d<MT, 1, 512>(pl, G, Y, y_lo, W, P, p_slab, M, Ntot, K, st);
-  else stream_launch_d<MT, 1, 1024>(pl, G, Y, y_lo, W, P, p_slab, M, Ntot, K, st);
+  if (W8 && g_w8_depth == 2) {
+    if (pl.nw <= 8) stream_launch_d<MT, (W8 ? 2 : 1), 512, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st);
+    else stream_launch_d<MT, (W8 ? 2 : 1), 1024, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st);
+    return;
+  }
+  if (pl.nw <= 8) stream_launch_d<MT, 1, 512, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st);
+  else stream_launch_d<MT, 1, 1024, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st);
 }
 
 }  // namespace
 
 #ifdef MN_DEV_HOOKS
 extern "C" MN_DEV_API void mn_stream_tune_plan(int kch, int nw) { g_kch = kch; g_nw = nw; }
+extern "C" MN_DEV_API void mn_stream_tune_w8(int depth) { g_w8_depth = depth; }
 #endif
 
 extern "C" int mn_stream_mfma_slices(int M, int Ntot, int K) {
   if (M > 32) return mn_stream_kloop_slices(M, Ntot, K);
   return stream_plan(M > 16 ? 2 : 1, Ntot, K, mn_num_cus()).nz;
+}
+extern "C" int mn_stream_mfma_w8_slices(int M, int Ntot, int K) {
+  if (M > 32) return mn_stream_kloop_w8_slices(M, Ntot, K);
+  return stream_plan(M > 16 ? 2 : 1, Ntot, K, mn_num_cus(), true).nz;
 }
 
 // Dense: Y [2][M][K] bf16 (hi rows then lo rows), W [Ntot][K], P [nz][M][Ntot].  Returns nz (< 0: error).
@@ -246,9 +290,24 @@ extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, in
   if (M > 32) return mn_stream_kloop(Y, W, P, M, Ntot, K, stream);      // 33..64 rows: K-loop form, two tiles per wave
   const int mt = M > 16 ? 2 : 1;
   const StreamPlan pl = stream_plan(mt, Ntot, K, mn_num_cus());
-  if (mt == 1) stream_launch<1>(pl, 1, Y, (int64_t)M * K, W, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream));
-  else stream_launch<2>(pl, 1, Y, (int64_t)M * K, W, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream));
+  if (mt == 1) stream_launch<1, false>(pl, 1, Y, (int64_t)M * K, W, nullptr, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream));
+  else stream_launch<2, false>(pl, 1, Y, (int64_t)M * K, W, nullptr, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream));
   MN_CHECK_LAUNCH("mn_stream_mfma");
+  return pl.nz;
+}
+
+// The same launch on fp8 weights: Wq e4m3 bytes [Ntot][K] (K % 16 == 0, 16-byte aligned rows), wscale fp32 [Ntot];
+// P [nz][M][Ntot] with nz = mn_stream_mfma_w8_slices(M, Ntot, K).
+extern "C" int mn_stream_mfma_w8(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K,
+                                 void* stream) {
+  MN_CHECK_ARG(Y && Wq && wscale && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 16 && (K % 16) == 0 && (((uintptr_t)Wq) & 15) == 0,
+               "mn_stream_mfma_w8: bad args (K %% 16 == 0, 16-byte aligned weights)");
+  if (M > 32) return mn_stream_kloop_w8(Y, Wq, wscale, P, M, Ntot, K, stream);
+  const int mt = M > 16 ? 2 : 1;
+  const StreamPlan pl = stream_plan(mt, Ntot, K, mn_num_cus(), true);
+  if (mt == 1) stream_launch<1, true>(pl, 1, Y, (int64_t)M * K, Wq, wscale, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream));
+  else stream_launch<2, true>(pl, 1, Y, (int64_t)M * K, Wq, wscale, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream));
+  MN_CHECK_LAUNCH("mn_stream_mfma_w8");
   return pl.nz;
 }
 
@@ -268,4 +327,12 @@ extern "C" int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint1
                                       int Ntot, int K, void* stream) {
   const int nz = mn_stream_mfma_grouped_slices(G, max_rows, Ntot, K);
   return mn_stream_kloop_grouped(Y, y_rows, W, w_stride, P, p_rows, off, xrows, G, max_rows, 0, nz, Ntot, K, stream);
+}
+
+// The grouped form on fp8 weights: group g's matrix is Wq + g * w_stride bytes, its row scales wscale + g * s_stride.
+extern "C" int mn_stream_mfma_grouped_w8(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale,
+                                         int64_t s_stride, float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G,
+                                         int max_rows, int Ntot, int K, void* stream) {
+  const int nz = mn_stream_mfma_grouped_slices(G, max_rows, Ntot, K);
+  return mn_stream_kloop_grouped_w8(Y, y_rows, Wq, w_stride, wscale, s_stride, P, p_rows, off, xrows, G, max_rows, nz, Ntot, K, stream);
 }

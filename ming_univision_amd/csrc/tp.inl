@@ -87,6 +87,7 @@ static void tp_consume(WideGlue& g, const mn_tp_comm* c, uint32_t epoch) {
   g.P = c->inbox[c->rank] + (int64_t)(epoch & 1u) * c->world * c->cap;
   g.nz = c->world; g.slab = c->cap;
   g.wait_flags = c->flags[c->rank]; g.wait_n = c->world; g.wait_stride = c->rows_cap; g.wait_epoch = epoch; g.wait_err = c->err;
+  g.wait_ticks = (uint64_t)(c->wait_ms ? c->wait_ms : MN_TP_WAIT_MS_DEFAULT) * 100000ull;      // ms -> ticks of the 100 MHz clock
 }
 
 // out[m] = sum over ranks of x[m] (fp32 [M, D] partial per rank).  Stand-alone form of the mechanism above.  phase: MN_TP_PUSH
@@ -184,11 +185,11 @@ static size_t llm_tp_carve(const mn_llm* m, const mn_llm_tp* tp, int rows, int64
     const size_t Pn = (size_t)rows * m->top_k;
     size_t pmax = (size_t)mn_stream_mfma_slices(rows, qkv_dim, H) * qkv_dim;
     const size_t c2 = (size_t)mn_stream_mfma_slices(rows, H, ad) * H, c3 = (size_t)2 * mn_stream_mfma_slices(rows, m->n_experts, H) * m->n_experts;
-    const size_t c4 = (size_t)mn_stream_mfma_slices(rows, 2 * SIc, H) * 2 * SIc;
+    const size_t c4 = (size_t)stream_slices(m->wfmt, rows, 2 * SIc, H) * 2 * SIc;
     if (c2 > pmax) pmax = c2;
     if (c3 > pmax) pmax = c3;
     if (c4 > pmax) pmax = c4;
-    const size_t s3 = (size_t)mn_stream_mfma_slices(rows, H, SIc) * rows * H;
+    const size_t s3 = (size_t)stream_slices(m->wfmt, rows, H, SIc) * rows * H;
     if (s3 > psh) psh = s3;
     o->pps = cv.take<float>(pmax * rows);
     o->p1 = cv.take<float>((size_t)mn_stream_mfma_grouped_slices(m->n_experts, rows, 2 * I, H) * Pn * 2 * I);
@@ -212,6 +213,9 @@ extern "C" int mn_llm_step_tp(const mn_llm* m, const mn_llm_tp* tp, mn_tp_comm* 
   MN_CHECK_ARG(m && tp && comm && x && row_seq && row_slot && row_pos && row_len && kv_cache && hidden_out && workspace,
                "mn_llm_step_tp: null pointer");
   MN_CHECK_ARG(llm_tp_ok(m, tp, comm, M) && x_row_div >= 1, "mn_llm_step_tp: unsupported shard / communicator for M=%d rows", M);
+  MN_CHECK_ARG(m->wfmt == MN_W_BF16 || (m->wfmt == MN_W_FP8_E4M3 && M <= 64 && m->w_gate_up_scale && m->w_down_scale && (m->hidden % 16) == 0 &&
+                                        (m->moe_inter % 16) == 0 && (tp->shared_inter == 0 || (tp->ws_gate_up_scale && tp->ws_down_scale))),
+               "mn_llm_step_tp: fp8 experts need row scales, widths %% 16 == 0 and <= 64 rows (M = %d)", M);
   const int n_seg = 2 * m->n_layers + 1;
   MN_CHECK_ARG(seg_begin >= 0 && seg_begin < seg_end && seg_end <= n_seg, "mn_llm_step_tp: segments [%d, %d) of %d", seg_begin, seg_end, n_seg);
   LlmTpWs tw;
@@ -318,21 +322,21 @@ extern "C" int mn_llm_step_tp(const mn_llm* m, const mn_llm_tp* tp, mn_tp_comm* 
       if (streaming) {
         // local experts on the grouped K-loop kernel: group g of the window = expert e0 + g, its rows are the sorted positions
         // [off[e0 + g], off[e0 + g + 1]) of the GLOBAL sort (gathered through perm); every distinct local expert is streamed once
-        int nz1 = mn_stream_mfma_grouped(w.yh, M, m->w_gate_up[l], (int64_t)2 * I * H, tw.p1, (int)P, w.off + e0, w.perm, e1 - e0, M,
-                                         2 * I, H, stream);
+        int nz1 = stream_grouped(m->wfmt, w.yh, M, m->w_gate_up[l], (int64_t)2 * I * H, m->wfmt ? m->w_gate_up_scale[l] : nullptr, 2 * I,
+                                 tw.p1, (int)P, w.off + e0, w.perm, e1 - e0, M, 2 * I, H, stream);
         if (nz1 < 0) return nz1;
         hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv(P * I, 1024)), dim3(256), 0, st, (const float*)tw.p1, nz1, (int)P, I,
                            (const bf16_t*)nullptr, w.y2, (const int32_t*)(w.off + e0), (const int32_t*)(w.off + e1));
-        const int nz2 = mn_stream_mfma_grouped(w.y2, (int)P, m->w_down[l], (int64_t)H * I, tw.p2, (int)P, w.off + e0, nullptr, e1 - e0, M,
-                                               H, I, stream);
+        const int nz2 = stream_grouped(m->wfmt, w.y2, (int)P, m->w_down[l], (int64_t)H * I, m->wfmt ? m->w_down_scale[l] : nullptr, H,
+                                       tw.p2, (int)P, w.off + e0, nullptr, e1 - e0, M, H, I, stream);
         if (nz2 < 0) return nz2;
         p.cy = tw.p2; p.cy_nz = nz2; p.cy_slab = P * H;
         if (SI) {
-          int nzg = mn_stream_mfma(w.yh, tp->ws_gate_up[l], pp, M, 2 * SI, H, stream);
+          int nzg = stream_dense(m->wfmt, w.yh, tp->ws_gate_up[l], m->wfmt ? tp->ws_gate_up_scale[l] : nullptr, pp, M, 2 * SI, H, stream);
           if (nzg < 0) return nzg;
           hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)M * SI, 1024)), dim3(256), 0, st, (const float*)pp, nzg, M,
                              SI, (const bf16_t*)nullptr, tw.ysh);
-          nzs = mn_stream_mfma(tw.ysh, tp->ws_down[l], psh, M, H, SI, stream);
+          nzs = stream_dense(m->wfmt, tw.ysh, tp->ws_down[l], m->wfmt ? tp->ws_down_scale[l] : nullptr, psh, M, H, SI, stream);
           if (nzs < 0) return nzs;
         }
       } else {
@@ -378,8 +382,8 @@ extern "C" int mn_rf_tp_segments(const mn_rf_head* h) { return h->steps * h->dep
 static size_t rf_tp_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, RfWideWs* o) {
   const size_t off = rf_wide_carve(h, rows, ws, cap, o);
   if (rows > 64) return off;
-  const size_t p12 = (size_t)mn_stream_mfma_slices(rows, 2 * h->hidden, h->w) * 2 * h->hidden * rows;
-  const size_t p3 = (size_t)mn_stream_mfma_slices(rows, h->w, h->hidden) * h->w * rows;
+  const size_t p12 = (size_t)stream_slices(h->wfmt, rows, 2 * h->hidden, h->w) * 2 * h->hidden * rows;
+  const size_t p3 = (size_t)stream_slices(h->wfmt, rows, h->w, h->hidden) * h->w * rows;
   Carver cv(ws ? (char*)ws + off : nullptr, cap > off ? cap - off : 0, ws == nullptr);
   float* pb = cv.take<float>(p12 > p3 ? p12 : p3);
   if (ws) o->pbuf_stream = pb;
@@ -401,6 +405,7 @@ extern "C" int mn_rf_sample_tp(const mn_rf_head* h, mn_tp_comm* comm, const floa
   MN_CHECK_ARG(rows <= 2048 && wide_glue_ok(h->w) && wide_glue_ok(h->z_dim) && wide_glue_ok(h->llm_hidden) && (h->w % 64) == 0 &&
                    (h->hidden % 64) == 0 && (h->z_dim % 64) == 0 && (h->llm_hidden % 64) == 0 && h->target <= 64 && (h->target % 4) == 0 &&
                    tp_comm_ok(comm, rows, h->w), "mn_rf_sample_tp: unsupported widths / communicator");
+  MN_CHECK_ARG(h->wfmt == MN_W_BF16 || (rf_fp8_ok(h) && rows <= 64), "mn_rf_sample_tp: fp8 weights need row scales, widths %% 16 == 0 and <= 64 rows");
   const int n_seg = h->steps * h->depth + 1;
   MN_CHECK_ARG(seg_begin >= 0 && seg_begin < seg_end && seg_end <= n_seg, "mn_rf_sample_tp: segments [%d, %d) of %d", seg_begin, seg_end, n_seg);
   RfWideWs w;
@@ -425,11 +430,11 @@ extern "C" int mn_rf_sample_tp(const mn_rf_head* h, mn_tp_comm* comm, const floa
   auto block_gemms = [&](int b) -> int {
     int nz;
     if (streaming) {
-      nz = mn_stream_mfma(w.ya, h->w12[b], w.pbuf, rows, 2 * HID, W, stream);
+      nz = stream_dense(h->wfmt, w.ya, h->w12[b], h->wfmt ? h->w12_scale[b] : nullptr, w.pbuf, rows, 2 * HID, W, stream);
       if (nz < 0) return nz;
       hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)rows * HID, 1024)), dim3(256), 0, st, (const float*)w.pbuf, nz,
                          rows, HID, h->b12[b], w.yb);
-      nz = mn_stream_mfma(w.yb, h->w3[b], w.pbuf, rows, W, HID, stream);
+      nz = stream_dense(h->wfmt, w.yb, h->w3[b], h->wfmt ? h->w3_scale[b] : nullptr, w.pbuf, rows, W, HID, stream);
       if (nz < 0) return nz;
     } else {
       if (w.ks12 > 1) {

@@ -8,6 +8,8 @@
 #pragma once
 #include "common.h"
 
+#define MN_TP_WAIT_MS_DEFAULT 30000u   // wall-time bound of a tensor-parallel arrival wait (mn_tp_comm.wait_ms = 0)
+
 struct WideGlue {
   // ---- source value v[m, :] ----
   const float* h; int64_t ldh;                         // residual stream row (used when neither x nor xin is given)
@@ -28,8 +30,11 @@ struct WideGlue {
   bf16_t* Y; int64_t ldy; int64_t y_lo_off;            // bf16 hi rows at Y, lo rows y_lo_off elements further (0: plain bf16, no lo rows), or NULL
   int M, D;
   // ---- tensor-parallel all-reduce, consumer side (tp.inl): before reading P (= this rank's inbox: nz = world slabs, one per
-  // sender), row m waits until sender s's arrival flag wait_flags[s * wait_stride + m] reached wait_epoch (bounded spin).
-  const uint32_t* wait_flags; int wait_n; int64_t wait_stride; uint32_t wait_epoch; uint32_t* wait_err;
+  // sender), row m waits until sender s's arrival flag wait_flags[s * wait_stride + m] reached wait_epoch.  The wait is bounded in
+  // WALL time (wait_ticks of the 100 MHz constant clock, from mn_tp_comm.wait_ms: host-side skew between ranks — a lazy code-object load, an
+  // allocator stall — is legitimate and can be long; a dead peer is not); on expiry the row sets wait_err AND poisons its outputs
+  // with NaN instead of consuming stale slabs, so a missed all-reduce can never pass for a result.
+  const uint32_t* wait_flags; int wait_n; int64_t wait_stride; uint32_t wait_epoch; uint32_t* wait_err; uint64_t wait_ticks;
 };
 
 namespace {
@@ -41,21 +46,26 @@ __global__ __launch_bounds__(1024) void wide_glue_kernel(const WideGlue p) {
   typedef uint32_t u2 __attribute__((ext_vector_type(2)));
   const int m = blockIdx.x, col = threadIdx.x * 4, D = p.D;
   const bool act = col < D;
+  int dead = 0;                                          // a sender's flag never came: every output of this row becomes NaN
   if (p.wait_flags) {                                    // uniform per launch
+    int expired = 0;
     if ((int)threadIdx.x < p.wait_n) {
       const uint32_t* f = p.wait_flags + (int64_t)threadIdx.x * p.wait_stride + m;
-      int spins = 0;
+      const uint64_t t0 = wall_clock64();                // constant 100 MHz, independent of the shader clock
       // relaxed polls, ONE acquire once the flag is there (an acquire load per poll would drop this CU's L1 on every iteration)
       while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - p.wait_epoch) < 0) {
-        if (++spins > (1 << 24)) {                       // ~ seconds: a peer died or the launch orders diverged — fail loudly, never hang
+        if (wall_clock64() - t0 > p.wait_ticks) {         // a peer died or the launch orders diverged
           if (p.wait_err) atomicExch(p.wait_err, 0x100u | (unsigned)threadIdx.x);
+          expired = 1;
           break;
         }
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(8);
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope: the senders may be other GPUs
+      // system scope (the senders may be other GPUs): drops this CU's L1 — the L1 is per CU, so the waves of this workgroup that
+      // did not poll read fresh lines after the barrier below (MI355X_MICROARCH.md: one poll, one acquire, barrier, plain loads)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
-    __syncthreads();
+    dead = __syncthreads_or(expired);
   }
   if (p.xin) {                                           // stage the row of the tiny-K projection
     if (threadIdx.x < p.kin) xs[threadIdx.x] = p.xin[(int64_t)m * p.kin + threadIdx.x];
@@ -118,6 +128,7 @@ __global__ __launch_bounds__(1024) void wide_glue_kernel(const WideGlue p) {
         for (int j = 0; j < 4; ++j) v += wv[j] * y[j];
       }
     }
+    if (dead) { const float q = __builtin_nanf(""); v = f4{q, q, q, q}; }
     if (p.h_out) *reinterpret_cast<f4*>(p.h_out + (int64_t)m * p.ldho + col) = v;
   }
   if (p.norm == 1) {

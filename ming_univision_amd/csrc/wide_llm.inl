@@ -57,7 +57,7 @@ struct LlmWideWs {
 
 static bool llm_wide_ok(const mn_llm* m, int rows) {
   const int ad = m->n_q * m->head_dim, n_slot = m->top_k + m->n_shared_slots;
-  return rows >= g_wide_min_llm && rows <= 2048 && wide_glue_ok(m->hidden) && (m->hidden % 64) == 0 && (ad % 64) == 0 && (m->moe_inter % 64) == 0 &&
+  return m->wfmt == MN_W_BF16 && rows >= g_wide_min_llm && rows <= 2048 && wide_glue_ok(m->hidden) && (m->hidden % 64) == 0 && (ad % 64) == 0 && (m->moe_inter % 64) == 0 &&
          m->n_experts <= 64 && (m->n_experts % 4) == 0 && m->n_experts + m->n_shared_slots <= 128 && (int64_t)rows * n_slot <= 65536 &&
          (m->head_dim == 64 || m->head_dim == 128);
 }

@@ -110,7 +110,7 @@ static size_t rf_wide_carve(const mn_rf_head* h, int rows, void* ws, size_t cap,
 }
 
 static bool rf_wide_ok(const mn_rf_head* h, int rows) {
-  return rows >= g_wide_min_rf && rows <= 2048 && wide_glue_ok(h->w) && wide_glue_ok(h->z_dim) && wide_glue_ok(h->llm_hidden) &&
+  return h->wfmt == MN_W_BF16 && rows >= g_wide_min_rf && rows <= 2048 && wide_glue_ok(h->w) && wide_glue_ok(h->z_dim) && wide_glue_ok(h->llm_hidden) &&
          (h->w % 64) == 0 && (h->hidden % 64) == 0 && (h->z_dim % 64) == 0 && (h->llm_hidden % 64) == 0 && h->target <= 64 &&
          (h->target % 4) == 0;
 }

@@ -6,8 +6,12 @@
 
 `model_name_or_path` is a directory with `config.json` (MingUniVisionConfig incl. `vishead_diffloss_config`)
 and `*.safetensors` shards keyed by the reference's parameter names; the tokenizer is read from the same
-directory when a `tokenizer.json` is present, otherwise the byte-level stand-in is used.  dtype "int4"/"int8"
-(bitsandbytes / quanto, :46-70) are outside the hot path and rejected.
+directory when a `tokenizer.json` is present, otherwise the byte-level stand-in is used.
+
+`dtype` is the reference's weight-format switch (:46-70: "bf16", or weight-only "int8" / "int4" through quanto / bitsandbytes).
+Here: "bf16" (default), and "fp8" — weight-only OCP e4m3 with one scale per output row for the decoder stack's experts and the RF
+head's ResBlock matrices (95 % of the bytes a visual token streams), quantised once at load from the same bf16 checkpoint; the
+arithmetic (fp32 / bf16 hi+lo activations, bf16 MFMA, fp32 accumulate) is unchanged.  "int8" / "int4" are not built.
 """
 import glob
 import os
@@ -58,8 +62,8 @@ class HFTokenizerAdapter:
 
 class MingUniVisionInfer:
     def __init__(self, model_name_or_path=None, dtype="bf16", device="cuda", config=None, seed=0, t_max=4096):
-        if dtype not in ("bf16",):
-            raise NotImplementedError(f"dtype={dtype!r}: weight-only int4/int8 modes are outside the hot path")
+        if dtype not in ("bf16", "fp8"):
+            raise NotImplementedError(f"dtype={dtype!r}: 'bf16' or 'fp8' (weight-only e4m3); the int4/int8 modes are not built")
         self.model_name_or_path = model_name_or_path
         self.dtype = dtype
         self.model, self.tokenizer, self.processor = self.load_model_processor(config, device, seed, t_max)
@@ -82,7 +86,7 @@ class MingUniVisionInfer:
         if tokenizer is None:
             tokenizer = SpecialTokenTokenizer()
         processor = BailingMMProcessor(tokenizer=tokenizer)
-        model = MingUniVisionForConditionalGeneration(config, state_dict=sd, device=device, seed=seed, t_max=t_max)
+        model = MingUniVisionForConditionalGeneration(config, state_dict=sd, device=device, seed=seed, t_max=t_max, weights=self.dtype)
         return model, tokenizer, processor
 
     def generate(self, messages, max_new_tokens=512, output_image_prefix="output", for_edit=False, **kw):

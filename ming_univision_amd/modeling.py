@@ -31,9 +31,13 @@ class MingUniVisionForConditionalGeneration:
     config_class = MingUniVisionConfig
     BATCH_SEQ0 = 3      # cache sequences 0..2 hold the (up to 3) CFG rows of the multi-round conversation of generate()
 
-    def __init__(self, config: MingUniVisionConfig, state_dict=None, device="cuda", seed=0, t_max=4096):
+    def __init__(self, config: MingUniVisionConfig, state_dict=None, device="cuda", seed=0, t_max=4096, weights="bf16"):
         """state_dict: reference-named tensors (`vision.*`, `model.model.*`, `model.lm_head.*`, `model.vis_head.*`,
-        `model.diffloss.*`, `linear_proj.*`); None -> deterministic synthetic weights (synth.py)."""
+        `model.diffloss.*`, `linear_proj.*`); None -> deterministic synthetic weights (synth.py).
+        weights="fp8": the experts of the decoder stack and the ResBlock matrices of the RF head are quantised at load to OCP e4m3
+        with one scale per output row (mingnative.h section 7) — the counterpart of the reference's weight-only `dtype` modes
+        (mingunivisioninfer.py:46-70); everything else, and all arithmetic, stays as in "bf16"."""
+        self.weights = weights
         assert config.llm_config is not None
         assert config.vishead_diffloss_config is not None          # modeling_bailingmm.py:118
         self.config = config
@@ -57,15 +61,30 @@ class MingUniVisionForConditionalGeneration:
                             for i in range(config.mlp_depth)]
         self.vision = MingTok(tcfg, state_dict=tok_sd, device=self.device, seed=seed, linear_proj=self.linear_proj)
         if state_dict is None:
-            self.model = BailingMoeDecoder.synthetic(cfg, self.device, seed=seed, t_max=t_max, n_seq=3)
+            self.model = BailingMoeDecoder.synthetic(cfg, self.device, seed=seed, t_max=t_max, n_seq=3, weights=weights)
             shapes = llm_param_shapes(cfg, config.vishead_diffloss_config, self.vision.latent_dim)
             rf_sd = {k: synth_tensor(k, s, seed, self.device, torch.bfloat16) for k, s in shapes.items()
                      if k.startswith("vis_head") or k.startswith("diffloss")}
         else:
             llm_sd = {k[len("model."):]: bf(v) for k, v in state_dict.items() if k.startswith("model.")}
-            self.model = BailingMoeDecoder.from_state_dict(cfg, llm_sd, t_max=t_max, n_seq=3)
+            self.model = BailingMoeDecoder.from_state_dict(cfg, llm_sd, t_max=t_max, n_seq=3, weights=weights)
             rf_sd = {k: v for k, v in llm_sd.items() if k.startswith("vis_head") or k.startswith("diffloss")}
-        self.rf = RectifiedFlowHead(rf_sd, cfg.hidden_size, config.vishead_diffloss_config, self.vision.latent_dim)
+        self.rf = RectifiedFlowHead(rf_sd, cfg.hidden_size, config.vishead_diffloss_config, self.vision.latent_dim, weights=weights)
+        self._init_state(seed)
+
+    @classmethod
+    def from_parts(cls, config, vision, model, rf, linear_proj, seed=0):
+        """Assemble the wrapper around components that already live in HBM (the way the reference's __init__ wires them,
+        modeling_bailingmm.py:93-129) — e.g. a second view of the same weights with another KV arena.  `model` is a
+        BailingMoeDecoder, `vision` a MingTok built with the same linear_proj list, `rf` a RectifiedFlowHead."""
+        self = cls.__new__(cls)
+        self.config, self.device = config, model.device
+        self.weights = getattr(model, "weights", "bf16")
+        self.linear_proj, self.vision, self.model, self.rf = linear_proj, vision, model, rf
+        self._init_state(seed)
+        return self
+
+    def _init_state(self, seed):
         self.tokenizer = None
         self.mfma_prefill_threshold = 64   # prompts longer than this prefill as GEMMs (prefill_wide / prefill_mfma)
         # Numerics of what feeds the LLM in understanding / editing (MingTok encode + linear_proj, long-prompt prefill):

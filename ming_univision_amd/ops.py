@@ -31,9 +31,11 @@ def as_bf16_bits(t):
 
 
 def skinny_gemm(x, w, bias=None, *, prologue="none", epilogue="none", out=None, pro_a=None, pro_b=None,
-                ln_g=None, ln_b=None, eps=1e-6, res=None, gate=None, n_out=None, use_mfma_route=True):
-    """out[M,N] = epilogue(prologue(x)[M,K] @ w[N(,2N),K]^T + bias).  x fp32, w/bias/ln bf16."""
-    _req(x, torch.float32, "x"); _req(w, torch.bfloat16, "w"); _req(bias, torch.bfloat16, "bias")
+                ln_g=None, ln_b=None, eps=1e-6, res=None, gate=None, n_out=None, use_mfma_route=True, wscale=None):
+    """out[M,N] = epilogue(prologue(x)[M,K] @ w[N(,2N),K]^T + bias).  x fp32, w/bias/ln bf16.
+    wscale (fp32 [N or 2N]) given: w holds OCP e4m3 bytes (uint8) with one scale per weight row (fp8 weight mode)."""
+    _req(x, torch.float32, "x"); _req(w, torch.uint8 if wscale is not None else torch.bfloat16, "w"); _req(bias, torch.bfloat16, "bias")
+    _req(wscale, torch.float32, "wscale")
     _req(ln_g, torch.bfloat16, "ln_g"); _req(ln_b, torch.bfloat16, "ln_b")
     _req(pro_a, torch.float32, "pro_a"); _req(pro_b, torch.float32, "pro_b")
     _req(res, torch.float32, "res"); _req(gate, torch.float32, "gate")
@@ -61,8 +63,13 @@ def skinny_gemm(x, w, bias=None, *, prologue="none", epilogue="none", out=None, 
     if gate is not None:
         a.gate, a.ldgate = ptr(gate), gate.stride(0)
     ws = None
-    nb = lib().mn_skinny_workspace_bytes(M, N, K, a.epilogue)
-    if nb > 0 and (M > 8 or use_mfma_route):
+    if wscale is not None:
+        assert wscale.numel() == w.shape[0] and w.is_contiguous()
+        a.wfmt, a.wscale = _lib.W_FP8_E4M3, ptr(wscale)
+        nb = lib().mn_skinny_workspace_bytes_w8(M, N, K, a.epilogue)
+    else:
+        nb = lib().mn_skinny_workspace_bytes(M, N, K, a.epilogue)
+    if nb > 0 and (M > 8 or use_mfma_route or wscale is not None):
         ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
         a.ws, a.ws_bytes = ptr(ws), nb
     check(lib().mn_skinny_gemm(C.byref(a), current_stream()), "mn_skinny_gemm")
@@ -399,3 +406,43 @@ def lmhead_argmax(hidden, w, vocab_offset=0):
     check(lib().mn_lmhead_argmax(ptr(hidden), hidden.stride(0), M, ptr(w), w.stride(0), V, H, vocab_offset, ptr(idx), ptr(val), ptr(ws), n,
                                  current_stream()), "mn_lmhead_argmax")
     return idx, val
+
+
+# ---- fp8 weight mode (mingnative.h section 7) ----------------------------------------------------------------------------------
+def quant_fp8_rows(w):
+    """bf16 [..., N, K] -> (e4m3 bytes uint8 [..., N, K], fp32 scales [..., N]): one power-of-two scale per output row,
+    W = e4m3(Wq) * scale exactly representable in bf16 (mn_quant_fp8_rows)."""
+    _req(w, torch.bfloat16, "w")
+    assert w.is_contiguous() and w.shape[-1] % 4 == 0
+    K = w.shape[-1]
+    n_rows = w.numel() // K
+    q = torch.empty(w.shape, dtype=torch.uint8, device=w.device)
+    scale = torch.empty(w.shape[:-1], dtype=torch.float32, device=w.device)
+    check(lib().mn_quant_fp8_rows(ptr(w), K, ptr(q), K, ptr(scale), n_rows, K, current_stream()), "mn_quant_fp8_rows")
+    return q, scale
+
+
+def dequant_fp8_rows(q, scale):
+    """(e4m3 bytes [..., N, K], scales [..., N]) -> bf16 [..., N, K] (exact for the power-of-two scales of quant_fp8_rows)."""
+    _req(q, torch.uint8, "q"); _req(scale, torch.float32, "scale")
+    assert q.is_contiguous() and scale.is_contiguous() and tuple(scale.shape) == tuple(q.shape[:-1])
+    K = q.shape[-1]
+    w = torch.empty(q.shape, dtype=torch.bfloat16, device=q.device)
+    check(lib().mn_dequant_fp8_rows(ptr(q), K, ptr(scale), ptr(w), K, q.numel() // K, K, current_stream()), "mn_dequant_fp8_rows")
+    return w
+
+
+def stream_mfma_w8(y2, q, scale):
+    """Weight-streaming MFMA launch on fp8 weights: y2 bf16 [2, M, K] (hi rows, lo rows), q uint8 [N, K], scale fp32 [N]
+    -> fp32 [M, N] (the K-slice partials summed here with torch: a test helper, the composites reduce them in their glue kernels)."""
+    _req(y2, torch.bfloat16, "y2"); _req(q, torch.uint8, "q"); _req(scale, torch.float32, "scale")
+    _, M, K = y2.shape
+    N = q.shape[0]
+    assert y2.is_contiguous() and q.is_contiguous() and q.shape[1] == K
+    nz = lib().mn_stream_mfma_w8_slices(M, N, K)
+    P = torch.empty(nz, M, N, dtype=torch.float32, device=q.device)
+    rc = lib().mn_stream_mfma_w8(ptr(y2), ptr(q), ptr(scale), ptr(P), M, N, K, current_stream())
+    if rc < 0:
+        check(rc, "mn_stream_mfma_w8")
+    assert rc == nz
+    return P.sum(0)

@@ -12,6 +12,11 @@ Load-time re-packing (results unchanged):
     [depth*3w + 2w, w] matrix so a step's modulations are ONE weight-streaming launch;
   * time_embed(t_s * 1000) only ever sees the `steps` fixed times of the Euler grid, so the
     [steps, w] table is computed once (with the same kernels) instead of per token.
+
+`weights="fp8"` (mingnative.h section 7; the reference's reduced-byte surface is the `dtype` switch of
+mingunivisioninfer.py:46-70): the ResBlock matrices w12 / w3 — 1.21 of the head's 1.29 B parameters, streamed 16 times per
+visual token — are quantised once at load to OCP e4m3 with one power-of-two scale per output row and streamed as bytes; the
+head then serves <= 64 rows per call (the HBM-bound route; the MFMA-bound wide route gains nothing from narrower weights).
 """
 import ctypes as C
 import math
@@ -24,8 +29,11 @@ from .configuration import DEFAULT_VISHEAD_DIFFLOSS, swiglu_hidden
 
 
 class RectifiedFlowHead:
-    def __init__(self, sd, llm_hidden, vishead_diffloss_config=None, latent_dim=32, prefix=""):
-        """sd: {reference parameter name: bf16 CUDA tensor} holding `vis_head.*` and `diffloss.net.*`."""
+    def __init__(self, sd, llm_hidden, vishead_diffloss_config=None, latent_dim=32, prefix="", weights="bf16"):
+        """sd: {reference parameter name: bf16 CUDA tensor} holding `vis_head.*` and `diffloss.net.*`.
+        weights: "bf16", or "fp8" = w12 / w3 quantised here to e4m3 + row scales (the bf16 originals are not kept)."""
+        assert weights in _lib.WFMT, f"weights={weights!r}: 'bf16' or 'fp8'"
+        self.weights = weights
         cfg = {**DEFAULT_VISHEAD_DIFFLOSS, **(vishead_diffloss_config or {})}
         assert cfg["vis_head_arch"] == "linear2-norm"          # modeling_bailing_moe.py:1568
         assert cfg["gen_method"].startswith("flow_matching_swiglu-")
@@ -69,7 +77,21 @@ class RectifiedFlowHead:
                                 g(n + "time_embed.mlp.0.bias"), epilogue="silu")
             temb.append(ops.skinny_gemm(h, g(n + "time_embed.mlp.2.weight"), g(n + "time_embed.mlp.2.bias")))
         self.t["temb"] = torch.cat(temb, 0).contiguous()
+        self._finalize(weights)
+
+    def _finalize(self, weights):
+        """Quantise the ResBlock matrices when asked to and build the pointer table the C ABI takes."""
+        self.weights = weights
+        self.scales = {}
+        if weights == "fp8":
+            self.lists = dict(self.lists)
+            for k in ("w12", "w3"):
+                qs = [ops.quant_fp8_rows(w) for w in self.lists[k]]
+                self.lists[k] = [q for q, _ in qs]
+                self.scales[k] = [sc for _, sc in qs]
+        llm_hidden = self.llm_hidden
         self._arrays = {k: ptr_array(v) for k, v in self.lists.items()}
+        self._scale_arrays = {k: ptr_array(v) for k, v in self.scales.items()}
         s = RfHead()
         s.w, s.depth, s.hidden, s.z_dim, s.target, s.steps, s.llm_hidden = (
             self.w, self.depth, self.hidden, self.w, self.target, self.steps, llm_hidden)
@@ -78,13 +100,38 @@ class RectifiedFlowHead:
             setattr(s, k, ptr(self.t[k]))
         for k, arr in self._arrays.items():
             setattr(s, k, C.cast(arr, _lib.PP))
+        s.wfmt = _lib.WFMT[weights]
+        if weights == "fp8":
+            s.w12_scale = C.cast(self._scale_arrays["w12"], _lib.PP)
+            s.w3_scale = C.cast(self._scale_arrays["w3"], _lib.PP)
         self.struct = s
         self._ws = {}
 
+    def to_fp8(self):
+        """A second head on the same HBM tensors whose ResBlock matrices are e4m3 copies (this bf16 head stays usable)."""
+        import copy
+        assert self.weights == "bf16"
+        new = copy.copy(self)
+        new._finalize("fp8")
+        return new
+
     def weight_bytes_per_step(self):
-        """bf16 bytes one Euler step must stream from HBM."""
-        per_block = (2 * self.hidden * self.w + self.w * self.hidden) * 2
+        """Weight bytes one Euler step must stream from HBM (bf16: 2 per ResBlock parameter; fp8: 1 + the row scales)."""
+        per_w = 1 if self.weights == "fp8" else 2
+        per_block = (2 * self.hidden * self.w + self.w * self.hidden) * per_w
+        if self.weights == "fp8":
+            per_block += (2 * self.hidden + self.w) * 4
         return self.depth * per_block + self.t["ada_w"].numel() * 2
+
+    def dequantized_blocks(self):
+        """fp8 mode: {reference parameter name: bf16 tensor} of the ResBlock matrices as the kernels see them (e4m3 * row scale,
+        exact in bf16) — what the oracle is fed in the parity tests, and a bf16 model of its own right."""
+        assert self.weights == "fp8"
+        out = {}
+        for i in range(self.depth):
+            for k, name in (("w12", "mlp.w12.weight"), ("w3", "mlp.w3.weight")):
+                out[f"diffloss.net.res_blocks.{i}.{name}"] = ops.dequant_fp8_rows(self.lists[k][i], self.scales[k][i])
+        return out
 
     def max_rows(self):
         """Rows one sample() accepts: 64, or 2048 when the wide route applies (all widths multiples of 64)."""

@@ -61,10 +61,32 @@ def shard_attention(wqkv, wdense, cfg, rank, world):
     return wqkv[rows].contiguous(), wdense[:, q0 * hd:(q0 + pl["n_q"]) * hd].contiguous()
 
 
+def shard_expert_scales(gu_scale, dn_scale, cfg, rank, world):
+    """fp8 weight mode: the row scales that go with shard_experts' four tensors.  gu_scale [E + S, 2I], dn_scale [E + S, H] ->
+    (routed gate/up [E / world, 2I], routed down [E / world, H], shared gate/up [2 * pad], shared down [H]).  A row of the shared
+    down projection keeps ONE scale only while the rank's columns lie inside one pseudo-expert (world even for S = 2)."""
+    E, S, I = cfg.num_experts, cfg.num_shared_experts or 0, cfg.moe_intermediate_size
+    pl = shard_plan(cfg, world)
+    e0 = rank * pl["n_experts"]
+    gs, ds = gu_scale[e0:e0 + pl["n_experts"]].contiguous(), dn_scale[e0:e0 + pl["n_experts"]].contiguous()
+    if not S:
+        return gs, ds, None, None
+    n, pad = pl["shared"], pl["shared_pad"]
+    u0 = rank * n
+    if u0 // I != (u0 + n - 1) // I:
+        raise ValueError(f"fp8 weights: rank {rank}'s slice [{u0}, {u0 + n}) of the shared expert straddles two pseudo-experts of width {I}")
+    sg = torch.cat([gu_scale[E + s, :I] for s in range(S)])         # scales of the shared gate_proj rows [S I]
+    su = torch.cat([gu_scale[E + s, I:] for s in range(S)])
+    ws_gs = torch.ones(2 * pad, dtype=torch.float32, device=gu_scale.device)
+    ws_gs[:n], ws_gs[pad:pad + n] = sg[u0:u0 + n], su[u0:u0 + n]
+    return gs, ds, ws_gs, dn_scale[E + u0 // I].contiguous()
+
+
 def shard_experts(w_gate_up, w_down, cfg, rank, world):
     """Packed experts of a layer (bailing_moe.pack_experts: [E + S, 2I, H] / [E + S, H, I], shared pseudo-experts last) -> this rank's
     routed experts [E / world, ...] and its slice of the shared expert: ws_gate_up [2 * pad, H] (gate rows, up rows), ws_down [H, pad]
-    with the slice zero-padded to a multiple of 64 units (silu(0) * 0 against zero down columns)."""
+    with the slice zero-padded to a multiple of 64 units (silu(0) * 0 against zero down columns).  Pure indexing: bf16 weights and
+    e4m3 bytes (uint8; zero byte = +0) alike."""
     E, S, I = cfg.num_experts, cfg.num_shared_experts or 0, cfg.moe_intermediate_size
     pl = shard_plan(cfg, world)
     e0 = rank * pl["n_experts"]
@@ -230,15 +252,14 @@ class TpDecoderShard:
         self.t_max, self.n_seq = dec.t_max, dec.n_seq
         L = cfg.num_hidden_layers
         self.layers = getattr(self, "_shard_layers", None) or []
+        self.weights = getattr(dec, "weights", "bf16")
         for ly in (dec.layers or []):
-            wqkv, wdense = shard_attention(ly["wqkv"], ly["wdense"], cfg, rank, world)
-            gu, dn, wsg, wsd = shard_experts(ly["w_gate_up"], ly["w_down"], cfg, rank, world)
-            self.layers.append(dict(ln1=ly["ln1"], wqkv=wqkv, wdense=wdense, ln2=ly["ln2"], gate=ly["gate"], image_gate=ly.get("image_gate"),
-                                    w_gate_up=gu, w_down=dn, ws_gate_up=wsg, ws_down=wsd))
+            self.layers.append(self._shard_layer(ly, cfg, rank, world))
         hd = cfg.head_dim
         self.kv_cache = torch.zeros(L, self.n_seq, 2, pl["n_kv"], self.t_max, hd, dtype=torch.float32, device=self.device)
         keys = ("ln1", "wqkv", "wdense", "ln2", "gate", "image_gate", "w_gate_up", "w_down", "ws_gate_up", "ws_down")
-        self._arrays = {k: ptr_array([ly.get(k) for ly in self.layers]) for k in keys}
+        skeys = ("w_gate_up_scale", "w_down_scale", "ws_gate_up_scale", "ws_down_scale")
+        self._arrays = {k: ptr_array([ly.get(k) for ly in self.layers]) for k in keys + skeys}
         s = Llm()
         s.hidden, s.n_layers, s.n_q, s.n_kv, s.head_dim = cfg.hidden_size, L, pl["n_q"], pl["n_kv"], hd
         s.n_experts, s.top_k, s.n_shared_slots = cfg.num_experts, cfg.num_experts_per_tok, 0
@@ -252,19 +273,39 @@ class TpDecoderShard:
         if dec.mrope_section is not None:
             s.mrope_sec_t, s.mrope_sec_h = dec.mrope_section[0], dec.mrope_section[1]
         self.mrope_section = dec.mrope_section
+        s.wfmt = _lib.WFMT[self.weights]
+        if self.weights == "fp8":
+            s.w_gate_up_scale = C.cast(self._arrays["w_gate_up_scale"], _lib.PP)
+            s.w_down_scale = C.cast(self._arrays["w_down_scale"], _lib.PP)
         self.struct = s
         t = LlmTp()
         t.expert0, t.n_local_experts, t.shared_inter = rank * pl["n_experts"], pl["n_experts"], pl["shared_pad"]
         if pl["shared_pad"]:
             t.ws_gate_up, t.ws_down = C.cast(self._arrays["ws_gate_up"], _lib.PP), C.cast(self._arrays["ws_down"], _lib.PP)
+            if self.weights == "fp8":
+                t.ws_gate_up_scale = C.cast(self._arrays["ws_gate_up_scale"], _lib.PP)
+                t.ws_down_scale = C.cast(self._arrays["ws_down_scale"], _lib.PP)
         self.tp = t
         self._keep = (dec.final_norm, dec.cos, dec.sin)
         self._ws = {}
 
+    @staticmethod
+    def _shard_layer(ly, cfg, rank, world):
+        """One layer of a full decoder (packed experts; bf16, or e4m3 bytes + row scales) -> this rank's tensors."""
+        wqkv, wdense = shard_attention(ly["wqkv"], ly["wdense"], cfg, rank, world)
+        gu, dn, wsg, wsd = shard_experts(ly["w_gate_up"], ly["w_down"], cfg, rank, world)
+        out = dict(ln1=ly["ln1"], wqkv=wqkv, wdense=wdense, ln2=ly["ln2"], gate=ly["gate"], image_gate=ly.get("image_gate"),
+                   w_gate_up=gu, w_down=dn, ws_gate_up=wsg, ws_down=wsd)
+        if ly["w_gate_up"].dtype == torch.uint8:
+            gs, ds, wsgs, wsds = shard_expert_scales(ly["w_gate_up_scale"], ly["w_down_scale"], cfg, rank, world)
+            out.update(w_gate_up_scale=gs, w_down_scale=ds, ws_gate_up_scale=wsgs, ws_down_scale=wsds)
+        return out
+
     @classmethod
-    def synthetic(cls, cfg, device, rank, world, seed=0, t_max=2048, n_seq=3, n_pos=None):
+    def synthetic(cls, cfg, device, rank, world, seed=0, t_max=2048, n_seq=3, n_pos=None, weights="bf16"):
         """A rank's shard of the random-init 16B-A3B-style stack WITHOUT ever holding the full model: every layer is synthesised
-        with the reference's parameter names (same seed on every rank -> the same full weights), packed, sliced and dropped."""
+        with the reference's parameter names (same seed on every rank -> the same full weights), packed, sliced and dropped.
+        weights="fp8": the packed experts of each layer are quantised (as the unsharded model's) before slicing."""
         from .bailing_moe import BailingMoeDecoder, pack_experts, rope_tables
         from .configuration import llm_layer_param_shapes
         from .synth import synth_tensor
@@ -283,14 +324,17 @@ class TpDecoderShard:
             sd = {k: synth_tensor(k, v, seed, device, torch.bfloat16) for k, v in llm_layer_param_shapes(cfg, li).items()}
             p = f"model.layers.{li}"
             gu, dn = pack_experts(sd, p + ".mlp", cfg)
-            wqkv, wdense = shard_attention(sd[p + ".attention.query_key_value.weight"], sd[p + ".attention.dense.weight"], cfg, rank, world)
-            gu_l, dn_l, wsg, wsd = shard_experts(gu, dn, cfg, rank, world)
-            self._shard_layers.append(dict(ln1=sd[p + ".input_layernorm.weight"], wqkv=wqkv, wdense=wdense,
-                                           ln2=sd[p + ".post_attention_layernorm.weight"], gate=sd[p + ".mlp.gate.weight"],
-                                           image_gate=sd.get(p + ".mlp.image_gate.weight") if cfg.multi_gate else None,
-                                           w_gate_up=gu_l, w_down=dn_l, ws_gate_up=wsg, ws_down=wsd))
-            del sd, gu, dn
+            ly = dict(ln1=sd[p + ".input_layernorm.weight"], wqkv=sd[p + ".attention.query_key_value.weight"],
+                      wdense=sd[p + ".attention.dense.weight"], ln2=sd[p + ".post_attention_layernorm.weight"],
+                      gate=sd[p + ".mlp.gate.weight"], image_gate=sd.get(p + ".mlp.image_gate.weight") if cfg.multi_gate else None,
+                      w_gate_up=gu, w_down=dn)
+            if weights == "fp8":
+                from .bailing_moe import quantize_layer_experts
+                quantize_layer_experts(ly)
+            self._shard_layers.append(cls._shard_layer(ly, cfg, rank, world))
+            del sd, gu, dn, ly
         full.layers = None
+        full.weights = weights
         self.__init__(full, rank, world)
         return self
 
@@ -298,7 +342,7 @@ class TpDecoderShard:
         return int(lib().mn_llm_tp_segments(C.byref(self.struct)))
 
     def weight_bytes(self):
-        return sum(t.numel() * 2 for ly in self.layers for k, t in ly.items() if t is not None and k not in ("ln1", "ln2"))
+        return sum(t.numel() * t.element_size() for ly in self.layers for k, t in ly.items() if t is not None and k not in ("ln1", "ln2"))
 
     def step_tp(self, comm, x, row_seq, row_slot, row_pos, row_len, key_mask=None, image_mask=None, out=None, rows=None, x_row_div=1,
                 seg_begin=0, seg_end=None):
@@ -336,12 +380,23 @@ class TpRfShard:
             w12.append(a); b12.append(bb); w3.append(c)
         self.lists = dict(rf.lists, w12=w12, b12=b12, w3=w3)
         self._arrays = {k: ptr_array(v) for k, v in self.lists.items()}
+        self.weights = getattr(rf, "weights", "bf16")
+        if self.weights == "fp8":      # row scales: w12's rows are sliced like its weights, w3's columns share the full rows' scales
+            hid, n = rf.hidden, rf.hidden // world
+            u0 = rank * n
+            self.scales = dict(w12=[torch.cat((sc[u0:u0 + n], sc[hid + u0:hid + u0 + n])).contiguous() for sc in rf.scales["w12"]],
+                               w3=rf.scales["w3"])
+            self._scale_arrays = {k: ptr_array(v) for k, v in self.scales.items()}
         s = RfHead()
         s.w, s.depth, s.hidden, s.z_dim, s.target, s.steps, s.llm_hidden = rf.w, rf.depth, self.hidden, rf.w, rf.target, rf.steps, rf.llm_hidden
         for k in ("vis_w", "vis_b", "vis_ln_g", "vis_ln_b", "cond_w", "cond_b", "in_w", "in_b", "temb", "ada_w", "ada_b", "fin_w", "fin_b"):
             setattr(s, k, ptr(rf.t[k]))
         for k, arr in self._arrays.items():
             setattr(s, k, C.cast(arr, _lib.PP))
+        s.wfmt = _lib.WFMT[self.weights]
+        if self.weights == "fp8":
+            s.w12_scale = C.cast(self._scale_arrays["w12"], _lib.PP)
+            s.w3_scale = C.cast(self._scale_arrays["w3"], _lib.PP)
         self.struct = s
         self.target = rf.target
         self._ws = {}
@@ -384,7 +439,9 @@ def vocab_parallel_pick(dist, pair):
 
 
 def pick_best(idxs, vals):
-    """idxs / vals [world, M] -> [M]: max logit, ties -> lowest id."""
+    """idxs / vals [world, M] -> [M]: max logit, ties -> lowest id; NaN counts as the maximum (torch.argmax's order), so a row of
+    NaN logits still yields a valid id."""
+    vals = torch.nan_to_num(vals, nan=float("inf"), posinf=float("inf"))
     best = vals.max(dim=0).values
     cand = torch.where(vals == best.unsqueeze(0), idxs, torch.full_like(idxs, torch.iinfo(torch.int64).max))
     return cand.min(dim=0).values
@@ -396,9 +453,15 @@ def pick_best(idxs, vals):
 class _TpDecoderBase:
     """The slice of BailingMoeDecoder's interface that generate_images / generate use."""
     MAX_ROWS = 2048
+    single_stream = True        # generate_images(n_groups > 1) is refused: one communicator = one stream (two-parity inbox)
+
+    def _row_cap(self):
+        """fp8 weights are served by the <= 64-row streaming kernels only (mingnative.h section 7)."""
+        fp8 = "fp8" in (getattr(self, "weights", "bf16"), getattr(self, "rf_weights", "bf16"))
+        return min(64 if fp8 else self.MAX_ROWS, self.rows_cap)
 
     def max_rows(self):
-        return min(self.MAX_ROWS, self.rows_cap)
+        return self._row_cap()
 
     def embed(self, ids):
         return self.full.embed(ids)
@@ -453,6 +516,7 @@ class TpSimGroup(_TpDecoderBase):
         self.shards = [TpDecoderShard(dec, r, world) for r in range(world)]
         self.rf_shards = [TpRfShard(rf, r, world) for r in range(world)] if rf is not None else None
         self.target = rf.target if rf is not None else None
+        self.weights, self.rf_weights = getattr(dec, "weights", "bf16"), getattr(rf, "weights", "bf16")
 
     # -- decoder -------------------------------------------------------------------------------------------------
     def step(self, x, row_seq, row_slot, row_pos, row_len, key_mask=None, image_mask=None, out=None, rows=None, x_row_div=1):
@@ -480,7 +544,7 @@ class TpSimGroup(_TpDecoderBase):
 
     # -- RF sampler ----------------------------------------------------------------------------------------------
     def rf_max_rows(self):
-        return min(2048, self.rows_cap)
+        return self._row_cap()
 
     def sample(self, hidden, noise, temperature=1.0, text_cfg=3.0, image_cfg=1.1, out=None, n_images=1):
         outs = [out if r == 0 and out is not None else torch.empty(noise.shape, dtype=torch.float32, device=hidden.device)
@@ -531,6 +595,7 @@ class TpRank(_TpDecoderBase):
         self.comm = make(dist, rows_cap, width, self.device)
         self.rf_shard = TpRfShard(rf, self.rank, self.world) if rf is not None else None
         self.target = rf.target if rf is not None else None
+        self.weights, self.rf_weights = self.shard.weights, getattr(rf, "weights", "bf16")
 
     def embed(self, ids):
         return self._embed(ids) if self._embed is not None else self.full.embed(ids)
@@ -548,7 +613,9 @@ class TpRank(_TpDecoderBase):
         V = lm.shape[0]
         n = -(-V // self.world)
         v0, v1 = min(V, self.rank * n), min(V, (self.rank + 1) * n)
-        return vocab_parallel_pick(self._dist, ops_lmhead(hidden, lm[v0:v1], v0))
+        ids = vocab_parallel_pick(self._dist, ops_lmhead(hidden, lm[v0:v1], v0))
+        self.check_err()                                 # a host sync point anyway (the caller reads the ids): expired waits surface here
+        return ids
 
     def _segmented(self, call, n_seg, n_floats):
         """Relayed transport: run the composite one segment at a time, delivering each all-reduce through the process group."""
@@ -576,7 +643,7 @@ class TpRank(_TpDecoderBase):
         self.shard.kv_cache[:, dst, :, :, :n].copy_(self.shard.kv_cache[:, src, :, :, :n])
 
     def rf_max_rows(self):
-        return min(2048, self.rows_cap)
+        return self._row_cap()
 
     def sample(self, hidden, noise, temperature=1.0, text_cfg=3.0, image_cfg=1.1, out=None, n_images=1):
         if out is None:

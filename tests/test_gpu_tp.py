@@ -59,6 +59,47 @@ def test_allreduce_oneshot_concurrent_ranks_really_wait():
             assert torch.equal(outs[r], xs[0] + xs[1])
 
 
+def test_allreduce_wait_that_expires_poisons_the_rows_and_raises():
+    """A sender that never pushes (dead peer / diverged launch order): the consumer's wall-time-bounded wait (200 ms here, 30 s by
+    default) expires, the rows come out as NaN — never as a sum of stale slabs — and check_err() raises naming the sender."""
+    from ming_univision_amd.tp import TpCommunicator
+    comms = TpCommunicator.simulated(2, rows_cap=8, width=256)
+    x = torch.ones(8, 256, device="cuda")
+    for c in comms:                                                    # a completed round first: the inbox holds stale finite data
+        c.all_reduce(x, phase=TpCommunicator.PUSH)
+    outs = [c.all_reduce(x, phase=TpCommunicator.REDUCE) for c in comms]
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, 2 * x) for o in outs)
+    comms[0].struct.wait_ms = 200
+    comms[0].all_reduce(3 * x, phase=TpCommunicator.PUSH)              # rank 1 never pushes round 2
+    import time
+    t0 = time.perf_counter()
+    out = comms[0].all_reduce(3 * x, phase=TpCommunicator.REDUCE)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert 0.15 < dt < 5.0, dt
+    assert bool(torch.isnan(out).all())
+    with pytest.raises(RuntimeError, match="gave up waiting for sender 1"):
+        comms[0].check_err()
+
+
+def test_lmhead_argmax_on_nan_rows_returns_a_valid_id():
+    """torch.argmax treats NaN as the maximum: a row of NaN logits (e.g. after a poisoned all-reduce) must still give an id inside
+    the vocabulary (the next step gathers word_embeddings[id])."""
+    from ming_univision_amd import ops
+    from ming_univision_amd.tp import pick_best
+    g = torch.Generator().manual_seed(0)
+    w = (torch.randn(1000, 256, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    h = torch.randn(3, 256, generator=g).cuda()
+    h[1] = float("nan")
+    idx, val = ops.lmhead_argmax(h, w, vocab_offset=5000)
+    ref = (h.double() @ w.double().T)
+    assert int(idx[0]) == 5000 + int(ref[0].argmax()) and int(idx[2]) == 5000 + int(ref[2].argmax())
+    assert int(idx[1]) == 5000 and bool(torch.isnan(val[1]))           # all NaN: the first one, like torch.argmax
+    best = pick_best(torch.tensor([[7, 3], [9, 1]]), torch.tensor([[float("nan"), 1.0], [float("nan"), 2.0]]))
+    assert best.tolist() == [7, 1]
+
+
 def test_ep_dispatch_and_combine_match_the_full_expert_sum():
     """mn_ep_dispatch / mn_ep_combine: 4 ranks x 2 experts; the tile list of a rank names only its experts, the combine over the
     ranks is the weighted un-permute of ALL picks."""
