@@ -354,6 +354,17 @@ MN_API int mn_add_bcast_f32(const float* a, const float* b, float* out, int64_t 
 MN_API int mn_group_mean_add(const float* y, const float* x, float* out, int M, int D, int Cout, void* stream);
 MN_API int mn_repeat_add(const float* y, const float* s, float* out, int M, int D, int Cin, float scale, float shift, void* stream);
 MN_API int mn_clamp_f32(float* x, int64_t n, float lo, float hi, void* stream);
+/* The MingTok layout shuffles as single passes that write the consumer's operand directly:
+ * mn_patchify_operand: PatchEmbed's conv k = s = P as a GEMM (layers/patch_embed.py:69-82): image fp32 [B,3,Hi,Wi] -> A operand bf16
+ *   [B * (Hi/P) * (Wi/P), 3 P^2] (row = patch, column = (c, py, px)); y_lo_off != 0: bf16 hi rows at Y, lo rows y_lo_off elements further.
+ * mn_tokens_assemble: prepare_tokens (vision_transformer.py:218-223): out[b, n] = (n < N ? tok[b N + n] : cls) + pos[n], cls LAST.
+ * mn_subtoken_rearrange: "b (h w) (x y c) -> b (h x w y) c" of forward_pixel_decoder (modeling_mingtok.py:184-188), fp32, Dp = c.
+ * mn_unpatchify_clamp: unpatchify 'nhwpqc->nchpwq' (vision_transformer.py:515-527) + clamp_ (modeling_mingtok.py:195): o fp32
+ *   [B * hh * ww, p * p * 3] -> image [B, 3, hh p, ww p]. */
+MN_API int mn_patchify_operand(const float* image, int B, int Hi, int Wi, int P, uint16_t* Y, int64_t y_lo_off, void* stream);
+MN_API int mn_tokens_assemble(const float* tok, const uint16_t* cls, const float* pos, float* out, int B, int N, int D, void* stream);
+MN_API int mn_subtoken_rearrange(const float* y, float* x, int B, int h, int w, int r, int Dp, void* stream);
+MN_API int mn_unpatchify_clamp(const float* o, float* image, int B, int hh, int ww, int p, float lo, float hi, void* stream);
 
 /* fp32 <-> bf16 conversion and hi/lo split helpers (elementwise, n elements). */
 MN_API int mn_f32_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream);

@@ -175,6 +175,10 @@ SYMBOLS = {
     "mn_group_mean_add": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "mn_repeat_add": (_i, [_p, _p, _p, _i, _i, _i, _f, _f, _p]),
     "mn_clamp_f32": (_i, [_p, _i64, _f, _f, _p]),
+    "mn_patchify_operand": (_i, [_p, _i, _i, _i, _i, _p, _i64, _p]),
+    "mn_tokens_assemble": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "mn_subtoken_rearrange": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "mn_unpatchify_clamp": (_i, [_p, _p, _i, _i, _i, _i, _f, _f, _p]),
     "mn_tp_alloc": (_i, [_sz, C.POINTER(C.c_void_p)]),
     "mn_tp_free": (_i, [_p]),
     "mn_tp_ipc_handle": (_i, [_p, _p]),

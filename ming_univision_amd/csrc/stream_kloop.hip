@@ -46,9 +46,10 @@ __device__ __forceinline__ int cslot(int row, int slot) { return row * (CK * 2) 
 // (exact) and parks it at each chunk, full-wave stores into the SAME 64-k bf16 tile the bf16 form uses, and the x pieces are
 // gathered with the matching stride (slot j of chunk 2p + h = k 16 j + 8 h .. + 8 of the piece).  The MFMA loop, the LDS
 // footprint (two workgroups per CU) and the barriers are those of the bf16 form; HBM bytes halve; the row scale multiplies the
-// fp32 accumulators at the partial store.  CK must be 64, D = 4 (two pieces in flight).
+// fp32 accumulators at the partial store.  CK must be 64; D = 4 is the loop's unroll (two pieces in flight per wave), the x ring
+// stays two chunks deep so that the four-row-tile form keeps the bf16 form's register count (two workgroups per CU).
 template <int MT, int NT, int D, int CK, bool W8>
-__global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
+__global__ __launch_bounds__(KW * 64, (W8 && MT == 4 && NT == 2) ? 4 : 1) void stream_kloop_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
                                                                const void* __restrict__ Wv, const float* __restrict__ wscale,
                                                                float* __restrict__ P, int64_t p_slab, int M, int Ntot, int K,
                                                                int nz, KGroups g) {
@@ -77,10 +78,10 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
   const int nch = (K + CK - 1) / CK;
   const int z = blockIdx.y;
   int c0, nc;
-  if constexpr (W8) {                                                 // ranges of whole chunk PAIRS: weight pieces stay line-aligned
-    const int np = (nch + 1) / 2, base = np / nz, rem = np % nz;
+  if constexpr (W8) {                                                 // ranges of whole 128-k PIECES = chunk pairs (a partial last
+    const int np = (K + 127) / 128, base = np / nz, rem = np % nz;    // piece still has both chunks: each covers half of every 16 k)
     c0 = 2 * (z * base + min(z, rem));
-    nc = min(2 * (base + (z < rem ? 1 : 0)), nch - c0);
+    nc = 2 * (base + (z < rem ? 1 : 0));
   } else {
     const int base = nch / nz, rem = nch % nz;
     c0 = z * base + min(z, rem);
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
   constexpr int RPI = 64 / SPR;                                       // rows per instruction (4 x 256 B or 8 x 128 B)
   constexpr int WI = 16 * NT / RPI;
   constexpr int DW = W8 ? D / 2 : D;                                  // ring depth in weight loads
+  constexpr int XD = W8 ? 2 : D;                                      // ring depth of the x chunks
   const bf16_t* wp[WI];
   const uint8_t* wq[WI];
   int wo[WI];
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
     wq[i] = Wq + (int64_t)n * K;
     wo[i] = cslot<CK>(row, lane % SPR);
   }
-  u32x4 xr_[D][XJ], wr_[DW][WI];
+  u32x4 xr_[XD][XJ], wr_[DW][WI];
   auto load_x = [&](u32x4 (&dst)[XJ], int c) {
     // bf16: chunk c = k [(c0 + c) 64, + 64); fp8: piece (c0 + c) / 2 (c0 is even), the lanes' first / second 8 k for even / odd c
     const int k = W8 ? (c0 + (c & ~1)) * CK + (c & 1) * 8 : (c0 + c) * CK;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
   };
   // ---- prologue: D chunks of x and of weights in flight; x chunk 0 becomes visible
 #pragma unroll
-  for (int d = 0; d < D; ++d)
+  for (int d = 0; d < XD; ++d)
     if (d < nc) load_x(xr_[d], d);
   const int nwl = W8 ? (nc + 1) / 2 : nc;                            // weight loads of this K-range
   if (active) {
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
       if (d < nwl) load_w(wr_[d], d);
   }
   store_x(xr_[0], 0);
-  if (D < nc) load_x(xr_[0], D);
+  if (XD < nc) load_x(xr_[0], XD);
   __syncthreads();
 
   f32x4 acc[MT][NT];
@@ -213,9 +215,9 @@ __global__ __launch_bounds__(KW * 64) void stream_kloop_kernel(const bf16_t* __r
         }
         // next x chunk into the other buffer (its last readers passed the previous barrier), ring refilled
         if (c + 1 < nc) {
-          const int dn = (d + 1) % D;
+          const int dn = (d + 1) % XD;
           store_x(xr_[dn], buf ^ 1);
-          if (c + 1 + D < nc) load_x(xr_[dn], c + 1 + D);
+          if (c + 1 + XD < nc) load_x(xr_[dn], c + 1 + XD);
         }
         __syncthreads();
       }
@@ -254,8 +256,7 @@ int kloop_nt(int max_rows) { return g_kl_nt > 0 ? g_kl_nt : (max_rows > 32 ? 2 :
 // number of K-ranges: enough workgroups to fill `slots` CUs-worth of residency, never more ranges than chunks (fp8: chunk pairs)
 int kloop_nz(int Ntot, int K, int slots, int nt, bool w8 = false) {
   const int tb = (int)mn_cdiv(mn_cdiv(Ntot, 16), KW * nt);
-  int nch = (int)mn_cdiv(K, w8 ? 64 : kloop_ck());
-  if (w8) nch = (nch + 1) / 2;
+  const int nch = (int)mn_cdiv(K, w8 ? 128 : kloop_ck());
   if (g_kl_nz > 0) return g_kl_nz < nch ? g_kl_nz : nch;
   int nz = slots / tb;
   if (nz < 1) nz = 1;
@@ -322,15 +323,17 @@ extern "C" MN_DEV_API void mn_stream_kloop_tune(int nz, int depth, int nt) { g_k
 // K-ranges to reduce, and other streams' kernels run beside them (end to end +3 % with three stream groups; a third or a
 // quarter of the chip, or narrowing RF w12 as well, measured worse)
 int g_kl_small_div = 2, g_kl_small_mb = 64;
-int kloop_dense_slots(int Ntot, int K, int wbytes = 2) {
+int kloop_dense_slots(int Ntot, int K) {
   const int cus = mn_num_cus();
-  return ((int64_t)Ntot * K * wbytes < ((int64_t)g_kl_small_mb << 20) && g_kl_small_div > 1) ? cus / g_kl_small_div : cus;
+  return ((int64_t)Ntot * K * 2 < ((int64_t)g_kl_small_mb << 20) && g_kl_small_div > 1) ? cus / g_kl_small_div : cus;
 }
 #ifdef MN_DEV_HOOKS
 extern "C" MN_DEV_API void mn_stream_kloop_tune_small(int div) { g_kl_small_div = div & 15; if (div >> 4) g_kl_small_mb = div >> 4; }
 #endif
 extern "C" int mn_stream_kloop_slices(int M, int Ntot, int K) { return kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K), kloop_nt(M)); }
-extern "C" int mn_stream_kloop_w8_slices(int M, int Ntot, int K) { return kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K, 1), kloop_nt(M), true); }
+// (the half-chip rule counts ELEMENTS: an fp8 matrix of the same shape keeps the bf16 form's share of the chip — with the byte
+// count RF w12 fell under the threshold and ran 34.9 instead of 2x us at 48 rows)
+extern "C" int mn_stream_kloop_w8_slices(int M, int Ntot, int K) { return kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K), kloop_nt(M), true); }
 
 // Dense: Y [2][M][K] bf16 (hi rows then lo rows), W [Ntot][K], P [nz][M][Ntot].  Returns nz (< 0: error).  M <= 64.
 extern "C" int mn_stream_kloop(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream) {
@@ -345,7 +348,7 @@ extern "C" int mn_stream_kloop(const uint16_t* Y, const uint16_t* W, float* P, i
 // Dense on fp8 weights: Wq e4m3 [Ntot][K] (K % 16 == 0), wscale fp32 [Ntot].  nz = mn_stream_kloop_w8_slices(M, Ntot, K).
 extern "C" int mn_stream_kloop_w8(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, void* stream) {
   MN_CHECK_ARG(Y && Wq && wscale && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 16 && (K % 16) == 0, "mn_stream_kloop_w8: bad args");
-  const int nz = kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K, 1), kloop_nt(M), true);
+  const int nz = kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K), kloop_nt(M), true);
   const KGroups g{nullptr, nullptr, 0, 0, 1 << 30, 0};
   kloop_dispatch(1, M, nz, Y, (int64_t)M * K, Wq, wscale, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
   MN_CHECK_LAUNCH("mn_stream_kloop_w8");

@@ -222,19 +222,17 @@ class MingTok:
         P, D = self.patch_size, self.enc_dim
         gh, gw = W // P, H // P
         N = gh * gw
-        # im2col (view/permute only): conv k=s=P == GEMM over (c, ph, pw)  (patch_embed.py:76-78)
-        cols = x.to(self.device, torch.float32).reshape(B, 3, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B * N, 3 * P * P)
+        # conv k = s = P == GEMM over (c, py, px) (patch_embed.py:76-78): ONE pass reads the image and writes the GEMM's bf16 (or
+        # hi / lo) operand; a second one appends the cls token LAST (:221) and adds the position embedding
         wpe = self._w("low_level_encoder.patch_embed.proj.weight").reshape(D, 3 * P * P)
+        cols = ops.patchify_operand(x.to(self.device, torch.float32).contiguous(), P, hilo=fp32)
         if fp32:
-            tok = ops.linear_hilo(ops.split_hilo(cols.contiguous()), wpe, self._w("low_level_encoder.patch_embed.proj.bias"))
+            tok = ops.linear_hilo(cols, wpe, self._w("low_level_encoder.patch_embed.proj.bias"))
         else:
-            tok = ops.gemm_bf16(ops.f32_to_bf16(cols.contiguous()), wpe, self._w("low_level_encoder.patch_embed.proj.bias"), "f32")
-        cls = ops.bf16_to_f32(self._w("low_level_encoder.cls_token").reshape(1, D))
-        xt = torch.cat((tok.reshape(B, N, D), cls.reshape(1, 1, D).expand(B, 1, D)), dim=1).contiguous()  # cls LAST (:221)
+            tok = ops.gemm_bf16(cols, wpe, self._w("low_level_encoder.patch_embed.proj.bias"), "f32")
         T = N + 1
         pe = self._pos_embed(N, W, H)
-        xf = xt.reshape(B * T, D)
-        check(lib().mn_add_bcast_f32(ptr(xf), ptr(pe), ptr(xf), xf.numel(), pe.numel(), current_stream()), "mn_add_bcast_f32")
+        xf = ops.tokens_assemble(tok, self._w("low_level_encoder.cls_token").reshape(D), pe, B, N).reshape(B * T, D)
         # blocks, then forward_out_layer (:173-178) whose LayerNorm + GELU rides the last block's tail
         if fp32:
             self._blocks_fp32(xf, "low_level_encoder.blocks.0", self.enc_depth, D, B, T, False)
@@ -298,8 +296,7 @@ class MingTok:
         else:
             y = ops.gemm_bf16(ops.f32_to_bf16(s32), self._w("sem_to_pix.weight"), self._w("sem_to_pix.bias"), "f32")
         h = w = int(math.sqrt(N))
-        # rearrange "b (h w) (x y c) -> b (h x w y) c" (view/permute only)
-        x = y.reshape(B, h, w, r, r, Dp).permute(0, 1, 3, 2, 4, 5).reshape(B * h * r * w * r, Dp).contiguous()
+        x = ops.subtoken_rearrange(y, B, h, w, r, Dp)           # "b (h w) (x y c) -> b (h x w y) c" in one pass
         T = N * r * r
         if fp32:
             self._blocks_fp32(x, "pixel_decoder.blocks.0", self.pix_depth, Dp, B, T, False)
@@ -311,10 +308,7 @@ class MingTok:
             o = ops.gemm_bf16(xn, self._w("pixel_decoder.head.weight"), self._w("pixel_decoder.head.bias"), "f32")
         p = self.pix_patch
         hh = ww = int(math.sqrt(T))
-        # unpatchify (vision_transformer.py:515-527): 'nhwpqc->nchpwq' (view/permute only)
-        img = o.reshape(B, hh, ww, p, p, 3).permute(0, 5, 1, 3, 2, 4).reshape(B, 3, hh * p, ww * p).contiguous()
-        check(lib().mn_clamp_f32(ptr(img), img.numel(), -1.0, 1.0, current_stream()), "mn_clamp_f32")
-        return img
+        return ops.unpatchify_clamp(o, B, hh, ww, p, -1.0, 1.0)  # 'nhwpqc->nchpwq' (vision_transformer.py:515-527) + clamp_ in one pass
 
     def forward_enc_dec(self, x, precision=None):
         """MingTok.forward_enc_dec (modeling_mingtok.py:150-153)."""

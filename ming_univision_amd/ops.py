@@ -446,3 +446,43 @@ def stream_mfma_w8(y2, q, scale):
         check(rc, "mn_stream_mfma_w8")
     assert rc == nz
     return P.sum(0)
+
+
+# ---- MingTok layout passes (layout_ops.hip) ---------------------------------------------------------------------------------------
+def patchify_operand(image, P, hilo=False):
+    """image fp32 [B,3,Hi,Wi] -> the patch-embed GEMM's A operand: bf16 [B*N, 3P^2], or the hi/lo pair [2, B*N, 3P^2] (hilo)."""
+    _req(image, torch.float32, "image")
+    B, C3, Hi, Wi = image.shape
+    assert C3 == 3 and image.is_contiguous()
+    rows, K = B * (Hi // P) * (Wi // P), 3 * P * P
+    y = torch.empty((2, rows, K) if hilo else (rows, K), dtype=torch.bfloat16, device=image.device)
+    check(lib().mn_patchify_operand(ptr(image), B, Hi, Wi, P, ptr(y), rows * K if hilo else 0, current_stream()), "mn_patchify_operand")
+    return y
+
+
+def tokens_assemble(tok, cls, pos, B, N):
+    """tok fp32 [B*N, D], cls bf16 [D], pos fp32 [N+1, D] -> fp32 [B, N+1, D]: patch tokens, cls LAST, + position embedding."""
+    _req(tok, torch.float32, "tok"); _req(cls, torch.bfloat16, "cls"); _req(pos, torch.float32, "pos")
+    D = tok.shape[1]
+    assert tok.is_contiguous() and pos.is_contiguous() and pos.numel() == (N + 1) * D and cls.numel() == D
+    out = torch.empty(B, N + 1, D, dtype=torch.float32, device=tok.device)
+    check(lib().mn_tokens_assemble(ptr(tok), ptr(cls), ptr(pos), ptr(out), B, N, D, current_stream()), "mn_tokens_assemble")
+    return out
+
+
+def subtoken_rearrange(y, B, h, w, r, Dp):
+    """y fp32 [B*h*w, r*r*Dp] -> fp32 [B*h*r*w*r, Dp] ("b (h w) (x y c) -> b (h x w y) c")."""
+    _req(y, torch.float32, "y")
+    assert y.is_contiguous() and y.numel() == B * h * w * r * r * Dp
+    x = torch.empty(B * h * r * w * r, Dp, dtype=torch.float32, device=y.device)
+    check(lib().mn_subtoken_rearrange(ptr(y), ptr(x), B, h, w, r, Dp, current_stream()), "mn_subtoken_rearrange")
+    return x
+
+
+def unpatchify_clamp(o, B, hh, ww, p, lo=-1.0, hi=1.0):
+    """o fp32 [B*hh*ww, p*p*3] -> image fp32 [B, 3, hh*p, ww*p] clamped to [lo, hi]."""
+    _req(o, torch.float32, "o")
+    assert o.is_contiguous() and o.numel() == B * hh * ww * p * p * 3
+    img = torch.empty(B, 3, hh * p, ww * p, dtype=torch.float32, device=o.device)
+    check(lib().mn_unpatchify_clamp(ptr(o), ptr(img), B, hh, ww, p, float(lo), float(hi), current_stream()), "mn_unpatchify_clamp")
+    return img

@@ -127,38 +127,41 @@ CenterCropProcessor = MingTokCenterCropProcessor
 
 
 def find_all_subsequences(sequence, subsequence):
-    """processing_bailingmm.py:364-372"""
-    n, m = len(sequence), len(subsequence)
-    if m == 0:
+    """Start offsets of every occurrence of `subsequence` (processing_bailingmm.py:364-372)."""
+    seq, sub = list(sequence), list(subsequence)
+    if not sub:
         return []
-    return [i for i in range(n - m + 1) if list(sequence[i:i + m]) == list(subsequence)]
+    return [i for i in range(len(seq) - len(sub) + 1) if seq[i:i + len(sub)] == sub]
+
+
+def last_user_turn(seq, user_tag, assistant_tag):
+    """(start, end, answered): the tokens of the LAST user turn — everything after the final user tag, up to the assistant tag that
+    follows it (answered) or to the end of the sequence.  None when the sequence has no user tag."""
+    users = find_all_subsequences(seq, user_tag)
+    if not users:
+        return None
+    u = users[-1]
+    start = u + len(user_tag)
+    following = [a for a in find_all_subsequences(seq, assistant_tag) if a >= u]
+    if following:
+        return start, max(start, following[0]), True
+    return start, len(seq), False
 
 
 def cfg_attention_masks(seq, user_prefix_ids, assistant_prefix_ids, image_token_ids):
-    """The uncond / text-uncond masks of BailingMMProcessor.tokenize (processing_bailingmm.py:304-352)
-    for ONE id sequence.  uncond: zero everything between the last HUMAN tag and the next ASSISTANT tag;
-    text-uncond: zero the same span except image tokens (and to the end when no ASSISTANT tag follows)."""
+    """The two classifier-free-guidance masks BailingMMProcessor.tokenize derives from ONE id sequence
+    (processing_bailingmm.py:304-352), expressed on the last user turn:
+      uncond       hides the whole turn — but only when an assistant tag closes it;
+      text-uncond  hides the turn's text and keeps its image tokens (`<image>`, `<imagePatch>`, `</image>`), closed or not."""
     seq = list(seq)
-    user_positions = find_all_subsequences(seq, user_prefix_ids)
-    assistant_positions = find_all_subsequences(seq, assistant_prefix_ids)
-    mask = [1] * len(seq)
-    text_mask = [1] * len(seq)
-    if user_positions:
-        last_user_start = user_positions[-1]
-        next_assistant_start = None
-        for pos in assistant_positions:
-            if pos >= last_user_start:
-                next_assistant_start = pos
-                break
-        start = last_user_start + len(user_prefix_ids)
-        if next_assistant_start is not None:
-            for i in range(start, next_assistant_start):
-                mask[i] = 0
-        end = next_assistant_start if next_assistant_start is not None else len(seq)
-        for i in range(start, end):
-            if seq[i] not in image_token_ids:
-                text_mask[i] = 0
-    return mask, text_mask
+    uncond, text_uncond = [1] * len(seq), [1] * len(seq)
+    turn = last_user_turn(seq, list(user_prefix_ids), list(assistant_prefix_ids))
+    if turn is not None:
+        start, end, answered = turn
+        if answered:
+            uncond[start:end] = [0] * (end - start)
+        text_uncond[start:end] = [int(t in image_token_ids) for t in seq[start:end]]
+    return uncond, text_uncond
 
 
 class BatchFeature(dict):
@@ -186,29 +189,39 @@ class BailingMMProcessor:
     def apply_system_template(self, text):
         return USER_PREFIX
 
+    @staticmethod
+    def _message_body(message):
+        """Text of one message: its text items in order; an image item contributes `<IMAGE>` placeholders for the images the
+        message's own text does not already mark with a literal `<image>` (the reference counts those on str(content), :392)."""
+        marked = str(message["content"]).count("<image>")
+        pieces = []
+        for item in message["content"]:
+            kind = item["type"]
+            if kind == "text":
+                pieces.append(item["text"])
+            elif kind == "image":
+                n = len(item["image"]) if isinstance(item["image"], (list, tuple)) else 1
+                if n > marked:
+                    pieces.append("\n".join(["<IMAGE>"] * (n - marked)))
+            elif kind in ("video", "audio"):
+                raise NotImplementedError("video/audio inputs are outside the MingTok hot path")
+        return "".join(pieces)
+
     def apply_chat_template(self, conversation, system_template=None, **kwargs):
-        text = ""
+        """GLM-style packing (processing_bailingmm.py:377-437): the system template (= the first HUMAN tag) opens the text, a HUMAN
+        turn is its bare body, an ASSISTANT turn is tag + body + `<|endoftext|>` + the next HUMAN tag; the generation prompt is a
+        trailing ASSISTANT tag."""
+        turns = []
         for message in conversation:
-            assert message["role"] in ["HUMAN", "ASSISTANT"]
-            if message["role"] == "ASSISTANT":
-                text += ASSISTANT_PREFIX
-            image_counts = str(message["content"]).count("<image>")
-            for content in message["content"]:
-                if content["type"] == "image":
-                    num_images = 1 if not isinstance(content["image"], (list, tuple)) else len(content["image"])
-                    if image_counts < num_images:
-                        text += ("<IMAGE>\n" * (num_images - image_counts)).rstrip("\n")
-                elif content["type"] == "text":
-                    text += content["text"]
-                elif content["type"] in ("video", "audio"):
-                    raise NotImplementedError("video/audio inputs are outside the MingTok hot path")
-            if message["role"] == "ASSISTANT":
-                text += "<|endoftext|>"
-                text += USER_PREFIX
+            role = message["role"]
+            assert role in ("HUMAN", "ASSISTANT")
+            body = self._message_body(message)
+            turns.append(ASSISTANT_PREFIX + body + "<|endoftext|>" + USER_PREFIX if role == "ASSISTANT" else body)
         if kwargs.get("add_generation_prompt", True):
-            text += ASSISTANT_PREFIX
-        sys_prompt = system_template if system_template is not None else self.apply_system_template(text)
-        return sys_prompt + text
+            turns.append(ASSISTANT_PREFIX)
+        text = "".join(turns)
+        head = system_template if system_template is not None else self.apply_system_template(text)
+        return head + text
 
     def process_vision_info(self, conversations):
         """Collect PIL images of a conversation (image part of bailingmm_utils.process_vision_info:503-539)."""
@@ -225,16 +238,16 @@ class BailingMMProcessor:
 
     # -- <IMAGE> expansion (processing_bailingmm.py:445-464) ------------------------------------
     def _expand_image_tokens(self, text, image_grid_thw, special_token="<IMAGE>"):
-        out, image_index = [], 0
-        num_query_token = torch.prod(torch.as_tensor(image_grid_thw), dim=1)
+        """Every `<IMAGE>` placeholder, in order over all samples, becomes `<image>` + one `<imagePatch>` per patch of the
+        corresponding grid (t * h * w) + `</image>` + newline."""
+        patches = iter(int(n) for n in torch.as_tensor(image_grid_thw).prod(dim=1))
+
+        def block():
+            return DEFAULT_IM_START_TOKEN + DEFAULT_IMAGE_PATCH_TOKEN * next(patches) + DEFAULT_IM_END_TOKEN + "\n"
+        out = []
         for sample in text:
-            num_images = sample.count(special_token)
-            for i in range(image_index, num_images + image_index):
-                img_text = (DEFAULT_IM_START_TOKEN + int(num_query_token[i]) * DEFAULT_IMAGE_PATCH_TOKEN
-                            + DEFAULT_IM_END_TOKEN + "\n")
-                sample = sample.replace(special_token, img_text, 1)
-            image_index += num_images
-            out.append(sample)
+            head, *rest = sample.split(special_token)
+            out.append(head + "".join(block() + part for part in rest))
         return out
 
     # -- tokenise + CFG masks (processing_bailingmm.py:282-361) ---------------------------------

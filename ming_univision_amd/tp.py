@@ -502,6 +502,15 @@ class _TpDecoderBase:
         return torch.cat(outs, 0)
 
 
+    # the wrapper's long-prompt entry points (MingUniVisionForConditionalGeneration.generate): a TP group prefills long prompts in
+    # passes of max_rows() rows through the same sharded step — fp32-class numerics (hi/lo operands) at every row count
+    def prefill_wide(self, embeds, seq=0, past=0, image_mask=None):
+        return self.prefill(embeds, seq=seq, past=past, image_mask=image_mask)
+
+    def prefill_mfma(self, embeds, seq=0, past=0, image_mask=None):
+        return self.prefill(embeds, seq=seq, past=past, image_mask=image_mask)[-1:]
+
+
 class TpSimGroup(_TpDecoderBase):
     """All `world` ranks of a TP group in one process on one GPU: every shard has its own weights, KV arena, workspace and
     communicator; a composite runs segment k on every rank before segment k + 1 on any (one stream), so each all-reduce's pushes

@@ -526,3 +526,31 @@ def test_gemm256_race_screen(ops):
     assert rel(o0, big.double().cpu() @ wbf.double().T) < 1e-5
     for it in range(20):
         assert torch.equal(ops.gemm256(big, wb, None, "f32"), o0), it
+
+
+def test_mingtok_layout_passes_match_the_views_they_replace():
+    """layout_ops.hip: im2col + cast / split, cls append + pos-embed add, the sub-token rearrange and unpatchify + clamp are bit-identical
+    to the reshape / permute / copy formulations of the reference (patch_embed.py:76-78, vision_transformer.py:218-223, 515-527;
+    modeling_mingtok.py:184-188, 195)."""
+    from ming_univision_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for B, Hi, Wi, P in ((2, 64, 96, 32), (3, 256, 256, 32), (1, 32, 32, 16)):
+        x = (torch.rand(B, 3, Hi, Wi, generator=g) * 2 - 1).cuda()
+        gh, gw = Hi // P, Wi // P
+        cols = x.reshape(B, 3, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, 3 * P * P).contiguous()
+        assert torch.equal(ops.patchify_operand(x, P), ops.f32_to_bf16(cols))
+        assert torch.equal(ops.patchify_operand(x, P, hilo=True), ops.split_hilo(cols))
+    B, N, D = 3, 64, 768
+    tok = torch.randn(B * N, D, generator=g).cuda()
+    cls = torch.randn(D, generator=g).to(torch.bfloat16).cuda()
+    pos = torch.randn(N + 1, D, generator=g).cuda()
+    want = torch.cat((tok.reshape(B, N, D), cls.float().reshape(1, 1, D).expand(B, 1, D)), 1) + pos.unsqueeze(0)
+    assert torch.equal(ops.tokens_assemble(tok, cls, pos, B, N), want)
+    B, h, w, r, Dp = 2, 4, 4, 2, 1024
+    y = torch.randn(B * h * w, r * r * Dp, generator=g).cuda()
+    want = y.reshape(B, h, w, r, r, Dp).permute(0, 1, 3, 2, 4, 5).reshape(B * h * r * w * r, Dp).contiguous()
+    assert torch.equal(ops.subtoken_rearrange(y, B, h, w, r, Dp), want)
+    B, hh, ww, p = 2, 8, 8, 16
+    o = (torch.randn(B * hh * ww, p * p * 3, generator=g) * 0.8).cuda()
+    want = o.reshape(B, hh, ww, p, p, 3).permute(0, 5, 1, 3, 2, 4).reshape(B, 3, hh * p, ww * p).clamp(-1.0, 1.0).contiguous()
+    assert torch.equal(ops.unpatchify_clamp(o, B, hh, ww, p), want)

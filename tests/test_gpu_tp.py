@@ -518,3 +518,98 @@ def test_bench_two_ranks_on_one_gpu(mode):
     else:
         assert res["scaling"] == "weak" and res["config"]["parallelism"] == "replicas x2"
         assert abs(res["value"] - 2 * 16 * 2 / (res["ms_per_step"] / 1e3)) < 1e-6 * res["value"]      # both replicas' images
+
+
+@pytest.mark.parametrize("past_mode", ["KEEP", "DROP"])
+def test_tp8_multi_round_edit_text_image_vs_oracle(past_mode, tmp_path, monkeypatch):
+    """BASELINE configs[4]'s workload under TP = 8 + EP = 8 (all shards on this GPU), full width (2 LLM layers, full RF head, full
+    MingTok): round 1 EDITS — an input image (512 x 512 -> 256 `<imagePatch>` tokens through MingTok + linear_proj, image-gate rows
+    in the sharded prefill) plus an instruction, processor-style masks -> THREE CFG rows -> image out; round 2 is text on top of
+    the cache; round 3 asks for a SECOND image with its own holes, its CFG rows built from the masks the PAST_MODE policy carried
+    over (modeling_bailingmm.py:229-234, 273-299; KEEP keeps round 1's holes, DROP replaces them by the cond mask).  Every round
+    against the oracle driven the same way (tests/util.OracleConversation): image latents / semantic tokens / last hidden states
+    <= 1e-3, greedy tokens equal."""
+    from oracle import bailing_ref
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder
+    from ming_univision_amd.mingtok import MingTok
+    from ming_univision_amd.modeling import MingUniVisionForConditionalGeneration
+    from ming_univision_amd.processing import cfg_attention_masks
+    from ming_univision_amd.rf_head import RectifiedFlowHead
+    from ming_univision_amd.tp import TpSimGroup
+    from tests.util import OracleConversation
+    monkeypatch.setenv("PAST_MODE", past_mode)
+    seed = 31
+    d = C.BailingMoeConfig.ming_univision_16b_a3b().to_dict()
+    d.pop("model_type", None)
+    d.update(num_hidden_layers=2, vocab_size=1024, num_image_tokens_for_gen=4, image_start_token=1000, image_patch_token=1001,
+             pad_token_id=0, eos_token_id=1)
+    rf_cfg = dict(C.DEFAULT_VISHEAD_DIFFLOSS)
+    tcfg = C.MingTokConfig()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    sd = llm_sd(d, rf_cfg, seed)
+    tsd = synth_state_dict(C.mingtok_param_shapes(tcfg), seed)
+    lsd = synth_state_dict(C.linear_proj_param_shapes(1024, d["hidden_size"], 2), seed)
+    sd_r, tsd_r, lsd_r = ({k: v.to(torch.bfloat16).float() for k, v in x.items()} for x in (sd, tsd, lsd))
+    ocfg = bailing_ref.LLMConfig(**{k: v for k, v in d.items() if k in bailing_ref.LLMConfig.__dataclass_fields__})
+    cfg = C.BailingMoeConfig(**d)
+    dsd, dl = _dev(sd), _dev(lsd)
+    dec = BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=320, n_seq=3)
+    rf = RectifiedFlowHead(dsd, cfg.hidden_size, rf_cfg)
+    lp = [(dl["linear_proj.0.weight"], dl["linear_proj.0.bias"]), (dl["linear_proj.2.weight"], dl["linear_proj.2.bias"])]
+    tok = MingTok(tcfg, state_dict=tsd, device="cuda", seed=seed, linear_proj=lp)
+    grp = TpSimGroup(dec, rf, 8, rows_cap=128)                       # the 275-token prompt prefills in 128-row sharded passes
+    mcfg = C.MingUniVisionConfig(mlp_depth=2, llm_config=d, vishead_diffloss_config=rf_cfg)
+    model = MingUniVisionForConditionalGeneration.from_parts(mcfg, tok, grp, grp.sampler(), lp, seed=seed)
+    ROLE, ROLE_E, HUMAN, ASSIST, IMG, IMG_E, PATCH = 990, 991, 300, 301, 996, 997, 1001
+    gen = torch.Generator().manual_seed(12)
+    px = torch.rand(1, 3, 512, 512, generator=gen) * 2 - 1
+    ids1 = [ROLE, HUMAN, ROLE_E, IMG] + [PATCH] * 256 + [IMG_E] + torch.randint(2, 900, (11,), generator=gen).tolist() + [ROLE, ASSIST, ROLE_E]
+    unc1, tunc1 = cfg_attention_masks(ids1, [ROLE, HUMAN, ROLE_E], [ROLE, ASSIST, ROLE_E], {IMG, IMG_E, PATCH})
+    assert unc1 != tunc1
+    ids2 = [ROLE, HUMAN, ROLE_E] + torch.randint(2, 900, (5,), generator=gen).tolist() + [ROLE, ASSIST, ROLE_E]
+    ids3 = [ROLE, HUMAN, ROLE_E] + torch.randint(2, 900, (7,), generator=gen).tolist() + [ROLE, ASSIST, ROLE_E]
+    unc3, tunc3 = cfg_attention_masks(ids3, [ROLE, HUMAN, ROLE_E], [ROLE, ASSIST, ROLE_E], {IMG, IMG_E, PATCH})
+    n_tok = d["num_image_tokens_for_gen"]
+    # the noise generate() will draw for an image (torch.randn on its generator, diff_loss_rf_swiglu.py:117-122) is replayed for the oracle
+    noises = []
+    for sd_ in (123, 456):
+        model.noise_generator.manual_seed(sd_)
+        noises.append(torch.randn(n_tok + 1, 32, generator=model.noise_generator, device="cuda").cpu())
+    t = lambda v: torch.tensor([v])
+    # ---- oracle conversation
+    oc = OracleConversation(sd_r, lsd_r, tsd_r, ocfg, steps=int(rf_cfg["num_sampling_steps"]), past_mode=past_mode, eos_token_id=1)
+    o1 = oc.round(t(ids1), t(unc1), t(tunc1), pixel_values=px, patch_id=PATCH, max_new_tokens=2, forced_first_token=1000, noises=noises[:1])
+    o2 = oc.round(t(ids2), max_new_tokens=3)
+    o3 = oc.round(t(ids3), t(unc3), t(tunc3), max_new_tokens=2, forced_first_token=1000, noises=noises[1:])
+    assert o1["images"][0]["last_hidden"].shape[0] == 3 and len(o3["images"]) == 1
+
+    # ---- the TP group through the facade
+    def run_round(ids, unc=None, tunc=None, noise_seed=None, **kw):
+        if noise_seed is not None:
+            model.noise_generator.manual_seed(noise_seed)
+        return model.generate(input_ids=t(ids), attention_mask=torch.ones(1, len(ids), dtype=torch.long),
+                              uncond_attention_mask=None if unc is None else t(unc),
+                              text_uncond_attention_mask=None if tunc is None else t(tunc), **kw)
+    s1 = run_round(ids1, unc1, tunc1, 123, pixel_values=px, max_new_tokens=2, forced_first_token=1000,
+                   output_image_prefix=str(tmp_path / "r1"))
+    g1 = model.last_generation
+    r1 = o1["images"][0]
+    e1 = (rel_err(g1["latents"], r1["latents"][:, 0]), rel_err(g1["sem"], r1["sem"][0]), rel_err(g1["last_hidden"], r1["last_hidden"][:, 0]))
+    print("TP = 8 %s round 1 (edit: image in, 3 CFG rows, image out) vs oracle: latents %.2e sem %.2e hidden %.2e" % ((past_mode,) + e1))
+    assert g1["last_hidden"].shape[0] == 3 and max(e1) < TOL, e1
+    assert s1[0, len(ids1):].tolist() == o1["tokens"]
+    s2 = run_round(ids2, max_new_tokens=3)
+    assert s2[0, len(ids2):].tolist() == o2["tokens"], (s2[0, len(ids2):].tolist(), o2["tokens"])
+    s3 = run_round(ids3, unc3, tunc3, 456, max_new_tokens=2, forced_first_token=1000, output_image_prefix=str(tmp_path / "r3"))
+    g3 = model.last_generation
+    r3 = o3["images"][0]
+    assert g3["last_hidden"].shape[0] == r3["last_hidden"].shape[0]
+    e3 = (rel_err(g3["latents"], r3["latents"][:, 0]), rel_err(g3["sem"], r3["sem"][0]), rel_err(g3["last_hidden"], r3["last_hidden"][:, 0]))
+    print("TP = 8 %s round 3 (second image on the carried-over cache + masks, %d CFG rows) vs oracle: latents %.2e sem %.2e hidden %.2e"
+          % ((past_mode, g3["last_hidden"].shape[0]) + e3))
+    assert max(e3) < TOL, e3
+    assert s3[0, len(ids3):].tolist() == o3["tokens"]
+    assert model.past_len == oc.cache_len
+    for a, b in zip((model.past_attention_mask, model.past_uncond_attention_mask, model.past_text_uncond_attention_mask), oc.past):
+        assert torch.equal(a, b)
+    grp.check_err()

@@ -40,3 +40,73 @@ def llm_sd(llm_dict, rf_dict, seed, device="cpu", dtype=torch.float32):
 def rel_err(a, b):
     a, b = a.double().cpu(), b.double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+class OracleConversation:
+    """The reference's multi-round flow (MingUniVisionForConditionalGeneration.generate, modeling_bailingmm.py:206-301, over
+    BailingMoeForCausalLM.forward's `<image>` branch, modeling_bailing_moe.py:1769-1796) driven with the oracle's pieces: one KV
+    cache and three attention masks carried from round to round (PAST_MODE KEEP / DROP, :273-299), greedy text tokens, an image
+    whenever `<image>` is emitted (or forced as the first token).  Test infrastructure."""
+
+    def __init__(self, sd, lsd, tsd, ocfg, steps, past_mode="DROP", eos_token_id=None):
+        from oracle import bailing_ref, mingtok_ref
+        self.B, self.M = bailing_ref, mingtok_ref
+        self.sd, self.lsd, self.tsd, self.cfg, self.steps, self.mode, self.eos = sd, lsd, tsd, ocfg, steps, past_mode, eos_token_id
+        self.kvs = bailing_ref.new_kv(ocfg)
+        self.past = None                     # (am, unc, tunc) of the rounds so far
+        self.cache_len = 0
+
+    def _emb(self, ids):
+        return self.sd["model.word_embeddings.weight"][ids]
+
+    def round(self, ids, unc=None, tunc=None, pixel_values=None, patch_id=None, max_new_tokens=2, forced_first_token=None, noises=None):
+        """ids [1, T]; unc / tunc [1, T] (default: ones).  Returns dict(tokens, images=[generate_image results], prompt_hidden)."""
+        B, cfg = self.B, self.cfg
+        T = ids.shape[1]
+        am = torch.ones(1, T, dtype=torch.long)
+        unc = am.clone() if unc is None else unc
+        tunc = am.clone() if tunc is None else tunc
+        if self.past is not None:
+            am, unc, tunc = (torch.cat((p, m), 1) for p, m in zip(self.past, (am, unc, tunc)))
+        prompt_mask_len = am.shape[1]
+        emb = self._emb(ids).clone()
+        image_mask = None
+        if pixel_values is not None:
+            feat = self.M.mingtok_forward(pixel_values, self.tsd)["x_norm_patchtokens"]
+            image_mask = ids == patch_id
+            emb[image_mask] = B.linear_proj(feat.float(), self.lsd).reshape(-1, cfg.hidden_size)
+        h = B.model_forward(emb, self.sd, cfg, None, None, self.kvs, image_mask=image_mask)[:, -1:]
+        prompt_hidden = h[:, 0]
+        cache_len = self.cache_len + T
+        toks, images = [], []
+        one = torch.ones(1, 1, dtype=torch.long)
+        while len(toks) < max_new_tokens:
+            tok = int(B.lm_logits(h, self.sd).argmax())
+            if not toks and forced_first_token is not None:
+                tok = int(forced_first_token)
+            toks.append(tok)
+            if tok == self.eos or len(toks) == max_new_tokens:
+                break                                                   # the call's last token is never fed
+            if tok == cfg.image_start_token:
+                if am.shape[1] < cache_len:
+                    am = torch.cat((am, torch.ones(1, cache_len - am.shape[1], dtype=torch.long)), 1)
+                caches = self.M.semdec_new_cache(self.tsd)
+                out = B.generate_image(self._emb(torch.tensor([[tok]])), self.kvs, torch.cat((am, one), 1), unc, tunc, self.sd, cfg,
+                                       noises[len(images)],
+                                       latent_to_sem=lambda lat: self.M.mingtok_feature_decoder_step(lat, self.tsd, caches),
+                                       linear_proj=lambda s_: B.linear_proj(s_, self.lsd), sem_to_pix=lambda s_: None, steps=self.steps)
+                images.append(out)
+                cache_len += 1 + cfg.num_image_tokens_for_gen
+                h = out["last_hidden"][0:1, -1:]
+                continue
+            h = B.model_forward(self._emb(torch.tensor([[tok]])), self.sd, cfg, None, None, self.kvs)[:, -1:]
+            cache_len += 1
+        self.cache_len = cache_len
+        am0, unc0, tunc0 = am[:, :prompt_mask_len], unc, tunc
+        pad1 = torch.ones(1, cache_len - prompt_mask_len, dtype=torch.long)
+        pad0 = torch.zeros(1, cache_len - prompt_mask_len, dtype=torch.long)
+        if self.mode == "KEEP":
+            self.past = (torch.cat((am0, pad1), 1), torch.cat((unc0, pad0), 1), torch.cat((tunc0, pad1), 1))
+        else:
+            self.past = (torch.cat((am0, pad1), 1), torch.cat((am0, pad0), 1), torch.cat((am0, pad1), 1))
+        return dict(tokens=toks, images=images, prompt_hidden=prompt_hidden)

@@ -5,10 +5,10 @@ set -euo pipefail
 : "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}"
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-TAG=${1:-r03}
+TAG=${1:-r04}
 D=/tmp/prof_$TAG
 rm -rf "$D"; mkdir -p "$D" gpurun_out
-rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batch1 > gpurun_out/${TAG}_bench_line_under_rocprof.json 2> gpurun_out/${TAG}_bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batch1 --no-other-configs > gpurun_out/${TAG}_bench_line_under_rocprof.json 2> gpurun_out/${TAG}_bench_under_rocprof.err
 TRACE=$(find "$D" -name "*kernel_trace.csv" | head -1)
 STATS=$(find "$D" -name "*kernel_stats.csv" | head -1)
 cp "$STATS" gpurun_out/${TAG}_bench_default_kernel_stats.csv
