@@ -104,10 +104,12 @@ typedef struct mn_skinny_args {
    * split into bf16 hi + lo) -> weight-streaming MFMA kernel over K slices -> reduce + epilogue, and need
    * mn_skinny_workspace_bytes(M, N, K, epilogue) bytes.  May be NULL for M <= 8 (fp32-FMA kernel is used). */
   void* ws; size_t ws_bytes;
-  /* fp8 weights (section 7): wfmt = MN_W_FP8_E4M3 -> `w` points to e4m3 bytes [N or 2N, K] (ldw == K, K % 16 == 0) and wscale to one
-   * fp32 scale per weight row.  Every row count (1..64) then takes the matrix-core route: ws is required
-   * (mn_skinny_workspace_bytes_w8), batch / nseg forms are not available. */
-  int32_t wfmt; const float* wscale;
+  /* fp8 weights (section 7): wfmt = MN_W_FP8_E4M3 -> `w` points to e4m3 bytes [N or 2N, K] (K % 16 == 0; strides count bytes) and
+   * wscale to one fp32 scale per weight row.  M == 1 with prologue NONE and epilogue NONE / SWIGLU / RESID — the expert launches of a
+   * 1- or 2-row decode step, batch and K-segment forms included — runs the one-row fp8 kernel (skinny_w8.hip): batch entry b reads its
+   * scales at wscale + w_index[b] * wscale_batch_stride, segment s at + seg_index[s] * wscale_seg_stride.  Everything else (1..64
+   * rows, dense weights with ldw == K, no batch / segments) takes the matrix-core route and needs ws (mn_skinny_workspace_bytes_w8). */
+  int32_t wfmt; const float* wscale; int64_t wscale_batch_stride; int64_t wscale_seg_stride;
 } mn_skinny_args;
 
 /* 1 <= M <= 64 (batch / nseg forms: M <= 8). */

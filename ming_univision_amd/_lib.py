@@ -36,7 +36,7 @@ class SkinnyArgs(C.Structure):
         ("res_batch_stride", C.c_int64),
         ("nseg", C.c_int32), ("seg_index", C.c_void_p), ("seg_scale", C.c_void_p), ("seg_w_stride", C.c_int64),
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
-        ("wfmt", C.c_int32), ("wscale", C.c_void_p),
+        ("wfmt", C.c_int32), ("wscale", C.c_void_p), ("wscale_batch_stride", C.c_int64), ("wscale_seg_stride", C.c_int64),
     ]
 
 

@@ -726,7 +726,7 @@ static size_t moe_carve(Carver& cv, int rows, int H, int I, int G, int n_slot, M
 // grouped-expert route from 3 rows (3 rows: 74.2 vs 70.6 tokens/s against the fp32-FMA pair kernels; 2 rows: 75.1 vs 76.8)
 constexpr int MOE_MFMA_MIN_ROWS = 3;
 static bool moe_mfma_ok(const mn_llm* m, int rows) {
-  return (rows >= MOE_MFMA_MIN_ROWS || m->wfmt) && rows * (m->top_k + m->n_shared_slots) <= 1024 &&
+  return rows >= MOE_MFMA_MIN_ROWS && rows * (m->top_k + m->n_shared_slots) <= 1024 &&
          m->n_experts + m->n_shared_slots <= 256 && (m->hidden % 8) == 0 && (m->moe_inter % 8) == 0;   // % 4: vector glue
 }
 
@@ -870,9 +870,9 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
                "mn_llm_step: null pointer");
   MN_CHECK_ARG(M >= 1 && (M <= 64 || llm_wide_ok(m, M)) && x_row_div >= 1,
                "mn_llm_step: M=%d (1..64, or up to 2048 rows with 64-aligned widths)", M);
-  // fp8 experts: every row count runs the grouped streaming kernels (the fp32-FMA pair kernels read bf16 rows)
+  // fp8 experts: 1 or 2 rows run the one-row fp8 kernel on the (row, expert) pairs, more the grouped streaming kernels
   MN_CHECK_ARG(m->wfmt == MN_W_BF16 || (m->wfmt == MN_W_FP8_E4M3 && m->w_gate_up_scale && m->w_down_scale && (m->hidden % 16) == 0 &&
-                                        (m->moe_inter % 16) == 0 && M <= 64 && moe_mfma_ok(m, M)),
+                                        (m->moe_inter % 16) == 0 && M <= 64 && (M < MOE_MFMA_MIN_ROWS || moe_mfma_ok(m, M))),
                "mn_llm_step: fp8 experts need row scales, widths %% 16 == 0 and <= 64 rows (M = %d)", M);
   if (llm_wide_ok(m, M))
     return llm_step_wide(m, x, ldx, x_row_div, M, image_mask, row_seq, row_slot, row_pos, row_len, key_mask, ld_mask, kv_cache, n_seq, t_max,
@@ -938,12 +938,14 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
         a.epilogue = MN_EPI_SWIGLU;
         a.batch = M * n_slot; a.w_index = w.ti; a.w_batch_stride = (int64_t)2 * I * H;
         a.x_batch_stride = H; a.x_batch_div = n_slot; a.out_batch_stride = I;
+        if (m->wfmt) { a.wfmt = m->wfmt; a.wscale = m->w_gate_up_scale[l]; a.wscale_batch_stride = 2 * I; a.ws = nullptr; }
         MN_TRY(mn_skinny_gemm(&a, stream));
         a = sk(w.hmid, (int64_t)n_slot * I, m->w_down[l], I, nullptr, w.h, H, 1, H, I);
         a.epilogue = MN_EPI_RESID; a.res = w.h; a.ldres = H; a.res_batch_stride = H;
         a.batch = M; a.w_index = nullptr; a.w_batch_stride = 0;
         a.x_batch_stride = (int64_t)n_slot * I; a.x_batch_div = 1; a.out_batch_stride = H;
         a.nseg = n_slot; a.seg_index = w.ti; a.seg_scale = w.tw; a.seg_w_stride = (int64_t)H * I;
+        if (m->wfmt) { a.wfmt = m->wfmt; a.wscale = m->w_down_scale[l]; a.wscale_seg_stride = H; a.ws = nullptr; }
         MN_TRY(mn_skinny_gemm(&a, stream));
       }
     }
@@ -992,12 +994,14 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
     a.epilogue = MN_EPI_SWIGLU;
     a.batch = M * n_slot; a.w_index = w.ti; a.w_batch_stride = (int64_t)2 * I * H;
     a.x_batch_stride = H; a.x_batch_div = n_slot; a.out_batch_stride = I;
+    if (m->wfmt) { a.wfmt = m->wfmt; a.wscale = m->w_gate_up_scale[l]; a.wscale_batch_stride = 2 * I; a.ws = nullptr; }
     MN_TRY(mn_skinny_gemm(&a, stream));
     a = sk(w.hmid, (int64_t)n_slot * I, m->w_down[l], I, nullptr, w.h, H, 1, H, I);
     a.epilogue = MN_EPI_RESID; a.res = w.h; a.ldres = H; a.res_batch_stride = H;
     a.batch = M; a.w_index = nullptr; a.w_batch_stride = 0;
     a.x_batch_stride = (int64_t)n_slot * I; a.x_batch_div = 1; a.out_batch_stride = H;
     a.nseg = n_slot; a.seg_index = w.ti; a.seg_scale = w.tw; a.seg_w_stride = (int64_t)H * I;
+    if (m->wfmt) { a.wfmt = m->wfmt; a.wscale = m->w_down_scale[l]; a.wscale_seg_stride = H; a.ws = nullptr; }
     MN_TRY(mn_skinny_gemm(&a, stream));
   }
   hipLaunchKernelGGL(rmsnorm_f32_kernel, dim3(M), dim3(256), 0, st, w.h, (int64_t)H, m->final_norm, m->rms_eps,

@@ -213,6 +213,7 @@ extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, in
 extern "C" int mn_stream_mfma_slices(int M, int Ntot, int K);
 extern "C" int mn_stream_mfma_w8(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, void* stream);
 extern "C" int mn_stream_mfma_w8_slices(int M, int Ntot, int K);
+extern "C" int mn_skinny_w8_row(const mn_skinny_args* args, void* stream);      // skinny_w8.hip
 
 namespace {
 
@@ -349,7 +350,14 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   ka.nseg = a.nseg > 0 ? a.nseg : 1;
   ka.batch = a.batch > 0 ? a.batch : 1;
   MN_CHECK_ARG(a.wfmt == MN_W_BF16 || a.wfmt == MN_W_FP8_E4M3, "mn_skinny_gemm: bad wfmt %d", a.wfmt);
-  if (a.wfmt == MN_W_FP8_E4M3) return skinny_medium(a, stream);     // checks dense weights / no batch forms / workspace
+  if (a.wfmt == MN_W_FP8_E4M3) {
+    // one row per batch entry with a plain prologue: the one-row fp8 kernel (expert pair launches, batch / segment forms included);
+    // everything else: the matrix-core route (checks dense weights / no batch forms / workspace)
+    const bool row_form = a.M == 1 && a.prologue == MN_PRO_NONE &&
+                          (a.epilogue == MN_EPI_NONE || a.epilogue == MN_EPI_SWIGLU || a.epilogue == MN_EPI_RESID);
+    if (row_form && (ka.batch > 1 || ka.nseg > 1 || a.ws == nullptr)) return mn_skinny_w8_row(&a, stream);
+    return skinny_medium(a, stream);
+  }
   if (a.M >= MEDIUM_MIN_M && ka.batch == 1 && ka.nseg == 1 && a.ldw == a.K && a.ws != nullptr) return skinny_medium(a, stream);
   MN_CHECK_ARG(a.M <= 8, "mn_skinny_gemm: M=%d > 8 needs the workspace route (ws, dense weights, no batch/nseg)", a.M);
   MN_CHECK_ARG(ka.nseg == 1 || a.prologue <= MN_PRO_ADD_SILU, "mn_skinny_gemm: normalising prologue with segments");

@@ -92,9 +92,10 @@ def moe_router(x, norm_w, eps, gate_w, image_gate_w, image_mask, top_k, norm_top
     return xn, idx, w
 
 
-def moe_experts(xn, idx, w, w_gate_up, w_down, res):
+def moe_experts(xn, idx, w, w_gate_up, w_down, res, gate_up_scale=None, down_scale=None):
     """Grouped expert MLPs of one MoE layer for M rows: returns res + sum_slot w * down(silu(gate x) * up x).
-    w_gate_up bf16 [E', 2I, H], w_down bf16 [E', H, I]; idx/w [M, n_slot] from moe_router."""
+    w_gate_up bf16 [E', 2I, H], w_down bf16 [E', H, I]; idx/w [M, n_slot] from moe_router.
+    fp8 weight mode: w_gate_up / w_down uint8 (e4m3) with gate_up_scale fp32 [E', 2I] and down_scale fp32 [E', H]."""
     M, H = xn.shape
     n_slot = idx.shape[1]
     I = w_down.shape[2]
@@ -105,6 +106,8 @@ def moe_experts(xn, idx, w, w_gate_up, w_down, res):
     a.epilogue = EPI["swiglu"]
     a.batch, a.w_index, a.w_batch_stride = M * n_slot, ptr(idx), 2 * I * H
     a.x_batch_stride, a.x_batch_div, a.out_batch_stride = H, n_slot, I
+    if gate_up_scale is not None:
+        a.wfmt, a.wscale, a.wscale_batch_stride = _lib.W_FP8_E4M3, ptr(gate_up_scale), 2 * I
     check(lib().mn_skinny_gemm(C.byref(a), current_stream()), "mn_skinny_gemm(moe gate_up)")
     out = torch.empty(M, H, dtype=torch.float32, device=xn.device)
     b = SkinnyArgs()
@@ -114,6 +117,8 @@ def moe_experts(xn, idx, w, w_gate_up, w_down, res):
     b.res, b.ldres, b.res_batch_stride = ptr(res), res.stride(0), res.stride(0)
     b.batch, b.x_batch_stride, b.x_batch_div, b.out_batch_stride = M, n_slot * I, 1, H
     b.nseg, b.seg_index, b.seg_scale, b.seg_w_stride = n_slot, ptr(idx), ptr(w), H * I
+    if down_scale is not None:
+        b.wfmt, b.wscale, b.wscale_seg_stride = _lib.W_FP8_E4M3, ptr(down_scale), H
     check(lib().mn_skinny_gemm(C.byref(b), current_stream()), "mn_skinny_gemm(moe down)")
     return out
 

@@ -114,6 +114,34 @@ def test_skinny_gemm_fp8_route_with_fused_prologue_and_epilogue():
         assert rel_err(y, ref) < 2e-5, (M, rel_err(y, ref))
 
 
+@pytest.mark.parametrize("M", [1, 2])
+def test_expert_pair_kernels_on_fp8_weights_against_float64(M):
+    """The one-row fp8 kernel (skinny_w8.hip) on the expert launches of a 1- / 2-row step at the 16B-A3B shapes: (row, expert) pairs
+    with the SwiGLU epilogue, then the down projection as 8 K-segments (6 routed + 2 shared) with per-segment row scales, router
+    weights and the residual — against the float64 formula on the dequantised weights."""
+    from ming_univision_amd import ops
+    g = torch.Generator().manual_seed(40 + M)
+    E, S, I, H, top = 64, 2, 1408, 2048, 6
+    gu = (torch.randn(E + S, 2 * I, H, generator=g) * H ** -0.5).to(torch.bfloat16).cuda()
+    dn = (torch.randn(E + S, H, I, generator=g) * I ** -0.5 * torch.logspace(-1, 1, H).reshape(1, H, 1)).to(torch.bfloat16).cuda()
+    gq, gs = ops.quant_fp8_rows(gu)
+    dq, ds = ops.quant_fp8_rows(dn)
+    xn = torch.randn(M, H, generator=g).cuda()
+    res = torch.randn(M, H, generator=g).cuda()
+    idx = torch.stack([torch.cat((torch.randperm(E, generator=g)[:top], torch.tensor([E, E + 1]))) for _ in range(M)]).to(torch.int32).cuda()
+    w = torch.cat((torch.rand(M, top, generator=g), torch.ones(M, S)), 1).cuda()
+    out = ops.moe_experts(xn, idx, w, gq, dq, res, gate_up_scale=gs, down_scale=ds)
+    gd, dd = ops.dequant_fp8_rows(gq, gs).double(), ops.dequant_fp8_rows(dq, ds).double()
+    ref = res.double().clone()
+    for m in range(M):
+        for s_ in range(top + S):
+            e = int(idx[m, s_])
+            r = gd[e] @ xn[m].double()
+            hmid = torch.nn.functional.silu(r[:I]) * r[I:]
+            ref[m] += float(w[m, s_]) * (dd[e] @ hmid.float().double())      # the kernel stores the SwiGLU output as fp32
+    assert rel_err(out, ref) < 2e-5, rel_err(out, ref)
+
+
 @pytest.fixture(scope="module")
 def full():
     from oracle import bailing_ref

@@ -11,8 +11,9 @@ h = hashlib.sha256()
 for f in files:
     h.update(open(os.path.join(ROOT, "ming_univision_amd", "csrc", f), "rb").read())
 head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
-dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "ming_univision_amd/csrc"], capture_output=True, text=True).stdout.strip())
-meta = {"kernel_src_sha16": h.hexdigest()[:16], "kernel_sources": files, "git_head": head + ("+uncommitted csrc changes" if dirty else ""),
+dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--"] + ["ming_univision_amd/csrc/" + f for f in files],
+                            capture_output=True, text=True).stdout.strip())      # of the NAMED sources only
+meta = {"kernel_src_sha16": h.hexdigest()[:16], "kernel_sources": files, "git_head": head + ("+uncommitted changes in these sources" if dirty else ""),
         "stamped": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ")}
 json.dump(meta, open(path + ".meta.json", "w"), indent=1)
 print(path + ".meta.json", meta)
