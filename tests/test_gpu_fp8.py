@@ -320,3 +320,45 @@ def test_fp8_facade_dtype_switch(tmp_path):
     psnr = 10 * np.log10(4.0 / float(((o8["images"] - o16["images"]) ** 2).mean()))
     print("tiny random-init model: PSNR(fp8 image, bf16 image) = %.1f dB (reported, not gated: see the module docstring)" % psnr)
     assert float((o8["images"] - o16["images"]).abs().max()) > 0          # the two formats really are different models
+
+
+def test_fp8_checkpoint_directory(tmp_path):
+    """The loader / repacker in fp8 mode: a checkpoint directory of bf16 safetensors shards keyed by the reference's
+    parameter names loads with dtype="fp8" (experts packed, then quantised; RF ResBlock matrices quantised), holds exactly the bytes /
+    scales the oracle's quantiser gives for those tensors, and generates the same tokens as the state-dict constructor in fp8 mode."""
+    from safetensors.torch import save_file
+    from oracle import fp8_ref
+    from ming_univision_amd.infer import MingUniVisionInfer
+    from ming_univision_amd.modeling import MingUniVisionForConditionalGeneration
+    from tests.util import load_golden, mingtok_sd
+    g = load_golden("genimg_tiny")
+    llm_cfg = dict(g["llm_config"]); llm_cfg["eos_token_id"] = 1
+    cfg = C.MingUniVisionConfig(mlp_depth=2, llm_config=llm_cfg, vishead_diffloss_config=g["rf_config"], mingtok_config=g["mingtok_config"])
+    sd = llm_sd(g["llm_config"], g["rf_config"], g["seed"])
+    ckpt = {"model." + k: v for k, v in sd.items()}
+    ckpt.update({"vision." + k: v for k, v in mingtok_sd(g["mingtok_config"], g["seed"]).items()})
+    ckpt.update(synth_state_dict(C.linear_proj_param_shapes(128, 256, 2), g["seed"]))
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    (d / "config.json").write_text(cfg.to_json_string())
+    keys = sorted(ckpt)
+    for i, part in enumerate((keys[:len(keys) // 2], keys[len(keys) // 2:])):
+        save_file({k: ckpt[k].to(torch.bfloat16).contiguous() for k in part}, str(d / f"model-0000{i + 1}-of-00002.safetensors"))
+    infer = MingUniVisionInfer(str(d), dtype="fp8", t_max=64)
+    dec, rf = infer.model.model, infer.model.rf
+    assert dec.weights == "fp8" and rf.weights == "fp8"
+    E, I = llm_cfg["num_experts"], llm_cfg["moe_intermediate_size"]
+    bf = lambda k: sd[k].to(torch.bfloat16).float()
+    q, s_ = fp8_ref.quantize_rows(torch.cat((bf("model.layers.1.mlp.experts.3.gate_proj.weight"), bf("model.layers.1.mlp.experts.3.up_proj.weight"))))
+    assert torch.equal(dec.layers[1]["w_gate_up"][3].cpu(), q) and torch.equal(dec.layers[1]["w_gate_up_scale"][3].cpu(), s_)
+    q, s_ = fp8_ref.quantize_rows(bf("model.layers.0.mlp.shared_experts.down_proj.weight")[:, I:2 * I].contiguous())
+    assert torch.equal(dec.layers[0]["w_down"][E + 1].cpu(), q) and torch.equal(dec.layers[0]["w_down_scale"][E + 1].cpu(), s_)
+    q, s_ = fp8_ref.quantize_rows(bf("diffloss.net.res_blocks.1.mlp.w3.weight"))
+    assert torch.equal(rf.lists["w3"][1].cpu(), q) and torch.equal(rf.scales["w3"][1].cpu(), s_)
+    direct = MingUniVisionForConditionalGeneration(cfg, state_dict=ckpt, seed=g["seed"], t_max=64, weights="fp8")
+    ids = g["ids"]
+    a = infer.model.generate(input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=5)
+    b = direct.generate(input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=5)
+    assert a.tolist() == b.tolist()
+    text = infer.generate([{"role": "HUMAN", "content": [{"type": "text", "text": "hi"}]}], max_new_tokens=3)
+    assert isinstance(text, str)
