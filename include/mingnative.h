@@ -399,6 +399,10 @@ typedef struct mn_rf_head {
    * the weight-streaming route only (rows <= 64: that route is HBM-bound, fp8 halves its bytes; mn_rf_max_rows returns 64). */
   int32_t wfmt;
   const float* const* w12_scale; const float* const* w3_scale;
+  /* optional (NULL = the adaLN GEMM always reads the bf16 ada_w): the stacked adaLN matrix as e4m3 bytes [depth*3w + 2w, w] + row
+   * scales.  Used when all Euler steps' rows fit one streaming launch (steps * rows <= 64, i.e. <= 4 CFG rows at 16 steps: the
+   * reference's call shape); ada_w must then hold the SAME values (the exact bf16 expansion) for the larger row counts. */
+  const uint8_t* ada_q; const float* ada_scale;
 } mn_rf_head;
 
 /* hidden [rows, llm_hidden] fp32 (last hidden states of the LLM step), rows = n_images x R image-major with
@@ -450,6 +454,16 @@ MN_API int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_row_d
                 const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len,
                 const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
                 float* hidden_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* mn_llm_step with flags.  MN_STEP_DISTINCT_SEQUENCES: every row belongs to a different cache sequence and row_len == row_slot + 1
+ * (a decode step of independent conversations / CFG rows — NOT a prefill chunk, whose rows attend each other's new K / V lines): the
+ * rotary embedding and the K / V append then ride the attention launch (one launch fewer per layer; <= 64 rows, n_q / n_kv in
+ * {1, 2, 4}).  Results are identical to mn_llm_step. */
+#define MN_STEP_DISTINCT_SEQUENCES 1
+MN_API int mn_llm_step_ex(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int M, const uint8_t* image_mask,
+                   const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len,
+                   const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
+                   float* hidden_out, void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /* a[i] += delta, b[i] += delta, c[i] += delta for i < M (any pointer may be NULL): advances the
  * device-resident row_slot / row_pos / row_len arrays between autoregressive steps without a host round trip. */

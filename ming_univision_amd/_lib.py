@@ -54,7 +54,7 @@ class RfHead(C.Structure):
         ("ada_w", C.c_void_p), ("ada_b", C.c_void_p),
         ("ln_g", PP), ("ln_b", PP), ("w12", PP), ("b12", PP), ("w3", PP), ("b3", PP),
         ("fin_w", C.c_void_p), ("fin_b", C.c_void_p),
-        ("wfmt", C.c_int32), ("w12_scale", PP), ("w3_scale", PP),
+        ("wfmt", C.c_int32), ("w12_scale", PP), ("w3_scale", PP), ("ada_q", C.c_void_p), ("ada_scale", C.c_void_p),
     ]
 
 
@@ -170,6 +170,7 @@ SYMBOLS = {
     "mn_rf_sample": (_i, [C.POINTER(RfHead), _p, _i64, _i, _i, _p, _f, _f, _f, _p, _p, _sz, _p]),
     "mn_llm_workspace_bytes": (_sz, [C.POINTER(Llm), _i, _i64]),
     "mn_llm_step": (_i, [C.POINTER(Llm), _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _i, _i64, _p, _p, _sz, _p]),
+    "mn_llm_step_ex": (_i, [C.POINTER(Llm), _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _i, _i64, _p, _p, _sz, _i, _p]),
     "mn_rows_advance": (_i, [_p, _p, _p, _i, _i, _p]),
     "mn_add_bcast_f32": (_i, [_p, _p, _p, _i64, _i64, _p]),
     "mn_group_mean_add": (_i, [_p, _p, _p, _i, _i, _i, _p]),

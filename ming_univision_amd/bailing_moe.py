@@ -229,10 +229,12 @@ class BailingMoeDecoder:
         return self._ws[key]
 
     def step(self, x, row_seq, row_slot, row_pos, row_len, key_mask=None, image_mask=None, out=None, rows=None,
-             x_row_div=1):
+             x_row_div=1, distinct_sequences=False):
         """One pass of the 28-layer stack over M <= 64 rows (weight-streaming kernels) or 65..2048 rows (wide route).
         x fp32 [M,H]; or [1,H] with rows=M to broadcast; or [M / x_row_div, H] with rows=M when the x_row_div CFG
         rows of an image share one embedding.  int32 device arrays per row; key_mask uint8 [M, >=len].
+        distinct_sequences: every row is a different cache sequence and row_len == row_slot + 1 (a decode step, not a prefill
+        chunk) — RoPE and the K / V append then ride the attention launch (mn_llm_step_ex; same results).
         Returns the post-final-norm hidden states [M,H] fp32."""
         M = rows or x.shape[0]
         ldx = 0 if (rows is not None and x.shape[0] == 1) else x.stride(0)
@@ -253,10 +255,11 @@ class BailingMoeDecoder:
         if out is None:
             out = torch.empty(M, self.cfg.hidden_size, dtype=torch.float32, device=self.device)
         ws = self._workspace(M)
-        check(lib().mn_llm_step(C.byref(self.struct), ptr(x), ldx, x_row_div, M, ptr(image_mask), ptr(row_seq), ptr(row_slot),
-                                ptr(row_pos), ptr(row_len), ptr(key_mask),
-                                0 if key_mask is None else key_mask.stride(0), ptr(self.kv_cache), self.n_seq,
-                                self.t_max, ptr(out), ptr(ws), ws.numel(), current_stream()), "mn_llm_step")
+        check(lib().mn_llm_step_ex(C.byref(self.struct), ptr(x), ldx, x_row_div, M, ptr(image_mask), ptr(row_seq), ptr(row_slot),
+                                   ptr(row_pos), ptr(row_len), ptr(key_mask),
+                                   0 if key_mask is None else key_mask.stride(0), ptr(self.kv_cache), self.n_seq,
+                                   self.t_max, ptr(out), ptr(ws), ws.numel(), 1 if distinct_sequences else 0, current_stream()),
+              "mn_llm_step")
         return out
 
     def prefill(self, embeds, seq=0, past=0, image_mask=None, chunk=MAX_ROWS):
@@ -623,10 +626,10 @@ class _GroupRun:
         st, dec, rf = self.st, self.dec, self.rf
         if ti == 0:
             dec.step(self.start_embed, st.row_seq, st.row_slot, st.row_pos, st.row_len, st.key_mask, None, out=self.hidden,
-                     rows=self.rows)
+                     rows=self.rows, distinct_sequences=True)        # every CFG row of every image has its own cache sequence
         else:
             dec.step(self.embed, st.row_seq, st.row_slot, st.row_pos, st.row_len, st.key_mask, None, out=self.hidden,
-                     rows=self.rows, x_row_div=self.rpi)
+                     rows=self.rows, x_row_div=self.rpi, distinct_sequences=True)
         if ti < self.n_tok:
             rf.sample(self.hidden, self.noise_t[ti], out=self.latents[ti], n_images=self.B, **self.kw)
             self.tok.decode_step(self.latents[ti], self.sem_state, sem_out=self.sems[ti], embed_out=self.embed)

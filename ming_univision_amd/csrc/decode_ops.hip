@@ -267,12 +267,25 @@ extern "C" int mn_rope_kv_append(const float* qkv, int64_t ldqkv, int M, int n_q
 // cover 4 consecutive q heads (= one GQA group when n_q/n_kv == 4, so K/V lines are shared in L1).
 // partial layout: [M][n_q][S][HD + 2]  (acc[HD], m, l)
 // -------------------------------------------------------------------------------------------
-template <int HD>
+// FUSED (round 4): the launch takes the RAW QKV projection instead of q — the rotary embedding of the row's q and new k, the
+// q scale and the K / V append of the new token (rope_kv_append_kernel, one launch per layer and step before) happen here: every
+// wave rotates its own q head into LDS; in the split that holds the new key, the first q head of each KV group writes the group's
+// K / V line into the arena (n_q / n_kv in {1, 2, 4}: the 4 heads of a block never straddle a KV group, so the line's readers are
+// waves of the SAME workgroup, ordered by vmcnt(0) + the barrier; the vector L1 holds no older copy of a line nobody read yet).
+struct AttnFuse {
+  const float* qkv; int64_t ldqkv; int nz; int64_t slab;        // raw QKV rows [(n_q + 2 n_kv) * HD], optionally nz K-slice partial slabs
+  int rope; const float* cos_tab; const float* sin_tab;          // [n_pos, HD / 2]
+  const int32_t* row_slot; const int32_t* row_pos; int sec_t, sec_h; float q_scale; int M;
+  float* kv_cache_w;                                              // the arena, writable
+};
+
+template <int HD, bool FUSED>
 __global__ __launch_bounds__(256) void attn_decode_split_kernel(
     const float* __restrict__ q, int n_q, int n_kv, const float* __restrict__ kv_cache, int64_t t_max,
     const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_len, const uint8_t* __restrict__ key_mask,
-    int64_t ld_mask, int S, int chunk_cap, float* __restrict__ partial) {
+    int64_t ld_mask, int S, int chunk_cap, float* __restrict__ partial, const AttnFuse fz) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ __attribute__((aligned(16))) float qs[FUSED ? 4 * HD : 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = blockIdx.x, s = blockIdx.z;
   const int h_raw = blockIdx.y * 4 + wave;
@@ -291,12 +304,50 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(
   const uint8_t* mk = key_mask ? key_mask + (int64_t)m * ld_mask : nullptr;
   float* out = partial + (((int64_t)m * n_q + h) * S + s) * (HD + 2);
 
+  if constexpr (FUSED) {
+    constexpr int half = HD / 2;
+    const float* row = fz.qkv + (int64_t)m * fz.ldqkv;
+    auto fetch = [&](int head, int i) {                 // element i of projection head `head` (q heads, then k heads, then v heads)
+      const float* p_ = row + (int64_t)head * HD + i;
+      float v = p_[0];
+      for (int z = 1; z < fz.nz; ++z) v += p_[z * fz.slab];
+      return v;
+    };
+    float c = 1.f, sn = 0.f;
+    if (lane < half && fz.rope) {
+      const int stream = fz.sec_t <= 0 ? 0 : (lane < fz.sec_t ? 0 : (lane < fz.sec_t + fz.sec_h ? 1 : 2));
+      const int pos = fz.row_pos[stream * fz.M + m];
+      c = fz.cos_tab[(int64_t)pos * half + lane];
+      sn = fz.sin_tab[(int64_t)pos * half + lane];
+    }
+    if (lane < half) {                                  // this wave's q head: rotate, scale, park in LDS
+      const float x1 = fetch(h, lane), x2 = fetch(h, lane + half);
+      qs[wave * HD + lane] = (x1 * c - x2 * sn) * fz.q_scale;
+      qs[wave * HD + lane + half] = (x2 * c + x1 * sn) * fz.q_scale;
+    }
+    const int slot = fz.row_slot[m];
+    const int ratio = n_q / n_kv;
+    // the new token's K / V line: written once per KV group, by the group's first q head, in the split that will read it
+    if (active && h % ratio == 0 && slot >= j0 && slot < j0 + chunk && (uint64_t)slot < (uint64_t)t_max && lane < half) {
+      const float k1 = fetch(n_q + kvh, lane), k2 = fetch(n_q + kvh, lane + half);
+      float* kd = fz.kv_cache_w + (((seq * 2 + 0) * n_kv + kvh) * t_max + slot) * HD;
+      float* vd = fz.kv_cache_w + (((seq * 2 + 1) * n_kv + kvh) * t_max + slot) * HD;
+      kd[lane] = k1 * c - k2 * sn;
+      kd[lane + half] = k2 * c + k1 * sn;
+      vd[lane] = fetch(n_q + n_kv + kvh, lane);
+      vd[lane + half] = fetch(n_q + n_kv + kvh, lane + half);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // (callers pass row_len = row_slot + 1: the split that contains `slot` always exists)
+  }
+
   // ---- scores: 16 lanes per key, 4 keys per wave-iteration
   constexpr int PER = HD / 16;  // floats per lane (8 for 128, 4 for 64)
   const int sub = lane & 15, kq = lane >> 4;
   float qv[PER];
 #pragma unroll
-  for (int i = 0; i < PER; ++i) qv[i] = qr[sub * PER + i];
+  for (int i = 0; i < PER; ++i) qv[i] = FUSED ? qs[wave * HD + sub * PER + i] : qr[sub * PER + i];
   float mx = -INFINITY;
   for (int j = j0 + kq; j < j0 + chunk; j += 4) {
     float d = 0.f;
@@ -554,13 +605,9 @@ extern "C" size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t
   return (size_t)M * n_q * attn_splits(M, n_q, t_max) * (hd + 2) * sizeof(float);
 }
 
-// Internal (engine.hip): mn_attn_decode whose output can also (or only) be written as bf16 hi/lo rows.
-extern "C" int mn_attn_decode_split(const float* q, int M, int n_q, int n_kv, int hd, const float* kv_cache,
-                                    int64_t t_max, const int32_t* row_seq, const int32_t* row_len,
-                                    const uint8_t* key_mask, int64_t ld_mask, float* out, uint16_t* split, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
-  MN_CHECK_ARG(M >= 1 && n_q >= 1 && n_kv >= 1 && n_q % n_kv == 0 && (hd == 64 || hd == 128), "mn_attn_decode: bad shape");
-  MN_CHECK_ARG(q && kv_cache && row_seq && row_len && (out || split) && workspace, "mn_attn_decode: null pointer");
+static int attn_decode_launch(const float* q, const AttnFuse* fz, int M, int n_q, int n_kv, int hd, const float* kv_cache, int64_t t_max,
+                              const int32_t* row_seq, const int32_t* row_len, const uint8_t* key_mask, int64_t ld_mask, float* out,
+                              uint16_t* split, void* workspace, size_t workspace_bytes, void* stream) {
   const int S = attn_splits(M, n_q, t_max);
   const size_t need = (size_t)M * n_q * S * (hd + 2) * sizeof(float);
   if (workspace_bytes < need) { mn_set_error("mn_attn_decode: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
@@ -570,24 +617,68 @@ extern "C" int mn_attn_decode_split(const float* q, int M, int n_q, int n_kv, in
   float* partial = reinterpret_cast<float*>(workspace);
   dim3 grid(M, (n_q + 3) / 4, S);
   hipStream_t st = mn_stream(stream);
-  if (attn_use_gqa(M, n_q, n_kv, hd)) {
+  const AttnFuse none{};
+  if (fz) {
+    if (hd == 128)
+      hipLaunchKernelGGL((attn_decode_split_kernel<128, true>), grid, dim3(256), lds, st, q, n_q, n_kv, kv_cache, t_max, row_seq, row_len,
+                         key_mask, ld_mask, S, chunk_cap, partial, *fz);
+    else
+      hipLaunchKernelGGL((attn_decode_split_kernel<64, true>), grid, dim3(256), lds, st, q, n_q, n_kv, kv_cache, t_max, row_seq, row_len,
+                         key_mask, ld_mask, S, chunk_cap, partial, *fz);
+  } else if (attn_use_gqa(M, n_q, n_kv, hd)) {
     hipLaunchKernelGGL((attn_decode_gqa_kernel<128, 4>), dim3(M, (n_kv + 3) / 4, S), dim3(256), lds * 4, st, q, n_q, n_kv, kv_cache,
                        t_max, row_seq, row_len, key_mask, ld_mask, S, chunk_cap, partial);
-    hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(M, n_q), dim3(128), 0, st, partial, n_q, S, out, split, M, kv_cache, n_kv, t_max,
-                       row_seq, row_len);
   } else if (hd == 128) {
-    hipLaunchKernelGGL(attn_decode_split_kernel<128>, grid, dim3(256), lds, st, q, n_q, n_kv, kv_cache, t_max, row_seq,
-                       row_len, key_mask, ld_mask, S, chunk_cap, partial);
+    hipLaunchKernelGGL((attn_decode_split_kernel<128, false>), grid, dim3(256), lds, st, q, n_q, n_kv, kv_cache, t_max, row_seq,
+                       row_len, key_mask, ld_mask, S, chunk_cap, partial, none);
+  } else {
+    hipLaunchKernelGGL((attn_decode_split_kernel<64, false>), grid, dim3(256), lds, st, q, n_q, n_kv, kv_cache, t_max, row_seq,
+                       row_len, key_mask, ld_mask, S, chunk_cap, partial, none);
+  }
+  if (hd == 128)
     hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(M, n_q), dim3(128), 0, st, partial, n_q, S, out, split, M, kv_cache, n_kv, t_max,
                        row_seq, row_len);
-  } else {
-    hipLaunchKernelGGL(attn_decode_split_kernel<64>, grid, dim3(256), lds, st, q, n_q, n_kv, kv_cache, t_max, row_seq,
-                       row_len, key_mask, ld_mask, S, chunk_cap, partial);
+  else
     hipLaunchKernelGGL(attn_decode_combine_kernel<64>, dim3(M, n_q), dim3(64), 0, st, partial, n_q, S, out, split, M, kv_cache, n_kv, t_max,
                        row_seq, row_len);
-  }
   MN_CHECK_LAUNCH("mn_attn_decode");
   return MN_OK;
+}
+
+// Internal (engine.hip): mn_attn_decode whose output can also (or only) be written as bf16 hi/lo rows.
+extern "C" int mn_attn_decode_split(const float* q, int M, int n_q, int n_kv, int hd, const float* kv_cache,
+                                    int64_t t_max, const int32_t* row_seq, const int32_t* row_len,
+                                    const uint8_t* key_mask, int64_t ld_mask, float* out, uint16_t* split, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  MN_CHECK_ARG(M >= 1 && n_q >= 1 && n_kv >= 1 && n_q % n_kv == 0 && (hd == 64 || hd == 128), "mn_attn_decode: bad shape");
+  MN_CHECK_ARG(q && kv_cache && row_seq && row_len && (out || split) && workspace, "mn_attn_decode: null pointer");
+  return attn_decode_launch(q, nullptr, M, n_q, n_kv, hd, kv_cache, t_max, row_seq, row_len, key_mask, ld_mask, out, split, workspace,
+                            workspace_bytes, stream);
+}
+
+// Internal (engine.hip): RoPE + q scale + KV append + masked decode attention in ONE split launch (+ the combine) from the raw QKV
+// projection (optionally as nz K-slice partial slabs): what mn_rope_kv_append_3d / mn_rope_kv_from_partials followed by
+// mn_attn_decode_split compute, one launch fewer per layer and step and no q round trip.  Needs row_len == row_slot + 1, at most 64
+// rows (the many-row GQA kernel keeps the separate append) and n_q / n_kv in {1, 2, 4}; mn_attn_fused_ok says whether a shape qualifies.
+extern "C" int mn_attn_fused_ok(int M, int n_q, int n_kv, int hd) {
+  if (g_kv_round_bf16) return 0;                     // the bf16-KV measurement hook lives in the stand-alone append kernel
+  const int ratio = n_kv > 0 && n_q % n_kv == 0 ? n_q / n_kv : 0;
+  return M >= 1 && !attn_use_gqa(M, n_q, n_kv, hd) && (hd == 64 || hd == 128) && (ratio == 1 || ratio == 2 || ratio == 4);
+}
+extern "C" int mn_attn_decode_fused(const float* qkv, int64_t ldqkv, int nz, int64_t slab, int M, int n_q, int n_kv, int hd, int rope,
+                                    const float* cos_tab, const float* sin_tab, const int32_t* row_seq, const int32_t* row_slot,
+                                    const int32_t* row_pos, int sec_t, int sec_h, float q_scale, float* kv_cache, int64_t t_max,
+                                    const int32_t* row_len, const uint8_t* key_mask, int64_t ld_mask, float* out, uint16_t* split,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  MN_CHECK_ARG(mn_attn_fused_ok(M, n_q, n_kv, hd) && nz >= 1, "mn_attn_decode_fused: unsupported shape");
+  MN_CHECK_ARG(qkv && kv_cache && row_seq && row_slot && row_len && (out || split) && workspace, "mn_attn_decode_fused: null pointer");
+  MN_CHECK_ARG(!rope || (cos_tab && sin_tab && row_pos), "mn_attn_decode_fused: rope needs tables and positions");
+  MN_CHECK_ARG(sec_t >= 0 && sec_h >= 0 && sec_t + sec_h <= hd / 2, "mn_attn_decode_fused: bad rotary sections %d/%d", sec_t, sec_h);
+  AttnFuse fz;
+  fz.qkv = qkv; fz.ldqkv = ldqkv; fz.nz = nz; fz.slab = slab; fz.rope = rope; fz.cos_tab = cos_tab; fz.sin_tab = sin_tab;
+  fz.row_slot = row_slot; fz.row_pos = row_pos; fz.sec_t = sec_t; fz.sec_h = sec_h; fz.q_scale = q_scale; fz.M = M; fz.kv_cache_w = kv_cache;
+  return attn_decode_launch(nullptr, &fz, M, n_q, n_kv, hd, kv_cache, t_max, row_seq, row_len, key_mask, ld_mask, out, split, workspace,
+                            workspace_bytes, stream);
 }
 
 extern "C" int mn_attn_decode(const float* q, int M, int n_q, int n_kv, int hd, const float* kv_cache,

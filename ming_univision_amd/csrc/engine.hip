@@ -24,6 +24,12 @@ extern "C" int mn_rope_kv_from_partials(const float* qkv, int64_t ldqkv, int nz,
 extern "C" int mn_attn_decode_split(const float* q, int M, int n_q, int n_kv, int hd, const float* kv_cache, int64_t t_max,
                                     const int32_t* row_seq, const int32_t* row_len, const uint8_t* key_mask, int64_t ld_mask,
                                     float* out, uint16_t* split, void* workspace, size_t workspace_bytes, void* stream);
+extern "C" int mn_attn_fused_ok(int M, int n_q, int n_kv, int hd);
+extern "C" int mn_attn_decode_fused(const float* qkv, int64_t ldqkv, int nz, int64_t slab, int M, int n_q, int n_kv, int hd, int rope,
+                                    const float* cos_tab, const float* sin_tab, const int32_t* row_seq, const int32_t* row_slot,
+                                    const int32_t* row_pos, int sec_t, int sec_h, float q_scale, float* kv_cache, int64_t t_max,
+                                    const int32_t* row_len, const uint8_t* key_mask, int64_t ld_mask, float* out, uint16_t* split,
+                                    void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint16_t* W, int64_t w_stride, float* P,
                                       int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows,
                                       int Ntot, int K, void* stream);
@@ -367,9 +373,12 @@ static bool rf_fp8_ok(const mn_rf_head* h) {
   return h->wfmt == MN_W_FP8_E4M3 && h->w12_scale && h->w3_scale && h->w <= 4096 && (h->w % 16) == 0 && (h->hidden % 16) == 0;
 }
 
+// fp8 adaLN: the modulations of all Euler steps as ONE streaming launch on e4m3 bytes when their rows fit it
+static bool rf_ada_w8(const mn_rf_head* h, int rows) { return h->wfmt && h->ada_q && h->ada_scale && (int64_t)h->steps * rows <= 64; }
+
 static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, float** z, float** c, float** ada,
                        float** hh, float** hid, float** v, float** x, bf16_t** y, unsigned** bar, char** skws,
-                       size_t* skws_bytes, bf16_t** ya, bf16_t** yb, float** pbuf) {
+                       size_t* skws_bytes, bf16_t** ya, bf16_t** yb, float** pbuf, float** pada = nullptr) {
   Carver cv(ws, cap, ws == nullptr);
   const int A = h->depth * 3 * h->w + 2 * h->w;
   *z = cv.take<float>((size_t)rows * h->z_dim);
@@ -393,6 +402,9 @@ static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, floa
   *ya = cv.take<bf16_t>(chain ? (size_t)2 * rows * h->w : 0);
   *yb = cv.take<bf16_t>(chain ? (size_t)2 * rows * h->hidden : 0);
   *pbuf = cv.take<float>(chain ? pmax * rows : 0);
+  const int SRn = h->steps * rows;
+  float* pa = cv.take<float>(rf_ada_w8(h, rows) ? (size_t)mn_stream_mfma_w8_slices(SRn, A, h->w) * SRn * A : 0);
+  if (pada) *pada = pa;
   return cv.off;
 }
 
@@ -426,9 +438,9 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   char* skws;
   size_t skws_bytes;
   bf16_t *ya, *yb;
-  float* pbuf;
+  float *pbuf, *pada;
   const size_t need = rf_carve(h, rows, workspace, workspace_bytes, &z, &c, &ada, &hh, &hid, &v, &x, &y, &bar, &skws, &skws_bytes,
-                               &ya, &yb, &pbuf);
+                               &ya, &yb, &pbuf, &pada);
   const bool chain = rf_chain_ok(h, rows);
   t_sk_ws = skws; t_sk_ws_bytes = skws_bytes;
   if (need > workspace_bytes) { mn_set_error("mn_rf_sample: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
@@ -450,7 +462,13 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   // accumulate into one output, so that the products stay fp32-accurate).   Linear(SiLU(t_emb[s] + c))  (diff_loss:263-266,283-286,376)
   const int64_t SR = (int64_t)h->steps * rows;
   hipLaunchKernelGGL(rf_build_y_kernel, dim3(mn_cdiv(SR * w, 256)), dim3(256), 0, st, h->temb, c, y, h->steps, rows, w);
-  MN_TRY(mn_gemm_bf16_hilo(y, w, SR * w, h->ada_w, w, h->ada_b, ada, A, (int)SR, A, w, stream));
+  if (rf_ada_w8(h, rows)) {      // <= 64 (step, row) pairs: stream the 0.36 GB of e4m3 adaLN bytes once, then slabs + bias -> ada
+    const int nza = mn_stream_mfma_w8(y, h->ada_q, h->ada_scale, pada, (int)SR, A, w, stream);
+    if (nza < 0) return nza;
+    hipLaunchKernelGGL(rf_glue_bias_out_kernel, dim3(mn_cdiv(SR * A, 256)), dim3(256), 0, st, pada, nza, (int)SR, A, h->ada_b, ada);
+  } else {
+    MN_TRY(mn_gemm_bf16_hilo(y, w, SR * w, h->ada_w, w, h->ada_b, ada, A, (int)SR, A, w, stream));
+  }
   const float step = 1.0f / (float)h->steps;
   const float* ada_all = ada;
   for (int s = 0; s < h->steps; ++s) {
@@ -862,10 +880,32 @@ extern "C" int mn_rows_advance(int32_t* a, int32_t* b, int32_t* c, int M, int de
   return MN_OK;
 }
 
+static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int M, const uint8_t* image_mask, const int32_t* row_seq,
+                         const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len,
+                         const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
+                         float* hidden_out, void* workspace, size_t workspace_bytes, int flags, void* stream);
+
 extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int M, const uint8_t* image_mask, const int32_t* row_seq,
                            const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len,
                            const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
                            float* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
+  return llm_step_impl(m, x, ldx, x_row_div, M, image_mask, row_seq, row_slot, row_pos, row_len, key_mask, ld_mask, kv_cache, n_seq, t_max,
+                       hidden_out, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int mn_llm_step_ex(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int M, const uint8_t* image_mask, const int32_t* row_seq,
+                              const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len,
+                              const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
+                              float* hidden_out, void* workspace, size_t workspace_bytes, int flags, void* stream) {
+  MN_CHECK_ARG((flags & ~MN_STEP_DISTINCT_SEQUENCES) == 0, "mn_llm_step_ex: unknown flags 0x%x", flags);
+  return llm_step_impl(m, x, ldx, x_row_div, M, image_mask, row_seq, row_slot, row_pos, row_len, key_mask, ld_mask, kv_cache, n_seq, t_max,
+                       hidden_out, workspace, workspace_bytes, flags, stream);
+}
+
+static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int M, const uint8_t* image_mask, const int32_t* row_seq,
+                         const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len,
+                         const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
+                         float* hidden_out, void* workspace, size_t workspace_bytes, int flags, void* stream) {
   MN_CHECK_ARG(m && x && row_seq && row_slot && row_pos && row_len && kv_cache && hidden_out && workspace,
                "mn_llm_step: null pointer");
   MN_CHECK_ARG(M >= 1 && (M <= 64 || llm_wide_ok(m, M)) && x_row_div >= 1,
@@ -886,6 +926,9 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
   const int64_t layer_kv = (int64_t)n_seq * 2 * nkv * t_max * hd;
   const float q_scale = 1.0f / sqrtf((float)hd);
   t_sk_ws = w.sk_ws; t_sk_ws_bytes = w.sk_ws_bytes;
+  // rows of DISTINCT cache sequences (decode steps; not a prefill chunk, whose rows read each other's new K / V lines): RoPE + KV
+  // append ride the attention launch
+  const bool fuse_attn = (flags & MN_STEP_DISTINCT_SEQUENCES) && mn_attn_fused_ok(M, nq, nkv, hd);
   if (llm_chain_ok(m, M) && !(image_mask && m->image_gate)) {
     // ---- chain path: 12 launches per layer (11 at 2 rows) instead of 18.  glue = llm_glue_kernel.
     const int E = m->n_experts, S = m->n_shared_slots, G = E + S, ad = nq * hd, P = M * n_slot;
@@ -906,12 +949,18 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
       // QKV launch -> partials; RoPE + KV append reduce them  (:743-789)
       int nz = mn_stream_mfma(w.yh, m->wqkv[l], w.pp, M, qkv_dim, H, stream);
       if (nz < 0) return nz;
-      MN_TRY(mn_rope_kv_from_partials(w.pp, qkv_dim, nz, (int64_t)M * qkv_dim, M, nq, nkv, hd, 1, m->cos_tab, m->sin_tab,
-                                      row_seq, row_slot, row_pos, m->mrope_sec_t, m->mrope_sec_h, q_scale, w.q, kv_l, t_max,
-                                      stream));
-      // masked GQA; the combine writes the dense projection's bf16 operand directly  (:791-812)
-      MN_TRY(mn_attn_decode_split(w.q, M, nq, nkv, hd, kv_l, t_max, row_seq, row_len, key_mask, ld_mask, nullptr, w.ya, w.attn_ws,
-                                  w.attn_ws_bytes, stream));
+      if (fuse_attn) {
+        MN_TRY(mn_attn_decode_fused(w.pp, qkv_dim, nz, (int64_t)M * qkv_dim, M, nq, nkv, hd, 1, m->cos_tab, m->sin_tab, row_seq, row_slot,
+                                    row_pos, m->mrope_sec_t, m->mrope_sec_h, q_scale, kv_l, t_max, row_len, key_mask, ld_mask, nullptr,
+                                    w.ya, w.attn_ws, w.attn_ws_bytes, stream));
+      } else {
+        MN_TRY(mn_rope_kv_from_partials(w.pp, qkv_dim, nz, (int64_t)M * qkv_dim, M, nq, nkv, hd, 1, m->cos_tab, m->sin_tab,
+                                        row_seq, row_slot, row_pos, m->mrope_sec_t, m->mrope_sec_h, q_scale, w.q, kv_l, t_max,
+                                        stream));
+        // masked GQA; the combine writes the dense projection's bf16 operand directly  (:791-812)
+        MN_TRY(mn_attn_decode_split(w.q, M, nq, nkv, hd, kv_l, t_max, row_seq, row_len, key_mask, ld_mask, nullptr, w.ya, w.attn_ws,
+                                    w.attn_ws_bytes, stream));
+      }
       nz = mn_stream_mfma(w.ya, m->wdense[l], w.pp, M, H, ad, stream);
       if (nz < 0) return nz;
       // glue: h += dense partials; RMSNorm(ln2) -> xn (fp32 for the 2-row expert kernels) and yh (gate + expert operand)
@@ -963,10 +1012,16 @@ extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_r
     mn_skinny_args a = sk(w.h, H, m->wqkv[l], H, nullptr, w.qkv, qkv_dim, M, qkv_dim, H);
     a.prologue = MN_PRO_RMSNORM; a.ln_g = m->ln1[l]; a.eps = m->rms_eps;
     MN_TRY(mn_skinny_gemm(&a, stream));
-    MN_TRY(mn_rope_kv_append_3d(w.qkv, qkv_dim, M, nq, nkv, hd, 1, m->cos_tab, m->sin_tab, row_seq, row_slot, row_pos,
-                                m->mrope_sec_t, m->mrope_sec_h, q_scale, w.q, kv_l, t_max, stream));
-    MN_TRY(mn_attn_decode(w.q, M, nq, nkv, hd, kv_l, t_max, row_seq, row_len, key_mask, ld_mask, w.attn, w.attn_ws,
-                          w.attn_ws_bytes, stream));
+    if (fuse_attn) {
+      MN_TRY(mn_attn_decode_fused(w.qkv, qkv_dim, 1, 0, M, nq, nkv, hd, 1, m->cos_tab, m->sin_tab, row_seq, row_slot, row_pos,
+                                  m->mrope_sec_t, m->mrope_sec_h, q_scale, kv_l, t_max, row_len, key_mask, ld_mask, w.attn, nullptr,
+                                  w.attn_ws, w.attn_ws_bytes, stream));
+    } else {
+      MN_TRY(mn_rope_kv_append_3d(w.qkv, qkv_dim, M, nq, nkv, hd, 1, m->cos_tab, m->sin_tab, row_seq, row_slot, row_pos,
+                                  m->mrope_sec_t, m->mrope_sec_h, q_scale, w.q, kv_l, t_max, stream));
+      MN_TRY(mn_attn_decode(w.q, M, nq, nkv, hd, kv_l, t_max, row_seq, row_len, key_mask, ld_mask, w.attn, w.attn_ws,
+                            w.attn_ws_bytes, stream));
+    }
     a = sk(w.attn, nq * hd, m->wdense[l], nq * hd, nullptr, w.h, H, M, H, nq * hd);
     a.epilogue = MN_EPI_RESID; a.res = w.h; a.ldres = H;
     MN_TRY(mn_skinny_gemm(&a, stream));
@@ -1070,10 +1125,15 @@ extern "C" int mn_semdec_step(const mn_semdec* s, const float* latent_norm, int 
     mn_skinny_args a = sk(w.h, D, s->wqkv[l], D, s->bqkv[l], w.qkv, 3 * D, M, 3 * D, D);
     a.prologue = MN_PRO_LN; a.ln_g = s->ln1_g[l]; a.ln_b = s->ln1_b[l]; a.eps = 1e-6f;
     MN_TRY(mn_skinny_gemm(&a, stream));
-    MN_TRY(mn_rope_kv_append(w.qkv, 3 * D, M, nh, nh, 64, 0, nullptr, nullptr, row_seq, row_slot, nullptr, 0.125f,
-                             w.q, kv_l, t_max, stream));
-    MN_TRY(mn_attn_decode(w.q, M, nh, nh, 64, kv_l, t_max, row_seq, row_len, nullptr, 0, w.attn, w.attn_ws,
-                          w.attn_ws_bytes, stream));
+    if (mn_attn_fused_ok(M, nh, nh, 64)) {     // every row is its own sequence (the step's contract): the K / V append rides the attention launch
+      MN_TRY(mn_attn_decode_fused(w.qkv, 3 * D, 1, 0, M, nh, nh, 64, 0, nullptr, nullptr, row_seq, row_slot, nullptr, 0, 0, 0.125f, kv_l,
+                                  t_max, row_len, nullptr, 0, w.attn, nullptr, w.attn_ws, w.attn_ws_bytes, stream));
+    } else {
+      MN_TRY(mn_rope_kv_append(w.qkv, 3 * D, M, nh, nh, 64, 0, nullptr, nullptr, row_seq, row_slot, nullptr, 0.125f,
+                               w.q, kv_l, t_max, stream));
+      MN_TRY(mn_attn_decode(w.q, M, nh, nh, 64, kv_l, t_max, row_seq, row_len, nullptr, 0, w.attn, w.attn_ws,
+                            w.attn_ws_bytes, stream));
+    }
     a = sk(w.attn, D, s->wproj[l], D, s->bproj[l], w.h, D, M, D, D);
     a.epilogue = MN_EPI_RESID; a.res = w.h; a.ldres = D;
     MN_TRY(mn_skinny_gemm(&a, stream));

@@ -308,7 +308,7 @@ class MingUniVisionForConditionalGeneration:
                 break
             if (step + 1) % sync_every == 0 and bool(finished.all()):      # the only host syncs of the loop
                 break
-            hidden = self.model.step(self.model.embed(tok), seq, slot, slot, ln)
+            hidden = self.model.step(self.model.embed(tok), seq, slot, slot, ln, distinct_sequences=True)
             check(lib().mn_rows_advance(ptr(slot), ptr(ln), None, B, 1, current_stream()), "mn_rows_advance")
         out = torch.stack(toks, 1).tolist()
         if timings is not None:
@@ -393,7 +393,7 @@ class MingUniVisionForConditionalGeneration:
                     tok_dev = torch.tensor([int(forced_first_token)], device=dev)
                 toks_dev.append(tok_dev)
                 if j + 1 < n or len(new_ids) + n < max_new_tokens:       # the last token of the call is never fed
-                    hidden = self.model.step(self.model.embed(tok_dev), seq0, slot, slot, ln)
+                    hidden = self.model.step(self.model.embed(tok_dev), seq0, slot, slot, ln, distinct_sequences=True)
                     check(lib().mn_rows_advance(ptr(slot), ptr(ln), None, 1, 1, current_stream()), "mn_rows_advance")
             toks = torch.cat(toks_dev).tolist()                          # the chunk's only host sync
             for j, tok in enumerate(toks):

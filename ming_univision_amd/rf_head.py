@@ -89,6 +89,11 @@ class RectifiedFlowHead:
                 qs = [ops.quant_fp8_rows(w) for w in self.lists[k]]
                 self.lists[k] = [q for q, _ in qs]
                 self.scales[k] = [sc for _, sc in qs]
+            # the stacked adaLN matrix: e4m3 bytes for the one-launch form (<= 4 CFG rows: all 16 steps' rows fit a streaming launch)
+            # + its exact bf16 expansion for the MFMA GEMM of the larger row counts — the same model either way
+            self.t = dict(self.t)
+            self.t["ada_q"], self.t["ada_scale"] = ops.quant_fp8_rows(self.t["ada_w"])
+            self.t["ada_w"] = ops.dequant_fp8_rows(self.t["ada_q"], self.t["ada_scale"])
         llm_hidden = self.llm_hidden
         self._arrays = {k: ptr_array(v) for k, v in self.lists.items()}
         self._scale_arrays = {k: ptr_array(v) for k, v in self.scales.items()}
@@ -104,6 +109,7 @@ class RectifiedFlowHead:
         if weights == "fp8":
             s.w12_scale = C.cast(self._scale_arrays["w12"], _lib.PP)
             s.w3_scale = C.cast(self._scale_arrays["w3"], _lib.PP)
+            s.ada_q, s.ada_scale = ptr(self.t["ada_q"]), ptr(self.t["ada_scale"])
         self.struct = s
         self._ws = {}
 
@@ -115,13 +121,19 @@ class RectifiedFlowHead:
         new._finalize("fp8")
         return new
 
-    def weight_bytes_per_step(self):
+    def weight_bytes_per_step(self, rows=2):
         """Weight bytes one Euler step must stream from HBM (bf16: 2 per ResBlock parameter; fp8: 1 + the row scales)."""
         per_w = 1 if self.weights == "fp8" else 2
         per_block = (2 * self.hidden * self.w + self.w * self.hidden) * per_w
         if self.weights == "fp8":
             per_block += (2 * self.hidden + self.w) * 4
-        return self.depth * per_block + self.t["ada_w"].numel() * 2
+        return self.depth * per_block + self.ada_bytes(rows)
+
+    def ada_bytes(self, rows=2):
+        """Bytes of the stacked adaLN matrix one visual token reads (once: all Euler steps in one launch): e4m3 in fp8 mode while
+        steps x rows <= 64, else bf16."""
+        n = self.t["ada_w"].numel()
+        return n + 4 * self.t["ada_w"].shape[0] if (self.weights == "fp8" and self.steps * rows <= 64) else 2 * n
 
     def dequantized_blocks(self):
         """fp8 mode: {reference parameter name: bf16 tensor} of the ResBlock matrices as the kernels see them (e4m3 * row scale,
@@ -131,6 +143,8 @@ class RectifiedFlowHead:
         for i in range(self.depth):
             for k, name in (("w12", "mlp.w12.weight"), ("w3", "mlp.w3.weight")):
                 out[f"diffloss.net.res_blocks.{i}.{name}"] = ops.dequant_fp8_rows(self.lists[k][i], self.scales[k][i])
+            out[f"diffloss.net.res_blocks.{i}.adaLN_modulation.1.weight"] = self.t["ada_w"][i * 3 * self.w:(i + 1) * 3 * self.w]
+        out["diffloss.net.final_layer.adaLN_modulation.1.weight"] = self.t["ada_w"][self.depth * 3 * self.w:]
         return out
 
     def max_rows(self):

@@ -528,7 +528,8 @@ class TpSimGroup(_TpDecoderBase):
         self.weights, self.rf_weights = getattr(dec, "weights", "bf16"), getattr(rf, "weights", "bf16")
 
     # -- decoder -------------------------------------------------------------------------------------------------
-    def step(self, x, row_seq, row_slot, row_pos, row_len, key_mask=None, image_mask=None, out=None, rows=None, x_row_div=1):
+    def step(self, x, row_seq, row_slot, row_pos, row_len, key_mask=None, image_mask=None, out=None, rows=None, x_row_div=1,
+             distinct_sequences=False):      # (the TP composites keep the stand-alone append: accepted for interface parity)
         M = rows or x.shape[0]
         outs = [out if r == 0 and out is not None else torch.empty(M, self.cfg.hidden_size, dtype=torch.float32, device=self.device)
                 for r in range(self.world)]
@@ -636,7 +637,8 @@ class TpRank(_TpDecoderBase):
                 self.comm.relay(base + seg + 1, n_floats)
         return out
 
-    def step(self, x, row_seq, row_slot, row_pos, row_len, key_mask=None, image_mask=None, out=None, rows=None, x_row_div=1):
+    def step(self, x, row_seq, row_slot, row_pos, row_len, key_mask=None, image_mask=None, out=None, rows=None, x_row_div=1,
+             distinct_sequences=False):      # (the TP composites keep the stand-alone append: accepted for interface parity)
         M = rows or x.shape[0]
         if out is None:
             out = torch.empty(M, self.cfg.hidden_size, dtype=torch.float32, device=self.device)
