@@ -596,6 +596,16 @@ MN_API size_t mn_lmhead_argmax_workspace_bytes(int M, int V, int H);
 MN_API int mn_lmhead_argmax(const float* hidden, int64_t ld_hidden, int M, const uint16_t* W, int64_t ldw, int V, int H,
                             int64_t vocab_offset, int64_t* idx, float* val, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Sampled pick (the `do_sample` branch of HF GenerationMixin.generate, which the reference forwards its generate kwargs to:
+ * modeling_bailingmm.py:249-262, modeling_bailing_moe.py:1769-1796; warpers in transformers/generation/logits_process.py —
+ * TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> softmax -> one multinomial draw):
+ * idx[m] = vocab_offset + the token the inverse CDF of the warped distribution of logits[m] gives at u[m] in [0, 1), tokens ranked by
+ * descending score, ties by ascending id.  top_k = 0 and top_p >= 1 switch the respective warper off; with top_k = 0 and top_p < 1
+ * the candidate set is the 2048 largest scores; top_k is capped at 2048.  The caller owns the uniform stream (u), so a decode is
+ * reproducible from a seed.  logits fp32 [M, V], row stride ld (e.g. the first bytes of mn_lmhead_argmax's workspace). */
+MN_API int mn_sample_logits(const float* logits, int64_t ld, int M, int V, float temperature, int top_k, float top_p, const float* u,
+                            int64_t vocab_offset, int64_t* idx, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * 7. fp8 weight mode (BASELINE configs[4] "fp8").
  *    No arithmetic counterpart in the reference: its reduced-byte surface is the `dtype` switch of MingUniVisionInfer

@@ -197,6 +197,7 @@ SYMBOLS = {
     "mn_rf_sample_tp": (_i, [C.POINTER(RfHead), C.POINTER(TpComm), _p, _i64, _i, _i, _p, _f, _f, _f, _p, _p, _sz, _i, _i, _p]),
     "mn_lmhead_argmax_workspace_bytes": (_sz, [_i, _i, _i]),
     "mn_lmhead_argmax": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _i64, _p, _p, _p, _sz, _p]),
+    "mn_sample_logits": (_i, [_p, _i64, _i, _i, _f, _i, _f, _p, _i64, _p, _p]),
     "mn_semdec_workspace_bytes": (_sz, [C.POINTER(SemDec), _i, _i64]),
     "mn_semdec_step": (_i, [C.POINTER(SemDec), _p, _i, _p, _p, _p, _p, _i, _i64, _p, _p, _p, _sz, _p]),
 }

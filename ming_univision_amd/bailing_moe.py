@@ -525,6 +525,11 @@ class BailingMoeDecoder:
         of greedy decoding; ties -> lowest id like torch.argmax).  hidden fp32 [M, H] -> int64 [M] on the device."""
         return ops.lmhead_argmax(hidden.contiguous(), self.lm_head)[0]
 
+    def sample(self, hidden, u, temperature=1.0, top_k=50, top_p=1.0):
+        """Sampled pick of every row (HF generate's `do_sample` branch: temperature -> top-k -> top-p -> one draw, at the caller's
+        uniforms u fp32 [M]): lm_head logits + mn_sample_logits.  hidden fp32 [M, H] -> int64 [M] on the device."""
+        return ops.sample_logits(self.logits(hidden.contiguous()), u, temperature, top_k, top_p)
+
     def embed(self, ids):
         """word_embeddings lookup -> fp32 rows (gather = memory plumbing)."""
         return ops.bf16_to_f32(self.word_embeddings[ids.reshape(-1)])

@@ -219,7 +219,8 @@ class MingUniVisionForConditionalGeneration:
 
     # ---- batched greedy text decoding (extension: image -> text understanding for B conversations in lock-step) -----------
     @torch.no_grad()
-    def generate_text_batch(self, requests, max_new_tokens=64, sync_every=8, timings=None):
+    def generate_text_batch(self, requests, max_new_tokens=64, sync_every=8, timings=None, do_sample=False, temperature=1.0, top_k=50,
+                            top_p=1.0, generator=None):
         """B independent single-round conversations decoded greedily in lock-step: one pass through the decoder stack per new
         token serves all B sequences (rows = B: the weight-streaming kernels up to 64 sequences, the wide MFMA route with
         grouped-GEMM experts above), lm_head as one GEMM, argmax / embedding lookup / row bookkeeping on the device; the host
@@ -228,13 +229,17 @@ class MingUniVisionForConditionalGeneration:
         sequence gets the tokens `generate` would give it alone (greedy, up to its first EOS).  Image generation is not
         triggered here (`<image>` is returned as a token).  Does not touch the multi-round state (its cache sequences included).
         Returns a list of B token-id lists (EOS included when reached).  `timings` (a dict, measurement only): synchronises
-        after the prefills and at the end and stores `prefill_s` / `decode_s`."""
+        after the prefills and at the end and stores `prefill_s` / `decode_s`.  `do_sample` / `temperature` / `top_k` / `top_p` /
+        `generator` as in `generate`: new token i of sequence b uses uniform [i, b] of one torch.rand(max_new_tokens, B) draw."""
+        if do_sample and not (temperature > 0 and top_k >= 0 and 0 < top_p <= 1):
+            raise ValueError("generate_text_batch: do_sample needs temperature > 0, top_k >= 0 and 0 < top_p <= 1")
+        sampling = (float(temperature), int(top_k), float(top_p), generator) if do_sample else None
         try:
-            return self._generate_text_batch(requests, max_new_tokens, sync_every, timings)
+            return self._generate_text_batch(requests, max_new_tokens, sync_every, timings, sampling)
         finally:
             self.model.release_sequences(self.BATCH_SEQ0)     # the batch's cache sequences are dead: give the arena back
 
-    def _generate_text_batch(self, requests, max_new_tokens, sync_every, timings):
+    def _generate_text_batch(self, requests, max_new_tokens, sync_every, timings, sampling=None):
         import time
         cfg, dev = self.config.llm_config, self.device
         B = len(requests)
@@ -300,8 +305,9 @@ class MingUniVisionForConditionalGeneration:
         ln = slot + 1
         finished = torch.zeros(B, dtype=torch.bool, device=dev)
         toks = []
+        uniforms = torch.rand(max_new_tokens, B, device=dev, generator=sampling[3]) if sampling else None
         for step in range(max_new_tokens):
-            tok = self.model.greedy(hidden)
+            tok = self.model.sample(hidden, uniforms[step], *sampling[:3]) if sampling else self.model.greedy(hidden)
             toks.append(tok)
             finished |= tok == cfg.eos_token_id
             if step + 1 == max_new_tokens:
@@ -325,10 +331,23 @@ class MingUniVisionForConditionalGeneration:
     def generate(self, input_ids=None, attention_mask=None, uncond_attention_mask=None, text_uncond_attention_mask=None,
                  pixel_values=None, image_grid_thw=None, past_key_values=None, output_image_prefix="output",
                  image_gen_temperature=1.0, image_gen_text_cfg=3.0, image_gen_image_cfg=1.1, max_new_tokens=512,
-                 use_cache=True, forced_first_token=None, **generate_kwargs):
-        """Greedy decode with the `<image>` trigger (modeling_bailingmm.py:206-301; modeling_bailing_moe.py:1769-1796).
+                 use_cache=True, forced_first_token=None, do_sample=False, temperature=1.0, top_k=50, top_p=1.0,
+                 generator=None, **generate_kwargs):
+        """Decode with the `<image>` trigger (modeling_bailingmm.py:206-301; modeling_bailing_moe.py:1769-1796).
         Returns the LongTensor `sequences` [1, T_in + n_new] like HF generate.  `forced_first_token` (extension
-        used by benchmarks/tests with random weights) overrides the first generated id."""
+        used by benchmarks/tests with random weights) overrides the first generated id.
+
+        Text tokens are picked greedily (the checkpoint's generation config: do_sample = false, mingunivision/config.json:30) or,
+        with `do_sample=True`, drawn the way HF generate draws them — the kwargs the reference forwards to it (:249-262):
+        `temperature`, `top_k` (0 = off; HF's default 50), `top_p` — on the device (mn_sample_logits), from the uniforms of
+        `generator` (a torch.Generator on the model's device; None = torch's default CUDA stream).  New token i of a call uses
+        the i-th uniform, so a run is reproducible from the generator's seed.  Any other generate kwarg raises TypeError: there
+        is no silent subset of HF generate here."""
+        if generate_kwargs:
+            raise TypeError(f"generate: unsupported arguments {sorted(generate_kwargs)} (supported beyond the reference's own: "
+                            "do_sample, temperature, top_k, top_p, generator)")
+        if do_sample and not (temperature > 0 and top_k >= 0 and 0 < top_p <= 1):
+            raise ValueError("generate: do_sample needs temperature > 0, top_k >= 0 and 0 < top_p <= 1")
         cfg = self.config.llm_config
         dev = self.device
         assert input_ids.shape[0] == 1, "the reference path is batch-size 1 (modeling_bailing_moe.py:1865)"
@@ -370,10 +389,11 @@ class MingUniVisionForConditionalGeneration:
         one = torch.ones(1, 1, dtype=am.dtype)
         seq0 = torch.zeros(1, dtype=torch.int32, device=dev)
         done = False
+        uniforms = torch.rand(max_new_tokens, device=dev, generator=generator) if do_sample else None
         # Greedy decode in chunks of `decode_chunk` tokens: argmax, embedding lookup and the row bookkeeping stay on the device, the
         # host reads the chunk's token ids once (one sync per chunk instead of one per token) and rolls back to the first EOS /
         # `<image>` it finds — greedy decoding is deterministic, the speculative steps behind such a token only wrote cache slots
-        # that the next real step overwrites.
+        # that the next real step overwrites.  Sampling keeps the scheme: new token i always uses uniforms[i], whatever the chunking.
         while not done and len(new_ids) < max_new_tokens:
             # every token of a chunk is fed (cache slot + rotary position cache_len + j) before the host looks at it: the
             # chunk must end inside the arena, also when the conversation stops a few slots short of t_max
@@ -388,7 +408,11 @@ class MingUniVisionForConditionalGeneration:
             ln = slot + 1
             toks_dev = []
             for j in range(n):
-                tok_dev = self.model.greedy(hidden[0:1])
+                if do_sample:
+                    i_new = len(new_ids) + j
+                    tok_dev = self.model.sample(hidden[0:1], uniforms[i_new:i_new + 1], temperature, top_k, top_p)
+                else:
+                    tok_dev = self.model.greedy(hidden[0:1])
                 if not new_ids and j == 0 and forced_first_token is not None:
                     tok_dev = torch.tensor([int(forced_first_token)], device=dev)
                 toks_dev.append(tok_dev)

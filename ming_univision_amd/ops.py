@@ -413,6 +413,18 @@ def lmhead_argmax(hidden, w, vocab_offset=0):
     return idx, val
 
 
+def sample_logits(logits, u, temperature=1.0, top_k=0, top_p=1.0, vocab_offset=0):
+    """Sampled pick of every row (mn_sample_logits: HF's temperature -> top-k -> top-p warpers, then the inverse CDF of the kept
+    tokens — descending score, ties by ascending id — at u[m] in [0, 1)).  logits fp32 [M, V], u fp32 [M] -> int64 [M]."""
+    _req(logits, torch.float32, "logits"); _req(u, torch.float32, "u")
+    M, V = logits.shape
+    assert logits.stride(1) == 1 and u.numel() == M and u.is_contiguous()
+    idx = torch.empty(M, dtype=torch.int64, device=logits.device)
+    check(lib().mn_sample_logits(ptr(logits), logits.stride(0), M, V, float(temperature), int(top_k), float(top_p), ptr(u), vocab_offset,
+                                 ptr(idx), current_stream()), "mn_sample_logits")
+    return idx
+
+
 # ---- fp8 weight mode (mingnative.h section 7) ----------------------------------------------------------------------------------
 def quant_fp8_rows(w):
     """bf16 [..., N, K] -> (e4m3 bytes uint8 [..., N, K], fp32 scales [..., N]): one power-of-two scale per output row,

@@ -472,6 +472,9 @@ class _TpDecoderBase:
     def greedy(self, hidden):
         return self.full.greedy(hidden)
 
+    def sample(self, hidden, u, temperature=1.0, top_k=50, top_p=1.0):
+        return self.full.sample(hidden, u, temperature, top_k, top_p)      # lm_head replicated: every rank draws the same token from the same u
+
     def prefill_many(self, embeds, seqs, past=0):
         """B prompts of equal length in lock-step (BailingMoeDecoder.prefill_many): embeds fp32 [B, T, H] -> hidden [B, T, H]."""
         B, T, H = embeds.shape
@@ -544,6 +547,9 @@ class TpSimGroup(_TpDecoderBase):
         for sh in self.shards:
             sh.kv_cache[:, dst, :, :, :n].copy_(sh.kv_cache[:, src, :, :, :n])
 
+    def sample(self, hidden, u, temperature=1.0, top_k=50, top_p=1.0):
+        return self.full.sample(hidden, u, temperature, top_k, top_p)
+
     def greedy(self, hidden):
         """The vocabulary-parallel greedy pick of TpRank.greedy with every rank's slice computed in this process."""
         lm = self.full.lm_head
@@ -612,6 +618,15 @@ class TpRank(_TpDecoderBase):
 
     def logits(self, hidden):
         return self._logits(hidden) if self._logits is not None else self.full.logits(hidden)
+
+    def sample(self, hidden, u, temperature=1.0, top_k=50, top_p=1.0):
+        """Sampled pick: the warped distribution needs the whole row of logits, so every rank computes it from the replicated lm_head
+        and draws at the same uniform (the callers seed their generators alike) — identical tokens on all ranks, no exchange."""
+        if self.full is None or self.full.lm_head is None:
+            raise RuntimeError("TpRank.sample needs the lm_head (build the rank from a full decoder with vocabulary weights)")
+        ids = self.full.sample(hidden, u, temperature, top_k, top_p)
+        self.check_err()
+        return ids
 
     def greedy(self, hidden):
         """Greedy pick with the lm_head split over the vocabulary (each rank streams V / world rows of it): mn_lmhead_argmax on the
