@@ -358,6 +358,7 @@ size_t sk_ws_need(int M, std::initializer_list<std::array<int, 3>> shapes) {   /
 
 }  // namespace
 
+#include "stream_fuse.h"
 #include "wide_glue.h"
 #include "wide_rf.inl"
 
@@ -373,12 +374,23 @@ static bool rf_fp8_ok(const mn_rf_head* h) {
   return h->wfmt == MN_W_FP8_E4M3 && h->w12_scale && h->w3_scale && h->w <= 4096 && (h->w % 16) == 0 && (h->hidden % 16) == 0;
 }
 
+// <= 4 rows (the CFG rows of one image — the reference's call shape): the SwiGLU glue launch is folded into w3's prologue
+// (stream_fuse.h): three launches per ResBlock instead of four.  g_rf_fuse: dev-library A/B switch.
+static int g_rf_fuse = 1;
+#ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_rf_tune_fuse(int on) { g_rf_fuse = on; }
+#endif
+static bool rf_fused_shape_ok(const mn_rf_head* h, int rows) {
+  return rows <= FUSE_MAX_ROWS && rf_chain_ok(h, rows) &&
+         stream_fused_ok(h->wfmt, rows, h->w, h->hidden, stream_slices(h->wfmt, rows, 2 * h->hidden, h->w));
+}
+
 // fp8 adaLN: the modulations of all Euler steps as ONE streaming launch on e4m3 bytes when their rows fit it
 static bool rf_ada_w8(const mn_rf_head* h, int rows) { return h->wfmt && h->ada_q && h->ada_scale && (int64_t)h->steps * rows <= 64; }
 
 static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, float** z, float** c, float** ada,
                        float** hh, float** hid, float** v, float** x, bf16_t** y, unsigned** bar, char** skws,
-                       size_t* skws_bytes, bf16_t** ya, bf16_t** yb, float** pbuf, float** pada = nullptr) {
+                       size_t* skws_bytes, bf16_t** ya, bf16_t** yb, float** pbuf, float** pada = nullptr, float** pbuf3 = nullptr) {
   Carver cv(ws, cap, ws == nullptr);
   const int A = h->depth * 3 * h->w + 2 * h->w;
   *z = cv.take<float>((size_t)rows * h->z_dim);
@@ -405,6 +417,10 @@ static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, floa
   const int SRn = h->steps * rows;
   float* pa = cv.take<float>(rf_ada_w8(h, rows) ? (size_t)mn_stream_mfma_w8_slices(SRn, A, h->w) * SRn * A : 0);
   if (pada) *pada = pa;
+  // fused w3: its slabs live beside w12's (its prologue reads those while other workgroups already write w3's); the workspace does
+  // not depend on the A/B switch
+  float* p3b = cv.take<float>(rf_fused_shape_ok(h, rows) ? p3 * rows : 0);
+  if (pbuf3) *pbuf3 = p3b;
   return cv.off;
 }
 
@@ -438,10 +454,10 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   char* skws;
   size_t skws_bytes;
   bf16_t *ya, *yb;
-  float *pbuf, *pada;
+  float *pbuf, *pada, *pbuf3;
   const size_t need = rf_carve(h, rows, workspace, workspace_bytes, &z, &c, &ada, &hh, &hid, &v, &x, &y, &bar, &skws, &skws_bytes,
-                               &ya, &yb, &pbuf, &pada);
-  const bool chain = rf_chain_ok(h, rows);
+                               &ya, &yb, &pbuf, &pada, &pbuf3);
+  const bool chain = rf_chain_ok(h, rows), fused = g_rf_fuse && rf_fused_shape_ok(h, rows);
   t_sk_ws = skws; t_sk_ws_bytes = skws_bytes;
   if (need > workspace_bytes) { mn_set_error("mn_rf_sample: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
   hipStream_t st = mn_stream(stream);
@@ -485,13 +501,20 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
         const float* mod = ada + (int64_t)b * 3 * w;
         int nz = stream_dense(h->wfmt, ya, h->w12[b], h->wfmt ? h->w12_scale[b] : nullptr, pbuf, rows, 2 * hid_n, w, stream);
         if (nz < 0) return nz;
-        hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)rows * hid_n, 1024)), dim3(256), 0, st, pbuf, nz,
-                           rows, hid_n, h->b12[b], yb);
-        nz = stream_dense(h->wfmt, yb, h->w3[b], h->wfmt ? h->w3_scale[b] : nullptr, pbuf, rows, w, hid_n, stream);
+        float* p3 = pbuf;
+        if (fused) {               // <= 4 rows: w3 builds SwiGLU(w12's slabs + bias) itself — no glue launch in between
+          const StreamFuse f{pbuf, nz, h->b12[b]};
+          p3 = pbuf3;
+          nz = stream_fused(h->wfmt, h->w3[b], h->wfmt ? h->w3_scale[b] : nullptr, p3, rows, w, hid_n, f, stream);
+        } else {
+          hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)rows * hid_n, 1024)), dim3(256), 0, st, pbuf, nz,
+                             rows, hid_n, h->b12[b], yb);
+          nz = stream_dense(h->wfmt, yb, h->w3[b], h->wfmt ? h->w3_scale[b] : nullptr, pbuf, rows, w, hid_n, stream);
+        }
         if (nz < 0) return nz;
         const bool last = b + 1 == h->depth;
         const float* nmod = last ? ada + (int64_t)h->depth * 3 * w : ada + (int64_t)(b + 1) * 3 * w;
-        hipLaunchKernelGGL(rf_glue_resid_ln_split_kernel, dim3(rows), dim3(1024), 0, st, pbuf, nz, rows, w, h->b3[b],
+        hipLaunchKernelGGL(rf_glue_resid_ln_split_kernel, dim3(rows), dim3(1024), 0, st, p3, nz, rows, w, h->b3[b],
                            mod + 2 * w, hh, last ? (const bf16_t*)nullptr : h->ln_g[b + 1],
                            last ? (const bf16_t*)nullptr : h->ln_b[b + 1], nmod, nmod + w, (int64_t)A, ya);
       }

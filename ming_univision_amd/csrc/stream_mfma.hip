@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "stream_fuse.h"
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -51,14 +52,27 @@ __device__ __forceinline__ int wslot(int row, int slot) { return row * (WCH * 2)
 // x image: element offset of 16-byte slot `slot` of row `row` (row stride = ks elements, a multiple of 256)
 __device__ __forceinline__ int xslot(int row, int srow, int slot) { return row * srow + ((slot ^ (row & 15)) << 3); }
 
+// ---- fused form for the RF ResBlock chain at <= 4 rows (the reference's call shape: the CFG rows of ONE image) ----
+// At 2-3 rows a ResBlock was four launches — w12, [slab sum + SwiGLU + split], w3, [slab sum + gated residual + LayerNorm-modulate +
+// split] — and each glue launch costs 5-6 us of a 40 us block although it moves a few KiB.  FUSE_SWIGLU folds the first one into
+// the w3 launch: the activation image a workgroup parks in LDS is COMPUTED from the w12 launch's slabs instead of copied,
+//   x[m, k] = silu(b[k] + sum_z Pp[z][m][k]) * (b[K + k] + sum_z Pp[z][m][K + k])
+// (every workgroup redoes it for its K-slice: 32 KiB of L2 reads at 2 rows, free next to its 200 KiB of weights — w3 takes 11.2 us
+// with or without).  RF sampler 8.35 -> 7.70 ms at 2 rows, 6.32 -> 5.74 in fp8 (profiles/r04_rf_fused_chain_ab.txt).  The same
+// file holds the negative result for the second glue launch: LayerNorm needs the whole row, so folding it takes a grid-wide
+// hand-off — the last-arriving workgroup of each column group reducing the slabs (write-through stores, one relaxed ticket, sc1
+// loads) measured 7.4 us of tail against the 6.0 us launch it replaced; removed again.
+constexpr int FUSE_PNZ = 6;         // slabs of the previous launch the prologue sums from registers (one float4 element per thread)
+
 // Y: bf16, hi rows at Y, lo rows at Y + y_lo (row stride K).  P: [nz][p_rows][Ntot] fp32, p_slab = p_rows * Ntot.
 // W8: the weights are OCP e4m3 bytes [Ntot][K] with one fp32 scale per output row (W[n,k] = e4m3(Wq[n,k]) * wscale[n]): a chunk
 // is 4 KiB of HBM traffic instead of 8, converted to bf16 (exact) in registers on its way into the wave's LDS tile, so the MFMA
 // loop is the bf16 one; the row scale multiplies the fp32 accumulators when a tile's partials are stored.
-template <int MT, int DEPTH, int MAXT, bool W8>
+template <int MT, int DEPTH, int MAXT, bool W8, int FUSE = FUSE_NONE>
 __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
                                                                const void* __restrict__ Wv, const float* __restrict__ wscale,
-                                                               float* __restrict__ P, int64_t p_slab, int M, int Ntot, int K, int ks) {
+                                                               float* __restrict__ P, int64_t p_slab, int M, int Ntot, int K, int ks,
+                                                               StreamFuse f = StreamFuse{}) {
   const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(Wv);
   const uint8_t* __restrict__ Wq = reinterpret_cast<const uint8_t*>(Wv);
   extern __shared__ __attribute__((aligned(16))) bf16_t xs_raw[];      // [2][16*MT][ks] x image, then nw x 8 KiB weight tiles
@@ -103,7 +117,36 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
       }
     }
   };
-  load_x();   // before the weights: loads retire in order, so the x image never waits behind a weight chunk
+  // fused form: the operands of the x image this workgroup BUILDS go to registers first, like the copied image's
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+  constexpr int NPZ = FUSE ? FUSE_PNZ : 1;
+  f4 pg[NPZ], pu[NPZ];
+  u2v bg = {0u, 0u}, bu = {0u, 0u};
+  const int kq = ks >> 2;                           // float4 elements per row of the slice; thread tid builds element (fm, fq4)
+  const int fm = FUSE ? tid / kq : 0, fq4 = tid - fm * kq;
+  const bool fon = FUSE && fm < M && fq4 * 4 < klen;
+  if constexpr (FUSE == FUSE_NONE) {
+    load_x();   // before the weights: loads retire in order, so the x image never waits behind a weight chunk
+  } else {
+#pragma unroll
+    for (int zz = 0; zz < NPZ; ++zz) pg[zz] = pu[zz] = f4{0.f, 0.f, 0.f, 0.f};
+    if (fon) {
+      const int64_t pslab = (int64_t)M * 2 * K;
+      const float* pp = f.pP + (int64_t)fm * 2 * K + k0 + fq4 * 4;
+#pragma unroll
+      for (int zz = 0; zz < NPZ; ++zz) {
+        if (zz < f.pnz) {
+          pg[zz] = *reinterpret_cast<const f4*>(pp + zz * pslab);
+          pu[zz] = *reinterpret_cast<const f4*>(pp + zz * pslab + K);
+        }
+      }
+      if (f.pb) {
+        bg = *reinterpret_cast<const u2v*>(f.pb + k0 + fq4 * 4);
+        bu = *reinterpret_cast<const u2v*>(f.pb + K + k0 + fq4 * 4);
+      }
+    }
+  }
   // ---- weight ring: one chunk (8 KiB per wave) in flight in registers
   constexpr int NI = W8 ? 4 : 8;                    // 16-byte loads per lane and chunk
   u32x4 ring[DEPTH][NI];
@@ -130,14 +173,32 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
     if (d < total) issue(ring[d]);
+  if constexpr (FUSE == FUSE_NONE) {
 #pragma unroll
-  for (int j = 0; j < RPW; ++j) {
-    const int rr = wave + j * nw;
-    const int h = rr >= xr_used ? 1 : 0, m = rr - h * xr_used;
+    for (int j = 0; j < RPW; ++j) {
+      const int rr = wave + j * nw;
+      const int h = rr >= xr_used ? 1 : 0, m = rr - h * xr_used;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int slot = lane + u * 64;
-      if (rr < 2 * xr_used && slot < slots) *reinterpret_cast<u32x4*>(xs_raw + xslot(h * XR + m, srow, slot)) = xv[j][u];
+      for (int u = 0; u < 2; ++u) {
+        const int slot = lane + u * 64;
+        if (rr < 2 * xr_used && slot < slots) *reinterpret_cast<u32x4*>(xs_raw + xslot(h * XR + m, srow, slot)) = xv[j][u];
+      }
+    }
+  } else {
+    // rows >= M and columns >= klen of the image are zero: clear it, then write what this launch computes
+    for (int i = tid; i < 2 * XR * (srow >> 3); i += blockDim.x) *reinterpret_cast<u32x4*>(xs_raw + i * 8) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    if (fon) {
+      f4 g = {bf16lo_to_f32(bg.x), bf16hi_to_f32(bg.x), bf16lo_to_f32(bg.y), bf16hi_to_f32(bg.y)};
+      f4 u = {bf16lo_to_f32(bu.x), bf16hi_to_f32(bu.x), bf16lo_to_f32(bu.y), bf16hi_to_f32(bu.y)};
+#pragma unroll
+      for (int zz = 0; zz < NPZ; ++zz) { g += pg[zz]; u += pu[zz]; }
+      uint32_t h0, l0, h1, l1;
+      split_pk_bf16(silu_f(g[0]) * u[0], silu_f(g[1]) * u[1], h0, l0);
+      split_pk_bf16(silu_f(g[2]) * u[2], silu_f(g[3]) * u[3], h1, l1);
+      const int off = xslot(fm, srow, fq4 >> 1) + (fq4 & 1) * 4;
+      *reinterpret_cast<u2v*>(xs_raw + off) = u2v{h0, h1};
+      *reinterpret_cast<u2v*>(xs_raw + XR * srow + off) = u2v{l0, l1};
     }
   }
   __syncthreads();
@@ -268,7 +329,41 @@ void stream_launch(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, c
   else stream_launch_d<MT, 1, 1024, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st);
 }
 
+template <bool W8>
+void stream_launch_fused(const StreamPlan& pl, const void* W, const float* wscale, float* P, int M, int Ntot, int K, const StreamFuse& f,
+                         hipStream_t st) {
+  static bool opted[2] = {false, false};
+  const int big = pl.nw > 8;
+  if (!opted[big]) {
+    if (big) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_lds_kernel<1, 1, 1024, W8, FUSE_SWIGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP);
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_lds_kernel<1, 1, 512, W8, FUSE_SWIGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP);
+    opted[big] = true;
+  }
+  if (big)
+    hipLaunchKernelGGL((stream_mfma_lds_kernel<1, 1, 1024, W8, FUSE_SWIGLU>), dim3(pl.gx, pl.nz, 1), dim3(pl.nw * 64), pl.lds, st, (const bf16_t*)nullptr,
+                       (int64_t)0, W, wscale, P, (int64_t)M * Ntot, M, Ntot, K, pl.ks, f);
+  else
+    hipLaunchKernelGGL((stream_mfma_lds_kernel<1, 1, 512, W8, FUSE_SWIGLU>), dim3(pl.gx, pl.nz, 1), dim3(pl.nw * 64), pl.lds, st, (const bf16_t*)nullptr,
+                       (int64_t)0, W, wscale, P, (int64_t)M * Ntot, M, Ntot, K, pl.ks, f);
+}
+
 }  // namespace
+
+// The launch plan of the fused form is the plain one's (same slices, same slabs).
+bool stream_fused_ok(int wfmt, int M, int Ntot, int K, int prev_nz) {
+  if (M < 1 || M > FUSE_MAX_ROWS || (K % (wfmt ? 16 : 8)) != 0 || prev_nz < 1 || prev_nz > FUSE_PNZ) return false;
+  const StreamPlan pl = stream_plan(1, Ntot, K, mn_num_cus(), wfmt != 0);
+  return (int64_t)M * (pl.ks / 4) <= (int64_t)pl.nw * 64;      // one float4 element of the x image per thread
+}
+
+int stream_fused(int wfmt, const void* W, const float* wscale, float* P, int M, int Ntot, int K, const StreamFuse& f, void* stream) {
+  MN_CHECK_ARG(W && P && f.pP && stream_fused_ok(wfmt, M, Ntot, K, f.pnz) && (!wfmt || wscale), "stream_fused: shape cannot run fused");
+  const StreamPlan pl = stream_plan(1, Ntot, K, mn_num_cus(), wfmt != 0);
+  if (wfmt) stream_launch_fused<true>(pl, W, wscale, P, M, Ntot, K, f, mn_stream(stream));
+  else stream_launch_fused<false>(pl, W, wscale, P, M, Ntot, K, f, mn_stream(stream));
+  MN_CHECK_LAUNCH("stream_fused");
+  return pl.nz;
+}
 
 #ifdef MN_DEV_HOOKS
 extern "C" MN_DEV_API void mn_stream_tune_plan(int kch, int nw) { g_kch = kch; g_nw = nw; }
