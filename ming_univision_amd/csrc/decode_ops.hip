@@ -660,8 +660,12 @@ extern "C" int mn_attn_decode_split(const float* q, int M, int n_q, int n_kv, in
 // projection (optionally as nz K-slice partial slabs): what mn_rope_kv_append_3d / mn_rope_kv_from_partials followed by
 // mn_attn_decode_split compute, one launch fewer per layer and step and no q round trip.  Needs row_len == row_slot + 1, at most 64
 // rows (the many-row GQA kernel keeps the separate append) and n_q / n_kv in {1, 2, 4}; mn_attn_fused_ok says whether a shape qualifies.
+static int g_attn_fuse = 1;                          // dev-library A/B switch
+#ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_attn_tune_fuse(int on) { g_attn_fuse = on; }
+#endif
 extern "C" int mn_attn_fused_ok(int M, int n_q, int n_kv, int hd) {
-  if (g_kv_round_bf16) return 0;                     // the bf16-KV measurement hook lives in the stand-alone append kernel
+  if (g_kv_round_bf16 || !g_attn_fuse) return 0;     // the bf16-KV measurement hook lives in the stand-alone append kernel
   const int ratio = n_kv > 0 && n_q % n_kv == 0 ? n_q / n_kv : 0;
   return M >= 1 && !attn_use_gqa(M, n_q, n_kv, hd) && (hd == 64 || hd == 128) && (ratio == 1 || ratio == 2 || ratio == 4);
 }
