@@ -587,9 +587,181 @@ __global__ void attn_decode_combine_kernel(const float* __restrict__ partial, in
   }
 }
 
+// -------------------------------------------------------------------------------------------
+// One-launch form for a few rows with short caches (the reference's call shapes: 1 row of text decode, the 2-3 CFG rows of an image,
+// the semantic decoder's row; <= 1024 keys): one 16-wave workgroup per (row, q head).  The key range is split over the WAVES of the
+// workgroup, their (acc, max, sum) partials meet in LDS — no partial round trip through memory and no combine launch (split 9.8 us +
+// combine 4.7 us per layer at 2 rows before).  Scores and PV run on 16 / 8 keys' loads in flight per wave.
+// FUSED: as in the split kernel the launch takes the raw QKV row; here every workgroup rotates its q head AND the new key of its KV
+// group into LDS and attends to that key from there (the first q head of the group also writes the K / V line into the arena: no
+// workgroup reads the new line from memory in this launch, so the heads of a group need no ordering among themselves).
+// (A form with ALL of a wave's K and V loads issued before the first score — <= 24 keys per wave, 123 VGPRs — measured no faster:
+// 2.046 vs 2.059 ms per 28-layer step at 1 row / 296 keys, slower at 40 keys; removed.  profiles/r04_attn_fused_ab.txt)
+template <int HD, bool FUSED>
+__global__ __launch_bounds__(1024) void attn_decode_one_kernel(
+    const float* __restrict__ q, int n_q, int n_kv, const float* __restrict__ kv_cache, int64_t t_max,
+    const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_len, const uint8_t* __restrict__ key_mask,
+    int64_t ld_mask, int chunk_cap, float* __restrict__ out, bf16_t* __restrict__ split, int M, const AttnFuse fz) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];      // [16][chunk_cap] scores, [16][HD + 2] partials, [3][HD] q / new k / new v
+  constexpr int NW = 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x, h = blockIdx.y;
+  float* sc = sm + wave * chunk_cap;
+  float* part = sm + NW * chunk_cap;
+  float* qs = part + NW * (HD + 2);
+  float* knew = qs + HD;
+  float* vnew = knew + HD;
+  const int len = row_len[m];
+  int chunk = (len + NW - 1) / NW;
+  chunk = (chunk + 3) & ~3;
+  const int j0 = wave * chunk, j1 = min(len, j0 + chunk);
+  const int kvh = h / (n_q / n_kv);
+  const int64_t seq = row_seq[m];
+  const float* Kb = kv_cache + ((seq * 2 + 0) * n_kv + kvh) * t_max * HD;
+  const float* Vb = kv_cache + ((seq * 2 + 1) * n_kv + kvh) * t_max * HD;
+  const uint8_t* mk = key_mask ? key_mask + (int64_t)m * ld_mask : nullptr;
+  int slot = -1;                                 // FUSED: the new key lives in LDS, not in the arena
+  if constexpr (FUSED) {
+    constexpr int half = HD / 2;
+    slot = fz.row_slot[m];
+    if (wave < 3 && lane < half) {               // wave 0: q head h, wave 1: the group's new k, wave 2: its new v
+      const float* row = fz.qkv + (int64_t)m * fz.ldqkv;
+      const int head = wave == 0 ? h : (wave == 1 ? n_q + kvh : n_q + n_kv + kvh);
+      const float* p_ = row + (int64_t)head * HD + lane;
+      float x1 = p_[0], x2 = p_[half];
+      for (int z = 1; z < fz.nz; ++z) { x1 += p_[z * fz.slab]; x2 += p_[z * fz.slab + half]; }
+      if (fz.rope && wave < 2) {
+        const int stream = fz.sec_t <= 0 ? 0 : (lane < fz.sec_t ? 0 : (lane < fz.sec_t + fz.sec_h ? 1 : 2));
+        const int pos = fz.row_pos[stream * fz.M + m];
+        const float c = fz.cos_tab[(int64_t)pos * half + lane], sn = fz.sin_tab[(int64_t)pos * half + lane];
+        const float o1 = x1 * c - x2 * sn, o2 = x2 * c + x1 * sn;
+        x1 = o1; x2 = o2;
+      }
+      if (wave == 0) { x1 *= fz.q_scale; x2 *= fz.q_scale; }
+      float* dst = wave == 0 ? qs : (wave == 1 ? knew : vnew);
+      dst[lane] = x1; dst[lane + half] = x2;
+      if (wave > 0 && h % (n_q / n_kv) == 0 && (uint64_t)slot < (uint64_t)t_max) {     // the arena line, once per KV group
+        float* ad = fz.kv_cache_w + (((seq * 2 + (wave - 1)) * n_kv + kvh) * t_max + slot) * HD;
+        ad[lane] = x1; ad[lane + half] = x2;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- scores: 16 lanes per key, 4 keys per step, 4 steps' loads in flight
+  constexpr int PER = HD / 16;
+  constexpr int DPL = HD / 64;
+  const int sub = lane & 15, kq = lane >> 4;
+  const int n = max(0, j1 - j0);
+  float qv[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) qv[i] = FUSED ? qs[sub * PER + i] : q[((int64_t)m * n_q + h) * HD + sub * PER + i];
+  float mx = -INFINITY;
+  for (int jb = j0; jb < j0 + chunk; jb += 16) {
+    f32x4 kv[4][PER / 4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = jb + u * 4 + kq;
+#pragma unroll
+      for (int i = 0; i < PER / 4; ++i) {
+        kv[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j < j1) {
+          if (FUSED && j == slot) kv[u][i] = *reinterpret_cast<const f32x4*>(knew + sub * PER + i * 4);
+          else kv[u][i] = *reinterpret_cast<const f32x4*>(Kb + (int64_t)j * HD + sub * PER + i * 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = jb + u * 4 + kq;
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < PER / 4; ++i) {
+        d = fmaf(kv[u][i].x, qv[i * 4], d); d = fmaf(kv[u][i].y, qv[i * 4 + 1], d);
+        d = fmaf(kv[u][i].z, qv[i * 4 + 2], d); d = fmaf(kv[u][i].w, qv[i * 4 + 3], d);
+      }
+      d = row16_sum(d);
+      const bool keep = j < j1 && (!mk || mk[j] != 0);
+      const float sv = keep ? d : -INFINITY;
+      if (sub == 0 && j < j0 + chunk && (j - j0) < chunk_cap) sc[j - j0] = sv;
+      mx = fmaxf(mx, sv);
+    }
+  }
+  mx = wave_max(mx);
+  __syncthreads();
+  float l = 0.f;
+  for (int j = lane; j < n; j += 64) {
+    const float p = (mx == -INFINITY) ? 0.f : __expf(sc[j] - mx);
+    sc[j] = p;
+    l += p;
+  }
+  l = wave_sum(l);
+  __syncthreads();
+  // ---- PV: lane owns HD / 64 dims, 8 keys' loads in flight
+  float acc[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) acc[i] = 0.f;
+  for (int jb = 0; jb < n; jb += 8) {
+    float v[8][DPL];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int i = 0; i < DPL; ++i) {
+        const int j = j0 + jb + u;
+        v[u][i] = 0.f;
+        if (jb + u < n) v[u][i] = (FUSED && j == slot) ? vnew[lane * DPL + i] : Vb[(int64_t)j * HD + lane * DPL + i];
+      }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float p = jb + u < n ? sc[jb + u] : 0.f;
+#pragma unroll
+      for (int i = 0; i < DPL; ++i) acc[i] = fmaf(p, v[u][i], acc[i]);
+    }
+  }
+  float* pw = part + wave * (HD + 2);
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) pw[lane * DPL + i] = acc[i];
+  if (lane == 0) { pw[HD] = mx; pw[HD + 1] = l; }
+  __syncthreads();
+  // ---- the 16 waves' partials -> the head's output
+  const int d = threadIdx.x;
+  if (d >= HD) return;
+  float mall = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) mall = fmaxf(mall, part[w * (HD + 2) + HD]);
+  float lt = 0.f, at = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const float ms = part[w * (HD + 2) + HD];
+    const float fw = (ms == -INFINITY) ? 0.f : __expf(ms - mall);
+    lt = fmaf(fw, part[w * (HD + 2) + HD + 1], lt);
+    at = fmaf(fw, part[w * (HD + 2) + d], at);
+  }
+  float v;
+  if (lt > 0.f) {
+    v = at / lt;
+  } else {      // no attended key: uniform over the row's keys (see attn_decode_combine_kernel)
+    float sum = 0.f;
+    for (int j = 0; j < len; ++j) sum += (FUSED && j == slot) ? vnew[d] : Vb[(int64_t)j * HD + d];
+    v = len > 0 ? sum / (float)len : 0.f;
+  }
+  const int64_t o = ((int64_t)m * n_q + h) * HD + d;
+  if (out) out[o] = v;
+  if (split) {
+    const bf16_t hi = f32_to_bf16(v);
+    split[o] = hi;
+    split[(int64_t)M * n_q * HD + o] = f32_to_bf16(v - bf16_to_f32(hi));
+  }
+}
+
 // Key-range splits (flash-decoding): enough workgroups to fill the chip at few rows, none needed at hundreds of rows;
 // one split never holds more than 4096 keys (its scores live in LDS).
 static bool attn_use_gqa(int M, int n_q, int n_kv, int hd) { return M > 64 && hd == 128 && n_q == 4 * n_kv; }
+// the one-launch form: <= g_one_rows rows whose caches hold <= 1024 keys (dev-library A/B: mn_attn_tune_one)
+static int g_one_rows = 16;
+#ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_attn_tune_one(int max_rows) { g_one_rows = max_rows; }
+#endif
+static bool attn_use_one(int M, int64_t t_max) { return M <= g_one_rows && t_max <= 1024; }
 static int attn_splits(int M, int n_q, int64_t t_max) {
   int S = (int)mn_cdiv(t_max, 32);
   if (S > 32) S = 32;
@@ -608,6 +780,22 @@ extern "C" size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t
 static int attn_decode_launch(const float* q, const AttnFuse* fz, int M, int n_q, int n_kv, int hd, const float* kv_cache, int64_t t_max,
                               const int32_t* row_seq, const int32_t* row_len, const uint8_t* key_mask, int64_t ld_mask, float* out,
                               uint16_t* split, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st0 = mn_stream(stream);
+  if (attn_use_one(M, t_max)) {                 // a few rows, short caches: one launch, the key split lives inside the workgroup
+    int cc = (int)mn_cdiv(t_max, 16);
+    cc = (cc + 3) & ~3;
+    const size_t lds1 = ((size_t)16 * cc + 16 * (hd + 2) + 3 * hd) * sizeof(float);
+    const AttnFuse nf{};
+    const AttnFuse& fa = fz ? *fz : nf;
+    const dim3 g1(M, n_q), b1(1024);
+#define MN_ONE(HD_, F_) hipLaunchKernelGGL((attn_decode_one_kernel<HD_, F_>), g1, b1, lds1, st0, q, n_q, n_kv, kv_cache, t_max, row_seq, row_len, \
+                                           key_mask, ld_mask, cc, out, split, M, fa)
+    if (hd == 128) { if (fz) MN_ONE(128, true); else MN_ONE(128, false); }
+    else           { if (fz) MN_ONE(64, true); else MN_ONE(64, false); }
+#undef MN_ONE
+    MN_CHECK_LAUNCH("mn_attn_decode(one launch)");
+    return MN_OK;
+  }
   const int S = attn_splits(M, n_q, t_max);
   const size_t need = (size_t)M * n_q * S * (hd + 2) * sizeof(float);
   if (workspace_bytes < need) { mn_set_error("mn_attn_decode: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
@@ -660,12 +848,16 @@ extern "C" int mn_attn_decode_split(const float* q, int M, int n_q, int n_kv, in
 // projection (optionally as nz K-slice partial slabs): what mn_rope_kv_append_3d / mn_rope_kv_from_partials followed by
 // mn_attn_decode_split compute, one launch fewer per layer and step and no q round trip.  Needs row_len == row_slot + 1, at most 64
 // rows (the many-row GQA kernel keeps the separate append) and n_q / n_kv in {1, 2, 4}; mn_attn_fused_ok says whether a shape qualifies.
-static int g_attn_fuse = 1;                          // dev-library A/B switch
+// Where the append rides the attention launch (tools/exp/attn_fused_ab.py, profiles/r04_attn_fused_ab.txt): always in the one-launch form
+// (every row count it serves gains 1-2 %: each workgroup keeps the new key in LDS, no hazard, no redundant reads worth counting); in
+// the split form at ONE row only (2.00 -> 1.92 ms per 28-layer step; from 2 rows on every split re-reduces the QKV slabs: 2.59 -> 2.74).
+static int g_attn_fuse = 1;                          // dev-library A/B switch: 0 = never fused
 #ifdef MN_DEV_HOOKS
 extern "C" MN_DEV_API void mn_attn_tune_fuse(int on) { g_attn_fuse = on; }
 #endif
-extern "C" int mn_attn_fused_ok(int M, int n_q, int n_kv, int hd) {
+extern "C" int mn_attn_fused_ok(int M, int n_q, int n_kv, int hd, int64_t t_max) {
   if (g_kv_round_bf16 || !g_attn_fuse) return 0;     // the bf16-KV measurement hook lives in the stand-alone append kernel
+  if (!attn_use_one(M, t_max) && M > 1) return 0;
   const int ratio = n_kv > 0 && n_q % n_kv == 0 ? n_q / n_kv : 0;
   return M >= 1 && !attn_use_gqa(M, n_q, n_kv, hd) && (hd == 64 || hd == 128) && (ratio == 1 || ratio == 2 || ratio == 4);
 }
@@ -674,7 +866,7 @@ extern "C" int mn_attn_decode_fused(const float* qkv, int64_t ldqkv, int nz, int
                                     const int32_t* row_pos, int sec_t, int sec_h, float q_scale, float* kv_cache, int64_t t_max,
                                     const int32_t* row_len, const uint8_t* key_mask, int64_t ld_mask, float* out, uint16_t* split,
                                     void* workspace, size_t workspace_bytes, void* stream) {
-  MN_CHECK_ARG(mn_attn_fused_ok(M, n_q, n_kv, hd) && nz >= 1, "mn_attn_decode_fused: unsupported shape");
+  MN_CHECK_ARG(mn_attn_fused_ok(M, n_q, n_kv, hd, t_max) && nz >= 1, "mn_attn_decode_fused: unsupported shape");
   MN_CHECK_ARG(qkv && kv_cache && row_seq && row_slot && row_len && (out || split) && workspace, "mn_attn_decode_fused: null pointer");
   MN_CHECK_ARG(!rope || (cos_tab && sin_tab && row_pos), "mn_attn_decode_fused: rope needs tables and positions");
   MN_CHECK_ARG(sec_t >= 0 && sec_h >= 0 && sec_t + sec_h <= hd / 2, "mn_attn_decode_fused: bad rotary sections %d/%d", sec_t, sec_h);

@@ -24,7 +24,7 @@ extern "C" int mn_rope_kv_from_partials(const float* qkv, int64_t ldqkv, int nz,
 extern "C" int mn_attn_decode_split(const float* q, int M, int n_q, int n_kv, int hd, const float* kv_cache, int64_t t_max,
                                     const int32_t* row_seq, const int32_t* row_len, const uint8_t* key_mask, int64_t ld_mask,
                                     float* out, uint16_t* split, void* workspace, size_t workspace_bytes, void* stream);
-extern "C" int mn_attn_fused_ok(int M, int n_q, int n_kv, int hd);
+extern "C" int mn_attn_fused_ok(int M, int n_q, int n_kv, int hd, int64_t t_max);
 extern "C" int mn_attn_decode_fused(const float* qkv, int64_t ldqkv, int nz, int64_t slab, int M, int n_q, int n_kv, int hd, int rope,
                                     const float* cos_tab, const float* sin_tab, const int32_t* row_seq, const int32_t* row_slot,
                                     const int32_t* row_pos, int sec_t, int sec_h, float q_scale, float* kv_cache, int64_t t_max,
@@ -951,10 +951,7 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
   t_sk_ws = w.sk_ws; t_sk_ws_bytes = w.sk_ws_bytes;
   // rows of DISTINCT cache sequences (decode steps; not a prefill chunk, whose rows read each other's new K / V lines): RoPE + KV
   // append ride the attention launch
-  // RoPE + KV append inside the attention launch pays at ONE row only (text decode: 2.00 -> 1.92 ms per 28-layer step); from 2 rows on
-  // the splits' redundant reduction of the QKV slabs costs more than the launch it saves (2 rows 2.59 -> 2.74 ms, 16 rows 5.89 -> 6.07,
-  // 64 rows even; tools/exp/attn_fused_ab.py, profiles/r04_attn_fused_ab.txt)
-  const bool fuse_attn = (flags & MN_STEP_DISTINCT_SEQUENCES) && M == 1 && mn_attn_fused_ok(M, nq, nkv, hd);
+  const bool fuse_attn = (flags & MN_STEP_DISTINCT_SEQUENCES) && mn_attn_fused_ok(M, nq, nkv, hd, t_max);
   if (llm_chain_ok(m, M) && !(image_mask && m->image_gate)) {
     // ---- chain path: 12 launches per layer (11 at 2 rows) instead of 18.  glue = llm_glue_kernel.
     const int E = m->n_experts, S = m->n_shared_slots, G = E + S, ad = nq * hd, P = M * n_slot;
@@ -1151,7 +1148,7 @@ extern "C" int mn_semdec_step(const mn_semdec* s, const float* latent_norm, int 
     mn_skinny_args a = sk(w.h, D, s->wqkv[l], D, s->bqkv[l], w.qkv, 3 * D, M, 3 * D, D);
     a.prologue = MN_PRO_LN; a.ln_g = s->ln1_g[l]; a.ln_b = s->ln1_b[l]; a.eps = 1e-6f;
     MN_TRY(mn_skinny_gemm(&a, stream));
-    if (M == 1 && mn_attn_fused_ok(M, nh, nh, 64)) {     // one row (batch 1): the K / V append rides the attention launch (see mn_llm_step_ex)
+    if (mn_attn_fused_ok(M, nh, nh, 64, t_max)) {     // one row (batch 1): the K / V append rides the attention launch (see mn_llm_step_ex)
       MN_TRY(mn_attn_decode_fused(w.qkv, 3 * D, 1, 0, M, nh, nh, 64, 0, nullptr, nullptr, row_seq, row_slot, nullptr, 0, 0, 0.125f, kv_l,
                                   t_max, row_len, nullptr, 0, w.attn, nullptr, w.attn_ws, w.attn_ws_bytes, stream));
     } else {
