@@ -286,6 +286,80 @@ __global__ void rf_euler_kernel(const float* __restrict__ v0, float* __restrict_
   for (int r = 0; r < rows; ++r) x[r * target + i] += vg * step;
 }
 
+// The boundary between two Euler steps of the matrix-core chain in ONE launch (one workgroup per row; five launches before: slab
+// sum + bias, CFG + Euler, the three launches of the input projection, LayerNorm-modulate + split):
+//   !first: v = fin_b + sum_z P[z] (the previous step's final-layer slabs), CFG combine over the image's rows, x[m] += vg * step
+//   h[m] = in_w x[m] + in_b   (diff_loss_rf_swiglu.py:371; target <= 256 inputs per output: a dot product per thread)
+//   Y = split( (LayerNorm(h[m]) * ln_g + ln_b) * (1 + scale[m]) + shift[m] )  — block 0's modulated input (:270, 290)
+// Every workgroup recomputes its image's vg (rpi x target sums of nz floats) and updates only its own row of x.
+__global__ __launch_bounds__(1024) void rf_step_boundary_kernel(
+    const float* __restrict__ P, int nz, int M, int T, const bf16_t* __restrict__ fin_b, float* __restrict__ x, int rpi, float text_cfg,
+    float image_cfg, float step, int first, const bf16_t* __restrict__ in_w, const bf16_t* __restrict__ in_b, int w, float* __restrict__ h,
+    const bf16_t* __restrict__ ln_g, const bf16_t* __restrict__ ln_b, const float* __restrict__ shift, const float* __restrict__ scale,
+    int64_t ldmod, bf16_t* __restrict__ Y) {
+  __shared__ float red[32];
+  __shared__ float xs[256];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  if (tid < T) {
+    float xv = x[(int64_t)m * T + tid];
+    if (!first) {
+      const int r0 = (m / rpi) * rpi;
+      float v[3] = {0.f, 0.f, 0.f};
+      for (int r = 0; r < rpi; ++r) {
+        float y = bf16_to_f32(fin_b[tid]);
+        for (int z = 0; z < nz; ++z) y += P[((int64_t)z * M + r0 + r) * T + tid];
+        v[r] = y;
+      }
+      const float vg = rpi == 3 ? v[1] + image_cfg * (v[2] - v[1]) + text_cfg * (v[0] - v[2])
+                                : (rpi == 2 ? v[1] + text_cfg * (v[0] - v[1]) : v[0]);
+      xv += vg * step;
+      x[(int64_t)m * T + tid] = xv;
+    }
+    xs[tid] = xv;
+  }
+  __syncthreads();
+  float hv[4];                                   // w <= 4096: columns tid, tid + 1024, ...
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int n = tid + c * 1024;
+    hv[c] = 0.f;
+    if (n < w) {
+      const bf16_t* wr = in_w + (int64_t)n * T;
+      float a = bf16_to_f32(in_b[n]);
+      for (int k = 0; k < T; k += 8) {           // T % 8 == 0 (host check): 16-byte rows
+        const mn_u4_t q = *reinterpret_cast<const mn_u4_t*>(wr + k);
+        a = fmaf(bf16lo_to_f32(q.x), xs[k], a); a = fmaf(bf16hi_to_f32(q.x), xs[k + 1], a);
+        a = fmaf(bf16lo_to_f32(q.y), xs[k + 2], a); a = fmaf(bf16hi_to_f32(q.y), xs[k + 3], a);
+        a = fmaf(bf16lo_to_f32(q.z), xs[k + 4], a); a = fmaf(bf16hi_to_f32(q.z), xs[k + 5], a);
+        a = fmaf(bf16lo_to_f32(q.w), xs[k + 6], a); a = fmaf(bf16hi_to_f32(q.w), xs[k + 7], a);
+      }
+      hv[c] = a;
+      h[(int64_t)m * w + n] = a;
+      sum += a;
+    }
+  }
+  const float mean = block_sum(sum, red) / (float)w;
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (tid + c * 1024 < w) { const float d = hv[c] - mean; ss += d * d; }
+  const float rstd = rsqrtf(block_sum(ss, red) / (float)w + 1e-6f);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int n = tid + c * 1024;
+    if (n < w) {
+      float v = (hv[c] - mean) * rstd;
+      if (ln_g) v *= bf16_to_f32(ln_g[n]);
+      if (ln_b) v += bf16_to_f32(ln_b[n]);
+      v = v * (1.0f + scale[(int64_t)m * ldmod + n]) + shift[(int64_t)m * ldmod + n];
+      const bf16_t hi = f32_to_bf16(v);
+      Y[(int64_t)m * w + n] = hi;
+      Y[(int64_t)(M + m) * w + n] = f32_to_bf16(v - bf16_to_f32(hi));
+    }
+  }
+}
+
 // semantic decoder input: de-normalise, Linear(in_dim -> D) + channel-repeat shortcut
 // (modeling_mingtok.py:168; vision_transformer.py:373-380)
 __global__ void semdec_in_kernel(const float* __restrict__ latent, int in_dim, float scale, float mean,
@@ -376,9 +450,9 @@ static bool rf_fp8_ok(const mn_rf_head* h) {
 
 // <= 4 rows (the CFG rows of one image — the reference's call shape): the SwiGLU glue launch is folded into w3's prologue
 // (stream_fuse.h): three launches per ResBlock instead of four.  g_rf_fuse: dev-library A/B switch.
-static int g_rf_fuse = 1;
+static int g_rf_fuse = 1, g_rf_boundary = 1;
 #ifdef MN_DEV_HOOKS
-extern "C" MN_DEV_API void mn_rf_tune_fuse(int on) { g_rf_fuse = on; }
+extern "C" MN_DEV_API void mn_rf_tune_fuse(int on) { g_rf_fuse = on & 1; g_rf_boundary = (on >> 1) & 1; }
 #endif
 static bool rf_fused_shape_ok(const mn_rf_head* h, int rows) {
   return rows <= FUSE_MAX_ROWS && rf_chain_ok(h, rows) &&
@@ -487,16 +561,26 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   }
   const float step = 1.0f / (float)h->steps;
   const float* ada_all = ada;
+  const bool boundary = chain && g_rf_boundary && T <= 256 && (T % 8) == 0 && w <= 4096;
+  int nz_fin = 0;
   for (int s = 0; s < h->steps; ++s) {
     const float* ada = ada_all + (int64_t)s * rows * A;
     // h = input_proj(x)  (diff_loss:371)
-    mn_skinny_args a = sk(x, T, h->in_w, T, h->in_b, hh, w, rows, w, T);
-    MN_TRY(mn_skinny_gemm(&a, stream));
+    mn_skinny_args a;
+    if (!boundary) {
+      a = sk(x, T, h->in_w, T, h->in_b, hh, w, rows, w, T);
+      MN_TRY(mn_skinny_gemm(&a, stream));
+    }
     if (chain) {
       // rows >= 5: stream(w12) -> [reduce + SwiGLU + split] -> stream(w3) -> [reduce + gated residual + next LN-modulate + split]
       const int hid_n = h->hidden;
-      hipLaunchKernelGGL(rf_glue_resid_ln_split_kernel, dim3(rows), dim3(1024), 0, st, (const float*)nullptr, 0, rows, w,
-                         (const bf16_t*)nullptr, (const float*)nullptr, hh, h->ln_g[0], h->ln_b[0], ada, ada + w, (int64_t)A, ya);
+      if (boundary)      // previous step's velocity + CFG + Euler, input projection, block 0's modulated input: one launch
+        hipLaunchKernelGGL(rf_step_boundary_kernel, dim3(rows), dim3(1024), 0, st, (const float*)pbuf, nz_fin, rows, T, h->fin_b, x, rpi,
+                           text_cfg, image_cfg, step, s == 0 ? 1 : 0, h->in_w, h->in_b, w, hh, h->ln_g[0], h->ln_b[0], ada, ada + w,
+                           (int64_t)A, ya);
+      else
+        hipLaunchKernelGGL(rf_glue_resid_ln_split_kernel, dim3(rows), dim3(1024), 0, st, (const float*)nullptr, 0, rows, w,
+                           (const bf16_t*)nullptr, (const float*)nullptr, hh, h->ln_g[0], h->ln_b[0], ada, ada + w, (int64_t)A, ya);
       for (int b = 0; b < h->depth; ++b) {
         const float* mod = ada + (int64_t)b * 3 * w;
         int nz = stream_dense(h->wfmt, ya, h->w12[b], h->wfmt ? h->w12_scale[b] : nullptr, pbuf, rows, 2 * hid_n, w, stream);
@@ -520,8 +604,11 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
       }
       const int nz = mn_stream_mfma(ya, h->fin_w, pbuf, rows, T, w, stream);   // final_layer.linear on the modulated LN(h)
       if (nz < 0) return nz;
-      hipLaunchKernelGGL(rf_glue_bias_out_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, pbuf, nz, rows, T, h->fin_b, v);
-      hipLaunchKernelGGL(rf_euler_kernel, dim3(n_images), dim3(256), 0, st, v, x, rpi, T, text_cfg, image_cfg, step);
+      nz_fin = nz;
+      if (!boundary || s + 1 == h->steps) {      // (with the boundary launch the next step consumes the slabs itself)
+        hipLaunchKernelGGL(rf_glue_bias_out_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, pbuf, nz, rows, T, h->fin_b, v);
+        hipLaunchKernelGGL(rf_euler_kernel, dim3(n_images), dim3(256), 0, st, v, x, rpi, T, text_cfg, image_cfg, step);
+      }
       continue;
     }
     for (int b = 0; b < h->depth; ++b) {
