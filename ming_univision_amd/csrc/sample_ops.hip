@@ -179,7 +179,7 @@ __global__ __launch_bounds__(1024) void sample_logits_kernel(const float* __rest
   if (keep0 && ex0 <= target && target < ex1) atomicMin(&s_pick, r0);
   if (keep1 && ex1 <= target && target < ex2) atomicMin(&s_pick, r1);
   __syncthreads();
-  if (tid == 0) s_pick = sidx[s_pick == 0x7fffffff ? s_need : s_pick];      // no owner: target rounded up to the kept mass -> last kept rank
+  if (tid == 0) s_pick = min(sidx[s_pick == 0x7fffffff ? s_need : s_pick], V - 1);      // no owner: target rounded up to the kept mass -> last kept rank; (NaN logits: any valid id)
   __syncthreads();
   if (tid == 0) idx[m] = (int64_t)s_pick + vocab_offset;
 }

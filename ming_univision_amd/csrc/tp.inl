@@ -386,7 +386,9 @@ static size_t rf_tp_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, R
   const size_t p3 = (size_t)stream_slices(h->wfmt, rows, h->w, h->hidden) * h->w * rows;
   Carver cv(ws ? (char*)ws + off : nullptr, cap > off ? cap - off : 0, ws == nullptr);
   float* pb = cv.take<float>(p12 > p3 ? p12 : p3);
-  if (ws) o->pbuf_stream = pb;
+  // <= 4 rows: w3 builds SwiGLU(w12's slabs) in its prologue (stream_fuse.h) and needs its own slab area
+  float* pb3 = cv.take<float>(rf_fused_shape_ok(h, rows) ? p3 : 0);
+  if (ws) { o->pbuf_stream = pb; o->pbuf_stream3 = pb3; }
   return off + cv.off;
 }
 
@@ -426,15 +428,22 @@ extern "C" int mn_rf_sample_tp(const mn_rf_head* h, mn_tp_comm* comm, const floa
   // block b of a step on this rank's hidden units: w12 -> SwiGLU -> w3 partial slabs -> push.  Up to 64 rows the two GEMMs are the
   // weight-streaming MFMA kernels of the <= 64-row route (the shard's bytes are what a launch costs there: 12.6 + 6.3 MB per block at
   // TP = 8 against 100.7 + 50.3 unsharded); above, gemm256 like the wide route.
-  const bool streaming = rows <= 64;
+  const bool streaming = rows <= 64, fused = streaming && g_rf_fuse && rf_fused_shape_ok(h, rows);
   auto block_gemms = [&](int b) -> int {
     int nz;
+    float* p3 = w.pbuf;
     if (streaming) {
       nz = stream_dense(h->wfmt, w.ya, h->w12[b], h->wfmt ? h->w12_scale[b] : nullptr, w.pbuf, rows, 2 * HID, W, stream);
       if (nz < 0) return nz;
-      hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)rows * HID, 1024)), dim3(256), 0, st, (const float*)w.pbuf, nz,
-                         rows, HID, h->b12[b], w.yb);
-      nz = stream_dense(h->wfmt, w.yb, h->w3[b], h->wfmt ? h->w3_scale[b] : nullptr, w.pbuf, rows, W, HID, stream);
+      if (fused) {                 // the CFG rows of one image: no SwiGLU glue launch (engine.hip, mn_rf_sample)
+        const StreamFuse f{w.pbuf, nz, h->b12[b]};
+        p3 = w.pbuf_stream3;
+        nz = stream_fused(h->wfmt, h->w3[b], h->wfmt ? h->w3_scale[b] : nullptr, p3, rows, W, HID, f, stream);
+      } else {
+        hipLaunchKernelGGL(rf_glue_swiglu_split_kernel, dim3(mn_cdiv((int64_t)rows * HID, 1024)), dim3(256), 0, st, (const float*)w.pbuf, nz,
+                           rows, HID, h->b12[b], w.yb);
+        nz = stream_dense(h->wfmt, w.yb, h->w3[b], h->wfmt ? h->w3_scale[b] : nullptr, w.pbuf, rows, W, HID, stream);
+      }
       if (nz < 0) return nz;
     } else {
       if (w.ks12 > 1) {
@@ -456,7 +465,7 @@ extern "C" int mn_rf_sample_tp(const mn_rf_head* h, mn_tp_comm* comm, const floa
     }
     TpPush p;
     memset(&p, 0, sizeof(p));
-    p.P = w.pbuf; p.nz = nz; p.slab = (int64_t)rows * W;
+    p.P = p3; p.nz = nz; p.slab = (int64_t)rows * W;
     tp_push(comm, ep + 1, p, rows, W, st);
     return 0;
   };

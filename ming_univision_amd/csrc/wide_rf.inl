@@ -33,6 +33,7 @@ static inline int64_t lo_at(int site, int64_t off) { return ((g_lo_drop >> site)
 struct RfWideWs {
   float *z, *c, *ada, *hh, *v, *x, *pbuf;
   float* pbuf_stream;    // tp.inl, <= 64 rows: K-slice slabs of the weight-streaming kernels
+  float* pbuf_stream3;   // tp.inl, <= 4 rows: w3's slabs when its prologue reads w12's (stream_fuse.h)
   bf16_t *hs, *zs, *y, *ya, *yb;
   int ks12, ks3, ksf;    // split-K requests of the w12 (1 = SwiGLU in the GEMM epilogue), w3 and final GEMMs
 };

@@ -203,3 +203,16 @@ def test_generate_text_batch_do_sample_matches_single_rows(tmp_path):
         stop = [i for i, t in enumerate(out[b]) if t in (1, cfg.llm_config.image_start_token)]    # `<image>` is only a token in the batch
         cut = stop[0] + 1 if stop else len(out[b])
         assert one[:cut] == out[b][:cut], (b, one, out[b])
+
+
+def test_sample_logits_nan_row_returns_a_valid_id():
+    """A poisoned row (the TP wait-expiry path writes NaN) must never turn into an out-of-range embedding index."""
+    from ming_univision_amd import ops
+    V = 5000
+    logits = torch.full((3, V), float("nan"), device="cuda")
+    logits[1] = torch.randn(V, device="cuda")
+    logits[1, 17] = float("nan")
+    u = torch.tensor([0.3, 0.7, 0.999], device="cuda")
+    for temperature, top_k, top_p in ((1.0, 50, 1.0), (1.0, 0, 0.9), (0.8, 0, 1.0)):
+        t = ops.sample_logits(logits, u, temperature, top_k, top_p)
+        assert bool(((t >= 0) & (t < V)).all()), t.tolist()
