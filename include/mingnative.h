@@ -346,6 +346,11 @@ MN_API int mn_swiglu_bf16(const uint16_t* x12, int64_t ldx, uint16_t* h, int64_t
  * qkv bf16 [B, T, 3, n_heads, 64] (the reshape of attention.py:83,98); out bf16 [B, T, n_heads*64].
  * causal: 0 = bidirectional (Attention / MemEffAttention), 1 = causal (MemEffCausalAttention). */
 MN_API int mn_attn_prefill_hd64(const uint16_t* qkv, uint16_t* out, int B, int T, int n_heads, int causal, void* stream);
+/* The same attention in the fp32-class regime (within 1e-3 of the fp32 reference path): qkv FP32
+ * [B, T, 3, n_heads, 64]; operands carried as bf16 hi + lo pairs, three MFMAs per product, fp32 softmax and accumulators.
+ * out fp32 [B * T, n_heads * 64] and / or split bf16 [2][B * T][n_heads * 64] (hi rows, then lo rows: the projection GEMM's
+ * operand); either may be NULL. */
+MN_API int mn_attn_prefill_hd64_f32(const float* qkv, float* out, uint16_t* split, int B, int T, int n_heads, int causal, void* stream);
 
 /* Small fp32 elementwise helpers of the ViT glue (all [M, D] row-major contiguous):
  *   mn_add_bcast_f32    out[i] = a[i] + b[i % period]     (+pos-embed, vision_transformer.py:222)

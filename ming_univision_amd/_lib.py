@@ -160,6 +160,7 @@ SYMBOLS = {
     "mn_layernorm_bf16": (_i, [_p, _i64, _p, _p, _f, _p, _i64, _i, _i, _i, _p]),
     "mn_swiglu_bf16": (_i, [_p, _i64, _p, _i64, _i, _i, _p]),
     "mn_attn_prefill_hd64": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "mn_attn_prefill_hd64_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "mn_f32_to_bf16": (_i, [_p, _p, _i64, _p]),
     "mn_bf16_to_f32": (_i, [_p, _p, _i64, _p]),
     "mn_f32_split_bf16": (_i, [_p, _p, _p, _i64, _p]),

@@ -21,6 +21,12 @@
 //     16-byte writes and never transposed by stores.  V rows are padded by 32 B: a 16-lane group reads 4 keys x 32 B and the
 //     eight groups of two waves tile the 64 banks.
 // The staging of tile t+1 is issued to registers before tile t is computed and written to LDS after it (one tile in flight).
+//
+// HILO (round 4; SRC 0 only): the fp32-class regime's attention — q / k / v are FP32 inside qkv, every operand is carried as a bf16
+// hi + lo pair (x = hi + lo to 2^-17) and every product as three MFMAs (hi hi + hi lo + lo hi; the lo lo term is 2^-16 of the
+// product), scores / softmax / accumulators fp32, output fp32 and / or the next GEMM's hi / lo operand.  It replaces the per-row
+// decode kernels the regime borrowed before (every query row re-reading all of K and V through L2: 8.5 ms of the 14.8 ms a
+// 1024^2 image spends in MingTok) with the tiled form: a staged 64-key tile serves 128 query rows.
 #include "common.h"
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -31,10 +37,14 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 namespace {
 constexpr int FKT = 64;
 typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+struct HL { uint32_t h, l; };
+__device__ __forceinline__ HL spl(float a, float b) { HL r; split_pk_bf16(a, b, r.h, r.l); return r; }
 typedef __attribute__((address_space(3))) v4s lds_v4s;
 
 struct FlashP {
   const bf16_t* q; const void* k; const void* v; bf16_t* out;
+  float* out_f32; bf16_t* out_split; int64_t split_lo_off;   // HILO: fp32 result and / or bf16 hi rows + lo rows (lo rows split_lo_off elements on)
   int64_t q_rs, q_hs, kv_rs, kv_hs, o_rs;          // element strides: rows and heads
   int64_t q_bs, kv_bs, o_bs;                       // SRC 0: per image
   int T, past, causal;
@@ -42,12 +52,14 @@ struct FlashP {
   const int32_t* seq_tab; int64_t kv_seq_stride;   // SRC 1: [n][3] = (cache sequence, first q / out row, span length); NULL: (0, 0, T)
 };
 
-template <int HD, int SRC>
+template <int HD, int SRC, bool HILO = false>
 __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
+  static_assert(!HILO || SRC == 0, "the hi/lo form reads packed fp32 qkv");
   constexpr int KROW = HD + 8, VROW = HD + 16, NKK = HD / 32, NDT = HD / 16;
-  constexpr int ESZ = SRC == 0 ? 2 : 4, PPR = HD * ESZ / 16, KPP = 256 / PPR, NP = FKT / KPP;
-  __shared__ __attribute__((aligned(16))) bf16_t ks[FKT * KROW];
-  __shared__ __attribute__((aligned(16))) bf16_t vs[FKT * VROW];
+  constexpr int ESZ = (SRC == 0 && !HILO) ? 2 : 4, PPR = HD * ESZ / 16, KPP = 256 / PPR, NP = FKT / KPP;
+  __shared__ __attribute__((aligned(16))) bf16_t ks[FKT * KROW * (HILO ? 2 : 1)];     // HILO: the hi tile, then the lo tile
+  __shared__ __attribute__((aligned(16))) bf16_t vs[FKT * VROW * (HILO ? 2 : 1)];
+  constexpr int KLO = FKT * KROW, VLO = FKT * VROW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
   int T = p.T, q0, q_hi_wg;
@@ -60,10 +72,10 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
     const int head = blockIdx.y, b = blockIdx.z;
     q0 = blockIdx.x * 128 + wave * 32;
     q_hi_wg = blockIdx.x * 128 + 127;
-    qb = p.q + b * p.q_bs + head * p.q_hs;
-    ob = p.out + b * p.o_bs + head * HD;
-    kb = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(p.k) + b * p.kv_bs + head * p.kv_hs);
-    vb = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(p.v) + b * p.kv_bs + head * p.kv_hs);
+    qb = p.q + (b * p.q_bs + head * p.q_hs) * (HILO ? 2 : 1);          // HILO: q is fp32 (pointer arithmetic in bf16 units)
+    ob = p.out + b * p.o_bs + head * HD;                                // (HILO: element offset of the image's first row, used below)
+    kb = reinterpret_cast<const char*>(p.k) + (b * p.kv_bs + head * p.kv_hs) * ESZ;
+    vb = reinterpret_cast<const char*>(p.v) + (b * p.kv_bs + head * p.kv_hs) * ESZ;
     if (km) km += b * p.mask_bs;
   } else {
     int seq = 0, r0 = 0;
@@ -84,11 +96,24 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
   const int ntile = ((p.causal ? past + min(T, q_hi_wg + 1) : k_total) + FKT - 1) / FKT;
 
   // Q fragments (B operand): Q[q][d = 32 kk + 8 g .. +8]; SRC 0 scales by 64^-0.5 = 0.125 (exact in bf16)
-  bf16x8 qf[2][NKK];
+  bf16x8 qf[2][NKK], qfl[HILO ? 2 : 1][HILO ? NKK : 1];
   int q_idx[2];
 #pragma unroll
   for (int qg = 0; qg < 2; ++qg) {
     q_idx[qg] = q0 + qg * 16 + i16;
+    if constexpr (HILO) {
+      const float* qr = reinterpret_cast<const float*>(qb) + (int64_t)min(q_idx[qg], T - 1) * p.q_rs + g * 8;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(qr + kk * 32), b = *reinterpret_cast<const f32x4*>(qr + kk * 32 + 4);
+        u32x4 hi, lo;
+        { const HL t_ = spl(a.x * 0.125f, a.y * 0.125f); hi.x = t_.h; lo.x = t_.l; } { const HL t_ = spl(a.z * 0.125f, a.w * 0.125f); hi.y = t_.h; lo.y = t_.l; }
+        { const HL t_ = spl(b.x * 0.125f, b.y * 0.125f); hi.z = t_.h; lo.z = t_.l; } { const HL t_ = spl(b.z * 0.125f, b.w * 0.125f); hi.w = t_.h; lo.w = t_.l; }
+        qf[qg][kk] = __builtin_bit_cast(bf16x8, hi);
+        qfl[qg][kk] = __builtin_bit_cast(bf16x8, lo);
+      }
+      continue;
+    }
     const bf16_t* qr = qb + (int64_t)min(q_idx[qg], T - 1) * p.q_rs + g * 8;
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) {
@@ -125,7 +150,16 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
       const int key = ps * KPP + krow;
-      if (SRC == 0) {
+      if constexpr (HILO) {
+        const f32x4 a = __builtin_bit_cast(f32x4, rk[ps]), b = __builtin_bit_cast(f32x4, rv[ps]);
+        u32x2 h, l;
+        { const HL t_ = spl(a.x, a.y); h.x = t_.h; l.x = t_.l; } { const HL t_ = spl(a.z, a.w); h.y = t_.h; l.y = t_.l; }
+        *reinterpret_cast<u32x2*>(&ks[key * KROW + piece * 4]) = h;
+        *reinterpret_cast<u32x2*>(&ks[KLO + key * KROW + piece * 4]) = l;
+        { const HL t_ = spl(b.x, b.y); h.x = t_.h; l.x = t_.l; } { const HL t_ = spl(b.z, b.w); h.y = t_.h; l.y = t_.l; }
+        *reinterpret_cast<u32x2*>(&vs[key * VROW + piece * 4]) = h;
+        *reinterpret_cast<u32x2*>(&vs[VLO + key * VROW + piece * 4]) = l;
+      } else if (SRC == 0) {
         *reinterpret_cast<u32x4*>(&ks[key * KROW + piece * 8]) = rk[ps];
         *reinterpret_cast<u32x4*>(&vs[key * VROW + piece * 8]) = rv[ps];
       } else {
@@ -158,6 +192,13 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kfr + f * 16 * KROW + kk * 32);
         s[0][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][kk], s[0][f], 0, 0, 0);
         s[1][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][kk], s[1][f], 0, 0, 0);
+        if constexpr (HILO) {
+          const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kfr + KLO + f * 16 * KROW + kk * 32);
+          s[0][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfl[0][kk], s[0][f], 0, 0, 0);
+          s[1][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfl[1][kk], s[1][f], 0, 0, 0);
+          s[0][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qf[0][kk], s[0][f], 0, 0, 0);
+          s[1][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qf[1][kk], s[1][f], 0, 0, 0);
+        }
       }
     }
     // a tile every query of the wave sees whole needs no mask arithmetic (all but the diagonal / last tile of a span)
@@ -184,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
         }
       }
     }
-    bf16x8 pf[2][2];
+    bf16x8 pf[2][2], pfl[HILO ? 2 : 1][2];
 #pragma unroll
     for (int qg = 0; qg < 2; ++qg) {
       float mx = fmaxf(fmaxf(s[qg][0][0], s[qg][0][1]), fmaxf(s[qg][0][2], s[qg][0][3]));
@@ -214,6 +255,14 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
       m_run[qg] = m_new;
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
+        if constexpr (HILO) {
+          u32x4 hi, lo;
+          { const HL t_ = spl(e[sl * 8 + 0], e[sl * 8 + 1]); hi.x = t_.h; lo.x = t_.l; } { const HL t_ = spl(e[sl * 8 + 2], e[sl * 8 + 3]); hi.y = t_.h; lo.y = t_.l; }
+          { const HL t_ = spl(e[sl * 8 + 4], e[sl * 8 + 5]); hi.z = t_.h; lo.z = t_.l; } { const HL t_ = spl(e[sl * 8 + 6], e[sl * 8 + 7]); hi.w = t_.h; lo.w = t_.l; }
+          pf[qg][sl] = __builtin_bit_cast(bf16x8, hi);
+          pfl[qg][sl] = __builtin_bit_cast(bf16x8, lo);
+          continue;
+        }
         const u32x4 pk = {cvt_pk_bf16(e[sl * 8 + 0], e[sl * 8 + 1]), cvt_pk_bf16(e[sl * 8 + 2], e[sl * 8 + 3]),
                           cvt_pk_bf16(e[sl * 8 + 4], e[sl * 8 + 5]), cvt_pk_bf16(e[sl * 8 + 6], e[sl * 8 + 7])};
         pf[qg][sl] = __builtin_bit_cast(bf16x8, pk);
@@ -225,11 +274,20 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
       for (int dt = 0; dt < NDT; ++dt) {
         const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(vfr + (sl * 32) * VROW + dt * 16));
         const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(vfr + (sl * 32 + 16) * VROW + dt * 16));
-        typedef short v8s __attribute__((ext_vector_type(8)));
         const v8s vv = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
         o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][sl], o[0][dt], 0, 0, 0);
         o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][sl], o[1][dt], 0, 0, 0);
+        if constexpr (HILO) {
+          const v4s llo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(vfr + VLO + (sl * 32) * VROW + dt * 16));
+          const v4s lhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(vfr + VLO + (sl * 32 + 16) * VROW + dt * 16));
+          const v8s vl = {llo.x, llo.y, llo.z, llo.w, lhi.x, lhi.y, lhi.z, lhi.w};
+          const bf16x8 vfl = __builtin_bit_cast(bf16x8, vl);
+          o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfl[0][sl], o[0][dt], 0, 0, 0);
+          o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfl[1][sl], o[1][dt], 0, 0, 0);
+          o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, pf[0][sl], o[0][dt], 0, 0, 0);
+          o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, pf[1][sl], o[1][dt], 0, 0, 0);
+        }
       }
   }
   if (!wave_on) return;
@@ -240,6 +298,21 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
     l += __shfl_xor(l, 32, 64);
     if (q_idx[qg] >= T) continue;
     const float inv = l > 0.f ? 1.0f / l : 0.f;   // no attended key: 0, not NaN
+    if constexpr (HILO) {
+      const int64_t eo = (ob - p.out) + (int64_t)q_idx[qg] * p.o_rs + g * 4;      // element offset of this lane's first output
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const f32x4 v = o[qg][dt] * inv;
+        if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + eo + dt * 16) = v;
+        if (p.out_split) {
+          u32x2 h, lo2;
+          { const HL t_ = spl(v.x, v.y); h.x = t_.h; lo2.x = t_.l; } { const HL t_ = spl(v.z, v.w); h.y = t_.h; lo2.y = t_.l; }
+          *reinterpret_cast<u32x2*>(p.out_split + eo + dt * 16) = h;
+          *reinterpret_cast<u32x2*>(p.out_split + p.split_lo_off + eo + dt * 16) = lo2;
+        }
+      }
+      continue;
+    }
     bf16_t* op = ob + (int64_t)q_idx[qg] * p.o_rs + g * 4;
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
@@ -261,6 +334,22 @@ extern "C" int mn_attn_prefill_hd64(const uint16_t* qkv, uint16_t* out, int B, i
   p.T = T; p.past = 0; p.causal = causal;
   hipLaunchKernelGGL((flash_prefill_kernel<64, 0>), dim3(mn_cdiv(T, 128), n_heads, B), dim3(256), 0, mn_stream(stream), p);
   MN_CHECK_LAUNCH("mn_attn_prefill_hd64");
+  return MN_OK;
+}
+
+// The fp32-class regime's form: qkv FP32 [B, T, 3, nh, 64] -> out fp32 [B * T, nh * 64] and / or split bf16 [2][B * T][nh * 64]
+// (hi rows, then lo rows: the projection GEMM's operand).  Operands as bf16 hi + lo pairs, three MFMAs per product.
+extern "C" int mn_attn_prefill_hd64_f32(const float* qkv, float* out, uint16_t* split, int B, int T, int n_heads, int causal, void* stream) {
+  MN_CHECK_ARG(qkv && (out || split) && B >= 1 && T >= 1 && n_heads >= 1, "mn_attn_prefill_hd64_f32: bad args");
+  FlashP p{};
+  const int64_t rs = (int64_t)3 * n_heads * 64;
+  p.q = reinterpret_cast<const bf16_t*>(qkv); p.k = qkv + (int64_t)n_heads * 64; p.v = qkv + (int64_t)2 * n_heads * 64;
+  p.out = nullptr; p.out_f32 = out; p.out_split = split; p.split_lo_off = (int64_t)B * T * n_heads * 64;
+  p.q_rs = rs; p.q_hs = 64; p.kv_rs = rs; p.kv_hs = 64; p.o_rs = (int64_t)n_heads * 64;
+  p.q_bs = (int64_t)T * rs; p.kv_bs = (int64_t)T * rs; p.o_bs = (int64_t)T * n_heads * 64;
+  p.T = T; p.past = 0; p.causal = causal;
+  hipLaunchKernelGGL((flash_prefill_kernel<64, 0, true>), dim3(mn_cdiv(T, 128), n_heads, B), dim3(256), 0, mn_stream(stream), p);
+  MN_CHECK_LAUNCH("mn_attn_prefill_hd64_f32");
   return MN_OK;
 }
 

@@ -179,19 +179,11 @@ class MingTok:
         return self._pos_cache[key]
 
     def _attention_fp32(self, qkv, B, T, nh, causal):
-        """softmax(q k^T / 8) v per (image, head) on the fp32 decode kernels: K / V go to a scratch arena [B, 2, nh, T, 64] (one
-        cache sequence per image), then every row attends keys [0, t] (causal) or [0, T) of its sequence.  qkv fp32 [B*T, 3*nh*64]
-        in the reshape of attention.py:83 -> fp32 [B*T, nh*64]."""
-        dev = self.device
-        key = ("attn", B, T, nh)
-        if key not in self._ws:
-            seq = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(T)
-            slot = torch.arange(T, dtype=torch.int32, device=dev).repeat(B)
-            self._ws[key] = (seq, slot, (slot + 1).contiguous(), torch.full((B * T,), T, dtype=torch.int32, device=dev),
-                             torch.empty(B, 2, nh, T, 64, dtype=torch.float32, device=dev))
-        seq, slot, len_causal, len_full, kv = self._ws[key]
-        q = ops.rope_kv_append(qkv, nh, nh, 64, kv, seq, slot, q_scale=0.125)
-        return ops.attn_decode(q, nh, nh, 64, kv, seq, len_causal if causal else len_full)
+        """softmax(q k^T / 8) v per (image, head), fp32-class: the hi/lo flash kernel (mn_attn_prefill_hd64_f32: operands as bf16
+        hi + lo pairs, three MFMAs per product, fp32 softmax).  qkv fp32 [B*T, 3*nh*64] in the reshape of attention.py:83 -> the
+        hi/lo pair bf16 [2, B*T, nh*64] of the result (the projection's operand).  (Round 3 borrowed the per-row decode kernels
+        over a scratch arena: every query row re-read all keys — 8.5 of the 14.8 ms a 1024^2 image spent in MingTok.)"""
+        return ops.attn_prefill_hd64_f32(qkv, B, T, nh, causal)
 
     def _block_fp32(self, x, prefix, D, B, T, causal):
         """Block.forward / CausalBlock.forward (layers/block.py:80-105, 301-327) on the fp32 residual x [B*T, D], fp32-class."""
@@ -199,7 +191,7 @@ class MingTok:
         xn, _ = ops.norm_act_split(x, "ln", self._w(prefix + ".norm1.weight"), self._w(prefix + ".norm1.bias"))
         qkv = ops.linear_hilo(xn, self._w(prefix + ".attn.qkv.weight"), self._w(prefix + ".attn.qkv.bias"))
         att = self._attention_fp32(qkv, B, T, nh, causal)
-        ops.linear_hilo(ops.split_hilo(att), self._w(prefix + ".attn.proj.weight"), self._w(prefix + ".attn.proj.bias"), out=x, resid=True)
+        ops.linear_hilo(att, self._w(prefix + ".attn.proj.weight"), self._w(prefix + ".attn.proj.bias"), out=x, resid=True)
         xn, _ = ops.norm_act_split(x, "ln", self._w(prefix + ".norm2.weight"), self._w(prefix + ".norm2.bias"))
         if (prefix + ".mlp.w12.weight") in self.sd:
             w12, b12, w3 = self._swiglu_padded(prefix)

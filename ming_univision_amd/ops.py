@@ -372,6 +372,18 @@ def attn_prefill_hd64(qkv, B, T, n_heads, causal):
     return out
 
 
+def attn_prefill_hd64_f32(qkv, B, T, n_heads, causal, want_f32=False):
+    """fp32-class flash attention: qkv fp32 [B*T, 3*n_heads*64] -> the hi/lo pair bf16 [2, B*T, n_heads*64] of the result (the
+    projection GEMM's operand) and, with want_f32, the fp32 result itself."""
+    _req(qkv, torch.float32, "qkv")
+    assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * n_heads * 64)
+    split = torch.empty(2, B * T, n_heads * 64, dtype=torch.bfloat16, device=qkv.device)
+    out = torch.empty(B * T, n_heads * 64, dtype=torch.float32, device=qkv.device) if want_f32 else None
+    check(lib().mn_attn_prefill_hd64_f32(ptr(qkv), ptr(out), ptr(split), B, T, n_heads, int(causal), current_stream()),
+          "mn_attn_prefill_hd64_f32")
+    return (split, out) if want_f32 else split
+
+
 def f32_to_bf16(x):
     _req(x, torch.float32, "x")
     x = x.contiguous()

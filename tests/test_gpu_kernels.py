@@ -238,6 +238,26 @@ def test_attn_prefill_hd64(ops, B, T, nh, causal):
     assert rel(out, ref) < 3 * 2 ** -8
 
 
+@pytest.mark.parametrize("B,T,nh,causal", [(2, 257, 12, False), (1, 300, 4, True), (3, 64, 2, True), (1, 1025, 16, False), (2, 130, 3, True)])
+def test_attn_prefill_hd64_f32_hilo(ops, B, T, nh, causal):
+    """The fp32-class flash attention (operands as bf16 hi + lo pairs, three MFMAs per product) against fp64 softmax attention on
+    fp32 inputs with a wide dynamic range: 1e-4-class error (the plain bf16 kernel above: 1e-2), fp32 and hi/lo outputs agree."""
+    g = torch.Generator().manual_seed(62)
+    qkv = torch.randn(B * T, 3 * nh * 64, generator=g) * (1.0 + 3.0 * torch.rand(B * T, 1, generator=g))
+    split, out = ops.attn_prefill_hd64_f32(qkv.cuda(), B, T, nh, causal, want_f32=True)
+    x = qkv.double().view(B, T, 3, nh, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = x[0] * 0.125, x[1], x[2]
+    att = q @ k.transpose(-1, -2)
+    if causal:
+        att = att.masked_fill(torch.triu(torch.ones(T, T, dtype=torch.bool), 1), float("-inf"))
+    ref = (att.softmax(-1) @ v).transpose(1, 2).reshape(B * T, nh * 64)
+    assert rel(out, ref) < 1e-4
+    rec = split[0].float() + split[1].float()
+    assert rel(rec, out) < 2 ** -15
+    only_split = ops.attn_prefill_hd64_f32(qkv.cuda(), B, T, nh, causal)
+    assert torch.equal(only_split, split)
+
+
 @pytest.mark.parametrize("past,with_mask", [(0, False), (37, False), (5, True)])
 def test_flash_prefill_gqa_hd128_spans(ops, past, with_mask):
     """GQA 16:4 flash attention (hd 128, bottom-right causal) of three prompt spans of different lengths in ONE launch, K / V
