@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MN_VERSION 120 /* 0.1.20: fp8 weight mode (section 7): wfmt / row-scale fields at the END of mn_skinny_args, mn_rf_head,
+#define MN_VERSION 121 /* 0.1.20: fp8 weight mode (section 7): wfmt / row-scale fields at the END of mn_skinny_args, mn_rf_head,
                           mn_llm and mn_llm_tp (zero = bf16: callers of 0.1.10 that zero-fill the structs are unchanged),
                           mn_quant_fp8_rows / mn_dequant_fp8_rows / mn_stream_mfma_w8 / mn_stream_mfma_grouped_w8 */
 
@@ -301,6 +301,12 @@ MN_API int mn_moe_combine_norm(const float* yg, const int32_t* slot_of, const fl
 MN_API int mn_flash_prefill_gqa_hd128(const uint16_t* q, const float* kv_layer, int64_t t_max, int n_q, int n_kv, int past,
                                const int32_t* seq_tab, int n_spans, int max_len, const uint8_t* key_mask, int64_t mask_stride,
                                uint16_t* out, void* stream);
+/* The fp32-class form (the attention of mn_llm_step_spans): q FP32 [rows, n_q, 128] (RoPE'd, pre-scaled), all operands as bf16 hi + lo
+ * pairs (three MFMAs per product), fp32 softmax / accumulators.  span_tab: device int32 [n_spans][4] = (seq_i, r0_i, len_i, past_i)
+ * — every span brings its own `past`.  out fp32 [rows, n_q * 128] and / or split bf16 hi rows, then lo rows split_lo_off elements
+ * on (either may be NULL).  No key mask. */
+MN_API int mn_flash_prefill_gqa_hd128_f32(const float* q, const float* kv_layer, int64_t t_max, int n_q, int n_kv, const int32_t* span_tab,
+                                          int n_spans, int max_len, float* out, uint16_t* split, int64_t split_lo_off, void* stream);
 
 /* mn_moe_sort plus the list of LIVE row tiles of the grouped GEMMs: tile t (t < *n_tiles) = rows [tile_m0[t], tile_m0[t] +
  * tile_rows) of group tile_g[t]; tile_g / tile_m0 hold up to T * n_slot / tile_rows + n_groups entries.  All device arrays.
@@ -469,6 +475,17 @@ MN_API int mn_llm_step_ex(const mn_llm* m, const float* x, int64_t ldx, int x_ro
                    const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len,
                    const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
                    float* hidden_out, void* workspace, size_t workspace_bytes, int flags, void* stream);
+
+/* mn_llm_step for a PREFILL chunk whose rows are whole spans of cache sequences (BailingMoeModel.forward on a prompt, :1391-1540;
+ * eager / flash causal attention, :791-812, 848-1045): span i = rows [r0_i, r0_i + len_i) of x, in order the slots
+ * [past_i, past_i + len_i) of cache sequence seq_i (row_seq / row_slot / row_pos / row_len describe the same rows, row_len =
+ * row_slot + 1; no key mask).  span_tab: device int32 [n_spans][4] = (seq_i, r0_i, len_i, past_i); max_len >= every len_i.
+ * On the wide route (> 64 rows, head dim 128, GQA 4:1) the attention then runs as tiled flash attention on bf16 hi/lo operands
+ * (fp32-class like the rest of the route) instead of row by row; every other shape takes mn_llm_step's path.  Same results. */
+MN_API int mn_llm_step_spans(const mn_llm* m, const float* x, int64_t ldx, int M, const uint8_t* image_mask, const int32_t* row_seq,
+                             const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len, float* kv_cache, int n_seq,
+                             int64_t t_max, const int32_t* span_tab, int n_spans, int max_len, float* hidden_out, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* a[i] += delta, b[i] += delta, c[i] += delta for i < M (any pointer may be NULL): advances the
  * device-resident row_slot / row_pos / row_len arrays between autoregressive steps without a host round trip. */

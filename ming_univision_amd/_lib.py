@@ -161,6 +161,7 @@ SYMBOLS = {
     "mn_swiglu_bf16": (_i, [_p, _i64, _p, _i64, _i, _i, _p]),
     "mn_attn_prefill_hd64": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mn_attn_prefill_hd64_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "mn_flash_prefill_gqa_hd128_f32": (_i, [_p, _p, _i64, _i, _i, _p, _i, _i, _p, _p, _i64, _p]),
     "mn_f32_to_bf16": (_i, [_p, _p, _i64, _p]),
     "mn_bf16_to_f32": (_i, [_p, _p, _i64, _p]),
     "mn_f32_split_bf16": (_i, [_p, _p, _p, _i64, _p]),
@@ -172,6 +173,7 @@ SYMBOLS = {
     "mn_llm_workspace_bytes": (_sz, [C.POINTER(Llm), _i, _i64]),
     "mn_llm_step": (_i, [C.POINTER(Llm), _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _i, _i64, _p, _p, _sz, _p]),
     "mn_llm_step_ex": (_i, [C.POINTER(Llm), _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _i, _i64, _p, _p, _sz, _i, _p]),
+    "mn_llm_step_spans": (_i, [C.POINTER(Llm), _p, _i64, _i, _p, _p, _p, _p, _p, _p, _i, _i64, _p, _i, _i, _p, _p, _sz, _p]),
     "mn_rows_advance": (_i, [_p, _p, _p, _i, _i, _p]),
     "mn_add_bcast_f32": (_i, [_p, _p, _p, _i64, _i64, _p]),
     "mn_group_mean_add": (_i, [_p, _p, _p, _i, _i, _i, _p]),
@@ -218,7 +220,7 @@ def lib():
         fn = getattr(handle, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if handle.mn_version() < 120:
+    if handle.mn_version() < 121:
         raise RuntimeError("libmingnative.so is too old")
     _lib = handle
     return _lib

@@ -229,12 +229,15 @@ class BailingMoeDecoder:
         return self._ws[key]
 
     def step(self, x, row_seq, row_slot, row_pos, row_len, key_mask=None, image_mask=None, out=None, rows=None,
-             x_row_div=1, distinct_sequences=False):
+             x_row_div=1, distinct_sequences=False, spans=None):
         """One pass of the 28-layer stack over M <= 64 rows (weight-streaming kernels) or 65..2048 rows (wide route).
         x fp32 [M,H]; or [1,H] with rows=M to broadcast; or [M / x_row_div, H] with rows=M when the x_row_div CFG
         rows of an image share one embedding.  int32 device arrays per row; key_mask uint8 [M, >=len].
         distinct_sequences: every row is a different cache sequence and row_len == row_slot + 1 (a decode step, not a prefill
         chunk) — RoPE and the K / V append then ride the attention launch (mn_llm_step_ex; same results).
+        spans: a PREFILL chunk described as whole spans of cache sequences — a list of (seq, first row, length, past): rows
+        [r0, r0 + len) are the slots [past, past + len) of sequence seq, in order, no key mask (mn_llm_step_spans: the wide route
+        then runs tiled flash attention on hi/lo operands instead of row-by-row decode attention; same results).
         Returns the post-final-norm hidden states [M,H] fp32."""
         M = rows or x.shape[0]
         ldx = 0 if (rows is not None and x.shape[0] == 1) else x.stride(0)
@@ -255,6 +258,15 @@ class BailingMoeDecoder:
         if out is None:
             out = torch.empty(M, self.cfg.hidden_size, dtype=torch.float32, device=self.device)
         ws = self._workspace(M)
+        if spans is not None:
+            assert key_mask is None and x_row_div == 1 and x.shape[0] == M and not distinct_sequences
+            assert sum(n for _, _, n, _ in spans) == M and all(p + n <= self.t_max for _, _, n, p in spans)
+            tab = torch.tensor([list(map(int, sp)) for sp in spans], dtype=torch.int32).to(self.device)
+            check(lib().mn_llm_step_spans(C.byref(self.struct), ptr(x), ldx, M, ptr(image_mask), ptr(row_seq), ptr(row_slot), ptr(row_pos),
+                                          ptr(row_len), ptr(self.kv_cache), self.n_seq, self.t_max, ptr(tab), len(spans),
+                                          max(n for _, _, n, _ in spans), ptr(out), ptr(ws), ws.numel(), current_stream()),
+                  "mn_llm_step_spans")
+            return out
         check(lib().mn_llm_step_ex(C.byref(self.struct), ptr(x), ldx, x_row_div, M, ptr(image_mask), ptr(row_seq), ptr(row_slot),
                                    ptr(row_pos), ptr(row_len), ptr(key_mask),
                                    0 if key_mask is None else key_mask.stride(0), ptr(self.kv_cache), self.n_seq,
@@ -316,7 +328,8 @@ class BailingMoeDecoder:
             m = min(step, T - c0)
             slot = torch.arange(past + c0, past + c0 + m, dtype=torch.int32, device=dev)
             seqs = torch.full((m,), seq, dtype=torch.int32, device=dev)
-            self.step(x[c0:c0 + m], seqs, slot, slot, slot + 1, None, None if im is None else im[c0:c0 + m], out=out[c0:c0 + m])
+            self.step(x[c0:c0 + m], seqs, slot, slot, slot + 1, None, None if im is None else im[c0:c0 + m], out=out[c0:c0 + m],
+                      spans=[(seq, 0, m, past + c0)])
         return out
 
     def ensure_sequences(self, n_seq):
@@ -363,11 +376,17 @@ class BailingMoeDecoder:
             im = torch.cat([torch.zeros(n, dtype=torch.uint8, device=dev) if m is None else m.reshape(-1).to(dev, torch.uint8)
                             for m, n in zip(image_masks, lens)]).contiguous()
         step = self.max_rows()
+        starts = [0]
+        for n in lens:
+            starts.append(starts[-1] + n)
         for r0 in range(0, x.shape[0], step):
             r1 = min(x.shape[0], r0 + step)
             sl = slot[r0:r1].contiguous()
+            # the pieces of the sequences this pass holds: (sequence, first row in the pass, rows, slots already in its cache)
+            spans = [(seqs[i], max(starts[i], r0) - r0, min(starts[i + 1], r1) - max(starts[i], r0), past + max(starts[i], r0) - starts[i])
+                     for i in range(len(lens)) if min(starts[i + 1], r1) > max(starts[i], r0)]
             self.step(x[r0:r1], seq[r0:r1].contiguous(), sl, sl, (sl + 1).contiguous(), None, None if im is None else im[r0:r1],
-                      out=out[r0:r1])
+                      out=out[r0:r1], spans=spans)
         last = torch.tensor(lens).cumsum(0) - 1
         return out[last.to(dev)]
 

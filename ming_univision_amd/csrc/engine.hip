@@ -25,6 +25,8 @@ extern "C" int mn_attn_decode_split(const float* q, int M, int n_q, int n_kv, in
                                     const int32_t* row_seq, const int32_t* row_len, const uint8_t* key_mask, int64_t ld_mask,
                                     float* out, uint16_t* split, void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int mn_attn_fused_ok(int M, int n_q, int n_kv, int hd, int64_t t_max);
+extern "C" int mn_flash_prefill_gqa_hd128_f32(const float* q, const float* kv_layer, int64_t t_max, int n_q, int n_kv, const int32_t* span_tab,
+                                              int n_spans, int max_len, float* out, uint16_t* split, int64_t split_lo_off, void* stream);
 extern "C" int mn_attn_decode_fused(const float* qkv, int64_t ldqkv, int nz, int64_t slab, int M, int n_q, int n_kv, int hd, int rope,
                                     const float* cos_tab, const float* sin_tab, const int32_t* row_seq, const int32_t* row_slot,
                                     const int32_t* row_pos, int sec_t, int sec_h, float q_scale, float* kv_cache, int64_t t_max,
@@ -993,7 +995,8 @@ extern "C" int mn_rows_advance(int32_t* a, int32_t* b, int32_t* c, int M, int de
 static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int M, const uint8_t* image_mask, const int32_t* row_seq,
                          const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len,
                          const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
-                         float* hidden_out, void* workspace, size_t workspace_bytes, int flags, void* stream);
+                         float* hidden_out, void* workspace, size_t workspace_bytes, int flags, void* stream,
+                         const int32_t* span_tab = nullptr, int n_spans = 0, int span_max_len = 0);
 
 extern "C" int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int M, const uint8_t* image_mask, const int32_t* row_seq,
                            const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len,
@@ -1012,10 +1015,23 @@ extern "C" int mn_llm_step_ex(const mn_llm* m, const float* x, int64_t ldx, int 
                        hidden_out, workspace, workspace_bytes, flags, stream);
 }
 
+// A prefill chunk whose rows are whole spans of cache sequences (mingnative.h): the attention of the wide route runs on the tiled
+// hi/lo flash kernel instead of the per-row decode kernels.  Other shapes take mn_llm_step's path (same results).
+extern "C" int mn_llm_step_spans(const mn_llm* m, const float* x, int64_t ldx, int M, const uint8_t* image_mask, const int32_t* row_seq,
+                                 const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len, float* kv_cache, int n_seq,
+                                 int64_t t_max, const int32_t* span_tab, int n_spans, int max_len, float* hidden_out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  MN_CHECK_ARG(span_tab && n_spans >= 1 && max_len >= 1 && max_len <= M, "mn_llm_step_spans: bad span table (n_spans %d, max_len %d, M %d)", n_spans,
+               max_len, M);
+  return llm_step_impl(m, x, ldx, 1, M, image_mask, row_seq, row_slot, row_pos, row_len, nullptr, 0, kv_cache, n_seq, t_max, hidden_out, workspace,
+                       workspace_bytes, 0, stream, span_tab, n_spans, max_len);
+}
+
 static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int M, const uint8_t* image_mask, const int32_t* row_seq,
                          const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len,
                          const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
-                         float* hidden_out, void* workspace, size_t workspace_bytes, int flags, void* stream) {
+                         float* hidden_out, void* workspace, size_t workspace_bytes, int flags, void* stream,
+                         const int32_t* span_tab, int n_spans, int span_max_len) {
   MN_CHECK_ARG(m && x && row_seq && row_slot && row_pos && row_len && kv_cache && hidden_out && workspace,
                "mn_llm_step: null pointer");
   MN_CHECK_ARG(M >= 1 && (M <= 64 || llm_wide_ok(m, M)) && x_row_div >= 1,
@@ -1026,7 +1042,7 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
                "mn_llm_step: fp8 experts need row scales, widths %% 16 == 0 and <= 64 rows (M = %d)", M);
   if (llm_wide_ok(m, M))
     return llm_step_wide(m, x, ldx, x_row_div, M, image_mask, row_seq, row_slot, row_pos, row_len, key_mask, ld_mask, kv_cache, n_seq, t_max,
-                         hidden_out, workspace, workspace_bytes, stream);
+                         hidden_out, workspace, workspace_bytes, stream, span_tab, n_spans, span_max_len);
   LlmWs w{};
   const size_t need = llm_carve(m, M, t_max, workspace, workspace_bytes, &w);
   if (need > workspace_bytes) { mn_set_error("mn_llm_step: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }

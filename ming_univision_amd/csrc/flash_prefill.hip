@@ -49,12 +49,15 @@ struct FlashP {
   int64_t q_bs, kv_bs, o_bs;                       // SRC 0: per image
   int T, past, causal;
   const uint8_t* key_mask; int64_t mask_bs;        // optional [*, keys] (1 = attend); SRC 1: one row per table entry
-  const int32_t* seq_tab; int64_t kv_seq_stride;   // SRC 1: [n][3] = (cache sequence, first q / out row, span length); NULL: (0, 0, T)
+  const int32_t* seq_tab; int64_t kv_seq_stride;   // SRC 1: [n][tab_w] = (cache sequence, first q / out row, span length[, past]); NULL: (0, 0, T)
+  int tab_w;                                       // 3, or 4 = every span brings its own `past`
+  int mask_per_row;                                // (unused with key_mask == NULL)
 };
 
 template <int HD, int SRC, bool HILO = false>
 __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
-  static_assert(!HILO || SRC == 0, "the hi/lo form reads packed fp32 qkv");
+  // query groups (16 queries each) per wave: the hi/lo form at head dim 128 keeps one (q, o, s, p hi + lo would not fit 256 registers)
+  constexpr int QG = (HILO && HD == 128) ? 1 : 2, QW = 16 * QG;
   constexpr int KROW = HD + 8, VROW = HD + 16, NKK = HD / 32, NDT = HD / 16;
   constexpr int ESZ = (SRC == 0 && !HILO) ? 2 : 4, PPR = HD * ESZ / 16, KPP = 256 / PPR, NP = FKT / KPP;
   __shared__ __attribute__((aligned(16))) bf16_t ks[FKT * KROW * (HILO ? 2 : 1)];     // HILO: the hi tile, then the lo tile
@@ -63,7 +66,8 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
   int T = p.T, q0, q_hi_wg;
-  const int past = p.past;
+  int past = p.past;
+  int64_t o_off;                                    // element offset of the (image | span, head)'s first output
   const bf16_t* qb;
   bf16_t* ob;
   const char *kb, *vb;
@@ -73,39 +77,46 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
     q0 = blockIdx.x * 128 + wave * 32;
     q_hi_wg = blockIdx.x * 128 + 127;
     qb = p.q + (b * p.q_bs + head * p.q_hs) * (HILO ? 2 : 1);          // HILO: q is fp32 (pointer arithmetic in bf16 units)
-    ob = p.out + b * p.o_bs + head * HD;                                // (HILO: element offset of the image's first row, used below)
+    o_off = b * p.o_bs + head * HD;
+    ob = p.out + o_off;
     kb = reinterpret_cast<const char*>(p.k) + (b * p.kv_bs + head * p.kv_hs) * ESZ;
     vb = reinterpret_cast<const char*>(p.v) + (b * p.kv_bs + head * p.kv_hs) * ESZ;
     if (km) km += b * p.mask_bs;
   } else {
     int seq = 0, r0 = 0;
-    if (p.seq_tab) { seq = p.seq_tab[blockIdx.z * 3]; r0 = p.seq_tab[blockIdx.z * 3 + 1]; T = p.seq_tab[blockIdx.z * 3 + 2]; }
+    if (p.seq_tab) {
+      const int32_t* te = p.seq_tab + blockIdx.z * p.tab_w;
+      seq = te[0]; r0 = te[1]; T = te[2];
+      if (p.tab_w > 3) past = te[3];
+    }
     const int kvh = blockIdx.y, head = kvh * 4 + wave;
-    q0 = blockIdx.x * 32;
-    q_hi_wg = q0 + 31;
+    q0 = blockIdx.x * QW;
+    q_hi_wg = q0 + QW - 1;
     if (q0 >= T) return;                                   // uniform per workgroup
-    qb = p.q + r0 * p.q_rs + head * p.q_hs;
-    ob = p.out + r0 * p.o_rs + head * HD;
+    qb = p.q + ((int64_t)r0 * p.q_rs + head * p.q_hs) * (HILO ? 2 : 1);
+    o_off = (int64_t)r0 * p.o_rs + head * HD;
+    ob = p.out + o_off;
     kb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(p.k) + seq * p.kv_seq_stride + kvh * p.kv_hs);
     vb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(p.v) + seq * p.kv_seq_stride + kvh * p.kv_hs);
     if (km) km += blockIdx.z * p.mask_bs;
   }
   const int k_total = past + T;
   const bool wave_on = q0 < T;
-  const int wave_kmax = p.causal ? past + min(T, q0 + 32) : k_total;       // keys this wave's queries can see
+  const int wave_kmax = p.causal ? past + min(T, q0 + QW) : k_total;       // keys this wave's queries can see
   const int ntile = ((p.causal ? past + min(T, q_hi_wg + 1) : k_total) + FKT - 1) / FKT;
 
   // Q fragments (B operand): Q[q][d = 32 kk + 8 g .. +8]; SRC 0 scales by 64^-0.5 = 0.125 (exact in bf16)
-  bf16x8 qf[2][NKK], qfl[HILO ? 2 : 1][HILO ? NKK : 1];
-  int q_idx[2];
+  bf16x8 qf[QG][NKK], qfl[HILO ? QG : 1][HILO ? NKK : 1];
+  int q_idx[QG];
 #pragma unroll
-  for (int qg = 0; qg < 2; ++qg) {
+  for (int qg = 0; qg < QG; ++qg) {
     q_idx[qg] = q0 + qg * 16 + i16;
     if constexpr (HILO) {
       const float* qr = reinterpret_cast<const float*>(qb) + (int64_t)min(q_idx[qg], T - 1) * p.q_rs + g * 8;
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(qr + kk * 32), b = *reinterpret_cast<const f32x4*>(qr + kk * 32 + 4);
+        f32x4 a = *reinterpret_cast<const f32x4*>(qr + kk * 32), b = *reinterpret_cast<const f32x4*>(qr + kk * 32 + 4);
+        if (SRC == 1) { a *= 8.0f; b *= 8.0f; }          // SRC 1: q arrives pre-scaled (the 0.125 below is SRC 0's 64^-0.5)
         u32x4 hi, lo;
         { const HL t_ = spl(a.x * 0.125f, a.y * 0.125f); hi.x = t_.h; lo.x = t_.l; } { const HL t_ = spl(a.z * 0.125f, a.w * 0.125f); hi.y = t_.h; lo.y = t_.l; }
         { const HL t_ = spl(b.x * 0.125f, b.y * 0.125f); hi.z = t_.h; lo.z = t_.l; } { const HL t_ = spl(b.z * 0.125f, b.w * 0.125f); hi.w = t_.h; lo.w = t_.l; }
@@ -127,12 +138,14 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
       qf[qg][kk] = __builtin_bit_cast(bf16x8, raw);
     }
   }
-  f32x4 o[2][NDT];
+  f32x4 o[QG][NDT];
+  float m_run[QG], l_run[QG];
 #pragma unroll
-  for (int qg = 0; qg < 2; ++qg)
+  for (int qg = 0; qg < QG; ++qg) {
+    m_run[qg] = -INFINITY; l_run[qg] = 0.f;
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) o[qg][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  }
 
   // staging: piece = 16 source bytes; a pass of the workgroup covers KPP whole key rows (coalesced)
   const int piece = tid % PPR, krow = tid / PPR;
@@ -182,22 +195,23 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
     if (kt + 1 < ntile) fetch(k0 + FKT);   // in flight under this tile's MFMAs
     if (!wave_on || k0 >= wave_kmax) continue;
 
-    f32x4 s[2][4];
+    f32x4 s[QG][4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-      s[0][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-      s[1][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int qg = 0; qg < QG; ++qg) s[qg][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kfr + f * 16 * KROW + kk * 32);
-        s[0][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][kk], s[0][f], 0, 0, 0);
-        s[1][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][kk], s[1][f], 0, 0, 0);
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) s[qg][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qg][kk], s[qg][f], 0, 0, 0);
         if constexpr (HILO) {
           const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kfr + KLO + f * 16 * KROW + kk * 32);
-          s[0][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfl[0][kk], s[0][f], 0, 0, 0);
-          s[1][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfl[1][kk], s[1][f], 0, 0, 0);
-          s[0][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qf[0][kk], s[0][f], 0, 0, 0);
-          s[1][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qf[1][kk], s[1][f], 0, 0, 0);
+#pragma unroll
+          for (int qg = 0; qg < QG; ++qg) {
+            s[qg][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfl[qg][kk], s[qg][f], 0, 0, 0);
+            s[qg][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qf[qg][kk], s[qg][f], 0, 0, 0);
+          }
         }
       }
     }
@@ -218,16 +232,16 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
           const int key = kb4 + r;
           const bool there = key < k_total && ((live >> r) & 1u);
 #pragma unroll
-          for (int qg = 0; qg < 2; ++qg) {
+          for (int qg = 0; qg < QG; ++qg) {
             const bool ok = there && (!p.causal || key <= past + q_idx[qg]);
             s[qg][f][r] = ok ? s[qg][f][r] : -INFINITY;
           }
         }
       }
     }
-    bf16x8 pf[2][2], pfl[HILO ? 2 : 1][2];
+    bf16x8 pf[QG][2], pfl[HILO ? QG : 1][2];
 #pragma unroll
-    for (int qg = 0; qg < 2; ++qg) {
+    for (int qg = 0; qg < QG; ++qg) {
       float mx = fmaxf(fmaxf(s[qg][0][0], s[qg][0][1]), fmaxf(s[qg][0][2], s[qg][0][3]));
 #pragma unroll
       for (int f = 1; f < 4; ++f) mx = fmaxf(mx, fmaxf(fmaxf(s[qg][f][0], s[qg][f][1]), fmaxf(s[qg][f][2], s[qg][f][3])));
@@ -276,30 +290,31 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashP p) {
         const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(vfr + (sl * 32 + 16) * VROW + dt * 16));
         const v8s vv = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
-        o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][sl], o[0][dt], 0, 0, 0);
-        o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][sl], o[1][dt], 0, 0, 0);
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) o[qg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qg][sl], o[qg][dt], 0, 0, 0);
         if constexpr (HILO) {
           const v4s llo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(vfr + VLO + (sl * 32) * VROW + dt * 16));
           const v4s lhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(vfr + VLO + (sl * 32 + 16) * VROW + dt * 16));
           const v8s vl = {llo.x, llo.y, llo.z, llo.w, lhi.x, lhi.y, lhi.z, lhi.w};
           const bf16x8 vfl = __builtin_bit_cast(bf16x8, vl);
-          o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfl[0][sl], o[0][dt], 0, 0, 0);
-          o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfl[1][sl], o[1][dt], 0, 0, 0);
-          o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, pf[0][sl], o[0][dt], 0, 0, 0);
-          o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, pf[1][sl], o[1][dt], 0, 0, 0);
+#pragma unroll
+          for (int qg = 0; qg < QG; ++qg) {
+            o[qg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfl[qg][sl], o[qg][dt], 0, 0, 0);
+            o[qg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, pf[qg][sl], o[qg][dt], 0, 0, 0);
+          }
         }
       }
   }
   if (!wave_on) return;
 #pragma unroll
-  for (int qg = 0; qg < 2; ++qg) {
+  for (int qg = 0; qg < QG; ++qg) {
     float l = l_run[qg];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     if (q_idx[qg] >= T) continue;
     const float inv = l > 0.f ? 1.0f / l : 0.f;   // no attended key: 0, not NaN
     if constexpr (HILO) {
-      const int64_t eo = (ob - p.out) + (int64_t)q_idx[qg] * p.o_rs + g * 4;      // element offset of this lane's first output
+      const int64_t eo = o_off + (int64_t)q_idx[qg] * p.o_rs + g * 4;      // element offset of this lane's first output
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
         const f32x4 v = o[qg][dt] * inv;
@@ -365,6 +380,25 @@ extern "C" int mn_flash_prefill_gqa_hd128_one(const uint16_t* q, const float* kv
   return MN_OK;
 }
 
+// The fp32-class form of mn_flash_prefill_gqa_hd128 (the wide-route prefill of mn_llm_step_spans): q FP32 [rows, n_q, 128] (RoPE'd,
+// pre-scaled), K / V from the fp32 arena, all operands as bf16 hi + lo pairs (three MFMAs per product); span table [n_spans][4] =
+// (cache sequence, first q / out row, span length, past); out fp32 [rows, n_q * 128] and / or split bf16 hi rows + lo rows
+// (lo rows split_lo_off elements after the hi rows).  No key mask.
+extern "C" int mn_flash_prefill_gqa_hd128_f32(const float* q, const float* kv_layer, int64_t t_max, int n_q, int n_kv, const int32_t* span_tab,
+                                              int n_spans, int max_len, float* out, uint16_t* split, int64_t split_lo_off, void* stream) {
+  MN_CHECK_ARG(q && kv_layer && (out || split) && span_tab && n_spans >= 1 && max_len >= 1 && max_len <= t_max && n_kv >= 1 && n_q == 4 * n_kv,
+               "mn_flash_prefill_gqa_hd128_f32: bad args (n_q must be 4 n_kv)");
+  FlashP p{};
+  p.q = reinterpret_cast<const bf16_t*>(q); p.k = kv_layer; p.v = kv_layer + (int64_t)n_kv * t_max * 128;
+  p.out_f32 = out; p.out_split = split; p.split_lo_off = split_lo_off;
+  p.q_rs = (int64_t)n_q * 128; p.q_hs = 128; p.kv_rs = 128; p.kv_hs = t_max * 128; p.o_rs = (int64_t)n_q * 128;
+  p.T = max_len; p.past = 0; p.causal = 1;
+  p.seq_tab = span_tab; p.tab_w = 4; p.kv_seq_stride = (int64_t)2 * n_kv * t_max * 128;
+  hipLaunchKernelGGL((flash_prefill_kernel<128, 1, true>), dim3(mn_cdiv(max_len, 16), n_kv, n_spans), dim3(256), 0, mn_stream(stream), p);
+  MN_CHECK_LAUNCH("mn_flash_prefill_gqa_hd128_f32");
+  return MN_OK;
+}
+
 // GQA 4:1 flash attention, head dim 128, of one or several prompt spans against the fp32 KV arena of one layer
 // (kv_layer [n_seq_total, 2, n_kv, t_max, 128]; span i = rows [r0_i, r0_i + len_i) of q / out, keys [0, past + len_i) of cache
 // sequence seq_i, bottom-right causal).  seq_tab: device int32 [n_spans][3] = (seq_i, r0_i, len_i); max_len >= every len_i.
@@ -378,7 +412,7 @@ extern "C" int mn_flash_prefill_gqa_hd128(const uint16_t* q, const float* kv_lay
   p.q = q; p.k = kv_layer; p.v = kv_layer + (int64_t)n_kv * t_max * 128; p.out = out;
   p.q_rs = (int64_t)n_q * 128; p.q_hs = 128; p.kv_rs = 128; p.kv_hs = t_max * 128; p.o_rs = (int64_t)n_q * 128;
   p.T = max_len; p.past = past; p.causal = 1; p.key_mask = key_mask; p.mask_bs = mask_stride;
-  p.seq_tab = seq_tab; p.kv_seq_stride = (int64_t)2 * n_kv * t_max * 128;
+  p.seq_tab = seq_tab; p.tab_w = 3; p.kv_seq_stride = (int64_t)2 * n_kv * t_max * 128;
   hipLaunchKernelGGL((flash_prefill_kernel<128, 1>), dim3(mn_cdiv(max_len, 32), n_kv, n_spans), dim3(256), 0, mn_stream(stream), p);
   MN_CHECK_LAUNCH("mn_flash_prefill_gqa_hd128");
   return MN_OK;

@@ -100,7 +100,7 @@ static size_t llm_wide_carve(const mn_llm* m, int rows, int64_t t_max, void* ws,
 static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int M, const uint8_t* image_mask, const int32_t* row_seq,
                          const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len, const uint8_t* key_mask,
                          int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max, float* hidden_out, void* workspace,
-                         size_t workspace_bytes, void* stream) {
+                         size_t workspace_bytes, void* stream, const int32_t* span_tab = nullptr, int n_spans = 0, int span_max_len = 0) {
   LlmWideWs w;
   const size_t need = llm_wide_carve(m, M, t_max, workspace, workspace_bytes, &w);
   if (need > workspace_bytes) { mn_set_error("mn_llm_step: workspace %zu < %zu", workspace_bytes, need); return MN_ENOSPACE; }
@@ -133,8 +133,13 @@ static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row
     MN_TRY(mn_rope_kv_from_partials(w.pp, qkv_dim, nz, (int64_t)M * qkv_dim, M, nq, nkv, hd, 1, m->cos_tab, m->sin_tab, row_seq,
                                     row_slot, row_pos, m->mrope_sec_t, m->mrope_sec_h, q_scale, w.q, kv_l, t_max, stream));
     // masked GQA against the cache; the combine writes the dense projection's hi/lo operand  (:791-812)
-    MN_TRY(mn_attn_decode_split(w.q, M, nq, nkv, hd, kv_l, t_max, row_seq, row_len, key_mask, ld_mask, nullptr, w.ya, w.attn_ws,
-                                w.attn_ws_bytes, stream));
+    // (a prefill chunk described as spans: the tiled hi/lo flash kernel — a staged K / V tile serves 16 query rows x 4 heads instead of
+    //  every row re-reading its whole prefix)
+    if (span_tab && hd == 128 && nq == 4 * nkv && !key_mask)
+      MN_TRY(mn_flash_prefill_gqa_hd128_f32(w.q, kv_l, t_max, nq, nkv, span_tab, n_spans, span_max_len, nullptr, w.ya, (int64_t)M * ad, stream));
+    else
+      MN_TRY(mn_attn_decode_split(w.q, M, nq, nkv, hd, kv_l, t_max, row_seq, row_len, key_mask, ld_mask, nullptr, w.ya, w.attn_ws,
+                                  w.attn_ws_bytes, stream));
     a = g256_hilo(w.ya, ad, lo_at(LO_LLM_DENSE, (int64_t)M * ad), m->wdense[l], ad, nullptr, w.pp, H, M, H, ad);
     a.c_zstride = (int64_t)M * H;
     nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks_dense, stream);

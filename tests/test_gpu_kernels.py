@@ -258,6 +258,38 @@ def test_attn_prefill_hd64_f32_hilo(ops, B, T, nh, causal):
     assert torch.equal(only_split, split)
 
 
+def test_flash_prefill_gqa_hd128_f32_hilo_spans(ops):
+    """The fp32-class GQA flash attention of mn_llm_step_spans (hd 128, 16:4, q fp32, K / V from the fp32 arena, operands as bf16 hi/lo
+    pairs): four spans with their OWN past (a sequence cut by a pass boundary continues with past > 0), against fp64 causal softmax
+    attention on the unrounded fp32 values: 1e-4-class; fp32 output and hi/lo output agree."""
+    from ming_univision_amd._lib import lib, ptr, check, current_stream
+    L = lib()
+    nq, nkv, t_max, hd = 16, 4, 260, 128
+    spans = [(2, 0, 70, 0), (0, 70, 33, 21), (3, 103, 129, 100), (1, 232, 17, 0)]        # (seq, r0, len, past)
+    M = sum(n for _, _, n, _ in spans)
+    g = torch.Generator().manual_seed(63)
+    kv = torch.randn(4, 2, nkv, t_max, hd, generator=g) * (0.5 + torch.rand(4, 2, nkv, t_max, 1, generator=g) * 2)
+    q = torch.randn(M, nq, hd, generator=g) * 0.2
+    tab = torch.tensor(spans, dtype=torch.int32).cuda()
+    out = torch.zeros(M, nq * hd, device="cuda")
+    split = torch.zeros(2, M, nq * hd, dtype=torch.bfloat16, device="cuda")
+    qd, kvd = q.cuda(), kv.cuda()                    # (named: a temporary's block would be reused by the next allocation)
+    check(L.mn_flash_prefill_gqa_hd128_f32(ptr(qd), ptr(kvd), t_max, nq, nkv, ptr(tab), len(spans), max(n for _, _, n, _ in spans),
+                                           ptr(out), ptr(split), M * nq * hd, current_stream()), "flash f32")
+    kd = kv.double()
+    for s_, r0, n, past in spans:
+        T = past + n
+        K = kd[s_, 0, :, :T].repeat_interleave(nq // nkv, 0)
+        V = kd[s_, 1, :, :T].repeat_interleave(nq // nkv, 0)
+        Q = q[r0:r0 + n].double().permute(1, 0, 2)
+        att = Q @ K.transpose(-1, -2)
+        ok = torch.arange(T)[None, :] <= (past + torch.arange(n))[:, None]
+        att = att.masked_fill(~ok[None], float("-inf"))
+        ref = (att.softmax(-1) @ V).permute(1, 0, 2).reshape(n, nq * hd)
+        assert rel(out[r0:r0 + n], ref) < 1e-4, (s_, r0, n, past)
+    assert rel(split[0].float() + split[1].float(), out) < 2 ** -15
+
+
 @pytest.mark.parametrize("past,with_mask", [(0, False), (37, False), (5, True)])
 def test_flash_prefill_gqa_hd128_spans(ops, past, with_mask):
     """GQA 16:4 flash attention (hd 128, bottom-right causal) of three prompt spans of different lengths in ONE launch, K / V
