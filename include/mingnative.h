@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MN_VERSION 121 /* 0.1.20: fp8 weight mode (section 7): wfmt / row-scale fields at the END of mn_skinny_args, mn_rf_head,
+#define MN_VERSION 122 /* 0.1.20: fp8 weight mode (section 7): wfmt / row-scale fields at the END of mn_skinny_args, mn_rf_head,
                           mn_llm and mn_llm_tp (zero = bf16: callers of 0.1.10 that zero-fill the structs are unchanged),
                           mn_quant_fp8_rows / mn_dequant_fp8_rows / mn_stream_mfma_w8 / mn_stream_mfma_grouped_w8 */
 
@@ -641,7 +641,13 @@ MN_API int mn_sample_logits(const float* logits, int64_t ld, int M, int V, float
  *    model is reported separately.  mn_quant_fp8_rows emits power-of-two scales, for which the dequantised weights are exactly
  *    representable in bf16 (mn_dequant_fp8_rows): the same model can be run through every bf16 route.
  * ------------------------------------------------------------------------------------------ */
-enum { MN_W_BF16 = 0, MN_W_FP8_E4M3 = 1 };
+enum { MN_W_BF16 = 0, MN_W_FP8_E4M3 = 1, MN_W_INT8 = 2 };
+/* MN_W_INT8 (round 4): the same weight-only mode on two's-complement int8 bytes — the reference's `dtype="int8"` surface
+ * (mingunivisioninfer.py:59-68: optimum-quanto qint8 weights, symmetric, one scale per output channel; third-party, absent here) —
+ *     W[n, k] = Wq[n, k] * scale[n],  Wq in [-127, 127],  scale[n] = 2^ceil(log2(amax_n / 127)).
+ * The power-of-two scale (quanto uses amax / 127: at most one of the seven magnitude bits more) keeps W exactly representable in bf16,
+ * like the e4m3 form.  Every `wfmt` field and the `_wq` entry points below take either format; kernels, row limits and call sites are
+ * the fp8 mode's (the bytes are converted to bf16 / fp32 in registers: sign-extend + v_cvt_f32_i32). */
 /* Row-wise quantisation at load: scale[n] = 2^ceil(log2(amax_n / 448)) (1 for an all-zero row), Wq[n, k] = e4m3_rne(W[n, k] / scale[n]).
  * W bf16 [n_rows, K] (row stride ldw), Wq bytes (row stride ldq), K % 4 == 0. */
 MN_API int mn_quant_fp8_rows(const uint16_t* W, int64_t ldw, uint8_t* Wq, int64_t ldq, float* scale, int64_t n_rows, int K, void* stream);
@@ -651,6 +657,16 @@ MN_API int mn_dequant_fp8_rows(const uint8_t* Wq, int64_t ldq, const float* scal
 /* mn_stream_mfma / mn_stream_mfma_grouped on fp8 weights: Wq e4m3 [Ntot, K] dense (K % 16 == 0, 16-byte aligned), wscale fp32
  * [Ntot]; grouped: group g reads Wq + g * w_stride bytes and wscale + g * s_stride floats.  Half the HBM bytes per launch. */
 MN_API int mn_stream_mfma_w8(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, void* stream);
+/* ... with the byte format as an argument (wfmt = MN_W_FP8_E4M3 | MN_W_INT8; the _w8 forms are wfmt = MN_W_FP8_E4M3) */
+MN_API int mn_stream_mfma_wq(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, int wfmt, void* stream);
+MN_API int mn_stream_mfma_grouped_wq(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale,
+                                     int64_t s_stride, float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G,
+                                     int max_rows, int Ntot, int K, int wfmt, void* stream);
+/* int8 rows: scale[n] = 2^ceil(log2(amax_n / 127)) (1 for an all-zero row), Wq[n, k] = rne(W[n, k] / scale[n]) in [-127, 127]; and back
+ * (exact in bf16).  Arguments as the fp8 pair. */
+MN_API int mn_quant_int8_rows(const uint16_t* W, int64_t ldw, uint8_t* Wq, int64_t ldq, float* scale, int64_t n_rows, int K, void* stream);
+MN_API int mn_dequant_int8_rows(const uint8_t* Wq, int64_t ldq, const float* scale, uint16_t* W, int64_t ldw, int64_t n_rows, int K,
+                                void* stream);
 MN_API int mn_stream_mfma_w8_slices(int M, int Ntot, int K);
 MN_API int mn_stream_mfma_grouped_w8(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale,
                                      int64_t s_stride, float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G,

@@ -105,8 +105,9 @@ class LlmTp(C.Structure):
     ]
 
 
-W_BF16, W_FP8_E4M3 = 0, 1          # mingnative.h section 7: weight formats of the streaming route
-WFMT = {"bf16": W_BF16, "fp8": W_FP8_E4M3}
+W_BF16, W_FP8_E4M3, W_INT8 = 0, 1, 2          # mingnative.h section 7: weight formats of the streaming route
+WFMT = {"bf16": W_BF16, "fp8": W_FP8_E4M3, "int8": W_INT8}
+W8 = ("fp8", "int8")                           # the weight-only 8-bit modes (bytes + one power-of-two scale per output row)
 
 _lib = None
 
@@ -121,6 +122,10 @@ SYMBOLS = {
     "mn_skinny_workspace_bytes_w8": (_sz, [_i, _i, _i, _i]),
     "mn_quant_fp8_rows": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _p]),
     "mn_dequant_fp8_rows": (_i, [_p, _i64, _p, _p, _i64, _i64, _i, _p]),
+    "mn_quant_int8_rows": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _p]),
+    "mn_dequant_int8_rows": (_i, [_p, _i64, _p, _p, _i64, _i64, _i, _p]),
+    "mn_stream_mfma_wq": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "mn_stream_mfma_grouped_wq": (_i, [_p, _i, _p, _i64, _p, _i64, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mn_stream_mfma_w8": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "mn_stream_mfma_w8_slices": (_i, [_i, _i, _i]),
     "mn_stream_mfma_grouped_w8": (_i, [_p, _i, _p, _i64, _p, _i64, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
@@ -220,7 +225,7 @@ def lib():
         fn = getattr(handle, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if handle.mn_version() < 121:
+    if handle.mn_version() < 122:
         raise RuntimeError("libmingnative.so is too old")
     _lib = handle
     return _lib

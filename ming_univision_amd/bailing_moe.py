@@ -57,10 +57,11 @@ def pack_experts(sd, prefix, cfg):
     return gu, dn
 
 
-def quantize_layer_experts(ly):
-    """fp8 weight mode: replace a layer's packed bf16 experts by e4m3 bytes + row scales [E + S, 2I] / [E + S, H] (in place)."""
+def quantize_layer_experts(ly, weights="fp8"):
+    """8-bit weight modes: replace a layer's packed bf16 experts by e4m3 ("fp8") or int8 bytes + row scales [E + S, 2I] / [E + S, H]
+    (in place)."""
     for k in ("w_gate_up", "w_down"):
-        ly[k], ly[k + "_scale"] = ops.quant_fp8_rows(ly[k])
+        ly[k], ly[k + "_scale"] = ops.quant_rows(ly[k], weights)
     return ly
 
 
@@ -77,12 +78,12 @@ class BailingMoeDecoder:
         w_gate_up, w_down (see pack_experts).  Use `from_state_dict` / `synthetic` to build them.
         weights="fp8": w_gate_up / w_down are e4m3 bytes (uint8) with `w_gate_up_scale` / `w_down_scale` (quantize_layer_experts;
         bf16 experts are quantised here)."""
-        assert weights in _lib.WFMT, f"weights={weights!r}: 'bf16' or 'fp8'"
+        assert weights in _lib.WFMT, f"weights={weights!r}: 'bf16', 'fp8' or 'int8'"
         self.weights = weights
-        if weights == "fp8":
+        if weights in _lib.W8:
             for ly in layers:
                 if ly["w_gate_up"].dtype != torch.uint8:
-                    quantize_layer_experts(ly)
+                    quantize_layer_experts(ly, weights)
         rs = cfg.rope_scaling
         assert rs is None or rs.get("type") == "3D", "Legacy or 3D rotary only (linear / NTK / YaRN are dead code, SURVEY.md a27)"
         # 3D rotary (:413-425, 463-469): same tables, per-frequency choice among the t / h / w position streams.
@@ -111,7 +112,7 @@ class BailingMoeDecoder:
         for k in keys:
             setattr(s, k, C.cast(self._arrays[k], _lib.PP))
         s.wfmt = _lib.WFMT[weights]
-        if weights == "fp8":
+        if weights in _lib.W8:
             for k in ("w_gate_up_scale", "w_down_scale"):
                 self._arrays[k] = ptr_array([ly[k] for ly in layers])
                 setattr(s, k, C.cast(self._arrays[k], _lib.PP))
@@ -161,8 +162,8 @@ class BailingMoeDecoder:
                 gate=sd[p + ".mlp.gate.weight"],
                 image_gate=sd.get(p + ".mlp.image_gate.weight") if cfg.multi_gate else None,
                 w_gate_up=gu, w_down=dn))
-            if kw.get("weights") == "fp8":          # layer by layer: the bf16 experts of one layer at a time
-                quantize_layer_experts(layers[-1])
+            if kw.get("weights") in _lib.W8:        # layer by layer: the bf16 experts of one layer at a time
+                quantize_layer_experts(layers[-1], kw["weights"])
             del sd, gu, dn
         H, V = cfg.hidden_size, cfg.vocab_size
         fn = synth_tensor("model.norm.weight", (H,), seed, device, torch.bfloat16)
@@ -178,13 +179,13 @@ class BailingMoeDecoder:
         return BailingMoeDecoder(self.cfg, self.layers, self.final_norm, self.word_embeddings, self.lm_head, t_max=t_max, n_seq=n_seq,
                                  n_pos=n_pos, weights=self.weights)
 
-    def to_fp8(self, t_max=None, n_seq=None):
-        """A second decoder whose experts are e4m3 copies of this one's (attention / router / vocabulary tensors shared; this bf16
-        decoder stays usable): + 0.5 bytes per expert parameter of HBM."""
-        assert self.weights == "bf16"
-        layers = [quantize_layer_experts(dict(ly)) for ly in self.layers]
+    def to_fp8(self, t_max=None, n_seq=None, weights="fp8"):
+        """A second decoder whose experts are 8-bit copies of this one's — e4m3 (default) or int8 (weights="int8") — (attention /
+        router / vocabulary tensors shared; this bf16 decoder stays usable): + 0.5 bytes per expert parameter of HBM."""
+        assert self.weights == "bf16" and weights in _lib.W8
+        layers = [quantize_layer_experts(dict(ly), weights) for ly in self.layers]
         return BailingMoeDecoder(self.cfg, layers, self.final_norm, self.word_embeddings, self.lm_head, t_max=t_max or self.t_max,
-                                 n_seq=n_seq or self.n_seq, weights="fp8")
+                                 n_seq=n_seq or self.n_seq, weights=weights)
 
     def weight_bytes_active(self, distinct_experts_per_layer):
         """Weight bytes one decode step streams: attention + router (bf16) + the distinct routed and the shared experts
@@ -216,9 +217,9 @@ class BailingMoeDecoder:
 
     def dequantized_experts(self, li):
         """fp8 mode: layer li's packed experts as the kernels see them (e4m3 * row scale, exact in bf16): (w_gate_up, w_down)."""
-        assert self.weights == "fp8"
+        assert self.weights in _lib.W8
         ly = self.layers[li]
-        return (ops.dequant_fp8_rows(ly["w_gate_up"], ly["w_gate_up_scale"]), ops.dequant_fp8_rows(ly["w_down"], ly["w_down_scale"]))
+        return (ops.dequant_rows(ly["w_gate_up"], ly["w_gate_up_scale"], self.weights), ops.dequant_rows(ly["w_down"], ly["w_down_scale"], self.weights))
 
     # ---- stepping -------------------------------------------------------------------------
     def _workspace(self, rows):

@@ -37,20 +37,25 @@ extern "C" int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint1
                                       int Ntot, int K, void* stream);
 extern "C" size_t mn_skinny_workspace_bytes_w8(int M, int N, int K, int epilogue);
 
-// ---- weight-format dispatch of the streaming launches (mingnative.h section 7): wfmt != 0 -> e4m3 bytes + fp32 row scales ----
+// ---- weight-format dispatch of the streaming launches (mingnative.h section 7): wfmt != 0 -> 8-bit bytes (e4m3 | int8) + fp32 row scales ----
+static inline bool mn_w8(int wfmt) { return wfmt == MN_W_FP8_E4M3 || wfmt == MN_W_INT8; }
+extern "C" int mn_stream_mfma_wq(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, int wfmt, void* stream);
+extern "C" int mn_stream_mfma_grouped_wq(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale, int64_t s_stride,
+                                         float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows, int Ntot, int K,
+                                         int wfmt, void* stream);
 static inline int stream_slices(int wfmt, int M, int Ntot, int K) {
   return wfmt ? mn_stream_mfma_w8_slices(M, Ntot, K) : mn_stream_mfma_slices(M, Ntot, K);
 }
 static inline int stream_dense(int wfmt, const uint16_t* Y, const void* W, const float* wscale, float* P, int M, int Ntot, int K, void* stream) {
-  return wfmt ? mn_stream_mfma_w8(Y, reinterpret_cast<const uint8_t*>(W), wscale, P, M, Ntot, K, stream)
+  return wfmt ? mn_stream_mfma_wq(Y, reinterpret_cast<const uint8_t*>(W), wscale, P, M, Ntot, K, wfmt, stream)
               : mn_stream_mfma(Y, reinterpret_cast<const uint16_t*>(W), P, M, Ntot, K, stream);
 }
 // grouped: w_stride counts weight ELEMENTS (= bytes for fp8), s_stride the row scales per group
 static inline int stream_grouped(int wfmt, const uint16_t* Y, int y_rows, const void* W, int64_t w_stride, const float* wscale, int64_t s_stride,
                                  float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows, int Ntot, int K,
                                  void* stream) {
-  return wfmt ? mn_stream_mfma_grouped_w8(Y, y_rows, reinterpret_cast<const uint8_t*>(W), w_stride, wscale, s_stride, P, p_rows, off, xrows,
-                                          G, max_rows, Ntot, K, stream)
+  return wfmt ? mn_stream_mfma_grouped_wq(Y, y_rows, reinterpret_cast<const uint8_t*>(W), w_stride, wscale, s_stride, P, p_rows, off, xrows,
+                                          G, max_rows, Ntot, K, wfmt, stream)
               : mn_stream_mfma_grouped(Y, y_rows, reinterpret_cast<const uint16_t*>(W), w_stride, P, p_rows, off, xrows, G, max_rows, Ntot,
                                        K, stream);
 }
@@ -447,7 +452,7 @@ static bool rf_chain_ok(const mn_rf_head* h, int rows) {
 }
 // fp8 weight mode: the RF blocks must be able to run as the matrix-core chain (the fp32-FMA kernels read bf16 rows)
 static bool rf_fp8_ok(const mn_rf_head* h) {
-  return h->wfmt == MN_W_FP8_E4M3 && h->w12_scale && h->w3_scale && h->w <= 4096 && (h->w % 16) == 0 && (h->hidden % 16) == 0;
+  return mn_w8(h->wfmt) && h->w12_scale && h->w3_scale && h->w <= 4096 && (h->w % 16) == 0 && (h->hidden % 16) == 0;
 }
 
 // <= 4 rows (the CFG rows of one image — the reference's call shape): the SwiGLU glue launch is folded into w3's prologue
@@ -555,7 +560,7 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   const int64_t SR = (int64_t)h->steps * rows;
   hipLaunchKernelGGL(rf_build_y_kernel, dim3(mn_cdiv(SR * w, 256)), dim3(256), 0, st, h->temb, c, y, h->steps, rows, w);
   if (rf_ada_w8(h, rows)) {      // <= 64 (step, row) pairs: stream the 0.36 GB of e4m3 adaLN bytes once, then slabs + bias -> ada
-    const int nza = mn_stream_mfma_w8(y, h->ada_q, h->ada_scale, pada, (int)SR, A, w, stream);
+    const int nza = mn_stream_mfma_wq(y, h->ada_q, h->ada_scale, pada, (int)SR, A, w, h->wfmt, stream);
     if (nza < 0) return nza;
     hipLaunchKernelGGL(rf_glue_bias_out_kernel, dim3(mn_cdiv(SR * A, 256)), dim3(256), 0, st, pada, nza, (int)SR, A, h->ada_b, ada);
   } else {
@@ -1037,7 +1042,7 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
   MN_CHECK_ARG(M >= 1 && (M <= 64 || llm_wide_ok(m, M)) && x_row_div >= 1,
                "mn_llm_step: M=%d (1..64, or up to 2048 rows with 64-aligned widths)", M);
   // fp8 experts: 1 or 2 rows run the one-row fp8 kernel on the (row, expert) pairs, more the grouped streaming kernels
-  MN_CHECK_ARG(m->wfmt == MN_W_BF16 || (m->wfmt == MN_W_FP8_E4M3 && m->w_gate_up_scale && m->w_down_scale && (m->hidden % 16) == 0 &&
+  MN_CHECK_ARG(m->wfmt == MN_W_BF16 || (mn_w8(m->wfmt) && m->w_gate_up_scale && m->w_down_scale && (m->hidden % 16) == 0 &&
                                         (m->moe_inter % 16) == 0 && M <= 64 && (M < MOE_MFMA_MIN_ROWS || moe_mfma_ok(m, M))),
                "mn_llm_step: fp8 experts need row scales, widths %% 16 == 0 and <= 64 rows (M = %d)", M);
   if (llm_wide_ok(m, M))

@@ -55,7 +55,74 @@ __global__ __launch_bounds__(256) void dequant_fp8_rows_kernel(const uint8_t* __
   }
 }
 
+// ---- int8 (MN_W_INT8): symmetric, one power-of-two scale per output row, q = rint(w / scale) in [-127, 127].
+// scale = 2^es with amax / 2^es in (63.5, 127]:  127 = 1.984375 * 2^6  ->  es = ea - 6 (+1 if ma > 1.984375).  |q| <= 127 is 7 bits, so
+// q * scale is exactly representable in bf16 like the e4m3 form's products: the int8 model is a bf16 model too.  (The reference's
+// int8 surface — optimum-quanto qint8 weights, mingunivisioninfer.py:59-68 — scales by amax / 127; the power of two costs at most one
+// of the 7 bits and buys that exactness.)
+__device__ __forceinline__ float pow2_scale_int8(float amax) {
+  const uint32_t u = __float_as_uint(amax);
+  if ((u & 0x7fffffffu) == 0u) return 1.0f;
+  int es = (int)(u >> 23) - 127 - 6 + ((u & 0x7fffffu) > 0x7e0000u ? 1 : 0);
+  es = es < -126 ? -126 : (es > 127 ? 127 : es);
+  return __uint_as_float((uint32_t)(es + 127) << 23);
+}
+
+__global__ __launch_bounds__(256) void quant_int8_rows_kernel(const bf16_t* __restrict__ W, int64_t ldw, uint8_t* __restrict__ Q, int64_t ldq,
+                                                              float* __restrict__ scale, int K) {
+  __shared__ float red[4];
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  const int64_t n = blockIdx.x;
+  const bf16_t* wr = W + n * ldw;
+  float amax = 0.f;
+  for (int k = threadIdx.x * 4; k < K; k += 1024) {
+    const u2 v = *reinterpret_cast<const u2*>(wr + k);
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(bf16lo_to_f32(v.x)), fabsf(bf16hi_to_f32(v.x))), fmaxf(fabsf(bf16lo_to_f32(v.y)), fabsf(bf16hi_to_f32(v.y)))));
+  }
+  amax = block_max(amax, red);
+  const float s = pow2_scale_int8(amax);
+  const float inv = 1.0f / s;                          // exact: s is a power of two
+  if (threadIdx.x == 0) scale[n] = s;
+  auto q8 = [&](float w) { return (uint32_t)((int)fminf(fmaxf(rintf(w * inv), -127.f), 127.f) & 0xff); };      // round to nearest even
+  for (int k = threadIdx.x * 4; k < K; k += 1024) {
+    const u2 v = *reinterpret_cast<const u2*>(wr + k);
+    *reinterpret_cast<uint32_t*>(Q + n * ldq + k) =
+        q8(bf16lo_to_f32(v.x)) | (q8(bf16hi_to_f32(v.x)) << 8) | (q8(bf16lo_to_f32(v.y)) << 16) | (q8(bf16hi_to_f32(v.y)) << 24);
+  }
+}
+
+__global__ __launch_bounds__(256) void dequant_int8_rows_kernel(const uint8_t* __restrict__ Q, int64_t ldq, const float* __restrict__ scale,
+                                                                bf16_t* __restrict__ W, int64_t ldw, int K) {
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  const int64_t n = blockIdx.x;
+  const float s = scale[n];
+  for (int k = threadIdx.x * 4; k < K; k += 1024) {
+    const int q = *reinterpret_cast<const int*>(Q + n * ldq + k);
+    const float f0 = (float)((q << 24) >> 24), f1 = (float)((q << 16) >> 24), f2 = (float)((q << 8) >> 24), f3 = (float)(q >> 24);
+    *reinterpret_cast<u2*>(W + n * ldw + k) = u2{cvt_pk_bf16(f0 * s, f1 * s), cvt_pk_bf16(f2 * s, f3 * s)};
+  }
+}
+
 }  // namespace
+
+extern "C" int mn_quant_int8_rows(const uint16_t* W, int64_t ldw, uint8_t* Wq, int64_t ldq, float* scale, int64_t n_rows, int K, void* stream) {
+  MN_CHECK_ARG(W && Wq && scale && n_rows >= 1 && n_rows < ((int64_t)1 << 31) && K >= 4 && (K % 4) == 0 && (ldw % 4) == 0 && (ldq % 4) == 0 &&
+                   (((uintptr_t)W) & 7) == 0 && (((uintptr_t)Wq) & 3) == 0,
+               "mn_quant_int8_rows: bad args (K, ldw, ldq multiples of 4)");
+  hipLaunchKernelGGL(quant_int8_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, mn_stream(stream), W, ldw, Wq, ldq, scale, K);
+  MN_CHECK_LAUNCH("mn_quant_int8_rows");
+  return MN_OK;
+}
+
+extern "C" int mn_dequant_int8_rows(const uint8_t* Wq, int64_t ldq, const float* scale, uint16_t* W, int64_t ldw, int64_t n_rows, int K,
+                                    void* stream) {
+  MN_CHECK_ARG(W && Wq && scale && n_rows >= 1 && n_rows < ((int64_t)1 << 31) && K >= 4 && (K % 4) == 0 && (ldw % 4) == 0 && (ldq % 4) == 0 &&
+                   (((uintptr_t)W) & 7) == 0 && (((uintptr_t)Wq) & 3) == 0,
+               "mn_dequant_int8_rows: bad args (K, ldw, ldq multiples of 4)");
+  hipLaunchKernelGGL(dequant_int8_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, mn_stream(stream), Wq, ldq, scale, W, ldw, K);
+  MN_CHECK_LAUNCH("mn_dequant_int8_rows");
+  return MN_OK;
+}
 
 extern "C" int mn_quant_fp8_rows(const uint16_t* W, int64_t ldw, uint8_t* Wq, int64_t ldq, float* scale, int64_t n_rows, int K, void* stream) {
   MN_CHECK_ARG(W && Wq && scale && n_rows >= 1 && n_rows < ((int64_t)1 << 31) && K >= 4 && (K % 4) == 0 && (ldw % 4) == 0 && (ldq % 4) == 0 &&

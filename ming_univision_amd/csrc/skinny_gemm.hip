@@ -211,7 +211,7 @@ int launch_m(const KArgs& ka, int R, int sw, int nt, dim3 grid, size_t lds, hipS
 // ===========================================================================================
 extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream);
 extern "C" int mn_stream_mfma_slices(int M, int Ntot, int K);
-extern "C" int mn_stream_mfma_w8(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, void* stream);
+extern "C" int mn_stream_mfma_wq(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, int wfmt, void* stream);
 extern "C" int mn_stream_mfma_w8_slices(int M, int Ntot, int K);
 extern "C" int mn_skinny_w8_row(const mn_skinny_args* args, void* stream);      // skinny_w8.hip
 
@@ -314,7 +314,7 @@ static int skinny_medium(const mn_skinny_args& a, void* stream) {
   MN_CHECK_ARG((a.batch <= 1) && (a.nseg <= 1), "mn_skinny_gemm: batch/nseg forms need M <= 8");
   MN_CHECK_ARG(a.ldw == a.K, "mn_skinny_gemm: M > 8 needs densely packed weights (ldw == K)");
   const int Ntot = a.epilogue == MN_EPI_SWIGLU ? 2 * a.N : a.N;
-  const bool w8 = a.wfmt == MN_W_FP8_E4M3;
+  const bool w8 = a.wfmt != MN_W_BF16;
   MN_CHECK_ARG(!w8 || (a.wscale && (a.K % 16) == 0), "mn_skinny_gemm: fp8 weights need wscale and K %% 16 == 0");
   const size_t need = w8 ? mn_skinny_workspace_bytes_w8(a.M, a.N, a.K, a.epilogue) : mn_skinny_workspace_bytes(a.M, a.N, a.K, a.epilogue);
   if (!a.ws || a.ws_bytes < need) { mn_set_error("mn_skinny_gemm: M=%d needs %zu workspace bytes", a.M, need); return MN_ENOSPACE; }
@@ -322,7 +322,7 @@ static int skinny_medium(const mn_skinny_args& a, void* stream) {
   float* P = reinterpret_cast<float*>(reinterpret_cast<char*>(a.ws) + (((size_t)2 * a.M * a.K * sizeof(bf16_t) + 255) & ~(size_t)255));
   hipStream_t st = mn_stream(stream);
   hipLaunchKernelGGL(medium_prologue_kernel, dim3(a.M), dim3(1024), 0, st, a, Y);
-  const int nz = w8 ? mn_stream_mfma_w8(Y, reinterpret_cast<const uint8_t*>(a.w), a.wscale, P, a.M, Ntot, a.K, stream)
+  const int nz = w8 ? mn_stream_mfma_wq(Y, reinterpret_cast<const uint8_t*>(a.w), a.wscale, P, a.M, Ntot, a.K, a.wfmt, stream)
                     : mn_stream_mfma(Y, a.w, P, a.M, Ntot, a.K, stream);
   if (nz < 0) return nz;
   hipLaunchKernelGGL(medium_epilogue_kernel, dim3((unsigned)mn_cdiv((int64_t)a.M * a.N, 256)), dim3(256), 0, st, a, P, nz, Ntot);
@@ -349,8 +349,8 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   MN_CHECK_ARG(a.epilogue >= 0 && a.epilogue <= MN_EPI_RESID_GATE, "mn_skinny_gemm: bad epilogue %d", a.epilogue);
   ka.nseg = a.nseg > 0 ? a.nseg : 1;
   ka.batch = a.batch > 0 ? a.batch : 1;
-  MN_CHECK_ARG(a.wfmt == MN_W_BF16 || a.wfmt == MN_W_FP8_E4M3, "mn_skinny_gemm: bad wfmt %d", a.wfmt);
-  if (a.wfmt == MN_W_FP8_E4M3) {
+  MN_CHECK_ARG(a.wfmt == MN_W_BF16 || a.wfmt == MN_W_FP8_E4M3 || a.wfmt == MN_W_INT8, "mn_skinny_gemm: bad wfmt %d", a.wfmt);
+  if (a.wfmt != MN_W_BF16) {
     // one row per batch entry with a plain prologue: the one-row fp8 kernel (expert pair launches, batch / segment forms included);
     // everything else: the matrix-core route (checks dense weights / no batch forms / workspace)
     const bool row_form = a.M == 1 && a.prologue == MN_PRO_NONE &&

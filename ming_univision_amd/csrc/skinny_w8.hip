@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "skinny_device.h"
+#include "w8_codec.h"
 
 namespace {
 
@@ -27,15 +28,15 @@ struct W8Args {
   int32_t inv_nchunk;  // ceil(65536 / nchunk)
 };
 
-__device__ __forceinline__ void fma16(const u32x4 q, const float* xl, float& acc) {
-  typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fma16(int wf, const u32x4 q, const float* xl, float& acc) {
   const uint32_t w[4] = {q.x, q.y, q.z, q.w};
   float t = acc;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const f32x4 x = *reinterpret_cast<const f32x4*>(xl + j * 256);
-    const f2 a = __builtin_amdgcn_cvt_pk_f32_fp8(w[j], false), b = __builtin_amdgcn_cvt_pk_f32_fp8(w[j], true);
-    t = fmaf(a.x, x.x, t); t = fmaf(a.y, x.y, t); t = fmaf(b.x, x.z, t); t = fmaf(b.y, x.w, t);
+    float wv[4];
+    w8x4_to_f32(wf, w[j], wv);                     // e4m3 or int8 bytes -> fp32, exact (w8_codec.h)
+    t = fmaf(wv[0], x.x, t); t = fmaf(wv[1], x.y, t); t = fmaf(wv[2], x.z, t); t = fmaf(wv[3], x.w, t);
   }
   acc = t;
 }
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(NT) void skinny_w8_kernel(const W8Args ka) {
 #pragma unroll
       for (int s = 0; s < SW; ++s)
 #pragma unroll
-        for (int r = 0; r < R; ++r) fma16(src[s][r], xp, acc[s][r]);
+        for (int r = 0; r < R; ++r) fma16(a.wfmt, src[s][r], xp, acc[s][r]);
       if (--seg_left == 0) {                              // segment done: fold its partial sums with ITS row scales
 #pragma unroll
         for (int s = 0; s < SW; ++s)
@@ -208,7 +209,7 @@ extern "C" int mn_skinny_w8_row(const mn_skinny_args* args, void* stream) {
   W8Args ka;
   ka.a = *args;
   const mn_skinny_args& a = ka.a;
-  MN_CHECK_ARG(a.M == 1 && a.wfmt == MN_W_FP8_E4M3 && a.wscale && a.x && a.w && a.out, "mn_skinny_gemm(fp8 row): M == 1, weights + row scales");
+  MN_CHECK_ARG(a.M == 1 && (a.wfmt == MN_W_FP8_E4M3 || a.wfmt == MN_W_INT8) && a.wscale && a.x && a.w && a.out, "mn_skinny_gemm(fp8 row): M == 1, weights + row scales");
   MN_CHECK_ARG(a.N >= 1 && a.K >= 16 && (a.K % 16) == 0 && (a.ldw % 16) == 0 && (((uintptr_t)a.w) & 15) == 0 &&
                    ((a.w_batch_stride | a.seg_w_stride) % 16) == 0,
                "mn_skinny_gemm(fp8 row): K, ldw and the matrix strides must be multiples of 16");

@@ -17,6 +17,7 @@
 // fragment reads and the kernel is LDS-bound (RF w12 at 64 rows: 40 us with NT = 1, 28-29 us with NT = 2, ring depth 2;
 // a 4-deep ring spills).  At <= 32 rows it is on par with the K-slice kernel (23-25 vs 24 us), which stays the default there.
 #include "common.h"
+#include "w8_codec.h"
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -31,7 +32,8 @@ struct KGroups {
   const int32_t* xrows;    // [total] x row of each sorted row; nullptr = identity (off[g] + r)
   int64_t w_stride;        // elements between consecutive groups' weight matrices
   int row_lo, row_hi;      // only groups with row_lo < rows <= row_hi are processed by this launch
-  int64_t s_stride;        // fp8 weights: floats between consecutive groups' row scales
+  int64_t s_stride;        // 8-bit weights: floats between consecutive groups' row scales
+  int wf;                  // 8-bit weights: MN_W_FP8_E4M3 | MN_W_INT8 (w8_codec.h)
 };
 
 // byte offset of 16-byte slot `slot` of chunk row `row` (CK k per chunk = CK/8 slots per row): the XOR swizzle makes
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(KW * 64, (W8 && MT == 4 && NT == 2) ? 4 : 1) void s
 #pragma unroll
             for (int i = 0; i < WI; ++i) {
               const u32x4 q = wr_[d >> 1][i];
-              *reinterpret_cast<u32x4*>(wt + wo[i]) = (d & 1) ? fp8x8_to_bf16(q.z, q.w) : fp8x8_to_bf16(q.x, q.y);
+              *reinterpret_cast<u32x4*>(wt + wo[i]) = (d & 1) ? w8x8_to_bf16(g.wf, q.z, q.w) : w8x8_to_bf16(g.wf, q.x, q.y);
             }
             if ((d & 1) && (c >> 1) + DW < nwl) load_w(wr_[d >> 1], (c >> 1) + DW);
           } else {
@@ -339,19 +341,21 @@ extern "C" int mn_stream_kloop_w8_slices(int M, int Ntot, int K) { return kloop_
 extern "C" int mn_stream_kloop(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream) {
   MN_CHECK_ARG(Y && W && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0, "mn_stream_kloop: bad args");
   const int nz = kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K), kloop_nt(M));
-  const KGroups g{nullptr, nullptr, 0, 0, 1 << 30, 0};
+  const KGroups g{nullptr, nullptr, 0, 0, 1 << 30, 0, 0};
   kloop_dispatch(1, M, nz, Y, (int64_t)M * K, W, nullptr, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
   MN_CHECK_LAUNCH("mn_stream_kloop");
   return nz;
 }
 
-// Dense on fp8 weights: Wq e4m3 [Ntot][K] (K % 16 == 0), wscale fp32 [Ntot].  nz = mn_stream_kloop_w8_slices(M, Ntot, K).
-extern "C" int mn_stream_kloop_w8(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, void* stream) {
-  MN_CHECK_ARG(Y && Wq && wscale && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 16 && (K % 16) == 0, "mn_stream_kloop_w8: bad args");
+// Dense on 8-bit weights (wfmt = MN_W_FP8_E4M3 | MN_W_INT8): Wq bytes [Ntot][K] (K % 16 == 0), wscale fp32 [Ntot].
+// nz = mn_stream_kloop_w8_slices(M, Ntot, K).
+extern "C" int mn_stream_kloop_wq(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, int wfmt, void* stream) {
+  MN_CHECK_ARG(Y && Wq && wscale && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 16 && (K % 16) == 0 && (wfmt == MN_W_FP8_E4M3 || wfmt == MN_W_INT8),
+               "mn_stream_kloop_wq: bad args");
   const int nz = kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K), kloop_nt(M), true);
-  const KGroups g{nullptr, nullptr, 0, 0, 1 << 30, 0};
+  const KGroups g{nullptr, nullptr, 0, 0, 1 << 30, 0, wfmt};
   kloop_dispatch(1, M, nz, Y, (int64_t)M * K, Wq, wscale, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
-  MN_CHECK_LAUNCH("mn_stream_kloop_w8");
+  MN_CHECK_LAUNCH("mn_stream_kloop_wq");
   return nz;
 }
 
@@ -363,21 +367,21 @@ extern "C" int mn_stream_kloop_grouped(const uint16_t* Y, int y_rows, const uint
   MN_CHECK_ARG(Y && W && P && off && G >= 1 && max_rows >= 1 && max_rows <= 64 && Ntot >= 1 && K >= 8 && (K % 8) == 0 &&
                    nz >= 1 && nz <= (K + kloop_ck() - 1) / kloop_ck(),
                "mn_stream_kloop_grouped: bad args");
-  const KGroups g{off, xrows, w_stride, row_lo, max_rows, 0};
+  const KGroups g{off, xrows, w_stride, row_lo, max_rows, 0, 0};
   kloop_dispatch(G, max_rows, nz, Y, (int64_t)y_rows * K, W, nullptr, P, (int64_t)p_rows * Ntot, 0, Ntot, K, g, mn_stream(stream));
   MN_CHECK_LAUNCH("mn_stream_kloop_grouped");
   return nz;
 }
 
-// Grouped form on fp8 weights (group g: Wq + g * w_stride bytes, wscale + g * s_stride floats).
-extern "C" int mn_stream_kloop_grouped_w8(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale,
+// Grouped form on 8-bit weights (group g: Wq + g * w_stride bytes, wscale + g * s_stride floats).
+extern "C" int mn_stream_kloop_grouped_wq(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale,
                                           int64_t s_stride, float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G,
-                                          int max_rows, int nz, int Ntot, int K, void* stream) {
+                                          int max_rows, int nz, int Ntot, int K, int wfmt, void* stream) {
   MN_CHECK_ARG(Y && Wq && wscale && P && off && G >= 1 && max_rows >= 1 && max_rows <= 64 && Ntot >= 1 && K >= 16 && (K % 16) == 0 &&
-                   (w_stride % 16) == 0 && nz >= 1 && nz <= (K + 127) / 128,
-               "mn_stream_kloop_grouped_w8: bad args");
-  const KGroups g{off, xrows, w_stride, 0, max_rows, s_stride};
+                   (w_stride % 16) == 0 && nz >= 1 && nz <= (K + 127) / 128 && (wfmt == MN_W_FP8_E4M3 || wfmt == MN_W_INT8),
+               "mn_stream_kloop_grouped_wq: bad args");
+  const KGroups g{off, xrows, w_stride, 0, max_rows, s_stride, wfmt};
   kloop_dispatch(G, max_rows, nz, Y, (int64_t)y_rows * K, Wq, wscale, P, (int64_t)p_rows * Ntot, 0, Ntot, K, g, mn_stream(stream));
-  MN_CHECK_LAUNCH("mn_stream_kloop_grouped_w8");
+  MN_CHECK_LAUNCH("mn_stream_kloop_grouped_wq");
   return nz;
 }

@@ -24,6 +24,7 @@
 
 #include "common.h"
 #include "stream_fuse.h"
+#include "w8_codec.h"
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -36,11 +37,11 @@ extern "C" int mn_stream_kloop_grouped(const uint16_t* Y, int y_rows, const uint
                                        int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows, int row_lo,
                                        int nz, int Ntot, int K, void* stream);
 // ... and on fp8 weights (e4m3 bytes + one fp32 scale per output row)
-extern "C" int mn_stream_kloop_w8(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, void* stream);
+extern "C" int mn_stream_kloop_wq(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, int wfmt, void* stream);
 extern "C" int mn_stream_kloop_w8_slices(int M, int Ntot, int K);
-extern "C" int mn_stream_kloop_grouped_w8(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale,
+extern "C" int mn_stream_kloop_grouped_wq(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale,
                                           int64_t s_stride, float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G,
-                                          int max_rows, int nz, int Ntot, int K, void* stream);
+                                          int max_rows, int nz, int Ntot, int K, int wfmt, void* stream);
 
 namespace {
 
@@ -72,7 +73,7 @@ template <int MT, int DEPTH, int MAXT, bool W8, int FUSE = FUSE_NONE>
 __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
                                                                const void* __restrict__ Wv, const float* __restrict__ wscale,
                                                                float* __restrict__ P, int64_t p_slab, int M, int Ntot, int K, int ks,
-                                                               StreamFuse f = StreamFuse{}) {
+                                                               StreamFuse f = StreamFuse{}, int wf = MN_W_FP8_E4M3) {
   const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(Wv);
   const uint8_t* __restrict__ Wq = reinterpret_cast<const uint8_t*>(Wv);
   extern __shared__ __attribute__((aligned(16))) bf16_t xs_raw[];      // [2][16*MT][ks] x image, then nw x 8 KiB weight tiles
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
         if constexpr (W8) {                          // 16 e4m3 -> 16 bf16 = the row's slots 2 fr and 2 fr + 1
 #pragma unroll
           for (int i = 0; i < NI; ++i) {
-            const u32x4 a = fp8x8_to_bf16(ring[d][i].x, ring[d][i].y), b = fp8x8_to_bf16(ring[d][i].z, ring[d][i].w);
+            const u32x4 a = w8x8_to_bf16(wf, ring[d][i].x, ring[d][i].y), b = w8x8_to_bf16(wf, ring[d][i].z, ring[d][i].w);
             // every other quad of lanes stores its odd slot first: the 8 lanes of one LDS write group (same row) then cover
             // slots {0, 2, 4, 6, 9, 11, 13, 15} (mod 16) = 8 distinct 16-byte bank groups
             const int row = i * 4 + fq, sw = (fr >> 2) & 1;
@@ -304,7 +305,7 @@ StreamPlan stream_plan(int mt, int Ntot, int K, int slots, bool w8 = false) {
 
 template <int MT, int DEPTH, int MAXT, bool W8>
 void stream_launch_d(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, const void* W, const float* wscale, float* P,
-                     int64_t p_slab, int M, int Ntot, int K, hipStream_t st) {
+                     int64_t p_slab, int M, int Ntot, int K, hipStream_t st, int wf = MN_W_FP8_E4M3) {
   static bool opted = false;
   if (!opted) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_lds_kernel<MT, DEPTH, MAXT, W8>),
@@ -312,26 +313,26 @@ void stream_launch_d(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo,
     opted = true;
   }
   hipLaunchKernelGGL((stream_mfma_lds_kernel<MT, DEPTH, MAXT, W8>), dim3(pl.gx, pl.nz, G), dim3(pl.nw * 64), pl.lds, st, Y, y_lo, W,
-                     wscale, P, p_slab, M, Ntot, K, pl.ks);
+                     wscale, P, p_slab, M, Ntot, K, pl.ks, StreamFuse{}, wf);
 }
 
 template <int MT, bool W8>
 void stream_launch(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, const void* W, const float* wscale, float* P,
-                   int64_t p_slab, int M, int Ntot, int K, hipStream_t st) {
+                   int64_t p_slab, int M, int Ntot, int K, hipStream_t st, int wf = MN_W_FP8_E4M3) {
   // 8-wave workgroups compile for 512 threads, larger ones for 1024
   // (a 2-deep ring measured 2-4 % slower at every shape: 20.4 vs 20.0 us on RF w12 at 16 rows, 24.6 vs 23.8 at 32)
   if (W8 && g_w8_depth == 2) {
-    if (pl.nw <= 8) stream_launch_d<MT, (W8 ? 2 : 1), 512, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st);
-    else stream_launch_d<MT, (W8 ? 2 : 1), 1024, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st);
+    if (pl.nw <= 8) stream_launch_d<MT, (W8 ? 2 : 1), 512, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st, wf);
+    else stream_launch_d<MT, (W8 ? 2 : 1), 1024, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st, wf);
     return;
   }
-  if (pl.nw <= 8) stream_launch_d<MT, 1, 512, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st);
-  else stream_launch_d<MT, 1, 1024, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st);
+  if (pl.nw <= 8) stream_launch_d<MT, 1, 512, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st, wf);
+  else stream_launch_d<MT, 1, 1024, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st, wf);
 }
 
 template <bool W8>
 void stream_launch_fused(const StreamPlan& pl, const void* W, const float* wscale, float* P, int M, int Ntot, int K, const StreamFuse& f,
-                         hipStream_t st) {
+                         hipStream_t st, int wf) {
   static bool opted[2] = {false, false};
   const int big = pl.nw > 8;
   if (!opted[big]) {
@@ -341,10 +342,10 @@ void stream_launch_fused(const StreamPlan& pl, const void* W, const float* wscal
   }
   if (big)
     hipLaunchKernelGGL((stream_mfma_lds_kernel<1, 1, 1024, W8, FUSE_SWIGLU>), dim3(pl.gx, pl.nz, 1), dim3(pl.nw * 64), pl.lds, st, (const bf16_t*)nullptr,
-                       (int64_t)0, W, wscale, P, (int64_t)M * Ntot, M, Ntot, K, pl.ks, f);
+                       (int64_t)0, W, wscale, P, (int64_t)M * Ntot, M, Ntot, K, pl.ks, f, wf);
   else
     hipLaunchKernelGGL((stream_mfma_lds_kernel<1, 1, 512, W8, FUSE_SWIGLU>), dim3(pl.gx, pl.nz, 1), dim3(pl.nw * 64), pl.lds, st, (const bf16_t*)nullptr,
-                       (int64_t)0, W, wscale, P, (int64_t)M * Ntot, M, Ntot, K, pl.ks, f);
+                       (int64_t)0, W, wscale, P, (int64_t)M * Ntot, M, Ntot, K, pl.ks, f, wf);
 }
 
 }  // namespace
@@ -359,8 +360,8 @@ bool stream_fused_ok(int wfmt, int M, int Ntot, int K, int prev_nz) {
 int stream_fused(int wfmt, const void* W, const float* wscale, float* P, int M, int Ntot, int K, const StreamFuse& f, void* stream) {
   MN_CHECK_ARG(W && P && f.pP && stream_fused_ok(wfmt, M, Ntot, K, f.pnz) && (!wfmt || wscale), "stream_fused: shape cannot run fused");
   const StreamPlan pl = stream_plan(1, Ntot, K, mn_num_cus(), wfmt != 0);
-  if (wfmt) stream_launch_fused<true>(pl, W, wscale, P, M, Ntot, K, f, mn_stream(stream));
-  else stream_launch_fused<false>(pl, W, wscale, P, M, Ntot, K, f, mn_stream(stream));
+  if (wfmt) stream_launch_fused<true>(pl, W, wscale, P, M, Ntot, K, f, mn_stream(stream), wfmt);
+  else stream_launch_fused<false>(pl, W, wscale, P, M, Ntot, K, f, mn_stream(stream), 0);
   MN_CHECK_LAUNCH("stream_fused");
   return pl.nz;
 }
@@ -393,17 +394,21 @@ extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, in
 
 // The same launch on fp8 weights: Wq e4m3 bytes [Ntot][K] (K % 16 == 0, 16-byte aligned rows), wscale fp32 [Ntot];
 // P [nz][M][Ntot] with nz = mn_stream_mfma_w8_slices(M, Ntot, K).
-extern "C" int mn_stream_mfma_w8(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K,
+extern "C" int mn_stream_mfma_wq(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, int wfmt,
                                  void* stream) {
-  MN_CHECK_ARG(Y && Wq && wscale && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 16 && (K % 16) == 0 && (((uintptr_t)Wq) & 15) == 0,
-               "mn_stream_mfma_w8: bad args (K %% 16 == 0, 16-byte aligned weights)");
-  if (M > 32) return mn_stream_kloop_w8(Y, Wq, wscale, P, M, Ntot, K, stream);
+  MN_CHECK_ARG(Y && Wq && wscale && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 16 && (K % 16) == 0 && (((uintptr_t)Wq) & 15) == 0 &&
+                   (wfmt == MN_W_FP8_E4M3 || wfmt == MN_W_INT8), "mn_stream_mfma_wq: bad args (K %% 16 == 0, 16-byte aligned weights, wfmt 1 | 2)");
+  if (M > 32) return mn_stream_kloop_wq(Y, Wq, wscale, P, M, Ntot, K, wfmt, stream);
   const int mt = M > 16 ? 2 : 1;
   const StreamPlan pl = stream_plan(mt, Ntot, K, mn_num_cus(), true);
-  if (mt == 1) stream_launch<1, true>(pl, 1, Y, (int64_t)M * K, Wq, wscale, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream));
-  else stream_launch<2, true>(pl, 1, Y, (int64_t)M * K, Wq, wscale, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream));
-  MN_CHECK_LAUNCH("mn_stream_mfma_w8");
+  if (mt == 1) stream_launch<1, true>(pl, 1, Y, (int64_t)M * K, Wq, wscale, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream), wfmt);
+  else stream_launch<2, true>(pl, 1, Y, (int64_t)M * K, Wq, wscale, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream), wfmt);
+  MN_CHECK_LAUNCH("mn_stream_mfma_wq");
   return pl.nz;
+}
+extern "C" int mn_stream_mfma_w8(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K,
+                                 void* stream) {
+  return mn_stream_mfma_wq(Y, Wq, wscale, P, M, Ntot, K, MN_W_FP8_E4M3, stream);
 }
 
 // ---- grouped form (MoE experts): every row count runs the K-loop kernel with 2 K-ranges — measured against this file's
@@ -425,9 +430,14 @@ extern "C" int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint1
 }
 
 // The grouped form on fp8 weights: group g's matrix is Wq + g * w_stride bytes, its row scales wscale + g * s_stride.
+extern "C" int mn_stream_mfma_grouped_wq(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale,
+                                         int64_t s_stride, float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G,
+                                         int max_rows, int Ntot, int K, int wfmt, void* stream) {
+  const int nz = mn_stream_mfma_grouped_slices(G, max_rows, Ntot, K);
+  return mn_stream_kloop_grouped_wq(Y, y_rows, Wq, w_stride, wscale, s_stride, P, p_rows, off, xrows, G, max_rows, nz, Ntot, K, wfmt, stream);
+}
 extern "C" int mn_stream_mfma_grouped_w8(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale,
                                          int64_t s_stride, float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G,
                                          int max_rows, int Ntot, int K, void* stream) {
-  const int nz = mn_stream_mfma_grouped_slices(G, max_rows, Ntot, K);
-  return mn_stream_kloop_grouped_w8(Y, y_rows, Wq, w_stride, wscale, s_stride, P, p_rows, off, xrows, G, max_rows, nz, Ntot, K, stream);
+  return mn_stream_mfma_grouped_wq(Y, y_rows, Wq, w_stride, wscale, s_stride, P, p_rows, off, xrows, G, max_rows, Ntot, K, MN_W_FP8_E4M3, stream);
 }

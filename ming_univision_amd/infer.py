@@ -9,7 +9,8 @@ and `*.safetensors` shards keyed by the reference's parameter names; the tokeniz
 directory when a `tokenizer.json` is present, otherwise the byte-level stand-in is used.
 
 `dtype` is the reference's weight-format switch (:46-70: "bf16", or weight-only "int8" / "int4" through quanto / bitsandbytes).
-Here: "bf16" (default), and "fp8" — weight-only OCP e4m3 with one scale per output row for the decoder stack's experts and the RF
+Here: "bf16" (default), "int8" — the reference's quanto mode restated: weight-only int8 with one (power-of-two) scale per output row —,
+and "fp8" — weight-only OCP e4m3 with one scale per output row for the decoder stack's experts and the RF
 head's ResBlock matrices (95 % of the bytes a visual token streams), quantised once at load from the same bf16 checkpoint; the
 arithmetic (fp32 / bf16 hi+lo activations, bf16 MFMA, fp32 accumulate) is unchanged.  "int8" / "int4" are not built.
 """
@@ -62,8 +63,9 @@ class HFTokenizerAdapter:
 
 class MingUniVisionInfer:
     def __init__(self, model_name_or_path=None, dtype="bf16", device="cuda", config=None, seed=0, t_max=4096):
-        if dtype not in ("bf16", "fp8"):
-            raise NotImplementedError(f"dtype={dtype!r}: 'bf16' or 'fp8' (weight-only e4m3); the int4/int8 modes are not built")
+        if dtype not in ("bf16", "fp8", "int8"):
+            raise NotImplementedError(f"dtype={dtype!r}: 'bf16', 'fp8' (weight-only e4m3) or 'int8' (weight-only int8, the reference's "
+                                      "quanto mode); the int4 (bitsandbytes nf4) mode is not built")
         self.model_name_or_path = model_name_or_path
         self.dtype = dtype
         self.model, self.tokenizer, self.processor = self.load_model_processor(config, device, seed, t_max)

@@ -31,9 +31,10 @@ def as_bf16_bits(t):
 
 
 def skinny_gemm(x, w, bias=None, *, prologue="none", epilogue="none", out=None, pro_a=None, pro_b=None,
-                ln_g=None, ln_b=None, eps=1e-6, res=None, gate=None, n_out=None, use_mfma_route=True, wscale=None):
+                ln_g=None, ln_b=None, eps=1e-6, res=None, gate=None, n_out=None, use_mfma_route=True, wscale=None, wfmt="fp8"):
     """out[M,N] = epilogue(prologue(x)[M,K] @ w[N(,2N),K]^T + bias).  x fp32, w/bias/ln bf16.
-    wscale (fp32 [N or 2N]) given: w holds OCP e4m3 bytes (uint8) with one scale per weight row (fp8 weight mode)."""
+    wscale (fp32 [N or 2N]) given: w holds 8-bit weight bytes (uint8: e4m3 for wfmt = "fp8", int8 for "int8") with one scale per
+    weight row (the weight-only modes of mingnative.h section 7)."""
     _req(x, torch.float32, "x"); _req(w, torch.uint8 if wscale is not None else torch.bfloat16, "w"); _req(bias, torch.bfloat16, "bias")
     _req(wscale, torch.float32, "wscale")
     _req(ln_g, torch.bfloat16, "ln_g"); _req(ln_b, torch.bfloat16, "ln_b")
@@ -65,7 +66,7 @@ def skinny_gemm(x, w, bias=None, *, prologue="none", epilogue="none", out=None, 
     ws = None
     if wscale is not None:
         assert wscale.numel() == w.shape[0] and w.is_contiguous()
-        a.wfmt, a.wscale = _lib.W_FP8_E4M3, ptr(wscale)
+        a.wfmt, a.wscale = _lib.WFMT[wfmt], ptr(wscale)
         nb = lib().mn_skinny_workspace_bytes_w8(M, N, K, a.epilogue)
     else:
         nb = lib().mn_skinny_workspace_bytes(M, N, K, a.epilogue)
@@ -92,10 +93,10 @@ def moe_router(x, norm_w, eps, gate_w, image_gate_w, image_mask, top_k, norm_top
     return xn, idx, w
 
 
-def moe_experts(xn, idx, w, w_gate_up, w_down, res, gate_up_scale=None, down_scale=None):
+def moe_experts(xn, idx, w, w_gate_up, w_down, res, gate_up_scale=None, down_scale=None, wfmt="fp8"):
     """Grouped expert MLPs of one MoE layer for M rows: returns res + sum_slot w * down(silu(gate x) * up x).
     w_gate_up bf16 [E', 2I, H], w_down bf16 [E', H, I]; idx/w [M, n_slot] from moe_router.
-    fp8 weight mode: w_gate_up / w_down uint8 (e4m3) with gate_up_scale fp32 [E', 2I] and down_scale fp32 [E', H]."""
+    8-bit weight modes: w_gate_up / w_down uint8 (e4m3 or int8 bytes, `wfmt`) with gate_up_scale fp32 [E', 2I] and down_scale fp32 [E', H]."""
     M, H = xn.shape
     n_slot = idx.shape[1]
     I = w_down.shape[2]
@@ -107,7 +108,7 @@ def moe_experts(xn, idx, w, w_gate_up, w_down, res, gate_up_scale=None, down_sca
     a.batch, a.w_index, a.w_batch_stride = M * n_slot, ptr(idx), 2 * I * H
     a.x_batch_stride, a.x_batch_div, a.out_batch_stride = H, n_slot, I
     if gate_up_scale is not None:
-        a.wfmt, a.wscale, a.wscale_batch_stride = _lib.W_FP8_E4M3, ptr(gate_up_scale), 2 * I
+        a.wfmt, a.wscale, a.wscale_batch_stride = _lib.WFMT[wfmt], ptr(gate_up_scale), 2 * I
     check(lib().mn_skinny_gemm(C.byref(a), current_stream()), "mn_skinny_gemm(moe gate_up)")
     out = torch.empty(M, H, dtype=torch.float32, device=xn.device)
     b = SkinnyArgs()
@@ -118,7 +119,7 @@ def moe_experts(xn, idx, w, w_gate_up, w_down, res, gate_up_scale=None, down_sca
     b.batch, b.x_batch_stride, b.x_batch_div, b.out_batch_stride = M, n_slot * I, 1, H
     b.nseg, b.seg_index, b.seg_scale, b.seg_w_stride = n_slot, ptr(idx), ptr(w), H * I
     if down_scale is not None:
-        b.wfmt, b.wscale, b.wscale_seg_stride = _lib.W_FP8_E4M3, ptr(down_scale), H
+        b.wfmt, b.wscale, b.wscale_seg_stride = _lib.WFMT[wfmt], ptr(down_scale), H
     check(lib().mn_skinny_gemm(C.byref(b), current_stream()), "mn_skinny_gemm(moe down)")
     return out
 
@@ -461,8 +462,36 @@ def dequant_fp8_rows(q, scale):
     return w
 
 
-def stream_mfma_w8(y2, q, scale):
-    """Weight-streaming MFMA launch on fp8 weights: y2 bf16 [2, M, K] (hi rows, lo rows), q uint8 [N, K], scale fp32 [N]
+def quant_rows(w, fmt):
+    """bf16 [..., N, K] -> (bytes uint8 [..., N, K], fp32 power-of-two scales [..., N]) in the 8-bit format `fmt` ("fp8": OCP e4m3,
+    "int8": two's complement in [-127, 127]); bytes * scale is exactly representable in bf16 in both."""
+    if fmt == "fp8":
+        return quant_fp8_rows(w)
+    assert fmt == "int8", fmt
+    _req(w, torch.bfloat16, "w")
+    assert w.is_contiguous() and w.shape[-1] % 4 == 0
+    K = w.shape[-1]
+    q = torch.empty(w.shape, dtype=torch.uint8, device=w.device)
+    scale = torch.empty(w.shape[:-1], dtype=torch.float32, device=w.device)
+    check(lib().mn_quant_int8_rows(ptr(w), K, ptr(q), K, ptr(scale), w.numel() // K, K, current_stream()), "mn_quant_int8_rows")
+    return q, scale
+
+
+def dequant_rows(q, scale, fmt):
+    """The inverse of quant_rows: bf16 [..., N, K], exact."""
+    if fmt == "fp8":
+        return dequant_fp8_rows(q, scale)
+    assert fmt == "int8", fmt
+    _req(q, torch.uint8, "q"); _req(scale, torch.float32, "scale")
+    assert q.is_contiguous() and scale.is_contiguous() and tuple(scale.shape) == tuple(q.shape[:-1])
+    K = q.shape[-1]
+    w = torch.empty(q.shape, dtype=torch.bfloat16, device=q.device)
+    check(lib().mn_dequant_int8_rows(ptr(q), K, ptr(scale), ptr(w), K, q.numel() // K, K, current_stream()), "mn_dequant_int8_rows")
+    return w
+
+
+def stream_mfma_w8(y2, q, scale, wfmt="fp8"):
+    """Weight-streaming MFMA launch on 8-bit weights (`wfmt`): y2 bf16 [2, M, K] (hi rows, lo rows), q uint8 [N, K], scale fp32 [N]
     -> fp32 [M, N] (the K-slice partials summed here with torch: a test helper, the composites reduce them in their glue kernels)."""
     _req(y2, torch.bfloat16, "y2"); _req(q, torch.uint8, "q"); _req(scale, torch.float32, "scale")
     _, M, K = y2.shape
@@ -470,9 +499,9 @@ def stream_mfma_w8(y2, q, scale):
     assert y2.is_contiguous() and q.is_contiguous() and q.shape[1] == K
     nz = lib().mn_stream_mfma_w8_slices(M, N, K)
     P = torch.empty(nz, M, N, dtype=torch.float32, device=q.device)
-    rc = lib().mn_stream_mfma_w8(ptr(y2), ptr(q), ptr(scale), ptr(P), M, N, K, current_stream())
+    rc = lib().mn_stream_mfma_wq(ptr(y2), ptr(q), ptr(scale), ptr(P), M, N, K, _lib.WFMT[wfmt], current_stream())
     if rc < 0:
-        check(rc, "mn_stream_mfma_w8")
+        check(rc, "mn_stream_mfma_wq")
     assert rc == nz
     return P.sum(0)
 

@@ -32,7 +32,7 @@ class RectifiedFlowHead:
     def __init__(self, sd, llm_hidden, vishead_diffloss_config=None, latent_dim=32, prefix="", weights="bf16"):
         """sd: {reference parameter name: bf16 CUDA tensor} holding `vis_head.*` and `diffloss.net.*`.
         weights: "bf16", or "fp8" = w12 / w3 quantised here to e4m3 + row scales (the bf16 originals are not kept)."""
-        assert weights in _lib.WFMT, f"weights={weights!r}: 'bf16' or 'fp8'"
+        assert weights in _lib.WFMT, f"weights={weights!r}: 'bf16', 'fp8' or 'int8'"
         self.weights = weights
         cfg = {**DEFAULT_VISHEAD_DIFFLOSS, **(vishead_diffloss_config or {})}
         assert cfg["vis_head_arch"] == "linear2-norm"          # modeling_bailing_moe.py:1568
@@ -83,17 +83,17 @@ class RectifiedFlowHead:
         """Quantise the ResBlock matrices when asked to and build the pointer table the C ABI takes."""
         self.weights = weights
         self.scales = {}
-        if weights == "fp8":
+        if weights in _lib.W8:
             self.lists = dict(self.lists)
             for k in ("w12", "w3"):
-                qs = [ops.quant_fp8_rows(w) for w in self.lists[k]]
+                qs = [ops.quant_rows(w, weights) for w in self.lists[k]]
                 self.lists[k] = [q for q, _ in qs]
                 self.scales[k] = [sc for _, sc in qs]
             # the stacked adaLN matrix: e4m3 bytes for the one-launch form (<= 4 CFG rows: all 16 steps' rows fit a streaming launch)
             # + its exact bf16 expansion for the MFMA GEMM of the larger row counts — the same model either way
             self.t = dict(self.t)
-            self.t["ada_q"], self.t["ada_scale"] = ops.quant_fp8_rows(self.t["ada_w"])
-            self.t["ada_w"] = ops.dequant_fp8_rows(self.t["ada_q"], self.t["ada_scale"])
+            self.t["ada_q"], self.t["ada_scale"] = ops.quant_rows(self.t["ada_w"], weights)
+            self.t["ada_w"] = ops.dequant_rows(self.t["ada_q"], self.t["ada_scale"], weights)
         llm_hidden = self.llm_hidden
         self._arrays = {k: ptr_array(v) for k, v in self.lists.items()}
         self._scale_arrays = {k: ptr_array(v) for k, v in self.scales.items()}
@@ -106,26 +106,27 @@ class RectifiedFlowHead:
         for k, arr in self._arrays.items():
             setattr(s, k, C.cast(arr, _lib.PP))
         s.wfmt = _lib.WFMT[weights]
-        if weights == "fp8":
+        if weights in _lib.W8:
             s.w12_scale = C.cast(self._scale_arrays["w12"], _lib.PP)
             s.w3_scale = C.cast(self._scale_arrays["w3"], _lib.PP)
             s.ada_q, s.ada_scale = ptr(self.t["ada_q"]), ptr(self.t["ada_scale"])
         self.struct = s
         self._ws = {}
 
-    def to_fp8(self):
-        """A second head on the same HBM tensors whose ResBlock matrices are e4m3 copies (this bf16 head stays usable)."""
+    def to_fp8(self, weights="fp8"):
+        """A second head on the same HBM tensors whose ResBlock matrices are 8-bit copies — e4m3 (default) or, with
+        weights="int8", int8 — (this bf16 head stays usable)."""
         import copy
-        assert self.weights == "bf16"
+        assert self.weights == "bf16" and weights in _lib.W8
         new = copy.copy(self)
-        new._finalize("fp8")
+        new._finalize(weights)
         return new
 
     def weight_bytes_per_step(self, rows=2):
         """Weight bytes one Euler step must stream from HBM (bf16: 2 per ResBlock parameter; fp8: 1 + the row scales)."""
-        per_w = 1 if self.weights == "fp8" else 2
+        per_w = 1 if self.weights in _lib.W8 else 2
         per_block = (2 * self.hidden * self.w + self.w * self.hidden) * per_w
-        if self.weights == "fp8":
+        if self.weights in _lib.W8:
             per_block += (2 * self.hidden + self.w) * 4
         return self.depth * per_block + self.ada_bytes(rows)
 
@@ -133,16 +134,16 @@ class RectifiedFlowHead:
         """Bytes of the stacked adaLN matrix one visual token reads (once: all Euler steps in one launch): e4m3 in fp8 mode while
         steps x rows <= 64, else bf16."""
         n = self.t["ada_w"].numel()
-        return n + 4 * self.t["ada_w"].shape[0] if (self.weights == "fp8" and self.steps * rows <= 64) else 2 * n
+        return n + 4 * self.t["ada_w"].shape[0] if (self.weights in _lib.W8 and self.steps * rows <= 64) else 2 * n
 
     def dequantized_blocks(self):
         """fp8 mode: {reference parameter name: bf16 tensor} of the ResBlock matrices as the kernels see them (e4m3 * row scale,
         exact in bf16) — what the oracle is fed in the parity tests, and a bf16 model of its own right."""
-        assert self.weights == "fp8"
+        assert self.weights in _lib.W8
         out = {}
         for i in range(self.depth):
             for k, name in (("w12", "mlp.w12.weight"), ("w3", "mlp.w3.weight")):
-                out[f"diffloss.net.res_blocks.{i}.{name}"] = ops.dequant_fp8_rows(self.lists[k][i], self.scales[k][i])
+                out[f"diffloss.net.res_blocks.{i}.{name}"] = ops.dequant_rows(self.lists[k][i], self.scales[k][i], self.weights)
             out[f"diffloss.net.res_blocks.{i}.adaLN_modulation.1.weight"] = self.t["ada_w"][i * 3 * self.w:(i + 1) * 3 * self.w]
         out["diffloss.net.final_layer.adaLN_modulation.1.weight"] = self.t["ada_w"][self.depth * 3 * self.w:]
         return out

@@ -274,7 +274,7 @@ class TpDecoderShard:
             s.mrope_sec_t, s.mrope_sec_h = dec.mrope_section[0], dec.mrope_section[1]
         self.mrope_section = dec.mrope_section
         s.wfmt = _lib.WFMT[self.weights]
-        if self.weights == "fp8":
+        if self.weights in _lib.W8:
             s.w_gate_up_scale = C.cast(self._arrays["w_gate_up_scale"], _lib.PP)
             s.w_down_scale = C.cast(self._arrays["w_down_scale"], _lib.PP)
         self.struct = s
@@ -282,7 +282,7 @@ class TpDecoderShard:
         t.expert0, t.n_local_experts, t.shared_inter = rank * pl["n_experts"], pl["n_experts"], pl["shared_pad"]
         if pl["shared_pad"]:
             t.ws_gate_up, t.ws_down = C.cast(self._arrays["ws_gate_up"], _lib.PP), C.cast(self._arrays["ws_down"], _lib.PP)
-            if self.weights == "fp8":
+            if self.weights in _lib.W8:
                 t.ws_gate_up_scale = C.cast(self._arrays["ws_gate_up_scale"], _lib.PP)
                 t.ws_down_scale = C.cast(self._arrays["ws_down_scale"], _lib.PP)
         self.tp = t
@@ -328,9 +328,9 @@ class TpDecoderShard:
                       wdense=sd[p + ".attention.dense.weight"], ln2=sd[p + ".post_attention_layernorm.weight"],
                       gate=sd[p + ".mlp.gate.weight"], image_gate=sd.get(p + ".mlp.image_gate.weight") if cfg.multi_gate else None,
                       w_gate_up=gu, w_down=dn)
-            if weights == "fp8":
+            if weights in _lib.W8:
                 from .bailing_moe import quantize_layer_experts
-                quantize_layer_experts(ly)
+                quantize_layer_experts(ly, weights)
             self._shard_layers.append(cls._shard_layer(ly, cfg, rank, world))
             del sd, gu, dn, ly
         full.layers = None
@@ -381,7 +381,7 @@ class TpRfShard:
         self.lists = dict(rf.lists, w12=w12, b12=b12, w3=w3)
         self._arrays = {k: ptr_array(v) for k, v in self.lists.items()}
         self.weights = getattr(rf, "weights", "bf16")
-        if self.weights == "fp8":      # row scales: w12's rows are sliced like its weights, w3's columns share the full rows' scales
+        if self.weights in _lib.W8:      # row scales: w12's rows are sliced like its weights, w3's columns share the full rows' scales
             hid, n = rf.hidden, rf.hidden // world
             u0 = rank * n
             self.scales = dict(w12=[torch.cat((sc[u0:u0 + n], sc[hid + u0:hid + u0 + n])).contiguous() for sc in rf.scales["w12"]],
@@ -394,7 +394,7 @@ class TpRfShard:
         for k, arr in self._arrays.items():
             setattr(s, k, C.cast(arr, _lib.PP))
         s.wfmt = _lib.WFMT[self.weights]
-        if self.weights == "fp8":
+        if self.weights in _lib.W8:
             s.w12_scale = C.cast(self._scale_arrays["w12"], _lib.PP)
             s.w3_scale = C.cast(self._scale_arrays["w3"], _lib.PP)
         self.struct = s
@@ -457,7 +457,7 @@ class _TpDecoderBase:
 
     def _row_cap(self):
         """fp8 weights are served by the <= 64-row streaming kernels only (mingnative.h section 7)."""
-        fp8 = "fp8" in (getattr(self, "weights", "bf16"), getattr(self, "rf_weights", "bf16"))
+        fp8 = any(getattr(self, a, "bf16") in _lib.W8 for a in ("weights", "rf_weights"))      # an 8-bit weight mode (fp8 or int8)
         return min(64 if fp8 else self.MAX_ROWS, self.rows_cap)
 
     def max_rows(self):

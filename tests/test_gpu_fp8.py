@@ -156,16 +156,17 @@ def full():
     return d, rf_cfg, sd, ocfg, seed
 
 
-def _fp8_models(full, n_seq):
-    """bf16 and fp8 HIP models of the full-width 2-layer configuration + the oracle's state dict of the fp8 model (dequantised)."""
+def _fp8_models(full, n_seq, fmt="fp8"):
+    """HIP models of the full-width 2-layer configuration in the 8-bit weight mode `fmt` ("fp8" | "int8") + the oracle's state dict
+    of that model (dequantised weights)."""
     from ming_univision_amd.bailing_moe import BailingMoeDecoder
     from ming_univision_amd.mingtok import MingTok
     from ming_univision_amd.rf_head import RectifiedFlowHead
     d, rf_cfg, sd, ocfg, seed = full
     cfg = C.BailingMoeConfig(**d)
     dsd = _dev(sd)
-    dec8 = BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=32, n_seq=n_seq, weights="fp8")
-    rf8 = RectifiedFlowHead(dsd, cfg.hidden_size, rf_cfg, weights="fp8")
+    dec8 = BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=32, n_seq=n_seq, weights=fmt)
+    rf8 = RectifiedFlowHead(dsd, cfg.hidden_size, rf_cfg, weights=fmt)
     assert dec8.layers[0]["w_gate_up"].dtype == torch.uint8 and rf8.lists["w12"][0].dtype == torch.uint8
     assert dec8.max_rows() == 64 and rf8.max_rows() == 64
     sd8 = dict(sd)                                                   # the oracle's weights of the fp8 model
@@ -174,7 +175,9 @@ def _fp8_models(full, n_seq):
     for k, v in rf8.dequantized_blocks().items():
         sd8[k] = v.float().cpu()
     # ... and they are what the oracle's own quantiser produces from the bf16 weights
-    from oracle import fp8_ref
+    from oracle import fp8_ref, int8_ref
+    if fmt == "int8":
+        fp8_ref = int8_ref                                            # (same function names)
     for k in ("model.layers.1.mlp.experts.5.up_proj.weight", "model.layers.0.mlp.shared_experts.gate_proj.weight",
               "diffloss.net.res_blocks.3.mlp.w12.weight", "diffloss.net.res_blocks.11.mlp.w3.weight"):
         assert torch.equal(sd8[k], fp8_ref.fake_quant_rows(sd[k])), k
