@@ -16,6 +16,8 @@
 // fragment read from LDS feeds two MFMAs per half — with one tile per wave every 4 KiB weight chunk costs 32 KiB of x
 // fragment reads and the kernel is LDS-bound (RF w12 at 64 rows: 40 us with NT = 1, 28-29 us with NT = 2, ring depth 2;
 // a 4-deep ring spills).  At <= 32 rows it is on par with the K-slice kernel (23-25 vs 24 us), which stays the default there.
+#include <type_traits>
+
 #include "common.h"
 #include "w8_codec.h"
 
@@ -184,11 +186,15 @@ __global__ __launch_bounds__(KW * 64, (W8 && MT == 4 && NT == 2) ? 4 : 1) void s
           if constexpr (W8) {
             // piece c / 2 sits in ring slot d / 2 (cb is a multiple of D): its first 8 k per lane for the even chunk, the second
             // 8 for the odd one, converted to one bf16 slot; after the odd chunk the registers take the piece DW ahead
+            auto park8 = [&](auto i8) {
+              constexpr bool I8 = decltype(i8)::value;
 #pragma unroll
-            for (int i = 0; i < WI; ++i) {
-              const u32x4 q = wr_[d >> 1][i];
-              *reinterpret_cast<u32x4*>(wt + wo[i]) = (d & 1) ? w8x8_to_bf16(g.wf, q.z, q.w) : w8x8_to_bf16(g.wf, q.x, q.y);
-            }
+              for (int i = 0; i < WI; ++i) {
+                const u32x4 q = wr_[d >> 1][i];
+                *reinterpret_cast<u32x4*>(wt + wo[i]) = (d & 1) ? w8x8_to_bf16<I8>(q.z, q.w) : w8x8_to_bf16<I8>(q.x, q.y);
+              }
+            };
+            if (g.wf == MN_W_INT8) park8(std::true_type{}); else park8(std::false_type{});    // one scalar branch per chunk
             if ((d & 1) && (c >> 1) + DW < nwl) load_w(wr_[d >> 1], (c >> 1) + DW);
           } else {
 #pragma unroll

@@ -21,6 +21,7 @@
 //
 // The grouped form (MoE experts) runs on the K-loop kernel (stream_kloop.hip) at every row count.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 #include "stream_fuse.h"
@@ -214,15 +215,19 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
       if (q < total) {
         // park the landed chunk in the wave's LDS tile ...
         if constexpr (W8) {                          // 16 e4m3 -> 16 bf16 = the row's slots 2 fr and 2 fr + 1
+          // every other quad of lanes stores its odd slot first: the 8 lanes of one LDS write group (same row) then cover
+          // slots {0, 2, 4, 6, 9, 11, 13, 15} (mod 16) = 8 distinct 16-byte bank groups
+          auto park8 = [&](auto i8) {
+            constexpr bool I8 = decltype(i8)::value;
 #pragma unroll
-          for (int i = 0; i < NI; ++i) {
-            const u32x4 a = w8x8_to_bf16(wf, ring[d][i].x, ring[d][i].y), b = w8x8_to_bf16(wf, ring[d][i].z, ring[d][i].w);
-            // every other quad of lanes stores its odd slot first: the 8 lanes of one LDS write group (same row) then cover
-            // slots {0, 2, 4, 6, 9, 11, 13, 15} (mod 16) = 8 distinct 16-byte bank groups
-            const int row = i * 4 + fq, sw = (fr >> 2) & 1;
-            *reinterpret_cast<u32x4*>(wbuf + wslot(row, 2 * fr + sw)) = sw ? b : a;
-            *reinterpret_cast<u32x4*>(wbuf + wslot(row, 2 * fr + 1 - sw)) = sw ? a : b;
-          }
+            for (int i = 0; i < NI; ++i) {
+              const u32x4 a = w8x8_to_bf16<I8>(ring[d][i].x, ring[d][i].y), b = w8x8_to_bf16<I8>(ring[d][i].z, ring[d][i].w);
+              const int row = i * 4 + fq, sw = (fr >> 2) & 1;
+              *reinterpret_cast<u32x4*>(wbuf + wslot(row, 2 * fr + sw)) = sw ? b : a;
+              *reinterpret_cast<u32x4*>(wbuf + wslot(row, 2 * fr + 1 - sw)) = sw ? a : b;
+            }
+          };
+          if (wf == MN_W_INT8) park8(std::true_type{}); else park8(std::false_type{});      // one scalar branch per chunk
         } else {
 #pragma unroll
           for (int i = 0; i < 8; ++i)

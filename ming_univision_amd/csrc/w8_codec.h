@@ -10,17 +10,22 @@ __device__ __forceinline__ mn_u2_t i8x4_to_bf16(uint32_t q) {
   const float f0 = (float)((s << 24) >> 24), f1 = (float)((s << 16) >> 24), f2 = (float)((s << 8) >> 24), f3 = (float)(s >> 24);
   return mn_u2_t{cvt_pk_bf16(f0, f1), cvt_pk_bf16(f2, f3)};
 }
-// eight weight bytes (k ascending) -> eight bf16 = one MFMA fragment / one 16-byte LDS slot
-__device__ __forceinline__ mn_u4_t w8x8_to_bf16(int wf, uint32_t q0, uint32_t q1) {
-  if (wf == MN_W_INT8) {
+// eight weight bytes (k ascending) -> eight bf16 = one MFMA fragment / one 16-byte LDS slot.  I8 is a compile-time choice: the
+// callers branch ONCE per parked chunk on the (wave-uniform) format and run a specialised loop (a per-dword branch cost 3 % of an
+// fp8 launch)
+template <bool I8>
+__device__ __forceinline__ mn_u4_t w8x8_to_bf16(uint32_t q0, uint32_t q1) {
+  if constexpr (I8) {
     const mn_u2_t a = i8x4_to_bf16(q0), b = i8x4_to_bf16(q1);
     return mn_u4_t{a.x, a.y, b.x, b.y};
+  } else {
+    return fp8x8_to_bf16(q0, q1);
   }
-  return fp8x8_to_bf16(q0, q1);
 }
 // four weight bytes -> four fp32
-__device__ __forceinline__ void w8x4_to_f32(int wf, uint32_t q, float (&o)[4]) {
-  if (wf == MN_W_INT8) {
+template <bool I8>
+__device__ __forceinline__ void w8x4_to_f32(uint32_t q, float (&o)[4]) {
+  if constexpr (I8) {
     const int s = (int)q;
     o[0] = (float)((s << 24) >> 24); o[1] = (float)((s << 16) >> 24); o[2] = (float)((s << 8) >> 24); o[3] = (float)(s >> 24);
   } else {
