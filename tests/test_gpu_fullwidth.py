@@ -240,3 +240,50 @@ def test_wide_llm_step_matches_narrow_route_ragged_rows():
                      for i in range(0, M, 50)])
     assert rel_err(wide, nar) < 2e-4
     assert rel_err(kv_w, dec.kv_cache) < 1e-5                                           # same K / V rows appended
+
+
+def test_span_prefill_across_pass_boundaries_vs_oracle_and_row_kernels(full):
+    """mn_llm_step_spans (tiled hi/lo flash attention on the wide route): three prompts of different lengths prefilled (a) in ONE pass,
+    (b) in 128-row passes that cut the sequences (spans that continue with past > 0, a last pass of <= 64 rows on the row kernels),
+    (c) with a non-zero `past` (second round of a conversation) — against the fp32 oracle (last hidden state of every prompt), and the
+    K / V lines they write against the 64-row decode-kernel prefill (the path without any tiling)."""
+    from oracle import bailing_ref
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder
+    d, rf_cfg, tcfg, sd, ocfg, seed = full
+    cfg = C.BailingMoeConfig(**d)
+    dec = BailingMoeDecoder.from_state_dict(cfg, _dev(sd), t_max=320, n_seq=6)
+    assert dec.max_rows() == 2048
+    g = torch.Generator().manual_seed(11)
+    lens = [150, 90, 200]
+    ids = [torch.randint(0, 900, (n,), generator=g) for n in lens]
+    embs = [dec.embed(i.cuda()) for i in ids]
+    ref_last, ref_mid = [], []
+    for i in ids:                                                   # oracle: each prompt alone, then 40 more tokens on its cache
+        kvs = bailing_ref.new_kv(ocfg)
+        h = bailing_ref.model_forward(sd["model.word_embeddings.weight"][i[None]], sd, ocfg, torch.ones(1, len(i), dtype=torch.long), None, kvs)
+        ref_last.append(h[0, -1:])
+    h1 = dec.prefill_ragged(embs, [0, 1, 2], past=0)                # (a) one 440-row pass, three spans
+    for b in range(3):
+        assert rel_err(h1[b:b + 1], ref_last[b]) < TOL, (b, rel_err(h1[b:b + 1], ref_last[b]))
+    kv_a = dec.kv_cache[:, :3].clone()
+    real = dec.max_rows
+    try:
+        dec.max_rows = lambda: 128                                  # (b) passes of 128 rows: 128 + 128 + 128 + 56
+        h2 = dec.prefill_ragged(embs, [3, 4, 5], past=0)
+    finally:
+        dec.max_rows = real
+    assert rel_err(h2, h1) < 1e-4, rel_err(h2, h1)                  # (other tile / split-K compositions, the last pass on the row kernels)
+    for b, n in enumerate(lens):
+        assert rel_err(dec.kv_cache[:, 3 + b, :, :, :n], kv_a[:, b, :, :, :n]) < 1e-4
+    # the row kernels (no tiling anywhere): same K / V lines and hidden states to summation order
+    dec2 = BailingMoeDecoder.from_state_dict(cfg, _dev(sd), t_max=320, n_seq=1)
+    hr = dec2.prefill(embs[2], seq=0, past=0)
+    assert rel_err(hr[-1:], h1[2:3]) < 2e-4
+    assert rel_err(dec2.kv_cache[:, 0, :, :, :200], kv_a[:, 2, :, :, :200]) < 2e-4
+    # (c) a second round on sequence 2: 100 more tokens from past = 200 through prefill_wide (one span with past > 0)
+    more = torch.randint(0, 900, (100,), generator=g)
+    h3 = dec.prefill_wide(dec.embed(more.cuda()), seq=2, past=200)
+    kvs = bailing_ref.new_kv(ocfg)
+    both = torch.cat((ids[2], more))
+    ho = bailing_ref.model_forward(sd["model.word_embeddings.weight"][both[None]], sd, ocfg, torch.ones(1, 300, dtype=torch.long), None, kvs)
+    assert rel_err(h3[-1:], ho[0, -1:]) < TOL, rel_err(h3[-1:], ho[0, -1:])
