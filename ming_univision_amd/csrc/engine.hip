@@ -324,6 +324,25 @@ __global__ __launch_bounds__(1024) void rf_step_boundary_kernel(
     }
     xs[tid] = xv;
   }
+  // (the weights of this thread's columns do not depend on x: with the usual 32 inputs they are requested before the barrier, so the
+  //  launch is one memory round trip + the reductions instead of three dependent ones: 16 -> 9 us)
+  mn_u4_t wq[4][4];
+  float bq[4];
+  const bool pre = T == 32;
+  if (pre) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int n = tid + c * 1024;
+      bq[c] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wq[c][j] = mn_u4_t{0u, 0u, 0u, 0u};
+      if (n < w) {
+        bq[c] = bf16_to_f32(in_b[n]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wq[c][j] = *reinterpret_cast<const mn_u4_t*>(in_w + (int64_t)n * 32 + j * 8);
+      }
+    }
+  }
   __syncthreads();
   float hv[4];                                   // w <= 4096: columns tid, tid + 1024, ...
   float sum = 0.f;
@@ -332,18 +351,44 @@ __global__ __launch_bounds__(1024) void rf_step_boundary_kernel(
     const int n = tid + c * 1024;
     hv[c] = 0.f;
     if (n < w) {
-      const bf16_t* wr = in_w + (int64_t)n * T;
-      float a = bf16_to_f32(in_b[n]);
-      for (int k = 0; k < T; k += 8) {           // T % 8 == 0 (host check): 16-byte rows
-        const mn_u4_t q = *reinterpret_cast<const mn_u4_t*>(wr + k);
-        a = fmaf(bf16lo_to_f32(q.x), xs[k], a); a = fmaf(bf16hi_to_f32(q.x), xs[k + 1], a);
-        a = fmaf(bf16lo_to_f32(q.y), xs[k + 2], a); a = fmaf(bf16hi_to_f32(q.y), xs[k + 3], a);
-        a = fmaf(bf16lo_to_f32(q.z), xs[k + 4], a); a = fmaf(bf16hi_to_f32(q.z), xs[k + 5], a);
-        a = fmaf(bf16lo_to_f32(q.w), xs[k + 6], a); a = fmaf(bf16hi_to_f32(q.w), xs[k + 7], a);
+      float a;
+      if (pre) {
+        a = bq[c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const mn_u4_t q = wq[c][j];
+          const float* xk = xs + j * 8;
+          a = fmaf(bf16lo_to_f32(q.x), xk[0], a); a = fmaf(bf16hi_to_f32(q.x), xk[1], a);
+          a = fmaf(bf16lo_to_f32(q.y), xk[2], a); a = fmaf(bf16hi_to_f32(q.y), xk[3], a);
+          a = fmaf(bf16lo_to_f32(q.z), xk[4], a); a = fmaf(bf16hi_to_f32(q.z), xk[5], a);
+          a = fmaf(bf16lo_to_f32(q.w), xk[6], a); a = fmaf(bf16hi_to_f32(q.w), xk[7], a);
+        }
+      } else {
+        const bf16_t* wr = in_w + (int64_t)n * T;
+        a = bf16_to_f32(in_b[n]);
+        for (int k = 0; k < T; k += 8) {           // T % 8 == 0 (host check): 16-byte rows
+          const mn_u4_t q = *reinterpret_cast<const mn_u4_t*>(wr + k);
+          a = fmaf(bf16lo_to_f32(q.x), xs[k], a); a = fmaf(bf16hi_to_f32(q.x), xs[k + 1], a);
+          a = fmaf(bf16lo_to_f32(q.y), xs[k + 2], a); a = fmaf(bf16hi_to_f32(q.y), xs[k + 3], a);
+          a = fmaf(bf16lo_to_f32(q.z), xs[k + 4], a); a = fmaf(bf16hi_to_f32(q.z), xs[k + 5], a);
+          a = fmaf(bf16lo_to_f32(q.w), xs[k + 6], a); a = fmaf(bf16hi_to_f32(q.w), xs[k + 7], a);
+        }
       }
       hv[c] = a;
       h[(int64_t)m * w + n] = a;
       sum += a;
+    }
+  }
+  float lgq[4], lbq[4], scq[4], shq[4];           // requested before the reductions' barriers
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int n = tid + c * 1024;
+    lgq[c] = 1.f; lbq[c] = 0.f; scq[c] = 0.f; shq[c] = 0.f;
+    if (n < w) {
+      if (ln_g) lgq[c] = bf16_to_f32(ln_g[n]);
+      if (ln_b) lbq[c] = bf16_to_f32(ln_b[n]);
+      scq[c] = scale[(int64_t)m * ldmod + n];
+      shq[c] = shift[(int64_t)m * ldmod + n];
     }
   }
   const float mean = block_sum(sum, red) / (float)w;
@@ -357,9 +402,8 @@ __global__ __launch_bounds__(1024) void rf_step_boundary_kernel(
     const int n = tid + c * 1024;
     if (n < w) {
       float v = (hv[c] - mean) * rstd;
-      if (ln_g) v *= bf16_to_f32(ln_g[n]);
-      if (ln_b) v += bf16_to_f32(ln_b[n]);
-      v = v * (1.0f + scale[(int64_t)m * ldmod + n]) + shift[(int64_t)m * ldmod + n];
+      v = v * lgq[c] + lbq[c];
+      v = v * (1.0f + scq[c]) + shq[c];
       const bf16_t hi = f32_to_bf16(v);
       Y[(int64_t)m * w + n] = hi;
       Y[(int64_t)(M + m) * w + n] = f32_to_bf16(v - bf16_to_f32(hi));
