@@ -184,6 +184,7 @@ template <int M, int R, int SW>
 int launch_nt(const KArgs& ka, int nt, dim3 grid, size_t lds, hipStream_t st) {
   if (nt == 256) launch_one<M, R, SW, 256>(ka, grid, lds, st);
   else if (nt == 768) launch_one<M, R, SW, 768>(ka, grid, lds, st);
+  else if (nt == 1024 && M == 1 && R <= 2) launch_one<(M == 1 ? 1 : 1), (R <= 2 ? R : 1), SW, 1024>(ka, grid, lds, st);
   else launch_one<M, R, SW, 512>(ka, grid, lds, st);
   return 0;
 }
@@ -413,8 +414,12 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
     // (e.g. N = 3072 on 256 CUs: 12 groups per CU)
     const int64_t per_cu = mn_cdiv((int64_t)a.N * ka.batch, cus);
     if (per_cu % 12 == 0 && per_cu % 8 != 0) nt = 768;
+    // one activation row (the expert pair launches of a 1- / 2-row step, text decode's projections): a wave's chain of dependent
+    // chunk round trips is the launch, so more waves per CU shorten it — 16 where every wave still gets a row group, else 12
+    // (tools/exp/moe_pair_tune.py: both expert launches 36.2 -> 33.9 us per layer at 1 row, 53.2 -> 49.4 at 2)
+    else if (a.M == 1) nt = (int64_t)a.N * ka.batch >= (int64_t)cus * 16 ? 1024 : 768;
   }
-  if (g_tune.nt == 256 || g_tune.nt == 512 || g_tune.nt == 768) {
+  if (g_tune.nt == 256 || g_tune.nt == 512 || g_tune.nt == 768 || (g_tune.nt == 1024 && a.M == 1)) {
     nt = g_tune.nt;
     bpc = g_tune.bpc > 0 ? g_tune.bpc : 1;
     const int max_bpc = (int)((160 * 1024) / lds);

@@ -205,6 +205,8 @@ void launch_one(const W8Args& ka, dim3 grid, size_t lds, hipStream_t st) {
 template <int R, int SW>
 void launch_nt(const W8Args& ka, int nt, dim3 grid, size_t lds, hipStream_t st) {
   if (nt == 256) launch_one<R, SW, 256>(ka, grid, lds, st);
+  else if (nt == 768) launch_one<R, SW, 768>(ka, grid, lds, st);
+  else if (nt == 1024) launch_one<R, SW, 1024>(ka, grid, lds, st);
   else launch_one<R, SW, 512>(ka, grid, lds, st);
 }
 
@@ -237,6 +239,7 @@ extern "C" int mn_skinny_w8_row(const mn_skinny_args* args, void* stream) {
   const int64_t groups_r1 = (int64_t)a.N * ka.batch;
   const int max_bpc = (int)((160 * 1024) / lds);
   if (groups_r1 < (int64_t)cus * 8 && max_bpc >= 2) { nt = 256; bpc = max_bpc > 4 ? 4 : max_bpc; }
+  else nt = groups_r1 >= (int64_t)cus * 16 ? 1024 : 768;      // more waves per CU shorten the launch (skinny_gemm.hip, one-row plan)
   const int wpb = nt / 64;
   const int64_t resident = mn_cdiv((int64_t)cus * bpc * wpb, ka.batch);
   int R = 1;
