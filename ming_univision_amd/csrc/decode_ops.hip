@@ -76,6 +76,24 @@ __global__ __launch_bounds__(1024) void moe_router_row_kernel(
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* xr = x + (int64_t)m * ldx;
+  const bool img = image_mask && image_gate_w && image_mask[m];
+  const bf16_t* G = img ? image_gate_w : gate_w;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};          // experts wave, wave + 16, wave + 32, wave + 48: four weight rows in flight per lane
+  // H <= 2048 (the 16B-A3B width): this lane's 16 weight slots do not depend on x — requested FIRST, so the launch is one memory round
+  // trip (x and the gate rows together) + the reductions, not two dependent ones
+  const bool pre = H <= 2048 && (H % 512) == 0;
+  u4 gw[4][4];
+  if (pre) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = wave + 16 * j, k = lane * 8 + 512 * i;
+        gw[i][j] = u4{0u, 0u, 0u, 0u};
+        if (e < E && k < H) gw[i][j] = *reinterpret_cast<const u4*>(G + (int64_t)e * H + k);
+      }
+  }
   float ss = 0.f;
   for (int k = tid; k < H; k += 1024) { const float v = xr[k]; ss += v * v; }
   ss = block_sum(ss, red);
@@ -86,10 +104,25 @@ __global__ __launch_bounds__(1024) void moe_router_row_kernel(
     x_norm[(int64_t)m * H + k] = v;
   }
   __syncthreads();
-  const bool img = image_mask && image_gate_w && image_mask[m];
-  const bf16_t* G = img ? image_gate_w : gate_w;
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};          // experts wave, wave + 16, wave + 32, wave + 48: four weight rows in flight per lane
+  if (pre) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = lane * 8 + 512 * i;
+      if (k < H) {
+        const f4 xa = *reinterpret_cast<const f4*>(&xs[k]), xb = *reinterpret_cast<const f4*>(&xs[k + 4]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u4 wv = gw[i][j];
+          float a = acc[j];
+          a = fmaf(bf16lo_to_f32(wv.x), xa.x, a); a = fmaf(bf16hi_to_f32(wv.x), xa.y, a);
+          a = fmaf(bf16lo_to_f32(wv.y), xa.z, a); a = fmaf(bf16hi_to_f32(wv.y), xa.w, a);
+          a = fmaf(bf16lo_to_f32(wv.z), xb.x, a); a = fmaf(bf16hi_to_f32(wv.z), xb.y, a);
+          a = fmaf(bf16lo_to_f32(wv.w), xb.z, a); a = fmaf(bf16hi_to_f32(wv.w), xb.w, a);
+          acc[j] = a;
+        }
+      }
+    }
+  } else
   for (int k = lane * 8; k < H; k += 512) {
     const f4 xa = *reinterpret_cast<const f4*>(&xs[k]), xb = *reinterpret_cast<const f4*>(&xs[k + 4]);
 #pragma unroll
