@@ -1381,10 +1381,65 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* __restri
     if (val) val[m] = bv;
   }
 }
+// Few rows (text decode): one workgroup scanning 126 k logits was 46 us of a 1.9 ms token — the scan is spread over ARGMAX_PARTS
+// workgroups per row (same comparator, so the same winner: value, then lowest index; NaN first), a 64-lane launch picks among them.
+constexpr int ARGMAX_PARTS = 64;
+__device__ __forceinline__ bool argmax_better(float v, int j, float bv, int bi) {
+  const bool vn = v != v, bn = bv != bv;
+  if (vn || bn) return vn && (!bn || j < bi);
+  return v > bv || (v == bv && j < bi);
+}
+__global__ __launch_bounds__(256) void argmax_part_kernel(const float* __restrict__ logits, int64_t ld, int V, float* __restrict__ pv,
+                                                          int* __restrict__ pi) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int m = blockIdx.x, part = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int chunk = (V + ARGMAX_PARTS - 1) / ARGMAX_PARTS;
+  const int j0 = part * chunk, j1 = min(V, j0 + chunk);
+  const float* r = logits + (int64_t)m * ld;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = j0 + threadIdx.x; j < j1; j += 256) {
+    const float v = r[j];
+    if (argmax_better(v, j, bv, bi)) { bv = v; bi = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (argmax_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w2 = 1; w2 < 4; ++w2)
+      if (argmax_better(sv[w2], si[w2], bv, bi)) { bv = sv[w2]; bi = si[w2]; }
+    pv[m * ARGMAX_PARTS + part] = bv;
+    pi[m * ARGMAX_PARTS + part] = bi;
+  }
+}
+__global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int V, int64_t vocab_offset,
+                                                          int64_t* __restrict__ idx, float* __restrict__ val) {
+  const int m = blockIdx.x, lane = threadIdx.x;
+  float bv = pv[m * ARGMAX_PARTS + lane];
+  int bi = pi[m * ARGMAX_PARTS + lane];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (argmax_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) {
+    if (bi >= V) bi = 0;
+    idx[m] = (int64_t)bi + vocab_offset;
+    if (val) val[m] = bv;
+  }
+}
 }  // namespace
 
 extern "C" size_t mn_lmhead_argmax_workspace_bytes(int M, int V, int H) {
   size_t n = (((size_t)M * V * sizeof(float)) + 255) & ~(size_t)255;        // the logits
+  n += (((size_t)M * ARGMAX_PARTS * 8) + 255) & ~(size_t)255;              // (value, index) of every scan part
   if (M > 8) n += (((size_t)2 * M * H * sizeof(bf16_t)) + 255) & ~(size_t)255;   // hi/lo operand of the MFMA route
   return n;
 }
@@ -1419,7 +1474,14 @@ extern "C" int mn_lmhead_argmax(const float* hidden, int64_t ld_hidden, int M, c
       MN_TRY(mn_skinny_gemm(&a, stream));
     }
   }
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3(M), dim3(1024), 0, st, (const float*)logits, (int64_t)V, V, vocab_offset, idx, val);
+  if (M <= 8 && V >= 16 * ARGMAX_PARTS) {
+    float* pv = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + need - ((((size_t)M * ARGMAX_PARTS * 8) + 255) & ~(size_t)255));
+    int* pi = reinterpret_cast<int*>(pv + (size_t)M * ARGMAX_PARTS);
+    hipLaunchKernelGGL(argmax_part_kernel, dim3(M, ARGMAX_PARTS), dim3(256), 0, st, (const float*)logits, (int64_t)V, V, pv, pi);
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(M), dim3(64), 0, st, (const float*)pv, (const int*)pi, V, vocab_offset, idx, val);
+  } else {
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(M), dim3(1024), 0, st, (const float*)logits, (int64_t)V, V, vocab_offset, idx, val);
+  }
   MN_CHECK_LAUNCH("mn_lmhead_argmax");
   return MN_OK;
 }
