@@ -502,8 +502,9 @@ static bool rf_fp8_ok(const mn_rf_head* h) {
 // <= 4 rows (the CFG rows of one image — the reference's call shape): the SwiGLU glue launch is folded into w3's prologue
 // (stream_fuse.h): three launches per ResBlock instead of four.  g_rf_fuse: dev-library A/B switch.
 static int g_rf_fuse = 1, g_rf_boundary = 1;
+static void g_rf_ada_stream_set(int v);
 #ifdef MN_DEV_HOOKS
-extern "C" MN_DEV_API void mn_rf_tune_fuse(int on) { g_rf_fuse = on & 1; g_rf_boundary = (on >> 1) & 1; }
+extern "C" MN_DEV_API void mn_rf_tune_fuse(int on) { g_rf_fuse = on & 1; g_rf_boundary = (on >> 1) & 1; g_rf_ada_stream_set((on >> 2) & 1 ? 0 : 1); }
 #endif
 static bool rf_fused_shape_ok(const mn_rf_head* h, int rows) {
   return rows <= FUSE_MAX_ROWS && rf_chain_ok(h, rows) &&
@@ -512,6 +513,13 @@ static bool rf_fused_shape_ok(const mn_rf_head* h, int rows) {
 
 // fp8 adaLN: the modulations of all Euler steps as ONE streaming launch on e4m3 bytes when their rows fit it
 static bool rf_ada_w8(const mn_rf_head* h, int rows) { return h->wfmt && h->ada_q && h->ada_scale && (int64_t)h->steps * rows <= 64; }
+// bf16 adaLN at <= 32 (step, row) pairs (the CFG rows of one image): the K-slice streaming launch reads the 0.72 GB once at 4.3 TB/s
+// where the 128-tile hi/lo GEMM manages 2.7 (267 -> ~180 us per token at 2 rows); g_rf_ada_stream: dev-library A/B switch
+static int g_rf_ada_stream = 1;
+static void g_rf_ada_stream_set(int v) { g_rf_ada_stream = v; }
+static bool rf_ada_stream(const mn_rf_head* h, int rows) {
+  return g_rf_ada_stream && !h->wfmt && (int64_t)h->steps * rows <= 32 && (h->w % 8) == 0;
+}
 
 static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, float** z, float** c, float** ada,
                        float** hh, float** hid, float** v, float** x, bf16_t** y, unsigned** bar, char** skws,
@@ -540,7 +548,8 @@ static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, floa
   *yb = cv.take<bf16_t>(chain ? (size_t)2 * rows * h->hidden : 0);
   *pbuf = cv.take<float>(chain ? pmax * rows : 0);
   const int SRn = h->steps * rows;
-  float* pa = cv.take<float>(rf_ada_w8(h, rows) ? (size_t)mn_stream_mfma_w8_slices(SRn, A, h->w) * SRn * A : 0);
+  float* pa = cv.take<float>(rf_ada_w8(h, rows) ? (size_t)mn_stream_mfma_w8_slices(SRn, A, h->w) * SRn * A
+                             : ((!h->wfmt && (int64_t)SRn <= 32 && (h->w % 8) == 0) ? (size_t)mn_stream_mfma_slices(SRn, A, h->w) * SRn * A : 0));
   if (pada) *pada = pa;
   // fused w3: its slabs live beside w12's (its prologue reads those while other workgroups already write w3's); the workspace does
   // not depend on the A/B switch
@@ -605,6 +614,10 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   hipLaunchKernelGGL(rf_build_y_kernel, dim3(mn_cdiv(SR * w, 256)), dim3(256), 0, st, h->temb, c, y, h->steps, rows, w);
   if (rf_ada_w8(h, rows)) {      // <= 64 (step, row) pairs: stream the 0.36 GB of e4m3 adaLN bytes once, then slabs + bias -> ada
     const int nza = mn_stream_mfma_wq(y, h->ada_q, h->ada_scale, pada, (int)SR, A, w, h->wfmt, stream);
+    if (nza < 0) return nza;
+    hipLaunchKernelGGL(rf_glue_bias_out_kernel, dim3(mn_cdiv(SR * A, 256)), dim3(256), 0, st, pada, nza, (int)SR, A, h->ada_b, ada);
+  } else if (rf_ada_stream(h, rows)) {
+    const int nza = mn_stream_mfma(y, h->ada_w, pada, (int)SR, A, w, stream);
     if (nza < 0) return nza;
     hipLaunchKernelGGL(rf_glue_bias_out_kernel, dim3(mn_cdiv(SR * A, 256)), dim3(256), 0, st, pada, nza, (int)SR, A, h->ada_b, ada);
   } else {
