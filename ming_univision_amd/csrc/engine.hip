@@ -513,12 +513,13 @@ static bool rf_fused_shape_ok(const mn_rf_head* h, int rows) {
 
 // fp8 adaLN: the modulations of all Euler steps as ONE streaming launch on e4m3 bytes when their rows fit it
 static bool rf_ada_w8(const mn_rf_head* h, int rows) { return h->wfmt && h->ada_q && h->ada_scale && (int64_t)h->steps * rows <= 64; }
-// bf16 adaLN at <= 32 (step, row) pairs (the CFG rows of one image): the K-slice streaming launch reads the 0.72 GB once at 4.3 TB/s
-// where the 128-tile hi/lo GEMM manages 2.7 (267 -> ~180 us per token at 2 rows); g_rf_ada_stream: dev-library A/B switch
+// bf16 adaLN at <= 64 (step, row) pairs (the CFG rows of one or two images): the streaming launch (K-slice form to 32 pairs, K-loop form
+// above) reads the 0.72 GB once at ~4 TB/s where the 128-tile hi/lo GEMM manages 2.7 — RF sampler 7.49 -> 7.30 ms at 2 rows, 7.70 ->
+// 7.51 at 3, 7.74 -> 7.54 at 4 (tools/exp/rf_fused_chain.py); g_rf_ada_stream: dev-library A/B switch
 static int g_rf_ada_stream = 1;
 static void g_rf_ada_stream_set(int v) { g_rf_ada_stream = v; }
 static bool rf_ada_stream(const mn_rf_head* h, int rows) {
-  return g_rf_ada_stream && !h->wfmt && (int64_t)h->steps * rows <= 32 && (h->w % 8) == 0;
+  return g_rf_ada_stream && !h->wfmt && (int64_t)h->steps * rows <= 64 && (h->w % 8) == 0;
 }
 
 static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, float** z, float** c, float** ada,
@@ -549,7 +550,7 @@ static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, floa
   *pbuf = cv.take<float>(chain ? pmax * rows : 0);
   const int SRn = h->steps * rows;
   float* pa = cv.take<float>(rf_ada_w8(h, rows) ? (size_t)mn_stream_mfma_w8_slices(SRn, A, h->w) * SRn * A
-                             : ((!h->wfmt && (int64_t)SRn <= 32 && (h->w % 8) == 0) ? (size_t)mn_stream_mfma_slices(SRn, A, h->w) * SRn * A : 0));
+                             : ((!h->wfmt && (int64_t)SRn <= 64 && (h->w % 8) == 0) ? (size_t)mn_stream_mfma_slices(SRn, A, h->w) * SRn * A : 0));
   if (pada) *pada = pa;
   // fused w3: its slabs live beside w12's (its prologue reads those while other workgroups already write w3's); the workspace does
   // not depend on the A/B switch
