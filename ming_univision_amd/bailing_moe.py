@@ -57,6 +57,14 @@ def pack_experts(sd, prefix, cfg):
     return gu, dn
 
 
+def pass_spans(starts, seqs, past, r0, r1):
+    """The pieces of stacked sequences that the row range [r0, r1) of one prefill pass holds, as mn_llm_step_spans wants them:
+    (cache sequence, first row inside the pass, rows, slots the sequence already has in its cache).  starts: the row offset of every
+    sequence in the stack (+ the total as last entry); a sequence cut by a pass boundary continues in the next pass with past > 0."""
+    return [(seqs[i], max(starts[i], r0) - r0, min(starts[i + 1], r1) - max(starts[i], r0), past + max(starts[i], r0) - starts[i])
+            for i in range(len(starts) - 1) if min(starts[i + 1], r1) > max(starts[i], r0)]
+
+
 def quantize_layer_experts(ly, weights="fp8"):
     """8-bit weight modes: replace a layer's packed bf16 experts by e4m3 ("fp8") or int8 bytes + row scales [E + S, 2I] / [E + S, H]
     (in place)."""
@@ -383,9 +391,7 @@ class BailingMoeDecoder:
         for r0 in range(0, x.shape[0], step):
             r1 = min(x.shape[0], r0 + step)
             sl = slot[r0:r1].contiguous()
-            # the pieces of the sequences this pass holds: (sequence, first row in the pass, rows, slots already in its cache)
-            spans = [(seqs[i], max(starts[i], r0) - r0, min(starts[i + 1], r1) - max(starts[i], r0), past + max(starts[i], r0) - starts[i])
-                     for i in range(len(lens)) if min(starts[i + 1], r1) > max(starts[i], r0)]
+            spans = pass_spans(starts, seqs, past, r0, r1)
             self.step(x[r0:r1], seq[r0:r1].contiguous(), sl, sl, (sl + 1).contiguous(), None, None if im is None else im[r0:r1],
                       out=out[r0:r1], spans=spans)
         last = torch.tensor(lens).cumsum(0) - 1

@@ -410,3 +410,43 @@ def test_hf_tokenizer_adapter_with_a_real_tokenizer_json(tmp_path):
     assert any(inside for inside in (h + 3 <= i < a for i in range(len(ids))))
     assert ad.decode([vocab["a"], vocab["cat"], 126081], skip_special_tokens=True).split() == ["a", "cat"]
     assert ad.batch_decode([[vocab["hello"]], [vocab["cat"], vocab["."]]]) == ["hello", "cat ."]
+
+
+def test_prefill_pass_spans_partition_the_stacked_sequences():
+    """pass_spans (the span tables of mn_llm_step_spans): whatever the pass size, the spans of all passes tile every sequence exactly
+    once, in order, with `past` = the slots the sequence already wrote; rows inside a pass are contiguous and in stack order."""
+    from ming_univision_amd.bailing_moe import pass_spans
+    import random
+    rnd = random.Random(0)
+    for trial in range(200):
+        n = rnd.randint(1, 6)
+        lens = [rnd.randint(1, 300) for _ in range(n)]
+        seqs = rnd.sample(range(20), n)
+        past = rnd.choice([0, 0, 17, 200])
+        step = rnd.choice([1, 7, 64, 128, 2048])
+        starts = [0]
+        for L in lens:
+            starts.append(starts[-1] + L)
+        covered = {s: past for s in seqs}                        # next expected slot of every sequence
+        for r0 in range(0, starts[-1], step):
+            r1 = min(starts[-1], r0 + step)
+            spans = pass_spans(starts, seqs, past, r0, r1)
+            assert sum(sp[2] for sp in spans) == r1 - r0
+            row = 0
+            for seq, first, rows, p in spans:
+                assert first == row and rows >= 1
+                assert p == covered[seq], (trial, seq, p, covered[seq])
+                covered[seq] += rows
+                row += rows
+        assert all(covered[s] == past + L for s, L in zip(seqs, lens))
+
+
+def test_sampling_arguments_are_validated_on_the_host():
+    """generate()'s sampling kwargs (the ones the reference forwards to HF generate) are checked before anything touches the GPU."""
+    import inspect
+    from ming_univision_amd.modeling import MingUniVisionForConditionalGeneration as M
+    sig = inspect.signature(M.generate)
+    for k, d in (("do_sample", False), ("temperature", 1.0), ("top_k", 50), ("top_p", 1.0), ("generator", None)):
+        assert sig.parameters[k].default == d               # HF's defaults (mingunivision/config.json:30,103-109)
+    sig = inspect.signature(M.generate_text_batch)
+    assert sig.parameters["do_sample"].default is False and sig.parameters["top_k"].default == 50
