@@ -228,8 +228,17 @@ __global__ void rope_kv_append_kernel(const float* __restrict__ qkv, int64_t ldq
                                       float* __restrict__ q_out, float* __restrict__ kv_cache, int64_t t_max, int round_kv) {
   const int m = blockIdx.x, h = blockIdx.y, i = threadIdx.x, half = hd >> 1;
   const float* src = qkv + (int64_t)m * ldqkv + (int64_t)h * hd;
-  float x1 = src[i], x2 = src[i + half];
-  for (int z = 1; z < nz; ++z) { x1 += src[z * slab + i]; x2 += src[z * slab + i + half]; }
+  float x1 = 0.f, x2 = 0.f;
+  for (int z0 = 0; z0 < nz; z0 += 8) {              // eight slabs' loads in flight (one by one: nz dependent round trips)
+    float a1[8], a2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a1[j] = z0 + j < nz ? src[(int64_t)(z0 + j) * slab + i] : 0.f;
+      a2[j] = z0 + j < nz ? src[(int64_t)(z0 + j) * slab + i + half] : 0.f;
+    }
+    for (int j = 0; j < 8; ++j) x1 += a1[j];                    // (the one-by-one loop's order: same bits)
+    for (int j = 0; j < 8; ++j) x2 += a2[j];
+  }
   const bool is_q = h < n_q, is_k = !is_q && h < n_q + n_kv;
   if (rope && (is_q || is_k)) {
     // 3D rotary (sec_t > 0): row_pos is [3][M] = t, h, w positions; frequency i of each half follows the t stream for
@@ -661,8 +670,17 @@ __global__ __launch_bounds__(1024) void attn_decode_one_kernel(
       const float* row = fz.qkv + (int64_t)m * fz.ldqkv;
       const int head = wave == 0 ? h : (wave == 1 ? n_q + kvh : n_q + n_kv + kvh);
       const float* p_ = row + (int64_t)head * HD + lane;
-      float x1 = p_[0], x2 = p_[half];
-      for (int z = 1; z < fz.nz; ++z) { x1 += p_[z * fz.slab]; x2 += p_[z * fz.slab + half]; }
+      float x1 = 0.f, x2 = 0.f;
+      for (int z0 = 0; z0 < fz.nz; z0 += 8) {      // eight slabs' loads in flight
+        float a1[8], a2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          a1[j] = z0 + j < fz.nz ? p_[(int64_t)(z0 + j) * fz.slab] : 0.f;
+          a2[j] = z0 + j < fz.nz ? p_[(int64_t)(z0 + j) * fz.slab + half] : 0.f;
+        }
+        for (int j = 0; j < 8; ++j) x1 += a1[j];                    // (the one-by-one loop's order: same bits)
+        for (int j = 0; j < 8; ++j) x2 += a2[j];
+      }
       if (fz.rope && wave < 2) {
         const int stream = fz.sec_t <= 0 ? 0 : (lane < fz.sec_t ? 0 : (lane < fz.sec_t + fz.sec_h ? 1 : 2));
         const int pos = fz.row_pos[stream * fz.M + m];

@@ -268,7 +268,12 @@ __global__ void rf_glue_bias_out_kernel(const float* __restrict__ P, int nz, int
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M * N) return;
   float y = bf16_to_f32(b[i % N]);
-  for (int z = 0; z < nz; ++z) y += P[(int64_t)z * M * N + i];
+  for (int z0 = 0; z0 < nz; z0 += 4) {              // four slabs' loads in flight
+    float t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = z0 + j < nz ? P[(int64_t)(z0 + j) * M * N + i] : 0.f;
+    for (int j = 0; j < 4; ++j) y += t[j];                      // (the one-by-one loop's order: same bits)
+  }
   out[i] = y;
 }
 
@@ -312,10 +317,20 @@ __global__ __launch_bounds__(1024) void rf_step_boundary_kernel(
     if (!first) {
       const int r0 = (m / rpi) * rpi;
       float v[3] = {0.f, 0.f, 0.f};
-      for (int r = 0; r < rpi; ++r) {
-        float y = bf16_to_f32(fin_b[tid]);
-        for (int z = 0; z < nz; ++z) y += P[((int64_t)z * M + r0 + r) * T + tid];
-        v[r] = y;
+      const float fb = bf16_to_f32(fin_b[tid]);
+      // all rows' slabs in batches of 8 independent loads (one by one this was rpi x nz = 24 dependent round trips: 16 us of launch)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        if (r < rpi) {
+          float y = fb;
+          for (int z0 = 0; z0 < nz; z0 += 8) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = z0 + j < nz ? P[((int64_t)(z0 + j) * M + r0 + r) * T + tid] : 0.f;
+            for (int j = 0; j < 8; ++j) y += t[j];                    // (the one-by-one loop's order: same bits)
+          }
+          v[r] = y;
+        }
       }
       const float vg = rpi == 3 ? v[1] + image_cfg * (v[2] - v[1]) + text_cfg * (v[0] - v[2])
                                 : (rpi == 2 ? v[1] + text_cfg * (v[0] - v[1]) : v[0]);
@@ -794,7 +809,12 @@ __global__ __launch_bounds__(1024) void llm_glue_kernel(int mode, const float* _
       v = *reinterpret_cast<const f4*>(h + (int64_t)m * H + col);
       if (mode == 1) {
         const float* pp = P + (int64_t)m * H + col;
-        for (int z = 0; z < nz; ++z) v += *reinterpret_cast<const f4*>(pp + z * slab);
+        for (int z0 = 0; z0 < nz; z0 += 8) {        // eight slabs' loads in flight (a one-by-one loop is nz dependent round trips)
+          f4 t[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t[j] = z0 + j < nz ? *reinterpret_cast<const f4*>(pp + (int64_t)(z0 + j) * slab) : f4{0.f, 0.f, 0.f, 0.f};
+          for (int j = 0; j < 8; ++j) v += t[j];                      // (the one-by-one loop's order: same bits)
+        }
       } else if (mode == 2) {
         for (int s = 0; s < n_slot; s += 4) {       // four slots x nz slabs of independent 16-byte loads in flight
           const float* pp[4];
@@ -853,7 +873,12 @@ __global__ __launch_bounds__(1024) void moe_route_group_kernel(const float* __re
     float s = -INFINITY;
     if (lane < E) {
       s = 0.f;
-      for (int z = 0; z < nz; ++z) s += P[((int64_t)z * M + m) * E + lane];
+      for (int z0 = 0; z0 < nz; z0 += 8) {          // eight slabs' loads in flight
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = z0 + j < nz ? P[((int64_t)(z0 + j) * M + m) * E + lane] : 0.f;
+        for (int j = 0; j < 8; ++j) s += t[j];                    // (the one-by-one loop's order: same bits)
+      }
     }
     const float mx = wave_max(s);
     float p = lane < E ? __expf(s - mx) : 0.f;
@@ -1413,9 +1438,18 @@ __global__ __launch_bounds__(256) void argmax_part_kernel(const float* __restric
   const float* r = logits + (int64_t)m * ld;
   float bv = -INFINITY;
   int bi = 0x7fffffff;
-  for (int j = j0 + threadIdx.x; j < j1; j += 256) {
-    const float v = r[j];
-    if (argmax_better(v, j, bv, bi)) { bv = v; bi = j; }
+  for (int jb = j0; jb < j1; jb += 2048) {         // eight independent loads per thread in flight (one batch at V = 126 464)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = jb + threadIdx.x + u * 256;
+      v[u] = j < j1 ? r[j] : -INFINITY;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = jb + threadIdx.x + u * 256;
+      if (j < j1 && argmax_better(v[u], j, bv, bi)) { bv = v[u]; bi = j; }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {

@@ -260,7 +260,12 @@ __global__ __launch_bounds__(256) void medium_epilogue_kernel(const mn_skinny_ar
   const int64_t slab = (int64_t)M * Ntot;
   auto gather = [&](int col) {
     float s = 0.f;
-    for (int z = 0; z < nz; ++z) s += P[z * slab + (int64_t)m * Ntot + col];
+    for (int z0 = 0; z0 < nz; z0 += 8) {            // eight slabs' loads in flight
+      float t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = z0 + j < nz ? P[(int64_t)(z0 + j) * slab + (int64_t)m * Ntot + col] : 0.f;
+      for (int j = 0; j < 8; ++j) s += t[j];                    // (the one-by-one loop's order: same bits)
+    }
     return s;
   };
   float y = gather(n);
