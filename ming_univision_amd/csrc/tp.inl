@@ -43,7 +43,13 @@ __global__ __launch_bounds__(1024) void tp_push_kernel(const TpPush p) {
     f4 v = {0.f, 0.f, 0.f, 0.f};
     if (p.P) {
       const float* pp = p.P + (int64_t)m * D + col;
-      for (int z = 0; z < p.nz; ++z) v += *reinterpret_cast<const f4*>(pp + z * p.slab);
+      for (int z0 = 0; z0 < p.nz; z0 += 8) {        // eight slabs' loads in flight, added in the one-by-one loop's order (same bits)
+        f4 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = z0 + j < p.nz ? *reinterpret_cast<const f4*>(pp + (int64_t)(z0 + j) * p.slab) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += t[j];
+      }
     }
     if (p.cy) {
       for (int s = 0; s < p.n_slot; ++s) {
