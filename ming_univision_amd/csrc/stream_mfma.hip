@@ -277,7 +277,7 @@ struct StreamPlan { int ks, nw, gx, nz; size_t lds; };
 
 // Tuning knobs for in-process A/B (not part of the stable ABI): force the slice length (in 256-k chunks) and the
 // waves per workgroup.
-int g_kch = 0, g_nw = 0, g_w8_depth = 1;      // fp8: one 4 KiB chunk in flight per wave measured faster than two (13.0 vs 13.3 us on RF w12, 8.1 vs 9.3 on w3)
+int g_kch = 0, g_nw = 0, g_tune_K = 0, g_w8_depth = 1;      // fp8: one 4 KiB chunk in flight per wave measured faster than two (13.0 vs 13.3 us on RF w12, 8.1 vs 9.3 on w3)
 
 // Launch shape for one [Ntot, K] matrix that has `slots` CUs to itself (dense: the whole chip; grouped: the chip's
 // share of one group).  One workgroup per CU (LDS-bound); the cost is the bytes a CU moves: weight chunks of its
@@ -290,10 +290,10 @@ StreamPlan stream_plan(int mt, int Ntot, int K, int slots, bool w8 = false) {
   StreamPlan best{};
   double best_cost = 1e30;
   for (int kch = 1; kch <= MAX_KCH; ++kch) {
-    if (g_kch > 0 && kch != g_kch) continue;
+    if (g_kch > 0 && kch != g_kch && (g_tune_K == 0 || g_tune_K == K)) continue;
     const int ks = kch * WCH, nz = (K + ks - 1) / ks;
     for (int nw = 8; nw <= 16; nw += 4) {
-      if (g_nw > 0 && nw != g_nw) continue;
+      if (g_nw > 0 && nw != g_nw && (g_tune_K == 0 || g_tune_K == K)) continue;
       const size_t lds = (size_t)2 * 16 * mt * ks * sizeof(bf16_t) + (size_t)nw * 16 * WCH * 2;
       if (lds > LDS_CAP) continue;
       int gx = (int)mn_cdiv(ntiles, nw);
@@ -372,7 +372,8 @@ int stream_fused(int wfmt, const void* W, const float* wscale, float* P, int M, 
 }
 
 #ifdef MN_DEV_HOOKS
-extern "C" MN_DEV_API void mn_stream_tune_plan(int kch, int nw) { g_kch = kch; g_nw = nw; }
+extern "C" MN_DEV_API void mn_stream_tune_plan(int kch, int nw) { g_kch = kch; g_nw = nw; g_tune_K = 0; }
+extern "C" MN_DEV_API void mn_stream_tune_plan_k(int K, int kch, int nw) { g_kch = kch; g_nw = nw; g_tune_K = K; }   // only matrices with this K
 extern "C" MN_DEV_API void mn_stream_tune_w8(int depth) { g_w8_depth = depth; }
 #endif
 
