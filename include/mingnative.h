@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MN_VERSION 122 /* 0.1.20: fp8 weight mode (section 7): wfmt / row-scale fields at the END of mn_skinny_args, mn_rf_head,
+#define MN_VERSION 123 /* 0.1.23: ABI guards mn_sizeof_* / mn_struct_layout.  0.1.20: fp8 weight mode (section 7): wfmt / row-scale fields at the END of mn_skinny_args, mn_rf_head,
                           mn_llm and mn_llm_tp (zero = bf16: callers of 0.1.10 that zero-fill the structs are unchanged),
                           mn_quant_fp8_rows / mn_dequant_fp8_rows / mn_stream_mfma_w8 / mn_stream_mfma_grouped_w8 */
 
@@ -52,6 +52,20 @@ MN_API int mn_version(void);
 MN_API const char* mn_last_error(void);
 /* Number of compute units of the current device (host query, cached). */
 MN_API int mn_num_cus(void);
+
+/* ABI guards (round 5): the binding side (ctypes Structures, cgo / JNI struct mirrors) can check that its layout of every struct
+ * below is the library's — a field added on one side only would otherwise corrupt calls silently.  mn_sizeof_* = sizeof(the struct);
+ * mn_struct_layout(which, offsets, cap) writes offsetof(every field, in declaration order) into offsets[0 .. min(n, cap)) and
+ * returns the field count n (MN_EINVAL for an unknown `which`). */
+enum mn_struct_id { MN_STRUCT_SKINNY_ARGS = 0, MN_STRUCT_RF_HEAD = 1, MN_STRUCT_LLM = 2, MN_STRUCT_SEMDEC = 3, MN_STRUCT_TP_COMM = 4,
+                    MN_STRUCT_LLM_TP = 5 };
+MN_API size_t mn_sizeof_skinny_args(void);
+MN_API size_t mn_sizeof_rf_head(void);
+MN_API size_t mn_sizeof_llm(void);
+MN_API size_t mn_sizeof_semdec(void);
+MN_API size_t mn_sizeof_tp_comm(void);
+MN_API size_t mn_sizeof_llm_tp(void);
+MN_API int mn_struct_layout(int which, size_t* offsets, int cap);
 
 /* ------------------------------------------------------------------------------------------
  * 1. Skinny GEMM (M <= 8 rows): out = epilogue( prologue(x) @ W^T + bias )
@@ -622,11 +636,16 @@ MN_API int mn_lmhead_argmax(const float* hidden, int64_t ld_hidden, int M, const
  * modeling_bailingmm.py:249-262, modeling_bailing_moe.py:1769-1796; warpers in transformers/generation/logits_process.py —
  * TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> softmax -> one multinomial draw):
  * idx[m] = vocab_offset + the token the inverse CDF of the warped distribution of logits[m] gives at u[m] in [0, 1), tokens ranked by
- * descending score, ties by ascending id.  top_k = 0 and top_p >= 1 switch the respective warper off; with top_k = 0 and top_p < 1
- * the candidate set is the 2048 largest scores; top_k is capped at 2048.  The caller owns the uniform stream (u), so a decode is
- * reproducible from a seed.  logits fp32 [M, V], row stride ld (e.g. the first bytes of mn_lmhead_argmax's workspace). */
+ * descending score, ties by ascending id.  top_k = 0 and top_p >= 1 switch the respective warper off.  The kernel ranks at most 2048
+ * candidates: top_k > 2048 is refused (MN_EINVAL); with top_k = 0 and top_p < 1 the nucleus limit is top_p of the FULL vocabulary's
+ * softmax mass and the nucleus is searched among the 2048 largest scores — HF's result exactly whenever its nucleus holds <= 2048 tokens.
+ * status (optional, int32 [M], may be NULL) reports the rows where that did not hold: MN_SAMPLE_NUCLEUS_TRUNCATED (the nucleus wanted more
+ * than 2048 tokens and was cut to the 2048 best) and MN_SAMPLE_TIES_TRUNCATED (more ties at the k-th score than candidates left: the lowest
+ * ids were kept).  The caller owns the uniform stream (u), so a decode is reproducible from a seed.  logits fp32 [M, V], row stride ld
+ * (e.g. the first bytes of mn_lmhead_argmax's workspace). */
+enum { MN_SAMPLE_NUCLEUS_TRUNCATED = 1, MN_SAMPLE_TIES_TRUNCATED = 2 };
 MN_API int mn_sample_logits(const float* logits, int64_t ld, int M, int V, float temperature, int top_k, float top_p, const float* u,
-                            int64_t vocab_offset, int64_t* idx, void* stream);
+                            int64_t vocab_offset, int64_t* idx, int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 7. fp8 weight mode (BASELINE configs[4] "fp8").

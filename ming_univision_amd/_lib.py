@@ -105,6 +105,28 @@ class LlmTp(C.Structure):
     ]
 
 
+# (struct id of mn_struct_layout, its mn_sizeof_* export, the ctypes mirror): checked against the library at load time (`lib()`)
+STRUCTS = ((0, "mn_sizeof_skinny_args", SkinnyArgs), (1, "mn_sizeof_rf_head", RfHead), (2, "mn_sizeof_llm", Llm),
+           (3, "mn_sizeof_semdec", SemDec), (4, "mn_sizeof_tp_comm", TpComm), (5, "mn_sizeof_llm_tp", LlmTp))
+
+
+def check_struct_layouts(handle):
+    """Every ctypes Structure above against the library's own sizeof / offsetof (mn_sizeof_*, mn_struct_layout): a field added or
+    moved on one side only raises here instead of corrupting calls.  Needs no GPU."""
+    for sid, sizer, klass in STRUCTS:
+        fn = getattr(handle, sizer)
+        fn.restype, fn.argtypes = C.c_size_t, []
+        if fn() != C.sizeof(klass):
+            raise RuntimeError(f"{klass.__name__}: ctypes size {C.sizeof(klass)} != library {fn()} ({sizer})")
+        lay = handle.mn_struct_layout
+        lay.restype, lay.argtypes = C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.c_int]
+        buf = (C.c_size_t * 128)()
+        n = lay(sid, buf, 128)
+        mine = [getattr(klass, name).offset for name, _ in klass._fields_]
+        if n != len(mine) or list(buf[:n]) != mine:
+            raise RuntimeError(f"{klass.__name__}: field offsets differ from the library's (struct id {sid}): {mine} vs {list(buf[:max(n, 0)])}")
+
+
 W_BF16, W_FP8_E4M3, W_INT8 = 0, 1, 2          # mingnative.h section 7: weight formats of the streaming route
 WFMT = {"bf16": W_BF16, "fp8": W_FP8_E4M3, "int8": W_INT8}
 W8 = ("fp8", "int8")                           # the weight-only 8-bit modes (bytes + one power-of-two scale per output row)
@@ -117,6 +139,9 @@ SYMBOLS = {
     "mn_version": (_i, []),
     "mn_last_error": (C.c_char_p, []),
     "mn_num_cus": (_i, []),
+    "mn_sizeof_skinny_args": (_sz, []), "mn_sizeof_rf_head": (_sz, []), "mn_sizeof_llm": (_sz, []), "mn_sizeof_semdec": (_sz, []),
+    "mn_sizeof_tp_comm": (_sz, []), "mn_sizeof_llm_tp": (_sz, []),
+    "mn_struct_layout": (_i, [_i, C.POINTER(C.c_size_t), _i]),
     "mn_skinny_gemm": (_i, [C.POINTER(SkinnyArgs), _p]),
     "mn_skinny_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mn_skinny_workspace_bytes_w8": (_sz, [_i, _i, _i, _i]),
@@ -205,7 +230,7 @@ SYMBOLS = {
     "mn_rf_sample_tp": (_i, [C.POINTER(RfHead), C.POINTER(TpComm), _p, _i64, _i, _i, _p, _f, _f, _f, _p, _p, _sz, _i, _i, _p]),
     "mn_lmhead_argmax_workspace_bytes": (_sz, [_i, _i, _i]),
     "mn_lmhead_argmax": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _i64, _p, _p, _p, _sz, _p]),
-    "mn_sample_logits": (_i, [_p, _i64, _i, _i, _f, _i, _f, _p, _i64, _p, _p]),
+    "mn_sample_logits": (_i, [_p, _i64, _i, _i, _f, _i, _f, _p, _i64, _p, _p, _p]),
     "mn_semdec_workspace_bytes": (_sz, [C.POINTER(SemDec), _i, _i64]),
     "mn_semdec_step": (_i, [C.POINTER(SemDec), _p, _i, _p, _p, _p, _p, _i, _i64, _p, _p, _p, _sz, _p]),
 }
@@ -225,8 +250,9 @@ def lib():
         fn = getattr(handle, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if handle.mn_version() < 122:
+    if handle.mn_version() < 123:
         raise RuntimeError("libmingnative.so is too old")
+    check_struct_layouts(handle)
     _lib = handle
     return _lib
 

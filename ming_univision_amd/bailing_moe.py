@@ -554,7 +554,19 @@ class BailingMoeDecoder:
     def sample(self, hidden, u, temperature=1.0, top_k=50, top_p=1.0):
         """Sampled pick of every row (HF generate's `do_sample` branch: temperature -> top-k -> top-p -> one draw, at the caller's
         uniforms u fp32 [M]): lm_head logits + mn_sample_logits.  hidden fp32 [M, H] -> int64 [M] on the device."""
-        return ops.sample_logits(self.logits(hidden.contiguous()), u, temperature, top_k, top_p)
+        st = torch.empty(hidden.shape[0], dtype=torch.int32, device=hidden.device)
+        ids = ops.sample_logits(self.logits(hidden.contiguous()), u, temperature, top_k, top_p, status=st)
+        # rows whose kept set was cut at the sampler's 2048 candidates (ops.SAMPLE_*), OR-ed on the device; read by
+        # `sampling_truncated()` at the caller's next host sync
+        flags = (st & 1).amax() | (st & 2).amax()
+        self.sample_flags = flags if getattr(self, "sample_flags", None) is None else self.sample_flags | flags
+        return ids
+
+    def sampling_truncated(self):
+        """Host sync: ops.SAMPLE_* bits seen by `sample` since the last call (0 = every draw was HF's distribution exactly)."""
+        f = getattr(self, "sample_flags", None)
+        self.sample_flags = None
+        return 0 if f is None else int(f)
 
     def embed(self, ids):
         """word_embeddings lookup -> fp32 rows (gather = memory plumbing)."""

@@ -11,8 +11,11 @@
 //
 // One 1024-thread workgroup per row.  The k-th largest score is found exactly by a three-pass radix select over order-preserving
 // 32-bit keys (11 + 11 + 10 bits, LDS histograms, the 126 k logits stay in L2), the survivors (<= 2048) are sorted by a bitonic
-// network in LDS.  top_k = 0 with top_p < 1 uses the 2048 largest scores as the candidate set (exact unless top-p would keep more
-// than 2048 tokens); top_k = 0 with top_p >= 1 (pure temperature sampling) draws from the FULL vocabulary in id order.
+// network in LDS.  top_k = 0 with top_p < 1: the nucleus is cut at top_p of the FULL vocabulary's softmax mass (one more pass over the
+// row) and searched among the 2048 largest scores — HF's result exactly whenever its nucleus holds <= 2048 tokens; a larger nucleus is
+// truncated to the 2048 best and reported (status bit MN_SAMPLE_NUCLEUS_TRUNCATED).  top_k > 2048 is refused by the entry point.
+// Ties at the k-th score that do not fit the 2048 candidates are kept in ascending id order (deterministic, status bit
+// MN_SAMPLE_TIES_TRUNCATED).  top_k = 0 with top_p >= 1 (pure temperature sampling) draws from the FULL vocabulary in id order.
 #include "common.h"
 
 namespace {
@@ -56,7 +59,7 @@ __device__ __forceinline__ int block_scan_i(int v, int* wsum) {
 
 __global__ __launch_bounds__(1024) void sample_logits_kernel(const float* __restrict__ logits, int64_t ld, int V, float inv_temp, int top_k,
                                                              float top_p, const float* __restrict__ u, int64_t vocab_offset,
-                                                             int64_t* __restrict__ idx) {
+                                                             int64_t* __restrict__ idx, int32_t* __restrict__ status) {
   __shared__ int hist[2048];
   __shared__ float sval[CAP];
   __shared__ int sidx[CAP];
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(1024) void sample_logits_kernel(const float* __rest
   float mx = -INFINITY;
   for (int j = tid; j < V; j += 1024) mx = fmaxf(mx, row[j]);
   mx = block_max(mx, red);
+  if (status && tid == 0) status[m] = 0;
 
   if (top_k <= 0 && top_p >= 1.0f) {
     // ---- pure temperature sampling over the whole vocabulary, inverse CDF in id order: contiguous chunk per thread
@@ -99,6 +103,12 @@ __global__ __launch_bounds__(1024) void sample_logits_kernel(const float* __rest
     return;
   }
 
+  // top-p without top-k: HF's softmax runs over the whole vocabulary, so the nucleus limit is top_p of the FULL mass
+  float z_full = 0.f;
+  if (top_k <= 0) {
+    for (int j = tid; j < V; j += 1024) z_full += __expf((row[j] - mx) * inv_temp);
+    z_full = block_sum(z_full, red);
+  }
   // ---- the K-th largest key, exactly: radix select from the top bits down
   int K = top_k > 0 ? min(top_k, CAP) : CAP;
   K = min(K, V);
@@ -130,19 +140,32 @@ __global__ __launch_bounds__(1024) void sample_logits_kernel(const float* __rest
     __syncthreads();
   }
   const uint32_t thr = prefix;                                     // key of the K-th largest score
-  // ---- survivors: every score >= the K-th largest (ties included), capped at CAP
+  // ---- survivors: every score > the K-th largest in any order (fewer than K <= CAP of them; the sort below is a total order), then
+  // the ties AT the K-th score in ascending id order while they fit — which ones stay never depends on atomics' arrival order
   if (tid == 0) s_cnt = 0;
   for (int i = tid; i < CAP; i += 1024) { sval[i] = -INFINITY; sidx[i] = 0x7fffffff; }
   __syncthreads();
+  const int per_t = (V + 1023) / 1024, t0 = tid * per_t, t1 = min(V, t0 + per_t);
+  int my_ties = 0;
   for (int j = tid; j < V; j += 1024) {
     const float v = row[j];
-    if (okey(v) >= thr) {
+    if (okey(v) > thr) {
       const int p = atomicAdd(&s_cnt, 1);
-      if (p < CAP) { sval[p] = v; sidx[p] = j; }
+      sval[p] = v; sidx[p] = j;
     }
   }
+  for (int j = t0; j < t1; ++j) my_ties += okey(row[j]) == thr;
+  const int ties_incl = block_scan_i(my_ties, wsi);               // (its barriers also publish s_cnt)
+  {
+    int p = s_cnt + ties_incl - my_ties;                          // contiguous id chunk per thread: ties land in id order
+    for (int j = t0; j < t1 && p < CAP; ++j)
+      if (okey(row[j]) == thr) { sval[p] = row[j]; sidx[p] = j; ++p; }
+  }
+  __shared__ int s_total;
+  if (tid == 1023) s_total = s_cnt + ties_incl;
   __syncthreads();
-  const int n = min(s_cnt, CAP);
+  const int n = min(s_total, CAP);
+  if (status && tid == 0 && top_k > 0 && s_total > CAP) atomicOr(&status[m], 2);   // (top_k = 0: only a truncated nucleus matters, below)
   // ---- bitonic sort, descending by score, ties by ascending id (a total order: the result does not depend on arrival order)
   for (int k2 = 2; k2 <= CAP; k2 <<= 1) {
     for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
@@ -168,12 +191,14 @@ __global__ __launch_bounds__(1024) void sample_logits_kernel(const float* __rest
   __syncthreads();
   // mass ranked above r0 / r1 / r1 + 1; the previous thread's inclusive sum is this thread's start, so the intervals tile [0, zk)
   const float ex0 = tid ? cdf[tid - 1] : 0.f, ex1 = ex0 + w0, ex2 = incl;
-  const float lim = top_p * cdf[1023];
+  const float lim = top_p * (top_k > 0 ? cdf[1023] : z_full);     // top-k first: its softmax is over what top-k kept
   const bool keep0 = r0 < n && (r0 == 0 || ex0 < lim), keep1 = r1 < n && ex1 < lim, keep2 = r1 + 1 < n && ex2 < lim;
   // the kept set is a prefix of the ranking (ex is monotone); its last rank and its mass
   __shared__ float s_zp;
   if (keep0 && !keep1) { s_zp = ex1; s_need = r0; }
   if (keep1 && !keep2) { s_zp = ex2; s_need = r1; }
+  // the nucleus wants more than the candidates hold (top_k = 0, near-uniform row): truncated to the CAP best, reported
+  if (status && tid == 0 && top_k <= 0 && n == CAP && cdf[1023] < lim) atomicOr(&status[m], 1);
   __syncthreads();
   const float target = uu * s_zp;
   if (keep0 && ex0 <= target && target < ex1) atomicMin(&s_pick, r0);
@@ -188,12 +213,14 @@ __global__ __launch_bounds__(1024) void sample_logits_kernel(const float* __rest
 
 // idx[m] = vocab_offset + a token drawn from row m of logits [M, V] (fp32, row stride ld) under HF's temperature / top-k / top-p
 // warpers at the uniform u[m] in [0, 1).  top_k = 0: off; top_p >= 1: off.  temperature > 0.
+// status (optional, int32 [M]): 0, or MN_SAMPLE_NUCLEUS_TRUNCATED | MN_SAMPLE_TIES_TRUNCATED for rows whose kept set was cut at 2048.
 extern "C" int mn_sample_logits(const float* logits, int64_t ld, int M, int V, float temperature, int top_k, float top_p, const float* u,
-                                int64_t vocab_offset, int64_t* idx, void* stream) {
+                                int64_t vocab_offset, int64_t* idx, int32_t* status, void* stream) {
   MN_CHECK_ARG(logits && u && idx && M >= 1 && V >= 1 && ld >= V && temperature > 0.f && top_k >= 0 && top_p > 0.f,
                "mn_sample_logits: bad args (temperature > 0, top_k >= 0, top_p > 0)");
+  MN_CHECK_ARG(top_k <= CAP, "mn_sample_logits: top_k = %d exceeds the %d candidates the kernel ranks", top_k, CAP);
   hipLaunchKernelGGL(sample_logits_kernel, dim3(M), dim3(1024), 0, mn_stream(stream), logits, ld, V, 1.0f / temperature, top_k, top_p, u,
-                     vocab_offset, idx);
+                     vocab_offset, idx, status);
   MN_CHECK_LAUNCH("mn_sample_logits");
   return MN_OK;
 }

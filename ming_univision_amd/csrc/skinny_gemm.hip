@@ -184,8 +184,11 @@ template <int M, int R, int SW>
 int launch_nt(const KArgs& ka, int nt, dim3 grid, size_t lds, hipStream_t st) {
   if (nt == 256) launch_one<M, R, SW, 256>(ka, grid, lds, st);
   else if (nt == 768) launch_one<M, R, SW, 768>(ka, grid, lds, st);
-  else if (nt == 1024 && M == 1 && R <= 2) launch_one<(M == 1 ? 1 : 1), (R <= 2 ? R : 1), SW, 1024>(ka, grid, lds, st);
-  else launch_one<M, R, SW, 512>(ka, grid, lds, st);
+  else if (nt == 1024) {
+    // the 16-wave form exists for one activation row and <= 2 weight rows per group only; the planner below never asks for another
+    if constexpr (M == 1 && R <= 2) launch_one<1, R, SW, 1024>(ka, grid, lds, st);
+    else return -1;
+  } else launch_one<M, R, SW, 512>(ka, grid, lds, st);
   return 0;
 }
 
@@ -444,6 +447,9 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   if (R * a.M > 64) R = 64 / a.M;
   if (sw == 2 && R > 2) R = 2;
   if (R == 3) R = 2;
+  // 16 waves per workgroup are instantiated for <= 2 weight rows per group only (a plan made for 16 waves used to fall through to the
+  // 8-wave kernel when N was large enough for R = 4, e.g. the one-row lm_head logits GEMV): such problems keep 16 waves at R = 2
+  if (nt == 1024 && R > 2) R = 2;
   const int ngroups = (a.N + R - 1) / R;
   int64_t gx = mn_cdiv(ngroups, waves_per_block);
   const int64_t cap = mn_cdiv((int64_t)cus * bpc, ka.batch);
@@ -451,13 +457,15 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   if (gx < 1) gx = 1;
   dim3 grid((unsigned)gx, (unsigned)ka.batch);
   hipStream_t st = mn_stream(stream);
+  int planned = 0;
   switch (a.M) {
-    case 1: launch_m<1>(ka, R, sw, nt, grid, lds, st); break;
-    case 2: launch_m<2>(ka, R, sw, nt, grid, lds, st); break;
-    case 3: launch_m<3>(ka, R, sw, nt, grid, lds, st); break;
-    case 4: launch_m<4>(ka, R, sw, nt, grid, lds, st); break;
-    default: launch_m<8>(ka, R, sw, nt, grid, lds, st); break;
+    case 1: planned = launch_m<1>(ka, R, sw, nt, grid, lds, st); break;
+    case 2: planned = launch_m<2>(ka, R, sw, nt, grid, lds, st); break;
+    case 3: planned = launch_m<3>(ka, R, sw, nt, grid, lds, st); break;
+    case 4: planned = launch_m<4>(ka, R, sw, nt, grid, lds, st); break;
+    default: planned = launch_m<8>(ka, R, sw, nt, grid, lds, st); break;
   }
+  MN_CHECK_ARG(planned == 0, "mn_skinny_gemm: no kernel for the plan (M=%d R=%d nt=%d)", a.M, R, nt);
   MN_CHECK_LAUNCH("mn_skinny_gemm");
   return MN_OK;
 }

@@ -27,6 +27,44 @@ def tensor_to_pil(image_tensor):
     return Image.fromarray(arr)
 
 
+# HF generate kwargs that are no-ops on this path at these values (the reference forwards **generate_kwargs to HF generate,
+# modeling_bailingmm.py:249-262): accepted silently when the value is the neutral one, TypeError otherwise.
+_NEUTRAL_GENERATE_KWARGS = {
+    "num_beams": 1, "num_beam_groups": 1, "num_return_sequences": 1, "repetition_penalty": 1.0, "length_penalty": 1.0,
+    "no_repeat_ngram_size": 0, "penalty_alpha": None, "typical_p": 1.0, "min_p": None, "min_new_tokens": 0, "min_length": 0,
+    "early_stopping": False, "output_scores": False, "output_attentions": False, "output_hidden_states": False,
+    "return_dict_in_generate": False, "synced_gpus": False, "streamer": None, "bad_words_ids": None, "logits_processor": None,
+    "stopping_criteria": None,
+}
+_IGNORED_GENERATE_KWARGS = ("pad_token_id", "bos_token_id", "use_cache", "return_tensors")   # change nothing for one unpadded sequence
+
+
+def filter_generate_kwargs(kw, default_eos, who):
+    """-> the set of end-of-sequence ids the decode loop stops at.  Raises TypeError for every kwarg that would change the result."""
+    kw = dict(kw)
+    eos = kw.pop("eos_token_id", default_eos)
+    eos_ids = set(eos) if isinstance(eos, (list, tuple, set)) else {eos}
+    for k in _IGNORED_GENERATE_KWARGS:
+        kw.pop(k, None)
+    bad = {}
+    for k, v in kw.items():
+        if k in _NEUTRAL_GENERATE_KWARGS and (v == _NEUTRAL_GENERATE_KWARGS[k] or v is None
+                                              or (k in ("logits_processor", "stopping_criteria", "bad_words_ids") and not v)):
+            continue
+        bad[k] = v
+    if bad:
+        raise TypeError(f"{who}: unsupported arguments {sorted(bad)} (supported beyond the reference's own: do_sample, temperature, "
+                        "top_k, top_p, generator, eos_token_id; HF kwargs are accepted only at values that change nothing)")
+    return eos_ids
+
+
+def check_sampling_args(do_sample, temperature, top_k, top_p, who):
+    if do_sample and not (temperature > 0 and top_k >= 0 and 0 < top_p <= 1):
+        raise ValueError(f"{who}: do_sample needs temperature > 0, top_k >= 0 and 0 < top_p <= 1")
+    if do_sample and top_k > ops.SAMPLE_CANDIDATES:
+        raise ValueError(f"{who}: top_k = {top_k} exceeds the {ops.SAMPLE_CANDIDATES} candidates the sampler ranks")
+
+
 class MingUniVisionForConditionalGeneration:
     config_class = MingUniVisionConfig
     BATCH_SEQ0 = 3      # cache sequences 0..2 hold the (up to 3) CFG rows of the multi-round conversation of generate()
@@ -96,6 +134,20 @@ class MingUniVisionForConditionalGeneration:
         self.noise_generator = torch.Generator(device=self.device)
         self.noise_generator.manual_seed(seed)
         self.reset_inner_state()
+
+    def _warn_if_sampling_truncated(self):
+        """After a host sync of a sampled decode: say so (once per call site) when a draw's kept set did not fit the sampler's
+        candidates — the only case in which the draw is not HF's warped distribution."""
+        probe = getattr(self.model, "sampling_truncated", None) or getattr(getattr(self.model, "full", None), "sampling_truncated", None)
+        bits = probe() if probe else 0
+        if bits:
+            import warnings
+            what = []
+            if bits & ops.SAMPLE_NUCLEUS_TRUNCATED:
+                what.append(f"a top-p nucleus of more than {ops.SAMPLE_CANDIDATES} tokens was cut to the {ops.SAMPLE_CANDIDATES} most likely")
+            if bits & ops.SAMPLE_TIES_TRUNCATED:
+                what.append("ties at the top-k threshold exceeded the candidate capacity (lowest ids kept)")
+            warnings.warn("sampled decode: " + "; ".join(what))
 
     # ---- state -----------------------------------------------------------------------------------
     def reset_inner_state(self):
@@ -231,8 +283,7 @@ class MingUniVisionForConditionalGeneration:
         Returns a list of B token-id lists (EOS included when reached).  `timings` (a dict, measurement only): synchronises
         after the prefills and at the end and stores `prefill_s` / `decode_s`.  `do_sample` / `temperature` / `top_k` / `top_p` /
         `generator` as in `generate`: new token i of sequence b uses uniform [i, b] of one torch.rand(max_new_tokens, B) draw."""
-        if do_sample and not (temperature > 0 and top_k >= 0 and 0 < top_p <= 1):
-            raise ValueError("generate_text_batch: do_sample needs temperature > 0, top_k >= 0 and 0 < top_p <= 1")
+        check_sampling_args(do_sample, temperature, top_k, top_p, "generate_text_batch")
         sampling = (float(temperature), int(top_k), float(top_p), generator) if do_sample else None
         try:
             return self._generate_text_batch(requests, max_new_tokens, sync_every, timings, sampling)
@@ -317,6 +368,8 @@ class MingUniVisionForConditionalGeneration:
             hidden = self.model.step(self.model.embed(tok), seq, slot, slot, ln, distinct_sequences=True)
             check(lib().mn_rows_advance(ptr(slot), ptr(ln), None, B, 1, current_stream()), "mn_rows_advance")
         out = torch.stack(toks, 1).tolist()
+        if sampling:
+            self._warn_if_sampling_truncated()
         if timings is not None:
             timings.update(prefill_s=t_prefill - t_start, decode_s=time.perf_counter() - t_prefill, steps=len(toks) - 1)
         res = []
@@ -341,13 +394,12 @@ class MingUniVisionForConditionalGeneration:
         with `do_sample=True`, drawn the way HF generate draws them — the kwargs the reference forwards to it (:249-262):
         `temperature`, `top_k` (0 = off; HF's default 50), `top_p` — on the device (mn_sample_logits), from the uniforms of
         `generator` (a torch.Generator on the model's device; None = torch's default CUDA stream).  New token i of a call uses
-        the i-th uniform, so a run is reproducible from the generator's seed.  Any other generate kwarg raises TypeError: there
-        is no silent subset of HF generate here."""
-        if generate_kwargs:
-            raise TypeError(f"generate: unsupported arguments {sorted(generate_kwargs)} (supported beyond the reference's own: "
-                            "do_sample, temperature, top_k, top_p, generator)")
-        if do_sample and not (temperature > 0 and top_k >= 0 and 0 < top_p <= 1):
-            raise ValueError("generate: do_sample needs temperature > 0, top_k >= 0 and 0 < top_p <= 1")
+        the i-th uniform, so a run is reproducible from the generator's seed.  Other HF generate kwargs: the ones that change
+        nothing on this path at the value given (`pad_token_id`, `use_cache`, `num_beams=1`, `repetition_penalty=1.0`, …) are
+        accepted, `eos_token_id` is honoured, anything that WOULD change the result raises TypeError (`filter_generate_kwargs`):
+        there is no silent subset of HF generate here."""
+        eos_ids = filter_generate_kwargs(generate_kwargs, self.config.llm_config.eos_token_id, "generate")
+        check_sampling_args(do_sample, temperature, top_k, top_p, "generate")
         cfg = self.config.llm_config
         dev = self.device
         assert input_ids.shape[0] == 1, "the reference path is batch-size 1 (modeling_bailing_moe.py:1865)"
@@ -420,9 +472,11 @@ class MingUniVisionForConditionalGeneration:
                     hidden = self.model.step(self.model.embed(tok_dev), seq0, slot, slot, ln, distinct_sequences=True)
                     check(lib().mn_rows_advance(ptr(slot), ptr(ln), None, 1, 1, current_stream()), "mn_rows_advance")
             toks = torch.cat(toks_dev).tolist()                          # the chunk's only host sync
+            if do_sample:
+                self._warn_if_sampling_truncated()
             for j, tok in enumerate(toks):
                 new_ids.append(tok)
-                if tok == cfg.eos_token_id or len(new_ids) == max_new_tokens:
+                if tok in eos_ids or len(new_ids) == max_new_tokens:
                     cache_len += j                                       # tokens 0..j-1 of the chunk were fed
                     done = True
                     break

@@ -426,15 +426,25 @@ def lmhead_argmax(hidden, w, vocab_offset=0):
     return idx, val
 
 
-def sample_logits(logits, u, temperature=1.0, top_k=0, top_p=1.0, vocab_offset=0):
+SAMPLE_CANDIDATES = 2048                   # candidates mn_sample_logits ranks (top_k above this is refused)
+SAMPLE_NUCLEUS_TRUNCATED, SAMPLE_TIES_TRUNCATED = 1, 2
+
+
+def sample_logits(logits, u, temperature=1.0, top_k=0, top_p=1.0, vocab_offset=0, status=None):
     """Sampled pick of every row (mn_sample_logits: HF's temperature -> top-k -> top-p warpers, then the inverse CDF of the kept
-    tokens — descending score, ties by ascending id — at u[m] in [0, 1)).  logits fp32 [M, V], u fp32 [M] -> int64 [M]."""
+    tokens — descending score, ties by ascending id — at u[m] in [0, 1)).  logits fp32 [M, V], u fp32 [M] -> int64 [M].
+    status: optional int32 [M] device tensor that receives SAMPLE_* bits for rows whose kept set was cut at 2048 candidates."""
     _req(logits, torch.float32, "logits"); _req(u, torch.float32, "u")
     M, V = logits.shape
     assert logits.stride(1) == 1 and u.numel() == M and u.is_contiguous()
+    if top_k > SAMPLE_CANDIDATES:
+        raise ValueError(f"top_k = {top_k}: the sampler ranks at most {SAMPLE_CANDIDATES} candidates")
+    if status is not None:
+        _req(status, torch.int32, "status")
+        assert status.numel() == M and status.is_contiguous()
     idx = torch.empty(M, dtype=torch.int64, device=logits.device)
     check(lib().mn_sample_logits(ptr(logits), logits.stride(0), M, V, float(temperature), int(top_k), float(top_p), ptr(u), vocab_offset,
-                                 ptr(idx), current_stream()), "mn_sample_logits")
+                                 ptr(idx), ptr(status) if status is not None else None, current_stream()), "mn_sample_logits")
     return idx
 
 

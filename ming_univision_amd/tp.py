@@ -562,7 +562,8 @@ class TpSimGroup(_TpDecoderBase):
     def rf_max_rows(self):
         return self._row_cap()
 
-    def sample(self, hidden, noise, temperature=1.0, text_cfg=3.0, image_cfg=1.1, out=None, n_images=1):
+    def rf_sample(self, hidden, noise, temperature=1.0, text_cfg=3.0, image_cfg=1.1, out=None, n_images=1):
+        """RectifiedFlowLoss.sample through the group (the TOKEN sampler above keeps the decoder interface's name `sample`)."""
         outs = [out if r == 0 and out is not None else torch.empty(noise.shape, dtype=torch.float32, device=hidden.device)
                 for r in range(self.world)]
         for seg in range(self.rf_shards[0].n_segments()):
@@ -589,7 +590,7 @@ class _SamplerView:
         return self._g.rf_max_rows()
 
     def sample(self, *a, **kw):
-        return self._g.sample(*a, **kw)
+        return self._g.rf_sample(*a, **kw)
 
 
 class TpRank(_TpDecoderBase):
@@ -671,7 +672,7 @@ class TpRank(_TpDecoderBase):
     def rf_max_rows(self):
         return self._row_cap()
 
-    def sample(self, hidden, noise, temperature=1.0, text_cfg=3.0, image_cfg=1.1, out=None, n_images=1):
+    def rf_sample(self, hidden, noise, temperature=1.0, text_cfg=3.0, image_cfg=1.1, out=None, n_images=1):
         if out is None:
             out = torch.empty(noise.shape, dtype=torch.float32, device=hidden.device)
 

@@ -150,9 +150,12 @@ def expert_mlp(x, sd, prefix):
     return F.linear(F.silu(g) * u, sd[prefix + ".down_proj.weight"])
 
 
-def moe_block(x, sd, prefix, cfg, image_mask=None):
+def moe_block(x, sd, prefix, cfg, image_mask=None, grouped=None):
     """BailingMoeSparseMoeBlock.forward (:556-606) + moe_infer (:608-639).
-    image_mask: bool [B,T] or None.  Rows flagged take the image_gate's routing."""
+    image_mask: bool [B,T] or None.  Rows flagged take the image_gate's routing.
+    grouped (default: above 64 rows): the reference's own order of work — moe_infer sorts the (row, slot) pairs by expert and runs
+    every expert once on all its rows (:613-631) — instead of the row-by-row restatement; the weighted sum over a row's slots
+    keeps the top-k order either way (:633-638).  tests/test_oracle_golden.py holds the two forms to each other."""
     B, T, H = x.shape
     x2 = x.reshape(-1, H)
     ti, tw, _ = gate(x2, sd[prefix + ".gate.weight"], cfg)
@@ -161,13 +164,23 @@ def moe_block(x, sd, prefix, cfg, image_mask=None):
         m = image_mask.reshape(-1, 1)
         ti = torch.where(m, ii, ti)
         tw = torch.where(m, iw, tw)
+    if grouped is None:
+        grouped = x2.shape[0] > 64
     y = torch.zeros_like(x2)
-    for r in range(x2.shape[0]):
-        acc = torch.zeros(H)
+    if grouped:
+        per_slot = torch.zeros(x2.shape[0], cfg.num_experts_per_tok, H)
+        for e in ti.unique().tolist():
+            r, kk = (ti == e).nonzero(as_tuple=True)
+            per_slot[r, kk] = expert_mlp(x2[r], sd, f"{prefix}.experts.{e}")
         for kk in range(cfg.num_experts_per_tok):
-            e = int(ti[r, kk])
-            acc = acc + tw[r, kk] * expert_mlp(x2[r:r + 1], sd, f"{prefix}.experts.{e}")[0]
-        y[r] = acc
+            y = y + tw[:, kk:kk + 1] * per_slot[:, kk]
+    else:
+        for r in range(x2.shape[0]):
+            acc = torch.zeros(H)
+            for kk in range(cfg.num_experts_per_tok):
+                e = int(ti[r, kk])
+                acc = acc + tw[r, kk] * expert_mlp(x2[r:r + 1], sd, f"{prefix}.experts.{e}")[0]
+            y[r] = acc
     if cfg.num_shared_experts:
         y = y + expert_mlp(x2, sd, prefix + ".shared_experts")
     return y.view(B, T, H), (ti, tw)

@@ -21,22 +21,27 @@ holds the draws to the warped distribution.
 """
 import numpy as np
 
-CANDIDATE_CAP = 2048      # mn_sample_logits: top_k is capped here; top_k = 0 with top_p < 1 uses the 2048 largest scores
+CANDIDATE_CAP = 2048      # mn_sample_logits ranks at most this many candidates
 
 
 def warped_distribution(logits, temperature=1.0, top_k=0, top_p=1.0, cap=None):
     """One row of logits -> (ids ranked by descending score / ascending id, their probabilities), after HF's warpers.
-    `cap` (None for the plain HF semantics) restates the kernel's candidate capacity."""
+    `cap` (None for the plain HF semantics) restates the kernel's candidate capacity: top_k above it is refused; a kept set larger
+    than it (a top-p nucleus of more than `cap` tokens without top-k, or ties at the k-th score) is cut to the first `cap` tokens of
+    the ranking — the rows the kernel reports through its status word; `truncated(…)` below tells which."""
     x = np.asarray(logits, dtype=np.float64) / float(temperature)
     V = x.shape[0]
     keep = np.ones(V, dtype=bool)
     k = int(top_k)
-    if cap is not None and (k > cap or (k <= 0 and top_p < 1.0)):
-        k = cap
+    if cap is not None and k > cap:
+        raise ValueError(f"top_k = {k} exceeds the {cap} candidates the kernel ranks")
     if k > 0:
         k = min(k, V)
         kth = np.sort(x)[V - k]
         keep &= x >= kth                                     # `scores < topk[-1]` is removed: ties with the k-th stay
+        if cap is not None and keep.sum() > cap:              # more ties than candidates: the lowest ids among the ties stay
+            ties = np.flatnonzero(keep & (x == kth))
+            keep[ties[cap - int((x > kth).sum()):]] = False
     if top_p < 1.0:
         ids = np.flatnonzero(keep)
         order = ids[np.lexsort((-ids, x[ids]))]              # ascending score (ties: descending id = reverse of the ranking)
@@ -48,8 +53,24 @@ def warped_distribution(logits, temperature=1.0, top_k=0, top_p=1.0, cap=None):
         keep[order[remove]] = False
     ids = np.flatnonzero(keep)
     ranked = ids[np.lexsort((ids, -x[ids]))]                 # descending score, ties by ascending id
+    if cap is not None and len(ranked) > cap:
+        ranked = ranked[:cap]
     p = np.exp(x[ranked] - x[ranked].max())
     return ranked, p / p.sum()
+
+
+def truncated(logits, temperature=1.0, top_k=0, top_p=1.0, cap=CANDIDATE_CAP):
+    """The status word mn_sample_logits reports for this row: 1 = the nucleus holds more than `cap` tokens (top_k = 0), 2 = more
+    ties at the k-th score than candidates."""
+    x = np.asarray(logits, dtype=np.float64) / float(temperature)
+    bits = 0
+    if top_k <= 0 and top_p < 1.0 and len(warped_distribution(logits, temperature, 0, top_p, None)[0]) > cap:
+        bits |= 1
+    if top_k > 0:
+        kth = np.sort(x)[x.shape[0] - min(int(top_k), x.shape[0])]
+        if int((x >= kth).sum()) > cap:
+            bits |= 2
+    return bits
 
 
 def top_p_margin(logits, temperature=1.0, top_k=0, top_p=1.0, cap=None):
@@ -57,7 +78,7 @@ def top_p_margin(logits, temperature=1.0, top_k=0, top_p=1.0, cap=None):
     token more or less in fp32 than in fp64; tests skip such rows).  inf when top-p is off."""
     if top_p >= 1.0:
         return np.inf
-    _, p = warped_distribution(logits, temperature, top_k if top_k > 0 else (cap or 0), 1.0, cap)
+    _, p = warped_distribution(logits, temperature, top_k, 1.0, None)
     above = np.concatenate(([0.0], np.cumsum(p)[:-1]))       # mass ranked above each token
     return float(np.min(np.abs(above[1:] - top_p))) if len(p) > 1 else np.inf
 

@@ -41,7 +41,7 @@ def _check_row(x, us, got, temperature, top_k, top_p):
 
 
 @pytest.mark.parametrize("temperature,top_k,top_p", [(1.0, 50, 1.0), (0.7, 50, 0.9), (1.3, 0, 0.8), (1.0, 1, 1.0), (0.6, 0, 1.0),
-                                                     (1.0, 5, 0.3), (2.0, 200, 0.95), (1.0, 2048, 1.0), (1.0, 5000, 0.999), (1.5, 0, 0.999)])
+                                                     (1.0, 5, 0.3), (2.0, 200, 0.95), (1.0, 2048, 1.0), (1.0, 2048, 0.999), (1.5, 0, 0.999)])
 def test_sample_logits_vs_oracle_draw_by_draw(temperature, top_k, top_p):
     from ming_univision_amd import ops
     rng = np.random.default_rng(17)
@@ -107,6 +107,48 @@ def test_draws_follow_the_warped_distribution(temperature, top_k, top_p):
     chi2 = float((((counts - p * N) ** 2)[keep] / (p * N)[keep]).sum())
     dof = int(keep.sum()) - 1
     assert chi2 < dof + 5 * np.sqrt(2 * dof) + 10, (chi2, dof)
+
+
+def test_sample_logits_candidate_capacity_status_and_full_vocabulary_nucleus():
+    """(1) top-p without top-k cuts at top_p of the FULL vocabulary's mass — a peaked row whose tail beyond rank 2048 holds
+    16 % of the mass keeps HF's nucleus, which the 2048-candidate normalisation would have shrunk; (2) top_k above the capacity is an
+    error on both sides of the C ABI; (3) a nucleus / tie set that does not fit is cut deterministically (lowest ids among ties) and
+    reported through the status word."""
+    from ming_univision_amd import _lib, ops
+    rng = np.random.default_rng(3)
+    cap = sample_ref.CANDIDATE_CAP
+    y = np.concatenate([np.array([13.0, 12.5, 12.0], np.float32), rng.standard_normal(120000).astype(np.float32)])
+    e = np.exp(y.astype(np.float64) - 13.0)
+    top_p = float(0.5 * (e[0] / e.sum() + e[0] / np.sort(e)[-cap:].sum()))
+    M = 32
+    us = rng.random(M).astype(np.float32)
+    st = torch.full((M,), -1, dtype=torch.int32, device="cuda")
+    got = ops.sample_logits(torch.from_numpy(y).cuda().repeat(M, 1).contiguous(), torch.from_numpy(us).cuda(), 1.0, 0, top_p, status=st).cpu().numpy()
+    assert st.tolist() == [0] * M
+    assert set(got.tolist()) == {0, 1}                                     # token 1 is in HF's nucleus (mass above it < top_p of the full mass)
+    _check_row(y, us, got, 1.0, 0, top_p)
+    # near-uniform row, top_p ~ 1: the nucleus wants ~ all 6000 tokens -> the 2048 best, flagged
+    x = rng.standard_normal(6000).astype(np.float32)
+    st.fill_(-1)
+    got = ops.sample_logits(torch.from_numpy(x).cuda().repeat(M, 1).contiguous(), torch.from_numpy(us).cuda(), 1.0, 0, 0.999999, status=st).cpu().numpy()
+    assert st.tolist() == [ops.SAMPLE_NUCLEUS_TRUNCATED] * M == [sample_ref.truncated(x, 1.0, 0, 0.999999)] * M
+    _check_row(x, us, got, 1.0, 0, 0.999999)
+    # 3000 ties at the 10th score: 9 better tokens + the 2039 lowest tied ids, whatever order the atomics arrive in
+    z = np.full(4000, 1.0, np.float32)
+    z[100:109] = 5.0
+    z[3500:] = 0.0
+    st.fill_(-1)
+    got = ops.sample_logits(torch.from_numpy(z).cuda().repeat(M, 1).contiguous(), torch.from_numpy(us).cuda(), 1.0, 10, 1.0, status=st).cpu().numpy()
+    assert st.tolist() == [ops.SAMPLE_TIES_TRUNCATED] * M == [sample_ref.truncated(z, 1.0, 10, 1.0)] * M
+    _check_row(z, us, got, 1.0, 10, 1.0)
+    again = ops.sample_logits(torch.from_numpy(z).cuda().repeat(M, 1).contiguous(), torch.from_numpy(us).cuda(), 1.0, 10, 1.0).cpu().numpy()
+    assert np.array_equal(got, again)
+    with pytest.raises(ValueError):
+        ops.sample_logits(torch.zeros(1, 6000, device="cuda"), torch.zeros(1, device="cuda"), 1.0, cap + 1, 1.0)
+    idx = torch.empty(1, dtype=torch.int64, device="cuda")
+    lg, u1 = torch.zeros(1, 6000, device="cuda"), torch.zeros(1, device="cuda")
+    rc = _lib.lib().mn_sample_logits(_lib.ptr(lg), 6000, 1, 6000, 1.0, cap + 1, 1.0, _lib.ptr(u1), 0, _lib.ptr(idx), None, None)
+    assert rc != 0 and b"top_k" in _lib.lib().mn_last_error()
 
 
 def test_generate_do_sample_vs_oracle_model(tmp_path):

@@ -207,6 +207,48 @@ def test_tp_llm_step_tiny_matches_unsharded_and_reference(world):
     grp.check_err()
 
 
+def test_tp_group_token_sampling_and_rf_sampling_are_two_methods(tmp_path):
+    """TpSimGroup / TpRank defined `sample` twice, so the TOKEN sampler (hidden, uniforms, temperature, top_k,
+    top_p) was shadowed by the RF sampler and `generate(do_sample=True)` on a TP decoder ran the RF head on the uniforms.  The RF
+    sampler is `rf_sample` now (reached through `sampler()`); a sampled decode through a TP = 2 group behind the façade draws the
+    same tokens as the unsharded model at the same generator seed, and the group's `sample` IS the unsharded token sampler."""
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder
+    from ming_univision_amd.mingtok import MingTok
+    from ming_univision_amd.modeling import MingUniVisionForConditionalGeneration
+    from ming_univision_amd.rf_head import RectifiedFlowHead
+    from ming_univision_amd.tp import TpRank, TpSimGroup
+    g = load_golden("genimg_tiny")
+    llm_cfg = dict(g["llm_config"]); llm_cfg["eos_token_id"] = 1
+    cfg = C.BailingMoeConfig(**llm_cfg)
+    mcfg = C.MingUniVisionConfig(mlp_depth=2, llm_config=llm_cfg, vishead_diffloss_config=g["rf_config"], mingtok_config=g["mingtok_config"])
+    dsd = _dev(llm_sd(g["llm_config"], g["rf_config"], g["seed"]))
+    dl = _dev(synth_state_dict(C.linear_proj_param_shapes(128, 256, 2), g["seed"]))
+    lp = [(dl["linear_proj.0.weight"], dl["linear_proj.0.bias"]), (dl["linear_proj.2.weight"], dl["linear_proj.2.bias"])]
+    tok = MingTok(C.MingTokConfig(**g["mingtok_config"]), state_dict=mingtok_sd(g["mingtok_config"], g["seed"]), linear_proj=lp)
+    rf = RectifiedFlowHead(dsd, cfg.hidden_size, g["rf_config"])
+    dec = BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=64, n_seq=3)
+    grp = TpSimGroup(BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=64, n_seq=3), rf, 2, rows_cap=64)
+    for klass in (TpSimGroup, TpRank):
+        assert klass.sample.__code__.co_varnames[:3] == ("self", "hidden", "u") and hasattr(klass, "rf_sample")
+    hidden = torch.randn(3, cfg.hidden_size, generator=torch.Generator().manual_seed(1)).cuda()
+    u = torch.tensor([0.11, 0.52, 0.93], device="cuda")
+    assert grp.sample(hidden, u, 0.8, 20, 0.9).tolist() == dec.sample(hidden, u, 0.8, 20, 0.9).tolist()
+    single = MingUniVisionForConditionalGeneration.from_parts(mcfg, tok, dec, rf, lp, seed=g["seed"])
+    shard = MingUniVisionForConditionalGeneration.from_parts(mcfg, tok, grp, grp.sampler(), lp, seed=g["seed"])
+    ids = g["ids"]
+    T = ids.shape[1]
+    for temperature, top_k, top_p, seed in ((1.0, 50, 1.0, 1), (0.7, 10, 0.9, 2), (1.3, 0, 0.8, 3)):
+        outs = []
+        for model in (single, shard):
+            model.reset_inner_state()
+            gen = torch.Generator(device="cuda").manual_seed(seed)
+            outs.append(model.generate(input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=6, do_sample=True,
+                                       temperature=temperature, top_k=top_k, top_p=top_p, generator=gen,
+                                       output_image_prefix=str(tmp_path / "s"))[0, T:].tolist())
+        assert outs[0] == outs[1], (temperature, top_k, top_p, outs)
+    grp.check_err()
+
+
 def test_tp_wide_rows_match_unsharded():
     """Above 64 rows the TP composites run on gemm256 (the wide route's kernels) instead of the weight-streaming ones: 70 rows of
     the tiny decoder (ragged cache lengths, holey masks, image-gate rows) on 2 ranks, and 66 rows of a small RF head on 4 ranks,

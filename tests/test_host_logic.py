@@ -450,3 +450,48 @@ def test_sampling_arguments_are_validated_on_the_host():
         assert sig.parameters[k].default == d               # HF's defaults (mingunivision/config.json:30,103-109)
     sig = inspect.signature(M.generate_text_batch)
     assert sig.parameters["do_sample"].default is False and sig.parameters["top_k"].default == 50
+    # HF kwargs the reference would forward (modeling_bailingmm.py:249-262): neutral values pass, result-changing ones raise
+    from ming_univision_amd.modeling import check_sampling_args, filter_generate_kwargs
+    assert filter_generate_kwargs({}, 7, "t") == {7}
+    assert filter_generate_kwargs(dict(pad_token_id=0, use_cache=True, num_beams=1, repetition_penalty=1.0, eos_token_id=[3, 9]), 7, "t") == {3, 9}
+    assert filter_generate_kwargs(dict(logits_processor=[], streamer=None), 7, "t") == {7}
+    for bad in (dict(num_beams=4), dict(repetition_penalty=1.2), dict(min_new_tokens=5), dict(frobnicate=1), dict(return_dict_in_generate=True)):
+        with pytest.raises(TypeError):
+            filter_generate_kwargs(bad, 7, "t")
+    check_sampling_args(True, 0.7, 2048, 0.9, "t")
+    check_sampling_args(False, 0.0, 5000, 2.0, "t")            # greedy: the sampling values are not looked at
+    for bad in ((0.0, 50, 1.0), (1.0, -1, 1.0), (1.0, 50, 0.0), (1.0, 50, 1.5), (1.0, 2049, 1.0)):
+        with pytest.raises(ValueError):
+            check_sampling_args(True, *bad, "t")
+
+
+def test_ctypes_structures_match_the_library_layout():
+    """`_lib.py`'s ctypes Structures against the C structs of the built library — sizeof through mn_sizeof_*, every
+    field offset through mn_struct_layout (no GPU needed) — and the guard itself: a Structure with one more field must be refused."""
+    from ming_univision_amd import _lib
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    _lib.check_struct_layouts(handle)
+    for sid, sizer, klass in _lib.STRUCTS:
+        fn = getattr(handle, sizer)
+        fn.restype = ctypes.c_size_t
+        assert fn() == ctypes.sizeof(klass) and fn() % 8 == 0, (sizer, fn(), ctypes.sizeof(klass))
+    handle.mn_struct_layout.restype = ctypes.c_int
+    handle.mn_struct_layout.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.c_int]
+    assert handle.mn_struct_layout(99, (ctypes.c_size_t * 4)(), 4) < 0
+
+    class Grown(ctypes.Structure):                     # a binding that added a field the library does not know
+        _fields_ = list(_lib.TpComm._fields_) + [("extra", ctypes.c_int64)]
+    real = _lib.STRUCTS
+    try:
+        _lib.STRUCTS = ((4, "mn_sizeof_tp_comm", Grown),)
+        with pytest.raises(RuntimeError):
+            _lib.check_struct_layouts(handle)
+
+        class Swapped(ctypes.Structure):               # same size, two fields in the other order
+            _fields_ = [("world", ctypes.c_int32), ("rank", ctypes.c_int32)] + list(_lib.TpComm._fields_[2:5]) + \
+                       [("epoch", ctypes.c_uint32), ("rows_cap", ctypes.c_int32)] + list(_lib.TpComm._fields_[7:])
+        assert ctypes.sizeof(Swapped) == ctypes.sizeof(_lib.TpComm)
+        _lib.STRUCTS = ((4, "mn_sizeof_tp_comm", Swapped),)
+        _lib.check_struct_layouts(handle)              # offsets equal: field NAMES are not part of a C layout ...
+    finally:
+        _lib.STRUCTS = real

@@ -101,6 +101,9 @@ def test_llm_pieces(llm):
     y, (idx, _) = bailing_ref.moe_block(g["moe_in"], sd, "model.layers.0.mlp", cfg, g["moe_image_mask"].bool())
     assert torch.equal(idx, g["moe_topk_idx"])
     assert rel_err(y, g["moe_out"]) < TOL
+    # the expert-sorted form the oracle switches to above 64 rows (moe_infer's own order of work) against the same golden output
+    yg, (idxg, _) = bailing_ref.moe_block(g["moe_in"], sd, "model.layers.0.mlp", cfg, g["moe_image_mask"].bool(), grouped=True)
+    assert torch.equal(idxg, idx) and rel_err(yg, g["moe_out"]) < TOL and rel_err(yg, y) < 2e-6
 
 
 def test_llm_prefill_and_cfg_decode(llm):
@@ -167,3 +170,51 @@ def test_rope3d_matches_reference():
     cl, sl = bailing_ref.rope_cos_sin(128, g["base"], 64)
     ql, kl = bailing_ref.apply_rope(g["q"], g["k"], cl, sl, g["pos3"][0])
     assert rel_err(qs, g["q_same"]) < 1e-6 and rel_err(ql, g["q_same"]) < 1e-6 and rel_err(kl, g["k_same"]) < 1e-6
+
+
+def test_streamed_oracle_and_decoder_backed_state_dict(llm):
+    """Test infrastructure of tests/test_gpu_fullsize.py, checked on the CPU at the tiny golden configuration: the state-dict view
+    over a decoder's packed tensors returns every per-layer reference parameter (inverse of pack_experts), and the layer-outermost
+    oracle walk over rows grouped by cache length equals `model_forward` row by row."""
+    from types import SimpleNamespace
+    from ming_univision_amd import configuration as C
+    from ming_univision_amd.bailing_moe import pack_experts
+    from tests.test_gpu_fullsize import _oracle_step_streamed
+    from tests.util import DecoderBackedSD
+    g, sd, cfg = llm
+    pcfg = C.BailingMoeConfig(**g["config"])
+    bsd = {k: v.to(torch.bfloat16) for k, v in sd.items()}
+    layers = []
+    for li in range(pcfg.num_hidden_layers):
+        p = f"model.layers.{li}"
+        gu, dn = pack_experts(bsd, p + ".mlp", pcfg)
+        layers.append(dict(ln1=bsd[p + ".input_layernorm.weight"], wqkv=bsd[p + ".attention.query_key_value.weight"],
+                           wdense=bsd[p + ".attention.dense.weight"], ln2=bsd[p + ".post_attention_layernorm.weight"],
+                           gate=bsd[p + ".mlp.gate.weight"], image_gate=bsd.get(p + ".mlp.image_gate.weight"), w_gate_up=gu, w_down=dn))
+    fake = SimpleNamespace(layers=layers, cfg=pcfg, n_shared=pcfg.num_shared_experts or 0, final_norm=bsd["model.norm.weight"],
+                           word_embeddings=None, lm_head=None)
+    view = DecoderBackedSD(fake)
+    names = [k for k in sd if k.startswith("model.layers.") and "audio_gate" not in k]     # the audio gate is not on the path
+    assert len(names) > 20
+    for k in names:
+        assert torch.equal(view[k], sd[k]), k                      # synthetic weights are bf16-rounded: the round trip is exact
+    assert view.get("model.layers.0.attention.query_key_value.bias") is None
+    gen = torch.Generator().manual_seed(5)
+    M, t_max = 7, 12
+    L, nkv, hd, H = cfg.num_hidden_layers, cfg.num_key_value_heads, cfg.head_dim, cfg.hidden_size
+    lens = torch.tensor([3, 5, 3, 8, 5, 3, 8])
+    kv = torch.randn(L, M, 2, nkv, t_max, hd, generator=gen) * 0.5
+    x = torch.randn(M, H, generator=gen) * 0.5
+    km = torch.ones(M, t_max, dtype=torch.uint8)
+    km[0, 1:2] = 0
+    km[3, 1:6] = 0
+    pos = torch.stack([(km[m, :int(lens[m]) + 1].long().cumsum(0) - 1)[-1] for m in range(M)])
+    ref, margin, nk, nv = _oracle_step_streamed(view, cfg, x, lens, km, pos, kv)
+    assert margin.shape == (M,) and bool((margin >= 0).all())
+    for m in range(M):
+        n = int(lens[m])
+        kvs = [dict(k=kv[l, m:m + 1, 0, :, :n].clone(), v=kv[l, m:m + 1, 1, :, :n].clone()) for l in range(L)]
+        h = bailing_ref.model_forward(x[m:m + 1, None], sd, cfg, km[m:m + 1, :n + 1].long(), pos[m:m + 1, None], kvs)
+        assert rel_err(ref[m], h[0, 0]) < 2e-6
+        assert rel_err(nk[:, m], torch.stack([kvs[l]["k"][0, :, n] for l in range(L)])) < 2e-6
+        assert rel_err(nv[:, m], torch.stack([kvs[l]["v"][0, :, n] for l in range(L)])) < 2e-6

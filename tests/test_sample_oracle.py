@@ -63,9 +63,30 @@ def test_sample_token_inverse_cdf():
 
 
 def test_candidate_cap_restates_the_kernel():
+    """What the kernel's 2048-candidate capacity changes, and only then: a nucleus that fits is HF's nucleus exactly — its
+    limit is top_p of the FULL vocabulary's mass, not of the 2048 best —; a larger one is cut and flagged; top_k above the capacity is
+    refused; ties that overflow keep the lowest ids."""
     rng = np.random.default_rng(1)
+    cap = sample_ref.CANDIDATE_CAP
     x = rng.standard_normal(6000).astype(np.float32)
-    ranked, _ = sample_ref.warped_distribution(x, 1.0, 0, 0.999999, cap=sample_ref.CANDIDATE_CAP)
-    assert len(ranked) <= sample_ref.CANDIDATE_CAP
-    ranked, _ = sample_ref.warped_distribution(x, 1.0, 5000, 1.0, cap=sample_ref.CANDIDATE_CAP)
-    assert len(ranked) == sample_ref.CANDIDATE_CAP
+    ranked, _ = sample_ref.warped_distribution(x, 1.0, 0, 0.999999, cap=cap)            # near-uniform: the nucleus wants ~all 6000
+    assert len(ranked) == cap and sample_ref.truncated(x, 1.0, 0, 0.999999) == 1
+    # a peaked row with a long tail: HF's nucleus is small although the tail beyond rank 2048 holds real mass
+    y = np.concatenate([np.array([13.0, 12.5, 12.0], np.float32), rng.standard_normal(120000).astype(np.float32)])
+    e = np.exp(y.astype(np.float64) - 13.0)
+    z_full, z_cap = e.sum(), np.sort(e)[-cap:].sum()
+    assert 1.0 - z_cap / z_full > 0.1                                                     # the mass the old Z_2048 limit ignored
+    top_p = 0.5 * (e[0] / z_full + e[0] / z_cap)            # between the mass above token 1 under the two normalisations
+    hf, p_hf = sample_ref.warped_distribution(y, 1.0, 0, top_p, cap=None)
+    got, p_got = sample_ref.warped_distribution(y, 1.0, 0, top_p, cap=cap)
+    assert hf.tolist() == [0, 1] and np.array_equal(hf, got) and np.allclose(p_hf, p_got) and sample_ref.truncated(y, 1.0, 0, top_p) == 0
+    assert e[0] / z_cap >= top_p                            # ... the 2048-candidate normalisation would have dropped token 1
+    with pytest.raises(ValueError):
+        sample_ref.warped_distribution(x, 1.0, 5000, 1.0, cap=cap)
+    # 3000 ties at the 10th score: the 9 better tokens + the 2039 lowest tied ids
+    z = np.full(4000, 1.0, np.float32)
+    z[100:109] = 5.0
+    z[3500:] = 0.0
+    ranked, _ = sample_ref.warped_distribution(z, 1.0, 10, 1.0, cap=cap)
+    assert len(ranked) == cap and sample_ref.truncated(z, 1.0, 10, 1.0) == 2
+    assert ranked[:9].tolist() == list(range(100, 109)) and ranked[9:].tolist() == [i for i in range(4000) if z[i] == 1.0][:cap - 9]

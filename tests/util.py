@@ -42,6 +42,67 @@ def rel_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+def row_errs(a, b):
+    """Per-row relative error: max|a_r - b_r| / max|b_r| over the last dimension's rows (every leading index is a row).  What
+    `rel_err`'s global max-norm cannot see: a small-magnitude row that is far off."""
+    a, b = a.double().cpu(), b.double().cpu()
+    a, b = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
+    return (a - b).abs().amax(1) / (b.abs().amax(1) + 1e-30)
+
+
+def rel_err_rows(a, b):
+    """The worst row of `row_errs`."""
+    return float(row_errs(a, b).max())
+
+
+class DecoderBackedSD(dict):
+    """The oracle's view of a BailingMoeDecoder that lives on the GPU: a state dict under the reference's parameter names
+    (`model.layers.{i}.…`, modeling_bailing_moe.py) whose per-layer entries are pulled from the decoder's packed bf16 device tensors
+    on first use (the inverse of `pack_experts`) as fp32 CPU tensors and dropped when another layer is asked for — the 16B-A3B stack
+    is 32 GB of bf16, the oracle walks it layer by layer.  Entries stored with `__setitem__` (RF head, vis_head, final norm) stay.
+    Test infrastructure."""
+
+    def __init__(self, dec, extra=None):
+        super().__init__()
+        self.dec, self._layer, self._held = dec, None, {}
+        self["model.norm.weight"] = dec.final_norm.float().cpu()
+        if dec.word_embeddings is not None:
+            self["model.word_embeddings.weight"] = dec.word_embeddings.float().cpu()
+        if dec.lm_head is not None:
+            self["lm_head.weight"] = dec.lm_head.float().cpu()
+        for k, v in (extra or {}).items():
+            self[k] = v
+
+    def __missing__(self, name):
+        parts = name.split(".")
+        assert parts[0] == "model" and parts[1] == "layers", name
+        li = int(parts[2])
+        if li != self._layer:
+            self._layer, self._held = li, {}
+        if name not in self._held:
+            self._held[name] = self._pull(li, ".".join(parts[3:])).cpu().float()
+        return self._held[name]
+
+    def _pull(self, li, tail):
+        ly, cfg = self.dec.layers[li], self.dec.cfg
+        E, S, I = cfg.num_experts, self.dec.n_shared, cfg.moe_intermediate_size
+        plain = {"input_layernorm.weight": "ln1", "attention.query_key_value.weight": "wqkv", "attention.dense.weight": "wdense",
+                 "post_attention_layernorm.weight": "ln2", "mlp.gate.weight": "gate", "mlp.image_gate.weight": "image_gate"}
+        if tail in plain:
+            return ly[plain[tail]]
+        gu, dn = ly["w_gate_up"], ly["w_down"]
+        assert gu.dtype == torch.bfloat16, "bf16 decoders only (8-bit ones: dequantized_state_dict)"
+        t = tail.split(".")
+        if t[1] == "experts":
+            e, which = int(t[2]), t[3]
+            return {"gate_proj": gu[e, :I], "up_proj": gu[e, I:], "down_proj": dn[e]}[which]
+        assert t[1] == "shared_experts", tail
+        which = t[2]
+        if which == "down_proj":
+            return torch.cat([dn[E + s] for s in range(S)], 1)
+        return torch.cat([gu[E + s, :I] if which == "gate_proj" else gu[E + s, I:] for s in range(S)], 0)
+
+
 class OracleConversation:
     """The reference's multi-round flow (MingUniVisionForConditionalGeneration.generate, modeling_bailingmm.py:206-301, over
     BailingMoeForCausalLM.forward's `<image>` branch, modeling_bailing_moe.py:1769-1796) driven with the oracle's pieces: one KV
