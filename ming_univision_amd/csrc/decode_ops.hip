@@ -17,6 +17,13 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // MoE router = gate logits (skinny GEMV with a fused RMSNorm prologue, all CUs) + this kernel:
 // one 256-thread block per row writes the normalised row (input of the experts) and wave 0 does
 // the fp32 softmax + iterative arg-max top-k + renormalisation.
+//
+// TIE RULE (every router of this library: this kernel, moe_router_row_kernel below, moe_route_group_kernel in engine.hip,
+// moe_topk_logits_kernel in prefill_ops.hip and the wide route's top-k in wide_llm.inl): expert e lives in lane e; a round takes the
+// wave maximum and `__ffsll(__ballot(cur == best))`, i.e. among EQUAL scores the LOWEST expert id wins, and the picked slots are in
+// descending score / ascending id order.  The reference calls `torch.topk` (modeling_bailing_moe.py:512), whose order among equal
+// values is unspecified; exact ties need two identical gate rows (fp32 scores of real weights tie with probability zero).
+// Pinned by tests/test_gpu_router_ties.py.
 // -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void moe_topk_kernel(
     const float* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ norm_w, float eps,

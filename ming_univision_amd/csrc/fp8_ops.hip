@@ -6,6 +6,7 @@
 // e4m3(q) * scale exactly representable in bf16 — the dequantised model is a bf16 model, runnable through every bf16 route and
 // through the fp32 oracle with bit-identical weights.
 #include "common.h"
+#include "w8_codec.h"
 
 namespace {
 
@@ -103,6 +104,49 @@ __global__ __launch_bounds__(256) void dequant_int8_rows_kernel(const uint8_t* _
   }
 }
 
+
+// ---- NF4 (MN_W_NF4): bitsandbytes' blockwise 4-bit NormalFloat (oracle/int4_ref.py; mingunivisioninfer.py:46-58).  One thread owns
+// eight consecutive k (one dword of codes), eight threads one 64-element block: absmax by three xor-shuffles, x = w * (1 / absmax) in fp32,
+// code = number of the 15 midpoints below x (dQuantizeNF4's comparison tree: a value ON a midpoint takes the lower entry).
+__global__ __launch_bounds__(256) void quant_nf4_rows_kernel(const bf16_t* __restrict__ W, int64_t ldw, uint8_t* __restrict__ Q, int64_t ldq,
+                                                             float* __restrict__ absmax, int K) {
+  constexpr float T[16] = MN_NF4_TABLE;
+  const int64_t n = blockIdx.x;
+  const bf16_t* wr = W + n * ldw;
+  for (int k = threadIdx.x * 8; k < K; k += 2048) {      // K % 64 == 0: the eight lanes of a block are in or out together
+    const mn_u4_t v = *reinterpret_cast<const mn_u4_t*>(wr + k);
+    const float w[8] = {bf16lo_to_f32(v.x), bf16hi_to_f32(v.x), bf16lo_to_f32(v.y), bf16hi_to_f32(v.y),
+                        bf16lo_to_f32(v.z), bf16hi_to_f32(v.z), bf16lo_to_f32(v.w), bf16hi_to_f32(v.w)};
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a = fmaxf(a, fabsf(w[i]));
+    a = fmaxf(a, __shfl_xor(a, 1, 64));
+    a = fmaxf(a, __shfl_xor(a, 2, 64));
+    a = fmaxf(a, __shfl_xor(a, 4, 64));
+    const float inv = a == 0.f ? 0.f : 1.0f / a;
+    if ((threadIdx.x & 7) == 0) absmax[n * (K >> 6) + (k >> 6)] = a;
+    uint32_t q = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float x = w[i] * inv;
+      uint32_t c = 0;
+#pragma unroll
+      for (int j = 0; j < 15; ++j) c += x > (float)(((double)T[j] + (double)T[j + 1]) * 0.5) ? 1u : 0u;
+      q |= c << (i < 4 ? 8 * i : 8 * (i - 4) + 4);        // nibble order e0 e4 e1 e5 e2 e6 e3 e7 (w8_codec.h)
+    }
+    *reinterpret_cast<uint32_t*>(Q + n * ldq + (k >> 1)) = q;
+  }
+}
+
+__global__ __launch_bounds__(256) void dequant_nf4_rows_kernel(const uint8_t* __restrict__ Q, int64_t ldq, const float* __restrict__ absmax,
+                                                               bf16_t* __restrict__ W, int64_t ldw, int K) {
+  const int64_t n = blockIdx.x;
+  for (int k = threadIdx.x * 8; k < K; k += 2048) {
+    const Nf4Tab t = nf4_table(absmax[n * (K >> 6) + (k >> 6)]);
+    *reinterpret_cast<mn_u4_t*>(W + n * ldw + k) = nf4x8_to_bf16(t, *reinterpret_cast<const uint32_t*>(Q + n * ldq + (k >> 1)));
+  }
+}
+
 }  // namespace
 
 extern "C" int mn_quant_int8_rows(const uint16_t* W, int64_t ldw, uint8_t* Wq, int64_t ldq, float* scale, int64_t n_rows, int K, void* stream) {
@@ -140,5 +184,25 @@ extern "C" int mn_dequant_fp8_rows(const uint8_t* Wq, int64_t ldq, const float* 
                "mn_dequant_fp8_rows: bad args (K, ldw, ldq multiples of 4)");
   hipLaunchKernelGGL(dequant_fp8_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, mn_stream(stream), Wq, ldq, scale, W, ldw, K);
   MN_CHECK_LAUNCH("mn_dequant_fp8_rows");
+  return MN_OK;
+}
+
+// NF4: W bf16 [n_rows][K] (row stride ldw elements) -> Wq [n_rows][K / 2] bytes (row stride ldq BYTES) + absmax fp32 [n_rows][K / 64].
+extern "C" int mn_quant_nf4_rows(const uint16_t* W, int64_t ldw, uint8_t* Wq, int64_t ldq, float* absmax, int64_t n_rows, int K, void* stream) {
+  MN_CHECK_ARG(W && Wq && absmax && n_rows >= 1 && n_rows < ((int64_t)1 << 31) && K >= 64 && (K % 64) == 0 && (ldw % 8) == 0 && (ldq % 4) == 0 &&
+                   (((uintptr_t)W) & 15) == 0 && (((uintptr_t)Wq) & 3) == 0,
+               "mn_quant_nf4_rows: bad args (K a multiple of the 64-element block, 16-byte aligned rows)");
+  hipLaunchKernelGGL(quant_nf4_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, mn_stream(stream), W, ldw, Wq, ldq, absmax, K);
+  MN_CHECK_LAUNCH("mn_quant_nf4_rows");
+  return MN_OK;
+}
+
+extern "C" int mn_dequant_nf4_rows(const uint8_t* Wq, int64_t ldq, const float* absmax, uint16_t* W, int64_t ldw, int64_t n_rows, int K,
+                                   void* stream) {
+  MN_CHECK_ARG(W && Wq && absmax && n_rows >= 1 && n_rows < ((int64_t)1 << 31) && K >= 64 && (K % 64) == 0 && (ldw % 8) == 0 && (ldq % 4) == 0 &&
+                   (((uintptr_t)W) & 15) == 0 && (((uintptr_t)Wq) & 3) == 0,
+               "mn_dequant_nf4_rows: bad args (K a multiple of the 64-element block, 16-byte aligned rows)");
+  hipLaunchKernelGGL(dequant_nf4_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, mn_stream(stream), Wq, ldq, absmax, W, ldw, K);
+  MN_CHECK_LAUNCH("mn_dequant_nf4_rows");
   return MN_OK;
 }

