@@ -130,6 +130,7 @@ typedef struct mn_skinny_args {
 MN_API int mn_skinny_gemm(const mn_skinny_args* args, void* stream);
 MN_API size_t mn_skinny_workspace_bytes(int M, int N, int K, int epilogue);
 MN_API size_t mn_skinny_workspace_bytes_w8(int M, int N, int K, int epilogue);
+MN_API size_t mn_skinny_workspace_bytes_wq(int wfmt, int M, int N, int K, int epilogue);   /* any weight format (section 7) */
 
 /* ------------------------------------------------------------------------------------------
  * 2. MoE router: RMSNorm + gate GEMV + fp32 softmax + top-k + renormalise, with the
@@ -660,7 +661,20 @@ MN_API int mn_sample_logits(const float* logits, int64_t ld, int M, int V, float
  *    model is reported separately.  mn_quant_fp8_rows emits power-of-two scales, for which the dequantised weights are exactly
  *    representable in bf16 (mn_dequant_fp8_rows): the same model can be run through every bf16 route.
  * ------------------------------------------------------------------------------------------ */
-enum { MN_W_BF16 = 0, MN_W_FP8_E4M3 = 1, MN_W_INT8 = 2 };
+enum { MN_W_BF16 = 0, MN_W_FP8_E4M3 = 1, MN_W_INT8 = 2, MN_W_NF4 = 3 };
+/* MN_W_NF4 (round 5): the reference's `dtype="int4"` surface (mingunivisioninfer.py:46-58: BitsAndBytesConfig(load_in_4bit, nf4,
+ * bf16 compute), i.e. bitsandbytes Linear4bit; third-party, absent here; restated in oracle/int4_ref.py) —
+ *     W[n, k] = bf16_rne(NF4[code[n, k]] * absmax[n, k / 64]),   blocks of 64 consecutive k, fp32 absmax, no double quantisation.
+ * Layout: `w` / Wq = rows of K / 2 bytes (two codes per byte; inside every dword the nibbles hold k 0 4 1 5 2 6 3 7 of its eight
+ * consecutive k, from bit 0 up), `wscale` = the absmax table [rows][K / 64].  K % 64 == 0.  Strides of the grouped forms count
+ * ELEMENTS for the codes (w_stride weights = w_stride / 2 bytes) and floats for the absmax tables.  The kernels look every block's 16
+ * possible bf16 values up with v_perm_b32 (w8_codec.h) on the way into the MFMA tile; nothing is scaled afterwards.  Routes: the
+ * weight-streaming launches (<= 64 rows; the experts run the grouped launch from one row on). */
+MN_API int mn_quant_nf4_rows(const uint16_t* W, int64_t ldw, uint8_t* Wq, int64_t ldq, float* absmax, int64_t n_rows, int K, void* stream);
+MN_API int mn_dequant_nf4_rows(const uint8_t* Wq, int64_t ldq, const float* absmax, uint16_t* W, int64_t ldw, int64_t n_rows, int K,
+                               void* stream);
+/* K-slice count of a dense streaming launch in format wfmt (the slab count the caller's reducing kernel sees) */
+MN_API int mn_stream_mfma_wq_slices(int wfmt, int M, int Ntot, int K);
 /* MN_W_INT8 (round 4): the same weight-only mode on two's-complement int8 bytes — the reference's `dtype="int8"` surface
  * (mingunivisioninfer.py:59-68: optimum-quanto qint8 weights, symmetric, one scale per output channel; third-party, absent here) —
  *     W[n, k] = Wq[n, k] * scale[n],  Wq in [-127, 127],  scale[n] = 2^ceil(log2(amax_n / 127)).

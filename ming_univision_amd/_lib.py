@@ -127,9 +127,15 @@ def check_struct_layouts(handle):
             raise RuntimeError(f"{klass.__name__}: field offsets differ from the library's (struct id {sid}): {mine} vs {list(buf[:max(n, 0)])}")
 
 
-W_BF16, W_FP8_E4M3, W_INT8 = 0, 1, 2          # mingnative.h section 7: weight formats of the streaming route
-WFMT = {"bf16": W_BF16, "fp8": W_FP8_E4M3, "int8": W_INT8}
-W8 = ("fp8", "int8")                           # the weight-only 8-bit modes (bytes + one power-of-two scale per output row)
+W_BF16, W_FP8_E4M3, W_INT8, W_NF4 = 0, 1, 2, 3   # mingnative.h section 7: weight formats of the streaming route
+WFMT = {"bf16": W_BF16, "fp8": W_FP8_E4M3, "int8": W_INT8, "int4": W_NF4}
+W8 = ("fp8", "int8", "int4")                   # the weight-only modes: codes (one or half a byte per weight) + a scale table
+# modes that convert EVERY nn.Linear of the model, as the reference's HF quantisation configs do (mingunivisioninfer.py:46-68:
+# `llm_int8_skip_modules` / `modules_to_not_convert` are given, which REPLACES HF's default skip list — so lm_head is converted too;
+# the "BailingAudioModel" entry matches no module path).  Not converted: nn.Embedding, Conv2d (patch embed), norms, biases, and the
+# router gates (BailingMoeGate holds a bare nn.Parameter, modeling_bailing_moe.py:497).  "fp8" is this library's own byte format for
+# the streamed tensors only (experts, RF ResBlocks, adaLN).
+FULL_MODEL = ("int4",)
 
 _lib = None
 
@@ -145,9 +151,13 @@ SYMBOLS = {
     "mn_skinny_gemm": (_i, [C.POINTER(SkinnyArgs), _p]),
     "mn_skinny_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mn_skinny_workspace_bytes_w8": (_sz, [_i, _i, _i, _i]),
+    "mn_skinny_workspace_bytes_wq": (_sz, [_i, _i, _i, _i, _i]),
     "mn_quant_fp8_rows": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _p]),
     "mn_dequant_fp8_rows": (_i, [_p, _i64, _p, _p, _i64, _i64, _i, _p]),
     "mn_quant_int8_rows": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _p]),
+    "mn_quant_nf4_rows": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _p]),
+    "mn_dequant_nf4_rows": (_i, [_p, _i64, _p, _p, _i64, _i64, _i, _p]),
+    "mn_stream_mfma_wq_slices": (_i, [_i, _i, _i, _i]),
     "mn_dequant_int8_rows": (_i, [_p, _i64, _p, _p, _i64, _i64, _i, _p]),
     "mn_stream_mfma_wq": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mn_stream_mfma_grouped_wq": (_i, [_p, _i, _p, _i64, _p, _i64, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),

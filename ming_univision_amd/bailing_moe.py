@@ -86,9 +86,18 @@ class BailingMoeDecoder:
         w_gate_up, w_down (see pack_experts).  Use `from_state_dict` / `synthetic` to build them.
         weights="fp8": w_gate_up / w_down are e4m3 bytes (uint8) with `w_gate_up_scale` / `w_down_scale` (quantize_layer_experts;
         bf16 experts are quantised here)."""
-        assert weights in _lib.WFMT, f"weights={weights!r}: 'bf16', 'fp8' or 'int8'"
-        self.weights = weights
-        if weights in _lib.W8:
+        assert weights in _lib.WFMT, f"weights={weights!r}: 'bf16', 'fp8', 'int8' or 'int4'"
+        self.weights = self.stream_fmt = weights         # the MODEL's mode / what the expert kernels read
+        if weights == "int4" and (cfg.hidden_size % 64 or cfg.moe_intermediate_size % 64):
+            # NF4 blocks (64 consecutive elements of the flattened matrix) would straddle rows: the experts keep the int4 model's VALUES
+            # as bf16 tensors on the bf16 route (ops.fake_quant blocks the flattened tensors like bitsandbytes)
+            self.stream_fmt = "bf16"
+            for ly in layers:
+                if not ly.get("_int4_values"):
+                    for k in ("w_gate_up", "w_down"):
+                        ly[k] = torch.stack([ops.fake_quant(ly[k][e], weights) for e in range(ly[k].shape[0])])
+                    ly["_int4_values"] = True
+        elif weights in _lib.W8:
             for ly in layers:
                 if ly["w_gate_up"].dtype != torch.uint8:
                     quantize_layer_experts(ly, weights)
@@ -119,8 +128,8 @@ class BailingMoeDecoder:
         s.moe_inter, s.norm_topk_prob, s.rms_eps = cfg.moe_intermediate_size, int(cfg.norm_topk_prob), cfg.rms_norm_eps
         for k in keys:
             setattr(s, k, C.cast(self._arrays[k], _lib.PP))
-        s.wfmt = _lib.WFMT[weights]
-        if weights in _lib.W8:
+        s.wfmt = _lib.WFMT[self.stream_fmt]
+        if self.stream_fmt in _lib.W8:
             for k in ("w_gate_up_scale", "w_down_scale"):
                 self._arrays[k] = ptr_array([ly[k] for ly in layers])
                 setattr(s, k, C.cast(self._arrays[k], _lib.PP))
@@ -149,8 +158,22 @@ class BailingMoeDecoder:
                 image_gate=sd.get(p + ".mlp.image_gate.weight") if cfg.multi_gate else None,
                 w_gate_up=gu, w_down=dn))
         root = prefix[:-len("model.")] if prefix.endswith("model.") else ""
-        return cls(cfg, layers, sd[prefix + "norm.weight"], sd.get(prefix + "word_embeddings.weight"),
-                   sd.get(root + "lm_head.weight"), **kw)
+        lm = sd.get(root + "lm_head.weight")
+        return cls(cfg, cls._convert_linears(layers, kw.get("weights", "bf16")), sd[prefix + "norm.weight"],
+                   sd.get(prefix + "word_embeddings.weight"), cls._convert_lm_head(lm, kw.get("weights", "bf16")), **kw)
+
+    @staticmethod
+    def _convert_linears(layers, weights):
+        """Modes that convert every nn.Linear (`_lib.FULL_MODEL`): the attention projections hold the mode's bf16 values (they stay on
+        the bf16 kernels: 3 % of a step's bytes); the experts are quantised into codes by the constructor.  Raw weights in, once."""
+        if weights in _lib.FULL_MODEL:
+            for ly in layers:
+                ly["wqkv"], ly["wdense"] = ops.fake_quant(ly["wqkv"], weights), ops.fake_quant(ly["wdense"], weights)
+        return layers
+
+    @staticmethod
+    def _convert_lm_head(lm, weights):
+        return ops.fake_quant(lm, weights) if (lm is not None and weights in _lib.FULL_MODEL) else lm
 
     @classmethod
     def synthetic(cls, cfg, device, seed=0, with_vocab=True, **kw):
@@ -171,14 +194,16 @@ class BailingMoeDecoder:
                 image_gate=sd.get(p + ".mlp.image_gate.weight") if cfg.multi_gate else None,
                 w_gate_up=gu, w_down=dn))
             if kw.get("weights") in _lib.W8:        # layer by layer: the bf16 experts of one layer at a time
-                quantize_layer_experts(layers[-1], kw["weights"])
+                if not (kw["weights"] == "int4" and (cfg.hidden_size % 64 or cfg.moe_intermediate_size % 64)):   # (else: __init__ keeps values)
+                    quantize_layer_experts(layers[-1], kw["weights"])
+                cls._convert_linears(layers[-1:], kw["weights"])
             del sd, gu, dn
         H, V = cfg.hidden_size, cfg.vocab_size
         fn = synth_tensor("model.norm.weight", (H,), seed, device, torch.bfloat16)
         emb = lm = None
         if with_vocab:
             emb = synth_tensor("model.word_embeddings.weight", (V, H), seed, device, torch.bfloat16)
-            lm = synth_tensor("lm_head.weight", (V, H), seed, device, torch.bfloat16)
+            lm = cls._convert_lm_head(synth_tensor("lm_head.weight", (V, H), seed, device, torch.bfloat16), kw.get("weights", "bf16"))
         return cls(cfg, layers, fn, emb, lm, **kw)
 
     def view(self, t_max, n_seq, n_pos=None):
@@ -191,9 +216,9 @@ class BailingMoeDecoder:
         """A second decoder whose experts are 8-bit copies of this one's — e4m3 (default) or int8 (weights="int8") — (attention /
         router / vocabulary tensors shared; this bf16 decoder stays usable): + 0.5 bytes per expert parameter of HBM."""
         assert self.weights == "bf16" and weights in _lib.W8
-        layers = [quantize_layer_experts(dict(ly), weights) for ly in self.layers]
-        return BailingMoeDecoder(self.cfg, layers, self.final_norm, self.word_embeddings, self.lm_head, t_max=t_max or self.t_max,
-                                 n_seq=n_seq or self.n_seq, weights=weights)
+        layers = self._convert_linears([quantize_layer_experts(dict(ly), weights) for ly in self.layers], weights)
+        return BailingMoeDecoder(self.cfg, layers, self.final_norm, self.word_embeddings, self._convert_lm_head(self.lm_head, weights),
+                                 t_max=t_max or self.t_max, n_seq=n_seq or self.n_seq, weights=weights)
 
     def weight_bytes_active(self, distinct_experts_per_layer):
         """Weight bytes one decode step streams: attention + router (bf16) + the distinct routed and the shared experts
@@ -201,7 +226,8 @@ class BailingMoeDecoder:
         cfg = self.cfg
         H, I = cfg.hidden_size, cfg.moe_intermediate_size
         attn = (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim * H + H * cfg.num_attention_heads * cfg.head_dim
-        per_expert = 2 * 3 * I * H if self.weights == "bf16" else 3 * I * H + (2 * I + H) * 4
+        per_expert = (2 * 3 * I * H if self.stream_fmt == "bf16" else
+                      (3 * I * H // 2 + 3 * I * H // 64 * 4 if self.stream_fmt == "int4" else 3 * I * H + (2 * I + H) * 4))
         return cfg.num_hidden_layers * (2 * (attn + cfg.num_experts * H) + (distinct_experts_per_layer + self.n_shared) * per_expert)
 
     def dequantized_state_dict(self, prefix="model."):
@@ -221,12 +247,19 @@ class BailingMoeDecoder:
                 out[f"{p}.shared_experts.gate_proj.weight"] = torch.cat([gu[E + s, :I] for s in range(S)], 0)
                 out[f"{p}.shared_experts.up_proj.weight"] = torch.cat([gu[E + s, I:] for s in range(S)], 0)
                 out[f"{p}.shared_experts.down_proj.weight"] = torch.cat([dn[E + s] for s in range(S)], 1)
+            if self.weights in _lib.FULL_MODEL:      # every nn.Linear is converted: the attention projections hold the mode's values
+                out[f"{prefix}layers.{li}.attention.query_key_value.weight"] = self.layers[li]["wqkv"]
+                out[f"{prefix}layers.{li}.attention.dense.weight"] = self.layers[li]["wdense"]
+        if self.weights in _lib.FULL_MODEL and self.lm_head is not None:
+            out[(prefix[:-len("model.")] if prefix.endswith("model.") else "") + "lm_head.weight"] = self.lm_head
         return out
 
     def dequantized_experts(self, li):
         """fp8 mode: layer li's packed experts as the kernels see them (e4m3 * row scale, exact in bf16): (w_gate_up, w_down)."""
         assert self.weights in _lib.W8
         ly = self.layers[li]
+        if self.stream_fmt not in _lib.W8:
+            return ly["w_gate_up"], ly["w_down"]
         return (ops.dequant_rows(ly["w_gate_up"], ly["w_gate_up_scale"], self.weights), ops.dequant_rows(ly["w_down"], ly["w_down_scale"], self.weights))
 
     # ---- stepping -------------------------------------------------------------------------

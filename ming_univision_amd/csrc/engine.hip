@@ -38,14 +38,17 @@ extern "C" int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint1
 extern "C" size_t mn_skinny_workspace_bytes_w8(int M, int N, int K, int epilogue);
 
 // ---- weight-format dispatch of the streaming launches (mingnative.h section 7): wfmt != 0 -> 8-bit bytes (e4m3 | int8) + fp32 row scales ----
-static inline bool mn_w8(int wfmt) { return wfmt == MN_W_FP8_E4M3 || wfmt == MN_W_INT8; }
+static inline bool mn_w8(int wfmt) { return wfmt == MN_W_FP8_E4M3 || wfmt == MN_W_INT8 || wfmt == MN_W_NF4; }
+// widths of a quantised matrix: K must hold whole 16-byte weight loads (NF4: whole 64-element absmax blocks)
+static inline int mn_wq_kmult(int wfmt) { return wfmt == MN_W_NF4 ? 64 : 16; }
+// scale-table floats per weight row: one row scale (e4m3 / int8) or one absmax per 64 k (NF4)
+static inline int64_t mn_wq_scales_per_row(int wfmt, int K) { return wfmt == MN_W_NF4 ? K / 64 : 1; }
+extern "C" int mn_stream_mfma_wq_slices(int wfmt, int M, int Ntot, int K);
 extern "C" int mn_stream_mfma_wq(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, int wfmt, void* stream);
 extern "C" int mn_stream_mfma_grouped_wq(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale, int64_t s_stride,
                                          float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows, int Ntot, int K,
                                          int wfmt, void* stream);
-static inline int stream_slices(int wfmt, int M, int Ntot, int K) {
-  return wfmt ? mn_stream_mfma_w8_slices(M, Ntot, K) : mn_stream_mfma_slices(M, Ntot, K);
-}
+static inline int stream_slices(int wfmt, int M, int Ntot, int K) { return mn_stream_mfma_wq_slices(wfmt, M, Ntot, K); }
 static inline int stream_dense(int wfmt, const uint16_t* Y, const void* W, const float* wscale, float* P, int M, int Ntot, int K, void* stream) {
   return wfmt ? mn_stream_mfma_wq(Y, reinterpret_cast<const uint8_t*>(W), wscale, P, M, Ntot, K, wfmt, stream)
               : mn_stream_mfma(Y, reinterpret_cast<const uint16_t*>(W), P, M, Ntot, K, stream);
@@ -54,8 +57,8 @@ static inline int stream_dense(int wfmt, const uint16_t* Y, const void* W, const
 static inline int stream_grouped(int wfmt, const uint16_t* Y, int y_rows, const void* W, int64_t w_stride, const float* wscale, int64_t s_stride,
                                  float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G, int max_rows, int Ntot, int K,
                                  void* stream) {
-  return wfmt ? mn_stream_mfma_grouped_wq(Y, y_rows, reinterpret_cast<const uint8_t*>(W), w_stride, wscale, s_stride, P, p_rows, off, xrows,
-                                          G, max_rows, Ntot, K, wfmt, stream)
+  return wfmt ? mn_stream_mfma_grouped_wq(Y, y_rows, reinterpret_cast<const uint8_t*>(W), w_stride, wscale,
+                                          s_stride * mn_wq_scales_per_row(wfmt, K), P, p_rows, off, xrows, G, max_rows, Ntot, K, wfmt, stream)
               : mn_stream_mfma_grouped(Y, y_rows, reinterpret_cast<const uint16_t*>(W), w_stride, P, p_rows, off, xrows, G, max_rows, Ntot,
                                        K, stream);
 }
@@ -511,7 +514,8 @@ static bool rf_chain_ok(const mn_rf_head* h, int rows) {
 }
 // fp8 weight mode: the RF blocks must be able to run as the matrix-core chain (the fp32-FMA kernels read bf16 rows)
 static bool rf_fp8_ok(const mn_rf_head* h) {
-  return mn_w8(h->wfmt) && h->w12_scale && h->w3_scale && h->w <= 4096 && (h->w % 16) == 0 && (h->hidden % 16) == 0;
+  return mn_w8(h->wfmt) && h->w12_scale && h->w3_scale && h->w <= 4096 && (h->w % mn_wq_kmult(h->wfmt)) == 0 &&
+         (h->hidden % mn_wq_kmult(h->wfmt)) == 0;
 }
 
 // <= 4 rows (the CFG rows of one image — the reference's call shape): the SwiGLU glue launch is folded into w3's prologue
@@ -564,7 +568,7 @@ static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, floa
   *yb = cv.take<bf16_t>(chain ? (size_t)2 * rows * h->hidden : 0);
   *pbuf = cv.take<float>(chain ? pmax * rows : 0);
   const int SRn = h->steps * rows;
-  float* pa = cv.take<float>(rf_ada_w8(h, rows) ? (size_t)mn_stream_mfma_w8_slices(SRn, A, h->w) * SRn * A
+  float* pa = cv.take<float>(rf_ada_w8(h, rows) ? (size_t)stream_slices(h->wfmt, SRn, A, h->w) * SRn * A
                              : ((!h->wfmt && (int64_t)SRn <= 64 && (h->w % 8) == 0) ? (size_t)mn_stream_mfma_slices(SRn, A, h->w) * SRn * A : 0));
   if (pada) *pada = pa;
   // fused w3: its slabs live beside w12's (its prologue reads those while other workgroups already write w3's); the workspace does
@@ -943,8 +947,10 @@ static size_t moe_carve(Carver& cv, int rows, int H, int I, int G, int n_slot, M
 
 // grouped-expert route from 3 rows (3 rows: 74.2 vs 70.6 tokens/s against the fp32-FMA pair kernels; 2 rows: 75.1 vs 76.8)
 constexpr int MOE_MFMA_MIN_ROWS = 3;
+// NF4 experts run the grouped streaming launch from ONE row on (the fp32-FMA pair kernels of 1- / 2-row steps read bf16 / byte rows)
+static inline int moe_mfma_min_rows(const mn_llm* m) { return m->wfmt == MN_W_NF4 ? 1 : MOE_MFMA_MIN_ROWS; }
 static bool moe_mfma_ok(const mn_llm* m, int rows) {
-  return rows >= MOE_MFMA_MIN_ROWS && rows * (m->top_k + m->n_shared_slots) <= 1024 &&
+  return rows >= moe_mfma_min_rows(m) && rows * (m->top_k + m->n_shared_slots) <= 1024 &&
          m->n_experts + m->n_shared_slots <= 256 && (m->hidden % 8) == 0 && (m->moe_inter % 8) == 0;   // % 4: vector glue
 }
 
@@ -1125,9 +1131,9 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
   MN_CHECK_ARG(M >= 1 && (M <= 64 || llm_wide_ok(m, M)) && x_row_div >= 1,
                "mn_llm_step: M=%d (1..64, or up to 2048 rows with 64-aligned widths)", M);
   // fp8 experts: 1 or 2 rows run the one-row fp8 kernel on the (row, expert) pairs, more the grouped streaming kernels
-  MN_CHECK_ARG(m->wfmt == MN_W_BF16 || (mn_w8(m->wfmt) && m->w_gate_up_scale && m->w_down_scale && (m->hidden % 16) == 0 &&
-                                        (m->moe_inter % 16) == 0 && M <= 64 && (M < MOE_MFMA_MIN_ROWS || moe_mfma_ok(m, M))),
-               "mn_llm_step: fp8 experts need row scales, widths %% 16 == 0 and <= 64 rows (M = %d)", M);
+  MN_CHECK_ARG(m->wfmt == MN_W_BF16 || (mn_w8(m->wfmt) && m->w_gate_up_scale && m->w_down_scale && (m->hidden % mn_wq_kmult(m->wfmt)) == 0 &&
+                                        (m->moe_inter % mn_wq_kmult(m->wfmt)) == 0 && M <= 64 && (M < moe_mfma_min_rows(m) || moe_mfma_ok(m, M))),
+               "mn_llm_step: quantised experts need scale tables, widths %% 16 == 0 (NF4: %% 64) and <= 64 rows (M = %d)", M);
   if (llm_wide_ok(m, M))
     return llm_step_wide(m, x, ldx, x_row_div, M, image_mask, row_seq, row_slot, row_pos, row_len, key_mask, ld_mask, kv_cache, n_seq, t_max,
                          hidden_out, workspace, workspace_bytes, stream, span_tab, n_spans, span_max_len);

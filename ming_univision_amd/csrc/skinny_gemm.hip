@@ -217,6 +217,7 @@ extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, in
 extern "C" int mn_stream_mfma_slices(int M, int Ntot, int K);
 extern "C" int mn_stream_mfma_wq(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, int wfmt, void* stream);
 extern "C" int mn_stream_mfma_w8_slices(int M, int Ntot, int K);
+extern "C" int mn_stream_mfma_wq_slices(int wfmt, int M, int Ntot, int K);
 extern "C" int mn_skinny_w8_row(const mn_skinny_args* args, void* stream);      // skinny_w8.hip
 
 namespace {
@@ -311,11 +312,15 @@ extern "C" size_t mn_skinny_workspace_bytes(int M, int N, int K, int epilogue) {
   return y + (size_t)mn_stream_mfma_slices(M, Ntot, K) * M * Ntot * sizeof(float) + 256;
 }
 
-// fp8 weights: every row count takes the matrix-core route (the fp32-FMA kernel reads bf16 rows)
-extern "C" size_t mn_skinny_workspace_bytes_w8(int M, int N, int K, int epilogue) {
+// quantised weights (wfmt != 0): every row count takes the matrix-core route (the fp32-FMA kernel reads bf16 rows)
+extern "C" size_t mn_skinny_workspace_bytes_wq(int wfmt, int M, int N, int K, int epilogue) {
+  if (wfmt == MN_W_BF16) return mn_skinny_workspace_bytes(M, N, K, epilogue);
   const int Ntot = epilogue == MN_EPI_SWIGLU ? 2 * N : N;
   const size_t y = ((size_t)2 * M * K * sizeof(bf16_t) + 255) & ~(size_t)255;
-  return y + (size_t)mn_stream_mfma_w8_slices(M, Ntot, K) * M * Ntot * sizeof(float) + 256;
+  return y + (size_t)mn_stream_mfma_wq_slices(wfmt, M, Ntot, K) * M * Ntot * sizeof(float) + 256;
+}
+extern "C" size_t mn_skinny_workspace_bytes_w8(int M, int N, int K, int epilogue) {
+  return mn_skinny_workspace_bytes_wq(MN_W_FP8_E4M3, M, N, K, epilogue);
 }
 
 static int skinny_medium(const mn_skinny_args& a, void* stream) {
@@ -325,7 +330,8 @@ static int skinny_medium(const mn_skinny_args& a, void* stream) {
   const int Ntot = a.epilogue == MN_EPI_SWIGLU ? 2 * a.N : a.N;
   const bool w8 = a.wfmt != MN_W_BF16;
   MN_CHECK_ARG(!w8 || (a.wscale && (a.K % 16) == 0), "mn_skinny_gemm: fp8 weights need wscale and K %% 16 == 0");
-  const size_t need = w8 ? mn_skinny_workspace_bytes_w8(a.M, a.N, a.K, a.epilogue) : mn_skinny_workspace_bytes(a.M, a.N, a.K, a.epilogue);
+  MN_CHECK_ARG(a.wfmt != MN_W_NF4 || (a.K % 64) == 0, "mn_skinny_gemm: NF4 weights need K %% 64 == 0");
+  const size_t need = mn_skinny_workspace_bytes_wq(a.wfmt, a.M, a.N, a.K, a.epilogue);
   if (!a.ws || a.ws_bytes < need) { mn_set_error("mn_skinny_gemm: M=%d needs %zu workspace bytes", a.M, need); return MN_ENOSPACE; }
   bf16_t* Y = reinterpret_cast<bf16_t*>(a.ws);
   float* P = reinterpret_cast<float*>(reinterpret_cast<char*>(a.ws) + (((size_t)2 * a.M * a.K * sizeof(bf16_t) + 255) & ~(size_t)255));
@@ -358,7 +364,8 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   MN_CHECK_ARG(a.epilogue >= 0 && a.epilogue <= MN_EPI_RESID_GATE, "mn_skinny_gemm: bad epilogue %d", a.epilogue);
   ka.nseg = a.nseg > 0 ? a.nseg : 1;
   ka.batch = a.batch > 0 ? a.batch : 1;
-  MN_CHECK_ARG(a.wfmt == MN_W_BF16 || a.wfmt == MN_W_FP8_E4M3 || a.wfmt == MN_W_INT8, "mn_skinny_gemm: bad wfmt %d", a.wfmt);
+  MN_CHECK_ARG(a.wfmt == MN_W_BF16 || a.wfmt == MN_W_FP8_E4M3 || a.wfmt == MN_W_INT8 || a.wfmt == MN_W_NF4, "mn_skinny_gemm: bad wfmt %d", a.wfmt);
+  MN_CHECK_ARG(a.wfmt != MN_W_NF4 || (ka.batch == 1 && ka.nseg == 1 && a.ws), "mn_skinny_gemm: NF4 weights run the workspace route only (no batch / segment forms)");
   if (a.wfmt != MN_W_BF16) {
     // one row per batch entry with a plain prologue: the one-row fp8 kernel (expert pair launches, batch / segment forms included);
     // everything else: the matrix-core route (checks dense weights / no batch forms / workspace)

@@ -52,12 +52,19 @@ __device__ __forceinline__ int cslot(int row, int slot) { return row * (CK * 2) 
 // footprint (two workgroups per CU) and the barriers are those of the bf16 form; HBM bytes halve; the row scale multiplies the
 // fp32 accumulators at the partial store.  CK must be 64; D = 4 is the loop's unroll (two pieces in flight per wave), the x ring
 // stays two chunks deep so that the four-row-tile form keeps the bf16 form's register count (two workgroups per CU).
-template <int MT, int NT, int D, int CK, bool W8>
-__global__ __launch_bounds__(KW * 64, (W8 && MT == 4 && NT == 2) ? 4 : 1) void stream_kloop_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
+// WQ = 2 (NF4, w8_codec.h): two codes per byte + wscale = the absmax table [rows][K / 64].  A weight load (16 bytes per lane) is a
+// piece of 256 k that serves FOUR 64-k chunks — chunk 4p + h takes dword h of every lane's four, i.e. k 32 j + 8 h .. + 8 of the piece
+// for the lane with slot j —; a lane's 32 k lie in one 64-element block, whose 16-entry value table is built when the piece's first
+// chunk is parked and kept for the other three.  D = 8 (two pieces per loop iteration, one in flight while the other is consumed).
+template <int MT, int NT, int D, int CK, int WQ>
+__global__ __launch_bounds__(KW * 64, (WQ == 1 && MT == 4 && NT == 2) ? 4 : 1) void stream_kloop_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
                                                                const void* __restrict__ Wv, const float* __restrict__ wscale,
                                                                float* __restrict__ P, int64_t p_slab, int M, int Ntot, int K,
                                                                int nz, KGroups g) {
+  constexpr bool W8 = WQ == 1, W4 = WQ == 2;
+  constexpr int PC = W4 ? 4 : (W8 ? 2 : 1);                           // 64-k chunks one weight load (piece) serves
   static_assert(!W8 || (CK == 64 && D == 4), "fp8 weight pieces span two 64-k chunks, two pieces in flight");
+  static_assert(!W4 || (CK == 64 && D == 8), "NF4 weight pieces span four 64-k chunks, two pieces per loop iteration");
   const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(Wv);
   const uint8_t* __restrict__ Wq = reinterpret_cast<const uint8_t*>(Wv);
   extern __shared__ __attribute__((aligned(16))) char lds[];          // x: [2 bufs][2 x 16MT rows][256 B]; w: [KW][16 NT][256 B]
@@ -72,8 +79,8 @@ __global__ __launch_bounds__(KW * 64, (W8 && MT == 4 && NT == 2) ? 4 : 1) void s
     nrows = g.off[blockIdx.z + 1] - row0;
     if (nrows <= g.row_lo || nrows > g.row_hi) return;
     W += (int64_t)blockIdx.z * g.w_stride;
-    Wq += (int64_t)blockIdx.z * g.w_stride;
-    if constexpr (W8) wscale += (int64_t)blockIdx.z * g.s_stride;
+    Wq += W4 ? ((int64_t)blockIdx.z * g.w_stride) >> 1 : (int64_t)blockIdx.z * g.w_stride;
+    if constexpr (WQ != 0) wscale += (int64_t)blockIdx.z * g.s_stride;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
@@ -82,10 +89,10 @@ __global__ __launch_bounds__(KW * 64, (W8 && MT == 4 && NT == 2) ? 4 : 1) void s
   const int nch = (K + CK - 1) / CK;
   const int z = blockIdx.y;
   int c0, nc;
-  if constexpr (W8) {                                                 // ranges of whole 128-k PIECES = chunk pairs (a partial last
-    const int np = (K + 127) / 128, base = np / nz, rem = np % nz;    // piece still has both chunks: each covers half of every 16 k)
-    c0 = 2 * (z * base + min(z, rem));
-    nc = 2 * (base + (z < rem ? 1 : 0));
+  if constexpr (PC > 1) {                                             // ranges of whole PIECES = PC chunks (a partial last piece
+    const int np = (K + PC * 64 - 1) / (PC * 64), base = np / nz, rem = np % nz;   // still has all its chunks: each covers 8 of every lane's k)
+    c0 = PC * (z * base + min(z, rem));
+    nc = PC * (base + (z < rem ? 1 : 0));
   } else {
     const int base = nch / nz, rem = nch % nz;
     c0 = z * base + min(z, rem);
@@ -108,40 +115,51 @@ __global__ __launch_bounds__(KW * 64, (W8 && MT == 4 && NT == 2) ? 4 : 1) void s
     xp[j] = nullptr;
     if (rr < 2 * XR && m < nrows) {
       const int xr = g.xrows ? g.xrows[row0 + m] : row0 + m;
-      xp[j] = Y + h * y_lo + (int64_t)xr * K + slot * (W8 ? 16 : 8);   // fp8: slot j of a chunk = k 16 j (+ 8 for odd chunks) of its piece
+      xp[j] = Y + h * y_lo + (int64_t)xr * K + slot * (8 * PC);   // fp8 / NF4: slot j of a chunk = k 8 PC j (+ 8 h for chunk h) of its piece
     }
   }
   // ---- weight pieces of this wave: instruction i -> row i * RPI + lane / SPR of its 16 NT rows, slot lane % SPR
   // (fp8: 16 bytes per lane = slot lane % 8 of BOTH chunks of the piece)
   constexpr int RPI = 64 / SPR;                                       // rows per instruction (4 x 256 B or 8 x 128 B)
   constexpr int WI = 16 * NT / RPI;
-  constexpr int DW = W8 ? D / 2 : D;                                  // ring depth in weight loads
-  constexpr int XD = W8 ? 2 : D;                                      // ring depth of the x chunks
+  constexpr int DW = D / PC;                                          // ring depth in weight loads
+  constexpr int XD = PC > 1 ? 2 : D;                                  // ring depth of the x chunks
   const bf16_t* wp[WI];
   const uint8_t* wq[WI];
+  const float* wa[WI];                                                // NF4: the row's absmax table
   int wo[WI];
-  const int wslot_k = (lane % SPR) * (W8 ? 16 : 8);
+  const int wslot_k = (lane % SPR) * (8 * PC);
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
     const int row = i * RPI + lane / SPR;
     const int n = min(t * 16 + row, Ntot - 1);
     wp[i] = W + (int64_t)n * K;
-    wq[i] = Wq + (int64_t)n * K;
+    wq[i] = Wq + (W4 ? ((int64_t)n * K) >> 1 : (int64_t)n * K);
+    wa[i] = W4 ? wscale + (int64_t)n * (K >> 6) : nullptr;
     wo[i] = cslot<CK>(row, lane % SPR);
   }
   u32x4 xr_[XD][XJ], wr_[DW][WI];
+  float wa_[W4 ? DW : 1][WI];                                         // NF4: absmax of the block every load of the piece lies in
+  Nf4Tab tab[W4 ? WI : 1];
   auto load_x = [&](u32x4 (&dst)[XJ], int c) {
     // bf16: chunk c = k [(c0 + c) 64, + 64); fp8: piece (c0 + c) / 2 (c0 is even), the lanes' first / second 8 k for even / odd c
-    const int k = W8 ? (c0 + (c & ~1)) * CK + (c & 1) * 8 : (c0 + c) * CK;
+    const int k = PC > 1 ? (c0 + (c & ~(PC - 1))) * CK + (c & (PC - 1)) * 8 : (c0 + c) * CK;
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
       dst[j] = u32x4{0u, 0u, 0u, 0u};                                  // rows >= nrows and k >= K stay zero
-      if (xp[j] && k + ((tid + j * (KW * 64)) % SPR) * (W8 ? 16 : 8) < K) dst[j] = *reinterpret_cast<const u32x4*>(xp[j] + k);
+      if (xp[j] && k + ((tid + j * (KW * 64)) % SPR) * (8 * PC) < K) dst[j] = *reinterpret_cast<const u32x4*>(xp[j] + k);
     }
   };
   // bf16: chunk c of the K-range; fp8: piece c = chunks 2c, 2c + 1
-  auto load_w = [&](u32x4 (&dst)[WI], int c) {
-    if constexpr (W8) {
+  auto load_w = [&](u32x4 (&dst)[WI], float (&dsta)[WI], int c) {
+    if constexpr (W4) {
+      const int k = min((c0 + 4 * c) * CK + wslot_k, K - 32);         // beyond K the x image is zero: any finite value will do
+#pragma unroll
+      for (int i = 0; i < WI; ++i) {
+        dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wq[i] + (k >> 1)));
+        dsta[i] = wa[i][k >> 6];
+      }
+    } else if constexpr (W8) {
       const int k = min((c0 + 2 * c) * CK + wslot_k, K - 16);         // beyond K the x image is zero: any finite value will do
 #pragma unroll
       for (int i = 0; i < WI; ++i) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wq[i] + k));
@@ -160,11 +178,11 @@ __global__ __launch_bounds__(KW * 64, (W8 && MT == 4 && NT == 2) ? 4 : 1) void s
 #pragma unroll
   for (int d = 0; d < XD; ++d)
     if (d < nc) load_x(xr_[d], d);
-  const int nwl = W8 ? (nc + 1) / 2 : nc;                            // weight loads of this K-range
+  const int nwl = (nc + PC - 1) / PC;                                // weight loads of this K-range
   if (active) {
 #pragma unroll
     for (int d = 0; d < DW; ++d)
-      if (d < nwl) load_w(wr_[d], d);
+      if (d < nwl) load_w(wr_[d], wa_[W4 ? d : 0], d);
   }
   store_x(xr_[0], 0);
   if (XD < nc) load_x(xr_[0], XD);
@@ -183,7 +201,20 @@ __global__ __launch_bounds__(KW * 64, (W8 && MT == 4 && NT == 2) ? 4 : 1) void s
         const int buf = d & 1;                                        // D is even: chunk parity == d parity
         if (active) {
           // park the landed weight chunk, refill its registers with the chunk D ahead
-          if constexpr (W8) {
+          if constexpr (W4) {
+            // piece c / 4 sits in ring slot d / 4 (cb is a multiple of D = 8): dword d & 3 of every load is this chunk's slot
+            if ((d & 3) == 0) {
+#pragma unroll
+              for (int i = 0; i < WI; ++i) tab[i] = nf4_table(wa_[d >> 2][i]);
+            }
+#pragma unroll
+            for (int i = 0; i < WI; ++i) {
+              const u32x4 q = wr_[d >> 2][i];
+              const uint32_t x = (d & 3) == 0 ? q.x : ((d & 3) == 1 ? q.y : ((d & 3) == 2 ? q.z : q.w));
+              *reinterpret_cast<u32x4*>(wt + wo[i]) = nf4x8_to_bf16(tab[i], x);
+            }
+            if ((d & 3) == 3 && (c >> 2) + DW < nwl) load_w(wr_[d >> 2], wa_[d >> 2], (c >> 2) + DW);
+          } else if constexpr (W8) {
             // piece c / 2 sits in ring slot d / 2 (cb is a multiple of D): its first 8 k per lane for the even chunk, the second
             // 8 for the odd one, converted to one bf16 slot; after the odd chunk the registers take the piece DW ahead
             auto park8 = [&](auto i8) {
@@ -195,11 +226,11 @@ __global__ __launch_bounds__(KW * 64, (W8 && MT == 4 && NT == 2) ? 4 : 1) void s
               }
             };
             if (g.wf == MN_W_INT8) park8(std::true_type{}); else park8(std::false_type{});    // one scalar branch per chunk
-            if ((d & 1) && (c >> 1) + DW < nwl) load_w(wr_[d >> 1], (c >> 1) + DW);
+            if ((d & 1) && (c >> 1) + DW < nwl) load_w(wr_[d >> 1], wa_[0], (c >> 1) + DW);
           } else {
 #pragma unroll
             for (int i = 0; i < WI; ++i) *reinterpret_cast<u32x4*>(wt + wo[i]) = wr_[d][i];
-            if (c + D < nc) load_w(wr_[d], c + D);
+            if (c + D < nc) load_w(wr_[d], wa_[0], c + D);
           }
           // CK / 32 MFMA steps of 32 k against every populated x tile (hi and lo)
 #pragma unroll
@@ -262,9 +293,10 @@ int kloop_ck() { return g_kl_ck > 0 ? g_kl_ck : 64; }
 int kloop_nt(int max_rows) { return g_kl_nt > 0 ? g_kl_nt : (max_rows > 32 ? 2 : 1); }
 
 // number of K-ranges: enough workgroups to fill `slots` CUs-worth of residency, never more ranges than chunks (fp8: chunk pairs)
-int kloop_nz(int Ntot, int K, int slots, int nt, bool w8 = false) {
+static inline int kloop_piece_k(int wfmt) { return wfmt == MN_W_NF4 ? 256 : (wfmt ? 128 : 0); }   // k per weight load (0: one chunk)
+int kloop_nz(int Ntot, int K, int slots, int nt, int piece_k = 0) {
   const int tb = (int)mn_cdiv(mn_cdiv(Ntot, 16), KW * nt);
-  const int nch = (int)mn_cdiv(K, w8 ? 128 : kloop_ck());
+  const int nch = (int)mn_cdiv(K, piece_k ? piece_k : kloop_ck());
   if (g_kl_nz > 0) return g_kl_nz < nch ? g_kl_nz : nch;
   int nz = slots / tb;
   if (nz < 1) nz = 1;
@@ -272,7 +304,7 @@ int kloop_nz(int Ntot, int K, int slots, int nt, bool w8 = false) {
   return nz;
 }
 
-template <int MT, int NT, int D, int CK, bool W8>
+template <int MT, int NT, int D, int CK, int W8>
 void kloop_launch(int G, int nz, const bf16_t* Y, int64_t y_lo, const void* W, const float* wscale, float* P, int64_t p_slab, int M,
                   int Ntot, int K, const KGroups& g, hipStream_t st) {
   constexpr int ROWB = CK * 2;
@@ -291,9 +323,14 @@ void kloop_launch(int G, int nz, const bf16_t* Y, int64_t y_lo, const void* W, c
 template <int MT>
 void kloop_launch_d(int nt, int G, int nz, const bf16_t* Y, int64_t y_lo, const void* W, const float* wscale, float* P, int64_t p_slab,
                     int M, int Ntot, int K, const KGroups& g, hipStream_t st) {
+  if (wscale && g.wf == MN_W_NF4) {     // NF4: 256-k weight pieces = four chunks
+    if (nt == 2) kloop_launch<MT, 2, 8, 64, 2>(G, nz, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, g, st);
+    else kloop_launch<MT, 1, 8, 64, 2>(G, nz, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, g, st);
+    return;
+  }
   if (wscale) {     // fp8 weights: 64-k x chunks, 128-k weight pieces, two pieces (= four chunks) in flight per wave
-    if (nt == 2) kloop_launch<MT, 2, 4, 64, true>(G, nz, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, g, st);
-    else kloop_launch<MT, 1, 4, 64, true>(G, nz, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, g, st);
+    if (nt == 2) kloop_launch<MT, 2, 4, 64, 1>(G, nz, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, g, st);
+    else kloop_launch<MT, 1, 4, 64, 1>(G, nz, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, g, st);
     return;
   }
   const int depth = g_kl_depth > 0 ? g_kl_depth : (nt == 2 ? 2 : 4);
@@ -301,11 +338,11 @@ void kloop_launch_d(int nt, int G, int nz, const bf16_t* Y, int64_t y_lo, const 
 #ifdef MN_DEV_HOOKS      // the 128-k chunk form exists for the A/B hook only (it spills at four row tiles): not in the product library
 #define MN_KL(NT_, D_)                                                                                      \
   do {                                                                                                      \
-    if (ck == 64) kloop_launch<MT, NT_, D_, 64, false>(G, nz, Y, y_lo, W, nullptr, P, p_slab, M, Ntot, K, g, st);           \
-    else kloop_launch<MT, NT_, D_, 128, false>(G, nz, Y, y_lo, W, nullptr, P, p_slab, M, Ntot, K, g, st);                   \
+    if (ck == 64) kloop_launch<MT, NT_, D_, 64, 0>(G, nz, Y, y_lo, W, nullptr, P, p_slab, M, Ntot, K, g, st);           \
+    else kloop_launch<MT, NT_, D_, 128, 0>(G, nz, Y, y_lo, W, nullptr, P, p_slab, M, Ntot, K, g, st);                   \
   } while (0)
 #else
-#define MN_KL(NT_, D_) kloop_launch<MT, NT_, D_, 64, false>(G, nz, Y, y_lo, W, nullptr, P, p_slab, M, Ntot, K, g, st)
+#define MN_KL(NT_, D_) kloop_launch<MT, NT_, D_, 64, 0>(G, nz, Y, y_lo, W, nullptr, P, p_slab, M, Ntot, K, g, st)
 #endif
   if (nt == 2) { if (depth == 2) MN_KL(2, 2); else MN_KL(2, 4); }
   else { if (depth == 2) MN_KL(1, 2); else MN_KL(1, 4); }
@@ -341,7 +378,10 @@ extern "C" MN_DEV_API void mn_stream_kloop_tune_small(int div) { g_kl_small_div 
 extern "C" int mn_stream_kloop_slices(int M, int Ntot, int K) { return kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K), kloop_nt(M)); }
 // (the half-chip rule counts ELEMENTS: an fp8 matrix of the same shape keeps the bf16 form's share of the chip — with the byte
 // count RF w12 fell under the threshold and ran 34.9 instead of 2x us at 48 rows)
-extern "C" int mn_stream_kloop_w8_slices(int M, int Ntot, int K) { return kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K), kloop_nt(M), true); }
+extern "C" int mn_stream_kloop_wq_slices(int wfmt, int M, int Ntot, int K) {
+  return kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K), kloop_nt(M), kloop_piece_k(wfmt));
+}
+extern "C" int mn_stream_kloop_w8_slices(int M, int Ntot, int K) { return mn_stream_kloop_wq_slices(MN_W_FP8_E4M3, M, Ntot, K); }
 
 // Dense: Y [2][M][K] bf16 (hi rows then lo rows), W [Ntot][K], P [nz][M][Ntot].  Returns nz (< 0: error).  M <= 64.
 extern "C" int mn_stream_kloop(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream) {
@@ -356,9 +396,10 @@ extern "C" int mn_stream_kloop(const uint16_t* Y, const uint16_t* W, float* P, i
 // Dense on 8-bit weights (wfmt = MN_W_FP8_E4M3 | MN_W_INT8): Wq bytes [Ntot][K] (K % 16 == 0), wscale fp32 [Ntot].
 // nz = mn_stream_kloop_w8_slices(M, Ntot, K).
 extern "C" int mn_stream_kloop_wq(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, int wfmt, void* stream) {
-  MN_CHECK_ARG(Y && Wq && wscale && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 16 && (K % 16) == 0 && (wfmt == MN_W_FP8_E4M3 || wfmt == MN_W_INT8),
+  MN_CHECK_ARG(Y && Wq && wscale && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 16 && (K % 16) == 0 &&
+                   (wfmt == MN_W_FP8_E4M3 || wfmt == MN_W_INT8 || (wfmt == MN_W_NF4 && (K % 64) == 0)),
                "mn_stream_kloop_wq: bad args");
-  const int nz = kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K), kloop_nt(M), true);
+  const int nz = kloop_nz(Ntot, K, kloop_dense_slots(Ntot, K), kloop_nt(M), kloop_piece_k(wfmt));
   const KGroups g{nullptr, nullptr, 0, 0, 1 << 30, 0, wfmt};
   kloop_dispatch(1, M, nz, Y, (int64_t)M * K, Wq, wscale, P, (int64_t)M * Ntot, M, Ntot, K, g, mn_stream(stream));
   MN_CHECK_LAUNCH("mn_stream_kloop_wq");
@@ -384,7 +425,8 @@ extern "C" int mn_stream_kloop_grouped_wq(const uint16_t* Y, int y_rows, const u
                                           int64_t s_stride, float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G,
                                           int max_rows, int nz, int Ntot, int K, int wfmt, void* stream) {
   MN_CHECK_ARG(Y && Wq && wscale && P && off && G >= 1 && max_rows >= 1 && max_rows <= 64 && Ntot >= 1 && K >= 16 && (K % 16) == 0 &&
-                   (w_stride % 16) == 0 && nz >= 1 && nz <= (K + 127) / 128 && (wfmt == MN_W_FP8_E4M3 || wfmt == MN_W_INT8),
+                   (w_stride % 32) == 0 && nz >= 1 && nz <= (K + kloop_piece_k(wfmt) - 1) / kloop_piece_k(wfmt) &&
+                   (wfmt == MN_W_FP8_E4M3 || wfmt == MN_W_INT8 || (wfmt == MN_W_NF4 && (K % 64) == 0)),
                "mn_stream_kloop_grouped_wq: bad args");
   const KGroups g{off, xrows, w_stride, 0, max_rows, s_stride, wfmt};
   kloop_dispatch(G, max_rows, nz, Y, (int64_t)y_rows * K, Wq, wscale, P, (int64_t)p_rows * Ntot, 0, Ntot, K, g, mn_stream(stream));

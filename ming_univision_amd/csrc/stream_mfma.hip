@@ -39,7 +39,7 @@ extern "C" int mn_stream_kloop_grouped(const uint16_t* Y, int y_rows, const uint
                                        int nz, int Ntot, int K, void* stream);
 // ... and on fp8 weights (e4m3 bytes + one fp32 scale per output row)
 extern "C" int mn_stream_kloop_wq(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, int wfmt, void* stream);
-extern "C" int mn_stream_kloop_w8_slices(int M, int Ntot, int K);
+extern "C" int mn_stream_kloop_wq_slices(int wfmt, int M, int Ntot, int K);
 extern "C" int mn_stream_kloop_grouped_wq(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale,
                                           int64_t s_stride, float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G,
                                           int max_rows, int nz, int Ntot, int K, int wfmt, void* stream);
@@ -51,6 +51,11 @@ constexpr int MAX_KCH = 4;           // K-slice <= 1024
 constexpr size_t LDS_CAP = 160 * 1024;
 
 __device__ __forceinline__ int wslot(int row, int slot) { return row * (WCH * 2) + (((slot) ^ (row & 15)) << 4); }
+// NF4 chunks are parked by eight lanes per row that own FOUR consecutive slots each (32 k = 16 bytes of codes per lane): with the
+// layout above the eight lanes of a write group would hit two bank groups.  The 4 x 8 slot grid of a row is transposed instead —
+// slot 4c + j lives at c + 8j — and XOR-ed with row & 7 inside the low three bits: the parked slots of a step (same j, c = 0..7) and
+// the fragment reads of a step (same slot, rows 0..7 | 8..15) both cover eight distinct 16-byte bank groups.
+__device__ __forceinline__ int wslot4(int row, int slot) { return row * (WCH * 2) + (((((slot >> 2) | ((slot & 3) << 3))) ^ (row & 7)) << 4); }
 // x image: element offset of 16-byte slot `slot` of row `row` (row stride = ks elements, a multiple of 256)
 __device__ __forceinline__ int xslot(int row, int srow, int slot) { return row * srow + ((slot ^ (row & 15)) << 3); }
 
@@ -70,11 +75,15 @@ constexpr int FUSE_PNZ = 6;         // slabs of the previous launch the prologue
 // W8: the weights are OCP e4m3 bytes [Ntot][K] with one fp32 scale per output row (W[n,k] = e4m3(Wq[n,k]) * wscale[n]): a chunk
 // is 4 KiB of HBM traffic instead of 8, converted to bf16 (exact) in registers on its way into the wave's LDS tile, so the MFMA
 // loop is the bf16 one; the row scale multiplies the fp32 accumulators when a tile's partials are stored.
-template <int MT, int DEPTH, int MAXT, bool W8, int FUSE = FUSE_NONE>
+// WQ: 0 = bf16 weights, 1 = one byte per weight (e4m3 | int8: `wf`), 2 = NF4 (two codes per byte, wscale = absmax [Ntot][K / 64]:
+// a chunk is 2 KiB of codes, every lane owns 32 k of one row = one 64-element block, decoded through the block's value table —
+// w8_codec.h — on its way into the wave's LDS tile; the products need no scale afterwards).
+template <int MT, int DEPTH, int MAXT, int WQ, int FUSE = FUSE_NONE>
 __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __restrict__ Y, int64_t y_lo,
                                                                const void* __restrict__ Wv, const float* __restrict__ wscale,
                                                                float* __restrict__ P, int64_t p_slab, int M, int Ntot, int K, int ks,
                                                                StreamFuse f = StreamFuse{}, int wf = MN_W_FP8_E4M3) {
+  constexpr bool W8 = WQ == 1, W4 = WQ == 2;
   const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(Wv);
   const uint8_t* __restrict__ Wq = reinterpret_cast<const uint8_t*>(Wv);
   extern __shared__ __attribute__((aligned(16))) bf16_t xs_raw[];      // [2][16*MT][ks] x image, then nw x 8 KiB weight tiles
@@ -150,15 +159,22 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
     }
   }
   // ---- weight ring: one chunk (8 KiB per wave) in flight in registers
-  constexpr int NI = W8 ? 4 : 8;                    // 16-byte loads per lane and chunk
+  constexpr int NI = W4 ? 2 : (W8 ? 4 : 8);         // 16-byte loads per lane and chunk
   u32x4 ring[DEPTH][NI];
+  float ringa[DEPTH][W4 ? NI : 1];                  // NF4: the absmax of the block each load lies in
   int it = t0, ich = 0;                             // issue cursor (tile, chunk), tile-major
   // bf16: instruction i of a chunk: rows (i & 1) * 8 + r8, 16-byte slot (i >> 1) * 8 + c8 — whole 128-byte lines
   // fp8:  instruction i: rows i * 4 + fq, bytes fr * 16 .. + 16 of the row's 256 (two whole lines per row)
-  auto issue = [&](u32x4 (&dst)[NI]) {
+  // nf4:  instruction i: rows i * 8 + r8, bytes c8 * 16 .. + 16 of the row's 128 (one whole line per row) = k c8 * 32 .. + 32
+  auto issue = [&](u32x4 (&dst)[NI], float (&dsta)[W4 ? NI : 1]) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      if constexpr (W8) {
+      if constexpr (W4) {
+        const int n = min(it * 16 + i * 8 + r8, Ntot - 1);
+        const int k = k0 + min(ich * WCH + c8 * 32, klen - 32);
+        dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wq + (((int64_t)n * K + k) >> 1)));
+        dsta[i] = wscale[(int64_t)n * (K >> 6) + (k >> 6)];
+      } else if constexpr (W8) {
         const int n = min(it * 16 + i * 4 + fq, Ntot - 1);
         const int k = min(ich * WCH + fr * 16, klen - 16);
         dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wq + (int64_t)n * K + k0 + k));
@@ -174,7 +190,7 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
   };
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
-    if (d < total) issue(ring[d]);
+    if (d < total) issue(ring[d], ringa[d]);
   if constexpr (FUSE == FUSE_NONE) {
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
@@ -214,7 +230,17 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
       const int q = q0 + d;
       if (q < total) {
         // park the landed chunk in the wave's LDS tile ...
-        if constexpr (W8) {                          // 16 e4m3 -> 16 bf16 = the row's slots 2 fr and 2 fr + 1
+        if constexpr (W4) {                          // 32 codes -> 32 bf16 = the row's slots 4 c8 .. 4 c8 + 3
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const Nf4Tab tb = nf4_table(ringa[d][i]);
+            const int row = i * 8 + r8;
+            *reinterpret_cast<u32x4*>(wbuf + wslot4(row, 4 * c8 + 0)) = nf4x8_to_bf16(tb, ring[d][i].x);
+            *reinterpret_cast<u32x4*>(wbuf + wslot4(row, 4 * c8 + 1)) = nf4x8_to_bf16(tb, ring[d][i].y);
+            *reinterpret_cast<u32x4*>(wbuf + wslot4(row, 4 * c8 + 2)) = nf4x8_to_bf16(tb, ring[d][i].z);
+            *reinterpret_cast<u32x4*>(wbuf + wslot4(row, 4 * c8 + 3)) = nf4x8_to_bf16(tb, ring[d][i].w);
+          }
+        } else if constexpr (W8) {                   // 16 e4m3 -> 16 bf16 = the row's slots 2 fr and 2 fr + 1
           // every other quad of lanes stores its odd slot first: the 8 lanes of one LDS write group (same row) then cover
           // slots {0, 2, 4, 6, 9, 11, 13, 15} (mod 16) = 8 distinct 16-byte bank groups
           auto park8 = [&](auto i8) {
@@ -234,11 +260,11 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
             *reinterpret_cast<u32x4*>(wbuf + wslot((i & 1) * 8 + r8, (i >> 1) * 8 + c8)) = ring[d][i];
         }
         // ... refill its registers with the chunk DEPTH ahead ...
-        if (q + DEPTH < total) issue(ring[d]);
+        if (q + DEPTH < total) issue(ring[d], ringa[d]);
         // ... and multiply: 8 MFMA steps of 32 k (columns >= klen of x are zero in LDS)
 #pragma unroll
         for (int sstep = 0; sstep < 8; ++sstep) {
-          const bf16x8 w = *reinterpret_cast<const bf16x8*>(wbuf + wslot(fr, sstep * 4 + fq));
+          const bf16x8 w = *reinterpret_cast<const bf16x8*>(wbuf + (W4 ? wslot4(fr, sstep * 4 + fq) : wslot(fr, sstep * 4 + fq)));
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             if (mt < mtn) {
@@ -274,6 +300,7 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
 }
 
 struct StreamPlan { int ks, nw, gx, nz; size_t lds; };
+static inline int wq_of(int wfmt) { return wfmt == MN_W_NF4 ? 2 : (wfmt ? 1 : 0); }
 
 // Tuning knobs for in-process A/B (not part of the stable ABI): force the slice length (in 256-k chunks) and the
 // waves per workgroup.
@@ -284,9 +311,9 @@ int g_kch = 0, g_nw = 0, g_tune_K = 0, g_w8_depth = 1;      // fp8: one 4 KiB ch
 // waves + its x image + its share of the partial slabs (written here, read back by the reducing kernel).
 // E.g. RF w12 (1024 tiles x 12 chunks) runs as 4 slices of 768 x 64 workgroups x 8 waves = exactly 2 tiles per wave,
 // RF w3 (192 tiles x 32 chunks) as 16 slices of 512 x 16 workgroups x 12 waves = exactly 1 tile per wave.
-StreamPlan stream_plan(int mt, int Ntot, int K, int slots, bool w8 = false) {
+StreamPlan stream_plan(int mt, int Ntot, int K, int slots, int wq = 0) {      // wq: 0 bf16, 1 one byte per weight, 2 NF4
   const int ntiles = (Ntot + 15) / 16;
-  const double chunk_bytes = w8 ? 4096.0 : 8192.0;  // HBM bytes of one 16-row x 256-k weight chunk
+  const double chunk_bytes = wq == 2 ? 2304.0 : (wq ? 4096.0 : 8192.0);  // HBM bytes of one 16-row x 256-k weight chunk (NF4: codes + absmax)
   StreamPlan best{};
   double best_cost = 1e30;
   for (int kch = 1; kch <= MAX_KCH; ++kch) {
@@ -308,7 +335,7 @@ StreamPlan stream_plan(int mt, int Ntot, int K, int slots, bool w8 = false) {
   return best;
 }
 
-template <int MT, int DEPTH, int MAXT, bool W8>
+template <int MT, int DEPTH, int MAXT, int W8>
 void stream_launch_d(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, const void* W, const float* wscale, float* P,
                      int64_t p_slab, int M, int Ntot, int K, hipStream_t st, int wf = MN_W_FP8_E4M3) {
   static bool opted = false;
@@ -321,21 +348,21 @@ void stream_launch_d(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo,
                      wscale, P, p_slab, M, Ntot, K, pl.ks, StreamFuse{}, wf);
 }
 
-template <int MT, bool W8>
+template <int MT, int W8>       // W8 = the kernel's WQ: 0 bf16, 1 byte formats, 2 NF4
 void stream_launch(const StreamPlan& pl, int G, const bf16_t* Y, int64_t y_lo, const void* W, const float* wscale, float* P,
                    int64_t p_slab, int M, int Ntot, int K, hipStream_t st, int wf = MN_W_FP8_E4M3) {
   // 8-wave workgroups compile for 512 threads, larger ones for 1024
   // (a 2-deep ring measured 2-4 % slower at every shape: 20.4 vs 20.0 us on RF w12 at 16 rows, 24.6 vs 23.8 at 32)
-  if (W8 && g_w8_depth == 2) {
-    if (pl.nw <= 8) stream_launch_d<MT, (W8 ? 2 : 1), 512, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st, wf);
-    else stream_launch_d<MT, (W8 ? 2 : 1), 1024, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st, wf);
+  if (W8 == 1 && g_w8_depth == 2) {
+    if (pl.nw <= 8) stream_launch_d<MT, (W8 == 1 ? 2 : 1), 512, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st, wf);
+    else stream_launch_d<MT, (W8 == 1 ? 2 : 1), 1024, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st, wf);
     return;
   }
   if (pl.nw <= 8) stream_launch_d<MT, 1, 512, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st, wf);
   else stream_launch_d<MT, 1, 1024, W8>(pl, G, Y, y_lo, W, wscale, P, p_slab, M, Ntot, K, st, wf);
 }
 
-template <bool W8>
+template <int W8>
 void stream_launch_fused(const StreamPlan& pl, const void* W, const float* wscale, float* P, int M, int Ntot, int K, const StreamFuse& f,
                          hipStream_t st, int wf) {
   static bool opted[2] = {false, false};
@@ -357,16 +384,17 @@ void stream_launch_fused(const StreamPlan& pl, const void* W, const float* wscal
 
 // The launch plan of the fused form is the plain one's (same slices, same slabs).
 bool stream_fused_ok(int wfmt, int M, int Ntot, int K, int prev_nz) {
-  if (M < 1 || M > FUSE_MAX_ROWS || (K % (wfmt ? 16 : 8)) != 0 || prev_nz < 1 || prev_nz > FUSE_PNZ) return false;
-  const StreamPlan pl = stream_plan(1, Ntot, K, mn_num_cus(), wfmt != 0);
+  if (M < 1 || M > FUSE_MAX_ROWS || (K % (wfmt == MN_W_NF4 ? 64 : (wfmt ? 16 : 8))) != 0 || prev_nz < 1 || prev_nz > FUSE_PNZ) return false;
+  const StreamPlan pl = stream_plan(1, Ntot, K, mn_num_cus(), wq_of(wfmt));
   return (int64_t)M * (pl.ks / 4) <= (int64_t)pl.nw * 64;      // one float4 element of the x image per thread
 }
 
 int stream_fused(int wfmt, const void* W, const float* wscale, float* P, int M, int Ntot, int K, const StreamFuse& f, void* stream) {
   MN_CHECK_ARG(W && P && f.pP && stream_fused_ok(wfmt, M, Ntot, K, f.pnz) && (!wfmt || wscale), "stream_fused: shape cannot run fused");
-  const StreamPlan pl = stream_plan(1, Ntot, K, mn_num_cus(), wfmt != 0);
-  if (wfmt) stream_launch_fused<true>(pl, W, wscale, P, M, Ntot, K, f, mn_stream(stream), wfmt);
-  else stream_launch_fused<false>(pl, W, wscale, P, M, Ntot, K, f, mn_stream(stream), 0);
+  const StreamPlan pl = stream_plan(1, Ntot, K, mn_num_cus(), wq_of(wfmt));
+  if (wfmt == MN_W_NF4) stream_launch_fused<2>(pl, W, wscale, P, M, Ntot, K, f, mn_stream(stream), wfmt);
+  else if (wfmt) stream_launch_fused<1>(pl, W, wscale, P, M, Ntot, K, f, mn_stream(stream), wfmt);
+  else stream_launch_fused<0>(pl, W, wscale, P, M, Ntot, K, f, mn_stream(stream), 0);
   MN_CHECK_LAUNCH("stream_fused");
   return pl.nz;
 }
@@ -381,10 +409,12 @@ extern "C" int mn_stream_mfma_slices(int M, int Ntot, int K) {
   if (M > 32) return mn_stream_kloop_slices(M, Ntot, K);
   return stream_plan(M > 16 ? 2 : 1, Ntot, K, mn_num_cus()).nz;
 }
-extern "C" int mn_stream_mfma_w8_slices(int M, int Ntot, int K) {
-  if (M > 32) return mn_stream_kloop_w8_slices(M, Ntot, K);
-  return stream_plan(M > 16 ? 2 : 1, Ntot, K, mn_num_cus(), true).nz;
+extern "C" int mn_stream_mfma_wq_slices(int wfmt, int M, int Ntot, int K) {
+  if (wfmt == MN_W_BF16) return mn_stream_mfma_slices(M, Ntot, K);
+  if (M > 32) return mn_stream_kloop_wq_slices(wfmt, M, Ntot, K);
+  return stream_plan(M > 16 ? 2 : 1, Ntot, K, mn_num_cus(), wq_of(wfmt)).nz;
 }
+extern "C" int mn_stream_mfma_w8_slices(int M, int Ntot, int K) { return mn_stream_mfma_wq_slices(MN_W_FP8_E4M3, M, Ntot, K); }
 
 // Dense: Y [2][M][K] bf16 (hi rows then lo rows), W [Ntot][K], P [nz][M][Ntot].  Returns nz (< 0: error).
 extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, int M, int Ntot, int K, void* stream) {
@@ -392,8 +422,8 @@ extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, in
   if (M > 32) return mn_stream_kloop(Y, W, P, M, Ntot, K, stream);      // 33..64 rows: K-loop form, two tiles per wave
   const int mt = M > 16 ? 2 : 1;
   const StreamPlan pl = stream_plan(mt, Ntot, K, mn_num_cus());
-  if (mt == 1) stream_launch<1, false>(pl, 1, Y, (int64_t)M * K, W, nullptr, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream));
-  else stream_launch<2, false>(pl, 1, Y, (int64_t)M * K, W, nullptr, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream));
+  if (mt == 1) stream_launch<1, 0>(pl, 1, Y, (int64_t)M * K, W, nullptr, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream));
+  else stream_launch<2, 0>(pl, 1, Y, (int64_t)M * K, W, nullptr, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream));
   MN_CHECK_LAUNCH("mn_stream_mfma");
   return pl.nz;
 }
@@ -403,12 +433,16 @@ extern "C" int mn_stream_mfma(const uint16_t* Y, const uint16_t* W, float* P, in
 extern "C" int mn_stream_mfma_wq(const uint16_t* Y, const uint8_t* Wq, const float* wscale, float* P, int M, int Ntot, int K, int wfmt,
                                  void* stream) {
   MN_CHECK_ARG(Y && Wq && wscale && P && M >= 1 && M <= 64 && Ntot >= 1 && K >= 16 && (K % 16) == 0 && (((uintptr_t)Wq) & 15) == 0 &&
-                   (wfmt == MN_W_FP8_E4M3 || wfmt == MN_W_INT8), "mn_stream_mfma_wq: bad args (K %% 16 == 0, 16-byte aligned weights, wfmt 1 | 2)");
+                   (wfmt == MN_W_FP8_E4M3 || wfmt == MN_W_INT8 || (wfmt == MN_W_NF4 && (K % 64) == 0)),
+               "mn_stream_mfma_wq: bad args (K %% 16 == 0 — NF4: %% 64 —, 16-byte aligned weights, wfmt 1 | 2 | 3)");
   if (M > 32) return mn_stream_kloop_wq(Y, Wq, wscale, P, M, Ntot, K, wfmt, stream);
   const int mt = M > 16 ? 2 : 1;
-  const StreamPlan pl = stream_plan(mt, Ntot, K, mn_num_cus(), true);
-  if (mt == 1) stream_launch<1, true>(pl, 1, Y, (int64_t)M * K, Wq, wscale, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream), wfmt);
-  else stream_launch<2, true>(pl, 1, Y, (int64_t)M * K, Wq, wscale, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream), wfmt);
+  const StreamPlan pl = stream_plan(mt, Ntot, K, mn_num_cus(), wq_of(wfmt));
+  if (wfmt == MN_W_NF4) {
+    if (mt == 1) stream_launch<1, 2>(pl, 1, Y, (int64_t)M * K, Wq, wscale, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream), wfmt);
+    else stream_launch<2, 2>(pl, 1, Y, (int64_t)M * K, Wq, wscale, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream), wfmt);
+  } else if (mt == 1) stream_launch<1, 1>(pl, 1, Y, (int64_t)M * K, Wq, wscale, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream), wfmt);
+  else stream_launch<2, 1>(pl, 1, Y, (int64_t)M * K, Wq, wscale, P, (int64_t)M * Ntot, M, Ntot, K, mn_stream(stream), wfmt);
   MN_CHECK_LAUNCH("mn_stream_mfma_wq");
   return pl.nz;
 }

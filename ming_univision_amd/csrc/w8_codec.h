@@ -72,8 +72,8 @@ __device__ __forceinline__ void nf4_lut4(const Nf4Tab& t, uint32_t n, uint32_t& 
 }
 // one dword = eight codes of eight consecutive k -> eight bf16 = one MFMA fragment / one 16-byte LDS slot
 __device__ __forceinline__ mn_u4_t nf4x8_to_bf16(const Nf4Tab& t, uint32_t x) {
-  mn_u4_t o;
-  nf4_lut4(t, x & 0x0f0f0f0fu, o.x, o.y);
-  nf4_lut4(t, (x >> 4) & 0x0f0f0f0fu, o.z, o.w);
-  return o;
+  uint32_t a, b, c, d;
+  nf4_lut4(t, x & 0x0f0f0f0fu, a, b);
+  nf4_lut4(t, (x >> 4) & 0x0f0f0f0fu, c, d);
+  return mn_u4_t{a, b, c, d};
 }

@@ -8,11 +8,17 @@
 and `*.safetensors` shards keyed by the reference's parameter names; the tokenizer is read from the same
 directory when a `tokenizer.json` is present, otherwise the byte-level stand-in is used.
 
-`dtype` is the reference's weight-format switch (:46-70: "bf16", or weight-only "int8" / "int4" through quanto / bitsandbytes).
-Here: "bf16" (default), "int8" — the reference's quanto mode restated: weight-only int8 with one (power-of-two) scale per output row —,
-and "fp8" — weight-only OCP e4m3 with one scale per output row for the decoder stack's experts and the RF
-head's ResBlock matrices (95 % of the bytes a visual token streams), quantised once at load from the same bf16 checkpoint; the
-arithmetic (fp32 / bf16 hi+lo activations, bf16 MFMA, fp32 accumulate) is unchanged.  "int8" / "int4" are not built.
+`dtype` is the reference's weight-format switch (:46-70: "bf16", or weight-only "int8" / "int4" through quanto / bitsandbytes):
+  "bf16" (default);
+  "int4" — bitsandbytes NF4 restated: every nn.Linear weight (lm_head included — the reference passes its own
+           skip list, which replaces HF's default one) becomes bf16(NF4[code] * absmax) with one fp32 absmax per 64 weights.  The RF
+           head's ResBlock / adaLN matrices and the decoder's experts — 95 % of the bytes a visual token streams — live in HBM as 4-bit
+           codes and are decoded inside the weight-streaming kernels; the other Linears hold the same model's values as bf16;
+  "int8" — weight-only int8 with one scale per output row for the experts and the RF ResBlock matrices (power-of-two scales: this
+           library's byte codec, NOT optimum-quanto's amax / 127 rule — see DESIGN.md);
+  "fp8"  — the same tensors as OCP e4m3 bytes + power-of-two row scales (no reference counterpart).
+All modes quantise once at load from the same bf16 checkpoint; the arithmetic (fp32 / bf16 hi+lo activations, bf16 MFMA, fp32
+accumulate) is unchanged.
 """
 import glob
 import os
@@ -63,9 +69,8 @@ class HFTokenizerAdapter:
 
 class MingUniVisionInfer:
     def __init__(self, model_name_or_path=None, dtype="bf16", device="cuda", config=None, seed=0, t_max=4096):
-        if dtype not in ("bf16", "fp8", "int8"):
-            raise NotImplementedError(f"dtype={dtype!r}: 'bf16', 'fp8' (weight-only e4m3) or 'int8' (weight-only int8, the reference's "
-                                      "quanto mode); the int4 (bitsandbytes nf4) mode is not built")
+        if dtype not in ("bf16", "fp8", "int8", "int4"):
+            raise ValueError(f"dtype={dtype!r}: 'bf16', 'int4' (bitsandbytes NF4), 'int8' or 'fp8' (weight-only byte formats)")
         self.model_name_or_path = model_name_or_path
         self.dtype = dtype
         self.model, self.tokenizer, self.processor = self.load_model_processor(config, device, seed, t_max)

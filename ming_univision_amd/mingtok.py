@@ -40,7 +40,7 @@ class SemDecodeState:
 class MingTok:
     config_class = MingTokConfig
 
-    def __init__(self, config: MingTokConfig, state_dict=None, device="cuda", seed=0, linear_proj=None, precision="bf16"):
+    def __init__(self, config: MingTokConfig, state_dict=None, device="cuda", seed=0, linear_proj=None, precision="bf16", weights="bf16"):
         """state_dict: reference-named tensors (any float dtype; stored as bf16 in HBM); None -> synthetic.
         linear_proj: optional list of (weight, bias) bf16 CUDA tensors (modeling_bailingmm.py:111-115)
         fused behind the decode step.
@@ -68,6 +68,11 @@ class MingTok:
             if missing:
                 raise KeyError(f"MingTok state dict is missing {missing[:5]}…")
             self.sd = {k: state_dict[k].to(self.device, torch.bfloat16).contiguous() for k in shapes}
+        # weight-only modes that convert every nn.Linear (_lib.FULL_MODEL: the reference's int4 / int8 loads walk the vision tower too):
+        # MingTok's Linears hold the mode's bf16 values and stay on the bf16 kernels (0.6 of the 37 GB a visual token reads).
+        # Not converted: the patch-embed Conv2d (4-D), LayerNorm gains, cls / pos / mask tokens.  `linear_proj` is the caller's.
+        self.weights = weights
+        self.sd = ops.convert_linears(self.sd, weights)
         self.enc_depth, self.sem_depth, self.pix_depth = enc.get("depth", 24), sem.get("decoder_depth", 1), pix.get("decoder_depth", 1)
         self.enc_dim, self.pix_dim = enc.get("embed_dim", 1024), pix.get("embed_dim", 1024)
         self._pos_cache = {}

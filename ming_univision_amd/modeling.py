@@ -95,9 +95,10 @@ class MingUniVisionForConditionalGeneration:
         else:
             lp = {k: bf(state_dict[k]) for k in lp_shapes}
             tok_sd = {k[len("vision."):]: v for k, v in state_dict.items() if k.startswith("vision.")}
+        lp = ops.convert_linears(lp, weights)               # int4 / int8: every nn.Linear of the model is converted (_lib.FULL_MODEL)
         self.linear_proj = [(lp[f"linear_proj.{2 * i}.weight"], lp[f"linear_proj.{2 * i}.bias"])
                             for i in range(config.mlp_depth)]
-        self.vision = MingTok(tcfg, state_dict=tok_sd, device=self.device, seed=seed, linear_proj=self.linear_proj)
+        self.vision = MingTok(tcfg, state_dict=tok_sd, device=self.device, seed=seed, linear_proj=self.linear_proj, weights=weights)
         if state_dict is None:
             self.model = BailingMoeDecoder.synthetic(cfg, self.device, seed=seed, t_max=t_max, n_seq=3, weights=weights)
             shapes = llm_param_shapes(cfg, config.vishead_diffloss_config, self.vision.latent_dim)

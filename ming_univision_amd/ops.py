@@ -44,7 +44,7 @@ def skinny_gemm(x, w, bias=None, *, prologue="none", epilogue="none", out=None, 
     N = w.shape[0] // 2 if epilogue == "swiglu" else w.shape[0]
     if n_out is not None:
         N = n_out
-    assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1
+    assert w.shape[1] == (K // 2 if (wscale is not None and wfmt == "int4") else K) and x.stride(1) == 1 and w.stride(1) == 1
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=x.device)
     a = SkinnyArgs()
@@ -65,9 +65,10 @@ def skinny_gemm(x, w, bias=None, *, prologue="none", epilogue="none", out=None, 
         a.gate, a.ldgate = ptr(gate), gate.stride(0)
     ws = None
     if wscale is not None:
-        assert wscale.numel() == w.shape[0] and w.is_contiguous()
+        assert wscale.numel() == w.shape[0] * (K // 64 if wfmt == "int4" else 1) and w.is_contiguous()
         a.wfmt, a.wscale = _lib.WFMT[wfmt], ptr(wscale)
-        nb = lib().mn_skinny_workspace_bytes_w8(M, N, K, a.epilogue)
+        a.ldw = K
+        nb = lib().mn_skinny_workspace_bytes_wq(a.wfmt, M, N, K, a.epilogue)
     else:
         nb = lib().mn_skinny_workspace_bytes(M, N, K, a.epilogue)
     if nb > 0 and (M > 8 or use_mfma_route or wscale is not None):
@@ -472,11 +473,36 @@ def dequant_fp8_rows(q, scale):
     return w
 
 
+def quant_nf4_rows(w):
+    """bf16 [..., N, K] (K % 64 == 0) -> (codes uint8 [..., N, K / 2] in the kernels' nibble order, absmax fp32 [..., N, K / 64]):
+    bitsandbytes NF4, blocks of 64 consecutive k (mn_quant_nf4_rows; held bit for bit to the CPU oracle's restatement by the tests)."""
+    _req(w, torch.bfloat16, "w")
+    K = w.shape[-1]
+    assert w.is_contiguous() and K % 64 == 0
+    q = torch.empty(w.shape[:-1] + (K // 2,), dtype=torch.uint8, device=w.device)
+    absmax = torch.empty(w.shape[:-1] + (K // 64,), dtype=torch.float32, device=w.device)
+    check(lib().mn_quant_nf4_rows(ptr(w), K, ptr(q), K // 2, ptr(absmax), w.numel() // K, K, current_stream()), "mn_quant_nf4_rows")
+    return q, absmax
+
+
+def dequant_nf4_rows(q, absmax):
+    """-> bf16 [..., N, K] = bf16_rne(NF4[code] * absmax): the int4 model's weights (what bitsandbytes' dequantize_4bit gives in bf16)."""
+    _req(q, torch.uint8, "q"); _req(absmax, torch.float32, "absmax")
+    K = q.shape[-1] * 2
+    assert q.is_contiguous() and absmax.is_contiguous() and tuple(absmax.shape) == tuple(q.shape[:-1]) + (K // 64,)
+    w = torch.empty(q.shape[:-1] + (K,), dtype=torch.bfloat16, device=q.device)
+    check(lib().mn_dequant_nf4_rows(ptr(q), K // 2, ptr(absmax), ptr(w), K, q.numel() // (K // 2), K, current_stream()), "mn_dequant_nf4_rows")
+    return w
+
+
 def quant_rows(w, fmt):
-    """bf16 [..., N, K] -> (bytes uint8 [..., N, K], fp32 power-of-two scales [..., N]) in the 8-bit format `fmt` ("fp8": OCP e4m3,
-    "int8": two's complement in [-127, 127]); bytes * scale is exactly representable in bf16 in both."""
+    """bf16 [..., N, K] -> (codes uint8, fp32 scale table) in the weight-only format `fmt`: "fp8" (OCP e4m3 bytes [..., N, K] + one
+    power-of-two scale per row [..., N]), "int8" (two's complement bytes + one scale per row), "int4" (NF4: [..., N, K / 2] + absmax
+    [..., N, K / 64])."""
     if fmt == "fp8":
         return quant_fp8_rows(w)
+    if fmt == "int4":
+        return quant_nf4_rows(w)
     assert fmt == "int8", fmt
     _req(w, torch.bfloat16, "w")
     assert w.is_contiguous() and w.shape[-1] % 4 == 0
@@ -488,9 +514,11 @@ def quant_rows(w, fmt):
 
 
 def dequant_rows(q, scale, fmt):
-    """The inverse of quant_rows: bf16 [..., N, K], exact."""
+    """The inverse of quant_rows: the bf16 weights [..., N, K] the kernels multiply with."""
     if fmt == "fp8":
         return dequant_fp8_rows(q, scale)
+    if fmt == "int4":
+        return dequant_nf4_rows(q, scale)
     assert fmt == "int8", fmt
     _req(q, torch.uint8, "q"); _req(scale, torch.float32, "scale")
     assert q.is_contiguous() and scale.is_contiguous() and tuple(scale.shape) == tuple(q.shape[:-1])
@@ -500,14 +528,36 @@ def dequant_rows(q, scale, fmt):
     return w
 
 
+def fake_quant(w, fmt):
+    """bf16 weights -> the bf16 weights of the `fmt` model (quantise, de-quantise): what a converted Linear that stays on the bf16
+    kernels holds.  "int4" blocks run over the FLATTENED tensor like bitsandbytes' (64 consecutive elements, whatever the row
+    length; a last partial block is padded with zeros, which changes neither its absmax nor its codes)."""
+    w = w.contiguous()
+    if fmt != "int4" or w.shape[-1] % 64 == 0:
+        return dequant_rows(*quant_rows(w, fmt), fmt)
+    n = w.numel()
+    flat = torch.zeros((n + 63) // 64 * 64, dtype=w.dtype, device=w.device)
+    flat[:n] = w.reshape(-1)
+    return dequant_rows(*quant_rows(flat.view(-1, 64), fmt), fmt).reshape(-1)[:n].reshape(w.shape).contiguous()
+
+
+def convert_linears(sd, fmt, skip=()):
+    """{name: bf16 tensor} -> the same dict with every nn.Linear weight (2-D `*.weight`; `skip`: name fragments to leave alone, e.g.
+    embeddings and the router gates, which are not nn.Linear in the reference) replaced by its `fmt` model value."""
+    if fmt not in _lib.FULL_MODEL:
+        return sd
+    return {k: (fake_quant(v, fmt) if k.endswith(".weight") and v.dim() == 2 and not any(f in k for f in skip) else v) for k, v in sd.items()}
+
+
 def stream_mfma_w8(y2, q, scale, wfmt="fp8"):
-    """Weight-streaming MFMA launch on 8-bit weights (`wfmt`): y2 bf16 [2, M, K] (hi rows, lo rows), q uint8 [N, K], scale fp32 [N]
-    -> fp32 [M, N] (the K-slice partials summed here with torch: a test helper, the composites reduce them in their glue kernels)."""
+    """Weight-streaming MFMA launch on quantised weights (`wfmt`): y2 bf16 [2, M, K] (hi rows, lo rows), q uint8 [N, K] (int4: [N, K / 2]),
+    scale fp32 [N] (int4: absmax [N, K / 64]) -> fp32 [M, N] (the K-slice partials summed here with torch: a test helper, the composites
+    reduce them in their glue kernels)."""
     _req(y2, torch.bfloat16, "y2"); _req(q, torch.uint8, "q"); _req(scale, torch.float32, "scale")
     _, M, K = y2.shape
     N = q.shape[0]
-    assert y2.is_contiguous() and q.is_contiguous() and q.shape[1] == K
-    nz = lib().mn_stream_mfma_w8_slices(M, N, K)
+    assert y2.is_contiguous() and q.is_contiguous() and q.shape[1] == (K // 2 if wfmt == "int4" else K) and scale.is_contiguous()
+    nz = lib().mn_stream_mfma_wq_slices(_lib.WFMT[wfmt], M, N, K)
     P = torch.empty(nz, M, N, dtype=torch.float32, device=q.device)
     rc = lib().mn_stream_mfma_wq(ptr(y2), ptr(q), ptr(scale), ptr(P), M, N, K, _lib.WFMT[wfmt], current_stream())
     if rc < 0:

@@ -32,7 +32,7 @@ class RectifiedFlowHead:
     def __init__(self, sd, llm_hidden, vishead_diffloss_config=None, latent_dim=32, prefix="", weights="bf16"):
         """sd: {reference parameter name: bf16 CUDA tensor} holding `vis_head.*` and `diffloss.net.*`.
         weights: "bf16", or "fp8" = w12 / w3 quantised here to e4m3 + row scales (the bf16 originals are not kept)."""
-        assert weights in _lib.WFMT, f"weights={weights!r}: 'bf16', 'fp8' or 'int8'"
+        assert weights in _lib.WFMT, f"weights={weights!r}: 'bf16', 'fp8', 'int8' or 'int4'"
         self.weights = weights
         cfg = {**DEFAULT_VISHEAD_DIFFLOSS, **(vishead_diffloss_config or {})}
         assert cfg["vis_head_arch"] == "linear2-norm"          # modeling_bailing_moe.py:1568
@@ -43,7 +43,12 @@ class RectifiedFlowHead:
         self.hidden = swiglu_hidden(self.w, int(cfg["gen_method"].split("-")[1]))
         self.target = latent_dim
         self.llm_hidden = llm_hidden
-        g = lambda k: sd[prefix + k]
+        full = weights in _lib.FULL_MODEL      # the reference's modes convert EVERY nn.Linear of the head (w12 / w3 / adaLN as streamed codes
+        #                                        below; the small ones hold the mode's bf16 values and stay on the bf16 kernels)
+
+        def g(k):
+            t = sd[prefix + k]
+            return ops.fake_quant(t, weights) if (full and k.endswith(".weight") and t.dim() == 2) else t
         n = "diffloss.net."
         self.t = dict(
             vis_w=g("vis_head.0.weight"), vis_b=g("vis_head.0.bias"),
@@ -53,14 +58,15 @@ class RectifiedFlowHead:
             fin_w=g(n + "final_layer.linear.weight"), fin_b=g(n + "final_layer.linear.bias"),
         )
         blocks = [n + f"res_blocks.{i}." for i in range(self.depth)]
-        self.t["ada_w"] = torch.cat([g(b + "adaLN_modulation.1.weight") for b in blocks]
-                                    + [g(n + "final_layer.adaLN_modulation.1.weight")], 0).contiguous()
-        self.t["ada_b"] = torch.cat([g(b + "adaLN_modulation.1.bias") for b in blocks]
-                                    + [g(n + "final_layer.adaLN_modulation.1.bias")], 0).contiguous()
+        raw = lambda k: sd[prefix + k]          # the streamed matrices are quantised ONCE, into codes, by _finalize
+        self.t["ada_w"] = torch.cat([raw(b + "adaLN_modulation.1.weight") for b in blocks]
+                                    + [raw(n + "final_layer.adaLN_modulation.1.weight")], 0).contiguous()
+        self.t["ada_b"] = torch.cat([raw(b + "adaLN_modulation.1.bias") for b in blocks]
+                                    + [raw(n + "final_layer.adaLN_modulation.1.bias")], 0).contiguous()
         self.lists = dict(
-            ln_g=[g(b + "in_ln.weight") for b in blocks], ln_b=[g(b + "in_ln.bias") for b in blocks],
-            w12=[g(b + "mlp.w12.weight") for b in blocks], b12=[g(b + "mlp.w12.bias") for b in blocks],
-            w3=[g(b + "mlp.w3.weight") for b in blocks], b3=[g(b + "mlp.w3.bias") for b in blocks],
+            ln_g=[raw(b + "in_ln.weight") for b in blocks], ln_b=[raw(b + "in_ln.bias") for b in blocks],
+            w12=[raw(b + "mlp.w12.weight") for b in blocks], b12=[raw(b + "mlp.w12.bias") for b in blocks],
+            w3=[raw(b + "mlp.w3.weight") for b in blocks], b3=[raw(b + "mlp.w3.bias") for b in blocks],
         )
         for v in list(self.t.values()) + sum(self.lists.values(), []):
             assert v.is_cuda and v.dtype == torch.bfloat16 and v.is_contiguous()
@@ -71,17 +77,32 @@ class RectifiedFlowHead:
         freqs = torch.exp(-math.log(10000.0) * torch.arange(0, half, dtype=torch.float32) / half)
         args = ts[:, None].float() * freqs[None]
         femb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(dev)
+        self._time_embed_weights = {n + "time_embed.mlp.0.weight": g(n + "time_embed.mlp.0.weight"),
+                                    n + "time_embed.mlp.2.weight": g(n + "time_embed.mlp.2.weight")}
         temb = []
         for i in range(0, self.steps, 8):
-            h = ops.skinny_gemm(femb[i:i + 8].contiguous(), g(n + "time_embed.mlp.0.weight"),
+            h = ops.skinny_gemm(femb[i:i + 8].contiguous(), self._time_embed_weights[n + "time_embed.mlp.0.weight"],
                                 g(n + "time_embed.mlp.0.bias"), epilogue="silu")
-            temb.append(ops.skinny_gemm(h, g(n + "time_embed.mlp.2.weight"), g(n + "time_embed.mlp.2.bias")))
+            temb.append(ops.skinny_gemm(h, self._time_embed_weights[n + "time_embed.mlp.2.weight"], g(n + "time_embed.mlp.2.bias")))
         self.t["temb"] = torch.cat(temb, 0).contiguous()
-        self._finalize(weights)
+        fmt = weights
+        if weights == "int4" and (self.w % 64 or self.hidden % 64):
+            # NF4 blocks are 64 consecutive elements of the FLATTENED matrix: with rows that are not a multiple of 64 long they straddle
+            # rows, which the streaming kernels' per-row absmax tables cannot express — such a head keeps the int4 MODEL (same values,
+            # ops.fake_quant blocks the flattened tensor) as bf16 tensors on the bf16 route
+            self.lists = dict(self.lists)
+            for k in ("w12", "w3"):
+                self.lists[k] = [ops.fake_quant(w_, weights) for w_ in self.lists[k]]
+            A3 = 3 * self.w
+            self.t["ada_w"] = torch.cat([ops.fake_quant(self.t["ada_w"][i * A3:(i + 1) * A3], weights) for i in range(self.depth)]
+                                        + [ops.fake_quant(self.t["ada_w"][self.depth * A3:], weights)], 0).contiguous()
+            fmt = "bf16"
+        self._finalize(fmt)
+        self.weights = weights                       # the MODEL's mode; self.stream_fmt: what the streaming kernels read
 
     def _finalize(self, weights):
         """Quantise the ResBlock matrices when asked to and build the pointer table the C ABI takes."""
-        self.weights = weights
+        self.weights = self.stream_fmt = weights
         self.scales = {}
         if weights in _lib.W8:
             self.lists = dict(self.lists)
@@ -118,23 +139,29 @@ class RectifiedFlowHead:
         weights="int8", int8 — (this bf16 head stays usable)."""
         import copy
         assert self.weights == "bf16" and weights in _lib.W8
+        assert weights not in _lib.FULL_MODEL, "modes that convert every Linear are built by the constructor (weights=...) from the raw weights"
         new = copy.copy(self)
         new._finalize(weights)
         return new
 
     def weight_bytes_per_step(self, rows=2):
         """Weight bytes one Euler step must stream from HBM (bf16: 2 per ResBlock parameter; fp8: 1 + the row scales)."""
-        per_w = 1 if self.weights in _lib.W8 else 2
-        per_block = (2 * self.hidden * self.w + self.w * self.hidden) * per_w
-        if self.weights in _lib.W8:
-            per_block += (2 * self.hidden + self.w) * 4
+        n_w = 2 * self.hidden * self.w + self.w * self.hidden
+        if self.stream_fmt == "int4":
+            per_block = n_w // 2 + n_w // 64 * 4                       # codes + one fp32 absmax per 64 weights
+        else:
+            per_block = n_w * (1 if self.stream_fmt in _lib.W8 else 2)
+            if self.stream_fmt in _lib.W8:
+                per_block += (2 * self.hidden + self.w) * 4
         return self.depth * per_block + self.ada_bytes(rows)
 
     def ada_bytes(self, rows=2):
         """Bytes of the stacked adaLN matrix one visual token reads (once: all Euler steps in one launch): e4m3 in fp8 mode while
         steps x rows <= 64, else bf16."""
         n = self.t["ada_w"].numel()
-        return n + 4 * self.t["ada_w"].shape[0] if (self.weights in _lib.W8 and self.steps * rows <= 64) else 2 * n
+        if self.stream_fmt == "int4" and self.steps * rows <= 64:
+            return n // 2 + n // 64 * 4
+        return n + 4 * self.t["ada_w"].shape[0] if (self.stream_fmt in _lib.W8 and self.steps * rows <= 64) else 2 * n
 
     def dequantized_blocks(self):
         """fp8 mode: {reference parameter name: bf16 tensor} of the ResBlock matrices as the kernels see them (e4m3 * row scale,
@@ -143,9 +170,14 @@ class RectifiedFlowHead:
         out = {}
         for i in range(self.depth):
             for k, name in (("w12", "mlp.w12.weight"), ("w3", "mlp.w3.weight")):
-                out[f"diffloss.net.res_blocks.{i}.{name}"] = ops.dequant_rows(self.lists[k][i], self.scales[k][i], self.weights)
+                out[f"diffloss.net.res_blocks.{i}.{name}"] = (ops.dequant_rows(self.lists[k][i], self.scales[k][i], self.stream_fmt)
+                                                              if self.stream_fmt in _lib.W8 else self.lists[k][i])
             out[f"diffloss.net.res_blocks.{i}.adaLN_modulation.1.weight"] = self.t["ada_w"][i * 3 * self.w:(i + 1) * 3 * self.w]
         out["diffloss.net.final_layer.adaLN_modulation.1.weight"] = self.t["ada_w"][self.depth * 3 * self.w:]
+        if self.weights in _lib.FULL_MODEL:          # every nn.Linear of the head is converted: the small ones as bf16 values
+            out.update({"vis_head.0.weight": self.t["vis_w"], "diffloss.net.cond_embed.weight": self.t["cond_w"],
+                        "diffloss.net.input_proj.weight": self.t["in_w"], "diffloss.net.final_layer.linear.weight": self.t["fin_w"]})
+            out.update(self._time_embed_weights)
         return out
 
     def max_rows(self):

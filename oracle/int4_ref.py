@@ -71,8 +71,15 @@ def dequantize_blocks(codes, absmax):
 
 
 def fake_quant(w):
-    """W -> the int4 model's weight values (fp32 tensor of bf16 values)."""
-    return dequantize_blocks(*quantize_blocks(w))
+    """W (any shape) -> the int4 model's weight values (fp32 tensor of bf16 values).  bitsandbytes blocks the FLATTENED tensor: for
+    rows that are a multiple of 64 long that is the per-row blocking above; otherwise blocks straddle rows (e.g. the RF head's
+    input_proj [w, 32]) and a last partial block stands alone (zero padding changes neither its absmax nor its codes)."""
+    if w.shape[-1] % BLOCK == 0:
+        return dequantize_blocks(*quantize_blocks(w))
+    n = w.numel()
+    flat = torch.zeros((n + BLOCK - 1) // BLOCK * BLOCK)
+    flat[:n] = w.float().reshape(-1)
+    return dequantize_blocks(*quantize_blocks(flat.view(-1, BLOCK))).reshape(-1)[:n].reshape(w.shape)
 
 
 def pack_bnb(codes):
