@@ -43,12 +43,7 @@ class RectifiedFlowHead:
         self.hidden = swiglu_hidden(self.w, int(cfg["gen_method"].split("-")[1]))
         self.target = latent_dim
         self.llm_hidden = llm_hidden
-        full = weights in _lib.FULL_MODEL      # the reference's modes convert EVERY nn.Linear of the head (w12 / w3 / adaLN as streamed codes
-        #                                        below; the small ones hold the mode's bf16 values and stay on the bf16 kernels)
-
-        def g(k):
-            t = sd[prefix + k]
-            return ops.fake_quant(t, weights) if (full and k.endswith(".weight") and t.dim() == 2) else t
+        g = lambda k: sd[prefix + k]
         n = "diffloss.net."
         self.t = dict(
             vis_w=g("vis_head.0.weight"), vis_b=g("vis_head.0.bias"),
@@ -58,18 +53,33 @@ class RectifiedFlowHead:
             fin_w=g(n + "final_layer.linear.weight"), fin_b=g(n + "final_layer.linear.bias"),
         )
         blocks = [n + f"res_blocks.{i}." for i in range(self.depth)]
-        raw = lambda k: sd[prefix + k]          # the streamed matrices are quantised ONCE, into codes, by _finalize
-        self.t["ada_w"] = torch.cat([raw(b + "adaLN_modulation.1.weight") for b in blocks]
-                                    + [raw(n + "final_layer.adaLN_modulation.1.weight")], 0).contiguous()
-        self.t["ada_b"] = torch.cat([raw(b + "adaLN_modulation.1.bias") for b in blocks]
-                                    + [raw(n + "final_layer.adaLN_modulation.1.bias")], 0).contiguous()
+        self.t["ada_w"] = torch.cat([g(b + "adaLN_modulation.1.weight") for b in blocks]
+                                    + [g(n + "final_layer.adaLN_modulation.1.weight")], 0).contiguous()
+        self.t["ada_b"] = torch.cat([g(b + "adaLN_modulation.1.bias") for b in blocks]
+                                    + [g(n + "final_layer.adaLN_modulation.1.bias")], 0).contiguous()
         self.lists = dict(
-            ln_g=[raw(b + "in_ln.weight") for b in blocks], ln_b=[raw(b + "in_ln.bias") for b in blocks],
-            w12=[raw(b + "mlp.w12.weight") for b in blocks], b12=[raw(b + "mlp.w12.bias") for b in blocks],
-            w3=[raw(b + "mlp.w3.weight") for b in blocks], b3=[raw(b + "mlp.w3.bias") for b in blocks],
+            ln_g=[g(b + "in_ln.weight") for b in blocks], ln_b=[g(b + "in_ln.bias") for b in blocks],
+            w12=[g(b + "mlp.w12.weight") for b in blocks], b12=[g(b + "mlp.w12.bias") for b in blocks],
+            w3=[g(b + "mlp.w3.weight") for b in blocks], b3=[g(b + "mlp.w3.bias") for b in blocks],
         )
         for v in list(self.t.values()) + sum(self.lists.values(), []):
             assert v.is_cuda and v.dtype == torch.bfloat16 and v.is_contiguous()
+        self._time = {k: g(n + "time_embed.mlp." + k) for k in ("0.weight", "0.bias", "2.weight", "2.bias")}
+        self._raw_t, self._raw_lists = dict(self.t), dict(self.lists)      # the checkpoint's tensors: every mode is derived from them, once
+        self._apply_mode(weights)
+
+    def _apply_mode(self, weights):
+        """Build the head of weight mode `weights` from the raw bf16 tensors.  Modes that convert every nn.Linear (_lib.FULL_MODEL, the
+        reference's int4 / int8 loads): the small Linears (vis_head, cond_embed, input_proj, time_embed, final layer) hold the mode's
+        bf16 values and stay on the bf16 kernels; w12 / w3 / adaLN are quantised into streamed codes by _finalize."""
+        full = weights in _lib.FULL_MODEL
+        conv = (lambda t: ops.fake_quant(t, weights)) if full else (lambda t: t)
+        n = "diffloss.net."
+        self.t, self.lists = dict(self._raw_t), dict(self._raw_lists)
+        for k in ("vis_w", "cond_w", "in_w", "fin_w"):
+            self.t[k] = conv(self.t[k])
+        self._time_embed_weights = {n + "time_embed.mlp.0.weight": conv(self._time["0.weight"]),
+                                    n + "time_embed.mlp.2.weight": conv(self._time["2.weight"])}
         dev = self.t["vis_w"].device
         # time-embedding table for t_s = linspace(1, 0, steps+1)[:-1] (diff_loss_rf_swiglu.py:135, 372-373)
         ts = torch.linspace(1.0, 0.0, self.steps + 1)[:-1] * 1000.0
@@ -77,20 +87,17 @@ class RectifiedFlowHead:
         freqs = torch.exp(-math.log(10000.0) * torch.arange(0, half, dtype=torch.float32) / half)
         args = ts[:, None].float() * freqs[None]
         femb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(dev)
-        self._time_embed_weights = {n + "time_embed.mlp.0.weight": g(n + "time_embed.mlp.0.weight"),
-                                    n + "time_embed.mlp.2.weight": g(n + "time_embed.mlp.2.weight")}
         temb = []
         for i in range(0, self.steps, 8):
             h = ops.skinny_gemm(femb[i:i + 8].contiguous(), self._time_embed_weights[n + "time_embed.mlp.0.weight"],
-                                g(n + "time_embed.mlp.0.bias"), epilogue="silu")
-            temb.append(ops.skinny_gemm(h, self._time_embed_weights[n + "time_embed.mlp.2.weight"], g(n + "time_embed.mlp.2.bias")))
+                                self._time["0.bias"], epilogue="silu")
+            temb.append(ops.skinny_gemm(h, self._time_embed_weights[n + "time_embed.mlp.2.weight"], self._time["2.bias"]))
         self.t["temb"] = torch.cat(temb, 0).contiguous()
         fmt = weights
         if weights == "int4" and (self.w % 64 or self.hidden % 64):
             # NF4 blocks are 64 consecutive elements of the FLATTENED matrix: with rows that are not a multiple of 64 long they straddle
             # rows, which the streaming kernels' per-row absmax tables cannot express — such a head keeps the int4 MODEL (same values,
             # ops.fake_quant blocks the flattened tensor) as bf16 tensors on the bf16 route
-            self.lists = dict(self.lists)
             for k in ("w12", "w3"):
                 self.lists[k] = [ops.fake_quant(w_, weights) for w_ in self.lists[k]]
             A3 = 3 * self.w
@@ -135,13 +142,12 @@ class RectifiedFlowHead:
         self._ws = {}
 
     def to_fp8(self, weights="fp8"):
-        """A second head on the same HBM tensors whose ResBlock matrices are 8-bit copies — e4m3 (default) or, with
-        weights="int8", int8 — (this bf16 head stays usable)."""
+        """A second head on the same HBM tensors in another weight mode — e4m3 (default), "int8" or "int4" — derived from the raw
+        bf16 tensors (this head stays usable)."""
         import copy
         assert self.weights == "bf16" and weights in _lib.W8
-        assert weights not in _lib.FULL_MODEL, "modes that convert every Linear are built by the constructor (weights=...) from the raw weights"
         new = copy.copy(self)
-        new._finalize(weights)
+        new._apply_mode(weights)
         return new
 
     def weight_bytes_per_step(self, rows=2):

@@ -253,6 +253,9 @@ class TpDecoderShard:
         L = cfg.num_hidden_layers
         self.layers = getattr(self, "_shard_layers", None) or []
         self.weights = getattr(dec, "weights", "bf16")
+        if self.weights == "int4":
+            raise NotImplementedError("tensor parallel shards of an int4 (NF4) decoder: the shared expert's width is split into slices that "
+                                      "cut its 64-element absmax blocks; run int4 on one GPU (its point is the footprint) or shard bf16 / fp8 / int8")
         for ly in (dec.layers or []):
             self.layers.append(self._shard_layer(ly, cfg, rank, world))
         hd = cfg.head_dim
@@ -329,6 +332,7 @@ class TpDecoderShard:
                       gate=sd[p + ".mlp.gate.weight"], image_gate=sd.get(p + ".mlp.image_gate.weight") if cfg.multi_gate else None,
                       w_gate_up=gu, w_down=dn)
             if weights in _lib.W8:
+                assert weights != "int4", "int4 (NF4) shards are not built: see TpDecoderShard.__init__"
                 from .bailing_moe import quantize_layer_experts
                 quantize_layer_experts(ly, weights)
             self._shard_layers.append(cls._shard_layer(ly, cfg, rank, world))
@@ -381,6 +385,8 @@ class TpRfShard:
         self.lists = dict(rf.lists, w12=w12, b12=b12, w3=w3)
         self._arrays = {k: ptr_array(v) for k, v in self.lists.items()}
         self.weights = getattr(rf, "weights", "bf16")
+        if self.weights == "int4":
+            raise NotImplementedError("tensor parallel shards of an int4 (NF4) RF head are not built (see TpDecoderShard)")
         if self.weights in _lib.W8:      # row scales: w12's rows are sliced like its weights, w3's columns share the full rows' scales
             hid, n = rf.hidden, rf.hidden // world
             u0 = rank * n

@@ -229,9 +229,12 @@ def test_int4_facade_dtype_switch(tmp_path):
     odd = MingUniVisionInfer(None, dtype="int4", config=cfg_odd, seed=g["seed"], t_max=64)
     assert odd.model.rf.weights == "int4" and odd.model.rf.stream_fmt == "bf16" and odd.model.rf.lists["w3"][0].dtype == torch.bfloat16
     from oracle import int4_ref
-    from ming_univision_amd.synth import synth_tensor
-    raw = synth_tensor("diffloss.net.res_blocks.1.mlp.w3.weight", (64, 176), g["seed"], "cpu", torch.float32)
-    assert torch.equal(odd.model.rf.lists["w3"][1].float().cpu(), int4_ref.fake_quant(raw))
+    odd16 = MingUniVisionInfer(None, dtype="bf16", config=cfg_odd, seed=g["seed"], t_max=64)
+    raw = odd16.model.rf.lists["w3"][1].float().cpu()
+    assert raw.shape == (64, 176) and torch.equal(odd.model.rf.lists["w3"][1].float().cpu(), int4_ref.fake_quant(raw))
+    out_odd = odd.model.generate(input_ids=g["ids"], attention_mask=torch.ones_like(g["ids"]), max_new_tokens=2,
+                                 forced_first_token=llm_cfg["image_start_token"], output_image_prefix=str(tmp_path / "i4o"))
+    assert torch.isfinite(odd.model.last_generation["latents"]).all() and out_odd.shape[1] == g["ids"].shape[1] + 2
     assert not torch.equal(inf4.model.model.lm_head, inf16.model.model.lm_head)          # lm_head is converted too
     assert not torch.equal(inf4.model.vision.sd["semantic_decoder.in_proj.weight"], inf16.model.vision.sd["semantic_decoder.in_proj.weight"])
     assert torch.equal(inf4.model.model.layers[0]["gate"], inf16.model.model.layers[0]["gate"])     # the router gate is not an nn.Linear
