@@ -675,12 +675,13 @@ MN_API int mn_dequant_nf4_rows(const uint8_t* Wq, int64_t ldq, const float* absm
                                void* stream);
 /* K-slice count of a dense streaming launch in format wfmt (the slab count the caller's reducing kernel sees) */
 MN_API int mn_stream_mfma_wq_slices(int wfmt, int M, int Ntot, int K);
-/* MN_W_INT8 (round 4): the same weight-only mode on two's-complement int8 bytes — the reference's `dtype="int8"` surface
- * (mingunivisioninfer.py:59-68: optimum-quanto qint8 weights, symmetric, one scale per output channel; third-party, absent here) —
- *     W[n, k] = Wq[n, k] * scale[n],  Wq in [-127, 127],  scale[n] = 2^ceil(log2(amax_n / 127)).
- * The power-of-two scale (quanto uses amax / 127: at most one of the seven magnitude bits more) keeps W exactly representable in bf16,
- * like the e4m3 form.  Every `wfmt` field and the `_wq` entry points below take either format; kernels, row limits and call sites are
- * the fp8 mode's (the bytes are converted to bf16 / fp32 in registers: sign-extend + v_cvt_f32_i32). */
+/* MN_W_INT8: the reference's `dtype="int8"` surface (mingunivisioninfer.py:59-68: HF QuantoConfig(weights="int8") = optimum-quanto qint8
+ * weights; third-party, absent here; restated in oracle/int8_ref.py) — symmetric, one scale per output row, in the weight's dtype:
+ *     scale[n] = bf16(amax_n / 127),  q = clamp(round(bf16(W / scale)), -128, 127),  W'[n, k] = bf16_rne(q[n, k] * scale[n]).
+ * (Round 4 used power-of-two scales applied to the accumulators; round 5 follows quanto: the product is rounded to bf16 PER ELEMENT,
+ * as quanto's qbytes_mm multiplies scale * weights in the activation dtype before the matmul — so the row scale rides the byte
+ * conversion inside the kernels and nothing is scaled afterwards.)  Routes: the weight-streaming launches (<= 64 rows; experts on the
+ * grouped launch from one row on). */
 /* Row-wise quantisation at load: scale[n] = 2^ceil(log2(amax_n / 448)) (1 for an all-zero row), Wq[n, k] = e4m3_rne(W[n, k] / scale[n]).
  * W bf16 [n_rows, K] (row stride ldw), Wq bytes (row stride ldq), K % 4 == 0. */
 MN_API int mn_quant_fp8_rows(const uint16_t* W, int64_t ldw, uint8_t* Wq, int64_t ldq, float* scale, int64_t n_rows, int K, void* stream);
@@ -695,8 +696,7 @@ MN_API int mn_stream_mfma_wq(const uint16_t* Y, const uint8_t* Wq, const float* 
 MN_API int mn_stream_mfma_grouped_wq(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale,
                                      int64_t s_stride, float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G,
                                      int max_rows, int Ntot, int K, int wfmt, void* stream);
-/* int8 rows: scale[n] = 2^ceil(log2(amax_n / 127)) (1 for an all-zero row), Wq[n, k] = rne(W[n, k] / scale[n]) in [-127, 127]; and back
- * (exact in bf16).  Arguments as the fp8 pair. */
+/* int8 rows by quanto's rule (above; scale 1 for an all-zero row), and back.  Arguments as the fp8 pair. */
 MN_API int mn_quant_int8_rows(const uint16_t* W, int64_t ldw, uint8_t* Wq, int64_t ldq, float* scale, int64_t n_rows, int K, void* stream);
 MN_API int mn_dequant_int8_rows(const uint8_t* Wq, int64_t ldq, const float* scale, uint16_t* W, int64_t ldw, int64_t n_rows, int K,
                                 void* stream);

@@ -135,7 +135,7 @@ W8 = ("fp8", "int8", "int4")                   # the weight-only modes: codes (o
 # the "BailingAudioModel" entry matches no module path).  Not converted: nn.Embedding, Conv2d (patch embed), norms, biases, and the
 # router gates (BailingMoeGate holds a bare nn.Parameter, modeling_bailing_moe.py:497).  "fp8" is this library's own byte format for
 # the streamed tensors only (experts, RF ResBlocks, adaLN).
-FULL_MODEL = ("int4",)
+FULL_MODEL = ("int4", "int8")
 
 _lib = None
 

@@ -65,11 +65,22 @@ def pass_spans(starts, seqs, past, r0, r1):
             for i in range(len(starts) - 1) if min(starts[i + 1], r1) > max(starts[i], r0)]
 
 
-def quantize_layer_experts(ly, weights="fp8"):
-    """8-bit weight modes: replace a layer's packed bf16 experts by e4m3 ("fp8") or int8 bytes + row scales [E + S, 2I] / [E + S, H]
-    (in place)."""
+def quantize_layer_experts(ly, weights="fp8", n_shared=0):
+    """Weight-only modes: replace a layer's packed bf16 experts by codes — e4m3 ("fp8") or int8 bytes + row scales [E + S, 2I] /
+    [E + S, H], or NF4 codes [.., K / 2] + absmax [.., K / 64] ("int4") — in place.
+    int8 follows optimum-quanto (one scale per output row of the Linear): the shared expert's down projection is ONE Linear whose rows
+    run over all S column blocks of the packed layout, so its S pseudo-experts are quantised together and share their row scales
+    (n_shared = S; rows of gate / up are output units of their own, and NF4's 64-element blocks never cross the I-wide column blocks)."""
     for k in ("w_gate_up", "w_down"):
-        ly[k], ly[k + "_scale"] = ops.quant_rows(ly[k], weights)
+        w = ly[k]
+        ly[k], ly[k + "_scale"] = ops.quant_rows(w, weights)
+        if k == "w_down" and weights == "int8" and n_shared > 1:
+            E = w.shape[0] - n_shared
+            I = w.shape[2]
+            q, sc = ops.quant_rows(torch.cat([w[E + s] for s in range(n_shared)], dim=1).contiguous(), weights)     # [H, S * I]
+            for s in range(n_shared):
+                ly[k][E + s] = q[:, s * I:(s + 1) * I]
+                ly[k + "_scale"][E + s] = sc
     return ly
 
 
@@ -100,7 +111,7 @@ class BailingMoeDecoder:
         elif weights in _lib.W8:
             for ly in layers:
                 if ly["w_gate_up"].dtype != torch.uint8:
-                    quantize_layer_experts(ly, weights)
+                    quantize_layer_experts(ly, weights, cfg.num_shared_experts or 0)
         rs = cfg.rope_scaling
         assert rs is None or rs.get("type") == "3D", "Legacy or 3D rotary only (linear / NTK / YaRN are dead code, SURVEY.md a27)"
         # 3D rotary (:413-425, 463-469): same tables, per-frequency choice among the t / h / w position streams.
@@ -195,7 +206,7 @@ class BailingMoeDecoder:
                 w_gate_up=gu, w_down=dn))
             if kw.get("weights") in _lib.W8:        # layer by layer: the bf16 experts of one layer at a time
                 if not (kw["weights"] == "int4" and (cfg.hidden_size % 64 or cfg.moe_intermediate_size % 64)):   # (else: __init__ keeps values)
-                    quantize_layer_experts(layers[-1], kw["weights"])
+                    quantize_layer_experts(layers[-1], kw["weights"], cfg.num_shared_experts or 0)
                 cls._convert_linears(layers[-1:], kw["weights"])
             del sd, gu, dn
         H, V = cfg.hidden_size, cfg.vocab_size
@@ -216,7 +227,7 @@ class BailingMoeDecoder:
         """A second decoder whose experts are 8-bit copies of this one's — e4m3 (default) or int8 (weights="int8") — (attention /
         router / vocabulary tensors shared; this bf16 decoder stays usable): + 0.5 bytes per expert parameter of HBM."""
         assert self.weights == "bf16" and weights in _lib.W8
-        layers = self._convert_linears([quantize_layer_experts(dict(ly), weights) for ly in self.layers], weights)
+        layers = self._convert_linears([quantize_layer_experts(dict(ly), weights, self.n_shared) for ly in self.layers], weights)
         return BailingMoeDecoder(self.cfg, layers, self.final_norm, self.word_embeddings, self._convert_lm_head(self.lm_head, weights),
                                  t_max=t_max or self.t_max, n_seq=n_seq or self.n_seq, weights=weights)
 
@@ -448,8 +459,8 @@ class BailingMoeDecoder:
         embeds_list[i] fp32 [T_i,H] goes to cache sequence seqs[i] from slot `past`.  Returns the final-norm hidden state of
         the LAST token of each sequence [B,H] fp32 (what the next-token logits need)."""
         import math
-        if self.weights != "bf16":
-            # fp8 experts exist for the <= 64-row streaming route only: shared 64-row passes through the decode kernels instead
+        if self.stream_fmt != "bf16":
+            # quantised experts exist for the <= 64-row streaming route only: shared 64-row passes through the decode kernels instead
             assert positions is None and key_masks is None, "fp8 weight mode: default positions / masks only"
             return self.prefill_ragged(embeds_list, seqs, past=past, image_masks=image_masks)
         cfg, L_ = self.cfg, lib()

@@ -947,8 +947,9 @@ static size_t moe_carve(Carver& cv, int rows, int H, int I, int G, int n_slot, M
 
 // grouped-expert route from 3 rows (3 rows: 74.2 vs 70.6 tokens/s against the fp32-FMA pair kernels; 2 rows: 75.1 vs 76.8)
 constexpr int MOE_MFMA_MIN_ROWS = 3;
-// NF4 experts run the grouped streaming launch from ONE row on (the fp32-FMA pair kernels of 1- / 2-row steps read bf16 / byte rows)
-static inline int moe_mfma_min_rows(const mn_llm* m) { return m->wfmt == MN_W_NF4 ? 1 : MOE_MFMA_MIN_ROWS; }
+// NF4 / int8 experts run the grouped streaming launch from ONE row on: their products are rounded to bf16 per element (bitsandbytes' /
+// quanto's de-quantisation), which the fp32-FMA pair kernels of 1- / 2-row steps do not do
+static inline int moe_mfma_min_rows(const mn_llm* m) { return (m->wfmt == MN_W_NF4 || m->wfmt == MN_W_INT8) ? 1 : MOE_MFMA_MIN_ROWS; }
 static bool moe_mfma_ok(const mn_llm* m, int rows) {
   return rows >= moe_mfma_min_rows(m) && rows * (m->top_k + m->n_shared_slots) <= 1024 &&
          m->n_experts + m->n_shared_slots <= 256 && (m->hidden % 8) == 0 && (m->moe_inter % 8) == 0;   // % 4: vector glue

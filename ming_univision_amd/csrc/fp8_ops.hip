@@ -56,19 +56,12 @@ __global__ __launch_bounds__(256) void dequant_fp8_rows_kernel(const uint8_t* __
   }
 }
 
-// ---- int8 (MN_W_INT8): symmetric, one power-of-two scale per output row, q = rint(w / scale) in [-127, 127].
-// scale = 2^es with amax / 2^es in (63.5, 127]:  127 = 1.984375 * 2^6  ->  es = ea - 6 (+1 if ma > 1.984375).  |q| <= 127 is 7 bits, so
-// q * scale is exactly representable in bf16 like the e4m3 form's products: the int8 model is a bf16 model too.  (The reference's
-// int8 surface — optimum-quanto qint8 weights, mingunivisioninfer.py:59-68 — scales by amax / 127; the power of two costs at most one
-// of the 7 bits and buys that exactness.)
-__device__ __forceinline__ float pow2_scale_int8(float amax) {
-  const uint32_t u = __float_as_uint(amax);
-  if ((u & 0x7fffffffu) == 0u) return 1.0f;
-  int es = (int)(u >> 23) - 127 - 6 + ((u & 0x7fffffu) > 0x7e0000u ? 1 : 0);
-  es = es < -126 ? -126 : (es > 127 ? 127 : es);
-  return __uint_as_float((uint32_t)(es + 127) << 23);
-}
-
+// ---- int8 (MN_W_INT8): optimum-quanto's qint8 weights (the reference's dtype="int8", mingunivisioninfer.py:59-68; restated in
+// oracle/int8_ref.py): symmetric, one scale per output row, everything in the weight's dtype (bf16):
+//     scale[n] = bf16(amax_n / 127)            (absmax_scale: qranges / qmax on a bf16 tensor)
+//     q[n, k]  = clamp(round_half_even(bf16(W[n, k] / scale[n])), -128, 127)      (quantize_symmetric: base / scale is a bf16 tensor)
+//     W'[n, k] = bf16(q[n, k] * scale[n])      (qbytes_mm multiplies scale * weights in the activation dtype before the matmul)
+// The scale is stored as fp32 holding the bf16 value.
 __global__ __launch_bounds__(256) void quant_int8_rows_kernel(const bf16_t* __restrict__ W, int64_t ldw, uint8_t* __restrict__ Q, int64_t ldq,
                                                               float* __restrict__ scale, int K) {
   __shared__ float red[4];
@@ -81,10 +74,10 @@ __global__ __launch_bounds__(256) void quant_int8_rows_kernel(const bf16_t* __re
     amax = fmaxf(amax, fmaxf(fmaxf(fabsf(bf16lo_to_f32(v.x)), fabsf(bf16hi_to_f32(v.x))), fmaxf(fabsf(bf16lo_to_f32(v.y)), fabsf(bf16hi_to_f32(v.y)))));
   }
   amax = block_max(amax, red);
-  const float s = pow2_scale_int8(amax);
-  const float inv = 1.0f / s;                          // exact: s is a power of two
+  float s = bf16_to_f32(f32_to_bf16(amax / 127.0f));
+  if (s == 0.f) s = 1.0f;                               // an all-zero row (or an amax that underflows bf16): q = 0
   if (threadIdx.x == 0) scale[n] = s;
-  auto q8 = [&](float w) { return (uint32_t)((int)fminf(fmaxf(rintf(w * inv), -127.f), 127.f) & 0xff); };      // round to nearest even
+  auto q8 = [&](float w) { return (uint32_t)((int)fminf(fmaxf(rintf(bf16_to_f32(f32_to_bf16(w / s))), -128.f), 127.f) & 0xff); };
   for (int k = threadIdx.x * 4; k < K; k += 1024) {
     const u2 v = *reinterpret_cast<const u2*>(wr + k);
     *reinterpret_cast<uint32_t*>(Q + n * ldq + k) =
@@ -98,12 +91,10 @@ __global__ __launch_bounds__(256) void dequant_int8_rows_kernel(const uint8_t* _
   const int64_t n = blockIdx.x;
   const float s = scale[n];
   for (int k = threadIdx.x * 4; k < K; k += 1024) {
-    const int q = *reinterpret_cast<const int*>(Q + n * ldq + k);
-    const float f0 = (float)((q << 24) >> 24), f1 = (float)((q << 16) >> 24), f2 = (float)((q << 8) >> 24), f3 = (float)(q >> 24);
-    *reinterpret_cast<u2*>(W + n * ldw + k) = u2{cvt_pk_bf16(f0 * s, f1 * s), cvt_pk_bf16(f2 * s, f3 * s)};
+    const mn_u2_t o = i8x4_to_bf16(*reinterpret_cast<const uint32_t*>(Q + n * ldq + k), s);      // the kernels' own conversion (w8_codec.h)
+    *reinterpret_cast<u2*>(W + n * ldw + k) = u2{o.x, o.y};
   }
 }
-
 
 // ---- NF4 (MN_W_NF4): bitsandbytes' blockwise 4-bit NormalFloat (oracle/int4_ref.py; mingunivisioninfer.py:46-58).  One thread owns
 // eight consecutive k (one dword of codes), eight threads one 64-element block: absmax by three xor-shuffles, x = w * (1 / absmax) in fp32,

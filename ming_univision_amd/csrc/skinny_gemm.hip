@@ -365,7 +365,8 @@ extern "C" int mn_skinny_gemm(const mn_skinny_args* args, void* stream) {
   ka.nseg = a.nseg > 0 ? a.nseg : 1;
   ka.batch = a.batch > 0 ? a.batch : 1;
   MN_CHECK_ARG(a.wfmt == MN_W_BF16 || a.wfmt == MN_W_FP8_E4M3 || a.wfmt == MN_W_INT8 || a.wfmt == MN_W_NF4, "mn_skinny_gemm: bad wfmt %d", a.wfmt);
-  MN_CHECK_ARG(a.wfmt != MN_W_NF4 || (ka.batch == 1 && ka.nseg == 1 && a.ws), "mn_skinny_gemm: NF4 weights run the workspace route only (no batch / segment forms)");
+  MN_CHECK_ARG((a.wfmt != MN_W_NF4 && a.wfmt != MN_W_INT8) || (ka.batch == 1 && ka.nseg == 1 && a.ws),
+               "mn_skinny_gemm: NF4 / int8 weights run the workspace route only (no batch / segment forms: their products are rounded per element)");
   if (a.wfmt != MN_W_BF16) {
     // one row per batch entry with a plain prologue: the one-row fp8 kernel (expert pair launches, batch / segment forms included);
     // everything else: the matrix-core route (checks dense weights / no batch forms / workspace)

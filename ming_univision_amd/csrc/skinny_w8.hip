@@ -28,7 +28,6 @@ struct W8Args {
   int32_t inv_nchunk;  // ceil(65536 / nchunk)
 };
 
-template <bool I8>
 __device__ __forceinline__ void fma16(const u32x4 q, const float* xl, float& acc) {
   const uint32_t w[4] = {q.x, q.y, q.z, q.w};
   float t = acc;
@@ -36,7 +35,7 @@ __device__ __forceinline__ void fma16(const u32x4 q, const float* xl, float& acc
   for (int j = 0; j < 4; ++j) {
     const f32x4 x = *reinterpret_cast<const f32x4*>(xl + j * 256);
     float wv[4];
-    w8x4_to_f32<I8>(w[j], wv);                     // e4m3 or int8 bytes -> fp32, exact (w8_codec.h)
+    fp8x4_to_f32(w[j], wv);                        // e4m3 bytes -> fp32, exact (w8_codec.h)
     t = fmaf(wv[0], x.x, t); t = fmaf(wv[1], x.y, t); t = fmaf(wv[2], x.z, t); t = fmaf(wv[3], x.w, t);
   }
   acc = t;
@@ -119,17 +118,10 @@ __global__ __launch_bounds__(NT) void skinny_w8_kernel(const W8Args ka) {
     int seg_left = nchunk, seg_id = 0;                    // chunks left in the current segment
     auto consume = [&](int ct, const u32x4 (&src)[SW][R]) {
       const float* xp = xl + (int64_t)ct * 1024;          // LDS image is [nseg * nchunk * 1024]
-      if (a.wfmt == MN_W_INT8) {                          // one scalar branch per chunk, the loops specialised
 #pragma unroll
-        for (int s = 0; s < SW; ++s)
+      for (int s = 0; s < SW; ++s)
 #pragma unroll
-          for (int r = 0; r < R; ++r) fma16<true>(src[s][r], xp, acc[s][r]);
-      } else {
-#pragma unroll
-        for (int s = 0; s < SW; ++s)
-#pragma unroll
-          for (int r = 0; r < R; ++r) fma16<false>(src[s][r], xp, acc[s][r]);
-      }
+        for (int r = 0; r < R; ++r) fma16(src[s][r], xp, acc[s][r]);
       if (--seg_left == 0) {                              // segment done: fold its partial sums with ITS row scales
 #pragma unroll
         for (int s = 0; s < SW; ++s)
@@ -219,7 +211,7 @@ extern "C" int mn_skinny_w8_row(const mn_skinny_args* args, void* stream) {
   W8Args ka;
   ka.a = *args;
   const mn_skinny_args& a = ka.a;
-  MN_CHECK_ARG(a.M == 1 && (a.wfmt == MN_W_FP8_E4M3 || a.wfmt == MN_W_INT8) && a.wscale && a.x && a.w && a.out, "mn_skinny_gemm(fp8 row): M == 1, weights + row scales");
+  MN_CHECK_ARG(a.M == 1 && a.wfmt == MN_W_FP8_E4M3 && a.wscale && a.x && a.w && a.out, "mn_skinny_gemm(fp8 row): M == 1, e4m3 weights + row scales");
   MN_CHECK_ARG(a.N >= 1 && a.K >= 16 && (a.K % 16) == 0 && (a.ldw % 16) == 0 && (((uintptr_t)a.w) & 15) == 0 &&
                    ((a.w_batch_stride | a.seg_w_stride) % 16) == 0,
                "mn_skinny_gemm(fp8 row): K, ldw and the matrix strides must be multiples of 16");

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(KW * 64, (WQ == 1 && MT == 4 && NT == 2) ? 4 : 1) v
   const bf16_t* wp[WI];
   const uint8_t* wq[WI];
   const float* wa[WI];                                                // NF4: the row's absmax table
+  float wsc[WI];
   int wo[WI];
   const int wslot_k = (lane % SPR) * (8 * PC);
 #pragma unroll
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(KW * 64, (WQ == 1 && MT == 4 && NT == 2) ? 4 : 1) v
     wq[i] = Wq + (W4 ? ((int64_t)n * K) >> 1 : (int64_t)n * K);
     wa[i] = W4 ? wscale + (int64_t)n * (K >> 6) : nullptr;
     wo[i] = cslot<CK>(row, lane % SPR);
+    wsc[i] = (W8 && g.wf == MN_W_INT8) ? wscale[n] : 1.0f;             // int8: the row scale rides the conversion (w8_codec.h)
   }
   u32x4 xr_[XD][XJ], wr_[DW][WI];
   float wa_[W4 ? DW : 1][WI];                                         // NF4: absmax of the block every load of the piece lies in
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(KW * 64, (WQ == 1 && MT == 4 && NT == 2) ? 4 : 1) v
 #pragma unroll
               for (int i = 0; i < WI; ++i) {
                 const u32x4 q = wr_[d >> 1][i];
-                *reinterpret_cast<u32x4*>(wt + wo[i]) = (d & 1) ? w8x8_to_bf16<I8>(q.z, q.w) : w8x8_to_bf16<I8>(q.x, q.y);
+                *reinterpret_cast<u32x4*>(wt + wo[i]) = (d & 1) ? w8x8_to_bf16<I8>(q.z, q.w, wsc[i]) : w8x8_to_bf16<I8>(q.x, q.y, wsc[i]);
               }
             };
             if (g.wf == MN_W_INT8) park8(std::true_type{}); else park8(std::false_type{});    // one scalar branch per chunk
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(KW * 64, (WQ == 1 && MT == 4 && NT == 2) ? 4 : 1) v
       const int nn = (t + nt) * 16 + fr;
       if (nn < Ntot) {
         float rs = 1.0f;
-        if constexpr (W8) rs = wscale[nn];
+        if constexpr (W8) rs = g.wf == MN_W_INT8 ? 1.0f : wscale[nn];      // (int8 products are already scaled)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll

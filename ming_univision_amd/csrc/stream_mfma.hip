@@ -247,8 +247,9 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
             constexpr bool I8 = decltype(i8)::value;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-              const u32x4 a = w8x8_to_bf16<I8>(ring[d][i].x, ring[d][i].y), b = w8x8_to_bf16<I8>(ring[d][i].z, ring[d][i].w);
               const int row = i * 4 + fq, sw = (fr >> 2) & 1;
+              const float sc = I8 ? wscale[min(t * 16 + row, Ntot - 1)] : 1.0f;      // int8: the row scale rides the conversion
+              const u32x4 a = w8x8_to_bf16<I8>(ring[d][i].x, ring[d][i].y, sc), b = w8x8_to_bf16<I8>(ring[d][i].z, ring[d][i].w, sc);
               *reinterpret_cast<u32x4*>(wbuf + wslot(row, 2 * fr + sw)) = sw ? b : a;
               *reinterpret_cast<u32x4*>(wbuf + wslot(row, 2 * fr + 1 - sw)) = sw ? a : b;
             }
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
         if (++ch == nch) {                          // tile done: D layout row m = fq*4 + r, col n = t*16 + fr
           const int nn = t * 16 + fr;
           float rs = 1.0f;
-          if constexpr (W8) rs = wscale[min(nn, Ntot - 1)];
+          if constexpr (W8) rs = wf == MN_W_INT8 ? 1.0f : wscale[min(nn, Ntot - 1)];       // (int8 products are already scaled)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             if (nn < Ntot) {

@@ -1,37 +1,39 @@
-// w8_codec.h — the 8-bit weight codecs of the weight-only modes (mingnative.h section 7): bytes -> bf16 / fp32, exact.
-//   MN_W_FP8_E4M3  OCP e4m3fn bytes: v_cvt_scalef32_pk_bf16_fp8 / v_cvt_pk_f32_fp8 (every e4m3 value is a bf16 value)
-//   MN_W_INT8      two's-complement bytes in [-127, 127]: sign-extend + v_cvt_f32_i32 (+ v_cvt_pk_bf16_f32: |q| <= 127 is 7 bits)
-// The format is a wave-uniform kernel argument: one scalar branch per converted dword group, the kernels are otherwise the same.
+// w8_codec.h — the weight codecs of the weight-only modes (mingnative.h section 7): codes -> bf16 / fp32.
+//   MN_W_FP8_E4M3  OCP e4m3fn bytes: v_cvt_scalef32_pk_bf16_fp8 / v_cvt_pk_f32_fp8 (every e4m3 value is a bf16 value); the power-of-two
+//                  row scale multiplies the fp32 accumulators afterwards
+//   MN_W_INT8      optimum-quanto's qint8 rule: W'[n, k] = bf16_rne(q[n, k] * scale[n]) with a bf16-valued scale = amax / 127 — the product
+//                  is rounded PER ELEMENT (quanto multiplies scale * weights in bf16 before the matmul), so the row scale rides the
+//                  conversion (v_cvt_f32_ubyteN of the byte + 128, one fma, v_cvt_pk_bf16_f32) and nothing is scaled afterwards
+//   MN_W_NF4       below
+// The format is a wave-uniform kernel argument: one scalar branch per converted chunk, the kernels are otherwise the same.
 #pragma once
 #include "common.h"
 
-__device__ __forceinline__ mn_u2_t i8x4_to_bf16(uint32_t q) {
-  const int s = (int)q;
-  const float f0 = (float)((s << 24) >> 24), f1 = (float)((s << 16) >> 24), f2 = (float)((s << 8) >> 24), f3 = (float)(s >> 24);
+// four int8 bytes q -> bf16_rne(q * s), two packed dwords.  (u - 128) * s as ONE fma of the biased byte: s * u - 128 s is exact in fp32
+// before its single rounding (|q| <= 128 is 8 bits, s has 8 significant bits), so this is fp32(q * s) exactly, then bf16 rounding.
+__device__ __forceinline__ mn_u2_t i8x4_to_bf16(uint32_t q, float s) {
+  const uint32_t u = q ^ 0x80808080u;
+  const float b = -128.0f * s;
+  const float f0 = fmaf((float)(u & 0xffu), s, b), f1 = fmaf((float)((u >> 8) & 0xffu), s, b);
+  const float f2 = fmaf((float)((u >> 16) & 0xffu), s, b), f3 = fmaf((float)(u >> 24), s, b);
   return mn_u2_t{cvt_pk_bf16(f0, f1), cvt_pk_bf16(f2, f3)};
 }
 // eight weight bytes (k ascending) -> eight bf16 = one MFMA fragment / one 16-byte LDS slot.  I8 is a compile-time choice: the
 // callers branch ONCE per parked chunk on the (wave-uniform) format and run a specialised loop (a per-dword branch cost 3 % of an
-// fp8 launch)
+// fp8 launch).  s: the row's scale (int8 only)
 template <bool I8>
-__device__ __forceinline__ mn_u4_t w8x8_to_bf16(uint32_t q0, uint32_t q1) {
+__device__ __forceinline__ mn_u4_t w8x8_to_bf16(uint32_t q0, uint32_t q1, float s) {
   if constexpr (I8) {
-    const mn_u2_t a = i8x4_to_bf16(q0), b = i8x4_to_bf16(q1);
+    const mn_u2_t a = i8x4_to_bf16(q0, s), b = i8x4_to_bf16(q1, s);
     return mn_u4_t{a.x, a.y, b.x, b.y};
   } else {
     return fp8x8_to_bf16(q0, q1);
   }
 }
-// four weight bytes -> four fp32
-template <bool I8>
-__device__ __forceinline__ void w8x4_to_f32(uint32_t q, float (&o)[4]) {
-  if constexpr (I8) {
-    const int s = (int)q;
-    o[0] = (float)((s << 24) >> 24); o[1] = (float)((s << 16) >> 24); o[2] = (float)((s << 8) >> 24); o[3] = (float)(s >> 24);
-  } else {
-    const mn_f2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(q, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(q, true);
-    o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
-  }
+// four e4m3 bytes -> four fp32 (the one-row fp32-FMA kernel of the e4m3 mode, skinny_w8.hip)
+__device__ __forceinline__ void fp8x4_to_f32(uint32_t q, float (&o)[4]) {
+  const mn_f2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(q, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(q, true);
+  o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
 }
 
 // ---- NF4 (MN_W_NF4): bitsandbytes' 4-bit NormalFloat, blockwise absmax (block = 64 consecutive k of a row), two codes per byte ----

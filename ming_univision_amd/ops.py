@@ -497,8 +497,8 @@ def dequant_nf4_rows(q, absmax):
 
 def quant_rows(w, fmt):
     """bf16 [..., N, K] -> (codes uint8, fp32 scale table) in the weight-only format `fmt`: "fp8" (OCP e4m3 bytes [..., N, K] + one
-    power-of-two scale per row [..., N]), "int8" (two's complement bytes + one scale per row), "int4" (NF4: [..., N, K / 2] + absmax
-    [..., N, K / 64])."""
+    power-of-two scale per row [..., N]), "int8" (optimum-quanto's qint8 rule: two's complement bytes + one bf16-valued scale per row),
+    "int4" (bitsandbytes NF4: [..., N, K / 2] + absmax [..., N, K / 64])."""
     if fmt == "fp8":
         return quant_fp8_rows(w)
     if fmt == "int4":

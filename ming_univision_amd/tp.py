@@ -334,7 +334,7 @@ class TpDecoderShard:
             if weights in _lib.W8:
                 assert weights != "int4", "int4 (NF4) shards are not built: see TpDecoderShard.__init__"
                 from .bailing_moe import quantize_layer_experts
-                quantize_layer_experts(ly, weights)
+                quantize_layer_experts(ly, weights, cfg.num_shared_experts or 0)
             self._shard_layers.append(cls._shard_layer(ly, cfg, rank, world))
             del sd, gu, dn, ly
         full.layers = None

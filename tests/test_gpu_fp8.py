@@ -157,8 +157,10 @@ def full():
 
 
 def _fp8_models(full, n_seq, fmt="fp8"):
-    """HIP models of the full-width 2-layer configuration in the 8-bit weight mode `fmt` ("fp8" | "int8") + the oracle's state dict
-    of that model (dequantised weights)."""
+    """HIP models of the full-width 2-layer configuration in the weight-only mode `fmt` ("fp8" | "int8") + the oracle's state dict
+    of that model (dequantised weights).  "int8" (the reference's quanto mode) converts EVERY nn.Linear — attention, lm_head, the small
+    RF Linears, MingTok, linear_proj — "fp8" (this library's own format) the streamed tensors only."""
+    from ming_univision_amd import _lib, ops
     from ming_univision_amd.bailing_moe import BailingMoeDecoder
     from ming_univision_amd.mingtok import MingTok
     from ming_univision_amd.rf_head import RectifiedFlowHead
@@ -169,25 +171,35 @@ def _fp8_models(full, n_seq, fmt="fp8"):
     rf8 = RectifiedFlowHead(dsd, cfg.hidden_size, rf_cfg, weights=fmt)
     assert dec8.layers[0]["w_gate_up"].dtype == torch.uint8 and rf8.lists["w12"][0].dtype == torch.uint8
     assert dec8.max_rows() == 64 and rf8.max_rows() == 64
-    sd8 = dict(sd)                                                   # the oracle's weights of the fp8 model
+    sd8 = dict(sd)                                                   # the oracle's weights of the quantised model
     for k, v in dec8.dequantized_state_dict().items():
         sd8[k] = v.float().cpu()
     for k, v in rf8.dequantized_blocks().items():
         sd8[k] = v.float().cpu()
     # ... and they are what the oracle's own quantiser produces from the bf16 weights
     from oracle import fp8_ref, int8_ref
+    full_model = fmt in _lib.FULL_MODEL
     if fmt == "int8":
         fp8_ref = int8_ref                                            # (same function names)
-    for k in ("model.layers.1.mlp.experts.5.up_proj.weight", "model.layers.0.mlp.shared_experts.gate_proj.weight",
-              "diffloss.net.res_blocks.3.mlp.w12.weight", "diffloss.net.res_blocks.11.mlp.w3.weight"):
+    keys = ["model.layers.1.mlp.experts.5.up_proj.weight", "model.layers.0.mlp.shared_experts.gate_proj.weight",
+            "diffloss.net.res_blocks.3.mlp.w12.weight", "diffloss.net.res_blocks.11.mlp.w3.weight"]
+    if full_model:
+        keys += ["model.layers.1.attention.query_key_value.weight", "model.layers.0.attention.dense.weight", "lm_head.weight",
+                 "vis_head.0.weight", "diffloss.net.cond_embed.weight", "diffloss.net.input_proj.weight", "diffloss.net.time_embed.mlp.2.weight",
+                 "diffloss.net.final_layer.linear.weight", "diffloss.net.res_blocks.7.adaLN_modulation.1.weight"]
+    for k in keys:
         assert torch.equal(sd8[k], fp8_ref.fake_quant_rows(sd[k])), k
-    # the shared expert's down projection is quantised per pseudo-expert (column block) in the packed layout
+    assert torch.equal(sd8["model.layers.0.mlp.gate.weight"], sd["model.layers.0.mlp.gate.weight"])        # the router is not an nn.Linear
     k = "model.layers.0.mlp.shared_experts.down_proj.weight"
     I = cfg.moe_intermediate_size
-    assert torch.equal(sd8[k], torch.cat([fp8_ref.fake_quant_rows(sd[k][:, s * I:(s + 1) * I].contiguous()) for s in range(2)], 1))
+    if fmt == "int8":    # quanto: one scale per output row of the WHOLE Linear — the two pseudo-experts of the packed layout share it
+        assert torch.equal(sd8[k], int8_ref.fake_quant_rows(sd[k]))
+    else:                # e4m3 (own format): quantised per pseudo-expert (column block) in the packed layout
+        assert torch.equal(sd8[k], torch.cat([fp8_ref.fake_quant_rows(sd[k][:, s * I:(s + 1) * I].contiguous()) for s in range(2)], 1))
     lsd = synth_state_dict(C.linear_proj_param_shapes(1024, cfg.hidden_size, 2), seed)
-    dl = _dev(lsd)
-    tok = MingTok(C.MingTokConfig(), device="cuda", seed=seed,
+    dl = ops.convert_linears(_dev(lsd), fmt)
+    lsd = {k_: v.float().cpu() for k_, v in dl.items()}
+    tok = MingTok(C.MingTokConfig(), device="cuda", seed=seed, weights=fmt if full_model else "bf16",
                   linear_proj=[(dl["linear_proj.0.weight"], dl["linear_proj.0.bias"]), (dl["linear_proj.2.weight"], dl["linear_proj.2.bias"])])
     return cfg, dsd, dec8, rf8, sd8, lsd, tok
 
