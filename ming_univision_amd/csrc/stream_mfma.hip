@@ -474,7 +474,11 @@ extern "C" int mn_stream_mfma_grouped(const uint16_t* Y, int y_rows, const uint1
 extern "C" int mn_stream_mfma_grouped_wq(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale,
                                          int64_t s_stride, float* P, int p_rows, const int32_t* off, const int32_t* xrows, int G,
                                          int max_rows, int Ntot, int K, int wfmt, void* stream) {
-  const int nz = mn_stream_mfma_grouped_slices(G, max_rows, Ntot, K);
+  // (K-ranges are whole weight pieces — 128 k of e4m3 / int8, 256 k of NF4 codes — so a short K may have fewer ranges than the bf16 form's
+  // two; callers size their slabs with mn_stream_mfma_grouped_slices, an upper bound, and reduce the count this call returns)
+  const int piece_k = wfmt == MN_W_NF4 ? 256 : 128;
+  int nz = mn_stream_mfma_grouped_slices(G, max_rows, Ntot, K);
+  if (nz > (K + piece_k - 1) / piece_k) nz = (K + piece_k - 1) / piece_k;
   return mn_stream_kloop_grouped_wq(Y, y_rows, Wq, w_stride, wscale, s_stride, P, p_rows, off, xrows, G, max_rows, nz, Ntot, K, wfmt, stream);
 }
 extern "C" int mn_stream_mfma_grouped_w8(const uint16_t* Y, int y_rows, const uint8_t* Wq, int64_t w_stride, const float* wscale,
