@@ -520,10 +520,11 @@ static bool rf_fp8_ok(const mn_rf_head* h) {
 
 // <= 4 rows (the CFG rows of one image — the reference's call shape): the SwiGLU glue launch is folded into w3's prologue
 // (stream_fuse.h): three launches per ResBlock instead of four.  g_rf_fuse: dev-library A/B switch.
-static int g_rf_fuse = 1, g_rf_boundary = 1;
+static int g_rf_fuse = 1, g_rf_boundary = 1, g_rf_kc = 1;
 static void g_rf_ada_stream_set(int v);
 #ifdef MN_DEV_HOOKS
-extern "C" MN_DEV_API void mn_rf_tune_fuse(int on) { g_rf_fuse = on & 1; g_rf_boundary = (on >> 1) & 1; g_rf_ada_stream_set((on >> 2) & 1 ? 0 : 1); }
+// bit 0: SwiGLU glue fused into w3; bit 1: one-launch Euler-step boundary; bit 2: adaLN NOT streamed; bit 3: K-complete chain OFF
+extern "C" MN_DEV_API void mn_rf_tune_fuse(int on) { g_rf_fuse = on & 1; g_rf_boundary = (on >> 1) & 1; g_rf_ada_stream_set((on >> 2) & 1 ? 0 : 1); g_rf_kc = (on >> 3) & 1 ? 0 : 1; }
 #endif
 static bool rf_fused_shape_ok(const mn_rf_head* h, int rows) {
   return rows <= FUSE_MAX_ROWS && rf_chain_ok(h, rows) &&
@@ -665,7 +666,22 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
       else
         hipLaunchKernelGGL(rf_glue_resid_ln_split_kernel, dim3(rows), dim3(1024), 0, st, (const float*)nullptr, 0, rows, w,
                            (const bf16_t*)nullptr, (const float*)nullptr, hh, h->ln_g[0], h->ln_b[0], ada, ada + w, (int64_t)A, ya);
-      for (int b = 0; b < h->depth; ++b) {
+      // <= 2 rows (the CFG rows of one image): K-complete launches (stream_kc.hip) — w12' normalises / modulates h itself and writes
+      // w3's operand, w3' applies the gated residual in place: two launches per block, no slabs, no glue between the blocks
+      const bool kc = g_rf_kc && fused && rf_kc_ok(h->wfmt, rows, w, hid_n);
+      for (int b = 0; kc && b < h->depth; ++b) {
+        const float* mod = ada + (int64_t)b * 3 * w;
+        MN_TRY(rf_w12_kc(h->wfmt, hh, rows, w, hid_n, h->ln_g[b], h->ln_b[b], mod, mod + w, (int64_t)A, h->w12[b],
+                         h->wfmt ? h->w12_scale[b] : nullptr, h->b12[b], yb, stream));
+        MN_TRY(rf_w3_kc(h->wfmt, yb, rows, w, hid_n, h->w3[b], h->wfmt ? h->w3_scale[b] : nullptr, h->b3[b], mod + 2 * w, (int64_t)A, hh, stream));
+      }
+      if (kc) {     // the final layer's input: LayerNorm (no affine) of h, modulated  (diff_loss_rf_swiglu.py:288-292)
+        const float* nmod = ada + (int64_t)h->depth * 3 * w;
+        hipLaunchKernelGGL(rf_glue_resid_ln_split_kernel, dim3(rows), dim3(1024), 0, st, (const float*)nullptr, 0, rows, w,
+                           (const bf16_t*)nullptr, (const float*)nullptr, hh, (const bf16_t*)nullptr, (const bf16_t*)nullptr, nmod, nmod + w,
+                           (int64_t)A, ya);
+      }
+      for (int b = 0; !kc && b < h->depth; ++b) {
         const float* mod = ada + (int64_t)b * 3 * w;
         int nz = stream_dense(h->wfmt, ya, h->w12[b], h->wfmt ? h->w12_scale[b] : nullptr, pbuf, rows, 2 * hid_n, w, stream);
         if (nz < 0) return nz;

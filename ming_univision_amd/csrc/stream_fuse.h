@@ -17,3 +17,13 @@ constexpr int FUSE_MAX_ROWS = 4;
 bool stream_fused_ok(int wfmt, int M, int Ntot, int K, int prev_nz);
 // Launch: W = bf16 [Ntot][K], or e4m3 bytes + wscale (wfmt != 0).  P [nz][M][Ntot], nz = the plain launch's slice count.  Returns nz (< 0: error).
 int stream_fused(int wfmt, const void* W, const float* wscale, float* P, int M, int Ntot, int K, const StreamFuse& f, void* stream);
+
+// ---- K-complete launches of the RF ResBlock chain at <= 2 rows (stream_kc.hip): whole output tiles per workgroup, K split over its
+// waves — no split-K slabs, so the residual + LayerNorm glue launch between two blocks disappears (two launches per block).
+bool rf_kc_ok(int wfmt, int M, int w, int hid);
+// Y3 [2][M][hid] bf16 (hi rows, lo rows) = split( silu(g) * u ),  (g, u) = LayerNorm(h; ln_g, ln_b)(1 + scale) + shift  @ W12^T + b12
+int rf_w12_kc(int wfmt, const float* h, int M, int w, int hid, const bf16_t* ln_g, const bf16_t* ln_b, const float* shift, const float* scale,
+              int64_t ldmod, const void* W12, const float* s12, const bf16_t* b12, bf16_t* Y3, void* stream);
+// h[m, n] += gate[m, n] * (Y3 @ W3^T + b3)[m, n]   in place
+int rf_w3_kc(int wfmt, const bf16_t* Y3, int M, int w, int hid, const void* W3, const float* s3, const bf16_t* b3, const float* gate,
+             int64_t ldmod, float* h, void* stream);

@@ -319,8 +319,8 @@ def test_fp8_facade_dtype_switch(tmp_path):
                 semantic_decoder=dict(in_dim=32, patch_size=32, embed_dim=128, decoder_depth=2, ffn_layer="swiglufused"),
                 pixel_decoder=dict(patch_size=16, decoder_depth=2, embed_dim=128))
     cfg = C.MingUniVisionConfig(mlp_depth=2, llm_config=d, vishead_diffloss_config=rf_cfg, mingtok_config=tcfg)
-    with pytest.raises(NotImplementedError):
-        MingUniVisionInfer(None, dtype="int4", config=cfg)
+    with pytest.raises(ValueError):
+        MingUniVisionInfer(None, dtype="fp4", config=cfg)
     inf8 = MingUniVisionInfer(None, dtype="fp8", config=cfg, seed=3, t_max=128)
     assert inf8.model.model.weights == "fp8" and inf8.model.rf.weights == "fp8"
     inf16 = MingUniVisionInfer(None, dtype="bf16", config=cfg, seed=3, t_max=128)

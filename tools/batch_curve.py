@@ -2,8 +2,8 @@
 2 CFG rows per image) over the number of images generated in lock-step, across the three routes — fused chain (<= 4 rows), weight-streaming
 kernels (<= 64 rows), wide MFMA route (65+ rows) — in bf16 and, up to the streaming route's 32 images, in fp8 / int8 / int4 weight modes.
 
-A point = one whole-image run of `--tokens` visual tokens (default 32: the per-token time is flat over an image's 256 tokens up to the cache
-length) after one untimed run, same prompts and noise for every weight mode.  Writes ONE JSON (stdout, or --out) with the curve and a check
+A point = one whole-image run of `--tokens` visual tokens (default 64 = an 8 x 8 grid: the per-token time is flat over an image's 256 tokens
+up to the cache length) after one untimed run, same prompts and noise for every weight mode.  Writes ONE JSON (stdout, or --out) with the curve and a check
 that no point falls more than 5 % under the linear interpolation of its neighbours — a cliff at a route switch would show there.
 
     python tools/batch_curve.py --out profiles/r05_batch_curve.json
@@ -26,7 +26,7 @@ import bench  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", default="1,2,4,8,16,32,33,48,64,128,256,512,768,1024")
-    ap.add_argument("--tokens", type=int, default=32)
+    ap.add_argument("--tokens", type=int, default=64, help="visual tokens per image: a square grid (64 = 8 x 8 -> a 256^2 image)")
     ap.add_argument("--prompt-len", type=int, default=40)
     ap.add_argument("--modes", default="bf16,fp8,int8,int4")
     ap.add_argument("--out", default=None)
