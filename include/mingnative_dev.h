@@ -19,6 +19,7 @@ MN_DEV_API void mn_skinny_tune(int R, int nt, int bpc);                 /* skinn
 MN_DEV_API void mn_stream_tune_plan(int kch, int nw);                   /* stream_mfma.hip K-slice length / waves */
 MN_DEV_API void mn_stream_tune_plan_k(int K, int kch, int nw);          /* stream_mfma.hip: mn_stream_tune_plan for the matrices with this K only */
 MN_DEV_API void mn_stream_tune_w8(int depth);                           /* stream_mfma.hip fp8 form: weight chunks in flight per wave (1 or 2) */
+MN_DEV_API void mn_moe_tune_down(int on);                               /* engine.hip: 1- / 2-row MoE down projection on moe_down.hip (1, default) or the K-segment skinny kernel (0) */
 MN_DEV_API void mn_rf_kc_tune(int rd12, int rd3);                         /* stream_kc.hip: weight chunks in flight per wave of w12' (1..3) / w3' (1, 2, 4) */
 MN_DEV_API void mn_rf_tune_fuse(int on);                                /* engine.hip, RF chain: bit 0 = SwiGLU glue folded into w3's prologue at <= 4 rows, bit 1 = the Euler-step boundary as one launch, bit 2 = bf16 adaLN through the GEMM instead of the streaming launch (default 3) */
 MN_DEV_API void mn_attn_tune_fuse(int on);                              /* decode_ops.hip: RoPE + KV append riding the decode-attention launch where it pays (1, default) or never (0) */

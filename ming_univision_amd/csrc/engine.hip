@@ -962,6 +962,10 @@ static size_t moe_carve(Carver& cv, int rows, int H, int I, int G, int n_slot, M
 }
 
 // grouped-expert route from 3 rows (3 rows: 74.2 vs 70.6 tokens/s against the fp32-FMA pair kernels; 2 rows: 75.1 vs 76.8)
+static int g_moe_down = 1;            // the 1- / 2-row down projection on moe_down.hip (dev-library A/B switch: mn_moe_tune_down)
+#ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_moe_tune_down(int on) { g_moe_down = on; }
+#endif
 constexpr int MOE_MFMA_MIN_ROWS = 3;
 // NF4 / int8 experts run the grouped streaming launch from ONE row on: their products are rounded to bf16 per element (bitsandbytes' /
 // quanto's de-quantisation), which the fp32-FMA pair kernels of 1- / 2-row steps do not do
@@ -1226,6 +1230,10 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
         a.x_batch_stride = H; a.x_batch_div = n_slot; a.out_batch_stride = I;
         if (m->wfmt) { a.wfmt = m->wfmt; a.wscale = m->w_gate_up_scale[l]; a.wscale_batch_stride = 2 * I; a.ws = nullptr; }
         MN_TRY(mn_skinny_gemm(&a, stream));
+        if (g_moe_down && moe_down_ok(m->wfmt, n_slot, H, I)) {      // segments over the waves: one HBM round trip (moe_down.hip)
+          MN_TRY(moe_down_rows(w.hmid, (int64_t)n_slot * I, m->w_down[l], (int64_t)H * I, w.ti, w.tw, w.h, H, w.h, H, M, H, I, n_slot, stream));
+          continue;
+        }
         a = sk(w.hmid, (int64_t)n_slot * I, m->w_down[l], I, nullptr, w.h, H, 1, H, I);
         a.epilogue = MN_EPI_RESID; a.res = w.h; a.ldres = H; a.res_batch_stride = H;
         a.batch = M; a.w_index = nullptr; a.w_batch_stride = 0;
@@ -1288,6 +1296,10 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
     a.x_batch_stride = H; a.x_batch_div = n_slot; a.out_batch_stride = I;
     if (m->wfmt) { a.wfmt = m->wfmt; a.wscale = m->w_gate_up_scale[l]; a.wscale_batch_stride = 2 * I; a.ws = nullptr; }
     MN_TRY(mn_skinny_gemm(&a, stream));
+    if (g_moe_down && moe_down_ok(m->wfmt, n_slot, H, I)) {          // segments over the waves: one HBM round trip (moe_down.hip)
+      MN_TRY(moe_down_rows(w.hmid, (int64_t)n_slot * I, m->w_down[l], (int64_t)H * I, w.ti, w.tw, w.h, H, w.h, H, M, H, I, n_slot, stream));
+      continue;
+    }
     a = sk(w.hmid, (int64_t)n_slot * I, m->w_down[l], I, nullptr, w.h, H, 1, H, I);
     a.epilogue = MN_EPI_RESID; a.res = w.h; a.ldres = H; a.res_batch_stride = H;
     a.batch = M; a.w_index = nullptr; a.w_batch_stride = 0;

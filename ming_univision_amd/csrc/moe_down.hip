@@ -1,0 +1,126 @@
+// moe_down.hip — the MoE down projection of a 1- / 2-row decode step (text decode; the 2-row CFG step of one image):
+//
+//   out[b][n] = res[b][n] + sum_{s < n_slot} tw[b, s] * sum_{k < I} hmid[b][s][k] * Wdown[ti[b, s]][n][k]
+//
+// (moe_infer's weighted un-permute over the selected experts + the shared ones, modeling_bailing_moe.py:604-639, for ONE row per batch
+// entry).  Round 4 ran this as the K-segment form of the fp32-FMA skinny kernel: a wave owned a few output rows and walked all
+// n_slot x ceil(I / 512) weight chunks of a row IN SEQUENCE through a 4-deep ring — 24 chunks = six dependent HBM round trips, and every
+// workgroup re-staged the 45 KB 8-segment activation image: 22.9 us for 92 MB at 2 rows, 16 us for 46 MB at one (2.9 TB/s; unchanged
+// by fp8 bytes: latency, not bytes — VERDICT r4 #7a).
+// Here the segments are spread over the waves instead: a workgroup owns RW = 8 output rows, wave s multiplies segment s (one expert)
+// for all of them — its slice of the activation (I floats, scaled by the router weight) lives in its REGISTERS, no LDS image — and all
+// RW x ceil(I / 512) weight loads of a wave are in flight at once: one HBM round trip per launch.  The n_slot partial sums of a row meet
+// in LDS, in slot order (deterministic).
+#include "common.h"
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int RW = 8;                // output rows per workgroup
+constexpr int MAX_SLOTS = 8;         // segments = waves per workgroup
+
+struct DownArgs {
+  const float* hmid; int64_t ld_hmid;               // [batch][n_slot * I] fp32
+  const bf16_t* W; int64_t w_stride;                // [E + S][H][I] bf16, elements between experts
+  const int32_t* ti; const float* tw;               // [batch][n_slot]
+  const float* res; int64_t ld_res;                 // [batch][H]
+  float* out; int64_t ld_out;
+  int H, I, n_slot;
+};
+
+template <int NCK>
+__global__ __launch_bounds__(MAX_SLOTS * 64) void moe_down_kernel(const DownArgs a) {
+  __shared__ float part[MAX_SLOTS][RW];
+  const int tid = threadIdx.x, lane = tid & 63, s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y, n0 = blockIdx.x * RW, I = a.I;
+  const bool live = s < a.n_slot;
+  // ---- this wave's slice of the activation first (loads retire in order: it lands before the weights) ...
+  float xk[NCK][8];
+  float sc = 0.f;
+  const bf16_t* wbase = a.W;
+  if (live) {
+    sc = a.tw[(int64_t)b * a.n_slot + s];
+    wbase = a.W + (int64_t)a.ti[(int64_t)b * a.n_slot + s] * a.w_stride;
+    const float* xp = a.hmid + (int64_t)b * a.ld_hmid + (int64_t)s * I;
+#pragma unroll
+    for (int c = 0; c < NCK; ++c) {
+      const int k = c * 512 + lane * 8;
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      f4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+      if (k < I) { lo = *reinterpret_cast<const f4*>(xp + k); hi = *reinterpret_cast<const f4*>(xp + k + 4); }      // I % 8 == 0
+      xk[c][0] = lo.x; xk[c][1] = lo.y; xk[c][2] = lo.z; xk[c][3] = lo.w; xk[c][4] = hi.x; xk[c][5] = hi.y; xk[c][6] = hi.z; xk[c][7] = hi.w;
+    }
+  }
+  // ---- ... then ALL weight pieces of this (segment, row block): RW x NCK 16-byte nontemporal loads per lane, one round trip
+  u32x4 wq[RW][NCK];
+  if (live) {
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const bf16_t* wr = wbase + (int64_t)min(n0 + r, a.H - 1) * I;
+#pragma unroll
+      for (int c = 0; c < NCK; ++c) {
+        const int k = min(c * 512 + lane * 8, I - 8);        // beyond I the activation registers are zero: any finite weights will do
+        wq[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + k));
+      }
+    }
+  }
+  // (the epilogue's residual is requested now, behind the weights, and used after the reduction)
+  float r_old = 0.f;
+  if (tid < RW && n0 + tid < a.H && a.res) r_old = a.res[(int64_t)b * a.ld_res + n0 + tid];
+  float acc[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) acc[r] = 0.f;
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < NCK; ++c) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = xk[c][e] * sc;       // the router weight rides the activation (as in the K-segment form)
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const u32x4 q = wq[r][c];
+        float t = acc[r];
+        t = fmaf(bf16lo_to_f32(q.x), x[0], t); t = fmaf(bf16hi_to_f32(q.x), x[1], t);
+        t = fmaf(bf16lo_to_f32(q.y), x[2], t); t = fmaf(bf16hi_to_f32(q.y), x[3], t);
+        t = fmaf(bf16lo_to_f32(q.z), x[4], t); t = fmaf(bf16hi_to_f32(q.z), x[5], t);
+        t = fmaf(bf16lo_to_f32(q.w), x[6], t); t = fmaf(bf16hi_to_f32(q.w), x[7], t);
+        acc[r] = t;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const float t = wave_sum(acc[r]);
+    if (lane == 0) part[s][r] = live ? t : 0.f;
+  }
+  __syncthreads();
+  if (tid < RW && n0 + tid < a.H) {
+    float y = r_old;
+    for (int q = 0; q < a.n_slot; ++q) y += part[q][tid];     // slot order: the same bits every run
+    a.out[(int64_t)b * a.ld_out + n0 + tid] = y;
+  }
+}
+
+}  // namespace
+
+// Can the down projection of this shape run here?  (bf16 weights; one wave per slot; I in whole 8-element pieces, <= 4 chunks of 512)
+bool moe_down_ok(int wfmt, int n_slot, int H, int I) {
+  return wfmt == MN_W_BF16 && n_slot >= 1 && n_slot <= MAX_SLOTS && H >= 1 && I >= 8 && (I % 8) == 0 && I <= 2048;
+}
+
+int moe_down_rows(const float* hmid, int64_t ld_hmid, const bf16_t* W, int64_t w_stride, const int32_t* ti, const float* tw, const float* res,
+                  int64_t ld_res, float* out, int64_t ld_out, int batch, int H, int I, int n_slot, void* stream) {
+  MN_CHECK_ARG(hmid && W && ti && tw && out && batch >= 1 && moe_down_ok(MN_W_BF16, n_slot, H, I) && (ld_hmid % 4) == 0 &&
+                   (((uintptr_t)W) & 15) == 0 && (w_stride % 8) == 0, "moe_down_rows: bad args");
+  const DownArgs a{hmid, ld_hmid, W, w_stride, ti, tw, res, ld_res, out, ld_out, H, I, n_slot};
+  const dim3 grid((unsigned)mn_cdiv(H, RW), (unsigned)batch), block(MAX_SLOTS * 64);
+  const int nck = (I + 511) / 512;
+  hipStream_t st = mn_stream(stream);
+  if (nck == 1) hipLaunchKernelGGL(moe_down_kernel<1>, grid, block, 0, st, a);
+  else if (nck == 2) hipLaunchKernelGGL(moe_down_kernel<2>, grid, block, 0, st, a);
+  else if (nck == 3) hipLaunchKernelGGL(moe_down_kernel<3>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(moe_down_kernel<4>, grid, block, 0, st, a);
+  MN_CHECK_LAUNCH("moe_down_rows");
+  return MN_OK;
+}

@@ -27,3 +27,9 @@ int rf_w12_kc(int wfmt, const float* h, int M, int w, int hid, const bf16_t* ln_
 // h[m, n] += gate[m, n] * (Y3 @ W3^T + b3)[m, n]   in place
 int rf_w3_kc(int wfmt, const bf16_t* Y3, int M, int w, int hid, const void* W3, const float* s3, const bf16_t* b3, const float* gate,
              int64_t ldmod, float* h, void* stream);
+
+// ---- the MoE down projection of a 1- / 2-row step with the segments spread over the waves of a workgroup (moe_down.hip):
+//   out[b][n] = res[b][n] + sum_s tw[b, s] * hmid[b][s * I ..] . W[ti[b, s]][n][..]      (bf16 weights)
+bool moe_down_ok(int wfmt, int n_slot, int H, int I);
+int moe_down_rows(const float* hmid, int64_t ld_hmid, const bf16_t* W, int64_t w_stride, const int32_t* ti, const float* tw, const float* res,
+                  int64_t ld_res, float* out, int64_t ld_out, int batch, int H, int I, int n_slot, void* stream);
