@@ -564,6 +564,11 @@ typedef struct mn_tp_comm {
   uint32_t epoch;
   uint32_t* err;
   uint32_t wait_ms;     /* 0 = 30 000 */
+  /* Rows above which an all-reduce runs TWO-SHOT (round 5): reduce-scatter by pushing column piece j to rank j, the owner sums the
+   * `world` pieces and pushes the reduced piece to every rank (all-gather) — 2 (world - 1) / world of the payload per rank instead of
+   * (world - 1) x: what a many-row TP step wants; the one-shot form (one xGMI hop) stays for decode sizes.  0 = the default (16 rows);
+   * < 0 = never (the relayed transport).  A two-shot all-reduce takes TWO epochs and adds one segment to the composites. */
+  int32_t two_shot_rows;
 } mn_tp_comm;
 
 /* Host-side setup (these DO allocate / map; they are not launchers): fine-grained (uncached, system-coherent) device memory, its
@@ -578,7 +583,10 @@ MN_API int mn_tp_ipc_close(void* dptr);
 /* out[m] = sum over the ranks of x[m]: x fp32 [M, D] (ldx == D) is this rank's partial, out fp32 [M, D] (ldo).  One-shot: the rank
  * pushes its rows into every rank's inbox over xGMI and sets their arrival flags; the reduce kernel waits on its LOCAL flags only.
  * 64 <= D <= 4096, D % 4 == 0, M <= rows_cap, M * D <= cap.  (latency-bound 4-18 KB payloads.) */
-enum { MN_TP_PUSH = 1, MN_TP_REDUCE = 2 };   /* phase bits: both = the whole all-reduce in one call; split = work between them */
+enum { MN_TP_PUSH = 1, MN_TP_REDUCE = 2, MN_TP_GATHER = 4 };   /* phase bits: all = the whole all-reduce in one call; split = work between them.
+                                                                  MN_TP_GATHER (two-shot only, between the other two): the owner's reduce + all-gather push */
+/* 1 or 2: how many segments (= epochs) an all-reduce of `rows` x D takes on this communicator (2 = two-shot). */
+MN_API int mn_tp_allreduce_segments(const mn_tp_comm* comm, int rows, int D);
 MN_API int mn_allreduce_oneshot(mn_tp_comm* comm, const float* x, int64_t ldx, float* out, int64_t ldo, int M, int D, int phase,
                                 void* stream);
 
@@ -599,7 +607,8 @@ MN_API int mn_ep_combine(mn_tp_comm* comm, const float* yg, const int32_t* slot_
  * GLOBAL expert count with gate / image_gate replicated, n_shared_slots = 0, w_gate_up[l] / w_down[l] = its n_local_experts routed
  * experts; the KV arena holds its KV heads only.  tp adds the expert window and the rank's slice of the shared expert
  * (gate rows then up rows of shared_inter units, zero-padded to a multiple of 64; 0 = none).
- * Segments (mn_llm_tp_segments = 2 * n_layers + 1): [seg_begin, seg_end) selects the launch ranges between all-reduces; a rank
+ * Segments (mn_llm_tp_segments = 2 * n_layers + 1 with one-shot all-reduces; (that - 1) * mn_tp_allreduce_segments(comm, rows, hidden) + 1
+ * in general — a two-shot all-reduce adds the owners' reduce + all-gather segment): [seg_begin, seg_end) selects the launch ranges between all-reduces; a rank
  * in production passes (0, n_segments).  Rows 1..2048; workspace mn_llm_tp_workspace_bytes.  Other arguments as mn_llm_step. */
 typedef struct mn_llm_tp {
   int32_t expert0, n_local_experts;

@@ -93,7 +93,7 @@ class TpComm(C.Structure):
         ("rank", C.c_int32), ("world", C.c_int32),
         ("inbox", PP), ("flags", PP),
         ("cap", C.c_int64), ("rows_cap", C.c_int32), ("epoch", C.c_uint32),
-        ("err", C.c_void_p), ("wait_ms", C.c_uint32),
+        ("err", C.c_void_p), ("wait_ms", C.c_uint32), ("two_shot_rows", C.c_int32),
     ]
 
 
@@ -158,6 +158,7 @@ SYMBOLS = {
     "mn_quant_nf4_rows": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _p]),
     "mn_dequant_nf4_rows": (_i, [_p, _i64, _p, _p, _i64, _i64, _i, _p]),
     "mn_stream_mfma_wq_slices": (_i, [_i, _i, _i, _i]),
+    "mn_tp_allreduce_segments": (_i, [C.POINTER(TpComm), _i, _i]),
     "mn_dequant_int8_rows": (_i, [_p, _i64, _p, _p, _i64, _i64, _i, _p]),
     "mn_stream_mfma_wq": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mn_stream_mfma_grouped_wq": (_i, [_p, _i, _p, _i64, _p, _i64, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -104,7 +104,7 @@ extern "C" int mn_struct_layout(int which, size_t* offsets, int cap) {
   };
   static const size_t comm[] = {
 #define F(f) MN_OFF(mn_tp_comm, f)
-      F(rank) F(world) F(inbox) F(flags) F(cap) F(rows_cap) F(epoch) F(err) F(wait_ms)
+      F(rank) F(world) F(inbox) F(flags) F(cap) F(rows_cap) F(epoch) F(err) F(wait_ms) F(two_shot_rows)
 #undef F
   };
   static const size_t llm_tp[] = {

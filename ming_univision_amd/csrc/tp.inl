@@ -33,6 +33,7 @@ struct TpPush {
   int world, rank, rows_cap, M, D;
   int64_t cap;
   uint32_t epoch;
+  int scatter_cols;                                                        // two-shot: columns [j gc, (j + 1) gc) go to rank j only (0: the row to every rank)
 };
 
 // Row m of this rank's partial: v = sum_z P[z][m] + sum_{s : expert(m, s) local} cw[m, s] * cy[cpos[m, s]]  ->  every rank's inbox.
@@ -62,8 +63,13 @@ __global__ __launch_bounds__(1024) void tp_push_kernel(const TpPush p) {
         }
       }
     }
-    const int64_t off = ((int64_t)(p.epoch & 1u) * p.world + p.rank) * p.cap + (int64_t)m * D + col;
-    for (int r = 0; r < p.world; ++r) *reinterpret_cast<f4*>(p.inbox[r] + off) = v;
+    if (p.scatter_cols) {      // two-shot, phase 1 (reduce-scatter): this thread's columns belong to ONE owner
+      const int j = col / p.scatter_cols;
+      *reinterpret_cast<f4*>(p.inbox[j] + ((int64_t)(p.epoch & 1u) * p.world + p.rank) * p.cap + (int64_t)m * p.scatter_cols + (col - j * p.scatter_cols)) = v;
+    } else {
+      const int64_t off = ((int64_t)(p.epoch & 1u) * p.world + p.rank) * p.cap + (int64_t)m * D + col;
+      for (int r = 0; r < p.world; ++r) *reinterpret_cast<f4*>(p.inbox[r] + off) = v;
+    }
   }
   // The row is visible on every rank before any of its flags (cdna_hip_programming.md §6 Guideline 16, flag form): every wave drains
   // its stores, barrier, then the flag lanes alone release at system scope — the wait restated after the fence, where the compiler
@@ -77,21 +83,94 @@ __global__ __launch_bounds__(1024) void tp_push_kernel(const TpPush p) {
   }
 }
 
+// Two-shot all-reduce, phase 2 (owner reduce + all-gather): rank j waits for the `world` pieces of its column slice [j gc, (j + 1) gc) of
+// row m (epoch `e`), sums them in sender order and pushes the reduced piece into slab (parity of e + 1, sender j) of EVERY rank's
+// inbox, then raises flag (j, m) = e + 1 everywhere.  Bytes per rank and all-reduce: 2 (world - 1) / world x M D 4 against (world - 1) x
+// M D 4 for the one-shot form — 4 x fewer at world = 8.  Same bounded wait, same poisoning on expiry as the consumer glue.
+struct TpGather {
+  float* inbox[MN_TP_MAX_WORLD];
+  uint32_t* flags[MN_TP_MAX_WORLD];
+  int world, rank, rows_cap, M, gc;
+  int64_t cap;
+  uint32_t epoch;                                                          // of phase 1; phase 2 publishes epoch + 1
+  uint32_t* err; uint64_t wait_ticks;
+};
+__global__ __launch_bounds__(1024) void tp_reduce_gather_kernel(const TpGather p) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int m = blockIdx.x, col = threadIdx.x * 4;
+  int expired = 0;
+  if ((int)threadIdx.x < p.world) {
+    const uint32_t* f = p.flags[p.rank] + (int64_t)threadIdx.x * p.rows_cap + m;
+    const uint64_t t0 = wall_clock64();
+    while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - p.epoch) < 0) {
+      if (wall_clock64() - t0 > p.wait_ticks) { if (p.err) atomicExch(p.err, 0x200u | (unsigned)threadIdx.x); expired = 1; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  }
+  const int dead = __syncthreads_or(expired);
+  if (col < p.gc) {
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    const float* mine = p.inbox[p.rank] + (int64_t)(p.epoch & 1u) * p.world * p.cap + (int64_t)m * p.gc + col;
+    for (int s0 = 0; s0 < p.world; s0 += 8) {        // eight senders' loads in flight, added in sender order (every rank: the same bits)
+      f4 t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = s0 + j < p.world ? *reinterpret_cast<const f4*>(mine + (int64_t)(s0 + j) * p.cap) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v += t[j];
+    }
+    if (dead) { const float q = __builtin_nanf(""); v = f4{q, q, q, q}; }
+    const int64_t off = ((int64_t)((p.epoch + 1u) & 1u) * p.world + p.rank) * p.cap + (int64_t)m * p.gc + col;
+    for (int r = 0; r < p.world; ++r) *reinterpret_cast<f4*>(p.inbox[r] + off) = v;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if ((int)threadIdx.x < p.world) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(p.flags[threadIdx.x] + (int64_t)p.rank * p.rows_cap + m, p.epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// Which form does an all-reduce of M rows x D take on this communicator?  One-shot up to two_shot_rows rows (default 16: one xGMI hop
+// is the point at decode sizes), two-shot above when the row splits into `world` pieces of whole float4s.  -> columns per owner, or 0.
+static int g_tp_two_shot_rows = 16;
+#ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_tp_tune_two_shot(int rows) { g_tp_two_shot_rows = rows; }
+#endif
+static int tp_two_shot_cols(const mn_tp_comm* c, int M, int D) {
+  const int lim = c->two_shot_rows ? c->two_shot_rows : g_tp_two_shot_rows;
+  if (lim < 0 || M <= lim || c->world < 2 || (D % (4 * c->world)) != 0) return 0;
+  return D / c->world;
+}
+
 static bool tp_comm_ok(const mn_tp_comm* c, int rows, int D) {
   return c && c->world >= 1 && c->world <= MN_TP_MAX_WORLD && c->rank >= 0 && c->rank < c->world && c->inbox && c->flags &&
          rows <= c->rows_cap && (int64_t)rows * D <= c->cap && (D % 4) == 0 && D >= 64 && D <= 4096;
 }
 
-static void tp_push(const mn_tp_comm* c, uint32_t epoch, TpPush p, int M, int D, hipStream_t st) {
+// gc: 0 = one-shot (the row to every rank); > 0 = two-shot phase 1 (column piece j to rank j)
+static void tp_push(const mn_tp_comm* c, uint32_t epoch, TpPush p, int M, int D, hipStream_t st, int gc = 0) {
   for (int r = 0; r < c->world; ++r) { p.inbox[r] = c->inbox[r]; p.flags[r] = c->flags[r]; }
-  p.world = c->world; p.rank = c->rank; p.rows_cap = c->rows_cap; p.cap = c->cap; p.epoch = epoch; p.M = M; p.D = D;
+  p.world = c->world; p.rank = c->rank; p.rows_cap = c->rows_cap; p.cap = c->cap; p.epoch = epoch; p.M = M; p.D = D; p.scatter_cols = gc;
   hipLaunchKernelGGL(tp_push_kernel, dim3(M), dim3(((D / 4 + 63) / 64) * 64), 0, st, p);
 }
 
+// two-shot phase 2: wait for phase 1 (epoch), reduce this rank's piece, publish it everywhere (epoch + 1)
+static void tp_reduce_gather(const mn_tp_comm* c, uint32_t epoch, int M, int gc, hipStream_t st) {
+  TpGather p;
+  for (int r = 0; r < c->world; ++r) { p.inbox[r] = c->inbox[r]; p.flags[r] = c->flags[r]; }
+  p.world = c->world; p.rank = c->rank; p.rows_cap = c->rows_cap; p.cap = c->cap; p.epoch = epoch; p.M = M; p.gc = gc; p.err = c->err;
+  p.wait_ticks = (uint64_t)(c->wait_ms ? c->wait_ms : MN_TP_WAIT_MS_DEFAULT) * 100000ull;
+  const int threads = ((gc / 4 + 63) / 64) * 64;
+  hipLaunchKernelGGL(tp_reduce_gather_kernel, dim3(M), dim3(threads < 64 ? 64 : threads), 0, st, p);
+}
+
 // Consumer side: the glue's slab sum reads this rank's inbox (one slab per sender) after the row's arrival flags.
-static void tp_consume(WideGlue& g, const mn_tp_comm* c, uint32_t epoch) {
+// gc > 0: the all-reduce was two-shot — `epoch` is its SECOND epoch and the slabs hold the reduced row in pieces of gc columns.
+static void tp_consume(WideGlue& g, const mn_tp_comm* c, uint32_t epoch, int gc = 0) {
   g.P = c->inbox[c->rank] + (int64_t)(epoch & 1u) * c->world * c->cap;
-  g.nz = c->world; g.slab = c->cap;
+  g.nz = c->world; g.slab = c->cap; g.gather_cols = gc;
   g.wait_flags = c->flags[c->rank]; g.wait_n = c->world; g.wait_stride = c->rows_cap; g.wait_epoch = epoch; g.wait_err = c->err;
   g.wait_ticks = (uint64_t)(c->wait_ms ? c->wait_ms : MN_TP_WAIT_MS_DEFAULT) * 100000ull;      // ms -> ticks of the 100 MHz clock
 }
@@ -99,29 +178,44 @@ static void tp_consume(WideGlue& g, const mn_tp_comm* c, uint32_t epoch) {
 // out[m] = sum over ranks of x[m] (fp32 [M, D] partial per rank).  Stand-alone form of the mechanism above.  phase: MN_TP_PUSH
 // (publish x to every rank), MN_TP_REDUCE (wait for the row's arrivals, sum into out; completes the all-reduce and advances the
 // epoch) or both; split phases let the caller put other work between them (or run several ranks from one process).
+extern "C" int mn_tp_allreduce_segments(const mn_tp_comm* comm, int rows, int D) {
+  MN_CHECK_ARG(comm != nullptr, "mn_tp_allreduce_segments: null communicator");
+  return tp_two_shot_cols(comm, rows, D) ? 2 : 1;
+}
+
+// (name kept from round 3; above two_shot_rows rows the call runs the two-shot form — phases MN_TP_PUSH | MN_TP_GATHER | MN_TP_REDUCE)
 extern "C" int mn_allreduce_oneshot(mn_tp_comm* comm, const float* x, int64_t ldx, float* out, int64_t ldo, int M, int D, int phase,
                                     void* stream) {
-  MN_CHECK_ARG(M >= 1 && tp_comm_ok(comm, M, D) && (phase & ~3) == 0 && phase != 0 && (!(phase & MN_TP_PUSH) || (x && ldx == D)) &&
+  MN_CHECK_ARG(M >= 1 && tp_comm_ok(comm, M, D) && (phase & ~7) == 0 && phase != 0 && (!(phase & MN_TP_PUSH) || (x && ldx == D)) &&
                    (!(phase & MN_TP_REDUCE) || (out && (ldo % 4) == 0)),
                "mn_allreduce_oneshot: bad args (rows <= rows_cap, rows * D <= cap, D %% 4 == 0, 64 <= D <= 4096, ldx == D)");
   hipStream_t st = mn_stream(stream);
-  const uint32_t ep = comm->epoch + 1;
+  const int gc = tp_two_shot_cols(comm, M, D);
+  const uint32_t ep = comm->epoch + 1;                 // phase 1's epoch; a two-shot all-reduce completes at ep + 1
   if (phase & MN_TP_PUSH) {
     TpPush p;
     memset(&p, 0, sizeof(p));
     p.P = x; p.nz = 1; p.slab = 0;
-    tp_push(comm, ep, p, M, D, st);
+    tp_push(comm, ep, p, M, D, st, gc);
   }
+  if ((phase & MN_TP_GATHER) && gc) tp_reduce_gather(comm, ep, M, gc, st);
   if (phase & MN_TP_REDUCE) {
     WideGlue g;
     memset(&g, 0, sizeof(g));
-    tp_consume(g, comm, ep);
-    // the glue adds the slabs P[0 .. nz) to a source row: take sender 0's slab as the source and sum the other world - 1
-    g.h = g.P; g.ldh = D; g.P += g.slab; g.nz -= 1;
-    if (g.nz == 0) g.P = nullptr;
+    tp_consume(g, comm, gc ? ep + 1 : ep, gc);
+    if (gc) {
+      // the pieces ARE the result: add them to a zero source row — reuse piece 0's own slab as a source is not possible (pieces are
+      // concatenated), so the glue reads h = out after clearing it
+      (void)hipMemsetAsync(out, 0, (size_t)M * ldo * sizeof(float), st);
+      g.h = out; g.ldh = ldo;
+    } else {
+      // the glue adds the slabs P[0 .. nz) to a source row: take sender 0's slab as the source and sum the other world - 1
+      g.h = g.P; g.ldh = D; g.P += g.slab; g.nz -= 1;
+      if (g.nz == 0) g.P = nullptr;
+    }
     g.out = out; g.ldo = ldo; g.M = M; g.D = D;
     wide_glue(g, st);
-    comm->epoch = ep;
+    comm->epoch = gc ? ep + 1 : ep;
   }
   MN_CHECK_LAUNCH("mn_allreduce_oneshot");
   return MN_OK;
@@ -142,7 +236,7 @@ extern "C" int mn_ep_combine(mn_tp_comm* comm, const float* yg, const int32_t* s
   memset(&p, 0, sizeof(p));
   p.P = P; p.nz = nz; p.slab = slab;
   p.cy = yg; p.cy_nz = 1; p.cpos = slot_of; p.cw = topk_w; p.ci = topk_idx; p.n_slot = n_slot; p.e0 = expert0; p.e1 = expert0 + n_local;
-  tp_push(comm, ep, p, M, D, st);
+  tp_push(comm, ep, p, M, D, st);                    // (stand-alone form: one call per rank, so always one-shot)
   WideGlue g;
   memset(&g, 0, sizeof(g));
   g.h = h; g.ldh = ldh;
@@ -210,7 +304,7 @@ extern "C" size_t mn_llm_tp_workspace_bytes(const mn_llm* m, const mn_llm_tp* tp
   return llm_tp_carve(m, tp, rows, t_max, nullptr, 0, &w);
 }
 
-extern "C" int mn_llm_tp_segments(const mn_llm* m) { return 2 * m->n_layers + 1; }
+extern "C" int mn_llm_tp_segments(const mn_llm* m) { return 2 * m->n_layers + 1; }      // one-shot all-reduces (<= two_shot_rows rows)
 
 extern "C" int mn_llm_step_tp(const mn_llm* m, const mn_llm_tp* tp, mn_tp_comm* comm, const float* x, int64_t ldx, int x_row_div, int M,
                               const uint8_t* image_mask, const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_pos,
@@ -222,7 +316,9 @@ extern "C" int mn_llm_step_tp(const mn_llm* m, const mn_llm_tp* tp, mn_tp_comm* 
   MN_CHECK_ARG(m->wfmt == MN_W_BF16 || (mn_w8(m->wfmt) && M <= 64 && m->w_gate_up_scale && m->w_down_scale && (m->hidden % 16) == 0 &&
                                         (m->moe_inter % 16) == 0 && (tp->shared_inter == 0 || (tp->ws_gate_up_scale && tp->ws_down_scale))),
                "mn_llm_step_tp: fp8 experts need row scales, widths %% 16 == 0 and <= 64 rows (M = %d)", M);
-  const int n_seg = 2 * m->n_layers + 1;
+  // above two_shot_rows rows every all-reduce is two-shot: one more segment (the owners' reduce + all-gather) and one more epoch each
+  const int gc = tp_two_shot_cols(comm, M, m->hidden), ars = gc ? 2 : 1;
+  const int n_seg = 2 * ars * m->n_layers + 1;
   MN_CHECK_ARG(seg_begin >= 0 && seg_begin < seg_end && seg_end <= n_seg, "mn_llm_step_tp: segments [%d, %d) of %d", seg_begin, seg_end, n_seg);
   LlmTpWs tw;
   const size_t need = llm_tp_carve(m, tp, M, t_max, workspace, workspace_bytes, &tw);
@@ -246,7 +342,7 @@ extern "C" int mn_llm_step_tp(const mn_llm* m, const mn_llm_tp* tp, mn_tp_comm* 
     if (on()) {
       memset(&g, 0, sizeof(g));
       if (l == 0) { g.x = x; g.ldx = ldx; g.x_row_div = x_row_div; }
-      else { g.h = w.h; g.ldh = H; tp_consume(g, comm, ep); }
+      else { g.h = w.h; g.ldh = H; tp_consume(g, comm, ep, gc); }
       g.h_out = fin ? nullptr : w.h; g.ldho = H;
       g.norm = 1; g.ng = fin ? m->final_norm : m->ln1[l]; g.eps = m->rms_eps;
       if (fin) { g.out = hidden_out; g.ldo = H; }
@@ -284,13 +380,14 @@ extern "C" int mn_llm_step_tp(const mn_llm* m, const mn_llm_tp* tp, mn_tp_comm* 
       TpPush p;                                     // all-reduce 1: the dense partial of this rank's heads
       memset(&p, 0, sizeof(p));
       p.P = pp; p.nz = nz; p.slab = (int64_t)M * H;
-      tp_push(comm, ep + 1, p, M, H, st);
+      tp_push(comm, ep + 1, p, M, H, st, gc);
     }
     ++seg; ++ep;
-    // ---- segment 2l + 1: h += all-reduced attention partials; RMSNorm(ln2); router (replicated); local experts + shared slice
+    if (gc) { if (on()) tp_reduce_gather(comm, ep, M, gc, st); ++seg; ++ep; }      // two-shot: the owners reduce and publish
+    // ---- next segment: h += all-reduced attention partials; RMSNorm(ln2); router (replicated); local experts + shared slice
     if (on()) {
       memset(&g, 0, sizeof(g));
-      g.h = w.h; g.ldh = H; tp_consume(g, comm, ep); g.h_out = w.h; g.ldho = H;
+      g.h = w.h; g.ldh = H; tp_consume(g, comm, ep, gc); g.h_out = w.h; g.ldho = H;
       g.norm = 1; g.ng = m->ln2[l]; g.eps = m->rms_eps; g.Y = w.yh; g.ldy = H; g.y_lo_off = (int64_t)M * H; g.M = M; g.D = H;
       wide_glue(g, st);
       mn_g256 a;
@@ -370,11 +467,12 @@ extern "C" int mn_llm_step_tp(const mn_llm* m, const mn_llm_tp* tp, mn_tp_comm* 
       }
       if (SI) { p.P = psh; p.nz = nzs; p.slab = (int64_t)M * H; }
       p.cpos = w.slot_of; p.cw = w.tw; p.ci = w.ti; p.n_slot = n_slot; p.e0 = e0; p.e1 = e1;
-      tp_push(comm, ep + 1, p, M, H, st);
+      tp_push(comm, ep + 1, p, M, H, st, gc);
     }
     ++seg; ++ep;
+    if (gc) { if (on()) tp_reduce_gather(comm, ep, M, gc, st); ++seg; ++ep; }
   }
-  if (seg_end == n_seg) comm->epoch += 2u * (uint32_t)m->n_layers;
+  if (seg_end == n_seg) comm->epoch += 2u * (uint32_t)ars * (uint32_t)m->n_layers;
   MN_CHECK_LAUNCH("mn_llm_step_tp");
   return MN_OK;
 }
@@ -414,7 +512,8 @@ extern "C" int mn_rf_sample_tp(const mn_rf_head* h, mn_tp_comm* comm, const floa
                    (h->hidden % 64) == 0 && (h->z_dim % 64) == 0 && (h->llm_hidden % 64) == 0 && h->target <= 64 && (h->target % 4) == 0 &&
                    tp_comm_ok(comm, rows, h->w), "mn_rf_sample_tp: unsupported widths / communicator");
   MN_CHECK_ARG(h->wfmt == MN_W_BF16 || (rf_fp8_ok(h) && rows <= 64), "mn_rf_sample_tp: fp8 weights need row scales, widths %% 16 == 0 and <= 64 rows");
-  const int n_seg = h->steps * h->depth + 1;
+  const int gc = tp_two_shot_cols(comm, rows, h->w), ars = gc ? 2 : 1;      // two-shot all-reduces above two_shot_rows rows (one more segment each)
+  const int n_seg = ars * h->steps * h->depth + 1;
   MN_CHECK_ARG(seg_begin >= 0 && seg_begin < seg_end && seg_end <= n_seg, "mn_rf_sample_tp: segments [%d, %d) of %d", seg_begin, seg_end, n_seg);
   RfWideWs w;
   const size_t need = rf_tp_carve(h, rows, workspace, workspace_bytes, &w);
@@ -472,7 +571,7 @@ extern "C" int mn_rf_sample_tp(const mn_rf_head* h, mn_tp_comm* comm, const floa
     TpPush p;
     memset(&p, 0, sizeof(p));
     p.P = p3; p.nz = nz; p.slab = (int64_t)rows * W;
-    tp_push(comm, ep + 1, p, rows, W, st);
+    tp_push(comm, ep + 1, p, rows, W, st, gc);
     return 0;
   };
   if (on()) {
@@ -507,6 +606,7 @@ extern "C" int mn_rf_sample_tp(const mn_rf_head* h, mn_tp_comm* comm, const floa
       MN_TRYZ(block_gemms(0));
     }
     ++seg; ++ep;
+    if (gc) { if (on()) tp_reduce_gather(comm, ep, rows, gc, st); ++seg; ++ep; }
     for (int b = 0; b < h->depth; ++b) {
       const float* mod = ada + (int64_t)b * 3 * W;
       const bool last = b + 1 == h->depth;
@@ -514,7 +614,7 @@ extern "C" int mn_rf_sample_tp(const mn_rf_head* h, mn_tp_comm* comm, const floa
         // hh += gate * (all-reduced w3 partials + b3); next in_ln / final LN + modulate  (diff_loss:270-272, 290)
         const float* nmod = last ? ada + (int64_t)h->depth * 3 * W : ada + (int64_t)(b + 1) * 3 * W;
         memset(&g, 0, sizeof(g));
-        g.h = w.hh; g.ldh = W; tp_consume(g, comm, ep); g.pbias = h->b3[b];
+        g.h = w.hh; g.ldh = W; tp_consume(g, comm, ep, gc); g.pbias = h->b3[b];
         g.gate = mod + 2 * W; g.ldgate = A; g.h_out = w.hh; g.ldho = W;
         g.norm = 2; g.ng = last ? nullptr : h->ln_g[b + 1]; g.nb = last ? nullptr : h->ln_b[b + 1]; g.eps = 1e-6f;
         g.shift = nmod; g.scale = nmod + W; g.ldmod = A;
@@ -534,10 +634,13 @@ extern "C" int mn_rf_sample_tp(const mn_rf_head* h, mn_tp_comm* comm, const floa
             hipLaunchKernelGGL(rf_gather_latent_kernel, dim3(mn_cdiv(n_images * T, 256)), dim3(256), 0, st, w.x, latent_out, n_images, rpi, T);
         }
       }
-      if (!last) { ++seg; ++ep; }
+      if (!last) {
+        ++seg; ++ep;
+        if (gc) { if (on()) tp_reduce_gather(comm, ep, rows, gc, st); ++seg; ++ep; }
+      }
     }
   }
-  if (seg_end == n_seg) comm->epoch += (uint32_t)(h->steps * h->depth);
+  if (seg_end == n_seg) comm->epoch += (uint32_t)(ars * h->steps * h->depth);
   MN_CHECK_LAUNCH("mn_rf_sample_tp");
   return MN_OK;
 }

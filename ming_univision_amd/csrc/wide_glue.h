@@ -35,6 +35,9 @@ struct WideGlue {
   // allocator stall — is legitimate and can be long; a dead peer is not); on expiry the row sets wait_err AND poisons its outputs
   // with NaN instead of consuming stale slabs, so a missed all-reduce can never pass for a result.
   const uint32_t* wait_flags; int wait_n; int64_t wait_stride; uint32_t wait_epoch; uint32_t* wait_err; uint64_t wait_ticks;
+  // two-shot all-reduce (tp.inl): the inbox holds the REDUCED row in `nz` column pieces of gather_cols columns, piece z in slab z at
+  // [m * gather_cols, + gather_cols) — the pieces are concatenated, not summed.  0: the slabs are summed (one-shot, split-K).
+  int gather_cols;
 };
 
 namespace {
@@ -104,6 +107,11 @@ __global__ __launch_bounds__(1024) void wide_glue_kernel(const WideGlue p) {
       if (p.pbias) y = f4{bf16_to_f32(p.pbias[col]), bf16_to_f32(p.pbias[col + 1]), bf16_to_f32(p.pbias[col + 2]), bf16_to_f32(p.pbias[col + 3])};
       const float* pp = p.P + (int64_t)m * D + col;
       int z = 0;
+      if (p.gather_cols) {                               // reduced row, owner by owner: this thread's four columns sit in one piece
+        const int zc = col / p.gather_cols;
+        y += *reinterpret_cast<const f4*>(p.P + (int64_t)zc * p.slab + (int64_t)m * p.gather_cols + (col - zc * p.gather_cols));
+        z = p.nz;
+      }
       for (; z + 4 <= p.nz; z += 4) {                    // independent 16-byte loads in flight
         const f4 a = *reinterpret_cast<const f4*>(pp + (z + 0) * p.slab), b = *reinterpret_cast<const f4*>(pp + (z + 1) * p.slab);
         const f4 c = *reinterpret_cast<const f4*>(pp + (z + 2) * p.slab), d = *reinterpret_cast<const f4*>(pp + (z + 3) * p.slab);

@@ -208,6 +208,7 @@ class TpCommunicator:
                            [flags.data_ptr() if r == rank else sink_flags.data_ptr() for r in range(world)], cap, rows_cap, err,
                            keep=(sink, sink_flags))
         c._relay = (dist, inbox, flags)
+        c.struct.two_shot_rows = -1              # the relay delivers whole rows between segments: one-shot form only
         return c
 
     def relay(self, epoch, n_floats):
@@ -223,10 +224,15 @@ class TpCommunicator:
             raise RuntimeError(f"tensor-parallel all-reduce: rank {self.rank} gave up waiting for sender {e & 0xff} (a peer died or the "
                                "ranks' launch sequences diverged)")
 
-    PUSH, REDUCE = 1, 2
+    PUSH, REDUCE, GATHER = 1, 2, 4
 
-    def all_reduce(self, x, out=None, phase=3):
-        """out = sum over ranks of x (fp32 [M, D]) through mn_allreduce_oneshot; phase = PUSH, REDUCE or both (3)."""
+    def allreduce_segments(self, rows, width):
+        """1 (one-shot) or 2 (two-shot: above `two_shot_rows` rows) — segments / epochs an all-reduce of rows x width takes here."""
+        return int(lib().mn_tp_allreduce_segments(C.byref(self.struct), rows, width))
+
+    def all_reduce(self, x, out=None, phase=7):
+        """out = sum over ranks of x (fp32 [M, D]) through mn_allreduce_oneshot; phase = PUSH, GATHER (two-shot only: the owners'
+        reduce + all-gather push, a no-op for a one-shot all-reduce), REDUCE, or all of them (7)."""
         assert x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and x.dim() == 2
         M, D = x.shape
         if out is None and phase & self.REDUCE:
@@ -342,8 +348,12 @@ class TpDecoderShard:
         self.__init__(full, rank, world)
         return self
 
-    def n_segments(self):
-        return int(lib().mn_llm_tp_segments(C.byref(self.struct)))
+    def n_segments(self, comm=None, rows=1):
+        """Segments of one step: 2 L + 1 with one-shot all-reduces; a two-shot all-reduce (above comm.two_shot_rows rows) adds the
+        owners' reduce + all-gather segment."""
+        base = int(lib().mn_llm_tp_segments(C.byref(self.struct)))
+        ars = 1 if comm is None else int(lib().mn_tp_allreduce_segments(C.byref(comm.struct), rows, self.cfg.hidden_size))
+        return (base - 1) * ars + 1
 
     def weight_bytes(self):
         return sum(t.numel() * t.element_size() for ly in self.layers for k, t in ly.items() if t is not None and k not in ("ln1", "ln2"))
@@ -362,7 +372,7 @@ class TpDecoderShard:
             n = lib().mn_llm_tp_workspace_bytes(C.byref(self.struct), C.byref(self.tp), M, self.t_max)
             self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.device)
         ws = self._ws[key]
-        n_seg = self.n_segments()
+        n_seg = self.n_segments(comm, M)
         check(lib().mn_llm_step_tp(C.byref(self.struct), C.byref(self.tp), C.byref(comm.struct), ptr(x), ldx, x_row_div, M, ptr(image_mask),
                                    ptr(row_seq), ptr(row_slot), ptr(row_pos), ptr(row_len), ptr(key_mask),
                                    0 if key_mask is None else key_mask.stride(0), ptr(self.kv_cache), self.n_seq, self.t_max, ptr(out),
@@ -407,8 +417,10 @@ class TpRfShard:
         self.target = rf.target
         self._ws = {}
 
-    def n_segments(self):
-        return int(lib().mn_rf_tp_segments(C.byref(self.struct)))
+    def n_segments(self, comm=None, rows=1):
+        base = int(lib().mn_rf_tp_segments(C.byref(self.struct)))
+        ars = 1 if comm is None else int(lib().mn_tp_allreduce_segments(C.byref(comm.struct), rows, self.rf.w))
+        return (base - 1) * ars + 1
 
     def sample_tp(self, comm, hidden, noise, temperature=1.0, text_cfg=3.0, image_cfg=1.1, out=None, n_images=1, seg_begin=0, seg_end=None):
         rows = hidden.shape[0]
@@ -419,7 +431,7 @@ class TpRfShard:
         ws = self._ws[key]
         if out is None:
             out = torch.empty(noise.shape, dtype=torch.float32, device=hidden.device)
-        n_seg = self.n_segments()
+        n_seg = self.n_segments(comm, rows)
         check(lib().mn_rf_sample_tp(C.byref(self.struct), C.byref(comm.struct), ptr(hidden), hidden.stride(0), rows, n_images, ptr(noise),
                                     float(temperature), float(text_cfg), float(image_cfg), ptr(out), ptr(ws), ws.numel(), seg_begin,
                                     n_seg if seg_end is None else seg_end, current_stream()), "mn_rf_sample_tp")
@@ -542,7 +554,7 @@ class TpSimGroup(_TpDecoderBase):
         M = rows or x.shape[0]
         outs = [out if r == 0 and out is not None else torch.empty(M, self.cfg.hidden_size, dtype=torch.float32, device=self.device)
                 for r in range(self.world)]
-        for seg in range(self.shards[0].n_segments()):
+        for seg in range(self.shards[0].n_segments(self.comms[0], M)):
             for r, sh in enumerate(self.shards):
                 sh.step_tp(self.comms[r], x, row_seq, row_slot, row_pos, row_len, key_mask, image_mask, out=outs[r], rows=rows,
                            x_row_div=x_row_div, seg_begin=seg, seg_end=seg + 1)
@@ -572,7 +584,7 @@ class TpSimGroup(_TpDecoderBase):
         """RectifiedFlowLoss.sample through the group (the TOKEN sampler above keeps the decoder interface's name `sample`)."""
         outs = [out if r == 0 and out is not None else torch.empty(noise.shape, dtype=torch.float32, device=hidden.device)
                 for r in range(self.world)]
-        for seg in range(self.rf_shards[0].n_segments()):
+        for seg in range(self.rf_shards[0].n_segments(self.comms[0], hidden.shape[0])):
             for r, sh in enumerate(self.rf_shards):
                 sh.sample_tp(self.comms[r], hidden, noise, temperature, text_cfg, image_cfg, out=outs[r], n_images=n_images,
                              seg_begin=seg, seg_end=seg + 1)
@@ -670,7 +682,7 @@ class TpRank(_TpDecoderBase):
                                       x_row_div=x_row_div, seg_begin=s0, seg_end=s1)
         if self.transport == "xgmi":
             return call()
-        return self._segmented(call, self.shard.n_segments(), M * self.cfg.hidden_size)
+        return self._segmented(call, self.shard.n_segments(self.comm, M), M * self.cfg.hidden_size)
 
     def copy_sequence(self, src, dst, n):
         self.shard.kv_cache[:, dst, :, :, :n].copy_(self.shard.kv_cache[:, src, :, :, :n])
@@ -687,7 +699,7 @@ class TpRank(_TpDecoderBase):
                                            seg_begin=s0, seg_end=s1)
         if self.transport == "xgmi":
             return call()
-        return self._segmented(call, self.rf_shard.n_segments(), hidden.shape[0] * self.rf_shard.rf.w)
+        return self._segmented(call, self.rf_shard.n_segments(self.comm, hidden.shape[0]), hidden.shape[0] * self.rf_shard.rf.w)
 
     def sampler(self):
         return _SamplerView(self)

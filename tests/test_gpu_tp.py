@@ -20,22 +20,42 @@ def _dev(sd):
 
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_allreduce_oneshot_phases(world):
-    """mn_allreduce_oneshot: every rank pushes, then every rank reduces — three rounds on one communicator (epoch parity, flags never
-    reset), ragged row counts; the result is the fp32 sum over the ranks, bit-identical on every rank (same order of additions)."""
+    """mn_allreduce_oneshot: every rank pushes, then every rank reduces — rounds on one communicator (epoch parity, flags never reset),
+    ragged row counts; the result is the fp32 sum over the ranks, bit-identical on every rank (same order of additions).  Above 16 rows
+    the all-reduce is TWO-SHOT (round 5): reduce-scatter push, the owners' reduce + all-gather push (phase GATHER), consume — two
+    epochs; one-shot and two-shot rounds alternate on the same communicator."""
     from ming_univision_amd.tp import TpCommunicator
     comms = TpCommunicator.simulated(world, rows_cap=40, width=512)
     g = torch.Generator().manual_seed(world)
-    for rnd, (M, D) in enumerate([(3, 512), (40, 256), (1, 64)]):
+    epoch = 0
+    for rnd, (M, D) in enumerate([(3, 512), (40, 256), (1, 64), (17, 512), (40, 512), (16, 512)]):
+        two = comms[0].allreduce_segments(M, D) == 2
+        assert two == (M > 16 and D % (4 * world) == 0)
         xs = [torch.randn(M, D, generator=g).cuda() for _ in range(world)]
         for r in range(world):
             comms[r].all_reduce(xs[r], phase=TpCommunicator.PUSH)
+        for r in range(world):
+            comms[r].all_reduce(xs[r], phase=TpCommunicator.GATHER)          # (nothing to do for a one-shot round)
         outs = [comms[r].all_reduce(xs[r], phase=TpCommunicator.REDUCE) for r in range(world)]
         ref = torch.stack(xs).double().sum(0)
+        epoch += 2 if two else 1
         for r in range(world):
             assert rel_err(outs[r], ref) < 1e-6, (rnd, r)
             assert torch.equal(outs[r], outs[0])                  # same order of additions on every rank: bit-identical
-            assert comms[r].struct.epoch == rnd + 1
+            assert comms[r].struct.epoch == epoch
             comms[r].check_err()
+    # the same 40 rows through the two-shot (default threshold) and the one-shot form (threshold raised): the same sum to fp32 rounding
+    # (the owners add the senders one by one, the one-shot consumer pairs its slabs)
+    xs = [torch.randn(40, 512, generator=g).cuda() for _ in range(world)]
+    res = []
+    for lim in (0, 1 << 20):                                       # default threshold (two-shot at 40 rows) / never
+        for c in comms:
+            c.struct.two_shot_rows = lim
+        for ph in (TpCommunicator.PUSH, TpCommunicator.GATHER):
+            for r in range(world):
+                comms[r].all_reduce(xs[r], phase=ph)
+        res.append([comms[r].all_reduce(xs[r], phase=TpCommunicator.REDUCE) for r in range(world)][0])
+    assert rel_err(res[0], res[1]) < 1e-6 and rel_err(res[0], torch.stack(xs).double().sum(0)) < 1e-6
 
 
 def test_allreduce_oneshot_concurrent_ranks_really_wait():
@@ -48,6 +68,21 @@ def test_allreduce_oneshot_concurrent_ranks_really_wait():
     g = torch.Generator().manual_seed(3)
     for _ in range(5):
         xs = [torch.randn(8, 256, generator=g).cuda() for _ in range(2)]
+        torch.cuda.synchronize()
+        outs = [None, None]
+        for r in (0, 1):
+            with torch.cuda.stream(streams[r]):
+                outs[r] = comms[r].all_reduce(xs[r])
+        torch.cuda.synchronize()
+        for r in (0, 1):
+            comms[r].check_err()
+            assert torch.equal(outs[r], xs[0] + xs[1])
+    # the two-shot form (40 rows): scatter push, owner reduce + all-gather, consume — all three enqueued per rank in ONE call, so the
+    # owners' kernels and the consumers really wait on the other stream's pushes
+    comms = TpCommunicator.simulated(2, rows_cap=40, width=256)
+    assert comms[0].allreduce_segments(40, 256) == 2
+    for _ in range(5):
+        xs = [torch.randn(40, 256, generator=g).cuda() for _ in range(2)]
         torch.cuda.synchronize()
         outs = [None, None]
         for r in (0, 1):
@@ -294,7 +329,8 @@ def test_tp_wide_rows_match_unsharded():
     noise = torch.randn(33, 32, generator=gen).cuda()
     ref = rf.sample(hidden, noise, n_images=33)
     outs = [torch.empty_like(ref) for _ in range(world)]
-    for seg in range(shards[0].n_segments()):
+    assert shards[0].n_segments(comms[0], 66) == 2 * (shards[0].n_segments() - 1) + 1      # 66 rows: every all-reduce two-shot
+    for seg in range(shards[0].n_segments(comms[0], 66)):
         for r in range(world):
             shards[r].sample_tp(comms[r], hidden, noise, out=outs[r], n_images=33, seg_begin=seg, seg_end=seg + 1)
     for r in range(world):
@@ -338,7 +374,8 @@ def test_tp_relayed_transport_matches_unsharded():
     seq = torch.zeros(T, dtype=torch.int32).cuda()
     im = g["image_mask"][0].to(torch.uint8).cuda()
     outs = [torch.empty(T, cfg.hidden_size, device="cuda") for _ in range(world)]
-    n_seg = shards[0].n_segments()
+    n_seg = shards[0].n_segments(comms[0], T)
+    assert n_seg == shards[0].n_segments()               # the relayed transport delivers whole rows: one-shot only
     base = comms[0].struct.epoch
     for s_ in range(n_seg):
         for r in range(world):
