@@ -520,11 +520,11 @@ static bool rf_fp8_ok(const mn_rf_head* h) {
 
 // <= 4 rows (the CFG rows of one image — the reference's call shape): the SwiGLU glue launch is folded into w3's prologue
 // (stream_fuse.h): three launches per ResBlock instead of four.  g_rf_fuse: dev-library A/B switch.
-static int g_rf_fuse = 1, g_rf_boundary = 1, g_rf_kc = 1;
+static int g_rf_fuse = 1, g_rf_boundary = 1, g_rf_kc = 1, g_rf_persist = 1;
 static void g_rf_ada_stream_set(int v);
 #ifdef MN_DEV_HOOKS
 // bit 0: SwiGLU glue fused into w3; bit 1: one-launch Euler-step boundary; bit 2: adaLN NOT streamed; bit 3: K-complete chain OFF
-extern "C" MN_DEV_API void mn_rf_tune_fuse(int on) { g_rf_fuse = on & 1; g_rf_boundary = (on >> 1) & 1; g_rf_ada_stream_set((on >> 2) & 1 ? 0 : 1); g_rf_kc = (on >> 3) & 1 ? 0 : 1; }
+extern "C" MN_DEV_API void mn_rf_tune_fuse(int on) { g_rf_fuse = on & 1; g_rf_boundary = (on >> 1) & 1; g_rf_ada_stream_set((on >> 2) & 1 ? 0 : 1); g_rf_kc = (on >> 3) & 1 ? 0 : 1; g_rf_persist = (on >> 4) & 1 ? 0 : 1; }
 #endif
 static bool rf_fused_shape_ok(const mn_rf_head* h, int rows) {
   return rows <= FUSE_MAX_ROWS && rf_chain_ok(h, rows) &&
@@ -551,7 +551,7 @@ static size_t rf_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, floa
   *c = cv.take<float>((size_t)rows * h->w);
   *ada = cv.take<float>((size_t)h->steps * rows * A);       // modulations of every Euler step
   *y = cv.take<bf16_t>((size_t)2 * h->steps * rows * h->w);
-  *bar = cv.take<unsigned>(64);
+  *bar = cv.take<unsigned>(RF_PERSIST_BAR_WORDS);
   *hh = cv.take<float>((size_t)rows * h->w);
   *hid = cv.take<float>((size_t)rows * h->hidden);
   *v = cv.take<float>((size_t)rows * h->target);
@@ -648,6 +648,7 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   const float* ada_all = ada;
   const bool boundary = chain && g_rf_boundary && T <= 256 && (T % 8) == 0 && w <= 4096;
   int nz_fin = 0;
+  unsigned n_persist = 0;                           // persistent launches so far (each takes its own range of barrier epochs)
   for (int s = 0; s < h->steps; ++s) {
     const float* ada = ada_all + (int64_t)s * rows * A;
     // h = input_proj(x)  (diff_loss:371)
@@ -669,7 +670,19 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
       // <= 2 rows (the CFG rows of one image): K-complete launches (stream_kc.hip) — w12' normalises / modulates h itself and writes
       // w3's operand, w3' applies the gated residual in place: two launches per block, no slabs, no glue between the blocks
       const bool kc = g_rf_kc && fused && rf_kc_ok(h->wfmt, rows, w, hid_n);
-      for (int b = 0; kc && b < h->depth; ++b) {
+      // ... and, one workgroup per CU, all blocks of the step as ONE persistent launch with grid barriers between the phases
+      const bool persist = kc && g_rf_persist && rf_persist_ok(h->wfmt, rows, w, hid_n, stream);
+      if (persist && s == 0) {
+        if (hipMemsetAsync(bar, 0, RF_PERSIST_BAR_WORDS * sizeof(unsigned), st) != hipSuccess) { mn_set_error("mn_rf_sample: hipMemsetAsync failed"); return MN_ELAUNCH; }
+      }
+      for (int b = 0; persist && b < h->depth; b += RF_PERSIST_MAX_BLOCKS) {
+        const int nb = h->depth - b < RF_PERSIST_MAX_BLOCKS ? h->depth - b : RF_PERSIST_MAX_BLOCKS;
+        MN_TRY(rf_blocks_persist(h->wfmt, hh, yb, rows, w, hid_n, ada + (int64_t)b * 3 * w, (int64_t)A, nb,
+                                 reinterpret_cast<const void* const*>(h->w12 + b), h->wfmt ? h->w12_scale + b : nullptr, h->b12 + b,
+                                 h->ln_g + b, h->ln_b + b, reinterpret_cast<const void* const*>(h->w3 + b),
+                                 h->wfmt ? h->w3_scale + b : nullptr, h->b3 + b, bar, 64u * n_persist++, stream));
+      }
+      for (int b = 0; kc && !persist && b < h->depth; ++b) {
         const float* mod = ada + (int64_t)b * 3 * w;
         MN_TRY(rf_w12_kc(h->wfmt, hh, rows, w, hid_n, h->ln_g[b], h->ln_b[b], mod, mod + w, (int64_t)A, h->w12[b],
                          h->wfmt ? h->w12_scale[b] : nullptr, h->b12[b], yb, stream));

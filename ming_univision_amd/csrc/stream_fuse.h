@@ -28,6 +28,18 @@ int rf_w12_kc(int wfmt, const float* h, int M, int w, int hid, const bf16_t* ln_
 int rf_w3_kc(int wfmt, const bf16_t* Y3, int M, int w, int hid, const void* W3, const float* s3, const bf16_t* b3, const float* gate,
              int64_t ldmod, float* h, void* stream);
 
+// ... and every block of one Euler step as ONE persistent launch (grid barrier between the phases, the next phase's first weight chunks
+// requested before the wait).  rf_persist_ok: a K-complete shape, one workgroup per CU, the stream not being captured.  `bar`:
+// RF_PERSIST_BAR_WORDS words of device memory zeroed by the caller; epoch0 = 0, 64, 128, ... for successive launches on it.
+// Arithmetic and its order are those of the two launches: same bits.
+constexpr int RF_PERSIST_MAX_BLOCKS = 16;
+constexpr int RF_PERSIST_BAR_WORDS = 320;
+bool rf_persist_ok(int wfmt, int M, int w, int hid, void* stream);
+int rf_blocks_persist(int wfmt, float* h, bf16_t* Y3, int M, int w, int hid, const float* mod, int64_t ldmod, int nblk,
+                      const void* const* W12, const float* const* s12, const bf16_t* const* b12, const bf16_t* const* ln_g,
+                      const bf16_t* const* ln_b, const void* const* W3, const float* const* s3, const bf16_t* const* b3,
+                      unsigned* bar, unsigned epoch0, void* stream);
+
 // ---- the MoE down projection of a 1- / 2-row step with the segments spread over the waves of a workgroup (moe_down.hip):
 //   out[b][n] = res[b][n] + sum_s tw[b, s] * hmid[b][s * I ..] . W[ti[b, s]][n][..]      (bf16 weights)
 bool moe_down_ok(int wfmt, int n_slot, int H, int I);

@@ -18,6 +18,7 @@
 // Two launches per ResBlock, no slabs, no glue.  Weight bytes, MFMA work and per-wave streaming (6 / 4 chunks of 8 KiB per wave; one /
 // two chunks in flight: deeper rings measured slower, as in the K-slice kernel) are those of the K-slice form; all four weight formats (bf16, e4m3, int8, NF4: w8_codec.h) are template instances.
 // Rows >= M of the MFMA's 16-row operand carry copies of the real rows: output rows are independent, the copies' results are never stored.
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -105,7 +106,7 @@ __device__ __forceinline__ int xoff(int row, int slot, int xstride) { return row
 template <int WQ>
 __device__ __forceinline__ void mma_chunk(f32x4& acc, const char* wbuf, const char* xs, int xstride, int M, int kc, int lane) {
   const int fr = lane & 15, fq = lane >> 4;
-  const int ra = fr < M ? fr : 0;                   // rows >= M: copies (their output rows are never stored)
+  const int ra = fr < M ? fr : 0;                   // rows >= M: copies (their output rows are never stored; masking their LDS reads off measured 2-4 % slower)
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     const bf16x8 w = *reinterpret_cast<const bf16x8*>(wbuf + (WQ == 2 ? wslot4(fr, s * 4 + fq) : wslot(fr, s * 4 + fq)));
@@ -117,6 +118,25 @@ __device__ __forceinline__ void mma_chunk(f32x4& acc, const char* wbuf, const ch
   }
 }
 
+// One wave's weight stream of a phase: rows [n0, n0 + 16) of W [Ntot][K], k from kbeg, nch chunks.
+struct WStream {
+  const void* W; const float* wscale; int n0, Ntot, K, kbeg, nch, wf; bool live;
+};
+template <int WQ>
+__device__ __forceinline__ void issue(Chunk<WQ>& c, const WStream& st, int chunk, int lane) {
+  issue<WQ>(c, st.W, st.wscale, st.n0, st.Ntot, st.K, st.kbeg + chunk * WCH, lane);
+}
+
+// Data that workgroups hand to each other INSIDE a launch (the persistent form below) is stored write-through and loaded past the L1
+// (`sc1`, cdna_hip_programming.md Guideline 16, R1): no release / acquire fence — an L2 write-back + L1 invalidate per barrier measured
+// 6 us (tools/exp/gridbar_bench.hip) — and the same instructions otherwise.
+constexpr int AUX_SC1 = 16;
+// dev-library timeline of the persistent launch (mn_rf_kc_trace): workgroup 0, thread 0 stamps the 100 MHz clock
+__device__ __forceinline__ void stamp(uint64_t* tr, int k) { if (tr && threadIdx.x == 0) tr[k] = wall_clock64(); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t coh_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
 struct W12Args {
   const float* h; int M, w, hid;
   const bf16_t* ln_g; const bf16_t* ln_b; const float* shift; const float* scale; int64_t ldmod;
@@ -125,10 +145,63 @@ struct W12Args {
 };
 
 // ---- w12': LayerNorm-modulate prologue, (gate, up) tile pairs x K-halves, SwiGLU + split epilogue -------------------------------------
-template <int WQ, int MR, int RD, int NW>
-__global__ __launch_bounds__(NW * 64) void rf_w12_kc_kernel(const W12Args a) {
-  constexpr int KS = NW / 4;                        // K-splits: NW waves = 2 tile pairs x (gate, up) x KS K-ranges
-  extern __shared__ __attribute__((aligned(16))) char lds[];
+// wave -> (tile pair, gate | up, K-range) of workgroup `vb`: the first weight row, the first k and the chunk count of its stream
+template <int NW>
+struct W12Wave {
+  static constexpr int KS = NW / 4;                 // K-splits: NW waves = 2 tile pairs x (gate, up) x KS K-ranges
+  int n0, kbeg, nch;
+  bool live;
+  __device__ __forceinline__ W12Wave(const W12Args& a, int vb, int wave) {
+    const int pair = wave / (2 * KS), which = (wave / KS) & 1, kh = wave % KS;
+    const int tile = vb * 2 + pair;                 // hidden units [16 tile, + 16)
+    live = tile * 16 < a.hid;
+    n0 = which * a.hid + tile * 16;
+    const int Kh = a.w / KS;
+    kbeg = kh * Kh;
+    nch = Kh / WCH;
+  }
+};
+
+// the first RD chunks of a wave's stream (the persistent form requests them BEFORE the grid barrier: weights do not depend on it)
+template <int WQ, int RD, int NW>
+__device__ __forceinline__ void w12_issue_first(const W12Args& a, int vb, Chunk<WQ> (&ring)[RD], int wave, int lane) {
+  const W12Wave<NW> wv(a, vb, wave);
+  if (wv.live) {
+#pragma unroll
+    for (int d = 0; d < RD; ++d)
+      if (d < wv.nch) issue<WQ>(ring[d], a.W, a.wscale, wv.n0, 2 * a.hid, a.w, wv.kbeg + d * WCH, lane);
+  }
+}
+
+template <int NW>
+__device__ __forceinline__ WStream w12_stream(const W12Args& a, int vb, int wave, bool on) {
+  const W12Wave<NW> wv(a, vb, wave);
+  return WStream{a.W, a.wscale, wv.n0, 2 * a.hid, a.w, wv.kbeg, wv.nch, a.wf, on && wv.live};
+}
+
+// Persistent form, before the barrier wait: chunk 0 of the wave's NEXT stream into its LDS tile `wbuf` (the workgroup's previous phase
+// is over: LDS is free), chunks 1 .. RD requested — what crosses the barrier in flight.  nx != NULL: chunk 0 was requested into *nx while
+// the previous phase's stream ran out (the bodies' nx / next arguments).
+template <int WQ, int RD>
+__device__ __forceinline__ void prefetch(const WStream& st, char* wbuf, Chunk<WQ>* nx, Chunk<WQ> (&ring)[RD], int lane) {
+  if (!st.live) return;
+  if (!nx) {                                        // chunk 0 through ring[0]
+    issue<WQ>(ring[0], st, 0, lane);
+    park<WQ>(ring[0], wbuf, lane, st.wf, st.wscale, st.n0, st.Ntot);
+  } else {
+    park<WQ>(*nx, wbuf, lane, st.wf, st.wscale, st.n0, st.Ntot);
+  }
+#pragma unroll
+  for (int d = 0; d < RD; ++d)
+    if (1 + d < st.nch) issue<WQ>(ring[d], st, 1 + d, lane);
+}
+
+// The body of workgroup `vb` of w12' (PRE, the persistent form: chunk 0 is parked, the ring holds chunks 1 .. RD, and the data other
+// workgroups produced is read / written coherently).
+template <int WQ, int MR, int RD, int NW, bool PRE>
+__device__ __forceinline__ void w12_body(const W12Args& a, char* lds, int vb, Chunk<WQ> (&ring)[RD], uint64_t* tr = nullptr,
+                                         Chunk<WQ>* nx = nullptr, const WStream* next = nullptr) {
+  constexpr int KS = NW / 4;
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef uint32_t u2 __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,12 +211,9 @@ __global__ __launch_bounds__(NW * 64) void rf_w12_kc_kernel(const W12Args a) {
   char* wbuf = lds + (size_t)2 * M * xstride + (size_t)wave * 16 * WCH * 2;
   float* red = reinterpret_cast<float*>(lds + (size_t)2 * M * xstride + (size_t)NW * 16 * WCH * 2);    // [NW waves][KC_MAX_M][16] + [16 stats]
   float* stat = red + NW * KC_MAX_M * 16;
-  // wave -> (pair, gate | up, K-half)
-  const int pair = wave / (2 * KS), which = (wave / KS) & 1, kh = wave % KS;
-  const int tile = blockIdx.x * 2 + pair;           // hidden units [16 tile, + 16)
-  const bool live = tile * 16 < hid;
-  const int n0 = which * hid + tile * 16;
-  const int Kh = K / KS, kbeg = kh * Kh, nch = Kh / WCH;
+  const W12Wave<NW> wv(a, vb, wave);
+  const bool live = wv.live;
+  const int n0 = wv.n0, kbeg = wv.kbeg, nch = wv.nch;
   // ---- prologue: x = LayerNorm(h; g, b) * (1 + scale) + shift  for all M rows, split into bf16 hi / lo  (diff_loss_rf_swiglu.py:270)
   constexpr int PC = 1024 / (NW * 64);               // float4 columns per thread and row: K <= 4096
   const int nq = K >> 2;
@@ -153,7 +223,12 @@ __global__ __launch_bounds__(NW * 64) void rf_w12_kc_kernel(const W12Args a) {
 #pragma unroll
     for (int j = 0; j < PC; ++j) {
       const int c = tid + j * (NW * 64);
-      hv[m][j] = (m < M && c < nq) ? *reinterpret_cast<const f4*>(a.h + (int64_t)m * K + c * 4) : f4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (PRE) {
+        const u32x4 t = (m < M && c < nq) ? __builtin_amdgcn_raw_buffer_load_b128(coh_rsrc(a.h, (uint32_t)M * K * 4), (m * K + c * 4) * 4, 0, AUX_SC1) : u32x4{0u, 0u, 0u, 0u};
+        hv[m][j] = f4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+      } else {
+        hv[m][j] = (m < M && c < nq) ? *reinterpret_cast<const f4*>(a.h + (int64_t)m * K + c * 4) : f4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   // modulation / LayerNorm parameters requested before the reductions (one round trip, like the glue kernel it replaces)
   f4 sc[MR][PC], sh[MR][PC];
@@ -171,12 +246,7 @@ __global__ __launch_bounds__(NW * 64) void rf_w12_kc_kernel(const W12Args a) {
   }
   // ---- then this wave's first weight chunks: loads retire in order, so the prologue's operands (requested above) arrive first and the
   // LayerNorm runs while the weight chunks are in flight
-  Chunk<WQ> ring[RD];
-  if (live) {
-#pragma unroll
-    for (int d = 0; d < RD; ++d)
-      if (d < nch) issue<WQ>(ring[d], a.W, a.wscale, n0, Ntot, K, kbeg + d * WCH, lane);
-  }
+  if constexpr (!PRE) w12_issue_first<WQ, RD, NW>(a, vb, ring, wave, lane);
   float mean[MR], rstd[MR];
   {
     float s[MR];
@@ -245,20 +315,25 @@ __global__ __launch_bounds__(NW * 64) void rf_w12_kc_kernel(const W12Args a) {
     }
   }
   __syncthreads();
+  stamp(tr, 1);
   // ---- stream this wave's K-half of its tile: RD chunks in flight
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  bool nx_todo = PRE && next && next->live;            // the next phase's chunk 0: requested as soon as this stream has no chunk left to request
   if (live) {
-    for (int c = 0; c < nch; c += RD) {
+    if constexpr (PRE) mma_chunk<WQ>(acc, wbuf, xs, xstride, M, kbeg, lane);       // chunk 0 was parked before the barrier; the ring holds 1 ..
+    for (int c = PRE ? 1 : 0; c < nch; c += RD) {
 #pragma unroll
       for (int d = 0; d < RD; ++d) {
         if (c + d < nch) {
           park<WQ>(ring[d], wbuf, lane, a.wf, a.wscale, n0, Ntot);
           if (c + d + RD < nch) issue<WQ>(ring[d], a.W, a.wscale, n0, Ntot, K, kbeg + (c + d + RD) * WCH, lane);
+          else if (nx_todo) { issue<WQ>(*nx, *next, 0, lane); nx_todo = false; }
           mma_chunk<WQ>(acc, wbuf, xs, xstride, M, kbeg + (c + d) * WCH, lane);
         }
       }
     }
   }
+  if (nx_todo) issue<WQ>(*nx, *next, 0, lane);
   // ---- the K-halves meet in LDS: lane (fr, fq = 0) holds rows 0..3 of column fr
   if ((lane >> 4) == 0) {
     float rs = 1.0f;
@@ -267,10 +342,11 @@ __global__ __launch_bounds__(NW * 64) void rf_w12_kc_kernel(const W12Args a) {
     for (int r = 0; r < KC_MAX_M; ++r) red[(wave * KC_MAX_M + r) * 16 + (lane & 15)] = acc[r] * rs;
   }
   __syncthreads();
+  stamp(tr, 2);
   // thread t < 2 pairs x M x 16: y = silu(gate + bg) * (up + bu), split, stored as w3's operand  (diff_loss_rf_swiglu.py:30-34)
   if (tid < 2 * KC_MAX_M * 16) {
     const int p = tid / (KC_MAX_M * 16), m = (tid / 16) % KC_MAX_M, col = tid & 15;
-    const int t2 = blockIdx.x * 2 + p, n = t2 * 16 + col;
+    const int t2 = vb * 2 + p, n = t2 * 16 + col;
     if (m < M && n < hid) {
       const int wg = p * 2 * KS, wu = wg + KS;
       float g = 0.f, u = 0.f;
@@ -282,11 +358,25 @@ __global__ __launch_bounds__(NW * 64) void rf_w12_kc_kernel(const W12Args a) {
       if (a.bias) { g += bf16_to_f32(a.bias[n]); u += bf16_to_f32(a.bias[hid + n]); }
       const float y = silu_f(g) * u;
       const bf16_t hi = f32_to_bf16(y);
-      a.Y[(int64_t)m * hid + n] = hi;
-      a.Y[(int64_t)(M + m) * hid + n] = f32_to_bf16(y - bf16_to_f32(hi));
+      const bf16_t lo = f32_to_bf16(y - bf16_to_f32(hi));
+      if constexpr (PRE) {
+        const __amdgpu_buffer_rsrc_t ry = coh_rsrc(a.Y, (uint32_t)2 * M * hid * 2);
+        __builtin_amdgcn_raw_buffer_store_b16((short)hi, ry, (m * hid + n) * 2, 0, AUX_SC1);
+        __builtin_amdgcn_raw_buffer_store_b16((short)lo, ry, ((M + m) * hid + n) * 2, 0, AUX_SC1);
+      } else {
+        a.Y[(int64_t)m * hid + n] = hi;
+        a.Y[(int64_t)(M + m) * hid + n] = lo;
+      }
     }
   }
   (void)stat;
+}
+
+template <int WQ, int MR, int RD, int NW>
+__global__ __launch_bounds__(NW * 64) void rf_w12_kc_kernel(const W12Args a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  Chunk<WQ> ring[RD];
+  w12_body<WQ, MR, RD, NW, false>(a, lds, (int)blockIdx.x, ring);
 }
 
 struct W3Args {
@@ -298,15 +388,29 @@ struct W3Args {
 
 // ---- w3': one output tile per workgroup, 8 K-ranges, gated-residual epilogue ---------------------------------------------------------------
 template <int WQ, int RD>
-__global__ __launch_bounds__(KC_WAVES * 64) void rf_w3_kc_kernel(const W3Args a) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
+__device__ __forceinline__ void w3_issue_first(const W3Args& a, int vb, Chunk<WQ> (&ring)[RD], int wave, int lane) {
+  const int Kw = a.hid / KC_WAVES, nch = Kw / WCH;
+#pragma unroll
+  for (int d = 0; d < RD; ++d)
+    if (d < nch) issue<WQ>(ring[d], a.W, a.wscale, vb * 16, a.w, a.hid, wave * Kw + d * WCH, lane);
+}
+
+__device__ __forceinline__ WStream w3_stream(const W3Args& a, int vb, int wave, bool on) {
+  const int Kw = a.hid / KC_WAVES;
+  return WStream{a.W, a.wscale, vb * 16, a.w, a.hid, wave * Kw, Kw / WCH, a.wf, on};
+}
+
+// The body of workgroup `vb` (one 16-column tile) of w3' (PRE: as in w12_body).
+template <int WQ, int RD, bool PRE>
+__device__ __forceinline__ void w3_body(const W3Args& a, char* lds, int vb, Chunk<WQ> (&ring)[RD], uint64_t* tr = nullptr,
+                                        Chunk<WQ>* nx = nullptr, const WStream* next = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int M = a.M, K = a.hid, Ntot = a.w;
   const int xstride = K * 2 + 64;
   char* xs = lds;
   char* wbuf = lds + (size_t)2 * M * xstride + (size_t)wave * 16 * WCH * 2;
   float* red = reinterpret_cast<float*>(lds + (size_t)2 * M * xstride + (size_t)KC_WAVES * 16 * WCH * 2);
-  const int n0 = blockIdx.x * 16;
+  const int n0 = vb * 16;
   const int Kw = K / KC_WAVES, kbeg = wave * Kw, nch = Kw / WCH;
   // ---- the operand (hi rows, lo rows: 2 M hid bf16, 16 bytes per thread and step) and the epilogue's operands go to registers FIRST:
   // loads retire in order, so they land before the (younger) weight chunks and the x image is in LDS while those are still in flight
@@ -317,45 +421,52 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_w3_kc_kernel(const W3Args a)
   for (int j = 0; j < XN; ++j) {
     const int i = tid + j * (KC_WAVES * 64);
     xr[j] = u32x4{0u, 0u, 0u, 0u};
-    if (i < 2 * M * spr) xr[j] = *reinterpret_cast<const u32x4*>(a.Y + (int64_t)i * 8);      // rows are contiguous: piece i = (row i / spr, slot i % spr)
+    if (i < 2 * M * spr) {                          // rows are contiguous: piece i = (row i / spr, slot i % spr)
+      if constexpr (PRE) xr[j] = __builtin_amdgcn_raw_buffer_load_b128(coh_rsrc(a.Y, (uint32_t)2 * M * K * 2), i * 16, 0, AUX_SC1);
+      else xr[j] = *reinterpret_cast<const u32x4*>(a.Y + (int64_t)i * 8);
+    }
   }
   float h_old = 0.f, g_old = 0.f, b_old = 0.f, s_old = 1.f;
   if (tid < KC_MAX_M * 16) {
     const int m = tid >> 4, n = n0 + (tid & 15);
     if (m < M && n < Ntot) {
-      h_old = a.h[(int64_t)m * Ntot + n];
+      if constexpr (PRE) h_old = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(coh_rsrc(a.h, (uint32_t)M * Ntot * 4), (m * Ntot + n) * 4, 0, AUX_SC1));
+      else h_old = a.h[(int64_t)m * Ntot + n];
       g_old = a.gate[(int64_t)m * a.ldmod + n];
       if (a.bias) b_old = bf16_to_f32(a.bias[n]);
       if constexpr (WQ == 1) { if (a.wf != MN_W_INT8) s_old = a.wscale[n]; }
     }
   }
   // RD chunks in flight per wave: with RD = 4 a wave's whole 1024-k range is requested up front — one HBM round trip per launch
-  Chunk<WQ> ring[RD];
-#pragma unroll
-  for (int d = 0; d < RD; ++d)
-    if (d < nch) issue<WQ>(ring[d], a.W, a.wscale, n0, Ntot, K, kbeg + d * WCH, lane);
+  if constexpr (!PRE) w3_issue_first<WQ, RD>(a, vb, ring, wave, lane);
 #pragma unroll
   for (int j = 0; j < XN; ++j) {
     const int i = tid + j * (KC_WAVES * 64);
     if (i < 2 * M * spr) { const int r = i / spr, sl = i - r * spr; *reinterpret_cast<u32x4*>(xs + xoff(r, sl, xstride)) = xr[j]; }
   }
   __syncthreads();
+  stamp(tr, 1);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int c = 0; c < nch; c += RD) {
+  bool nx_todo = PRE && next && next->live;
+  if constexpr (PRE) mma_chunk<WQ>(acc, wbuf, xs, xstride, M, kbeg, lane);
+  for (int c = PRE ? 1 : 0; c < nch; c += RD) {
 #pragma unroll
     for (int d = 0; d < RD; ++d) {
       if (c + d < nch) {
         park<WQ>(ring[d], wbuf, lane, a.wf, a.wscale, n0, Ntot);
         if (c + d + RD < nch) issue<WQ>(ring[d], a.W, a.wscale, n0, Ntot, K, kbeg + (c + d + RD) * WCH, lane);
+        else if (nx_todo) { issue<WQ>(*nx, *next, 0, lane); nx_todo = false; }
         mma_chunk<WQ>(acc, wbuf, xs, xstride, M, kbeg + (c + d) * WCH, lane);
       }
     }
   }
+  if (nx_todo) issue<WQ>(*nx, *next, 0, lane);
   if ((lane >> 4) == 0) {
 #pragma unroll
     for (int r = 0; r < KC_MAX_M; ++r) red[(wave * KC_MAX_M + r) * 16 + (lane & 15)] = acc[r];
   }
   __syncthreads();
+  stamp(tr, 2);
   // thread t < M x 16:  h[m, n] += gate[m, n] * (sum over the K-ranges + b3[n])   (ResBlock, diff_loss_rf_swiglu.py:272)
   if (tid < KC_MAX_M * 16) {
     const int m = tid >> 4, col = tid & 15, n = n0 + col;
@@ -364,11 +475,142 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_w3_kc_kernel(const W3Args a)
 #pragma unroll
       for (int wv = 0; wv < KC_WAVES; ++wv) y += red[(wv * KC_MAX_M + m) * 16 + col];
       y = y * s_old + b_old;                        // (s_old: the e4m3 row scale, 1 otherwise)
-      a.h[(int64_t)m * Ntot + n] = h_old + g_old * y;
+      if constexpr (PRE) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h_old + g_old * y), coh_rsrc(a.h, (uint32_t)M * Ntot * 4), (m * Ntot + n) * 4, 0, AUX_SC1);
+      else a.h[(int64_t)m * Ntot + n] = h_old + g_old * y;
     }
   }
 }
 
+template <int WQ, int RD>
+__global__ __launch_bounds__(KC_WAVES * 64) void rf_w3_kc_kernel(const W3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  Chunk<WQ> ring[RD];
+  w3_body<WQ, RD, false>(a, lds, (int)blockIdx.x, ring);
+}
+
+// ---- the ResBlocks of one Euler step as ONE persistent launch ----------------------------------------------------------------------------
+// 24 dependent launches per Euler step leave the HBM pipe empty for a launch gap + a ramp each (w12' 20.8 us for 14.6 us of bytes, w3'
+// 12.5 for 7.3: profiles/r05_batch1_site_stats.txt).  Weights do not depend on the activations, so a workgroup that stays resident can
+// REQUEST the next phase's first weight chunks before it waits for the other workgroups: the grid barrier's round trip is covered by
+// loads already in flight.  One workgroup per CU (co-residency: grid <= CU count, checked by the host; LDS > 80 KiB keeps a second
+// workgroup of another launch off the CU), phases = the bodies above, between them a grid barrier in device memory (GridBar): every
+// wave drains its stores, workgroup barrier, one lane releases at agent scope (L2 write-back: the eight XCDs' L2s are not coherent
+// with each other inside a launch) and raises the workgroup's flag; the waiting wave polls the flags with agent-scope loads, acquires
+// (L2 invalidate) and releases its workgroup.  The wait is bounded (wall clock): on expiry the error word is set, h is poisoned with
+// NaN and the launch runs to its end without further waits.
+constexpr int PB_MAX = 16;
+struct PersistBlk {
+  const void* W12; const float* s12; const bf16_t* b12; const bf16_t* ln_g; const bf16_t* ln_b;
+  const void* W3; const float* s3; const bf16_t* b3;
+};
+struct PersistArgs {
+  float* h; bf16_t* Y; int M, w, hid, wf, nblk;
+  const float* mod; int64_t ldmod;                  // block b: shift = mod + 3 w b, scale = shift + w, gate = shift + 2 w
+  unsigned* bar;                                    // [0, 256) one flag per workgroup, [256] error word
+  unsigned epoch0;                                  // the launch's barriers publish epoch0 + 1, + 2, ...
+  uint64_t wait_ticks;
+  uint64_t* trace;                                  // dev library only: [workgroups][2 nblk phases][8 stamps], or NULL
+  PersistBlk blk[PB_MAX];
+};
+
+// Flag barrier.  (A first build counted arrivals with one agent-scope atomic word: 256 read-modify-writes of ONE address are served
+// one after the other at the memory side — 18 us per barrier, profiles/r05_rf_persist_ab.txt.)  Every workgroup owns one word of a
+// 1 KiB flag array — word (wg % 8) * 32 + wg / 8: the workgroups of one XCD share a 128-byte line — and stores the barrier's epoch into
+// it (plain stores to distinct words pipeline); wave 0 of every workgroup polls the whole array, 4 words per lane, until every word
+// has reached the epoch.  Epochs only grow: the host zeroes the array once per sampler call and hands each launch its first epoch.
+struct GridBar {
+  unsigned* flags; unsigned G, epoch; uint64_t ticks; int dead;
+  __device__ __forceinline__ void arrive() {
+    ++epoch;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {                          // (payload stores were write-through and are drained: no release fence)
+      const unsigned wg = blockIdx.x;
+      __hip_atomic_store(flags + ((wg & 7u) * 32u + (wg >> 3)), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __device__ __forceinline__ void wait() {
+    if (threadIdx.x < 64 && !dead) {
+      const unsigned lane = threadIdx.x;
+      const uint64_t t0 = wall_clock64();
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned i = lane + 64u * j, wg = (i & 31u) * 8u + (i >> 5);
+          const unsigned v = __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && (wg >= G || (int32_t)(v - epoch) >= 0);
+        }
+        if (__all(ok)) break;
+        if (wall_clock64() - t0 > ticks) { if (lane == 0) atomicExch(flags + 256, 0x300u); dead = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();                                // (the phases read other workgroups' data past the L1: no acquire fence)
+  }
+};
+
+template <int WQ>
+__global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const PersistArgs p) {
+  constexpr int RD3 = WQ == 1 ? 4 : 2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int vb = blockIdx.x, n12 = (p.hid + 31) / 32, n3 = (p.w + 15) / 16;
+  GridBar gb{p.bar, gridDim.x, p.epoch0, p.wait_ticks, 0};
+  // ONE register ring for both phases (w12' keeps one chunk in flight, w3' RD3).  Requesting the next phase's chunk 0 EARLY — while
+  // this phase's stream runs out: the bodies' nx / next arguments — measured slower (its traffic delays the workgroups still streaming,
+  // and 32 more live registers spill; profiles/README.md r05): chunk 0 is requested after the arrival.
+  Chunk<WQ> r3[RD3];
+  Chunk<WQ> (&r12)[1] = *reinterpret_cast<Chunk<WQ> (*)[1]>(&r3[0]);
+  auto args12 = [&](int b) {
+    const float* mod = p.mod + (int64_t)b * 3 * p.w;
+    return W12Args{p.h, p.M, p.w, p.hid, p.blk[b].ln_g, p.blk[b].ln_b, mod, mod + p.w, p.ldmod, p.blk[b].W12, p.blk[b].s12, p.blk[b].b12, p.wf, p.Y};
+  };
+  auto args3 = [&](int b) {
+    return W3Args{p.Y, p.M, p.w, p.hid, p.blk[b].W3, p.blk[b].s3, p.blk[b].b3, p.wf, p.mod + (int64_t)b * 3 * p.w + 2 * p.w, p.ldmod, p.h};
+  };
+  char* wbuf12 = lds + (size_t)2 * p.M * (p.w * 2 + 64) + (size_t)wave * 16 * WCH * 2;
+  char* wbuf3 = lds + (size_t)2 * p.M * (p.hid * 2 + 64) + (size_t)wave * 16 * WCH * 2;
+  W12Args a12 = args12(0);
+  WStream s12 = w12_stream<KC_WAVES>(a12, vb, wave, vb < n12);
+  prefetch<WQ, 1>(s12, wbuf12, nullptr, r12, lane);
+  __syncthreads();
+  uint64_t* tr = p.trace ? p.trace + (size_t)vb * 2 * p.nblk * 8 : nullptr;
+  for (int b = 0; b < p.nblk; ++b) {
+    const W3Args a3 = args3(b);
+    const WStream s3 = w3_stream(a3, vb, wave, vb < n3);
+    stamp(tr, 0);
+    if (vb < n12) w12_body<WQ, 2, 1, KC_WAVES, true>(a12, lds, vb, r12, tr);
+    stamp(tr, 3);
+    gb.arrive();
+    stamp(tr, 4);
+    prefetch<WQ, RD3>(s3, wbuf3, nullptr, r3, lane);
+    stamp(tr, 5);
+    gb.wait();
+    stamp(tr, 6);
+    if (tr) tr += 8;
+    stamp(tr, 0);
+    const bool more = b + 1 < p.nblk;
+    if (more) { a12 = args12(b + 1); s12 = w12_stream<KC_WAVES>(a12, vb, wave, vb < n12); } else s12.live = false;
+    if (vb < n3) w3_body<WQ, RD3, true>(a3, lds, vb, r3, tr);
+    stamp(tr, 3);
+    if (more) {
+      gb.arrive();
+      stamp(tr, 4);
+      prefetch<WQ, 1>(s12, wbuf12, nullptr, r12, lane);
+      stamp(tr, 5);
+      gb.wait();
+      stamp(tr, 6);
+    }
+    if (tr) tr += 8;
+  }
+  // a timed-out barrier poisons the state: the caller's result is NaN, never a silently wrong number
+  const int dead = __syncthreads_or(tid < 64 ? gb.dead : 0);
+  if (dead && vb < n3 && tid < p.M * 16 && vb * 16 + (tid & 15) < p.w) p.h[(int64_t)(tid >> 4) * p.w + vb * 16 + (tid & 15)] = __builtin_nanf("");
+}
+
+uint64_t* g_kc_trace = nullptr;
+int g_kc_persist_all = 0;            // dev library: the persistent launch for int8 / NF4 as well (mn_rf_kc_persist_all)
 int g_kc_rd12 = 1, g_kc_rd3 = 0;     // weight chunks in flight per wave; rd3 = 0: by format (dev-library A/B knob: mn_rf_kc_tune)       // weight chunks in flight per wave (dev-library A/B knob: mn_rf_kc_tune)
 
 size_t w12_lds(int M, int w, int nw) { return (size_t)2 * M * (w * 2 + 64) + (size_t)nw * 16 * WCH * 2 + (nw * KC_MAX_M * 16 + 16) * sizeof(float); }
@@ -383,6 +625,8 @@ void opt_in(Kern k) {
 
 #ifdef MN_DEV_HOOKS
 extern "C" MN_DEV_API void mn_rf_kc_tune(int rd12, int rd3) { g_kc_rd12 = rd12 & 15; g_kc_rd3 = rd3; }
+extern "C" MN_DEV_API void mn_rf_kc_persist_all(int on) { g_kc_persist_all = on; }
+extern "C" MN_DEV_API void mn_rf_kc_trace(void* buf) { g_kc_trace = static_cast<uint64_t*>(buf); }
 #endif
 
 // Can the ResBlock chain of this shape run as K-complete launches?  (whole chunks per wave, the x images + weight tiles within the
@@ -392,6 +636,72 @@ bool rf_kc_ok(int wfmt, int M, int w, int hid) {
   if (wfmt == MN_W_NF4 && ((w % 64) != 0 || (hid % 64) != 0)) return false;
   if ((int64_t)M * hid > 16384) return false;       // w3': the operand image is staged through 8 x 16 bytes per thread
   return w12_lds(M, w, 8) <= 160 * 1024 && w3_lds(M, hid) <= 160 * 1024;
+}
+
+// Can the whole block chain of a step run as one persistent launch?  K-complete shapes whose phases fit one workgroup per CU.
+bool rf_persist_ok(int wfmt, int M, int w, int hid, void* stream) {
+  if (!rf_kc_ok(wfmt, M, w, hid)) return false;
+  // bf16 and e4m3 gain (sampler call at 2 rows 6.84 -> 6.34 ms, 5.26 -> 5.00); int8 and NF4 spend the phase in their decoders, not in
+  // launch gaps: 5.91 -> 6.23 and 5.41 -> 5.39 (tools/exp/rf_persist_ab.py, profiles/r05_rf_persist_ab.txt) — they keep the launches
+  if ((wfmt == MN_W_INT8 || wfmt == MN_W_NF4) && !g_kc_persist_all) return false;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    n_cu = v;
+  }
+  const int G = mn_cdiv(hid, 32) > mn_cdiv(w, 16) ? mn_cdiv(hid, 32) : mn_cdiv(w, 16);
+  if (G > n_cu || G > 256) return false;                // (256: the barrier's flag array)
+  const size_t l12 = w12_lds(M, w, KC_WAVES), l3 = w3_lds(M, hid);
+  if ((l12 > l3 ? l12 : l3) <= 80 * 1024) return false;   // (two workgroups would fit a CU: the co-residency argument needs one)
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(mn_stream(stream), &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;      // (no event calls inside a capture)
+  return true;
+}
+
+// Blocks [b0, b0 + nblk) of one Euler step in one launch.  `bar`: RF_PERSIST_BAR_WORDS words of device memory, zeroed by the caller;
+// epoch0: this launch's first barrier epoch — successive launches on one flag array take epoch0 = 0, 64, 128, ... (a launch has
+// 2 nblk - 1 <= 31 barriers).  Two persistent launches must never share the device — each would hold CUs the other
+// waits for — so launches on different streams are ordered by an event.
+int rf_blocks_persist(int wfmt, float* h, bf16_t* Y3, int M, int w, int hid, const float* mod, int64_t ldmod, int nblk,
+                      const void* const* W12, const float* const* s12, const bf16_t* const* b12, const bf16_t* const* ln_g,
+                      const bf16_t* const* ln_b, const void* const* W3, const float* const* s3, const bf16_t* const* b3,
+                      unsigned* bar, unsigned epoch0, void* stream) {
+  MN_CHECK_ARG(h && Y3 && mod && bar && nblk >= 1 && nblk <= PB_MAX && rf_kc_ok(wfmt, M, w, hid), "rf_blocks_persist: bad args");
+  PersistArgs p{};
+  p.h = h; p.Y = Y3; p.M = M; p.w = w; p.hid = hid; p.wf = wfmt; p.nblk = nblk; p.mod = mod; p.ldmod = ldmod; p.bar = bar; p.epoch0 = epoch0; p.trace = g_kc_trace;
+  p.wait_ticks = 2000ull * 100000ull;               // 2 s of the 100 MHz clock
+  for (int b = 0; b < nblk; ++b)
+    p.blk[b] = PersistBlk{W12[b], wfmt ? s12[b] : nullptr, b12[b], ln_g[b], ln_b[b], W3[b], wfmt ? s3[b] : nullptr, b3[b]};
+  const int G = mn_cdiv(hid, 32) > mn_cdiv(w, 16) ? mn_cdiv(hid, 32) : mn_cdiv(w, 16);
+  const size_t l12 = w12_lds(M, w, KC_WAVES), l3 = w3_lds(M, hid), lds = l12 > l3 ? l12 : l3;
+  static std::mutex mu;
+  static hipEvent_t ev = nullptr;
+  static hipStream_t last = nullptr;
+  static bool any = false;
+  hipStream_t st = mn_stream(stream);
+  std::lock_guard<std::mutex> lk(mu);
+  static size_t opted = 0;                           // (the kernel holds 256 bytes of static LDS: ask for what the launch needs, not for all 160 KiB)
+  if (lds > opted) {
+    const void* ks[3] = {reinterpret_cast<const void*>(&rf_blocks_persist_kernel<0>), reinterpret_cast<const void*>(&rf_blocks_persist_kernel<1>),
+                         reinterpret_cast<const void*>(&rf_blocks_persist_kernel<2>)};
+    for (const void* k : ks)
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        mn_set_error("rf_blocks_persist: cannot reserve %zu bytes of LDS", lds);
+        return MN_ELAUNCH;
+      }
+    opted = lds;
+  }
+  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { mn_set_error("rf_blocks_persist: hipEventCreate failed"); return MN_ELAUNCH; }
+  if (any && last != st) (void)hipStreamWaitEvent(st, ev, 0);
+  const dim3 grid((unsigned)G), block(KC_WAVES * 64);
+  if (wfmt == MN_W_NF4) hipLaunchKernelGGL(rf_blocks_persist_kernel<2>, grid, block, lds, st, p);
+  else if (wfmt) hipLaunchKernelGGL(rf_blocks_persist_kernel<1>, grid, block, lds, st, p);
+  else hipLaunchKernelGGL(rf_blocks_persist_kernel<0>, grid, block, lds, st, p);
+  MN_CHECK_LAUNCH("rf_blocks_persist");
+  (void)hipEventRecord(ev, st);
+  last = st; any = true;
+  return MN_OK;
 }
 
 int rf_w12_kc(int wfmt, const float* h, int M, int w, int hid, const bf16_t* ln_g, const bf16_t* ln_b, const float* shift, const float* scale,

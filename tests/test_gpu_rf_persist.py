@@ -1,0 +1,61 @@
+"""The persistent per-Euler-step launch of the RF head at the reference's call shape (stream_kc.hip: every ResBlock of a step in one
+launch, grid barriers between the phases).  Parity with the oracle is covered where the other routes are (test_gpu_fullwidth.py,
+test_gpu_rf_shapes.py, test_gpu_fp8.py run this launch at 2 rows); here: what only a resident, barrier-synchronised launch can get
+wrong — state left in the barrier words between calls, and two such launches meeting on the device from two streams."""
+import pytest
+import torch
+
+from ming_univision_amd import configuration as C
+from ming_univision_amd.synth import synth_tensor
+
+pytestmark = pytest.mark.gpu
+
+LLM_HIDDEN = 2048
+
+
+def _head(weights="bf16", seed=7):
+    from ming_univision_amd.rf_head import RectifiedFlowHead
+    w, d, steps, mult = 3072, 12, 16, 4                               # the 16B-A3B head: 256 + 192 workgroups per phase pair
+    rf_cfg = dict(diffloss_w=w, diffloss_d=d, num_sampling_steps=str(steps), gen_method=f"flow_matching_swiglu-{mult}",
+                  vis_head_arch="linear2-norm")
+    shapes = {"vis_head.0.weight": (w, LLM_HIDDEN), "vis_head.0.bias": (w,), "vis_head.1.weight": (w,), "vis_head.1.bias": (w,)}
+    shapes.update(C.rf_param_shapes(w, d, w, 32, mult))
+    sd = {k: synth_tensor(k, s, seed, "cuda", torch.bfloat16) for k, s in shapes.items()}
+    return RectifiedFlowHead(sd, LLM_HIDDEN, rf_cfg, weights=weights)
+
+
+@pytest.mark.parametrize("weights", ["bf16", "fp8"])
+def test_repeated_calls_and_two_streams_give_the_same_bits(weights):
+    rf = _head(weights)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    cases = [(torch.randn(2, LLM_HIDDEN, device="cuda", generator=g), torch.randn(1, 32, device="cuda", generator=g)) for _ in range(4)]
+    ref = [rf.sample(h, n, n_images=1).clone() for h, n in cases]
+    for r in ref:
+        assert torch.isfinite(r).all()
+    # the same workspace (barrier words included) again and again
+    for _ in range(3):
+        for (h, n), r in zip(cases, ref):
+            assert torch.equal(rf.sample(h, n, n_images=1), r)
+    # two streams, each with its own workspace, enqueued back to back: the launches must be ordered on the device, not interleaved
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = {}
+    for rep in range(3):
+        for i, (h, n) in enumerate(cases):
+            st = s1 if i % 2 == 0 else s2
+            with torch.cuda.stream(st):
+                outs[(rep, i)] = rf.sample(h, n, n_images=1)
+    torch.cuda.synchronize()
+    for (rep, i), o in outs.items():
+        assert torch.equal(o, ref[i]), (rep, i)
+
+
+def test_one_row_and_three_rows_keep_their_routes():
+    """1 row (no CFG) and 3 rows (image editing: 3 CFG rows) around the 2-row launch: finite, deterministic results."""
+    rf = _head("fp8")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for rows in (1, 3):
+        h = torch.randn(rows, LLM_HIDDEN, device="cuda", generator=g)
+        n = torch.randn(1, 32, device="cuda", generator=g)
+        a = rf.sample(h, n, n_images=1).clone()
+        assert torch.isfinite(a).all() and torch.equal(rf.sample(h, n, n_images=1), a)

@@ -185,6 +185,8 @@ def test_ep_dispatch_and_combine_match_the_full_expert_sum():
         parts.append(part)
     for r in range(world):
         comms[r].all_reduce(parts[r], phase=TpCommunicator.PUSH)
+    for r in range(world):                                              # (37 rows: the two-shot form — every owner reduces and publishes)
+        comms[r].all_reduce(parts[r], phase=TpCommunicator.GATHER)
     total = comms[0].all_reduce(parts[0], phase=TpCommunicator.REDUCE) + h
     ref = h.double().cpu().clone()
     for r in range(world):
