@@ -21,7 +21,9 @@ def _head(weights="bf16", seed=7):
     shapes = {"vis_head.0.weight": (w, LLM_HIDDEN), "vis_head.0.bias": (w,), "vis_head.1.weight": (w,), "vis_head.1.bias": (w,)}
     shapes.update(C.rf_param_shapes(w, d, w, 32, mult))
     sd = {k: synth_tensor(k, s, seed, "cuda", torch.bfloat16) for k, s in shapes.items()}
-    return RectifiedFlowHead(sd, LLM_HIDDEN, rf_cfg, weights=weights)
+    rf = RectifiedFlowHead(sd, LLM_HIDDEN, rf_cfg, weights=weights)
+    rf._sd = sd
+    return rf
 
 
 @pytest.mark.parametrize("weights", ["bf16", "fp8"])
@@ -59,3 +61,20 @@ def test_one_row_and_three_rows_keep_their_routes():
         n = torch.randn(1, 32, device="cuda", generator=g)
         a = rf.sample(h, n, n_images=1).clone()
         assert torch.isfinite(a).all() and torch.equal(rf.sample(h, n, n_images=1), a)
+
+
+def test_bf16_one_row_takes_the_matrix_core_launches_and_matches_the_oracle():
+    """bf16 at ONE row used the fp32-FMA kernels; where the shape runs K-complete it now takes the same launches as 2 rows."""
+    from oracle import rf_ref
+    from tests.util import rel_err
+    rf = _head("bf16")
+    osd = {k: v.float().cpu() for k, v in rf._sd.items()}
+    rsd = {k[len("diffloss."):]: v for k, v in osd.items() if k.startswith("diffloss.")}
+    g = torch.Generator().manual_seed(11)
+    h, n = torch.randn(1, LLM_HIDDEN, generator=g), torch.randn(1, 32, generator=g)
+    torch.set_num_threads(min(64, max(torch.get_num_threads(), 16)))
+    ref = rf_ref.sample(rf_ref.vis_head(h, osd), n, rsd, steps=16)[0]
+    got = rf.sample(h.cuda(), n.cuda(), n_images=1)
+    e = rel_err(got, ref)
+    print(f"bf16 head, 1 row: {e:.2e}")
+    assert e < 1e-3
