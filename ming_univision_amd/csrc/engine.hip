@@ -522,11 +522,11 @@ static bool rf_fp8_ok(const mn_rf_head* h) {
 
 // <= 4 rows (the CFG rows of one image — the reference's call shape): the SwiGLU glue launch is folded into w3's prologue
 // (stream_fuse.h): three launches per ResBlock instead of four.  g_rf_fuse: dev-library A/B switch.
-static int g_rf_fuse = 1, g_rf_boundary = 1, g_rf_kc = 1, g_rf_persist = 1;
+static int g_rf_fuse = 1, g_rf_boundary = 1, g_rf_kc = 1, g_rf_persist = 1, g_rf_whole = 1;
 static void g_rf_ada_stream_set(int v);
 #ifdef MN_DEV_HOOKS
 // bit 0: SwiGLU glue fused into w3; bit 1: one-launch Euler-step boundary; bit 2: adaLN NOT streamed; bit 3: K-complete chain OFF
-extern "C" MN_DEV_API void mn_rf_tune_fuse(int on) { g_rf_fuse = on & 1; g_rf_boundary = (on >> 1) & 1; g_rf_ada_stream_set((on >> 2) & 1 ? 0 : 1); g_rf_kc = (on >> 3) & 1 ? 0 : 1; g_rf_persist = (on >> 4) & 1 ? 0 : 1; }
+extern "C" MN_DEV_API void mn_rf_tune_fuse(int on) { g_rf_fuse = on & 1; g_rf_boundary = (on >> 1) & 1; g_rf_ada_stream_set((on >> 2) & 1 ? 0 : 1); g_rf_kc = (on >> 3) & 1 ? 0 : 1; g_rf_persist = (on >> 4) & 1 ? 0 : 1; g_rf_whole = (on >> 5) & 1 ? 0 : 1; }
 #endif
 static bool rf_fused_shape_ok(const mn_rf_head* h, int rows) {
   return rows <= FUSE_MAX_ROWS && rf_chain_ok(h, rows) &&
@@ -651,6 +651,18 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
   const bool boundary = chain && g_rf_boundary && T <= 256 && (T % 8) == 0 && w <= 4096;
   int nz_fin = 0;
   unsigned n_persist = 0;                           // persistent launches so far (each takes its own range of barrier epochs)
+  // <= 2 rows, one workgroup per CU: the WHOLE sampler as one persistent launch — Euler-step boundaries and the final layer are two
+  // more phases per step instead of three launches (stream_kc.hip)
+  if (chain && g_rf_kc && g_rf_persist && g_rf_whole && fused && rf_persist_ok(h->wfmt, rows, w, h->hidden, stream) &&
+      rf_sampler_persist_ok(rows, w, h->hidden, h->depth, T, rpi, n_images)) {
+    if (hipMemsetAsync(bar, 0, RF_PERSIST_BAR_WORDS * sizeof(unsigned), st) != hipSuccess) { mn_set_error("mn_rf_sample: hipMemsetAsync failed"); return MN_ELAUNCH; }
+    const RfSamplerTail tail{h->steps, T, rpi, n_images, (int64_t)rows * A, h->in_w, h->in_b, h->fin_w, h->fin_b, noise, temperature, text_cfg, image_cfg, v, latent_out};
+    MN_TRY(rf_blocks_persist(h->wfmt, hh, yb, rows, w, h->hidden, ada_all, (int64_t)A, h->depth, reinterpret_cast<const void* const*>(h->w12),
+                             h->wfmt ? h->w12_scale : nullptr, h->b12, h->ln_g, h->ln_b, reinterpret_cast<const void* const*>(h->w3),
+                             h->wfmt ? h->w3_scale : nullptr, h->b3, bar, 0u, &tail, stream));
+    MN_CHECK_LAUNCH("mn_rf_sample");
+    return MN_OK;
+  }
   for (int s = 0; s < h->steps; ++s) {
     const float* ada = ada_all + (int64_t)s * rows * A;
     // h = input_proj(x)  (diff_loss:371)
@@ -682,7 +694,7 @@ extern "C" int mn_rf_sample(const mn_rf_head* h, const float* hidden, int64_t ld
         MN_TRY(rf_blocks_persist(h->wfmt, hh, yb, rows, w, hid_n, ada + (int64_t)b * 3 * w, (int64_t)A, nb,
                                  reinterpret_cast<const void* const*>(h->w12 + b), h->wfmt ? h->w12_scale + b : nullptr, h->b12 + b,
                                  h->ln_g + b, h->ln_b + b, reinterpret_cast<const void* const*>(h->w3 + b),
-                                 h->wfmt ? h->w3_scale + b : nullptr, h->b3 + b, bar, 64u * n_persist++, stream));
+                                 h->wfmt ? h->w3_scale + b : nullptr, h->b3 + b, bar, 64u * n_persist++, nullptr, stream));
       }
       for (int b = 0; kc && !persist && b < h->depth; ++b) {
         const float* mod = ada + (int64_t)b * 3 * w;

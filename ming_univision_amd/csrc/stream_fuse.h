@@ -35,10 +35,22 @@ int rf_w3_kc(int wfmt, const bf16_t* Y3, int M, int w, int hid, const void* W3, 
 constexpr int RF_PERSIST_MAX_BLOCKS = 16;
 constexpr int RF_PERSIST_BAR_WORDS = 320;
 bool rf_persist_ok(int wfmt, int M, int w, int hid, void* stream);
+// The whole sampler in ONE launch: per Euler step a boundary phase (CFG + Euler update of the ODE state — replicated in every workgroup's
+// LDS — and the input projection), the blocks, and a final-layer phase (LayerNorm-modulate + final linear, one output column per
+// workgroup); the last update writes `latent`.  Replaces per step: rf_step_boundary_kernel, the LN glue and the final streaming launch.
+struct RfSamplerTail {
+  int steps, T, rpi, n_images;
+  int64_t mod_step;                                 // floats between two Euler steps' modulations
+  const bf16_t* in_w; const bf16_t* in_b; const bf16_t* fin_w; const bf16_t* fin_b;
+  const float* noise; float temperature, text_cfg, image_cfg;
+  float* v;                                         // [M][T] scratch
+  float* latent;                                    // [n_images][T]
+};
+bool rf_sampler_persist_ok(int M, int w, int hid, int depth, int T, int rpi, int n_images);
 int rf_blocks_persist(int wfmt, float* h, bf16_t* Y3, int M, int w, int hid, const float* mod, int64_t ldmod, int nblk,
                       const void* const* W12, const float* const* s12, const bf16_t* const* b12, const bf16_t* const* ln_g,
                       const bf16_t* const* ln_b, const void* const* W3, const float* const* s3, const bf16_t* const* b3,
-                      unsigned* bar, unsigned epoch0, void* stream);
+                      unsigned* bar, unsigned epoch0, const RfSamplerTail* whole, void* stream);
 
 // ---- the MoE down projection of a 1- / 2-row step with the segments spread over the waves of a workgroup (moe_down.hip):
 //   out[b][n] = res[b][n] + sum_s tw[b, s] * hmid[b][s * I ..] . W[ti[b, s]][n][..]      (bf16 weights)

@@ -510,6 +510,15 @@ struct PersistArgs {
   unsigned epoch0;                                  // the launch's barriers publish epoch0 + 1, + 2, ...
   uint64_t wait_ticks;
   uint64_t* trace;                                  // dev library only: [workgroups][2 nblk phases][8 stamps], or NULL
+  // the whole sampler in the launch (steps > 0): Euler-step boundaries and the final layer as two more phases per step
+  int steps, T, rpi, n_images;
+  int64_t mod_step;                                 // floats between two Euler steps' modulations
+  const bf16_t* in_w; const bf16_t* in_b;           // input_proj [w][T], [w]
+  const bf16_t* fin_w; const bf16_t* fin_b;         // final_layer.linear [T][w], [T]
+  const float* noise; float temperature, text_cfg, image_cfg;
+  float* v;                                         // [M][T]: the final layer's output, handed to the next boundary phase
+  float* latent;                                    // [n_images][T]
+  uint32_t lds_top;                                 // byte offset of the launch-long LDS state: x [M][T] (<= 512 floats) + 64 floats of scratch
   PersistBlk blk[PB_MAX];
 };
 
@@ -550,6 +559,131 @@ struct GridBar {
   }
 };
 
+// ---- whole-sampler form: the two light phases around the blocks of an Euler step ---------------------------------------------------------
+// Boundary phase (every workgroup): the ODE state x [M][T] lives in EVERY workgroup's LDS (replicated: 64 floats, no hand-off, no race) —
+// step 0: x = noise * temperature; later: v = the final layer's output of the previous step (coherent loads), CFG combine over the image's rows,
+// x += vg / steps (diff_loss_rf_swiglu.py:144-179) — then the workgroup's 16 columns of h = input_proj(x) (:371), stored write-through.
+// The arithmetic and its order are rf_step_boundary_kernel's (engine.hip).
+__device__ __forceinline__ float persist_x_update(const PersistArgs& p, const float* xs, int m, int t) {
+  const int T = p.T, rpi = p.rpi, r0 = (m / rpi) * rpi;
+  const __amdgpu_buffer_rsrc_t rv = coh_rsrc(p.v, (uint32_t)p.M * T * 4);
+  float v[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    if (r < rpi) v[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, ((r0 + r) * T + t) * 4, 0, AUX_SC1));
+  const float vg = rpi == 3 ? v[1] + p.image_cfg * (v[2] - v[1]) + p.text_cfg * (v[0] - v[2])
+                            : (rpi == 2 ? v[1] + p.text_cfg * (v[0] - v[1]) : v[0]);
+  return xs[m * T + t] + vg * (1.0f / (float)p.steps);
+}
+
+__device__ __forceinline__ void persist_boundary_phase(const PersistArgs& p, char* lds, int s, int vb, int n3) {
+  float* xs = reinterpret_cast<float*>(lds + p.lds_top);
+  const int tid = threadIdx.x, M = p.M, T = p.T;
+  if (tid < M * T) {
+    const int m = tid / T, t = tid - m * T;
+    xs[tid] = s == 0 ? p.noise[(m / p.rpi) * T + t] * p.temperature : persist_x_update(p, xs, m, t);
+  }
+  __syncthreads();
+  if (vb < n3 && tid < KC_MAX_M * 16) {
+    const int m = tid >> 4, n = vb * 16 + (tid & 15);
+    if (m < M && n < p.w) {
+      const bf16_t* wr = p.in_w + (int64_t)n * T;
+      const float* xk = xs + m * T;
+      float a = bf16_to_f32(p.in_b[n]);
+      for (int k = 0; k < T; k += 8) {                // T % 8 == 0 (host check): 16-byte rows
+        const u32x4 q = *reinterpret_cast<const u32x4*>(wr + k);
+        a = fmaf(bf16lo_to_f32(q.x), xk[k], a); a = fmaf(bf16hi_to_f32(q.x), xk[k + 1], a);
+        a = fmaf(bf16lo_to_f32(q.y), xk[k + 2], a); a = fmaf(bf16hi_to_f32(q.y), xk[k + 3], a);
+        a = fmaf(bf16lo_to_f32(q.z), xk[k + 4], a); a = fmaf(bf16hi_to_f32(q.z), xk[k + 5], a);
+        a = fmaf(bf16lo_to_f32(q.w), xk[k + 6], a); a = fmaf(bf16hi_to_f32(q.w), xk[k + 7], a);
+      }
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a), coh_rsrc(p.h, (uint32_t)M * p.w * 4), (m * p.w + n) * 4, 0, AUX_SC1);
+    }
+  }
+}
+
+// Final-layer phase (workgroup t < T owns output column t of every row): v[m][t] = fin_b[t] + sum_k fin_w[t][k] *
+// (LayerNorm(h[m])[k] * (1 + scale[m][k]) + shift[m][k])   (no affine; diff_loss_rf_swiglu.py:288-292) in fp32.
+__device__ __forceinline__ void persist_final_phase(const PersistArgs& p, char* lds, const float* mod_s, int vb) {
+  if (vb >= p.T) return;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  constexpr int NT = KC_WAVES * 64, PC = 1024 / NT, MR = 2;
+  float* red = reinterpret_cast<float*>(lds + p.lds_top) + 512;        // [8 waves][2 rows] + results
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, M = p.M, K = p.w, nq = K >> 2;
+  const float* shift = mod_s + (int64_t)p.nblk * 3 * K;
+  const float* scale = shift + K;
+  const __amdgpu_buffer_rsrc_t rh = coh_rsrc(p.h, (uint32_t)M * K * 4);
+  f4 hv[MR][PC], sc[MR][PC], sh[MR][PC];
+  u2 fw[PC];
+#pragma unroll
+  for (int j = 0; j < PC; ++j) {
+    const int c = tid + j * NT;
+    fw[j] = c < nq ? *reinterpret_cast<const u2*>(p.fin_w + (int64_t)vb * K + c * 4) : u2{0u, 0u};
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const bool on = m < M && c < nq;
+      const u32x4 t = on ? __builtin_amdgcn_raw_buffer_load_b128(rh, (m * K + c * 4) * 4, 0, AUX_SC1) : u32x4{0u, 0u, 0u, 0u};
+      hv[m][j] = f4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+      sc[m][j] = on ? *reinterpret_cast<const f4*>(scale + (int64_t)m * p.ldmod + c * 4) : f4{0.f, 0.f, 0.f, 0.f};
+      sh[m][j] = on ? *reinterpret_cast<const f4*>(shift + (int64_t)m * p.ldmod + c * 4) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  auto block_sum2 = [&](float (&x)[MR]) {             // sums over the workgroup of MR values, every thread gets them
+#pragma unroll
+    for (int m = 0; m < MR; ++m) x[m] = wave_sum(x[m]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+      for (int m = 0; m < MR; ++m) red[wave * MR + m] = x[m];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      float t = 0.f;
+      for (int wv = 0; wv < KC_WAVES; ++wv) t += red[wv * MR + m];
+      x[m] = t;
+    }
+  };
+  float mean[MR], rstd[MR], dot[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    mean[m] = 0.f;
+#pragma unroll
+    for (int j = 0; j < PC; ++j) mean[m] += (hv[m][j].x + hv[m][j].y) + (hv[m][j].z + hv[m][j].w);
+  }
+  block_sum2(mean);
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    mean[m] /= (float)K;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < PC; ++j)
+      if (tid + j * NT < nq) { const f4 d = hv[m][j] - mean[m]; ss += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
+    rstd[m] = ss;
+  }
+  block_sum2(rstd);
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    rstd[m] = rsqrtf(rstd[m] / (float)K + 1e-6f);
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < PC; ++j) {
+      const float w4[4] = {bf16lo_to_f32(fw[j].x), bf16hi_to_f32(fw[j].x), bf16lo_to_f32(fw[j].y), bf16hi_to_f32(fw[j].y)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xn = (hv[m][j][e] - mean[m]) * rstd[m];
+        a = fmaf(xn * (1.0f + sc[m][j][e]) + sh[m][j][e], w4[e], a);
+      }
+    }
+    dot[m] = a;
+  }
+  block_sum2(dot);
+  if (tid < M) {
+    const float y = (tid == 0 ? dot[0] : dot[1]) + bf16_to_f32(p.fin_b[vb]);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), coh_rsrc(p.v, (uint32_t)M * p.T * 4), (tid * p.T + vb) * 4, 0, AUX_SC1);
+  }
+}
+
 template <int WQ>
 __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const PersistArgs p) {
   constexpr int RD3 = WQ == 1 ? 4 : 2;
@@ -562,22 +696,31 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const 
   // and 32 more live registers spill; profiles/README.md r05): chunk 0 is requested after the arrival.
   Chunk<WQ> r3[RD3];
   Chunk<WQ> (&r12)[1] = *reinterpret_cast<Chunk<WQ> (*)[1]>(&r3[0]);
-  auto args12 = [&](int b) {
-    const float* mod = p.mod + (int64_t)b * 3 * p.w;
+  auto args12 = [&](const float* base, int b) {
+    const float* mod = base + (int64_t)b * 3 * p.w;
     return W12Args{p.h, p.M, p.w, p.hid, p.blk[b].ln_g, p.blk[b].ln_b, mod, mod + p.w, p.ldmod, p.blk[b].W12, p.blk[b].s12, p.blk[b].b12, p.wf, p.Y};
   };
-  auto args3 = [&](int b) {
-    return W3Args{p.Y, p.M, p.w, p.hid, p.blk[b].W3, p.blk[b].s3, p.blk[b].b3, p.wf, p.mod + (int64_t)b * 3 * p.w + 2 * p.w, p.ldmod, p.h};
+  auto args3 = [&](const float* base, int b) {
+    return W3Args{p.Y, p.M, p.w, p.hid, p.blk[b].W3, p.blk[b].s3, p.blk[b].b3, p.wf, base + (int64_t)b * 3 * p.w + 2 * p.w, p.ldmod, p.h};
   };
   char* wbuf12 = lds + (size_t)2 * p.M * (p.w * 2 + 64) + (size_t)wave * 16 * WCH * 2;
   char* wbuf3 = lds + (size_t)2 * p.M * (p.hid * 2 + 64) + (size_t)wave * 16 * WCH * 2;
-  W12Args a12 = args12(0);
+  const bool whole = p.steps > 0;                   // the whole sampler: steps x (boundary phase, blocks, final-layer phase)
+  const int nsteps = whole ? p.steps : 1;
+  W12Args a12 = args12(p.mod, 0);
   WStream s12 = w12_stream<KC_WAVES>(a12, vb, wave, vb < n12);
-  prefetch<WQ, 1>(s12, wbuf12, nullptr, r12, lane);
+  prefetch<WQ, 1>(s12, wbuf12, nullptr, r12, lane);      // (neither light phase touches the weight tiles or the ring)
   __syncthreads();
-  uint64_t* tr = p.trace ? p.trace + (size_t)vb * 2 * p.nblk * 8 : nullptr;
+  uint64_t* tr = !whole && p.trace ? p.trace + (size_t)vb * 2 * p.nblk * 8 : nullptr;
+  for (int s = 0; s < nsteps; ++s) {
+  const float* mod_s = p.mod + (int64_t)s * p.mod_step;
+  if (whole) {
+    persist_boundary_phase(p, lds, s, vb, n3);
+    gb.arrive();
+    gb.wait();
+  }
   for (int b = 0; b < p.nblk; ++b) {
-    const W3Args a3 = args3(b);
+    const W3Args a3 = args3(mod_s, b);
     const WStream s3 = w3_stream(a3, vb, wave, vb < n3);
     stamp(tr, 0);
     if (vb < n12) w12_body<WQ, 2, 1, KC_WAVES, true>(a12, lds, vb, r12, tr);
@@ -590,11 +733,15 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const 
     stamp(tr, 6);
     if (tr) tr += 8;
     stamp(tr, 0);
-    const bool more = b + 1 < p.nblk;
-    if (more) { a12 = args12(b + 1); s12 = w12_stream<KC_WAVES>(a12, vb, wave, vb < n12); } else s12.live = false;
+    const bool last = b + 1 == p.nblk;
+    const bool more = !last || (whole && s + 1 < nsteps);         // another w12' follows in this launch: the next block's, or the next step's first
+    if (more) {
+      a12 = args12(last ? mod_s + p.mod_step : mod_s, last ? 0 : b + 1);
+      s12 = w12_stream<KC_WAVES>(a12, vb, wave, vb < n12);
+    } else s12.live = false;
     if (vb < n3) w3_body<WQ, RD3, true>(a3, lds, vb, r3, tr);
     stamp(tr, 3);
-    if (more) {
+    if (more || whole) {
       gb.arrive();
       stamp(tr, 4);
       prefetch<WQ, 1>(s12, wbuf12, nullptr, r12, lane);
@@ -604,13 +751,24 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const 
     }
     if (tr) tr += 8;
   }
+  if (whole) {
+    persist_final_phase(p, lds, mod_s, vb);
+    gb.arrive();
+    gb.wait();
+  }
+  }
   // a timed-out barrier poisons the state: the caller's result is NaN, never a silently wrong number
   const int dead = __syncthreads_or(tid < 64 ? gb.dead : 0);
+  if (whole && vb == 0 && tid < p.n_images * p.T) {      // the last Euler update; one row per image leaves (the rows of an image hold the same x)
+    const float* xs = reinterpret_cast<const float*>(lds + p.lds_top);
+    const int img = tid / p.T, t = tid - img * p.T;
+    p.latent[img * p.T + t] = dead ? __builtin_nanf("") : persist_x_update(p, xs, img * p.rpi, t);
+  }
   if (dead && vb < n3 && tid < p.M * 16 && vb * 16 + (tid & 15) < p.w) p.h[(int64_t)(tid >> 4) * p.w + vb * 16 + (tid & 15)] = __builtin_nanf("");
 }
 
 uint64_t* g_kc_trace = nullptr;
-int g_kc_persist_all = 0;            // dev library: the persistent launch for int8 / NF4 as well (mn_rf_kc_persist_all)
+int g_kc_persist_all = 0;            // dev library: the persistent launch for int8 as well (mn_rf_kc_persist_all)
 int g_kc_rd12 = 1, g_kc_rd3 = 0;     // weight chunks in flight per wave; rd3 = 0: by format (dev-library A/B knob: mn_rf_kc_tune)       // weight chunks in flight per wave (dev-library A/B knob: mn_rf_kc_tune)
 
 size_t w12_lds(int M, int w, int nw) { return (size_t)2 * M * (w * 2 + 64) + (size_t)nw * 16 * WCH * 2 + (nw * KC_MAX_M * 16 + 16) * sizeof(float); }
@@ -641,9 +799,10 @@ bool rf_kc_ok(int wfmt, int M, int w, int hid) {
 // Can the whole block chain of a step run as one persistent launch?  K-complete shapes whose phases fit one workgroup per CU.
 bool rf_persist_ok(int wfmt, int M, int w, int hid, void* stream) {
   if (!rf_kc_ok(wfmt, M, w, hid)) return false;
-  // bf16 and e4m3 gain (sampler call at 2 rows 6.84 -> 6.34 ms, 5.26 -> 5.00); int8 and NF4 spend the phase in their decoders, not in
-  // launch gaps: 5.91 -> 6.23 and 5.41 -> 5.39 (tools/exp/rf_persist_ab.py, profiles/r05_rf_persist_ab.txt) — they keep the launches
-  if ((wfmt == MN_W_INT8 || wfmt == MN_W_NF4) && !g_kc_persist_all) return false;
+  // bf16, e4m3 and NF4 gain — sampler call at 2 rows, 24 launches per step -> one launch per step -> the whole sampler in one launch:
+  // bf16 6.81 -> 6.46 -> 6.22 ms, e4m3 5.26 -> 5.17 -> 4.97, NF4 5.39 -> 5.40 -> 5.17; int8 spends the phases in its decoder, not in
+  // launch gaps (5.91 -> 6.35 -> 6.17) and keeps the launches  (tools/exp/rf_persist_ab.py, profiles/r05_rf_persist_ab.txt)
+  if (wfmt == MN_W_INT8 && !g_kc_persist_all) return false;
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0, v = 0;
@@ -659,22 +818,40 @@ bool rf_persist_ok(int wfmt, int M, int w, int hid, void* stream) {
   return true;
 }
 
+// ... and the whole sampler (every Euler step: boundary phase, blocks, final-layer phase) when all blocks fit one launch, the ODE state fits
+// the replicated LDS copy and there is a workgroup per final-layer column.
+bool rf_sampler_persist_ok(int M, int w, int hid, int depth, int T, int rpi, int n_images) {
+  const int G = mn_cdiv(hid, 32) > mn_cdiv(w, 16) ? mn_cdiv(hid, 32) : mn_cdiv(w, 16);
+  const size_t l12 = w12_lds(M, w, KC_WAVES), l3 = w3_lds(M, hid);
+  return depth >= 1 && depth <= PB_MAX && T >= 8 && (T % 8) == 0 && M * T <= 512 && T <= G && rpi >= 1 && rpi <= 3 && n_images * rpi == M &&
+         (l12 > l3 ? l12 : l3) + 16 + (512 + 64) * sizeof(float) + 256 <= 160 * 1024;
+}
+
 // Blocks [b0, b0 + nblk) of one Euler step in one launch.  `bar`: RF_PERSIST_BAR_WORDS words of device memory, zeroed by the caller;
 // epoch0: this launch's first barrier epoch — successive launches on one flag array take epoch0 = 0, 64, 128, ... (a launch has
-// 2 nblk - 1 <= 31 barriers).  Two persistent launches must never share the device — each would hold CUs the other
+// 2 nblk - 1 <= 31 barriers).  `whole`: the whole sampler in this launch (steps x (2 nblk + 2) barriers: give it a zeroed flag array).  Two persistent launches must never share the device — each would hold CUs the other
 // waits for — so launches on different streams are ordered by an event.
 int rf_blocks_persist(int wfmt, float* h, bf16_t* Y3, int M, int w, int hid, const float* mod, int64_t ldmod, int nblk,
                       const void* const* W12, const float* const* s12, const bf16_t* const* b12, const bf16_t* const* ln_g,
                       const bf16_t* const* ln_b, const void* const* W3, const float* const* s3, const bf16_t* const* b3,
-                      unsigned* bar, unsigned epoch0, void* stream) {
+                      unsigned* bar, unsigned epoch0, const RfSamplerTail* whole, void* stream) {
   MN_CHECK_ARG(h && Y3 && mod && bar && nblk >= 1 && nblk <= PB_MAX && rf_kc_ok(wfmt, M, w, hid), "rf_blocks_persist: bad args");
+  MN_CHECK_ARG(!whole || rf_sampler_persist_ok(M, w, hid, nblk, whole->T, whole->rpi, whole->n_images), "rf_blocks_persist: shape cannot run the whole sampler in one launch");
   PersistArgs p{};
   p.h = h; p.Y = Y3; p.M = M; p.w = w; p.hid = hid; p.wf = wfmt; p.nblk = nblk; p.mod = mod; p.ldmod = ldmod; p.bar = bar; p.epoch0 = epoch0; p.trace = g_kc_trace;
   p.wait_ticks = 2000ull * 100000ull;               // 2 s of the 100 MHz clock
   for (int b = 0; b < nblk; ++b)
     p.blk[b] = PersistBlk{W12[b], wfmt ? s12[b] : nullptr, b12[b], ln_g[b], ln_b[b], W3[b], wfmt ? s3[b] : nullptr, b3[b]};
   const int G = mn_cdiv(hid, 32) > mn_cdiv(w, 16) ? mn_cdiv(hid, 32) : mn_cdiv(w, 16);
-  const size_t l12 = w12_lds(M, w, KC_WAVES), l3 = w3_lds(M, hid), lds = l12 > l3 ? l12 : l3;
+  const size_t l12 = w12_lds(M, w, KC_WAVES), l3 = w3_lds(M, hid), top = ((l12 > l3 ? l12 : l3) + 15) & ~(size_t)15;
+  const size_t lds = top + (whole ? (512 + 64) * sizeof(float) : 0);
+  if (whole) {
+    p.steps = whole->steps; p.T = whole->T; p.rpi = whole->rpi; p.n_images = whole->n_images; p.mod_step = whole->mod_step;
+    p.in_w = whole->in_w; p.in_b = whole->in_b; p.fin_w = whole->fin_w; p.fin_b = whole->fin_b; p.noise = whole->noise;
+    p.temperature = whole->temperature; p.text_cfg = whole->text_cfg; p.image_cfg = whole->image_cfg; p.v = whole->v; p.latent = whole->latent;
+    p.lds_top = (uint32_t)top;
+    p.trace = nullptr;
+  }
   static std::mutex mu;
   static hipEvent_t ev = nullptr;
   static hipStream_t last = nullptr;

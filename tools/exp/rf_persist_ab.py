@@ -1,7 +1,8 @@
 """A/B of the persistent per-Euler-step launch (stream_kc.hip: the 12 ResBlocks = 24 phases of a step in ONE launch, grid barriers
 between the phases, the next phase's first weight chunks requested before the wait) against the same phases as 24 launches, at the
 reference's call shape — 1 image, 1 / 2 CFG rows — full 16B-A3B RF head, every weight format: ms per RF sampler call (16 Euler steps)
-interleaved in one process, and whether the sampled latents are the same BITS (same arithmetic in the same order: they must be).
+interleaved in one process, and whether the sampled latents are the same BITS (the per-step launch: same arithmetic in the same order,
+they must be; the whole-sampler launch computes the final layer in fp32 FMAs instead of hi/lo MFMA slabs: equal to ~1e-6) — and the whole sampler as one launch.
     python tools/exp/rf_persist_ab.py [bf16,fp8,int8,int4] [rows,...]"""
 import sys, os, argparse, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -33,17 +34,21 @@ for weights in WEIGHTS:
         hid = torch.randn(rows, cfg.hidden_size, device=dev, generator=g)
         noise = torch.randn(1, 32, device=dev, generator=g)
         res = {}
+        ARMS = (("24 launches per step", 3 | 16), ("one persistent launch per step", 3 | 32), ("the whole sampler in one launch", 3))
         for rnd in range(3):                       # interleaved rounds: box drift shows as spread between rounds
-            for on in (3 | 16, 3):                 # bit 4 set = persistent launch OFF
+            for name, on in ARMS:                  # bit 4 set = persistent launch OFF, bit 5 = whole-sampler launch OFF
                 L.mn_rf_tune_fuse(on)
                 lat = torch.empty(1, 32, device=dev)
                 t = ev(lambda: rf.sample(hid, noise, n_images=1, out=lat))
-                res.setdefault(on, []).append((t, lat.clone()))
-        old, new = res[3 | 16], res[3]
-        same = all(torch.equal(a[1], b[1]) for a in old for b in new)
-        print(f"{weights} rows {rows}: 24 launches per step {min(t for t, _ in old):6.3f} ms ({', '.join('%.3f' % t for t, _ in old)}), "
-              f"one persistent launch {min(t for t, _ in new):6.3f} ms ({', '.join('%.3f' % t for t, _ in new)})  latents bit-identical: {same}"
-              f"  finite: {bool(torch.isfinite(new[0][1]).all())}", flush=True)
+                res.setdefault(name, []).append((t, lat.clone()))
+        base = res[ARMS[0][0]]
+        line = f"{weights} rows {rows}:"
+        for name, _ in ARMS:
+            r = res[name]
+            same = all(torch.equal(a[1], b[1]) for a in base for b in r)
+            d = max(((a[1] - b[1]).abs().max() / a[1].abs().max()).item() for a in base for b in r)
+            line += f"  {name} {min(t for t, _ in r):6.3f} ms ({', '.join('%.3f' % t for t, _ in r)})" + ("" if name == ARMS[0][0] else f" [same bits as the launches: {same}; max diff {d:.1e}; finite {bool(torch.isfinite(r[0][1]).all())}]")
+        print(line, flush=True)
     if weights != "bf16":
         del rf
         torch.cuda.empty_cache()
