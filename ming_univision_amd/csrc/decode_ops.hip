@@ -76,7 +76,7 @@ __global__ __launch_bounds__(1024) void moe_router_row_kernel(
     const float* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ norm_w, float eps, const bf16_t* __restrict__ gate_w,
     const bf16_t* __restrict__ image_gate_w, const uint8_t* __restrict__ image_mask, int M, int H, int E, int top_k,
     int norm_topk_prob, int n_shared, float* __restrict__ x_norm, int32_t* __restrict__ topk_idx, float* __restrict__ topk_w,
-    float* __restrict__ logits_out) {
+    float* __restrict__ logits_out, const float* __restrict__ P, int nz, int64_t slab, float* __restrict__ h_out) {
   __shared__ __attribute__((aligned(16))) float xs[4096];
   __shared__ float red[16];
   __shared__ float lg[64];
@@ -101,14 +101,40 @@ __global__ __launch_bounds__(1024) void moe_router_row_kernel(
         if (e < E && k < H) gw[i][j] = *reinterpret_cast<const u4*>(G + (int64_t)e * H + k);
       }
   }
+  // P != NULL (the decoder chain at <= 4 rows): the row is h + the nz K-slice partial slabs of the attention output projection, summed
+  // here (in slab order, like llm_glue_kernel) and written back to h_out — the residual glue launch and the gate launch fold into this one
+  float xv[4];                                    // H <= 4096: columns tid, tid + 1024, ...
   float ss = 0.f;
-  for (int k = tid; k < H; k += 1024) { const float v = xr[k]; ss += v * v; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = tid + 1024 * i;
+    xv[i] = 0.f;
+    if (k < H) {
+      float v = xr[k];
+      if (P) {
+        const float* pp = P + (int64_t)m * H + k;
+        for (int z0 = 0; z0 < nz; z0 += 8) {
+          float t[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t[j] = z0 + j < nz ? pp[(int64_t)(z0 + j) * slab] : 0.f;
+          for (int j = 0; j < 8; ++j) v += t[j];
+        }
+        h_out[(int64_t)m * H + k] = v;
+      }
+      xv[i] = v;
+      ss += v * v;
+    }
+  }
   ss = block_sum(ss, red);
   const float rstd = rsqrtf(ss / (float)H + eps);
-  for (int k = tid; k < H; k += 1024) {
-    const float v = xr[k] * rstd * bf16_to_f32(norm_w[k]);
-    xs[k] = v;
-    x_norm[(int64_t)m * H + k] = v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = tid + 1024 * i;
+    if (k < H) {
+      const float v = xv[i] * rstd * bf16_to_f32(norm_w[k]);
+      xs[k] = v;
+      x_norm[(int64_t)m * H + k] = v;
+    }
   }
   __syncthreads();
   if (pre) {
@@ -185,6 +211,19 @@ static int g_router_rows = 4;      // rows up to which mn_moe_router runs as one
 extern "C" MN_DEV_API void mn_moe_router_tune(int max_rows) { g_router_rows = max_rows; }
 #endif
 
+// The decoder chain's form at <= 4 rows (engine.hip): h[m] += sum of the nz partial slabs P [nz][M][H]; RMSNorm -> x_norm; gate; top-k — one launch
+bool moe_router_rows_ok(int M, int H, int E) { return M >= 1 && M <= g_router_rows && H <= 4096 && (H % 8) == 0 && E <= 64; }
+int moe_router_rows(float* h, const float* P, int nz, const uint16_t* norm_w, float eps, const uint16_t* gate_w, int M, int H, int E, int top_k,
+                    int norm_topk_prob, int n_shared_slots, float* x_norm, int32_t* topk_idx, float* topk_w, float* logits_ws, void* stream) {
+  MN_CHECK_ARG(h && P && norm_w && gate_w && x_norm && topk_idx && topk_w && logits_ws && moe_router_rows_ok(M, H, E) && top_k >= 1 && top_k <= E &&
+               top_k + n_shared_slots <= 64, "moe_router_rows: bad args");
+  hipLaunchKernelGGL(moe_router_row_kernel, dim3(M), dim3(1024), 0, mn_stream(stream), (const float*)h, (int64_t)H, norm_w, eps, gate_w,
+                     (const bf16_t*)nullptr, (const uint8_t*)nullptr, M, H, E, top_k, norm_topk_prob, n_shared_slots, x_norm, topk_idx, topk_w,
+                     logits_ws, P, nz, (int64_t)M * H, h);
+  MN_CHECK_LAUNCH("moe_router_rows");
+  return MN_OK;
+}
+
 extern "C" int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w, float eps,
                              const uint16_t* gate_w, const uint16_t* image_gate_w, const uint8_t* image_mask,
                              int M, int H, int E, int top_k, int norm_topk_prob, int n_shared_slots,
@@ -197,7 +236,8 @@ extern "C" int mn_moe_router(const float* x, int64_t ldx, const uint16_t* norm_w
   const bool both = image_mask && image_gate_w;
   if (M <= g_router_rows && H <= 4096) {
     hipLaunchKernelGGL(moe_router_row_kernel, dim3(M), dim3(1024), 0, mn_stream(stream), x, ldx, norm_w, eps, gate_w, image_gate_w,
-                       image_mask, M, H, E, top_k, norm_topk_prob, n_shared_slots, x_norm, topk_idx, topk_w, logits_ws);
+                       image_mask, M, H, E, top_k, norm_topk_prob, n_shared_slots, x_norm, topk_idx, topk_w, logits_ws,
+                       (const float*)nullptr, 0, (int64_t)0, (float*)nullptr);
     MN_CHECK_LAUNCH("mn_moe_router");
     return MN_OK;
   }

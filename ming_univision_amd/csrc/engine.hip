@@ -1006,9 +1006,12 @@ static bool moe_mfma_ok(const mn_llm* m, int rows) {
 // one wave per router row: 64 experts at most).  Measured end to end against the unfused sequence (same box, tokens/s):
 // 2 rows 78.5 vs 76.5, 8 rows 254 vs 247, 16 rows 451 vs 442, 32 rows 699 vs 698; at 64 rows the one-workgroup-per-row
 // glue kernels lose to the wider unfused ones (1084 vs 1122), so the chain stops at 32.
-static int g_chain_max_rows = 32;
+static int g_chain_max_rows = 32, g_chain_router = 1;
+bool moe_router_rows_ok(int M, int H, int E);
+int moe_router_rows(float* h, const float* P, int nz, const uint16_t* norm_w, float eps, const uint16_t* gate_w, int M, int H, int E, int top_k,
+                    int norm_topk_prob, int n_shared_slots, float* x_norm, int32_t* topk_idx, float* topk_w, float* logits_ws, void* stream);
 #ifdef MN_DEV_HOOKS
-extern "C" MN_DEV_API void mn_llm_tune_chain(int max_rows) { g_chain_max_rows = max_rows; }   // A/B hook (tools/)
+extern "C" MN_DEV_API void mn_llm_tune_chain(int max_rows) { g_chain_max_rows = max_rows & 0xffff; g_chain_router = (max_rows >> 16) & 1 ? 0 : 1; }   // A/B hook (tools/): bit 16 = the one-launch router of the chain OFF
 #endif
 static bool llm_chain_ok(const mn_llm* m, int rows) {
   return rows >= 2 && rows <= g_chain_max_rows && (m->hidden % 8) == 0 && m->hidden <= 4096 && ((m->n_q * m->head_dim) % 8) == 0 &&
@@ -1231,6 +1234,13 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
       }
       nz = mn_stream_mfma(w.ya, m->wdense[l], w.pp, M, H, ad, stream);
       if (nz < 0) return nz;
+      // <= 4 rows on the fp32-FMA expert kernels: residual + RMSNorm(ln2) + gate + top-k in ONE launch (decode_ops.hip) instead of glue,
+      // gate launch and the one-workgroup top-k
+      if (!grouped && g_chain_router && moe_router_rows_ok(M, H, E)) {
+        MN_TRY(moe_router_rows(w.h, w.pp, nz, m->ln2[l], m->rms_eps, m->gate[l], M, H, E, m->top_k, m->norm_topk_prob, S, w.xn, w.ti, w.tw,
+                               w.logits, stream));
+        goto experts_2rows;
+      }
       // glue: h += dense partials; RMSNorm(ln2) -> xn (fp32 for the 2-row expert kernels) and yh (gate + expert operand)
       hipLaunchKernelGGL(llm_glue_kernel, dim3(M), dim3(gt), 0, st, 1, (const float*)nullptr, (int64_t)0, 1, (const float*)w.pp, nz,
                          (int64_t)M * H, (const int32_t*)nullptr, (const float*)nullptr, n_slot, w.h, M, H, m->ln2[l],
@@ -1251,6 +1261,7 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
                              w.moe.off, nullptr, G, M, H, I, stream);
         if (nz2 < 0) return nz2;
       } else {   // 2 rows: (row, expert) pairs on the fp32-FMA kernels, accumulated straight into h
+      experts_2rows:
         mn_skinny_args a = sk(w.xn, H, m->w_gate_up[l], H, nullptr, w.hmid, I, 1, I, H);
         a.epilogue = MN_EPI_SWIGLU;
         a.batch = M * n_slot; a.w_index = w.ti; a.w_batch_stride = (int64_t)2 * I * H;
