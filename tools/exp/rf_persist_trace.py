@@ -10,6 +10,8 @@ import bench
 from ming_univision_amd._lib import lib
 L = lib()
 L.mn_rf_kc_trace.argtypes = [ctypes.c_void_p]; L.mn_rf_kc_trace.restype = None
+L.mn_rf_tune_fuse.argtypes = [ctypes.c_int]; L.mn_rf_tune_fuse.restype = None
+L.mn_rf_tune_fuse(3 | 32)                            # one launch per Euler step (the whole-sampler launch carries no stamps)
 L.mn_rf_kc_persist_all.argtypes = [ctypes.c_int]; L.mn_rf_kc_persist_all.restype = None
 L.mn_rf_kc_persist_all(1)                          # (A/B every format; the product enables bf16 and e4m3)
 dev = torch.device("cuda", 0)
