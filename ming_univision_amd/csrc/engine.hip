@@ -1007,10 +1007,12 @@ static bool moe_mfma_ok(const mn_llm* m, int rows) {
 // 2 rows 78.5 vs 76.5, 8 rows 254 vs 247, 16 rows 451 vs 442, 32 rows 699 vs 698; at 64 rows the one-workgroup-per-row
 // glue kernels lose to the wider unfused ones (1084 vs 1122), so the chain stops at 32.
 static int g_chain_max_rows = 32, g_chain_router = 1;
+static int g_moe_gate_up = 1, g_moe_gate_up_rows = 1;      // the one-launch router + gate/up of 1-row steps (dev-library A/B: mn_moe_tune_gate_up)
 bool moe_router_rows_ok(int M, int H, int E);
 int moe_router_rows(float* h, const float* P, int nz, const uint16_t* norm_w, float eps, const uint16_t* gate_w, int M, int H, int E, int top_k,
                     int norm_topk_prob, int n_shared_slots, float* x_norm, int32_t* topk_idx, float* topk_w, float* logits_ws, void* stream);
 #ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_moe_tune_gate_up(int on, int max_rows) { g_moe_gate_up = on; g_moe_gate_up_rows = max_rows; }
 extern "C" MN_DEV_API void mn_llm_tune_chain(int max_rows) { g_chain_max_rows = max_rows & 0xffff; g_chain_router = (max_rows >> 16) & 1 ? 0 : 1; }   // A/B hook (tools/): bit 16 = the one-launch router of the chain OFF
 #endif
 static bool llm_chain_ok(const mn_llm* m, int rows) {
@@ -1308,6 +1310,14 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
     a = sk(w.attn, nq * hd, m->wdense[l], nq * hd, nullptr, w.h, H, M, H, nq * hd);
     a.epilogue = MN_EPI_RESID; a.res = w.h; a.ldres = H;
     MN_TRY(mn_skinny_gemm(&a, stream));
+    // one row on bf16 experts: RMSNorm + router + the selected experts' gate/up in ONE launch (moe_gate_up.hip), then the down projection
+    if (g_moe_gate_up && M <= g_moe_gate_up_rows && !(image_mask && m->image_gate) && !moe_mfma_ok(m, M) && g_moe_down &&
+        moe_gate_up_ok(m->wfmt, H, I, m->n_experts, m->top_k, m->n_shared_slots) && moe_down_ok(m->wfmt, n_slot, H, I)) {
+      MN_TRY(moe_gate_up_routed(w.h, H, m->ln2[l], m->rms_eps, m->gate[l], m->w_gate_up[l], (int64_t)2 * I * H, M, H, I, m->n_experts, m->top_k,
+                                m->n_shared_slots, m->norm_topk_prob, w.hmid, (int64_t)n_slot * I, w.ti, w.tw, w.logits, stream));
+      MN_TRY(moe_down_rows(w.hmid, (int64_t)n_slot * I, m->w_down[l], (int64_t)H * I, w.ti, w.tw, w.h, H, w.h, H, M, H, I, n_slot, stream));
+      continue;
+    }
     // MoE: RMSNorm + router -> grouped expert gate/up (SwiGLU) -> grouped down + weighted sum + residual (:1218-1225, :556-639)
     MN_TRY(mn_moe_router(w.h, H, m->ln2[l], m->rms_eps, m->gate[l], m->image_gate ? m->image_gate[l] : nullptr,
                          image_mask, M, H, m->n_experts, m->top_k, m->norm_topk_prob, m->n_shared_slots, w.xn, w.ti,

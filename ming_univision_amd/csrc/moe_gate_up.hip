@@ -1,0 +1,182 @@
+// moe_gate_up.hip — router + expert gate/up projections of a 1-row decode step (text decode) in ONE launch:
+//
+//   xn = RMSNorm(h[b]; ln2)                                             (modeling_bailing_moe.py:1218-1221)
+//   (ti, tw)[b] = top-k of softmax(xn · gate^T), shared experts appended  (BailingMoeGate.forward :505-520)
+//   hmid[b][s][i] = silu(xn · Wg[ti[b, s]][i]) * (xn · Wu[ti[b, s]][i])   (BailingMoeMLP, :608-639, the selected + shared experts)
+//
+// Round 4/5 ran this as two launches: the one-workgroup-per-row router (8.6 us: one CU pulls the 256 KB of gate rows and does the
+// top-k while 255 CUs idle) and the fp32-FMA pair launch (18.8 us for 92 MB).  Routing is cheap to REPEAT and expensive to WAIT for:
+// here every workgroup routes its row itself — each wave holds the normalised row in registers (no LDS image, no block reduction: a
+// wave reduces the row's square sum on its own), computes 8 of the 64 gate logits (the 256 KB of gate rows come from
+// L2), one workgroup barrier, then every wave does the 64-lane softmax / top-k redundantly and wave s takes slot s — and streams
+// `UNITS` = 6 hidden units of that expert (gate row + up row each: 192 registers of loads per lane, ALL in flight at once: the whole
+// launch is one HBM round trip; one workgroup per CU, 235 workgroups for I = 1408).  (Letting the shared experts' waves stream before
+// the routing would overlap a quarter of the bytes with it, but their 192 registers of loads and the routing waves' gate rows do not
+// fit one register file: 660 B of scratch per lane.)
+// (A first form — 2 units per workgroup, 704 workgroups, two per CU — was SLOWER than the two launches, 40 us per layer against 27: every
+// workgroup re-reads the 256 KB of gate rows, 180 MB of L2 traffic for 92 MB of weights.)
+// The logits' per-lane arithmetic and the tie rule (lowest expert id among equal probabilities) are moe_router_row_kernel's
+// (decode_ops.hip); the row's square sum is reduced per wave here, per workgroup there — 1-ulp differences of the logits.
+#include "common.h"
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int GU_WAVES = 8;          // = slots per row (top_k + shared) at most
+constexpr int UNITS = 6;             // hidden units per workgroup and wave: 6 x (gate, up) rows x K in flight per lane (192 registers at H = 2048)
+constexpr int GB = 8;                // gate rows per wave (64 experts over 8 waves), requested together: one L2 round trip
+
+struct GateUpArgs {
+  const float* h; int64_t ldh;                       // [batch][H] fp32
+  const bf16_t* norm_w; float eps;
+  const bf16_t* gate_w;                              // [E][H]
+  const bf16_t* W; int64_t w_stride;                 // [E + S][2 I][H]: gate rows [0, I), up rows [I, 2 I)
+  int H, I, E, top_k, n_shared, norm_topk_prob;
+  float* hmid; int64_t ld_hmid;                      // [batch][n_slot * I]
+  int32_t* ti; float* tw; float* logits;             // [batch][n_slot], [batch][n_slot], [batch][E]
+};
+
+__device__ __forceinline__ float dot8(const u32x4 q, const float* x, float t) {
+  t = fmaf(bf16lo_to_f32(q.x), x[0], t); t = fmaf(bf16hi_to_f32(q.x), x[1], t);
+  t = fmaf(bf16lo_to_f32(q.y), x[2], t); t = fmaf(bf16hi_to_f32(q.y), x[3], t);
+  t = fmaf(bf16lo_to_f32(q.z), x[4], t); t = fmaf(bf16hi_to_f32(q.z), x[5], t);
+  t = fmaf(bf16lo_to_f32(q.w), x[6], t); t = fmaf(bf16hi_to_f32(q.w), x[7], t);
+  return t;
+}
+
+template <int NCK>                                   // H = NCK x 512
+__global__ __launch_bounds__(GU_WAVES * 64) void moe_gate_up_routed_kernel(const GateUpArgs a) {
+  __shared__ float lg[64];
+  const int tid = threadIdx.x, lane = tid & 63, s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y, i0 = blockIdx.x * UNITS, H = a.H, I = a.I, E = a.E, n_slot = a.top_k + a.n_shared;
+  const bool live = s < n_slot;
+  // ---- the row, this lane's K positions (k = c 512 + lane 8 ..): every wave holds the whole row
+  const float* xr = a.h + (int64_t)b * a.ldh;
+  float x[NCK][8];
+  u32x4 nw[NCK];
+#pragma unroll
+  for (int c = 0; c < NCK; ++c) {
+    const int k = c * 512 + lane * 8;
+    const f4 lo = *reinterpret_cast<const f4*>(xr + k), hi = *reinterpret_cast<const f4*>(xr + k + 4);
+    x[c][0] = lo.x; x[c][1] = lo.y; x[c][2] = lo.z; x[c][3] = lo.w; x[c][4] = hi.x; x[c][5] = hi.y; x[c][6] = hi.z; x[c][7] = hi.w;
+    nw[c] = *reinterpret_cast<const u32x4*>(a.norm_w + k);
+  }
+  u32x4 wq[UNITS][2][NCK];
+  auto request = [&](int e) {                        // ALL of this wave's expert rows in one round trip
+    const bf16_t* wb = a.W + (int64_t)e * a.w_stride;
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+      const int i = min(i0 + u, I - 1);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const bf16_t* wr = wb + ((int64_t)g * I + i) * H;
+#pragma unroll
+        for (int c = 0; c < NCK; ++c) wq[u][g][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + c * 512 + lane * 8));
+      }
+    }
+  };
+  // ---- RMSNorm: the wave reduces the square sum of the row on its own (same value in every wave)
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCK; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += x[c][e] * x[c][e];
+  ss = wave_sum(ss);
+  const float rstd = rsqrtf(ss / (float)H + a.eps);
+#pragma unroll
+  for (int c = 0; c < NCK; ++c) {
+    const uint32_t w4[4] = {nw[c].x, nw[c].y, nw[c].z, nw[c].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x[c][2 * e] = x[c][2 * e] * rstd * bf16lo_to_f32(w4[e]);
+      x[c][2 * e + 1] = x[c][2 * e + 1] * rstd * bf16hi_to_f32(w4[e]);
+    }
+  }
+  // ---- gate logits: the 8 waves share the E experts (wave s: experts s, s + 8, ...), all rows of a wave requested together (the 256 KB
+  // of gate rows are L2-resident after the first workgroup; the expert rows' registers are not live yet)
+  {
+    u32x4 gq[GB][NCK];
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+      const int e = min(s + GU_WAVES * j, E - 1);
+#pragma unroll
+      for (int c = 0; c < NCK; ++c) gq[j][c] = *reinterpret_cast<const u32x4*>(a.gate_w + (int64_t)e * H + c * 512 + lane * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCK; ++c) t = dot8(gq[j][c], x[c], t);
+      t = wave_sum(t);
+      if (lane == 0 && s + GU_WAVES * j < E) lg[s + GU_WAVES * j] = t;
+    }
+  }
+  __syncthreads();
+  // ---- softmax over E (fp32), iterative arg-max, ties -> lowest expert id: every wave, redundantly; wave s keeps slot s
+  float sl = lane < E ? lg[lane] : -INFINITY;
+  const float mx = wave_max(sl);
+  float pr = lane < E ? __expf(sl - mx) : 0.f;
+  const float denom = wave_sum(pr);
+  pr = pr / denom;
+  float cur = lane < E ? pr : -1.f, wsum = 0.f, myw = 0.f;
+  int myidx = 0, slot_e = E + (s - a.top_k);
+  for (int k = 0; k < a.top_k; ++k) {
+    const float best = wave_max(cur);
+    const int sel = __ffsll((long long)__ballot(cur == best)) - 1;
+    if (lane == k) { myw = best; myidx = sel; }
+    if (k == s) slot_e = sel;
+    if (lane == sel) cur = -1.f;
+    wsum += best;
+  }
+  if (blockIdx.x == 0 && s == 0) {                   // one workgroup per row publishes the routing (the down projection reads it)
+    if (lane < E && a.logits) a.logits[(int64_t)b * E + lane] = sl;
+    if (lane < a.top_k) {
+      a.ti[(int64_t)b * n_slot + lane] = myidx;
+      a.tw[(int64_t)b * n_slot + lane] = (a.norm_topk_prob && a.top_k > 1) ? myw / wsum : myw;
+    } else if (lane < n_slot) {
+      a.ti[(int64_t)b * n_slot + lane] = E + (lane - a.top_k);
+      a.tw[(int64_t)b * n_slot + lane] = 1.0f;
+    }
+  }
+  if (!live) return;
+  request(slot_e);
+  // ---- UNITS hidden units of expert slot_e: y = silu(xn . Wg[i]) * (xn . Wu[i])
+#pragma unroll
+  for (int u = 0; u < UNITS; ++u) {
+    float g = 0.f, up = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCK; ++c) { g = dot8(wq[u][0][c], x[c], g); up = dot8(wq[u][1][c], x[c], up); }
+    g = wave_sum(g);
+    up = wave_sum(up);
+    if (lane == 0 && i0 + u < I) a.hmid[(int64_t)b * a.ld_hmid + (int64_t)s * I + i0 + u] = silu_f(g) * up;
+  }
+}
+
+}  // namespace
+
+// Can the router + gate/up of this shape run as the one launch?  (bf16 experts, <= 64 routed experts, one wave per slot, the row in registers)
+bool moe_gate_up_ok(int wfmt, int H, int I, int E, int top_k, int n_shared) {
+  return wfmt == MN_W_BF16 && H >= 512 && H <= 2048 && (H % 512) == 0 && I >= 1 && E >= 1 && E <= 64 && top_k >= 1 && top_k <= E &&
+         top_k + n_shared <= GU_WAVES;
+}
+
+int moe_gate_up_routed(const float* h, int64_t ldh, const bf16_t* norm_w, float eps, const bf16_t* gate_w, const bf16_t* W, int64_t w_stride,
+                       int batch, int H, int I, int E, int top_k, int n_shared, int norm_topk_prob, float* hmid, int64_t ld_hmid, int32_t* ti,
+                       float* tw, float* logits, void* stream) {
+  MN_CHECK_ARG(h && norm_w && gate_w && W && hmid && ti && tw && batch >= 1 && moe_gate_up_ok(MN_W_BF16, H, I, E, top_k, n_shared) &&
+                   (ldh % 4) == 0 && (((uintptr_t)W) & 15) == 0 && (((uintptr_t)gate_w) & 15) == 0 && (w_stride % 8) == 0,
+               "moe_gate_up_routed: bad args");
+  const GateUpArgs a{h, ldh, norm_w, eps, gate_w, W, w_stride, H, I, E, top_k, n_shared, norm_topk_prob, hmid, ld_hmid, ti, tw, logits};
+  const dim3 grid((unsigned)mn_cdiv(I, UNITS), (unsigned)batch), block(GU_WAVES * 64);
+  hipStream_t st = mn_stream(stream);
+  switch (H / 512) {
+    case 1: hipLaunchKernelGGL(moe_gate_up_routed_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(moe_gate_up_routed_kernel<2>, grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(moe_gate_up_routed_kernel<3>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(moe_gate_up_routed_kernel<4>, grid, block, 0, st, a); break;
+  }
+  MN_CHECK_LAUNCH("moe_gate_up_routed");
+  return MN_OK;
+}

@@ -34,11 +34,11 @@ def _lowest_id_gate(x2d, w, cfg):
     return order, tw, logits
 
 
-def _tied_model():
+def _tied_model(hidden=256):
     from oracle import bailing_ref
     d = C.BailingMoeConfig.ming_univision_16b_a3b().to_dict()
     d.pop("model_type", None)
-    d.update(hidden_size=256, moe_intermediate_size=64, vocab_size=512, num_hidden_layers=2, num_image_tokens_for_gen=3,
+    d.update(hidden_size=hidden, moe_intermediate_size=64, vocab_size=512, num_hidden_layers=2, num_image_tokens_for_gen=3,
              image_start_token=500, pad_token_id=0)
     rf_cfg = dict(diffloss_w=64, diffloss_d=2, num_sampling_steps="4", gen_method="flow_matching_swiglu-4")
     sd = llm_sd(d, rf_cfg, 17)
@@ -90,6 +90,47 @@ def test_decoder_step_with_tied_gate_rows_follows_lowest_expert_id(M):
         M, int(cut.sum()), float(errs.max()), float(errs[cut].max()) if int(cut.sum()) else 0.0))
     assert M < 40 or int(cut.sum()) >= 1                     # the case is exercised (the other expert of the pair would give O(1e-1))
     assert float(errs.max()) < 1e-3, errs
+
+
+def test_one_row_steps_with_tied_gate_rows_follow_lowest_expert_id():
+    """ONE row, hidden 512, no image gate: the step takes the one-launch router + gate/up kernel (moe_gate_up.hip), whose every
+    workgroup routes the row itself — the same rule must hold there.  24 one-row steps; at least one has its tie across the top-k cut."""
+    from oracle import bailing_ref
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder
+    d, sd, ocfg = _tied_model(hidden=512)
+    cfg = C.BailingMoeConfig(**d)
+    t_max, n = 8, 4
+    dec = BailingMoeDecoder.from_state_dict(cfg, {k: v.to("cuda", torch.bfloat16).contiguous() for k, v in sd.items()}, t_max=t_max, n_seq=1)
+    cuts, worst = 0, 0.0
+    orig = bailing_ref.gate
+    for seed in range(24):
+        g = torch.Generator().manual_seed(100 + seed)
+        x = torch.randn(1, cfg.hidden_size, generator=g) * 0.5
+        kv = torch.randn(cfg.num_hidden_layers, 1, 2, cfg.num_key_value_heads, t_max, cfg.head_dim, generator=g) * 0.5
+        dec.kv_cache.copy_(kv.cuda())
+        slot = torch.full((1,), n, dtype=torch.int32, device="cuda")
+        out = dec.step(x.cuda(), torch.zeros(1, dtype=torch.int32).cuda(), slot, slot, slot + 1, distinct_sequences=True)
+        boundary = []
+
+        def gate_rec(x2d, w, c):
+            ti, tw, lg = _lowest_id_gate(x2d, w, c)
+            srt = torch.sort(lg, dim=-1, descending=True, stable=True)
+            k = c.num_experts_per_tok
+            boundary.append(srt.values[:, k - 1] == srt.values[:, k])
+            return ti, tw, lg
+        bailing_ref.gate = gate_rec
+        try:
+            kvs = [dict(k=kv[l, :, 0, :, :n].clone(), v=kv[l, :, 1, :, :n].clone()) for l in range(cfg.num_hidden_layers)]
+            ref = bailing_ref.model_forward(x[:, None], sd, ocfg, torch.ones(1, n + 1, dtype=torch.long),
+                                            torch.full((1, 1), n, dtype=torch.long), kvs)[:, 0]
+        finally:
+            bailing_ref.gate = orig
+        cuts += int(torch.stack(boundary).any())
+        e = float(row_errs(out, ref).max())
+        worst = max(worst, e)
+        assert e < 1e-3, (seed, e)
+    print("one-row steps with tied gate rows: %d of 24 with an exact tie across the top-k cut; worst %.2e" % (cuts, worst))
+    assert cuts >= 1
 
 
 def test_router_entry_points_with_exactly_tied_logits():
