@@ -11,9 +11,13 @@
 // for all of them — its slice of the activation (I floats, scaled by the router weight) lives in its REGISTERS, no LDS image — and all
 // RW x ceil(I / 512) weight loads of a wave are in flight at once: one HBM round trip per launch.  The n_slot partial sums of a row meet
 // in LDS, in slot order (deterministic).
+#include <type_traits>
+
 #include "common.h"
+#include "w8_codec.h"
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -22,14 +26,15 @@ constexpr int MAX_SLOTS = 8;         // segments = waves per workgroup
 
 struct DownArgs {
   const float* hmid; int64_t ld_hmid;               // [batch][n_slot * I] fp32
-  const bf16_t* W; int64_t w_stride;                // [E + S][H][I] bf16, elements between experts
+  const void* W; int64_t w_stride;                  // [E + S][H][I] bf16 (or e4m3 bytes), elements between experts
+  const float* wscale; int64_t wscale_stride;       // e4m3: one fp32 scale per output row, [E + S][H]
   const int32_t* ti; const float* tw;               // [batch][n_slot]
   const float* res; int64_t ld_res;                 // [batch][H]
   float* out; int64_t ld_out;
   int H, I, n_slot;
 };
 
-template <int NCK>
+template <int NCK, int WQ>                          // WQ 0: bf16 weights, 1: e4m3 bytes + row scales (applied to the K sums)
 __global__ __launch_bounds__(MAX_SLOTS * 64) void moe_down_kernel(const DownArgs a) {
   __shared__ float part[MAX_SLOTS][RW];
   const int tid = threadIdx.x, lane = tid & 63, s = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -38,10 +43,15 @@ __global__ __launch_bounds__(MAX_SLOTS * 64) void moe_down_kernel(const DownArgs
   // ---- this wave's slice of the activation first (loads retire in order: it lands before the weights) ...
   float xk[NCK][8];
   float sc = 0.f;
-  const bf16_t* wbase = a.W;
+  typedef typename std::conditional<WQ == 1, uint8_t, bf16_t>::type wt;
+  typedef typename std::conditional<WQ == 1, u32x2, u32x4>::type wv;        // 8 weights per lane and piece
+  const wt* wbase = static_cast<const wt*>(a.W);
+  const float* sbase = a.wscale;
   if (live) {
     sc = a.tw[(int64_t)b * a.n_slot + s];
-    wbase = a.W + (int64_t)a.ti[(int64_t)b * a.n_slot + s] * a.w_stride;
+    const int e = a.ti[(int64_t)b * a.n_slot + s];
+    wbase += (int64_t)e * a.w_stride;
+    if constexpr (WQ == 1) sbase += (int64_t)e * a.wscale_stride;
     const float* xp = a.hmid + (int64_t)b * a.ld_hmid + (int64_t)s * I;
 #pragma unroll
     for (int c = 0; c < NCK; ++c) {
@@ -53,16 +63,19 @@ __global__ __launch_bounds__(MAX_SLOTS * 64) void moe_down_kernel(const DownArgs
     }
   }
   // ---- ... then ALL weight pieces of this (segment, row block): RW x NCK 16-byte nontemporal loads per lane, one round trip
-  u32x4 wq[RW][NCK];
+  wv wq[RW][NCK];
+  float rs[RW];
   if (live) {
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-      const bf16_t* wr = wbase + (int64_t)min(n0 + r, a.H - 1) * I;
+      const wt* wr = wbase + (int64_t)min(n0 + r, a.H - 1) * I;
 #pragma unroll
       for (int c = 0; c < NCK; ++c) {
         const int k = min(c * 512 + lane * 8, I - 8);        // beyond I the activation registers are zero: any finite weights will do
-        wq[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + k));
+        wq[r][c] = __builtin_nontemporal_load(reinterpret_cast<const wv*>(wr + k));
       }
+      rs[r] = 1.0f;
+      if constexpr (WQ == 1) rs[r] = sbase[min(n0 + r, a.H - 1)];
     }
   }
   // (the epilogue's residual is requested now, behind the weights, and used after the reduction)
@@ -79,12 +92,22 @@ __global__ __launch_bounds__(MAX_SLOTS * 64) void moe_down_kernel(const DownArgs
       for (int e = 0; e < 8; ++e) x[e] = xk[c][e] * sc;       // the router weight rides the activation (as in the K-segment form)
 #pragma unroll
       for (int r = 0; r < RW; ++r) {
-        const u32x4 q = wq[r][c];
         float t = acc[r];
-        t = fmaf(bf16lo_to_f32(q.x), x[0], t); t = fmaf(bf16hi_to_f32(q.x), x[1], t);
-        t = fmaf(bf16lo_to_f32(q.y), x[2], t); t = fmaf(bf16hi_to_f32(q.y), x[3], t);
-        t = fmaf(bf16lo_to_f32(q.z), x[4], t); t = fmaf(bf16hi_to_f32(q.z), x[5], t);
-        t = fmaf(bf16lo_to_f32(q.w), x[6], t); t = fmaf(bf16hi_to_f32(q.w), x[7], t);
+        if constexpr (WQ == 1) {
+          float w0[4], w1[4];
+          fp8x4_to_f32(wq[r][c].x, w0);
+          fp8x4_to_f32(wq[r][c].y, w1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t = fmaf(w0[e], x[e], t);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t = fmaf(w1[e], x[4 + e], t);
+        } else {
+          const u32x4 q = wq[r][c];
+          t = fmaf(bf16lo_to_f32(q.x), x[0], t); t = fmaf(bf16hi_to_f32(q.x), x[1], t);
+          t = fmaf(bf16lo_to_f32(q.y), x[2], t); t = fmaf(bf16hi_to_f32(q.y), x[3], t);
+          t = fmaf(bf16lo_to_f32(q.z), x[4], t); t = fmaf(bf16hi_to_f32(q.z), x[5], t);
+          t = fmaf(bf16lo_to_f32(q.w), x[6], t); t = fmaf(bf16hi_to_f32(q.w), x[7], t);
+        }
         acc[r] = t;
       }
     }
@@ -92,7 +115,7 @@ __global__ __launch_bounds__(MAX_SLOTS * 64) void moe_down_kernel(const DownArgs
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
     const float t = wave_sum(acc[r]);
-    if (lane == 0) part[s][r] = live ? t : 0.f;
+    if (lane == 0) part[s][r] = live ? t * rs[r] : 0.f;       // (rs: the e4m3 row scale, 1 for bf16)
   }
   __syncthreads();
   if (tid < RW && n0 + tid < a.H) {
@@ -104,23 +127,29 @@ __global__ __launch_bounds__(MAX_SLOTS * 64) void moe_down_kernel(const DownArgs
 
 }  // namespace
 
-// Can the down projection of this shape run here?  (bf16 weights; one wave per slot; I in whole 8-element pieces, <= 4 chunks of 512)
+// Can the down projection of this shape run here?  (bf16 or e4m3 weights; one wave per slot; I in whole 8-element pieces, <= 4 chunks of 512)
 bool moe_down_ok(int wfmt, int n_slot, int H, int I) {
-  return wfmt == MN_W_BF16 && n_slot >= 1 && n_slot <= MAX_SLOTS && H >= 1 && I >= 8 && (I % 8) == 0 && I <= 2048;
+  return (wfmt == MN_W_BF16 || wfmt == MN_W_FP8_E4M3) && n_slot >= 1 && n_slot <= MAX_SLOTS && H >= 1 && I >= 8 && (I % 8) == 0 && I <= 2048;
 }
 
-int moe_down_rows(const float* hmid, int64_t ld_hmid, const bf16_t* W, int64_t w_stride, const int32_t* ti, const float* tw, const float* res,
-                  int64_t ld_res, float* out, int64_t ld_out, int batch, int H, int I, int n_slot, void* stream) {
-  MN_CHECK_ARG(hmid && W && ti && tw && out && batch >= 1 && moe_down_ok(MN_W_BF16, n_slot, H, I) && (ld_hmid % 4) == 0 &&
-                   (((uintptr_t)W) & 15) == 0 && (w_stride % 8) == 0, "moe_down_rows: bad args");
-  const DownArgs a{hmid, ld_hmid, W, w_stride, ti, tw, res, ld_res, out, ld_out, H, I, n_slot};
+int moe_down_rows(int wfmt, const float* hmid, int64_t ld_hmid, const void* W, int64_t w_stride, const float* wscale, int64_t wscale_stride,
+                  const int32_t* ti, const float* tw, const float* res, int64_t ld_res, float* out, int64_t ld_out, int batch, int H, int I,
+                  int n_slot, void* stream) {
+  MN_CHECK_ARG(hmid && W && ti && tw && out && batch >= 1 && moe_down_ok(wfmt, n_slot, H, I) && (ld_hmid % 4) == 0 &&
+                   (((uintptr_t)W) & 15) == 0 && (w_stride % 8) == 0 && (wfmt == MN_W_BF16 || wscale), "moe_down_rows: bad args");
+  const DownArgs a{hmid, ld_hmid, W, w_stride, wscale, wscale_stride, ti, tw, res, ld_res, out, ld_out, H, I, n_slot};
   const dim3 grid((unsigned)mn_cdiv(H, RW), (unsigned)batch), block(MAX_SLOTS * 64);
   const int nck = (I + 511) / 512;
   hipStream_t st = mn_stream(stream);
-  if (nck == 1) hipLaunchKernelGGL(moe_down_kernel<1>, grid, block, 0, st, a);
-  else if (nck == 2) hipLaunchKernelGGL(moe_down_kernel<2>, grid, block, 0, st, a);
-  else if (nck == 3) hipLaunchKernelGGL(moe_down_kernel<3>, grid, block, 0, st, a);
-  else hipLaunchKernelGGL(moe_down_kernel<4>, grid, block, 0, st, a);
+#define MN_DOWN(WQ_)                                                                            \
+  do {                                                                                          \
+    if (nck == 1) hipLaunchKernelGGL((moe_down_kernel<1, WQ_>), grid, block, 0, st, a);         \
+    else if (nck == 2) hipLaunchKernelGGL((moe_down_kernel<2, WQ_>), grid, block, 0, st, a);    \
+    else if (nck == 3) hipLaunchKernelGGL((moe_down_kernel<3, WQ_>), grid, block, 0, st, a);    \
+    else hipLaunchKernelGGL((moe_down_kernel<4, WQ_>), grid, block, 0, st, a);                  \
+  } while (0)
+  if (wfmt == MN_W_FP8_E4M3) MN_DOWN(1); else MN_DOWN(0);
+#undef MN_DOWN
   MN_CHECK_LAUNCH("moe_down_rows");
   return MN_OK;
 }

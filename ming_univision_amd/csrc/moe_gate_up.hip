@@ -17,9 +17,13 @@
 // workgroup re-reads the 256 KB of gate rows, 180 MB of L2 traffic for 92 MB of weights.)
 // The logits' per-lane arithmetic and the tie rule (lowest expert id among equal probabilities) are moe_router_row_kernel's
 // (decode_ops.hip); the row's square sum is reduced per wave here, per workgroup there — 1-ulp differences of the logits.
+#include <type_traits>
+
 #include "common.h"
+#include "w8_codec.h"
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -32,12 +36,23 @@ struct GateUpArgs {
   const float* h; int64_t ldh;                       // [batch][H] fp32
   const bf16_t* norm_w; float eps;
   const bf16_t* gate_w;                              // [E][H]
-  const bf16_t* W; int64_t w_stride;                 // [E + S][2 I][H]: gate rows [0, I), up rows [I, 2 I)
+  const void* W; int64_t w_stride;                   // [E + S][2 I][H] bf16 (or e4m3 bytes): gate rows [0, I), up rows [I, 2 I)
+  const float* wscale; int64_t wscale_stride;        // e4m3: one fp32 scale per weight row, [E + S][2 I]
   int H, I, E, top_k, n_shared, norm_topk_prob;
   float* hmid; int64_t ld_hmid;                      // [batch][n_slot * I]
   int32_t* ti; float* tw; float* logits;             // [batch][n_slot], [batch][n_slot], [batch][E]
 };
 
+__device__ __forceinline__ float dot8(const u32x2 q, const float* x, float t) {       // eight e4m3 weights
+  float w0[4], w1[4];
+  fp8x4_to_f32(q.x, w0);
+  fp8x4_to_f32(q.y, w1);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) t = fmaf(w0[e], x[e], t);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) t = fmaf(w1[e], x[4 + e], t);
+  return t;
+}
 __device__ __forceinline__ float dot8(const u32x4 q, const float* x, float t) {
   t = fmaf(bf16lo_to_f32(q.x), x[0], t); t = fmaf(bf16hi_to_f32(q.x), x[1], t);
   t = fmaf(bf16lo_to_f32(q.y), x[2], t); t = fmaf(bf16hi_to_f32(q.y), x[3], t);
@@ -46,7 +61,7 @@ __device__ __forceinline__ float dot8(const u32x4 q, const float* x, float t) {
   return t;
 }
 
-template <int NCK>                                   // H = NCK x 512
+template <int NCK, int WQ>                           // H = NCK x 512; WQ 0: bf16 experts, 1: e4m3 bytes + row scales (applied to the K sums)
 __global__ __launch_bounds__(GU_WAVES * 64) void moe_gate_up_routed_kernel(const GateUpArgs a) {
   __shared__ float lg[64];
   const int tid = threadIdx.x, lane = tid & 63, s = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,17 +78,19 @@ __global__ __launch_bounds__(GU_WAVES * 64) void moe_gate_up_routed_kernel(const
     x[c][0] = lo.x; x[c][1] = lo.y; x[c][2] = lo.z; x[c][3] = lo.w; x[c][4] = hi.x; x[c][5] = hi.y; x[c][6] = hi.z; x[c][7] = hi.w;
     nw[c] = *reinterpret_cast<const u32x4*>(a.norm_w + k);
   }
-  u32x4 wq[UNITS][2][NCK];
+  typedef typename std::conditional<WQ == 1, uint8_t, bf16_t>::type wt;
+  typedef typename std::conditional<WQ == 1, u32x2, u32x4>::type wv;         // 8 weights per lane and piece
+  wv wq[UNITS][2][NCK];
   auto request = [&](int e) {                        // ALL of this wave's expert rows in one round trip
-    const bf16_t* wb = a.W + (int64_t)e * a.w_stride;
+    const wt* wb = static_cast<const wt*>(a.W) + (int64_t)e * a.w_stride;
 #pragma unroll
     for (int u = 0; u < UNITS; ++u) {
       const int i = min(i0 + u, I - 1);
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const bf16_t* wr = wb + ((int64_t)g * I + i) * H;
+        const wt* wr = wb + ((int64_t)g * I + i) * H;
 #pragma unroll
-        for (int c = 0; c < NCK; ++c) wq[u][g][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + c * 512 + lane * 8));
+        for (int c = 0; c < NCK; ++c) wq[u][g][c] = __builtin_nontemporal_load(reinterpret_cast<const wv*>(wr + c * 512 + lane * 8));
       }
     }
   };
@@ -150,33 +167,44 @@ __global__ __launch_bounds__(GU_WAVES * 64) void moe_gate_up_routed_kernel(const
     for (int c = 0; c < NCK; ++c) { g = dot8(wq[u][0][c], x[c], g); up = dot8(wq[u][1][c], x[c], up); }
     g = wave_sum(g);
     up = wave_sum(up);
+    if constexpr (WQ == 1) {
+      const float* sb = a.wscale + (int64_t)slot_e * a.wscale_stride;
+      const int i = min(i0 + u, I - 1);
+      g *= sb[i];
+      up *= sb[I + i];
+    }
     if (lane == 0 && i0 + u < I) a.hmid[(int64_t)b * a.ld_hmid + (int64_t)s * I + i0 + u] = silu_f(g) * up;
   }
 }
 
 }  // namespace
 
-// Can the router + gate/up of this shape run as the one launch?  (bf16 experts, <= 64 routed experts, one wave per slot, the row in registers)
+// Can the router + gate/up of this shape run as the one launch?  (bf16 or e4m3 experts, <= 64 routed experts, one wave per slot, the row in registers)
 bool moe_gate_up_ok(int wfmt, int H, int I, int E, int top_k, int n_shared) {
-  return wfmt == MN_W_BF16 && H >= 512 && H <= 2048 && (H % 512) == 0 && I >= 1 && E >= 1 && E <= 64 && top_k >= 1 && top_k <= E &&
-         top_k + n_shared <= GU_WAVES;
+  return (wfmt == MN_W_BF16 || wfmt == MN_W_FP8_E4M3) && H >= 512 && H <= 2048 && (H % 512) == 0 && I >= 1 && E >= 1 && E <= 64 && top_k >= 1 &&
+         top_k <= E && top_k + n_shared <= GU_WAVES;
 }
 
-int moe_gate_up_routed(const float* h, int64_t ldh, const bf16_t* norm_w, float eps, const bf16_t* gate_w, const bf16_t* W, int64_t w_stride,
-                       int batch, int H, int I, int E, int top_k, int n_shared, int norm_topk_prob, float* hmid, int64_t ld_hmid, int32_t* ti,
-                       float* tw, float* logits, void* stream) {
-  MN_CHECK_ARG(h && norm_w && gate_w && W && hmid && ti && tw && batch >= 1 && moe_gate_up_ok(MN_W_BF16, H, I, E, top_k, n_shared) &&
-                   (ldh % 4) == 0 && (((uintptr_t)W) & 15) == 0 && (((uintptr_t)gate_w) & 15) == 0 && (w_stride % 8) == 0,
-               "moe_gate_up_routed: bad args");
-  const GateUpArgs a{h, ldh, norm_w, eps, gate_w, W, w_stride, H, I, E, top_k, n_shared, norm_topk_prob, hmid, ld_hmid, ti, tw, logits};
+int moe_gate_up_routed(int wfmt, const float* h, int64_t ldh, const bf16_t* norm_w, float eps, const bf16_t* gate_w, const void* W, int64_t w_stride,
+                       const float* wscale, int64_t wscale_stride, int batch, int H, int I, int E, int top_k, int n_shared, int norm_topk_prob,
+                       float* hmid, int64_t ld_hmid, int32_t* ti, float* tw, float* logits, void* stream) {
+  MN_CHECK_ARG(h && norm_w && gate_w && W && hmid && ti && tw && batch >= 1 && moe_gate_up_ok(wfmt, H, I, E, top_k, n_shared) &&
+                   (ldh % 4) == 0 && (((uintptr_t)W) & 15) == 0 && (((uintptr_t)gate_w) & 15) == 0 && (w_stride % 8) == 0 &&
+                   (wfmt == MN_W_BF16 || wscale), "moe_gate_up_routed: bad args");
+  const GateUpArgs a{h, ldh, norm_w, eps, gate_w, W, w_stride, wscale, wscale_stride, H, I, E, top_k, n_shared, norm_topk_prob, hmid, ld_hmid, ti, tw, logits};
   const dim3 grid((unsigned)mn_cdiv(I, UNITS), (unsigned)batch), block(GU_WAVES * 64);
   hipStream_t st = mn_stream(stream);
-  switch (H / 512) {
-    case 1: hipLaunchKernelGGL(moe_gate_up_routed_kernel<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(moe_gate_up_routed_kernel<2>, grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL(moe_gate_up_routed_kernel<3>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(moe_gate_up_routed_kernel<4>, grid, block, 0, st, a); break;
-  }
+#define MN_GU(WQ_)                                                                                          \
+  do {                                                                                                      \
+    switch (H / 512) {                                                                                      \
+      case 1: hipLaunchKernelGGL((moe_gate_up_routed_kernel<1, WQ_>), grid, block, 0, st, a); break;        \
+      case 2: hipLaunchKernelGGL((moe_gate_up_routed_kernel<2, WQ_>), grid, block, 0, st, a); break;        \
+      case 3: hipLaunchKernelGGL((moe_gate_up_routed_kernel<3, WQ_>), grid, block, 0, st, a); break;        \
+      default: hipLaunchKernelGGL((moe_gate_up_routed_kernel<4, WQ_>), grid, block, 0, st, a); break;       \
+    }                                                                                                       \
+  } while (0)
+  if (wfmt == MN_W_FP8_E4M3) MN_GU(1); else MN_GU(0);
+#undef MN_GU
   MN_CHECK_LAUNCH("moe_gate_up_routed");
   return MN_OK;
 }

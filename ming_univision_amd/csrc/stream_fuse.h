@@ -53,14 +53,15 @@ int rf_blocks_persist(int wfmt, float* h, bf16_t* Y3, int M, int w, int hid, con
                       unsigned* bar, unsigned epoch0, const RfSamplerTail* whole, void* stream);
 
 // ---- the MoE down projection of a 1- / 2-row step with the segments spread over the waves of a workgroup (moe_down.hip):
-//   out[b][n] = res[b][n] + sum_s tw[b, s] * hmid[b][s * I ..] . W[ti[b, s]][n][..]      (bf16 weights)
+//   out[b][n] = res[b][n] + sum_s tw[b, s] * hmid[b][s * I ..] . W[ti[b, s]][n][..]      (bf16 weights, or e4m3 bytes + row scales)
 bool moe_down_ok(int wfmt, int n_slot, int H, int I);
-int moe_down_rows(const float* hmid, int64_t ld_hmid, const bf16_t* W, int64_t w_stride, const int32_t* ti, const float* tw, const float* res,
-                  int64_t ld_res, float* out, int64_t ld_out, int batch, int H, int I, int n_slot, void* stream);
+int moe_down_rows(int wfmt, const float* hmid, int64_t ld_hmid, const void* W, int64_t w_stride, const float* wscale, int64_t wscale_stride,
+                  const int32_t* ti, const float* tw, const float* res, int64_t ld_res, float* out, int64_t ld_out, int batch, int H, int I,
+                  int n_slot, void* stream);
 
 // ---- router + expert gate/up of a 1-row decode step in ONE launch (moe_gate_up.hip): every workgroup routes its row itself, wave s
 // streams hidden units of the slot-s expert.  Writes hmid [batch][n_slot * I], and (one workgroup per row) ti / tw / logits.
 bool moe_gate_up_ok(int wfmt, int H, int I, int E, int top_k, int n_shared);
-int moe_gate_up_routed(const float* h, int64_t ldh, const bf16_t* norm_w, float eps, const bf16_t* gate_w, const bf16_t* W, int64_t w_stride,
-                       int batch, int H, int I, int E, int top_k, int n_shared, int norm_topk_prob, float* hmid, int64_t ld_hmid, int32_t* ti,
-                       float* tw, float* logits, void* stream);
+int moe_gate_up_routed(int wfmt, const float* h, int64_t ldh, const bf16_t* norm_w, float eps, const bf16_t* gate_w, const void* W, int64_t w_stride,
+                       const float* wscale, int64_t wscale_stride, int batch, int H, int I, int E, int top_k, int n_shared, int norm_topk_prob,
+                       float* hmid, int64_t ld_hmid, int32_t* ti, float* tw, float* logits, void* stream);
