@@ -1271,7 +1271,7 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
         if (m->wfmt) { a.wfmt = m->wfmt; a.wscale = m->w_gate_up_scale[l]; a.wscale_batch_stride = 2 * I; a.ws = nullptr; }
         MN_TRY(mn_skinny_gemm(&a, stream));
         if (g_moe_down && moe_down_ok(m->wfmt, n_slot, H, I)) {      // segments over the waves: one HBM round trip (moe_down.hip)
-          MN_TRY(moe_down_rows(m->wfmt, w.hmid, (int64_t)n_slot * I, m->w_down[l], (int64_t)H * I, m->wfmt ? m->w_down_scale[l] : nullptr, (int64_t)H, w.ti, w.tw, w.h, H, w.h, H, M, H, I, n_slot, stream));
+          MN_TRY(moe_down_rows(m->wfmt, w.hmid, (int64_t)n_slot * I, m->w_down[l], (int64_t)H * I, m->wfmt ? m->w_down_scale[l] : nullptr, (int64_t)H * mn_wq_scales_per_row(m->wfmt, I), w.ti, w.tw, w.h, H, w.h, H, M, H, I, n_slot, stream));
           continue;
         }
         a = sk(w.hmid, (int64_t)n_slot * I, m->w_down[l], I, nullptr, w.h, H, 1, H, I);
@@ -1310,13 +1310,14 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
     a = sk(w.attn, nq * hd, m->wdense[l], nq * hd, nullptr, w.h, H, M, H, nq * hd);
     a.epilogue = MN_EPI_RESID; a.res = w.h; a.ldres = H;
     MN_TRY(mn_skinny_gemm(&a, stream));
-    // one row on bf16 experts: RMSNorm + router + the selected experts' gate/up in ONE launch (moe_gate_up.hip), then the down projection
-    if (g_moe_gate_up && M <= g_moe_gate_up_rows && !(image_mask && m->image_gate) && !moe_mfma_ok(m, M) && g_moe_down &&
+    // one row: RMSNorm + router + the selected experts' gate/up in ONE launch (moe_gate_up.hip), then the down projection (moe_down.hip) — every
+    // weight format (int8 / NF4 decode per element like the grouped MFMA launch they replace here: text decode int8 434 -> 699, int4 426 -> 619 tokens/s)
+    if (g_moe_gate_up && M <= g_moe_gate_up_rows && !(image_mask && m->image_gate) && g_moe_down &&
         moe_gate_up_ok(m->wfmt, H, I, m->n_experts, m->top_k, m->n_shared_slots) && moe_down_ok(m->wfmt, n_slot, H, I)) {
       MN_TRY(moe_gate_up_routed(m->wfmt, w.h, H, m->ln2[l], m->rms_eps, m->gate[l], m->w_gate_up[l], (int64_t)2 * I * H,
-                                m->wfmt ? m->w_gate_up_scale[l] : nullptr, (int64_t)2 * I, M, H, I, m->n_experts, m->top_k,
+                                m->wfmt ? m->w_gate_up_scale[l] : nullptr, (int64_t)2 * I * mn_wq_scales_per_row(m->wfmt, H), M, H, I, m->n_experts, m->top_k,
                                 m->n_shared_slots, m->norm_topk_prob, w.hmid, (int64_t)n_slot * I, w.ti, w.tw, w.logits, stream));
-      MN_TRY(moe_down_rows(m->wfmt, w.hmid, (int64_t)n_slot * I, m->w_down[l], (int64_t)H * I, m->wfmt ? m->w_down_scale[l] : nullptr, (int64_t)H, w.ti, w.tw, w.h, H, w.h, H, M, H, I, n_slot, stream));
+      MN_TRY(moe_down_rows(m->wfmt, w.hmid, (int64_t)n_slot * I, m->w_down[l], (int64_t)H * I, m->wfmt ? m->w_down_scale[l] : nullptr, (int64_t)H * mn_wq_scales_per_row(m->wfmt, I), w.ti, w.tw, w.h, H, w.h, H, M, H, I, n_slot, stream));
       continue;
     }
     // MoE: RMSNorm + router -> grouped expert gate/up (SwiGLU) -> grouped down + weighted sum + residual (:1218-1225, :556-639)
@@ -1346,7 +1347,7 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
     if (m->wfmt) { a.wfmt = m->wfmt; a.wscale = m->w_gate_up_scale[l]; a.wscale_batch_stride = 2 * I; a.ws = nullptr; }
     MN_TRY(mn_skinny_gemm(&a, stream));
     if (g_moe_down && moe_down_ok(m->wfmt, n_slot, H, I)) {          // segments over the waves: one HBM round trip (moe_down.hip)
-      MN_TRY(moe_down_rows(m->wfmt, w.hmid, (int64_t)n_slot * I, m->w_down[l], (int64_t)H * I, m->wfmt ? m->w_down_scale[l] : nullptr, (int64_t)H, w.ti, w.tw, w.h, H, w.h, H, M, H, I, n_slot, stream));
+      MN_TRY(moe_down_rows(m->wfmt, w.hmid, (int64_t)n_slot * I, m->w_down[l], (int64_t)H * I, m->wfmt ? m->w_down_scale[l] : nullptr, (int64_t)H * mn_wq_scales_per_row(m->wfmt, I), w.ti, w.tw, w.h, H, w.h, H, M, H, I, n_slot, stream));
       continue;
     }
     a = sk(w.hmid, (int64_t)n_slot * I, m->w_down[l], I, nullptr, w.h, H, 1, H, I);

@@ -27,14 +27,14 @@ constexpr int MAX_SLOTS = 8;         // segments = waves per workgroup
 struct DownArgs {
   const float* hmid; int64_t ld_hmid;               // [batch][n_slot * I] fp32
   const void* W; int64_t w_stride;                  // [E + S][H][I] bf16 (or e4m3 bytes), elements between experts
-  const float* wscale; int64_t wscale_stride;       // e4m3: one fp32 scale per output row, [E + S][H]
+  const float* wscale; int64_t wscale_stride;       // e4m3 / int8: one fp32 scale per output row, [E + S][H]; NF4: one absmax per 64 k, [E + S][H][I / 64]
   const int32_t* ti; const float* tw;               // [batch][n_slot]
   const float* res; int64_t ld_res;                 // [batch][H]
   float* out; int64_t ld_out;
   int H, I, n_slot;
 };
 
-template <int NCK, int WQ>                          // WQ 0: bf16 weights, 1: e4m3 bytes + row scales (applied to the K sums)
+template <int NCK, int WQ>                          // WQ 0: bf16 weights, 1: e4m3 bytes + row scales (on the K sums), 2: int8 (quanto), 3: NF4
 __global__ __launch_bounds__(MAX_SLOTS * 64) void moe_down_kernel(const DownArgs a) {
   __shared__ float part[MAX_SLOTS][RW];
   const int tid = threadIdx.x, lane = tid & 63, s = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -43,15 +43,16 @@ __global__ __launch_bounds__(MAX_SLOTS * 64) void moe_down_kernel(const DownArgs
   // ---- this wave's slice of the activation first (loads retire in order: it lands before the weights) ...
   float xk[NCK][8];
   float sc = 0.f;
-  typedef typename std::conditional<WQ == 1, uint8_t, bf16_t>::type wt;
-  typedef typename std::conditional<WQ == 1, u32x2, u32x4>::type wv;        // 8 weights per lane and piece
-  const wt* wbase = static_cast<const wt*>(a.W);
+  // a piece = this lane's 8 consecutive weights of one row and chunk: 16 bytes of bf16, 8 of e4m3 / int8, 4 of NF4 codes
+  typedef typename std::conditional<WQ == 0, u32x4, typename std::conditional<WQ == 3, uint32_t, u32x2>::type>::type wv;
+  constexpr int BPP = WQ == 0 ? 16 : (WQ == 3 ? 4 : 8);
+  const uint8_t* wbase = static_cast<const uint8_t*>(a.W);
   const float* sbase = a.wscale;
   if (live) {
     sc = a.tw[(int64_t)b * a.n_slot + s];
     const int e = a.ti[(int64_t)b * a.n_slot + s];
-    wbase += (int64_t)e * a.w_stride;
-    if constexpr (WQ == 1) sbase += (int64_t)e * a.wscale_stride;
+    wbase += ((int64_t)e * a.w_stride >> 3) * BPP;
+    if constexpr (WQ != 0) sbase += (int64_t)e * a.wscale_stride;
     const float* xp = a.hmid + (int64_t)b * a.ld_hmid + (int64_t)s * I;
 #pragma unroll
     for (int c = 0; c < NCK; ++c) {
@@ -64,18 +65,20 @@ __global__ __launch_bounds__(MAX_SLOTS * 64) void moe_down_kernel(const DownArgs
   }
   // ---- ... then ALL weight pieces of this (segment, row block): RW x NCK 16-byte nontemporal loads per lane, one round trip
   wv wq[RW][NCK];
-  float rs[RW];
+  float rs[RW][WQ == 3 ? NCK : 1];                    // e4m3 / int8: the row's scale; NF4: the absmax of the piece's 64-block
   if (live) {
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-      const wt* wr = wbase + (int64_t)min(n0 + r, a.H - 1) * I;
+      const int64_t row = min(n0 + r, a.H - 1);
+      const uint8_t* wr = wbase + ((row * I) >> 3) * BPP;
 #pragma unroll
       for (int c = 0; c < NCK; ++c) {
         const int k = min(c * 512 + lane * 8, I - 8);        // beyond I the activation registers are zero: any finite weights will do
-        wq[r][c] = __builtin_nontemporal_load(reinterpret_cast<const wv*>(wr + k));
+        wq[r][c] = __builtin_nontemporal_load(reinterpret_cast<const wv*>(wr + (k >> 3) * BPP));
+        if constexpr (WQ == 3) rs[r][c] = sbase[row * (I >> 6) + (k >> 6)];
       }
-      rs[r] = 1.0f;
-      if constexpr (WQ == 1) rs[r] = sbase[min(n0 + r, a.H - 1)];
+      if constexpr (WQ == 0) rs[r][0] = 1.0f;
+      else if constexpr (WQ != 3) rs[r][0] = sbase[row];
     }
   }
   // (the epilogue's residual is requested now, behind the weights, and used after the reduction)
@@ -93,7 +96,15 @@ __global__ __launch_bounds__(MAX_SLOTS * 64) void moe_down_kernel(const DownArgs
 #pragma unroll
       for (int r = 0; r < RW; ++r) {
         float t = acc[r];
-        if constexpr (WQ == 1) {
+        if constexpr (WQ >= 2) {                          // int8: bf16(q * scale), NF4: bf16(NF4[code] * absmax) — rounded per element (w8_codec.h)
+          u32x4 q;
+          if constexpr (WQ == 2) q = w8x8_to_bf16<true>(wq[r][c].x, wq[r][c].y, rs[r][0]);
+          else q = nf4x8_to_bf16(nf4_table(rs[r][c]), wq[r][c]);
+          t = fmaf(bf16lo_to_f32(q.x), x[0], t); t = fmaf(bf16hi_to_f32(q.x), x[1], t);
+          t = fmaf(bf16lo_to_f32(q.y), x[2], t); t = fmaf(bf16hi_to_f32(q.y), x[3], t);
+          t = fmaf(bf16lo_to_f32(q.z), x[4], t); t = fmaf(bf16hi_to_f32(q.z), x[5], t);
+          t = fmaf(bf16lo_to_f32(q.w), x[6], t); t = fmaf(bf16hi_to_f32(q.w), x[7], t);
+        } else if constexpr (WQ == 1) {
           float w0[4], w1[4];
           fp8x4_to_f32(wq[r][c].x, w0);
           fp8x4_to_f32(wq[r][c].y, w1);
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(MAX_SLOTS * 64) void moe_down_kernel(const DownArgs
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
     const float t = wave_sum(acc[r]);
-    if (lane == 0) part[s][r] = live ? t * rs[r] : 0.f;       // (rs: the e4m3 row scale, 1 for bf16)
+    if (lane == 0) part[s][r] = live ? (WQ == 1 ? t * rs[r][0] : t) : 0.f;       // (e4m3: the row scale on the sum)
   }
   __syncthreads();
   if (tid < RW && n0 + tid < a.H) {
@@ -127,9 +138,10 @@ __global__ __launch_bounds__(MAX_SLOTS * 64) void moe_down_kernel(const DownArgs
 
 }  // namespace
 
-// Can the down projection of this shape run here?  (bf16 or e4m3 weights; one wave per slot; I in whole 8-element pieces, <= 4 chunks of 512)
+// Can the down projection of this shape run here?  (bf16, e4m3, int8 or NF4 weights; one wave per slot; I in whole 8-element pieces, <= 4 chunks of 512)
 bool moe_down_ok(int wfmt, int n_slot, int H, int I) {
-  return (wfmt == MN_W_BF16 || wfmt == MN_W_FP8_E4M3) && n_slot >= 1 && n_slot <= MAX_SLOTS && H >= 1 && I >= 8 && (I % 8) == 0 && I <= 2048;
+  return (wfmt == MN_W_BF16 || wfmt == MN_W_FP8_E4M3 || wfmt == MN_W_INT8 || (wfmt == MN_W_NF4 && (I % 64) == 0)) && n_slot >= 1 &&
+         n_slot <= MAX_SLOTS && H >= 1 && I >= 8 && (I % 8) == 0 && I <= 2048;
 }
 
 int moe_down_rows(int wfmt, const float* hmid, int64_t ld_hmid, const void* W, int64_t w_stride, const float* wscale, int64_t wscale_stride,
@@ -148,7 +160,7 @@ int moe_down_rows(int wfmt, const float* hmid, int64_t ld_hmid, const void* W, i
     else if (nck == 3) hipLaunchKernelGGL((moe_down_kernel<3, WQ_>), grid, block, 0, st, a);    \
     else hipLaunchKernelGGL((moe_down_kernel<4, WQ_>), grid, block, 0, st, a);                  \
   } while (0)
-  if (wfmt == MN_W_FP8_E4M3) MN_DOWN(1); else MN_DOWN(0);
+  if (wfmt == MN_W_FP8_E4M3) MN_DOWN(1); else if (wfmt == MN_W_INT8) MN_DOWN(2); else if (wfmt == MN_W_NF4) MN_DOWN(3); else MN_DOWN(0);
 #undef MN_DOWN
   MN_CHECK_LAUNCH("moe_down_rows");
   return MN_OK;

@@ -37,7 +37,7 @@ struct GateUpArgs {
   const bf16_t* norm_w; float eps;
   const bf16_t* gate_w;                              // [E][H]
   const void* W; int64_t w_stride;                   // [E + S][2 I][H] bf16 (or e4m3 bytes): gate rows [0, I), up rows [I, 2 I)
-  const float* wscale; int64_t wscale_stride;        // e4m3: one fp32 scale per weight row, [E + S][2 I]
+  const float* wscale; int64_t wscale_stride;        // e4m3 / int8: one fp32 scale per weight row, [E + S][2 I]; NF4: one absmax per 64 k, [E + S][2 I][H / 64]
   int H, I, E, top_k, n_shared, norm_topk_prob;
   float* hmid; int64_t ld_hmid;                      // [batch][n_slot * I]
   int32_t* ti; float* tw; float* logits;             // [batch][n_slot], [batch][n_slot], [batch][E]
@@ -61,7 +61,7 @@ __device__ __forceinline__ float dot8(const u32x4 q, const float* x, float t) {
   return t;
 }
 
-template <int NCK, int WQ>                           // H = NCK x 512; WQ 0: bf16 experts, 1: e4m3 bytes + row scales (applied to the K sums)
+template <int NCK, int WQ>                           // H = NCK x 512; WQ 0: bf16 experts, 1: e4m3 bytes + row scales (on the K sums), 2: int8 (quanto), 3: NF4 (w8_codec.h)
 __global__ __launch_bounds__(GU_WAVES * 64) void moe_gate_up_routed_kernel(const GateUpArgs a) {
   __shared__ float lg[64];
   const int tid = threadIdx.x, lane = tid & 63, s = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -78,21 +78,37 @@ __global__ __launch_bounds__(GU_WAVES * 64) void moe_gate_up_routed_kernel(const
     x[c][0] = lo.x; x[c][1] = lo.y; x[c][2] = lo.z; x[c][3] = lo.w; x[c][4] = hi.x; x[c][5] = hi.y; x[c][6] = hi.z; x[c][7] = hi.w;
     nw[c] = *reinterpret_cast<const u32x4*>(a.norm_w + k);
   }
-  typedef typename std::conditional<WQ == 1, uint8_t, bf16_t>::type wt;
-  typedef typename std::conditional<WQ == 1, u32x2, u32x4>::type wv;         // 8 weights per lane and piece
+  // a piece = this lane's 8 consecutive weights of one row and chunk: 16 bytes of bf16, 8 of e4m3 / int8, 4 of NF4 codes
+  typedef typename std::conditional<WQ == 0, u32x4, typename std::conditional<WQ == 3, uint32_t, u32x2>::type>::type wv;
+  constexpr int BPP = WQ == 0 ? 16 : (WQ == 3 ? 4 : 8);
   wv wq[UNITS][2][NCK];
+  float wsc[UNITS][2][WQ == 3 ? NCK : 1];             // int8: the row's scale; NF4: the absmax of the piece's 64-block; e4m3: the row scale (used on the sums)
   auto request = [&](int e) {                        // ALL of this wave's expert rows in one round trip
-    const wt* wb = static_cast<const wt*>(a.W) + (int64_t)e * a.w_stride;
+    const uint8_t* wb = static_cast<const uint8_t*>(a.W) + ((int64_t)e * a.w_stride >> 3) * BPP;
+    const float* sb = WQ ? a.wscale + (int64_t)e * a.wscale_stride : nullptr;
 #pragma unroll
     for (int u = 0; u < UNITS; ++u) {
       const int i = min(i0 + u, I - 1);
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const wt* wr = wb + ((int64_t)g * I + i) * H;
+        const int64_t row = (int64_t)g * I + i;
+        const uint8_t* wr = wb + ((row * H) >> 3) * BPP;
 #pragma unroll
-        for (int c = 0; c < NCK; ++c) wq[u][g][c] = __builtin_nontemporal_load(reinterpret_cast<const wv*>(wr + c * 512 + lane * 8));
+        for (int c = 0; c < NCK; ++c) wq[u][g][c] = __builtin_nontemporal_load(reinterpret_cast<const wv*>(wr + (c * 64 + lane) * BPP));
+        if constexpr (WQ == 3) {
+#pragma unroll
+          for (int c = 0; c < NCK; ++c) wsc[u][g][c] = sb[row * (H >> 6) + c * 8 + (lane >> 3)];
+        } else if constexpr (WQ != 0) {
+          wsc[u][g][0] = sb[row];
+        }
       }
     }
+  };
+  auto dot_piece = [&](const wv& q, float sc, const float* xx, float t) {
+    if constexpr (WQ == 0) return dot8(q, xx, t);
+    else if constexpr (WQ == 1) return dot8(q, xx, t);                                  // e4m3 values; the row scale multiplies the sum
+    else if constexpr (WQ == 2) return dot8(w8x8_to_bf16<true>(q.x, q.y, sc), xx, t);      // bf16(q * scale) per element (quanto)
+    else return dot8(nf4x8_to_bf16(nf4_table(sc), q), xx, t);                            // bf16(NF4[code] * absmax) per element (bitsandbytes)
   };
   // ---- RMSNorm: the wave reduces the square sum of the row on its own (same value in every wave)
   float ss = 0.f;
@@ -164,25 +180,23 @@ __global__ __launch_bounds__(GU_WAVES * 64) void moe_gate_up_routed_kernel(const
   for (int u = 0; u < UNITS; ++u) {
     float g = 0.f, up = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCK; ++c) { g = dot8(wq[u][0][c], x[c], g); up = dot8(wq[u][1][c], x[c], up); }
+    for (int c = 0; c < NCK; ++c) {
+      g = dot_piece(wq[u][0][c], wsc[u][0][WQ == 3 ? c : 0], x[c], g);
+      up = dot_piece(wq[u][1][c], wsc[u][1][WQ == 3 ? c : 0], x[c], up);
+    }
     g = wave_sum(g);
     up = wave_sum(up);
-    if constexpr (WQ == 1) {
-      const float* sb = a.wscale + (int64_t)slot_e * a.wscale_stride;
-      const int i = min(i0 + u, I - 1);
-      g *= sb[i];
-      up *= sb[I + i];
-    }
+    if constexpr (WQ == 1) { g *= wsc[u][0][0]; up *= wsc[u][1][0]; }
     if (lane == 0 && i0 + u < I) a.hmid[(int64_t)b * a.ld_hmid + (int64_t)s * I + i0 + u] = silu_f(g) * up;
   }
 }
 
 }  // namespace
 
-// Can the router + gate/up of this shape run as the one launch?  (bf16 or e4m3 experts, <= 64 routed experts, one wave per slot, the row in registers)
+// Can the router + gate/up of this shape run as the one launch?  (bf16, e4m3, int8 or NF4 experts, <= 64 routed experts, one wave per slot, the row in registers)
 bool moe_gate_up_ok(int wfmt, int H, int I, int E, int top_k, int n_shared) {
-  return (wfmt == MN_W_BF16 || wfmt == MN_W_FP8_E4M3) && H >= 512 && H <= 2048 && (H % 512) == 0 && I >= 1 && E >= 1 && E <= 64 && top_k >= 1 &&
-         top_k <= E && top_k + n_shared <= GU_WAVES;
+  return (wfmt == MN_W_BF16 || wfmt == MN_W_FP8_E4M3 || wfmt == MN_W_INT8 || wfmt == MN_W_NF4) && H >= 512 && H <= 2048 && (H % 512) == 0 &&
+         I >= 1 && E >= 1 && E <= 64 && top_k >= 1 && top_k <= E && top_k + n_shared <= GU_WAVES;
 }
 
 int moe_gate_up_routed(int wfmt, const float* h, int64_t ldh, const bf16_t* norm_w, float eps, const bf16_t* gate_w, const void* W, int64_t w_stride,
@@ -203,7 +217,7 @@ int moe_gate_up_routed(int wfmt, const float* h, int64_t ldh, const bf16_t* norm
       default: hipLaunchKernelGGL((moe_gate_up_routed_kernel<4, WQ_>), grid, block, 0, st, a); break;       \
     }                                                                                                       \
   } while (0)
-  if (wfmt == MN_W_FP8_E4M3) MN_GU(1); else MN_GU(0);
+  if (wfmt == MN_W_FP8_E4M3) MN_GU(1); else if (wfmt == MN_W_INT8) MN_GU(2); else if (wfmt == MN_W_NF4) MN_GU(3); else MN_GU(0);
 #undef MN_GU
   MN_CHECK_LAUNCH("moe_gate_up_routed");
   return MN_OK;
