@@ -311,6 +311,8 @@ class BailingMoeDecoder:
         if out is None:
             out = torch.empty(M, self.cfg.hidden_size, dtype=torch.float32, device=self.device)
         ws = self._workspace(M)
+        if spans is not None and M <= MAX_ROWS:
+            spans = None                                  # <= 64 rows: the span table is not read (no wide route) — skip its blocking host-to-device copy
         if spans is not None:
             assert key_mask is None and x_row_div == 1 and x.shape[0] == M and not distinct_sequences
             assert sum(n for _, _, n, _ in spans) == M and all(p + n <= self.t_max for _, _, n, p in spans)

@@ -180,26 +180,24 @@ __device__ __forceinline__ WStream w12_stream(const W12Args& a, int vb, int wave
 }
 
 // Persistent form, before the barrier wait: chunk 0 of the wave's NEXT stream into its LDS tile `wbuf` (the workgroup's previous phase
-// is over: LDS is free), chunks 1 .. RD requested — what crosses the barrier in flight.  nx != NULL: chunk 0 was requested into *nx while
-// the previous phase's stream ran out (the bodies' nx / next arguments).
+// is over: LDS is free), chunks 1 .. RD requested — what crosses the barrier in flight.
 template <int WQ, int RD>
-__device__ __forceinline__ void prefetch(const WStream& st, char* wbuf, Chunk<WQ>* nx, Chunk<WQ> (&ring)[RD], int lane) {
+__device__ __forceinline__ void prefetch(const WStream& st, char* wbuf, Chunk<WQ> (&ring)[RD], int lane) {
   if (!st.live) return;
   // chunk 0 and the ring are requested TOGETHER (one memory round trip, not two dependent ones) and chunk 0 is parked when it lands, the
   // ring still in flight: sampler call 6.22 -> 6.16 ms bf16, 4.97 -> 4.84 e4m3, 5.17 -> 5.18 NF4 (profiles/r05_rf_persist_ab.txt)
   Chunk<WQ> c0;
-  if (!nx) issue<WQ>(c0, st, 0, lane);
+  issue<WQ>(c0, st, 0, lane);
 #pragma unroll
   for (int d = 0; d < RD; ++d)
     if (1 + d < st.nch) issue<WQ>(ring[d], st, 1 + d, lane);
-  park<WQ>(nx ? *nx : c0, wbuf, lane, st.wf, st.wscale, st.n0, st.Ntot);
+  park<WQ>(c0, wbuf, lane, st.wf, st.wscale, st.n0, st.Ntot);
 }
 
 // The body of workgroup `vb` of w12' (PRE, the persistent form: chunk 0 is parked, the ring holds chunks 1 .. RD, and the data other
 // workgroups produced is read / written coherently).
 template <int WQ, int MR, int RD, int NW, bool PRE>
-__device__ __forceinline__ void w12_body(const W12Args& a, char* lds, int vb, Chunk<WQ> (&ring)[RD], uint64_t* tr = nullptr,
-                                         Chunk<WQ>* nx = nullptr, const WStream* next = nullptr) {
+__device__ __forceinline__ void w12_body(const W12Args& a, char* lds, int vb, Chunk<WQ> (&ring)[RD], uint64_t* tr = nullptr) {
   constexpr int KS = NW / 4;
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef uint32_t u2 __attribute__((ext_vector_type(2)));
@@ -317,7 +315,6 @@ __device__ __forceinline__ void w12_body(const W12Args& a, char* lds, int vb, Ch
   stamp(tr, 1);
   // ---- stream this wave's K-half of its tile: RD chunks in flight
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  bool nx_todo = PRE && next && next->live;            // the next phase's chunk 0: requested as soon as this stream has no chunk left to request
   if (live) {
     if constexpr (PRE) mma_chunk<WQ>(acc, wbuf, xs, xstride, M, kbeg, lane);       // chunk 0 was parked before the barrier; the ring holds 1 ..
     for (int c = PRE ? 1 : 0; c < nch; c += RD) {
@@ -326,13 +323,11 @@ __device__ __forceinline__ void w12_body(const W12Args& a, char* lds, int vb, Ch
         if (c + d < nch) {
           park<WQ>(ring[d], wbuf, lane, a.wf, a.wscale, n0, Ntot);
           if (c + d + RD < nch) issue<WQ>(ring[d], a.W, a.wscale, n0, Ntot, K, kbeg + (c + d + RD) * WCH, lane);
-          else if (nx_todo) { issue<WQ>(*nx, *next, 0, lane); nx_todo = false; }
           mma_chunk<WQ>(acc, wbuf, xs, xstride, M, kbeg + (c + d) * WCH, lane);
         }
       }
     }
   }
-  if (nx_todo) issue<WQ>(*nx, *next, 0, lane);
   // ---- the K-halves meet in LDS: lane (fr, fq = 0) holds rows 0..3 of column fr
   if ((lane >> 4) == 0) {
     float rs = 1.0f;
@@ -401,8 +396,7 @@ __device__ __forceinline__ WStream w3_stream(const W3Args& a, int vb, int wave, 
 
 // The body of workgroup `vb` (one 16-column tile) of w3' (PRE: as in w12_body).
 template <int WQ, int RD, bool PRE>
-__device__ __forceinline__ void w3_body(const W3Args& a, char* lds, int vb, Chunk<WQ> (&ring)[RD], uint64_t* tr = nullptr,
-                                        Chunk<WQ>* nx = nullptr, const WStream* next = nullptr) {
+__device__ __forceinline__ void w3_body(const W3Args& a, char* lds, int vb, Chunk<WQ> (&ring)[RD], uint64_t* tr = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int M = a.M, K = a.hid, Ntot = a.w;
   const int xstride = K * 2 + 64;
@@ -446,7 +440,6 @@ __device__ __forceinline__ void w3_body(const W3Args& a, char* lds, int vb, Chun
   __syncthreads();
   stamp(tr, 1);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  bool nx_todo = PRE && next && next->live;
   if constexpr (PRE) mma_chunk<WQ>(acc, wbuf, xs, xstride, M, kbeg, lane);
   for (int c = PRE ? 1 : 0; c < nch; c += RD) {
 #pragma unroll
@@ -454,12 +447,10 @@ __device__ __forceinline__ void w3_body(const W3Args& a, char* lds, int vb, Chun
       if (c + d < nch) {
         park<WQ>(ring[d], wbuf, lane, a.wf, a.wscale, n0, Ntot);
         if (c + d + RD < nch) issue<WQ>(ring[d], a.W, a.wscale, n0, Ntot, K, kbeg + (c + d + RD) * WCH, lane);
-        else if (nx_todo) { issue<WQ>(*nx, *next, 0, lane); nx_todo = false; }
         mma_chunk<WQ>(acc, wbuf, xs, xstride, M, kbeg + (c + d) * WCH, lane);
       }
     }
   }
-  if (nx_todo) issue<WQ>(*nx, *next, 0, lane);
   if ((lane >> 4) == 0) {
 #pragma unroll
     for (int r = 0; r < KC_MAX_M; ++r) red[(wave * KC_MAX_M + r) * 16 + (lane & 15)] = acc[r];
@@ -691,7 +682,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const 
   const int vb = blockIdx.x, n12 = (p.hid + 31) / 32, n3 = (p.w + 15) / 16;
   GridBar gb{p.bar, gridDim.x, p.epoch0, p.wait_ticks, 0};
   // ONE register ring for both phases (w12' keeps one chunk in flight, w3' RD3).  Requesting the next phase's chunk 0 EARLY — while
-  // this phase's stream runs out: the bodies' nx / next arguments — measured slower (its traffic delays the workgroups still streaming,
+  // this phase's stream runs out — measured slower (its traffic delays the workgroups still streaming,
   // and 32 more live registers spill; profiles/README.md r05): chunk 0 is requested after the arrival.
   Chunk<WQ> r3[RD3];
   Chunk<WQ> (&r12)[1] = *reinterpret_cast<Chunk<WQ> (*)[1]>(&r3[0]);
@@ -708,7 +699,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const 
   const int nsteps = whole ? p.steps : 1;
   W12Args a12 = args12(p.mod, 0);
   WStream s12 = w12_stream<KC_WAVES>(a12, vb, wave, vb < n12);
-  prefetch<WQ, 1>(s12, wbuf12, nullptr, r12, lane);      // (neither light phase touches the weight tiles or the ring)
+  prefetch<WQ, 1>(s12, wbuf12, r12, lane);      // (neither light phase touches the weight tiles or the ring)
   __syncthreads();
   uint64_t* tr = !whole && p.trace ? p.trace + (size_t)vb * 2 * p.nblk * 8 : nullptr;
   for (int s = 0; s < nsteps; ++s) {
@@ -726,7 +717,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const 
     stamp(tr, 3);
     gb.arrive();
     stamp(tr, 4);
-    prefetch<WQ, RD3>(s3, wbuf3, nullptr, r3, lane);
+    prefetch<WQ, RD3>(s3, wbuf3, r3, lane);
     stamp(tr, 5);
     gb.wait();
     stamp(tr, 6);
@@ -743,7 +734,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const 
     if (more || whole) {
       gb.arrive();
       stamp(tr, 4);
-      prefetch<WQ, 1>(s12, wbuf12, nullptr, r12, lane);
+      prefetch<WQ, 1>(s12, wbuf12, r12, lane);
       stamp(tr, 5);
       gb.wait();
       stamp(tr, 6);

@@ -9,6 +9,7 @@ import bench
 from ming_univision_amd._lib import lib
 L = lib()
 L.mn_llm_tune_chain.argtypes = [ctypes.c_int]; L.mn_llm_tune_chain.restype = None
+L.mn_moe_tune_gate_up.argtypes = [ctypes.c_int, ctypes.c_int]; L.mn_moe_tune_gate_up.restype = None
 dev = torch.device("cuda", 0)
 weights = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 args = argparse.Namespace(tiny=False, tokens=256, layers=None, prompt_len=40, images=1, cfg_rows=2, weights="bf16")
@@ -23,8 +24,9 @@ for rows in (2, 3, 4):
     def run(): return small.step(x, seq, slot, slot, slot + 1, distinct_sequences=True)
     res = {}
     for rnd in range(3):
-        for mx in (32, 32 | (1 << 16), 1):
-            L.mn_llm_tune_chain(mx)
+        for mx in (32, 32 | (1 << 16), 1, 2):
+            L.mn_llm_tune_chain(1 if mx == 2 else mx)
+            L.mn_moe_tune_gate_up(1, 4 if mx == 2 else 1)      # arm 2: the fp32-FMA sequence with the one-launch router + gate/up at every row count
             run(); torch.cuda.synchronize()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -36,5 +38,7 @@ for rows in (2, 3, 4):
     d2 = (res[32][0][1] - old[0][1]).abs().max().item() / res[32][0][1].abs().max().item()
     print(f"{weights} {rows} rows: chain with glue + gate launch + top-k launch {min(t for t, _ in old):.3f} ms ({', '.join('%.3f' % t for t, _ in old)}), differs by {d2:.1e}; "
           f"chain with the one-launch router {min(t for t, _ in res[32]):.3f} ms ({', '.join('%.3f' % t for t, _ in res[32])}); "
-          f"fp32-FMA sequence {min(t for t, _ in res[1]):.3f} ms ({', '.join('%.3f' % t for t, _ in res[1])}); hidden states differ by {d:.1e}", flush=True)
+          f"fp32-FMA sequence {min(t for t, _ in res[1]):.3f} ms ({', '.join('%.3f' % t for t, _ in res[1])}); "
+          f"fp32-FMA sequence with the one-launch router + gate/up {min(t for t, _ in res[2]):.3f} ms ({', '.join('%.3f' % t for t, _ in res[2])}); hidden states differ by {d:.1e}", flush=True)
 L.mn_llm_tune_chain(32)
+L.mn_moe_tune_gate_up(1, 1)
