@@ -18,6 +18,7 @@
 // Two launches per ResBlock, no slabs, no glue.  Weight bytes, MFMA work and per-wave streaming (6 / 4 chunks of 8 KiB per wave; one /
 // two chunks in flight: deeper rings measured slower, as in the K-slice kernel) are those of the K-slice form; all four weight formats (bf16, e4m3, int8, NF4: w8_codec.h) are template instances.
 // Rows >= M of the MFMA's 16-row operand carry copies of the real rows: output rows are independent, the copies' results are never stored.
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 
@@ -789,6 +790,10 @@ bool rf_kc_ok(int wfmt, int M, int w, int hid) {
 // Can the whole block chain of a step run as one persistent launch?  K-complete shapes whose phases fit one workgroup per CU.
 bool rf_persist_ok(int wfmt, int M, int w, int hid, void* stream) {
   if (!rf_kc_ok(wfmt, M, w, hid)) return false;
+  // MINGNATIVE_RF_PERSIST=0 keeps the launches: a persistent grid needs every CU of the device for itself (two PROCESSES sharing one GPU
+  // could hold each other's CUs until the barrier's 2 s timeout poisons the result with NaN; inside one process launches are ordered)
+  static const bool env_on = [] { const char* e = getenv("MINGNATIVE_RF_PERSIST"); return !(e && e[0] == '0'); }();
+  if (!env_on) return false;
   // bf16, e4m3 and NF4 gain — sampler call at 2 rows, 24 launches per step -> one launch per step -> the whole sampler in one launch:
   // bf16 6.81 -> 6.46 -> 6.22 ms, e4m3 5.26 -> 5.17 -> 4.97, NF4 5.39 -> 5.40 -> 5.17; int8 spends the phases in its decoder, not in
   // launch gaps (5.91 -> 6.35 -> 6.17) and keeps the launches  (tools/exp/rf_persist_ab.py, profiles/r05_rf_persist_ab.txt)

@@ -78,3 +78,31 @@ def test_bf16_one_row_takes_the_matrix_core_launches_and_matches_the_oracle():
     e = rel_err(got, ref)
     print(f"bf16 head, 1 row: {e:.2e}")
     assert e < 1e-3
+
+
+def test_env_switch_keeps_the_launches_and_agrees():
+    """MINGNATIVE_RF_PERSIST=0 (two processes on one GPU) keeps the two launches per ResBlock: same latents to 1e-5 (the whole-sampler
+    launch computes the final layer in fp32 FMAs, the launches in hi/lo MFMA slabs)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import json, torch, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from tests.test_gpu_rf_persist import _head, LLM_HIDDEN\n"
+        "rf = _head('bf16')\n"
+        "g = torch.Generator(device='cuda').manual_seed(3)\n"
+        "h = torch.randn(2, LLM_HIDDEN, device='cuda', generator=g); n = torch.randn(1, 32, device='cuda', generator=g)\n"
+        "print('LAT', json.dumps(rf.sample(h, n, n_images=1).flatten().tolist()))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, MINGNATIVE_RF_PERSIST="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lat0 = torch.tensor(json.loads([l for l in out.stdout.splitlines() if l.startswith("LAT ")][0][4:]))
+    rf = _head("bf16")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    h = torch.randn(2, LLM_HIDDEN, device="cuda", generator=g); n = torch.randn(1, 32, device="cuda", generator=g)
+    lat1 = rf.sample(h, n, n_images=1).flatten().cpu()
+    d = float((lat1 - lat0).abs().max() / lat0.abs().max())
+    print("persistent launch vs MINGNATIVE_RF_PERSIST=0: %.2e" % d)
+    assert d < 1e-5 and d > 0.0          # (> 0: the other process really took the other route)
