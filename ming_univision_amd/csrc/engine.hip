@@ -1185,8 +1185,8 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
                "mn_llm_step: M=%d (1..64, or up to 2048 rows with 64-aligned widths)", M);
   // fp8 experts: 1 or 2 rows run the one-row fp8 kernel on the (row, expert) pairs, more the grouped streaming kernels
   MN_CHECK_ARG(m->wfmt == MN_W_BF16 || (mn_w8(m->wfmt) && m->w_gate_up_scale && m->w_down_scale && (m->hidden % mn_wq_kmult(m->wfmt)) == 0 &&
-                                        (m->moe_inter % mn_wq_kmult(m->wfmt)) == 0 && M <= 64 && (M < moe_mfma_min_rows(m) || moe_mfma_ok(m, M))),
-               "mn_llm_step: quantised experts need scale tables, widths %% 16 == 0 (NF4: %% 64) and <= 64 rows (M = %d)", M);
+                                        (m->moe_inter % mn_wq_kmult(m->wfmt)) == 0 && (llm_wide_ok(m, M) || (M <= 64 && (M < moe_mfma_min_rows(m) || moe_mfma_ok(m, M))))),
+               "mn_llm_step: quantised experts need scale tables, widths %% 16 == 0 (NF4: %% 64) and <= 64 rows or the wide route's shapes (M = %d)", M);
   if (llm_wide_ok(m, M))
     return llm_step_wide(m, x, ldx, x_row_div, M, image_mask, row_seq, row_slot, row_pos, row_len, key_mask, ld_mask, kv_cache, n_seq, t_max,
                          hidden_out, workspace, workspace_bytes, stream, span_tab, n_spans, span_max_len);

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void moe_topk_partials_kernel(const float* __r
 struct LlmWideWs {
   float *h, *pp, *q, *yg, *tw;
   bf16_t *yh, *ya, *y2;
+  bf16_t *wq_gu, *wq_dn;           // weight-only modes: ONE layer's expert weights de-quantised, [G][2 I][H] / [G][H][I] (wide_rf.inl)
   int32_t *ti, *cnt, *off, *perm, *slot_of, *tile_g, *tile_m0, *n_tiles;
   int max_mtiles;
   void* attn_ws;
@@ -57,7 +58,8 @@ struct LlmWideWs {
 
 static bool llm_wide_ok(const mn_llm* m, int rows) {
   const int ad = m->n_q * m->head_dim, n_slot = m->top_k + m->n_shared_slots;
-  return m->wfmt == MN_W_BF16 && rows >= g_wide_min_llm && rows <= 2048 && wide_glue_ok(m->hidden) && (m->hidden % 64) == 0 && (ad % 64) == 0 && (m->moe_inter % 64) == 0 &&
+  const bool fmt_ok = m->wfmt == MN_W_BF16 || ((m->wfmt == MN_W_FP8_E4M3 || m->wfmt == MN_W_INT8 || m->wfmt == MN_W_NF4) && m->w_gate_up_scale && m->w_down_scale);
+  return fmt_ok && rows >= g_wide_min_llm && rows <= 2048 && wide_glue_ok(m->hidden) && (m->hidden % 64) == 0 && (ad % 64) == 0 && (m->moe_inter % 64) == 0 &&
          m->n_experts <= 64 && (m->n_experts % 4) == 0 && m->n_experts + m->n_shared_slots <= 128 && (int64_t)rows * n_slot <= 65536 &&
          (m->head_dim == 64 || m->head_dim == 128);
 }
@@ -94,6 +96,8 @@ static size_t llm_wide_carve(const mn_llm* m, int rows, int64_t t_max, void* ws,
   o->n_tiles = cv.take<int32_t>(4);
   o->attn_ws_bytes = mn_attn_decode_workspace_bytes(rows, m->n_q, m->head_dim, t_max);
   o->attn_ws = cv.take<char>(o->attn_ws_bytes);
+  o->wq_gu = cv.take<bf16_t>(m->wfmt ? (size_t)G * 2 * m->moe_inter * H : 0);
+  o->wq_dn = cv.take<bf16_t>(m->wfmt ? (size_t)G * H * m->moe_inter : 0);
   return cv.off;
 }
 
@@ -168,12 +172,18 @@ static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row
     MN_TRY(mn_moe_sort_tiles(w.ti, M, n_slot, G, w.cnt, w.off, w.perm, w.slot_of, lo_at(LO_LLM_EXPERTS, 1) ? 128 : 256, w.tile_g, w.tile_m0,
                              w.n_tiles, stream));
     // experts: grouped gate/up (rows gathered by perm, SwiGLU + split epilogue), grouped down -> yg [P, H]  (:617-628, 483-484)
-    a = g256_hilo(w.yh, H, lo_at(LO_LLM_EXPERTS, (int64_t)M * H), m->w_gate_up[l], H, nullptr, w.y2, I, M, I, H);
+    const bf16_t *wgu = m->w_gate_up[l], *wdn = m->w_down[l];
+    if (m->wfmt) {          // weight-only mode: this layer's W' into the scratch (1.14 GB at the 16B-A3B shape; ~0.35 ms per layer and step)
+      MN_TRYZ(wide_dequant_rows(m->wfmt, m->w_gate_up[l], m->w_gate_up_scale[l], w.wq_gu, (int64_t)G * 2 * I, H, stream));
+      MN_TRYZ(wide_dequant_rows(m->wfmt, m->w_down[l], m->w_down_scale[l], w.wq_dn, (int64_t)G * H, I, stream));
+      wgu = w.wq_gu; wdn = w.wq_dn;
+    }
+    a = g256_hilo(w.yh, H, lo_at(LO_LLM_EXPERTS, (int64_t)M * H), wgu, H, nullptr, w.y2, I, M, I, H);
     a.w_pair_rows = I; a.c_lo_off = P * I;
     a.g_off = w.off; a.g_cnt = w.cnt; a.w_gstride = (int64_t)2 * I * H; a.a_rows = w.perm; a.n_groups = G;
     a.tile_g = w.tile_g; a.tile_m0 = w.tile_m0; a.n_tiles = w.n_tiles; a.max_mtiles = w.max_mtiles;
     MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
-    a = g256_hilo(w.y2, I, lo_at(LO_LLM_EXPERTS, P * I), m->w_down[l], I, nullptr, w.yg, H, M, H, I);
+    a = g256_hilo(w.y2, I, lo_at(LO_LLM_EXPERTS, P * I), wdn, I, nullptr, w.yg, H, M, H, I);
     a.g_off = w.off; a.g_cnt = w.cnt; a.w_gstride = (int64_t)H * I; a.n_groups = G;
     a.tile_g = w.tile_g; a.tile_m0 = w.tile_m0; a.n_tiles = w.n_tiles; a.max_mtiles = w.max_mtiles;
     MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));

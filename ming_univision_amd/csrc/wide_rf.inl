@@ -35,8 +35,22 @@ struct RfWideWs {
   float* pbuf_stream;    // tp.inl, <= 64 rows: K-slice slabs of the weight-streaming kernels
   float* pbuf_stream3;   // tp.inl, <= 4 rows: w3's slabs when its prologue reads w12's (stream_fuse.h)
   bf16_t *hs, *zs, *y, *ya, *yb;
+  bf16_t *wq12, *wq3;    // weight-only modes: the blocks' weights de-quantised once per call, [depth][2 hidden][w] / [depth][w][hidden]
   int ks12, ks3, ksf;    // split-K requests of the w12 (1 = SwiGLU in the GEMM epilogue), w3 and final GEMMs
 };
+
+// Weight-only modes on the wide route: the byte codes are expanded ONCE per call / layer into a bf16 scratch (exactly the format's W':
+// mn_dequant_*_rows, bit-identical to what the streaming kernels' decoders produce) and the bf16 GEMMs run on that — the model keeps
+// its reduced footprint, a call pays one pass over the codes (the RF head: 1.8 GB of bf16 per sampler call against ~29 GB of GEMM reads).
+extern "C" int mn_dequant_fp8_rows(const uint8_t*, int64_t, const float*, uint16_t*, int64_t, int64_t, int, void*);
+extern "C" int mn_dequant_int8_rows(const uint8_t*, int64_t, const float*, uint16_t*, int64_t, int64_t, int, void*);
+extern "C" int mn_dequant_nf4_rows(const uint8_t*, int64_t, const float*, uint16_t*, int64_t, int64_t, int, void*);
+static int wide_dequant_rows(int wfmt, const void* q, const float* scale, bf16_t* out, int64_t n_rows, int K, void* stream) {
+  const uint8_t* qb = reinterpret_cast<const uint8_t*>(q);
+  if (wfmt == MN_W_NF4) return mn_dequant_nf4_rows(qb, K / 2, scale, out, K, n_rows, K, stream);
+  if (wfmt == MN_W_INT8) return mn_dequant_int8_rows(qb, K, scale, out, K, n_rows, K, stream);
+  return mn_dequant_fp8_rows(qb, K, scale, out, K, n_rows, K, stream);
+}
 
 // y = silu(gate) * up from the split-K slabs of a w12 GEMM run without its SwiGLU epilogue (columns [0, HID) gate, [HID, 2 HID)
 // up; b12 in the same order), stored as the w3 GEMM's bf16 hi / lo operand.  Used when the row count leaves the SwiGLU form of
@@ -107,11 +121,14 @@ static size_t rf_wide_carve(const mn_rf_head* h, int rows, void* ws, size_t cap,
   o->y = cv.take<bf16_t>((size_t)2 * SR * h->w);
   o->ya = cv.take<bf16_t>((size_t)2 * rows * h->w);
   o->yb = cv.take<bf16_t>((size_t)2 * rows * h->hidden);
+  o->wq12 = cv.take<bf16_t>(h->wfmt ? (size_t)h->depth * 2 * h->hidden * h->w : 0);
+  o->wq3 = cv.take<bf16_t>(h->wfmt ? (size_t)h->depth * h->w * h->hidden : 0);
   return cv.off;
 }
 
 static bool rf_wide_ok(const mn_rf_head* h, int rows) {
-  return h->wfmt == MN_W_BF16 && rows >= g_wide_min_rf && rows <= 2048 && wide_glue_ok(h->w) && wide_glue_ok(h->z_dim) && wide_glue_ok(h->llm_hidden) &&
+  const bool fmt_ok = h->wfmt == MN_W_BF16 || ((h->wfmt == MN_W_FP8_E4M3 || h->wfmt == MN_W_INT8 || h->wfmt == MN_W_NF4) && h->w12_scale && h->w3_scale && h->ada_w);
+  return fmt_ok && rows >= g_wide_min_rf && rows <= 2048 && wide_glue_ok(h->w) && wide_glue_ok(h->z_dim) && wide_glue_ok(h->llm_hidden) &&
          (h->w % 64) == 0 && (h->hidden % 64) == 0 && (h->z_dim % 64) == 0 && (h->llm_hidden % 64) == 0 && h->target <= 64 &&
          (h->target % 4) == 0;
 }
@@ -162,6 +179,12 @@ static int rf_sample_wide(const mn_rf_head* h, const float* hidden, int64_t ld_h
   a = g256_hilo(w.y, W, lo_at(LO_RF_ADA, SR * W), h->ada_w, W, h->ada_b, w.ada, A, (int)SR, A, W);
   MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
 
+  if (h->wfmt) {          // weight-only mode: W' of every block, once per call
+    for (int b = 0; b < h->depth; ++b) {
+      MN_TRYZ(wide_dequant_rows(h->wfmt, h->w12[b], h->w12_scale[b], w.wq12 + (int64_t)b * 2 * HID * W, (int64_t)2 * HID, W, stream));
+      MN_TRYZ(wide_dequant_rows(h->wfmt, h->w3[b], h->w3_scale[b], w.wq3 + (int64_t)b * W * HID, (int64_t)W, HID, stream));
+    }
+  }
   const float step = 1.0f / (float)h->steps;
   const int64_t lo_a = (int64_t)rows * W, lo_b = (int64_t)rows * HID;
   for (int s = 0; s < h->steps; ++s) {
@@ -174,19 +197,21 @@ static int rf_sample_wide(const mn_rf_head* h, const float* hidden, int64_t ld_h
     wide_glue(g, st);
     for (int b = 0; b < h->depth; ++b) {
       const float* mod = ada + (int64_t)b * 3 * W;
+      const bf16_t* w12b = h->wfmt ? w.wq12 + (int64_t)b * 2 * HID * W : h->w12[b];
+      const bf16_t* w3b = h->wfmt ? w.wq3 + (int64_t)b * W * HID : h->w3[b];
       if (w.ks12 > 1) {
-        a = g256_hilo(w.ya, W, lo_at(LO_RF_W12, lo_a), h->w12[b], W, nullptr, w.pbuf, 2 * HID, rows, 2 * HID, W);
+        a = g256_hilo(w.ya, W, lo_at(LO_RF_W12, lo_a), w12b, W, nullptr, w.pbuf, 2 * HID, rows, 2 * HID, W);
         a.c_zstride = (int64_t)rows * 2 * HID;
         const int nz12 = mn_gemm256_ex(&a, MN_G256_F32, w.ks12, stream);
         if (nz12 < 0) return nz12;
         hipLaunchKernelGGL(rf_swiglu_slabs_kernel, dim3(mn_cdiv((int64_t)rows * (HID / 4), 256)), dim3(256), 0, st, w.pbuf, nz12,
                            (int64_t)rows * 2 * HID, h->b12[b], w.yb, lo_b, rows, HID);
       } else {
-        a = g256_hilo(w.ya, W, lo_at(LO_RF_W12, lo_a), h->w12[b], W, h->b12[b], w.yb, HID, rows, HID, W);
+        a = g256_hilo(w.ya, W, lo_at(LO_RF_W12, lo_a), w12b, W, h->b12[b], w.yb, HID, rows, HID, W);
         a.w_pair_rows = HID; a.c_lo_off = lo_b;
         MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_SPLIT, 1, stream));
       }
-      a = g256_hilo(w.yb, HID, lo_at(LO_RF_W3, lo_b), h->w3[b], HID, nullptr, w.pbuf, W, rows, W, HID);
+      a = g256_hilo(w.yb, HID, lo_at(LO_RF_W3, lo_b), w3b, HID, nullptr, w.pbuf, W, rows, W, HID);
       a.c_zstride = (int64_t)rows * W;
       const int nz = mn_gemm256_ex(&a, MN_G256_F32, w.ks3, stream);
       if (nz < 0) return nz;

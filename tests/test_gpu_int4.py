@@ -105,7 +105,7 @@ def _int4_models(full, n_seq):
     dec4 = BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=32, n_seq=n_seq, weights="int4")
     rf4 = RectifiedFlowHead(dsd, cfg.hidden_size, rf_cfg, weights="int4")
     assert dec4.layers[0]["w_gate_up"].dtype == torch.uint8 and dec4.layers[0]["w_gate_up"].shape[-1] == cfg.hidden_size // 2
-    assert rf4.lists["w12"][0].dtype == torch.uint8 and dec4.max_rows() == 64 and rf4.max_rows() == 64
+    assert rf4.lists["w12"][0].dtype == torch.uint8 and dec4.max_rows() == 2048 and rf4.max_rows() == 2048
     sd4 = dict(sd)
     for k, v in dec4.dequantized_state_dict().items():
         sd4[k] = v.float().cpu()

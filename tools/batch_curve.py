@@ -1,6 +1,7 @@
 """Throughput-vs-batch curve of the headline workload: visual tokens/s of BASELINE configs[3] (16B-A3B text -> 512^2,
 2 CFG rows per image) over the number of images generated in lock-step, across the three routes — fused chain (<= 4 rows), weight-streaming
-kernels (<= 64 rows), wide MFMA route (65+ rows) — in bf16 and, up to the streaming route's 32 images, in fp8 / int8 / int4 weight modes.
+kernels (<= 64 rows), wide MFMA route (65+ rows) — in bf16 and in the fp8 / int8 / int4 weight modes (whose wide route expands the codes
+into a bf16 scratch: the RF head once per sampler call, a decoder layer's experts once per layer and step).
 
 A point = one whole-image run of `--tokens` visual tokens (default 64 = an 8 x 8 grid: the per-token time is flat over an image's 256 tokens
 up to the cache length) after one untimed run, same prompts and noise for every weight mode.  Writes ONE JSON (stdout, or --out) with the curve and a check
@@ -43,7 +44,7 @@ def main():
         if mode == "bf16":
             d, r, lim = dec, rf, max(images)
         else:
-            d, r, lim = dec.to_fp8(n_seq=64, weights=mode), rf.to_fp8(mode), 32            # quantised modes: the <= 64-row route only
+            d, r, lim = dec.to_fp8(n_seq=2 * max(images), weights=mode), rf.to_fp8(mode), max(images)   # (above 64 rows: the wide route on a de-quantised scratch)
         pts = []
         for B in images:
             if B > lim:
