@@ -106,3 +106,25 @@ def test_env_switch_keeps_the_launches_and_agrees():
     d = float((lat1 - lat0).abs().max() / lat0.abs().max())
     print("persistent launch vs MINGNATIVE_RF_PERSIST=0: %.2e" % d)
     assert d < 1e-5 and d > 0.0          # (> 0: the other process really took the other route)
+
+
+def test_sampler_inside_a_graph_capture_takes_the_launches():
+    """A captured stream gets the two launches per ResBlock (the persistent launch orders itself against other streams with event
+    calls, which a capture must not see): capture + replay give the eager result to 1e-5."""
+    rf = _head("bf16")
+    g = torch.Generator(device="cuda").manual_seed(9)
+    h = torch.randn(2, LLM_HIDDEN, device="cuda", generator=g)
+    n = torch.randn(1, 32, device="cuda", generator=g)
+    out = torch.empty(1, 32, device="cuda")
+    eager = rf.sample(h, n, n_images=1).clone()
+    rf.sample(h, n, n_images=1, out=out)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        rf.sample(h, n, n_images=1, out=out)
+    out.zero_()
+    gr.replay()
+    torch.cuda.synchronize()
+    d = float((out - eager).abs().max() / eager.abs().max())
+    print("captured sampler vs eager persistent launch: %.2e" % d)
+    assert torch.isfinite(out).all() and d < 1e-5

@@ -21,7 +21,7 @@ def graphed(fn):
     return gr.replay
 for B in [int(v) for v in (sys.argv[1:] or ["1", "4", "16"])]:
     R = 2 * B
-    args = argparse.Namespace(tiny=False, tokens=256, layers=None, prompt_len=40, images=B, cfg_rows=2)
+    args = argparse.Namespace(tiny=False, tokens=256, layers=None, prompt_len=40, images=B, cfg_rows=2, weights="bf16")
     cfg, dec, rf, tok = bench.build_models(args, dev, 0)
     x = torch.randn(B, cfg.hidden_size, device=dev, generator=g)
     seq = torch.arange(R, dtype=torch.int32, device=dev)
