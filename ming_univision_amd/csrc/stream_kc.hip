@@ -760,7 +760,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const 
 
 uint64_t* g_kc_trace = nullptr;
 int g_kc_persist_all = 0;            // dev library: the persistent launch for int8 as well (mn_rf_kc_persist_all)
-int g_kc_rd12 = 1, g_kc_rd3 = 0;     // weight chunks in flight per wave; rd3 = 0: by format (dev-library A/B knob: mn_rf_kc_tune)       // weight chunks in flight per wave (dev-library A/B knob: mn_rf_kc_tune)
+int g_kc_rd12 = 1, g_kc_rd3 = 0;     // weight chunks in flight per wave; rd3 = 0: by format (dev-library A/B knob: mn_rf_kc_tune)
 
 size_t w12_lds(int M, int w, int nw) { return (size_t)2 * M * (w * 2 + 64) + (size_t)nw * 16 * WCH * 2 + (nw * KC_MAX_M * 16 + 16) * sizeof(float); }
 size_t w3_lds(int M, int hid) { return (size_t)2 * M * (hid * 2 + 64) + (size_t)KC_WAVES * 16 * WCH * 2 + KC_WAVES * KC_MAX_M * 16 * sizeof(float); }
