@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "grid_bar.h"
 #include "stream_fuse.h"
 #include "w8_codec.h"
 
@@ -513,43 +514,6 @@ struct PersistArgs {
   PersistBlk blk[PB_MAX];
 };
 
-// Flag barrier.  (A first build counted arrivals with one agent-scope atomic word: 256 read-modify-writes of ONE address are served
-// one after the other at the memory side — 18 us per barrier, profiles/r05_rf_persist_ab.txt.)  Every workgroup owns one word of a
-// 1 KiB flag array — word (wg % 8) * 32 + wg / 8: the workgroups of one XCD share a 128-byte line — and stores the barrier's epoch into
-// it (plain stores to distinct words pipeline); wave 0 of every workgroup polls the whole array, 4 words per lane, until every word
-// has reached the epoch.  Epochs only grow: the host zeroes the array once per sampler call and hands each launch its first epoch.
-struct GridBar {
-  unsigned* flags; unsigned G, epoch; uint64_t ticks; int dead;
-  __device__ __forceinline__ void arrive() {
-    ++epoch;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {                          // (payload stores were write-through and are drained: no release fence)
-      const unsigned wg = blockIdx.x;
-      __hip_atomic_store(flags + ((wg & 7u) * 32u + (wg >> 3)), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  __device__ __forceinline__ void wait() {
-    if (threadIdx.x < 64 && !dead) {
-      const unsigned lane = threadIdx.x;
-      const uint64_t t0 = wall_clock64();
-      for (;;) {
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const unsigned i = lane + 64u * j, wg = (i & 31u) * 8u + (i >> 5);
-          const unsigned v = __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = ok && (wg >= G || (int32_t)(v - epoch) >= 0);
-        }
-        if (__all(ok)) break;
-        if (wall_clock64() - t0 > ticks) { if (lane == 0) atomicExch(flags + 256, 0x300u); dead = 1; break; }
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
-    __syncthreads();                                // (the phases read other workgroups' data past the L1: no acquire fence)
-  }
-};
-
 // ---- whole-sampler form: the two light phases around the blocks of an Euler step ---------------------------------------------------------
 // Boundary phase (every workgroup): the ODE state x [M][T] lives in EVERY workgroup's LDS (replicated: 64 floats, no hand-off, no race) —
 // step 0: x = noise * temperature; later: v = the final layer's output of the previous step (coherent loads), CFG combine over the image's rows,
@@ -847,33 +811,51 @@ int rf_blocks_persist(int wfmt, float* h, bf16_t* Y3, int M, int w, int hid, con
     p.lds_top = (uint32_t)top;
     p.trace = nullptr;
   }
-  static std::mutex mu;
-  static hipEvent_t ev = nullptr;
-  static hipStream_t last = nullptr;
-  static bool any = false;
   hipStream_t st = mn_stream(stream);
-  std::lock_guard<std::mutex> lk(mu);
-  static size_t opted = 0;                           // (the kernel holds 256 bytes of static LDS: ask for what the launch needs, not for all 160 KiB)
-  if (lds > opted) {
-    const void* ks[3] = {reinterpret_cast<const void*>(&rf_blocks_persist_kernel<0>), reinterpret_cast<const void*>(&rf_blocks_persist_kernel<1>),
-                         reinterpret_cast<const void*>(&rf_blocks_persist_kernel<2>)};
-    for (const void* k : ks)
-      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        mn_set_error("rf_blocks_persist: cannot reserve %zu bytes of LDS", lds);
-        return MN_ELAUNCH;
-      }
-    opted = lds;
+  static std::mutex mu_attr;
+  {
+    std::lock_guard<std::mutex> lk(mu_attr);
+    static size_t opted = 0;                         // (the kernel holds 256 bytes of static LDS: ask for what the launch needs, not for all 160 KiB)
+    if (lds > opted) {
+      const void* ks[3] = {reinterpret_cast<const void*>(&rf_blocks_persist_kernel<0>), reinterpret_cast<const void*>(&rf_blocks_persist_kernel<1>),
+                           reinterpret_cast<const void*>(&rf_blocks_persist_kernel<2>)};
+      for (const void* k : ks)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+          mn_set_error("rf_blocks_persist: cannot reserve %zu bytes of LDS", lds);
+          return MN_ELAUNCH;
+        }
+      opted = lds;
+    }
   }
-  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { mn_set_error("rf_blocks_persist: hipEventCreate failed"); return MN_ELAUNCH; }
-  if (any && last != st) (void)hipStreamWaitEvent(st, ev, 0);
+  { const int rc_o = mn_persist_order_before(st); if (rc_o != MN_OK) return rc_o; }
   const dim3 grid((unsigned)G), block(KC_WAVES * 64);
   if (wfmt == MN_W_NF4) hipLaunchKernelGGL(rf_blocks_persist_kernel<2>, grid, block, lds, st, p);
   else if (wfmt) hipLaunchKernelGGL(rf_blocks_persist_kernel<1>, grid, block, lds, st, p);
   else hipLaunchKernelGGL(rf_blocks_persist_kernel<0>, grid, block, lds, st, p);
+  mn_persist_order_after(st);
   MN_CHECK_LAUNCH("rf_blocks_persist");
-  (void)hipEventRecord(ev, st);
-  last = st; any = true;
   return MN_OK;
+}
+
+// (grid_bar.h) persistent launches on different streams are ordered by an event
+static std::mutex g_persist_mu;
+static hipEvent_t g_persist_ev = nullptr;
+static hipStream_t g_persist_last = nullptr;
+static bool g_persist_any = false;
+int mn_persist_order_before(hipStream_t st) {
+  g_persist_mu.lock();                               // held until mn_persist_order_after: launch + record are one step
+  if (!g_persist_ev && hipEventCreateWithFlags(&g_persist_ev, hipEventDisableTiming) != hipSuccess) {
+    g_persist_mu.unlock();
+    mn_set_error("persistent launch: hipEventCreate failed");
+    return MN_ELAUNCH;
+  }
+  if (g_persist_any && g_persist_last != st) (void)hipStreamWaitEvent(st, g_persist_ev, 0);
+  return MN_OK;
+}
+void mn_persist_order_after(hipStream_t st) {
+  (void)hipEventRecord(g_persist_ev, st);
+  g_persist_last = st; g_persist_any = true;
+  g_persist_mu.unlock();
 }
 
 int rf_w12_kc(int wfmt, const float* h, int M, int w, int hid, const bf16_t* ln_g, const bf16_t* ln_b, const float* shift, const float* scale,
