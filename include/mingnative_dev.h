@@ -29,7 +29,6 @@ MN_DEV_API void mn_attn_tune_one(int max_rows);                         /* decod
 MN_DEV_API void mn_stream_kloop_tune(int nz, int depth, int nt);        /* stream_kloop.hip */
 MN_DEV_API void mn_stream_kloop_tune_small(int div);
 MN_DEV_API void mn_moe_router_tune(int max_rows);                       /* one-launch router up to this many rows */
-MN_DEV_API void mn_wide_tune_dequant(int overlap);                       /* engine.hip / wide_llm.inl: weight-only modes on the wide route — expand layer l + 1's expert codes on a side stream under layer l (1) or in line (0) */
 MN_DEV_API void mn_moe_tune_gate_up(int on, int max_rows);               /* engine.hip: router + expert gate/up of <= max_rows-row steps as one launch (moe_gate_up.hip) */
 MN_DEV_API void mn_llm_tune_chain(int max_rows);                        /* fused decoder chain up to this many rows */
 MN_DEV_API void mn_gemm_tune(int glds);                                 /* batch_ops.hip: global_load_lds staging */

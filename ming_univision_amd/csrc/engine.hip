@@ -11,8 +11,6 @@
 #include <array>
 #include <initializer_list>
 
-#include <mutex>
-
 #include "common.h"
 
 extern "C" size_t mn_attn_decode_workspace_bytes(int M, int n_q, int hd, int64_t t_max);
@@ -968,10 +966,6 @@ __global__ __launch_bounds__(1024) void moe_route_group_kernel(const float* __re
   }
 }
 
-static int g_wide_dequant_overlap = 1;      // weight-only modes on the wide route: expand layer l + 1 on a side stream under layer l (dev-library A/B: mn_wide_tune_dequant)
-#ifdef MN_DEV_HOOKS
-extern "C" MN_DEV_API void mn_wide_tune_dequant(int overlap) { g_wide_dequant_overlap = overlap; }
-#endif
 #include "wide_llm.inl"
 #include "tp.inl"
 

@@ -138,6 +138,35 @@ __global__ __launch_bounds__(256) void dequant_nf4_rows_kernel(const uint8_t* __
   }
 }
 
+// ---- the byte formats' expansion for CONTIGUOUS row blocks (ldq = ldw = K), 16 weights per thread: the wide route
+// of the weight-only modes expands a decoder layer's experts on every step (wide_llm.inl) — 46 GB of traffic per step at the 16B-A3B
+// shape — and the row-per-workgroup kernels above (4-byte loads, written for load time) moved it at 3.9 TB/s; these: 5.5 TB/s.  (NF4's
+// row kernel already stores 16 bytes per lane, coalesced; a 32-weights-per-thread form measured slower.)
+template <bool I8>
+__global__ __launch_bounds__(256) void dequant8_flat_kernel(const uint8_t* __restrict__ Q, const float* __restrict__ scale, bf16_t* __restrict__ W,
+                                                            int64_t n_pieces, int K) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;                 // piece = 16 consecutive weights of one row (K % 16 == 0)
+  if (i >= n_pieces) return;
+  const int64_t e = i * 16;
+  const float s = scale[e / K];
+  const mn_u4_t q = __builtin_nontemporal_load(reinterpret_cast<const mn_u4_t*>(Q + e));
+  mn_u4_t lo, hi;
+  if constexpr (I8) {
+    const mn_u2_t a = i8x4_to_bf16(q.x, s), b = i8x4_to_bf16(q.y, s), c = i8x4_to_bf16(q.z, s), d = i8x4_to_bf16(q.w, s);
+    lo = mn_u4_t{a.x, a.y, b.x, b.y}; hi = mn_u4_t{c.x, c.y, d.x, d.y};
+  } else {
+    const uint32_t qs[4] = {q.x, q.y, q.z, q.w};
+    uint32_t o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const mn_f2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(qs[j], false), b = __builtin_amdgcn_cvt_pk_f32_fp8(qs[j], true);
+      o[2 * j] = cvt_pk_bf16(a.x * s, a.y * s); o[2 * j + 1] = cvt_pk_bf16(b.x * s, b.y * s);
+    }
+    lo = mn_u4_t{o[0], o[1], o[2], o[3]}; hi = mn_u4_t{o[4], o[5], o[6], o[7]};
+  }
+  *reinterpret_cast<mn_u4_t*>(W + e) = lo;
+  *reinterpret_cast<mn_u4_t*>(W + e + 8) = hi;
+}
 }  // namespace
 
 extern "C" int mn_quant_int8_rows(const uint16_t* W, int64_t ldw, uint8_t* Wq, int64_t ldq, float* scale, int64_t n_rows, int K, void* stream) {
@@ -154,6 +183,10 @@ extern "C" int mn_dequant_int8_rows(const uint8_t* Wq, int64_t ldq, const float*
   MN_CHECK_ARG(W && Wq && scale && n_rows >= 1 && n_rows < ((int64_t)1 << 31) && K >= 4 && (K % 4) == 0 && (ldw % 4) == 0 && (ldq % 4) == 0 &&
                    (((uintptr_t)W) & 7) == 0 && (((uintptr_t)Wq) & 3) == 0,
                "mn_dequant_int8_rows: bad args (K, ldw, ldq multiples of 4)");
+  if (ldq == K && ldw == K && (K % 16) == 0 && ((((uintptr_t)W) | ((uintptr_t)Wq)) & 15) == 0) {      // contiguous rows: 16 weights per thread
+    const int64_t np = n_rows * (K / 16);
+    hipLaunchKernelGGL(dequant8_flat_kernel<true>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, mn_stream(stream), Wq, scale, W, np, K);
+  } else
   hipLaunchKernelGGL(dequant_int8_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, mn_stream(stream), Wq, ldq, scale, W, ldw, K);
   MN_CHECK_LAUNCH("mn_dequant_int8_rows");
   return MN_OK;
@@ -173,6 +206,10 @@ extern "C" int mn_dequant_fp8_rows(const uint8_t* Wq, int64_t ldq, const float* 
   MN_CHECK_ARG(W && Wq && scale && n_rows >= 1 && n_rows < ((int64_t)1 << 31) && K >= 4 && (K % 4) == 0 && (ldw % 4) == 0 && (ldq % 4) == 0 &&
                    (((uintptr_t)W) & 7) == 0 && (((uintptr_t)Wq) & 3) == 0,
                "mn_dequant_fp8_rows: bad args (K, ldw, ldq multiples of 4)");
+  if (ldq == K && ldw == K && (K % 16) == 0 && ((((uintptr_t)W) | ((uintptr_t)Wq)) & 15) == 0) {      // contiguous rows: 16 weights per thread
+    const int64_t np = n_rows * (K / 16);
+    hipLaunchKernelGGL(dequant8_flat_kernel<false>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, mn_stream(stream), Wq, scale, W, np, K);
+  } else
   hipLaunchKernelGGL(dequant_fp8_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, mn_stream(stream), Wq, ldq, scale, W, ldw, K);
   MN_CHECK_LAUNCH("mn_dequant_fp8_rows");
   return MN_OK;

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void moe_topk_partials_kernel(const float* __r
 struct LlmWideWs {
   float *h, *pp, *q, *yg, *tw;
   bf16_t *yh, *ya, *y2;
-  bf16_t *wq_gu[2], *wq_dn[2];     // weight-only modes: a layer's expert weights de-quantised, [G][2 I][H] / [G][H][I] (wide_rf.inl); two sets: layer l + 1 is expanded on a side stream while layer l computes
+  bf16_t *wq_gu, *wq_dn;           // weight-only modes: ONE layer's expert weights de-quantised, [G][2 I][H] / [G][H][I] (wide_rf.inl)
   int32_t *ti, *cnt, *off, *perm, *slot_of, *tile_g, *tile_m0, *n_tiles;
   int max_mtiles;
   void* attn_ws;
@@ -96,39 +96,10 @@ static size_t llm_wide_carve(const mn_llm* m, int rows, int64_t t_max, void* ws,
   o->n_tiles = cv.take<int32_t>(4);
   o->attn_ws_bytes = mn_attn_decode_workspace_bytes(rows, m->n_q, m->head_dim, t_max);
   o->attn_ws = cv.take<char>(o->attn_ws_bytes);
-  for (int i = 0; i < 2; ++i) {
-    o->wq_gu[i] = cv.take<bf16_t>(m->wfmt ? (size_t)G * 2 * m->moe_inter * H : 0);
-    o->wq_dn[i] = cv.take<bf16_t>(m->wfmt ? (size_t)G * H * m->moe_inter : 0);
-  }
+  o->wq_gu = cv.take<bf16_t>(m->wfmt ? (size_t)G * 2 * m->moe_inter * H : 0);
+  o->wq_dn = cv.take<bf16_t>(m->wfmt ? (size_t)G * H * m->moe_inter : 0);
   return cv.off;
 }
-
-// Weight-only modes: the expansion of layer l + 1's expert codes (HBM-bound, ~0.35 ms) runs on a SIDE stream under layer l's GEMMs
-// (MFMA-bound), into the other scratch set; events order it against the GEMMs that read / last read the set (fork / join on the caller's
-// stream, so a capture of the step stays one graph).  One side stream per process; events per call.
-struct WideDequantPipe {
-  hipStream_t side = nullptr;
-  hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr}, fork = nullptr;
-  bool ok = false;
-  bool init() {
-    static std::mutex mu;
-    static hipStream_t s_side = nullptr;
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      if (!s_side && hipStreamCreateWithFlags(&s_side, hipStreamNonBlocking) != hipSuccess) return false;
-    }
-    side = s_side;
-    for (int i = 0; i < 2; ++i)
-      if (hipEventCreateWithFlags(&ready[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) return false;
-    if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
-    ok = true;
-    return true;
-  }
-  ~WideDequantPipe() {
-    for (int i = 0; i < 2; ++i) { if (ready[i]) (void)hipEventDestroy(ready[i]); if (done[i]) (void)hipEventDestroy(done[i]); }
-    if (fork) (void)hipEventDestroy(fork);
-  }
-};
 
 static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row_div, int M, const uint8_t* image_mask, const int32_t* row_seq,
                          const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len, const uint8_t* key_mask,
@@ -144,18 +115,6 @@ static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row
   const int64_t layer_kv = (int64_t)n_seq * 2 * nkv * t_max * hd;
   const float q_scale = 1.0f / sqrtf((float)hd);
   WideGlue g;
-  WideDequantPipe pipe;
-  auto expand = [&](int l, void* on) -> int {            // layer l's W' into scratch set l & 1, enqueued on stream `on`
-    MN_TRYZ(wide_dequant_rows(m->wfmt, m->w_gate_up[l], m->w_gate_up_scale[l], w.wq_gu[l & 1], (int64_t)G * 2 * I, H, on));
-    MN_TRYZ(wide_dequant_rows(m->wfmt, m->w_down[l], m->w_down_scale[l], w.wq_dn[l & 1], (int64_t)G * H, I, on));
-    return MN_OK;
-  };
-  if (m->wfmt && g_wide_dequant_overlap && pipe.init()) {      // fork: the side stream starts behind the caller's stream, with layer 0
-    (void)hipEventRecord(pipe.fork, st);
-    (void)hipStreamWaitEvent(pipe.side, pipe.fork, 0);
-    MN_TRYZ(expand(0, pipe.side));
-    (void)hipEventRecord(pipe.ready[0], pipe.side);
-  }
   for (int l = 0; l <= m->n_layers; ++l) {
     // glue: (stack input | previous layer's expert combine + residual) -> RMSNorm(ln1 | final norm)
     const bool fin = l == m->n_layers;
@@ -214,18 +173,10 @@ static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row
                              w.n_tiles, stream));
     // experts: grouped gate/up (rows gathered by perm, SwiGLU + split epilogue), grouped down -> yg [P, H]  (:617-628, 483-484)
     const bf16_t *wgu = m->w_gate_up[l], *wdn = m->w_down[l];
-    if (m->wfmt) {          // weight-only mode: this layer's W' comes from the scratch (1.14 GB per set at the 16B-A3B shape; ~0.35 ms per layer and step)
-      if (pipe.ok) {
-        if (l + 1 < m->n_layers) {                        // layer l + 1 into the other set, once layer l - 1's GEMMs have read it
-          if (l >= 1) (void)hipStreamWaitEvent(pipe.side, pipe.done[(l + 1) & 1], 0);
-          MN_TRYZ(expand(l + 1, pipe.side));
-          (void)hipEventRecord(pipe.ready[(l + 1) & 1], pipe.side);
-        }
-        (void)hipStreamWaitEvent(st, pipe.ready[l & 1], 0);
-      } else {
-        MN_TRYZ(expand(l, stream));
-      }
-      wgu = w.wq_gu[l & 1]; wdn = w.wq_dn[l & 1];
+    if (m->wfmt) {          // weight-only mode: this layer's W' into the scratch (1.14 GB at the 16B-A3B shape; ~0.35 ms per layer and step)
+      MN_TRYZ(wide_dequant_rows(m->wfmt, m->w_gate_up[l], m->w_gate_up_scale[l], w.wq_gu, (int64_t)G * 2 * I, H, stream));
+      MN_TRYZ(wide_dequant_rows(m->wfmt, m->w_down[l], m->w_down_scale[l], w.wq_dn, (int64_t)G * H, I, stream));
+      wgu = w.wq_gu; wdn = w.wq_dn;
     }
     a = g256_hilo(w.yh, H, lo_at(LO_LLM_EXPERTS, (int64_t)M * H), wgu, H, nullptr, w.y2, I, M, I, H);
     a.w_pair_rows = I; a.c_lo_off = P * I;
@@ -236,7 +187,6 @@ static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row
     a.g_off = w.off; a.g_cnt = w.cnt; a.w_gstride = (int64_t)H * I; a.n_groups = G;
     a.tile_g = w.tile_g; a.tile_m0 = w.tile_m0; a.n_tiles = w.n_tiles; a.max_mtiles = w.max_mtiles;
     MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
-    if (pipe.ok) (void)hipEventRecord(pipe.done[l & 1], st);     // (the side stream's last work was waited for above: the caller's stream joins it)
   }
   MN_CHECK_LAUNCH("mn_llm_step(wide)");
   return MN_OK;
