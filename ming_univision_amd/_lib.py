@@ -256,6 +256,8 @@ def lib():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `make -C {_HERE}/csrc` "
             "(or __graft_entry__.build()). There is no CPU/PyTorch fallback.")
+    import torch  # noqa: F401  (before the library: the process must hold ONE HIP runtime — torch's bundled one; loaded first, the
+    #                            library binds the system copy and torch's later launches fail with "no ROCm-capable device is detected")
     handle = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(handle, name)  # AttributeError if the symbol is missing
