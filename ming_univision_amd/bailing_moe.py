@@ -19,8 +19,8 @@ All arithmetic runs in libmingnative; this module owns HBM residency:
   * `weights="fp8"` (mingnative.h section 7; the reference's reduced-byte surface is the `dtype` switch of
     mingunivisioninfer.py:46-70): the packed experts — 15.5 of the stack's 16.2 B parameters, 87-92 % of the bytes a decode step
     streams — are quantised once at load to OCP e4m3 with one power-of-two scale per output row of every expert and streamed
-    as bytes; attention, router, norms, embeddings and lm_head stay bf16.  The stack then serves <= 64 rows per step (the
-    HBM-bound route) and long prompts prefill in 64-row passes.
+    as bytes; attention, router, norms, embeddings and lm_head stay bf16.  Up to 64 rows per step the codes are decoded inside the
+    weight-streaming kernels (the HBM-bound route); the wide route (65..2048 rows) expands a layer's experts into a bf16 scratch first.
 """
 import ctypes as C
 
@@ -462,7 +462,7 @@ class BailingMoeDecoder:
         the LAST token of each sequence [B,H] fp32 (what the next-token logits need)."""
         import math
         if self.stream_fmt != "bf16":
-            # quantised experts exist for the <= 64-row streaming route only: shared 64-row passes through the decode kernels instead
+            # bf16-autocast prefill kernels read bf16 expert weights: a quantised stack takes the shared passes through the step kernels instead
             assert positions is None and key_masks is None, "fp8 weight mode: default positions / masks only"
             return self.prefill_ragged(embeds_list, seqs, past=past, image_masks=image_masks)
         cfg, L_ = self.cfg, lib()

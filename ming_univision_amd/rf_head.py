@@ -16,7 +16,8 @@ Load-time re-packing (results unchanged):
 `weights="fp8"` (mingnative.h section 7; the reference's reduced-byte surface is the `dtype` switch of
 mingunivisioninfer.py:46-70): the ResBlock matrices w12 / w3 — 1.21 of the head's 1.29 B parameters, streamed 16 times per
 visual token — are quantised once at load to OCP e4m3 with one power-of-two scale per output row and streamed as bytes; the
-head then serves <= 64 rows per call (the HBM-bound route; the MFMA-bound wide route gains nothing from narrower weights).
+codes are decoded inside the weight-streaming kernels up to 64 rows per call (the HBM-bound route); the MFMA-bound wide route gains
+nothing from narrower weights and expands the blocks into a bf16 scratch once per call (wide_rf.inl).
 """
 import ctypes as C
 import math
