@@ -1007,12 +1007,12 @@ static bool moe_mfma_ok(const mn_llm* m, int rows) {
 // 2 rows 78.5 vs 76.5, 8 rows 254 vs 247, 16 rows 451 vs 442, 32 rows 699 vs 698; at 64 rows the one-workgroup-per-row
 // glue kernels lose to the wider unfused ones (1084 vs 1122), so the chain stops at 32.
 static int g_chain_max_rows = 32, g_chain_router = 1;
-static int g_moe_gate_up = 1, g_moe_gate_up_rows = 1;      // the one-launch router + gate/up of 1-row steps (dev-library A/B: mn_moe_tune_gate_up)
+static int g_moe_gate_up = 1, g_moe_gate_up_rows = 1, g_moe_gate_up_chain_rows = 2, g_moe_gate_up_chain_all = 0;      // (chain: int8 / NF4 by default — bf16 / e4m3 keep the pair launches: 2.25 vs 2.64 ms, 1.71 vs 1.84)      // the one-launch router + gate/up of 1-row steps (dev-library A/B: mn_moe_tune_gate_up)
 bool moe_router_rows_ok(int M, int H, int E);
 int moe_router_rows(float* h, const float* P, int nz, const uint16_t* norm_w, float eps, const uint16_t* gate_w, int M, int H, int E, int top_k,
                     int norm_topk_prob, int n_shared_slots, float* x_norm, int32_t* topk_idx, float* topk_w, float* logits_ws, void* stream);
 #ifdef MN_DEV_HOOKS
-extern "C" MN_DEV_API void mn_moe_tune_gate_up(int on, int max_rows) { g_moe_gate_up = on; g_moe_gate_up_rows = max_rows; }
+extern "C" MN_DEV_API void mn_moe_tune_gate_up(int on, int max_rows) { g_moe_gate_up = on; g_moe_gate_up_rows = max_rows & 0xff; g_moe_gate_up_chain_rows = (max_rows >> 8) & 0xff; g_moe_gate_up_chain_all = (max_rows >> 16) & 1; }
 extern "C" MN_DEV_API void mn_llm_tune_chain(int max_rows) { g_chain_max_rows = max_rows & 0xffff; g_chain_router = (max_rows >> 16) & 1 ? 0 : 1; }   // A/B hook (tools/): bit 16 = the one-launch router of the chain OFF
 #endif
 static bool llm_chain_ok(const mn_llm* m, int rows) {
@@ -1205,7 +1205,12 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
   if (llm_chain_ok(m, M) && !(image_mask && m->image_gate)) {
     // ---- chain path: 12 launches per layer (11 at 2 rows) instead of 18.  glue = llm_glue_kernel.
     const int E = m->n_experts, S = m->n_shared_slots, G = E + S, ad = nq * hd, P = M * n_slot;
-    const bool grouped = moe_mfma_ok(m, M);
+    // 2 rows (the CFG rows of one image): the experts run as router + gate/up in ONE launch and the wave-segmented down projection,
+    // straight into h (moe_gate_up.hip, moe_down.hip) — int8 / NF4 (2.26 -> 2.05 ms, 2.48 -> 2.38 per step against their grouped streaming launches;
+    // bf16 / e4m3 keep the pair launches, which are faster there)
+    const bool gu_chain = g_moe_gate_up && M <= g_moe_gate_up_chain_rows && g_moe_down && moe_gate_up_ok(m->wfmt, H, I, E, m->top_k, S) &&
+                          moe_down_ok(m->wfmt, n_slot, H, I) && (m->wfmt == MN_W_INT8 || m->wfmt == MN_W_NF4 || g_moe_gate_up_chain_all);
+    const bool grouped = moe_mfma_ok(m, M) && !gu_chain;
     const int gt = ((H / 4 + 63) / 64) * 64;                           // threads of a glue workgroup
     int nz2 = 0;                                                       // slabs of the previous layer's expert down-projection
     for (int l = 0; l < m->n_layers; ++l) {
@@ -1236,6 +1241,18 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
       }
       nz = mn_stream_mfma(w.ya, m->wdense[l], w.pp, M, H, ad, stream);
       if (nz < 0) return nz;
+      // residual + RMSNorm(ln2) + router + the selected experts' gate/up in ONE launch (every workgroup sums the slabs and routes its row
+      // itself), then the down projection
+      if (gu_chain) {
+        MN_TRY(moe_gate_up_routed(m->wfmt, w.h, H, m->ln2[l], m->rms_eps, m->gate[l], m->w_gate_up[l], (int64_t)2 * I * H,
+                                  m->wfmt ? m->w_gate_up_scale[l] : nullptr, (int64_t)2 * I * mn_wq_scales_per_row(m->wfmt, H), M, H, I, E, m->top_k,
+                                  S, m->norm_topk_prob, w.hmid, (int64_t)n_slot * I, w.ti, w.tw, w.logits, w.pp, nz, (int64_t)M * H, stream));
+        MN_TRY(moe_down_rows(m->wfmt, w.hmid, (int64_t)n_slot * I, m->w_down[l], (int64_t)H * I, m->wfmt ? m->w_down_scale[l] : nullptr,
+                             (int64_t)H * mn_wq_scales_per_row(m->wfmt, I), w.ti, w.tw, w.h, H, w.h, H, M, H, I, n_slot, stream, w.pp, nz,
+                             (int64_t)M * H));
+        nz2 = 0;
+        continue;
+      }
       // <= 4 rows on the fp32-FMA expert kernels: residual + RMSNorm(ln2) + gate + top-k in ONE launch (decode_ops.hip) instead of glue,
       // gate launch and the one-workgroup top-k
       if (!grouped && g_chain_router && moe_router_rows_ok(M, H, E)) {
@@ -1316,7 +1333,7 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
         moe_gate_up_ok(m->wfmt, H, I, m->n_experts, m->top_k, m->n_shared_slots) && moe_down_ok(m->wfmt, n_slot, H, I)) {
       MN_TRY(moe_gate_up_routed(m->wfmt, w.h, H, m->ln2[l], m->rms_eps, m->gate[l], m->w_gate_up[l], (int64_t)2 * I * H,
                                 m->wfmt ? m->w_gate_up_scale[l] : nullptr, (int64_t)2 * I * mn_wq_scales_per_row(m->wfmt, H), M, H, I, m->n_experts, m->top_k,
-                                m->n_shared_slots, m->norm_topk_prob, w.hmid, (int64_t)n_slot * I, w.ti, w.tw, w.logits, stream));
+                                m->n_shared_slots, m->norm_topk_prob, w.hmid, (int64_t)n_slot * I, w.ti, w.tw, w.logits, nullptr, 0, 0, stream));
       MN_TRY(moe_down_rows(m->wfmt, w.hmid, (int64_t)n_slot * I, m->w_down[l], (int64_t)H * I, m->wfmt ? m->w_down_scale[l] : nullptr, (int64_t)H * mn_wq_scales_per_row(m->wfmt, I), w.ti, w.tw, w.h, H, w.h, H, M, H, I, n_slot, stream));
       continue;
     }

@@ -32,6 +32,7 @@ struct DownArgs {
   const float* res; int64_t ld_res;                 // [batch][H]
   float* out; int64_t ld_out;
   int H, I, n_slot;
+  const float* P; int nz; int64_t slab;             // optional: res[b][n] += sum of nz partial slabs P [nz][batch][H] (the decoder chain's attention output projection)
 };
 
 template <int NCK, int WQ>                          // WQ 0: bf16 weights, 1: e4m3 bytes + row scales (on the K sums), 2: int8 (quanto), 3: NF4
@@ -83,7 +84,10 @@ __global__ __launch_bounds__(MAX_SLOTS * 64) void moe_down_kernel(const DownArgs
   }
   // (the epilogue's residual is requested now, behind the weights, and used after the reduction)
   float r_old = 0.f;
-  if (tid < RW && n0 + tid < a.H && a.res) r_old = a.res[(int64_t)b * a.ld_res + n0 + tid];
+  if (tid < RW && n0 + tid < a.H && a.res) {
+    r_old = a.res[(int64_t)b * a.ld_res + n0 + tid];
+    for (int z = 0; z < a.nz; ++z) r_old += a.P[(int64_t)z * a.slab + (int64_t)b * a.H + n0 + tid];      // (slab order, like llm_glue_kernel)
+  }
   float acc[RW];
 #pragma unroll
   for (int r = 0; r < RW; ++r) acc[r] = 0.f;
@@ -146,10 +150,10 @@ bool moe_down_ok(int wfmt, int n_slot, int H, int I) {
 
 int moe_down_rows(int wfmt, const float* hmid, int64_t ld_hmid, const void* W, int64_t w_stride, const float* wscale, int64_t wscale_stride,
                   const int32_t* ti, const float* tw, const float* res, int64_t ld_res, float* out, int64_t ld_out, int batch, int H, int I,
-                  int n_slot, void* stream) {
+                  int n_slot, void* stream, const float* P, int nz, int64_t slab) {
   MN_CHECK_ARG(hmid && W && ti && tw && out && batch >= 1 && moe_down_ok(wfmt, n_slot, H, I) && (ld_hmid % 4) == 0 &&
                    (((uintptr_t)W) & 15) == 0 && (w_stride % 8) == 0 && (wfmt == MN_W_BF16 || wscale), "moe_down_rows: bad args");
-  const DownArgs a{hmid, ld_hmid, W, w_stride, wscale, wscale_stride, ti, tw, res, ld_res, out, ld_out, H, I, n_slot};
+  const DownArgs a{hmid, ld_hmid, W, w_stride, wscale, wscale_stride, ti, tw, res, ld_res, out, ld_out, H, I, n_slot, P, P ? nz : 0, slab};
   const dim3 grid((unsigned)mn_cdiv(H, RW), (unsigned)batch), block(MAX_SLOTS * 64);
   const int nck = (I + 511) / 512;
   hipStream_t st = mn_stream(stream);

@@ -29,7 +29,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int GU_WAVES = 8;          // = slots per row (top_k + shared) at most
-constexpr int UNITS = 6;             // hidden units per workgroup and wave: 6 x (gate, up) rows x K in flight per lane (192 registers at H = 2048)
+// hidden units per workgroup and wave (template UNITS): 6 x (gate, up) rows x K in flight per lane = 192 registers of bf16 pieces at H = 2048;
+// the byte formats' pieces are half / a quarter as long: 12 units — two rows' launches then fit ONE round of workgroups (118 x 2 <= 256)
 constexpr int GB = 8;                // gate rows per wave (64 experts over 8 waves), requested together: one L2 round trip
 
 struct GateUpArgs {
@@ -41,6 +42,8 @@ struct GateUpArgs {
   int H, I, E, top_k, n_shared, norm_topk_prob;
   float* hmid; int64_t ld_hmid;                      // [batch][n_slot * I]
   int32_t* ti; float* tw; float* logits;             // [batch][n_slot], [batch][n_slot], [batch][E]
+  const float* P; int nz; int64_t slab;               // the decoder chain's form: the row is h + sum of nz partial slabs P [nz][batch][H] (slab floats apart); h itself is
+                                                      // NOT updated here (workgroups of a later round would read the updated row): the down projection adds the slabs to its residual
 };
 
 __device__ __forceinline__ float dot8(const u32x2 q, const float* x, float t) {       // eight e4m3 weights
@@ -61,7 +64,7 @@ __device__ __forceinline__ float dot8(const u32x4 q, const float* x, float t) {
   return t;
 }
 
-template <int NCK, int WQ>                           // H = NCK x 512; WQ 0: bf16 experts, 1: e4m3 bytes + row scales (on the K sums), 2: int8 (quanto), 3: NF4 (w8_codec.h)
+template <int NCK, int WQ, int UNITS>                // H = NCK x 512; WQ 0: bf16 experts, 1: e4m3 bytes + row scales (on the K sums), 2: int8 (quanto), 3: NF4 (w8_codec.h)
 __global__ __launch_bounds__(GU_WAVES * 64) void moe_gate_up_routed_kernel(const GateUpArgs a) {
   __shared__ float lg[64];
   const int tid = threadIdx.x, lane = tid & 63, s = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,7 +77,11 @@ __global__ __launch_bounds__(GU_WAVES * 64) void moe_gate_up_routed_kernel(const
 #pragma unroll
   for (int c = 0; c < NCK; ++c) {
     const int k = c * 512 + lane * 8;
-    const f4 lo = *reinterpret_cast<const f4*>(xr + k), hi = *reinterpret_cast<const f4*>(xr + k + 4);
+    f4 lo = *reinterpret_cast<const f4*>(xr + k), hi = *reinterpret_cast<const f4*>(xr + k + 4);
+    if (a.P) {                                       // (slab order, like llm_glue_kernel: the same bits as the glue launch it replaces)
+      const float* pp = a.P + (int64_t)b * H + k;
+      for (int z = 0; z < a.nz; ++z) { lo += *reinterpret_cast<const f4*>(pp + z * a.slab); hi += *reinterpret_cast<const f4*>(pp + z * a.slab + 4); }
+    }
     x[c][0] = lo.x; x[c][1] = lo.y; x[c][2] = lo.z; x[c][3] = lo.w; x[c][4] = hi.x; x[c][5] = hi.y; x[c][6] = hi.z; x[c][7] = hi.w;
     nw[c] = *reinterpret_cast<const u32x4*>(a.norm_w + k);
   }
@@ -201,24 +208,29 @@ bool moe_gate_up_ok(int wfmt, int H, int I, int E, int top_k, int n_shared) {
 
 int moe_gate_up_routed(int wfmt, const float* h, int64_t ldh, const bf16_t* norm_w, float eps, const bf16_t* gate_w, const void* W, int64_t w_stride,
                        const float* wscale, int64_t wscale_stride, int batch, int H, int I, int E, int top_k, int n_shared, int norm_topk_prob,
-                       float* hmid, int64_t ld_hmid, int32_t* ti, float* tw, float* logits, void* stream) {
+                       float* hmid, int64_t ld_hmid, int32_t* ti, float* tw, float* logits, const float* P, int nz, int64_t slab, void* stream) {
   MN_CHECK_ARG(h && norm_w && gate_w && W && hmid && ti && tw && batch >= 1 && moe_gate_up_ok(wfmt, H, I, E, top_k, n_shared) &&
                    (ldh % 4) == 0 && (((uintptr_t)W) & 15) == 0 && (((uintptr_t)gate_w) & 15) == 0 && (w_stride % 8) == 0 &&
-                   (wfmt == MN_W_BF16 || wscale), "moe_gate_up_routed: bad args");
-  const GateUpArgs a{h, ldh, norm_w, eps, gate_w, W, w_stride, wscale, wscale_stride, H, I, E, top_k, n_shared, norm_topk_prob, hmid, ld_hmid, ti, tw, logits};
-  const dim3 grid((unsigned)mn_cdiv(I, UNITS), (unsigned)batch), block(GU_WAVES * 64);
+                   (wfmt == MN_W_BF16 || wscale) && (!P || (nz >= 1 && ldh == H)), "moe_gate_up_routed: bad args");
+  const GateUpArgs a{h, ldh, norm_w, eps, gate_w, W, w_stride, wscale, wscale_stride, H, I, E, top_k, n_shared, norm_topk_prob, hmid, ld_hmid, ti, tw, logits,
+                     P, nz, slab};
+  // two rows in a byte format: 12 units per wave — both rows' workgroups are resident at once (one round trip for the launch)
+  const bool wide = batch >= 2 && wfmt != MN_W_BF16 && 2 * mn_cdiv(I, 12) <= 256;
+  const dim3 grid((unsigned)mn_cdiv(I, wide ? 12 : 6), (unsigned)batch), block(GU_WAVES * 64);
   hipStream_t st = mn_stream(stream);
-#define MN_GU(WQ_)                                                                                          \
-  do {                                                                                                      \
-    switch (H / 512) {                                                                                      \
-      case 1: hipLaunchKernelGGL((moe_gate_up_routed_kernel<1, WQ_>), grid, block, 0, st, a); break;        \
-      case 2: hipLaunchKernelGGL((moe_gate_up_routed_kernel<2, WQ_>), grid, block, 0, st, a); break;        \
-      case 3: hipLaunchKernelGGL((moe_gate_up_routed_kernel<3, WQ_>), grid, block, 0, st, a); break;        \
-      default: hipLaunchKernelGGL((moe_gate_up_routed_kernel<4, WQ_>), grid, block, 0, st, a); break;       \
-    }                                                                                                       \
+#define MN_GU2(WQ_, U_)                                                                                         \
+  do {                                                                                                          \
+    switch (H / 512) {                                                                                          \
+      case 1: hipLaunchKernelGGL((moe_gate_up_routed_kernel<1, WQ_, U_>), grid, block, 0, st, a); break;        \
+      case 2: hipLaunchKernelGGL((moe_gate_up_routed_kernel<2, WQ_, U_>), grid, block, 0, st, a); break;        \
+      case 3: hipLaunchKernelGGL((moe_gate_up_routed_kernel<3, WQ_, U_>), grid, block, 0, st, a); break;        \
+      default: hipLaunchKernelGGL((moe_gate_up_routed_kernel<4, WQ_, U_>), grid, block, 0, st, a); break;       \
+    }                                                                                                           \
   } while (0)
-  if (wfmt == MN_W_FP8_E4M3) MN_GU(1); else if (wfmt == MN_W_INT8) MN_GU(2); else if (wfmt == MN_W_NF4) MN_GU(3); else MN_GU(0);
+#define MN_GU(WQ_) do { if (wide) MN_GU2(WQ_, 12); else MN_GU2(WQ_, 6); } while (0)
+  if (wfmt == MN_W_FP8_E4M3) MN_GU(1); else if (wfmt == MN_W_INT8) MN_GU(2); else if (wfmt == MN_W_NF4) MN_GU(3); else MN_GU2(0, 6);
 #undef MN_GU
+#undef MN_GU2
   MN_CHECK_LAUNCH("moe_gate_up_routed");
   return MN_OK;
 }

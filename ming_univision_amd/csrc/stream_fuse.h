@@ -57,11 +57,13 @@ int rf_blocks_persist(int wfmt, float* h, bf16_t* Y3, int M, int w, int hid, con
 bool moe_down_ok(int wfmt, int n_slot, int H, int I);
 int moe_down_rows(int wfmt, const float* hmid, int64_t ld_hmid, const void* W, int64_t w_stride, const float* wscale, int64_t wscale_stride,
                   const int32_t* ti, const float* tw, const float* res, int64_t ld_res, float* out, int64_t ld_out, int batch, int H, int I,
-                  int n_slot, void* stream);
+                  int n_slot, void* stream, const float* P = nullptr, int nz = 0, int64_t slab = 0);
 
 // ---- router + expert gate/up of a 1-row decode step in ONE launch (moe_gate_up.hip): every workgroup routes its row itself, wave s
-// streams hidden units of the slot-s expert.  Writes hmid [batch][n_slot * I], and (one workgroup per row) ti / tw / logits.
+// streams hidden units of the slot-s expert.  Writes hmid [batch][n_slot * I], and (one workgroup per row) ti / tw / logits.  P != NULL
+// (the decoder chain at 2 rows): the row is h + the nz partial slabs P [nz][batch][H] of the attention output projection
+// (h is not updated: moe_down_rows adds the same slabs to its residual).
 bool moe_gate_up_ok(int wfmt, int H, int I, int E, int top_k, int n_shared);
 int moe_gate_up_routed(int wfmt, const float* h, int64_t ldh, const bf16_t* norm_w, float eps, const bf16_t* gate_w, const void* W, int64_t w_stride,
                        const float* wscale, int64_t wscale_stride, int batch, int H, int I, int E, int top_k, int n_shared, int norm_topk_prob,
-                       float* hmid, int64_t ld_hmid, int32_t* ti, float* tw, float* logits, void* stream);
+                       float* hmid, int64_t ld_hmid, int32_t* ti, float* tw, float* logits, const float* P, int nz, int64_t slab, void* stream);

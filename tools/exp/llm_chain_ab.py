@@ -25,8 +25,10 @@ for rows in (2, 3, 4):
     res = {}
     for rnd in range(3):
         for mx in (32, 32 | (1 << 16), 1, 2):
-            L.mn_llm_tune_chain(1 if mx == 2 else mx)
-            L.mn_moe_tune_gate_up(1, 4 if mx == 2 else 1)      # arm 2: the fp32-FMA sequence with the one-launch router + gate/up at every row count
+            L.mn_llm_tune_chain(1 if mx == 2 else (32 if mx == 32 | (1 << 16) else mx))
+            # arm 32: the shipped chain (router + gate/up in one launch at 2 rows); arm 32|1<<16: the chain with the separate router launch and the pair launch;
+            # arm 1: the fp32-FMA sequence; arm 2: that sequence with the one-launch router + gate/up at every row count
+            L.mn_moe_tune_gate_up(1, (4 if mx == 2 else 1) | ((0 if mx == 32 | (1 << 16) else 2) << 8) | (1 << 16))      # (bit 16: the one-launch form for bf16 / e4m3 too)
             run(); torch.cuda.synchronize()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -36,9 +38,9 @@ for rows in (2, 3, 4):
     d = (res[32][0][1] - res[1][0][1]).abs().max().item() / res[32][0][1].abs().max().item()
     old = res[32 | (1 << 16)]
     d2 = (res[32][0][1] - old[0][1]).abs().max().item() / res[32][0][1].abs().max().item()
-    print(f"{weights} {rows} rows: chain with glue + gate launch + top-k launch {min(t for t, _ in old):.3f} ms ({', '.join('%.3f' % t for t, _ in old)}), differs by {d2:.1e}; "
-          f"chain with the one-launch router {min(t for t, _ in res[32]):.3f} ms ({', '.join('%.3f' % t for t, _ in res[32])}); "
+    print(f"{weights} {rows} rows: chain with the router launch + pair launch {min(t for t, _ in old):.3f} ms ({', '.join('%.3f' % t for t, _ in old)}), differs by {d2:.1e}; "
+          f"chain with router + gate/up in ONE launch {min(t for t, _ in res[32]):.3f} ms ({', '.join('%.3f' % t for t, _ in res[32])}); "
           f"fp32-FMA sequence {min(t for t, _ in res[1]):.3f} ms ({', '.join('%.3f' % t for t, _ in res[1])}); "
           f"fp32-FMA sequence with the one-launch router + gate/up {min(t for t, _ in res[2]):.3f} ms ({', '.join('%.3f' % t for t, _ in res[2])}); hidden states differ by {d:.1e}", flush=True)
 L.mn_llm_tune_chain(32)
-L.mn_moe_tune_gate_up(1, 1)
+L.mn_moe_tune_gate_up(1, 1 | (2 << 8))
