@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MN_VERSION 123 /* 0.1.23: ABI guards mn_sizeof_* / mn_struct_layout.  0.1.20: fp8 weight mode (section 7): wfmt / row-scale fields at the END of mn_skinny_args, mn_rf_head,
+#define MN_VERSION 124 /* 0.1.24: mn_persist_set_status_word; mn_tp_allreduce PUSH|REDUCE above the one-shot row limit implies GATHER.  0.1.23: ABI guards mn_sizeof_* / mn_struct_layout.  0.1.20: fp8 weight mode (section 7): wfmt / row-scale fields at the END of mn_skinny_args, mn_rf_head,
                           mn_llm and mn_llm_tp (zero = bf16: callers of 0.1.10 that zero-fill the structs are unchanged),
                           mn_quant_fp8_rows / mn_dequant_fp8_rows / mn_stream_mfma_w8 / mn_stream_mfma_grouped_w8 */
 
@@ -436,6 +436,13 @@ typedef struct mn_rf_head {
  * noise [n_images, target] fp32; latent_out [n_images, target] fp32 (all CFG rows of an image carry the same
  * latent).  n_images = 1 is the reference's batch-size-1 call.  Workspace: mn_rf_workspace_bytes(h, rows). */
 MN_API size_t mn_rf_workspace_bytes(const mn_rf_head* h, int rows);
+/* (0.1.24) At <= 2 rows the sampler runs as ONE persistent launch whose phases are separated by an in-launch grid barrier (every
+ * workgroup must be resident).  A barrier wait is bounded (2 s): on expiry the result is NaN in every workgroup — and, because a
+ * launcher never synchronises, the library raises the CALLER's status word so the host can tell "NaN because a co-tenant process /
+ * a CU mask kept the grid from being resident" from a numerical failure: register one zero-initialised uint32 of DEVICE memory per
+ * process (NULL = off; the word is the only process state the library keeps besides the launch-ordering event), read it at any host
+ * sync, non-zero = a wait expired since it was last cleared (0x300; clear it yourself).  Remedy: MINGNATIVE_RF_PERSIST=0 (launch chain). */
+MN_API int mn_persist_set_status_word(uint32_t* device_word);
 /* Rows one call accepts: 64 (weight-streaming kernels), or 2048 when every width is a multiple of 64 — then calls with more
  * than 64 rows take the wide route (each Linear a 256 x 256-tile MFMA GEMM on bf16 hi/lo operands, gemm256.hip). */
 MN_API int mn_rf_max_rows(const mn_rf_head* h);
@@ -480,6 +487,11 @@ MN_API int mn_llm_step(const mn_llm* m, const float* x, int64_t ldx, int x_row_d
                 const int32_t* row_seq, const int32_t* row_slot, const int32_t* row_pos, const int32_t* row_len,
                 const uint8_t* key_mask, int64_t ld_mask, float* kv_cache, int n_seq, int64_t t_max,
                 float* hidden_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Diagnostic (0.1.24; parity tests with teacher-forced routing): while `capture` is non-NULL every mn_llm_step* call copies each layer's
+ * routing — int32 [n_layers][M][top_k + n_shared_slots]: the chosen expert ids in the path's own slot order, then the shared
+ * pseudo-experts n_experts + j — to it, on the call's stream.  Process-global, not thread-safe; NULL (default) = off. */
+MN_API int mn_llm_route_capture(int32_t* capture);
 
 /* mn_llm_step with flags.  MN_STEP_DISTINCT_SEQUENCES: every row belongs to a different cache sequence and row_len == row_slot + 1
  * (a decode step of independent conversations / CFG rows — NOT a prefill chunk, whose rows attend each other's new K / V lines): the

@@ -21,6 +21,7 @@ MN_DEV_API void mn_stream_tune_plan_k(int K, int kch, int nw);          /* strea
 MN_DEV_API void mn_stream_tune_w8(int depth);                           /* stream_mfma.hip fp8 form: weight chunks in flight per wave (1 or 2) */
 MN_DEV_API void mn_moe_tune_down(int on);                               /* engine.hip: 1- / 2-row MoE down projection on moe_down.hip (1, default) or the K-segment skinny kernel (0) */
 MN_DEV_API void mn_rf_kc_trace(void* buf);                               /* stream_kc.hip: device buffer of [workgroups][2 x blocks][8] uint64 clock stamps (100 MHz) of the persistent launch (0: phase start, 1: operand image ready, 2: stream done, 3: epilogue done, 4: arrived, 5: next phase's weights requested, 6: barrier passed), or NULL */
+MN_DEV_API void mn_rf_kc_fault(int wg, unsigned wait_ms);                /* stream_kc.hip, tests: workgroup `wg` of every persistent launch arrives 3 x wait_ms late and the barrier waits give up after wait_ms (wg < 0, 0: off, 2 s) */
 MN_DEV_API void mn_rf_kc_persist_all(int on);                            /* stream_kc.hip: the persistent launches for int8 heads too (default: bf16, e4m3 and NF4) */
 MN_DEV_API void mn_rf_kc_tune(int rd12, int rd3);                         /* stream_kc.hip: weight chunks in flight per wave of w12' (1..3) / w3' (1, 2, 4) */
 MN_DEV_API void mn_rf_tune_fuse(int on);                                /* engine.hip, RF chain: bit 0 = SwiGLU glue folded into w3's prologue at <= 4 rows, bit 1 = the Euler-step boundary as one launch, bit 2 = bf16 adaLN through the GEMM instead of the streaming launch, bit 3 = K-complete launches OFF, bit 4 = the persistent per-step launch OFF, bit 5 = the whole-sampler launch OFF (default 3) */

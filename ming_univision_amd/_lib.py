@@ -207,6 +207,8 @@ SYMBOLS = {
     "mn_bf16_to_f32": (_i, [_p, _p, _i64, _p]),
     "mn_f32_split_bf16": (_i, [_p, _p, _p, _i64, _p]),
     "mn_rf_workspace_bytes": (_sz, [C.POINTER(RfHead), _i]),
+    "mn_persist_set_status_word": (_i, [_p]),
+    "mn_llm_route_capture": (_i, [_p]),
     "mn_rf_max_rows": (_i, [C.POINTER(RfHead)]),
     "mn_llm_max_rows": (_i, [C.POINTER(Llm)]),
     "mn_semdec_max_rows": (_i, [C.POINTER(SemDec)]),
@@ -263,11 +265,38 @@ def lib():
         fn = getattr(handle, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if handle.mn_version() < 123:
+    if handle.mn_version() < 124:
         raise RuntimeError("libmingnative.so is too old")
     check_struct_layouts(handle)
     _lib = handle
     return _lib
+
+
+_persist_word = None
+
+
+def persist_status_word(device):
+    """The process's sticky status word of the persistent launches (mn_persist_set_status_word): one zeroed int32 in HBM, registered
+    with the library at first use.  A grid-barrier wait that expires raises it; persist_check() reads it at a host sync."""
+    global _persist_word
+    if _persist_word is None:
+        import torch
+        _persist_word = torch.zeros(1, dtype=torch.int32, device=device)
+        check(lib().mn_persist_set_status_word(ptr(_persist_word)), "mn_persist_set_status_word")
+    return _persist_word
+
+
+def persist_check():
+    """Host sync point: raise if a persistent launch gave up waiting at its grid barrier since the last check (its results are NaN)."""
+    if _persist_word is None:
+        return
+    e = int(_persist_word.item())
+    if e:
+        _persist_word.zero_()
+        raise RuntimeError(
+            "persistent RF-sampler launch: a grid-barrier wait expired (status 0x%x) — not every workgroup of the launch was resident "
+            "(another process on this GPU, a CU mask, or a second persistent launch); the affected results are NaN.  Set "
+            "MINGNATIVE_RF_PERSIST=0 to run the sampler as a launch chain." % e)
 
 
 def check(rc, what=""):

@@ -789,6 +789,8 @@ def generate_images(dec: BailingMoeDecoder, rf, tok, start_embed, past_lens, att
     sem_b = torch.cat([r.sems for r in runs], dim=1).transpose(0, 1).contiguous()
     hidden = torch.cat([r.hidden for r in runs], dim=0)
     image = tok.forward_pixel_decoder(sem_b) if decode_pixels else None
+    if hasattr(rf, "check_err"):         # persistent sampler launches: an expired grid-barrier wait (NaN latents) raises here — one device
+        rf.check_err()                   # word read AFTER the pixel decoder is enqueued (the caller's own sync comes next anyway)
     am_out = [torch.cat((a, torch.ones(rpi, n_tok, dtype=a.dtype)), dim=-1) for a in ams]
     return dict(image=image, latents=latents.transpose(0, 1), sem=sem_b, last_hidden=hidden, attention_mask=am_out,
                 cache_len=[p + n_tok + 1 for p in past_lens])

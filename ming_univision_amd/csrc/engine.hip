@@ -966,6 +966,15 @@ __global__ __launch_bounds__(1024) void moe_route_group_kernel(const float* __re
   }
 }
 
+// Diagnostic (tests: teacher-forced routing parity, mn_llm_route_capture): when set, every layer's routing [M][n_slot] int32 — the top-k
+// expert ids, then the shared pseudo-experts — is copied to capture + l * M * n_slot right after the layer's router has run.
+static int32_t* g_route_capture = nullptr;
+static inline void route_capture(int l, const int32_t* ti, int M, int n_slot, hipStream_t st) {
+  if (g_route_capture)
+    (void)hipMemcpyAsync(g_route_capture + (size_t)l * M * n_slot, ti, (size_t)M * n_slot * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+}
+extern "C" int mn_llm_route_capture(int32_t* capture) { g_route_capture = capture; return MN_OK; }
+
 #include "wide_llm.inl"
 #include "tp.inl"
 
@@ -1247,6 +1256,7 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
         MN_TRY(moe_gate_up_routed(m->wfmt, w.h, H, m->ln2[l], m->rms_eps, m->gate[l], m->w_gate_up[l], (int64_t)2 * I * H,
                                   m->wfmt ? m->w_gate_up_scale[l] : nullptr, (int64_t)2 * I * mn_wq_scales_per_row(m->wfmt, H), M, H, I, E, m->top_k,
                                   S, m->norm_topk_prob, w.hmid, (int64_t)n_slot * I, w.ti, w.tw, w.logits, w.pp, nz, (int64_t)M * H, stream));
+        route_capture(l, w.ti, M, n_slot, st);
         MN_TRY(moe_down_rows(m->wfmt, w.hmid, (int64_t)n_slot * I, m->w_down[l], (int64_t)H * I, m->wfmt ? m->w_down_scale[l] : nullptr,
                              (int64_t)H * mn_wq_scales_per_row(m->wfmt, I), w.ti, w.tw, w.h, H, w.h, H, M, H, I, n_slot, stream, w.pp, nz,
                              (int64_t)M * H));
@@ -1258,6 +1268,7 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
       if (!grouped && g_chain_router && moe_router_rows_ok(M, H, E)) {
         MN_TRY(moe_router_rows(w.h, w.pp, nz, m->ln2[l], m->rms_eps, m->gate[l], M, H, E, m->top_k, m->norm_topk_prob, S, w.xn, w.ti, w.tw,
                                w.logits, stream));
+        route_capture(l, w.ti, M, n_slot, st);
         goto experts_2rows;
       }
       // glue: h += dense partials; RMSNorm(ln2) -> xn (fp32 for the 2-row expert kernels) and yh (gate + expert operand)
@@ -1270,6 +1281,7 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
       hipLaunchKernelGGL(moe_route_group_kernel, dim3(1), dim3(1024), 0, st, (const float*)w.pp, nz, M, E, m->top_k,
                          m->norm_topk_prob, S, w.tw, w.ti, G, grouped ? w.moe.off : (int32_t*)nullptr, w.moe.xrows,
                          w.moe.pair_pos);
+      route_capture(l, w.ti, M, n_slot, st);
       if (grouped) {
         nz = stream_grouped(m->wfmt, w.yh, M, m->w_gate_up[l], (int64_t)2 * I * H, m->wfmt ? m->w_gate_up_scale[l] : nullptr, 2 * I,
                             w.moe.p1, P, w.moe.off, w.moe.xrows, G, M, 2 * I, H, stream);
@@ -1334,6 +1346,7 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
       MN_TRY(moe_gate_up_routed(m->wfmt, w.h, H, m->ln2[l], m->rms_eps, m->gate[l], m->w_gate_up[l], (int64_t)2 * I * H,
                                 m->wfmt ? m->w_gate_up_scale[l] : nullptr, (int64_t)2 * I * mn_wq_scales_per_row(m->wfmt, H), M, H, I, m->n_experts, m->top_k,
                                 m->n_shared_slots, m->norm_topk_prob, w.hmid, (int64_t)n_slot * I, w.ti, w.tw, w.logits, nullptr, 0, 0, stream));
+      route_capture(l, w.ti, M, n_slot, st);
       MN_TRY(moe_down_rows(m->wfmt, w.hmid, (int64_t)n_slot * I, m->w_down[l], (int64_t)H * I, m->wfmt ? m->w_down_scale[l] : nullptr, (int64_t)H * mn_wq_scales_per_row(m->wfmt, I), w.ti, w.tw, w.h, H, w.h, H, M, H, I, n_slot, stream));
       continue;
     }
@@ -1341,6 +1354,7 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
     MN_TRY(mn_moe_router(w.h, H, m->ln2[l], m->rms_eps, m->gate[l], m->image_gate ? m->image_gate[l] : nullptr,
                          image_mask, M, H, m->n_experts, m->top_k, m->norm_topk_prob, m->n_shared_slots, w.xn, w.ti,
                          w.tw, w.logits, w.sk_ws, w.sk_ws_bytes, stream));
+    route_capture(l, w.ti, M, n_slot, st);
     if (moe_mfma_ok(m, M)) {
       const int G = m->n_experts + m->n_shared_slots, P = M * n_slot;
       hipLaunchKernelGGL(moe_group_split_kernel, dim3(M + 1), dim3(256), 0, st, w.ti, M, n_slot, G, w.moe.off, w.moe.xrows,

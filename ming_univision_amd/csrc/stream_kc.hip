@@ -18,6 +18,7 @@
 // Two launches per ResBlock, no slabs, no glue.  Weight bytes, MFMA work and per-wave streaming (6 / 4 chunks of 8 KiB per wave; one /
 // two chunks in flight: deeper rings measured slower, as in the K-slice kernel) are those of the K-slice form; all four weight formats (bf16, e4m3, int8, NF4: w8_codec.h) are template instances.
 // Rows >= M of the MFMA's 16-row operand carry copies of the real rows: output rows are independent, the copies' results are never stored.
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
@@ -486,10 +487,13 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_w3_kc_kernel(const W3Args a)
 // REQUEST the next phase's first weight chunks before it waits for the other workgroups: the grid barrier's round trip is covered by
 // loads already in flight.  One workgroup per CU (co-residency: grid <= CU count, checked by the host; LDS > 80 KiB keeps a second
 // workgroup of another launch off the CU), phases = the bodies above, between them a grid barrier in device memory (GridBar): every
-// wave drains its stores, workgroup barrier, one lane releases at agent scope (L2 write-back: the eight XCDs' L2s are not coherent
-// with each other inside a launch) and raises the workgroup's flag; the waiting wave polls the flags with agent-scope loads, acquires
-// (L2 invalidate) and releases its workgroup.  The wait is bounded (wall clock): on expiry the error word is set, h is poisoned with
-// NaN and the launch runs to its end without further waits.
+// wave drains its stores (vmcnt(0)), workgroup barrier, one lane raises the workgroup's flag; wave 0 polls the flags with agent-scope
+// loads and releases its workgroup.  The barrier contains NO release / acquire fence (an L2 write-back + L1 invalidate per barrier
+// measured 6 us): the eight XCDs' L2s are not coherent with each other, so correctness rests on the PAYLOAD — every datum handed between
+// workgroups (h, w3's operand Y, v) MUST be stored write-through (`sc1` buffer stores) and loaded past the L1 (`sc1` loads).  A later
+// phase that reads or writes a hand-off buffer with plain loads / stores is a coherence bug, not a style choice.  The wait is bounded
+// (wall clock): on expiry the error word and the caller's status word are set, the result is NaN in every workgroup (GridBar::poisoned)
+// and the launch runs to its end without further waits.
 constexpr int PB_MAX = 16;
 struct PersistBlk {
   const void* W12; const float* s12; const bf16_t* b12; const bf16_t* ln_g; const bf16_t* ln_b;
@@ -500,6 +504,7 @@ struct PersistArgs {
   const float* mod; int64_t ldmod;                  // block b: shift = mod + 3 w b, scale = shift + w, gate = shift + 2 w
   unsigned* bar;                                    // [0, 256) one flag per workgroup, [256] error word
   unsigned epoch0;                                  // the launch's barriers publish epoch0 + 1, + 2, ...
+  unsigned* status;                                 // the caller's sticky status word (grid_bar.h) or nullptr
   uint64_t wait_ticks;
   uint64_t* trace;                                  // dev library only: [workgroups][2 nblk phases][8 stamps], or NULL
   // the whole sampler in the launch (steps > 0): Euler-step boundaries and the final layer as two more phases per step
@@ -511,6 +516,7 @@ struct PersistArgs {
   float* v;                                         // [M][T]: the final layer's output, handed to the next boundary phase
   float* latent;                                    // [n_images][T]
   uint32_t lds_top;                                 // byte offset of the launch-long LDS state: x [M][T] (<= 512 floats) + 64 floats of scratch
+  int fault_wg;                                     // dev library only: the workgroup that plays "late-resident" (-1: none)
   PersistBlk blk[PB_MAX];
 };
 
@@ -645,7 +651,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const 
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int vb = blockIdx.x, n12 = (p.hid + 31) / 32, n3 = (p.w + 15) / 16;
-  GridBar gb{p.bar, gridDim.x, p.epoch0, p.wait_ticks, 0};
+  GridBar gb{p.bar, gridDim.x, p.epoch0, p.wait_ticks, 0, p.status};
   // ONE register ring for both phases (w12' keeps one chunk in flight, w3' RD3).  Requesting the next phase's chunk 0 EARLY — while
   // this phase's stream runs out — measured slower (its traffic delays the workgroups still streaming,
   // and 32 more live registers spill; profiles/README.md r05): chunk 0 is requested after the arrival.
@@ -667,6 +673,12 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const 
   prefetch<WQ, 1>(s12, wbuf12, r12, lane);      // (neither light phase touches the weight tiles or the ring)
   __syncthreads();
   uint64_t* tr = !whole && p.trace ? p.trace + (size_t)vb * 2 * p.nblk * 8 : nullptr;
+#ifdef MN_DEV_HOOKS
+  if (p.fault_wg == vb) {                           // fault injection (tests): this workgroup is "late-resident" — 3 x the others' patience
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < 3 * p.wait_ticks) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   for (int s = 0; s < nsteps; ++s) {
   const float* mod_s = p.mod + (int64_t)s * p.mod_step;
   if (whole) {
@@ -713,7 +725,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const 
   }
   }
   // a timed-out barrier poisons the state: the caller's result is NaN, never a silently wrong number
-  const int dead = __syncthreads_or(tid < 64 ? gb.dead : 0);
+  const int dead = gb.poisoned();
   if (whole && vb == 0 && tid < p.n_images * p.T) {      // the last Euler update; one row per image leaves (the rows of an image hold the same x)
     const float* xs = reinterpret_cast<const float*>(lds + p.lds_top);
     const int img = tid / p.T, t = tid - img * p.T;
@@ -724,6 +736,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const 
 
 uint64_t* g_kc_trace = nullptr;
 int g_kc_persist_all = 0;            // dev library: the persistent launch for int8 as well (mn_rf_kc_persist_all)
+int g_kc_fault_wg = -1; unsigned g_kc_fault_ms = 0;   // dev library: fault injection of the grid barrier (mn_rf_kc_fault)
 int g_kc_rd12 = 1, g_kc_rd3 = 0;     // weight chunks in flight per wave; rd3 = 0: by format (dev-library A/B knob: mn_rf_kc_tune)
 
 size_t w12_lds(int M, int w, int nw) { return (size_t)2 * M * (w * 2 + 64) + (size_t)nw * 16 * WCH * 2 + (nw * KC_MAX_M * 16 + 16) * sizeof(float); }
@@ -740,6 +753,7 @@ void opt_in(Kern k) {
 extern "C" MN_DEV_API void mn_rf_kc_tune(int rd12, int rd3) { g_kc_rd12 = rd12 & 15; g_kc_rd3 = rd3; }
 extern "C" MN_DEV_API void mn_rf_kc_persist_all(int on) { g_kc_persist_all = on; }
 extern "C" MN_DEV_API void mn_rf_kc_trace(void* buf) { g_kc_trace = static_cast<uint64_t*>(buf); }
+extern "C" MN_DEV_API void mn_rf_kc_fault(int wg, unsigned wait_ms) { g_kc_fault_wg = wg; g_kc_fault_ms = wait_ms; }
 #endif
 
 // Can the ResBlock chain of this shape run as K-complete launches?  (whole chunks per wave, the x images + weight tiles within the
@@ -797,8 +811,10 @@ int rf_blocks_persist(int wfmt, float* h, bf16_t* Y3, int M, int w, int hid, con
   MN_CHECK_ARG(h && Y3 && mod && bar && nblk >= 1 && nblk <= PB_MAX && rf_kc_ok(wfmt, M, w, hid), "rf_blocks_persist: bad args");
   MN_CHECK_ARG(!whole || rf_sampler_persist_ok(M, w, hid, nblk, whole->T, whole->rpi, whole->n_images), "rf_blocks_persist: shape cannot run the whole sampler in one launch");
   PersistArgs p{};
-  p.h = h; p.Y = Y3; p.M = M; p.w = w; p.hid = hid; p.wf = wfmt; p.nblk = nblk; p.mod = mod; p.ldmod = ldmod; p.bar = bar; p.epoch0 = epoch0; p.trace = g_kc_trace;
+  p.h = h; p.Y = Y3; p.M = M; p.w = w; p.hid = hid; p.wf = wfmt; p.nblk = nblk; p.mod = mod; p.ldmod = ldmod; p.bar = bar; p.epoch0 = epoch0; p.trace = g_kc_trace; p.status = mn_persist_status_word();
   p.wait_ticks = 2000ull * 100000ull;               // 2 s of the 100 MHz clock
+  p.fault_wg = g_kc_fault_wg;
+  if (g_kc_fault_ms) p.wait_ticks = (uint64_t)g_kc_fault_ms * 100000ull;
   for (int b = 0; b < nblk; ++b)
     p.blk[b] = PersistBlk{W12[b], wfmt ? s12[b] : nullptr, b12[b], ln_g[b], ln_b[b], W3[b], wfmt ? s3[b] : nullptr, b3[b]};
   const int G = mn_cdiv(hid, 32) > mn_cdiv(w, 16) ? mn_cdiv(hid, 32) : mn_cdiv(w, 16);
@@ -834,6 +850,14 @@ int rf_blocks_persist(int wfmt, float* h, bf16_t* Y3, int M, int w, int hid, con
   else hipLaunchKernelGGL(rf_blocks_persist_kernel<0>, grid, block, lds, st, p);
   mn_persist_order_after(st);
   MN_CHECK_LAUNCH("rf_blocks_persist");
+  return MN_OK;
+}
+
+// (grid_bar.h) the caller's sticky status word: raised (0x300) by a persistent launch whose grid barrier gave up
+static std::atomic<unsigned*> g_persist_status{nullptr};
+unsigned* mn_persist_status_word() { return g_persist_status.load(std::memory_order_relaxed); }
+extern "C" int mn_persist_set_status_word(uint32_t* device_word) {
+  g_persist_status.store(device_word, std::memory_order_relaxed);
   return MN_OK;
 }
 

@@ -198,7 +198,11 @@ extern "C" int mn_allreduce_oneshot(mn_tp_comm* comm, const float* x, int64_t ld
     p.P = x; p.nz = 1; p.slab = 0;
     tp_push(comm, ep, p, M, D, st, gc);
   }
-  if ((phase & MN_TP_GATHER) && gc) tp_reduce_gather(comm, ep, M, gc, st);
+  // PUSH | REDUCE in ONE call is the documented "whole all-reduce" (0.1.2x callers pass 3): above the one-shot row limit the owners'
+  // reduce-and-publish step belongs to it — without it REDUCE would wait for an epoch nobody publishes.  Split-phase callers
+  // (PUSH alone, then GATHER, then REDUCE) are unchanged.
+  const bool whole = (phase & (MN_TP_PUSH | MN_TP_REDUCE)) == (MN_TP_PUSH | MN_TP_REDUCE);
+  if (((phase & MN_TP_GATHER) || whole) && gc) tp_reduce_gather(comm, ep, M, gc, st);
   if (phase & MN_TP_REDUCE) {
     WideGlue g;
     memset(&g, 0, sizeof(g));
@@ -206,7 +210,11 @@ extern "C" int mn_allreduce_oneshot(mn_tp_comm* comm, const float* x, int64_t ld
     if (gc) {
       // the pieces ARE the result: add them to a zero source row — reuse piece 0's own slab as a source is not possible (pieces are
       // concatenated), so the glue reads h = out after clearing it
-      (void)hipMemsetAsync(out, 0, (size_t)M * ldo * sizeof(float), st);
+      // (only the payload: `out` may be a strided view — columns [D, ldo) belong to the caller, and row M - 1 ends at column D)
+      if (hipMemset2DAsync(out, (size_t)ldo * sizeof(float), 0, (size_t)D * sizeof(float), (size_t)M, st) != hipSuccess) {
+        mn_set_error("mn_allreduce_oneshot: hipMemset2DAsync failed");
+        return MN_ELAUNCH;
+      }
       g.h = out; g.ldh = ldo;
     } else {
       // the glue adds the slabs P[0 .. nz) to a source row: take sender 0's slab as the source and sum the other world - 1

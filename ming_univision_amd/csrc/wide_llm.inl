@@ -169,6 +169,7 @@ static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row
     }
     hipLaunchKernelGGL(moe_topk_partials_kernel, dim3(mn_cdiv(M, 4)), dim3(256), 0, st, (const float*)w.pp, p_img, image_mask, nz,
                        (int64_t)M * E, M, E, m->top_k, m->norm_topk_prob, m->n_shared_slots, w.ti, w.tw);
+    route_capture(l, w.ti, M, n_slot, st);
     MN_TRY(mn_moe_sort_tiles(w.ti, M, n_slot, G, w.cnt, w.off, w.perm, w.slot_of, lo_at(LO_LLM_EXPERTS, 1) ? 128 : 256, w.tile_g, w.tile_m0,
                              w.n_tiles, stream));
     // experts: grouped gate/up (rows gathered by perm, SwiGLU + split epilogue), grouped down -> yg [P, H]  (:617-628, 483-484)

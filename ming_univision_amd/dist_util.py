@@ -50,15 +50,25 @@ class ReplicaGroup:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(self, fn, steps):
-        """barrier -> `steps` calls of fn() -> barrier; returns MAX over ranks of the wall time."""
+    def timed(self, fn, steps, step_ms=None):
+        """barrier -> `steps` calls of fn() -> barrier; returns MAX over ranks of the wall time.  step_ms (a list): filled with THIS
+        rank's per-step milliseconds, from events recorded on the current stream between the steps (no extra host sync)."""
+        cuda = step_ms is not None and self.device is not None and torch.device(self.device).type == "cuda"
         self.barrier()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if cuda else None
         t0 = time.perf_counter()
         out = None
-        for _ in range(steps):
+        if cuda:
+            ev[0].record()
+        for i in range(steps):
             out = fn()
+            if cuda:
+                ev[i + 1].record()
         self.barrier()
-        return self.max_over_ranks(time.perf_counter() - t0), out
+        dt = time.perf_counter() - t0
+        if cuda:
+            step_ms.extend(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+        return self.max_over_ranks(dt), out
 
     def total(self, per_rank_units):
         """Whole-job units processed (all ranks do the same amount)."""

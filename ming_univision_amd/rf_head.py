@@ -32,7 +32,9 @@ from .configuration import DEFAULT_VISHEAD_DIFFLOSS, swiglu_hidden
 class RectifiedFlowHead:
     def __init__(self, sd, llm_hidden, vishead_diffloss_config=None, latent_dim=32, prefix="", weights="bf16"):
         """sd: {reference parameter name: bf16 CUDA tensor} holding `vis_head.*` and `diffloss.net.*`.
-        weights: "bf16", or "fp8" = w12 / w3 quantised here to e4m3 + row scales (the bf16 originals are not kept)."""
+        weights: "bf16", or a weight-only mode ("fp8" / "int8" / "int4") = w12 / w3 / adaLN quantised here into streamed codes.  A head
+        BUILT in a weight-only mode keeps no reference to the bf16 originals (the mode exists for its footprint: 2.4 GB of bf16 ResBlock
+        matrices at the 16B-A3B shapes — they are freed as soon as the caller drops `sd`); only a bf16 head keeps them, for to_fp8()."""
         assert weights in _lib.WFMT, f"weights={weights!r}: 'bf16', 'fp8', 'int8' or 'int4'"
         self.weights = weights
         cfg = {**DEFAULT_VISHEAD_DIFFLOSS, **(vishead_diffloss_config or {})}
@@ -68,6 +70,10 @@ class RectifiedFlowHead:
         self._time = {k: g(n + "time_embed.mlp." + k) for k in ("0.weight", "0.bias", "2.weight", "2.bias")}
         self._raw_t, self._raw_lists = dict(self.t), dict(self.lists)      # the checkpoint's tensors: every mode is derived from them, once
         self._apply_mode(weights)
+        if weights != "bf16":
+            # a quantised head must not pin the bf16 matrices it was derived from (to_fp8 is a bf16 head's method)
+            self._raw_t = self._raw_lists = None
+            self._time = {k: v for k, v in self._time.items() if k.endswith("bias")}
 
     def _apply_mode(self, weights):
         """Build the head of weight mode `weights` from the raw bf16 tensors.  Modes that convert every nn.Linear (_lib.FULL_MODEL, the
@@ -146,7 +152,7 @@ class RectifiedFlowHead:
         """A second head on the same HBM tensors in another weight mode — e4m3 (default), "int8" or "int4" — derived from the raw
         bf16 tensors (this head stays usable)."""
         import copy
-        assert self.weights == "bf16" and weights in _lib.W8
+        assert self.weights == "bf16" and weights in _lib.W8 and self._raw_t is not None
         new = copy.copy(self)
         new._apply_mode(weights)
         return new
@@ -187,6 +193,11 @@ class RectifiedFlowHead:
             out.update(self._time_embed_weights)
         return out
 
+    def check_err(self):
+        """Host sync point (reads one device word): raises if a persistent sampler launch gave up at its grid barrier — the latents
+        of that call are NaN by construction; this names the cause (grid_bar.h)."""
+        _lib.persist_check()
+
     def max_rows(self):
         """Rows one sample() accepts: 64, or 2048 when the wide route applies (all widths multiples of 64)."""
         return int(lib().mn_rf_max_rows(C.byref(self.struct)))
@@ -207,6 +218,7 @@ class RectifiedFlowHead:
         assert noise.dtype == torch.float32 and noise.is_cuda and noise.is_contiguous()
         assert noise.numel() == n_images * self.target and rows % n_images == 0
         ws = self._workspace(rows, hidden.device)
+        _lib.persist_status_word(hidden.device)          # (registered once per process: an expired grid-barrier wait is reported, check_err)
         if out is None:
             out = torch.empty(noise.shape, dtype=torch.float32, device=hidden.device)
         assert out.is_contiguous() and out.numel() == n_images * self.target

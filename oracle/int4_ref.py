@@ -6,7 +6,9 @@ The reference's int4 surface is `MingUniVisionInfer(dtype="int4")` (mingunivisio
     BitsAndBytesConfig(load_in_4bit=True, bnb_4bit_compute_dtype=torch.bfloat16, bnb_4bit_quant_type="nf4",
                        llm_int8_skip_modules=["BailingAudioModel"])
 i.e. the third-party `bitsandbytes` (requirements.txt:27, UNPINNED; absent from this image and from /root/reference) behind HF's
-`replace_with_bnb_linear`: every nn.Linear except the output head (and the audio tower) becomes a `Linear4bit` whose weight is stored as
+`replace_with_bnb_linear`: every nn.Linear except the modules of the caller's skip list becomes a `Linear4bit` — the reference's own
+list (the audio tower) REPLACES HF's default one ("keep the output head"), so `lm_head` converts too, as `_lib.FULL_MODEL` and the
+loaders here do — whose weight is stored as
 
     * 4-bit codes into the 16-entry NF4 table — the quantiles of N(0, 1) construction of the QLoRA paper (Dettmers et al. 2023, §3
       "4-bit NormalFloat", appendix E; bitsandbytes `functional.create_normal_map(offset=0.9677083)`), normalised to [-1, 1] with an

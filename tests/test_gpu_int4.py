@@ -244,3 +244,35 @@ def test_int4_facade_dtype_switch(tmp_path):
     assert out.shape[1] == ids.shape[1] + 2 and torch.isfinite(inf4.model.last_generation["latents"]).all()
     with pytest.raises(ValueError):
         MingUniVisionInfer(None, dtype="int3", config=cfg)
+
+
+def test_quantised_head_does_not_pin_the_bf16_matrices():
+    """a head BUILT in a weight-only mode (the model load path) must not keep the bf16 ResBlock matrices it was quantised
+    from — `torch.cuda.memory_allocated` after the caller drops its state dict is the codes + the small tensors, not codes + originals."""
+    import gc
+    from ming_univision_amd.rf_head import RectifiedFlowHead
+    rf_cfg = dict(diffloss_w=512, diffloss_d=4, num_sampling_steps="4", gen_method="flow_matching_swiglu-4")
+    cfg = C.BailingMoeConfig(vocab_size=64, hidden_size=256, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1,
+                             head_dim=128, num_experts=4, num_shared_experts=1, num_experts_per_tok=2, moe_intermediate_size=64)
+    shapes = {k: s for k, s in C.llm_param_shapes(cfg, rf_cfg, 32).items() if k.startswith("vis_head") or k.startswith("diffloss")}
+
+    def footprint(mode):
+        gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
+        base = torch.cuda.memory_allocated()
+        sd = _dev(synth_state_dict(shapes, 3))
+        head = RectifiedFlowHead(sd, cfg.hidden_size, rf_cfg, weights=mode)
+        del sd
+        gc.collect(); torch.cuda.synchronize()
+        used = torch.cuda.memory_allocated() - base
+        assert (head._raw_t is None) == (mode != "bf16")
+        return used, head
+    b16, h16 = footprint("bf16")
+    blocks_bf16 = 2 * sum(w_.numel() for k in ("w12", "w3") for w_ in h16.lists[k])
+    del h16
+    for mode, codes_over_bf16 in (("int4", 0.25 + 4 / 128.0), ("int8", 0.5), ("fp8", 0.5)):
+        used, head = footprint(mode)
+        saved = b16 - used
+        # the ResBlock matrices shrink to their codes; nothing else grows by more than the adaLN codes (+ row scales)
+        ada = head.t["ada_q"].numel() + 4 * head.t["ada_scale"].numel()
+        assert saved >= blocks_bf16 * (1 - codes_over_bf16) - ada - (2 << 20), (mode, b16, used, blocks_bf16)
+        del head

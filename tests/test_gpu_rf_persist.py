@@ -128,3 +128,40 @@ def test_sampler_inside_a_graph_capture_takes_the_launches():
     d = float((out - eager).abs().max() / eager.abs().max())
     print("captured sampler vs eager persistent launch: %.2e" % d)
     assert torch.isfinite(out).all() and d < 1e-5
+
+
+def test_a_late_resident_workgroup_poisons_the_result_and_raises_on_the_host():
+    """one workgroup of the persistent launch arrives after the others' barrier patience has run out (what a co-tenant
+    process or a CU mask does).  Every other workgroup times out, the straggler itself does NOT — it must still see the error word:
+    the latents are NaN (never finite-but-wrong), the caller's status word is raised and RectifiedFlowHead.check_err() names the
+    cause; the next call (no fault) is bit-identical to an undisturbed one.  Runs on libmingnative_dev.so (the fault hook)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import tools.devlib\n"
+        "from ming_univision_amd._lib import lib\n"
+        "from tests.test_gpu_rf_persist import _head, LLM_HIDDEN\n"
+        "rf = _head('bf16')\n"
+        "g = torch.Generator(device='cuda').manual_seed(3)\n"
+        "h = torch.randn(2, LLM_HIDDEN, device='cuda', generator=g); n = torch.randn(1, 32, device='cuda', generator=g)\n"
+        "good = rf.sample(h, n, n_images=1).clone(); rf.check_err()\n"
+        "assert torch.isfinite(good).all()\n"
+        "for wg in (0, 5, 255):\n"
+        "    lib().mn_rf_kc_fault(wg, 3)\n"
+        "    bad = rf.sample(h, n, n_images=1).clone()\n"
+        "    torch.cuda.synchronize()\n"
+        "    assert torch.isnan(bad).all(), (wg, bad)\n"
+        "    try:\n"
+        "        rf.check_err(); raise SystemExit('check_err did not raise for wg %%d' %% wg)\n"
+        "    except RuntimeError as e:\n"
+        "        assert 'MINGNATIVE_RF_PERSIST=0' in str(e)\n"
+        "    lib().mn_rf_kc_fault(-1, 0)\n"
+        "    again = rf.sample(h, n, n_images=1); rf.check_err()\n"
+        "    assert torch.equal(again, good), wg\n"
+        "print('FAULT_OK')\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "FAULT_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])

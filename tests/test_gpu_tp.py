@@ -94,6 +94,36 @@ def test_allreduce_oneshot_concurrent_ranks_really_wait():
             assert torch.equal(outs[r], xs[0] + xs[1])
 
 
+def test_allreduce_phase3_above_the_one_shot_limit_and_strided_out():
+    """(1) phase = PUSH | REDUCE (3) was the documented whole all-reduce before the two-shot form existed: above 16 rows it
+    must still complete (the owners' gather step is implied), not wait for an epoch nobody publishes; (2) the two-shot consumer clears
+    `out` before adding the pieces — only the payload columns: a strided `out` keeps what the caller holds in columns [D, ldo) and
+    nothing is written past the last row."""
+    import ctypes as C
+    from ming_univision_amd._lib import check, current_stream, lib, ptr
+    from ming_univision_amd.tp import TpCommunicator
+    comms = TpCommunicator.simulated(2, rows_cap=40, width=256)
+    assert comms[0].allreduce_segments(40, 256) == 2
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(40, 256, generator=g).cuda() for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ldo = 256 + 64
+    bufs = [torch.full((40 * ldo + 64,), 7.0, device="cuda") for _ in range(2)]        # 64 guard floats behind the last row
+    torch.cuda.synchronize()
+    for r in (0, 1):
+        comms[r].struct.wait_ms = 2000
+        with torch.cuda.stream(streams[r]):
+            check(lib().mn_allreduce_oneshot(C.byref(comms[r].struct), ptr(xs[r]), 256, ptr(bufs[r]), ldo, 40, 256,
+                                             TpCommunicator.PUSH | TpCommunicator.REDUCE, current_stream()), "mn_allreduce_oneshot")
+    torch.cuda.synchronize()
+    for r in (0, 1):
+        comms[r].check_err()
+        out = bufs[r][:40 * ldo].view(40, ldo)
+        assert torch.equal(out[:, :256], xs[0] + xs[1])
+        assert bool((out[:, 256:] == 7.0).all()) and bool((bufs[r][40 * ldo:] == 7.0).all())
+        assert comms[r].struct.epoch == 2
+
+
 def test_allreduce_wait_that_expires_poisons_the_rows_and_raises():
     """A sender that never pushes (dead peer / diverged launch order): the consumer's wall-time-bounded wait (200 ms here, 30 s by
     default) expires, the rows come out as NaN — never as a sum of stale slabs — and check_err() raises naming the sender."""
