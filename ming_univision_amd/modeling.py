@@ -386,10 +386,12 @@ class MingUniVisionForConditionalGeneration:
                  pixel_values=None, image_grid_thw=None, past_key_values=None, output_image_prefix="output",
                  image_gen_temperature=1.0, image_gen_text_cfg=3.0, image_gen_image_cfg=1.1, max_new_tokens=512,
                  use_cache=True, forced_first_token=None, do_sample=False, temperature=1.0, top_k=50, top_p=1.0,
-                 generator=None, **generate_kwargs):
+                 generator=None, image_noises=None, **generate_kwargs):
         """Decode with the `<image>` trigger (modeling_bailingmm.py:206-301; modeling_bailing_moe.py:1769-1796).
         Returns the LongTensor `sequences` [1, T_in + n_new] like HF generate.  `forced_first_token` (extension
-        used by benchmarks/tests with random weights) overrides the first generated id.
+        used by benchmarks/tests with random weights) overrides the first generated id; `image_noises` (extension: fp32
+        [num_image_tokens_for_gen + 1, latent_dim]) replaces the noise RectifiedFlowLoss.sample would draw for the call's image
+        (diff_loss_rf_swiglu.py:117-122: torch.randn per visual token) — how a recorded run of the reference is replayed.
 
         Text tokens are picked greedily (the checkpoint's generation config: do_sample = false, mingunivision/config.json:30) or,
         with `do_sample=True`, drawn the way HF generate draws them — the kwargs the reference forwards to it (:249-262):
@@ -489,7 +491,11 @@ class MingUniVisionForConditionalGeneration:
                     n_tok = n_img_tok
                     if cache_len + n_tok + 1 > self.model.t_max:
                         raise ValueError(f"{cache_len} cached tokens + {n_tok + 1} image slots exceed the KV arena (t_max = {self.model.t_max})")
-                    noises = torch.randn(n_tok + 1, self.vision.latent_dim, generator=self.noise_generator, device=dev)
+                    if image_noises is not None:
+                        noises = image_noises.to(dev, torch.float32).contiguous()
+                        assert noises.shape == (n_tok + 1, self.vision.latent_dim), tuple(noises.shape)
+                    else:
+                        noises = torch.randn(n_tok + 1, self.vision.latent_dim, generator=self.noise_generator, device=dev)
                     # NB: the reference swallows the caller's CFG scales and always runs 3.0 / 1.1
                     out = generate_image(self.model, self.rf, self.vision, x, cache_len, torch.cat((am, one), 1), unc, tunc,
                                          noises, temperature=image_gen_temperature, text_cfg=3.0, image_cfg=1.1)

@@ -379,6 +379,116 @@ def gen_processor():
     print("wrote", os.path.join(GOLDEN, "processor.json"))
 
 
+def gen_multiround():
+    """The multi-round state machine captured from the REFERENCE's own
+    MingUniVisionForConditionalGeneration.generate (modeling_bailingmm.py:206-301) -> BailingMoeForCausalLM.generate / forward's
+    `<image>` branch (modeling_bailing_moe.py:1769-1796) / prepare_inputs_for_generation (:1968-2080), driven by the installed
+    transformers' greedy loop through ref_shim.cache_position_452 (the 4.52.4 `cache_position` contract; nothing of the reference is
+    patched except I/O: MingTok.from_pretrained returns the tiny seeded tokenizer instead of reading ./models/MingTok-Vision, and
+    tensor_to_pil — which hard-codes .cuda() and writes a PNG — hands the image tensor back).
+
+    Conversation, the shape of test_infer_unified.py's editing block, under PAST_MODE = KEEP and = DROP:
+      round 0  image (64 x 64 -> 4 <imagePatch> tokens) + instruction, 3 distinct CFG masks, `<image>` forced as the first new token
+               (a LogitsProcessor: the reference forwards generate kwargs to HF), then two greedy text tokens;
+      round 1  text-only instruction on the carried cache / masks, `<image>` forced again, two greedy tokens;
+      round 2  text-only, nothing forced: four greedy text tokens on top of two generated images.
+    Stored per mode and round: input ids and the three masks handed in, the returned sequences, the three carried masks and the cache
+    length afterwards, the generated image (all CFG rows), every prepare_inputs_for_generation call's bookkeeping
+    (ids seen, cache length, mask length out, new ids, first position id), and layer 0's K cache after the last round."""
+    import torch.nn as nn  # noqa: F401
+    from transformers import LogitsProcessor, LogitsProcessorList
+    ref_shim.install_multimodal()
+    import modeling_bailing_moe as mbm
+    import modeling_bailingmm as mm
+    from configuration_bailing_moe import BailingMoeConfig
+    from configuration_bailingmm import MingUniVisionConfig
+    from mingtok.modeling_mingtok import MingTok
+    from ming_univision_amd.processing import cfg_attention_masks
+    seed = 14
+    llm_dict = dict(TINY_LLM, image_patch_token=498, eos_token_id=1)
+    ROLE, ROLE_E, HUMAN, ASSIST, IMG, IMG_E, PATCH = 490, 491, 300, 301, 496, 497, 498
+    tok = build_ref_mingtok(TINY_MINGTOK, seed)
+    orig_fp, orig_pil = MingTok.from_pretrained, mbm.tensor_to_pil
+    images = []
+
+    class _NoFile:
+        def save(self, *a, **k):
+            pass
+    MingTok.from_pretrained = classmethod(lambda cls, *a, **k: tok)
+    mbm.tensor_to_pil = lambda t: (images.append(t.detach().float().clone()), _NoFile())[1]
+
+    class Force(LogitsProcessor):
+        def __init__(self, at, token):
+            self.at, self.token = at, token
+
+        def __call__(self, input_ids, scores):
+            if input_ids.shape[1] == self.at:
+                scores = torch.full_like(scores, float("-inf"))
+                scores[:, self.token] = 0.0
+            return scores
+    g = torch.Generator().manual_seed(31)
+    px = torch.rand(1, 3, 64, 64, generator=g) * 2 - 1
+    noises = torch.randn(16, 32, generator=g)
+    rounds_in = [
+        dict(ids=[ROLE, HUMAN, ROLE_E, IMG, PATCH, PATCH, PATCH, PATCH, IMG_E, 21, 22, 23, 24, ROLE, ASSIST, ROLE_E], px=True, force=True, n_new=3),
+        dict(ids=[ROLE, HUMAN, ROLE_E, 31, 32, 33, ROLE, ASSIST, ROLE_E], px=False, force=True, n_new=3),
+        dict(ids=[ROLE, HUMAN, ROLE_E, 41, 42, ROLE, ASSIST, ROLE_E], px=False, force=False, n_new=4),
+    ]
+    res = {}
+    old_mode = os.environ.get("PAST_MODE")
+    try:
+        for mode in ("KEEP", "DROP"):
+            os.environ["PAST_MODE"] = mode
+            llm = BailingMoeConfig(**llm_dict, _attn_implementation="eager")
+            llm.rope_scaling = None
+            llm._attn_implementation = "eager"
+            llm.image_start_token = llm_dict["image_start_token"]
+            cfg = MingUniVisionConfig(mlp_depth=2, llm_config=llm, vishead_diffloss_config=dict(TINY_RF))
+            model = mm.MingUniVisionForConditionalGeneration(cfg).eval()
+            shapes = fill_from_synth(model.model, seed)
+            assert shapes == C.llm_param_shapes(C.BailingMoeConfig(**llm_dict), TINY_RF, 32)
+            lp_shapes = C.linear_proj_param_shapes(128, llm.hidden_size, 2)
+            model.linear_proj.load_state_dict({k[len("linear_proj."):]: synth_tensor(k, s_, seed) for k, s_ in lp_shapes.items()})
+            trace = []
+            start = ref_shim.cache_position_452(model.model, trace)
+            cache = ref_shim.make_legacy_cache()
+            with torch.no_grad(), ReplayRandn(noises) as rr:
+                for r, spec in enumerate(rounds_in):
+                    ids = torch.tensor([spec["ids"]])
+                    unc, tunc = cfg_attention_masks(spec["ids"], [ROLE, HUMAN, ROLE_E], [ROLE, ASSIST, ROLE_E], {IMG, IMG_E, PATCH})
+                    am, unc, tunc = torch.ones_like(ids), torch.tensor([unc]), torch.tensor([tunc])
+                    n_img, n_tr, n_noise = len(images), len(trace), rr.i
+                    start()
+                    kw = dict(logits_processor=LogitsProcessorList([Force(ids.shape[1], llm_dict["image_start_token"])])) if spec["force"] else {}
+                    seq = model.generate(input_ids=ids, attention_mask=am, uncond_attention_mask=unc, text_uncond_attention_mask=tunc,
+                                         pixel_values=px if spec["px"] else None, past_key_values=cache if r == 0 else None,
+                                         max_new_tokens=spec["n_new"], use_cache=True, do_sample=False, pad_token_id=0, eos_token_id=None,
+                                         output_image_prefix=os.path.join(GOLDEN, "_never_written"), **kw)
+                    t = f"{mode}_r{r}_"
+                    res[t + "ids"], res[t + "unc"], res[t + "tunc"] = ids, unc, tunc
+                    res[t + "seq"] = seq
+                    res[t + "past_am"] = model.past_attention_mask
+                    res[t + "past_unc"] = model.past_uncond_attention_mask
+                    res[t + "past_tunc"] = model.past_text_uncond_attention_mask
+                    res[t + "cache_len"] = np.array(model.past_key_values.get_seq_length())
+                    res[t + "trace"] = np.array(trace[n_tr:], dtype=np.int64).reshape(-1, 5)
+                    res[t + "noise0"] = np.array(n_noise)
+                    if len(images) > n_img:
+                        assert len(images) == n_img + 1
+                        res[t + "image"] = images[-1]
+            res[mode + "_k0"] = model.past_key_values.key_cache[0]
+            res[mode + "_checksum"] = np.array(checksum(model.model))
+    finally:
+        MingTok.from_pretrained, mbm.tensor_to_pil = orig_fp, orig_pil
+        if old_mode is None:
+            os.environ.pop("PAST_MODE", None)
+        else:
+            os.environ["PAST_MODE"] = old_mode
+    save("multiround_tiny", llm_config=llm_dict, rf_config=TINY_RF, mingtok_config=TINY_MINGTOK, seed=seed, pixel_values=px, noises=noises,
+         special_ids=dict(ROLE=ROLE, ROLE_E=ROLE_E, HUMAN=HUMAN, ASSIST=ASSIST, IMG=IMG, IMG_E=IMG_E, PATCH=PATCH),
+         rounds=[dict(force=s_["force"], n_new=s_["n_new"], px=s_["px"]) for s_ in rounds_in], **res)
+
+
 def main():
     ref_shim.install()
     os.makedirs(GOLDEN, exist_ok=True)
@@ -389,6 +499,7 @@ def main():
     gen_genimg()
     gen_processor()
     gen_rope3d()
+    gen_multiround()
 
 
 if __name__ == "__main__":

@@ -18,6 +18,12 @@ the minimum so that the reference modules import and run unmodified:
   * `LegacyDynamicCache`: the 4.52 `DynamicCache` surface the reference uses
     (key_cache / value_cache / update / get_seq_length / get_usable_length,
     modeling_bailing_moe.py:778,789,1896-1902,1993; attention.py:150)
+  * round 6, for the multi-round state machine (`install_multimodal`, `cache_position_452`): import-only stubs of the audio
+    packages modeling_bailingmm.py:22 / modeling_utils.py:17 pull in (funasr, whisper — no arithmetic, never called on the
+    vision path) and the ONE piece of the transformers-4.52.4 `generate` contract that 5.x dropped and the reference's
+    prepare_inputs_for_generation (modeling_bailing_moe.py:1968-2080) relies on: `cache_position` kept in model_kwargs
+    (4.52.4 GenerationMixin._get_initial_cache_position / _update_model_kwargs_for_generation).  With it the installed
+    transformers' own greedy loop drives the reference's generate / forward / prepare_inputs_for_generation UNMODIFIED.
 """
 import os
 import sys
@@ -151,4 +157,73 @@ def make_legacy_cache():
         def to_legacy_cache(self):
             return tuple((k, v) for k, v in zip(self.key_cache, self.value_cache))
 
+        # what transformers 5.x's generate asks a cache object before it starts (no arithmetic)
+        is_compileable = False
+
+        @property
+        def layers(self):
+            return [None] * len(self.key_cache)
+
     return LegacyDynamicCache()
+
+
+def install_multimodal():
+    """Make `import modeling_bailingmm` work: import-only stubs for the audio towers it pulls in at module scope
+    (modeling_bailingmm.py:22 `funasr.models.sanm.encoder.SANMEncoder`, modeling_utils.py:17 `whisper.model.AudioEncoder`).
+    Neither class is instantiated or called on the vision / text path."""
+    install()
+    import torch.nn as nn
+    for n in ("funasr", "funasr.models", "funasr.models.sanm"):
+        if n not in sys.modules:
+            _stub_module(n)
+    if "funasr.models.sanm.encoder" not in sys.modules:
+        _stub_module("funasr.models.sanm.encoder", SANMEncoder=type("SANMEncoder", (nn.Module,), {}))
+    if "whisper" not in sys.modules:
+        _stub_module("whisper")
+        _stub_module("whisper.model", AudioEncoder=type("AudioEncoder", (nn.Module,), {}))
+
+
+def cache_position_452(lm, trace=None):
+    """Wrap `lm.prepare_inputs_for_generation` (the REFERENCE's function, untouched) so that it receives what transformers 4.52.4's
+    generate would hand it and 5.x no longer does:
+      * `cache_position`: first call of a generate = arange(len(inputs_embeds or input_ids))[cache.get_seq_length():]
+        (GenerationMixin._get_initial_cache_position), every later call = previous[-1:] + 1 (_update_model_kwargs_for_generation;
+        an EMPTY first value stays empty — that is what a follow-up round on a longer cache gets, and the reference's slicing
+        rules :2001-2016 are written around it);
+      * `position_ids` = None as the reference's caller passes it (modeling_bailingmm.py:254; 5.x keeps a running tensor there);
+      * 5.x-only kwargs (`next_sequence_length`, `is_first_iteration`) are dropped.
+    trace (a list): appended per call with (len(input_ids seen), cache length before, attention-mask length out, n new ids,
+    first position id) — the bookkeeping the fixture pins.  Returns `start()`: call it before every generate."""
+    import functools
+
+    import torch
+    orig = lm.prepare_inputs_for_generation
+    state = {"cp": None}
+
+    @functools.wraps(orig)
+    def prep(input_ids, **kw):
+        kw.pop("next_sequence_length", None)
+        kw.pop("is_first_iteration", None)
+        kw["position_ids"] = None
+        if state["cp"] is None:
+            emb = kw.get("inputs_embeds")
+            n = emb.shape[1] if emb is not None else input_ids.shape[1]
+            cp = torch.ones(n, dtype=torch.int64).cumsum(0) - 1
+            pkv = kw.get("past_key_values")
+            if pkv is not None and pkv.get_seq_length() is not None:
+                cp = cp[pkv.get_seq_length():]
+            state["cp"] = cp
+        else:
+            state["cp"] = state["cp"][-1:] + 1
+        before = kw["past_key_values"].get_seq_length()
+        out = orig(input_ids, cache_position=state["cp"], **kw)
+        if trace is not None:
+            n_new = out["input_ids"].shape[1] if out.get("input_ids") is not None else out["inputs_embeds"].shape[1]
+            trace.append((int(input_ids.shape[1]), int(before), int(out["attention_mask"].shape[1]), int(n_new),
+                          int(out["position_ids"][0, 0])))
+        return out
+    lm.prepare_inputs_for_generation = prep
+
+    def start():
+        state["cp"] = None
+    return start

@@ -251,7 +251,7 @@ def test_quantised_head_does_not_pin_the_bf16_matrices():
     from — `torch.cuda.memory_allocated` after the caller drops its state dict is the codes + the small tensors, not codes + originals."""
     import gc
     from ming_univision_amd.rf_head import RectifiedFlowHead
-    rf_cfg = dict(diffloss_w=512, diffloss_d=4, num_sampling_steps="4", gen_method="flow_matching_swiglu-4")
+    rf_cfg = dict(diffloss_w=768, diffloss_d=4, num_sampling_steps="4", gen_method="flow_matching_swiglu-4")      # SwiGLU hidden 2048: whole NF4 blocks
     cfg = C.BailingMoeConfig(vocab_size=64, hidden_size=256, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1,
                              head_dim=128, num_experts=4, num_shared_experts=1, num_experts_per_tok=2, moe_intermediate_size=64)
     shapes = {k: s for k, s in C.llm_param_shapes(cfg, rf_cfg, 32).items() if k.startswith("vis_head") or k.startswith("diffloss")}
@@ -271,6 +271,7 @@ def test_quantised_head_does_not_pin_the_bf16_matrices():
     del h16
     for mode, codes_over_bf16 in (("int4", 0.25 + 4 / 128.0), ("int8", 0.5), ("fp8", 0.5)):
         used, head = footprint(mode)
+        assert head.stream_fmt == mode
         saved = b16 - used
         # the ResBlock matrices shrink to their codes; nothing else grows by more than the adaLN codes (+ row scales)
         ada = head.t["ada_q"].numel() + 4 * head.t["ada_scale"].numel()

@@ -435,6 +435,47 @@ def test_past_mode_keep_and_drop_masks(tmp_path, monkeypatch):
     assert float((state["KEEP"] - state["DROP"]).abs().max()) > 1e-4
 
 
+@pytest.mark.parametrize("mode", ["KEEP", "DROP"])
+def test_multiround_conversation_vs_the_references_own_generate(mode, tmp_path, monkeypatch):
+    """SURVEY §8 a24 against the REFERENCE ITSELF (tests/golden/multiround_tiny.npz: MingUniVisionForConditionalGeneration.generate,
+    modeling_bailingmm.py:206-301 + modeling_bailing_moe.py:1769-1796, 1968-2080, run by oracle/gen_golden.gen_multiround): image +
+    instruction -> image (3 CFG rows), text -> image on the carried cache and masks, text -> text, under PAST_MODE KEEP and DROP.
+    The façade on the HIP path must return the reference's greedy tokens, carry the reference's three masks and cache length into
+    every next round, and produce its images (all rows the reference saves: row 0) — the second image depends on every K / V line and
+    every mask bit the first round left behind."""
+    g = load_golden("multiround_tiny")
+    llm_cfg = dict(g["llm_config"])
+    sd = llm_sd(g["llm_config"], g["rf_config"], g["seed"])
+    tsd = mingtok_sd(g["mingtok_config"], g["seed"])
+    lsd = synth_state_dict(C.linear_proj_param_shapes(128, 256, 2), g["seed"])
+    model = _facade(llm_cfg, g["rf_config"], g["mingtok_config"], g["seed"], 96, 128, sd, tsd, lsd)
+    monkeypatch.setenv("PAST_MODE", mode)
+    n_tok = llm_cfg["num_image_tokens_for_gen"]
+    for r, spec in enumerate(g["rounds"]):
+        t = f"{mode}_r{r}_"
+        ids, n0 = g[t + "ids"], g[t + "noise0"]
+        seq = model.generate(input_ids=ids, attention_mask=torch.ones_like(ids), uncond_attention_mask=g[t + "unc"],
+                             text_uncond_attention_mask=g[t + "tunc"], pixel_values=g["pixel_values"] if spec["px"] else None,
+                             max_new_tokens=spec["n_new"], forced_first_token=llm_cfg["image_start_token"] if spec["force"] else None,
+                             image_noises=g["noises"][n0:n0 + n_tok + 1], output_image_prefix=str(tmp_path / f"{mode}{r}"), eos_token_id=None)
+        assert seq.cpu().tolist() == g[t + "seq"].tolist(), (r, seq.tolist(), g[t + "seq"].tolist())
+        assert model.past_len == g[t + "cache_len"]
+        assert torch.equal(model.past_attention_mask, g[t + "past_am"])
+        assert torch.equal(model.past_uncond_attention_mask, g[t + "past_unc"])
+        assert torch.equal(model.past_text_uncond_attention_mask, g[t + "past_tunc"])
+        if spec["force"]:
+            ref_img = g[t + "image"]
+            assert model.last_generation["last_hidden"].shape[0] == ref_img.shape[0]          # the same number of CFG rows
+            p = psnr(model.last_image[0], ref_img[0])
+            print(f"multi-round {mode} round {r}: image PSNR vs the reference's {p:.1f} dB")
+            assert p > 40.0                                              # generate_image's pixel decoder runs in the bf16 regime
+    # layer 0's K cache of the whole conversation (the conditional sequence = cache sequence 0)
+    k0 = model.model.kv_cache[0, 0, 0, :, :model.past_len].cpu()
+    e = rel_err(k0, g[mode + "_k0"][0])
+    print(f"multi-round {mode}: layer-0 K lines of {model.past_len} slots vs the reference's: {e:.2e}")
+    assert e < TOL
+
+
 def test_generate_eos_in_the_middle_of_a_chunk_and_arena_end():
     """Greedy decoding runs in speculative chunks of 8 tokens.  An EOS at position 2 of a chunk must leave exactly the state the
     token-by-token loop leaves (past_len, masks, the next round's tokens); a conversation that ends a few slots short of t_max

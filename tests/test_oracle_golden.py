@@ -157,6 +157,47 @@ def test_generate_image(tag):
     assert rel_err(bailing_ref.lm_logits(out["last_hidden"][0:1], sd), g[tag + "_logits"]) < 1e-4
 
 
+@pytest.mark.parametrize("mode", ["KEEP", "DROP"])
+def test_multiround_state_machine_vs_reference(mode):
+    """the restated multi-round flow (tests/util.OracleConversation — what the GPU tests check the HIP façade against)
+    versus the REFERENCE's own MingUniVisionForConditionalGeneration.generate over three rounds (image + instruction -> image; text ->
+    image; text -> text), PAST_MODE KEEP and DROP: the greedy tokens, the three masks carried to the next round, the cache length after
+    every round, the generated images (all CFG rows) and layer 0's K cache at the end (every appended line, generated image tokens
+    included)."""
+    from tests.util import OracleConversation
+    g = load_golden("multiround_tiny")
+    sd = llm_sd(g["llm_config"], g["rf_config"], g["seed"])
+    tsd = mingtok_sd(g["mingtok_config"], g["seed"])
+    lsd = synth_state_dict(C.linear_proj_param_shapes(128, 256, 2), g["seed"])
+    assert abs(checksum(sd) - g[mode + "_checksum"]) < 1e-6 * g[mode + "_checksum"]
+    cfg = bailing_ref.LLMConfig(**{k: v for k, v in g["llm_config"].items() if k in bailing_ref.LLMConfig.__dataclass_fields__})
+    conv = OracleConversation(sd, lsd, tsd, cfg, int(g["rf_config"]["num_sampling_steps"]), past_mode=mode, decode_pixels=True)
+    n_tok = g["llm_config"]["num_image_tokens_for_gen"]
+    for r, spec in enumerate(g["rounds"]):
+        t = f"{mode}_r{r}_"
+        ids = g[t + "ids"]
+        n0 = g[t + "noise0"]
+        out = conv.round(ids, g[t + "unc"], g[t + "tunc"], pixel_values=g["pixel_values"] if spec["px"] else None,
+                         patch_id=g["special_ids"]["PATCH"], max_new_tokens=spec["n_new"],
+                         forced_first_token=g["llm_config"]["image_start_token"] if spec["force"] else None,
+                         noises=[g["noises"][n0:n0 + n_tok + 1]])
+        assert out["tokens"] == g[t + "seq"][0, ids.shape[1]:].tolist(), (r, out["tokens"])
+        assert torch.equal(g[t + "seq"][0, :ids.shape[1]], ids[0])
+        assert conv.cache_len == g[t + "cache_len"] == conv.kvs[0]["k"].shape[2]
+        for mine, ref in zip(conv.past, (g[t + "past_am"], g[t + "past_unc"], g[t + "past_tunc"])):
+            assert torch.equal(mine, ref), (r, mine, ref)
+        if spec["force"]:
+            img = out["images"][0]["image"]
+            assert img.shape == g[t + "image"].shape and rel_err(img, g[t + "image"]) < 1e-4, r
+            # the reference's bookkeeping of the image step: <image> is fed against the prompt's cache, the next text token against the
+            # cache + 1 + n_tok generated lines at position = cache length (modeling_bailing_moe.py:1993 `past_length`)
+            tr = g[t + "trace"]
+            assert tr[1, 1] + 1 + n_tok == tr[2, 1] and tr[2, 4] == tr[2, 1] and tr[2, 2] == tr[2, 1] + 1
+        else:
+            assert not out["images"]
+    assert rel_err(conv.kvs[0]["k"], g[mode + "_k0"]) < 1e-4
+
+
 def test_rope3d_matches_reference():
     """3D rotary branch (rope_scaling.type == "3D", modeling_bailing_moe.py:413-425, 463-469): the restatement against
     the reference's own functions, with distinct t / h / w position streams and with equal streams (== Legacy)."""

@@ -107,10 +107,13 @@ class OracleConversation:
     """The reference's multi-round flow (MingUniVisionForConditionalGeneration.generate, modeling_bailingmm.py:206-301, over
     BailingMoeForCausalLM.forward's `<image>` branch, modeling_bailing_moe.py:1769-1796) driven with the oracle's pieces: one KV
     cache and three attention masks carried from round to round (PAST_MODE KEEP / DROP, :273-299), greedy text tokens, an image
-    whenever `<image>` is emitted (or forced as the first token).  Test infrastructure."""
+    whenever `<image>` is emitted (or forced as the first token).  Test infrastructure.  PINNED (round 6) to the reference's own
+    generate on a three-round conversation under KEEP and DROP: tests/golden/multiround_tiny.npz (oracle/gen_golden.gen_multiround),
+    tests/test_oracle_golden.py::test_multiround_state_machine_vs_reference."""
 
-    def __init__(self, sd, lsd, tsd, ocfg, steps, past_mode="DROP", eos_token_id=None):
+    def __init__(self, sd, lsd, tsd, ocfg, steps, past_mode="DROP", eos_token_id=None, decode_pixels=False):
         from oracle import bailing_ref, mingtok_ref
+        self.decode_pixels = decode_pixels
         self.B, self.M = bailing_ref, mingtok_ref
         self.sd, self.lsd, self.tsd, self.cfg, self.steps, self.mode, self.eos = sd, lsd, tsd, ocfg, steps, past_mode, eos_token_id
         self.kvs = bailing_ref.new_kv(ocfg)
@@ -155,7 +158,9 @@ class OracleConversation:
                 out = B.generate_image(self._emb(torch.tensor([[tok]])), self.kvs, torch.cat((am, one), 1), unc, tunc, self.sd, cfg,
                                        noises[len(images)],
                                        latent_to_sem=lambda lat: self.M.mingtok_feature_decoder_step(lat, self.tsd, caches),
-                                       linear_proj=lambda s_: B.linear_proj(s_, self.lsd), sem_to_pix=lambda s_: None, steps=self.steps)
+                                       linear_proj=lambda s_: B.linear_proj(s_, self.lsd),
+                                       sem_to_pix=(lambda s_: self.M.pixel_decoder_forward(s_, self.tsd)) if self.decode_pixels else (lambda s_: None),
+                                       steps=self.steps)
                 images.append(out)
                 cache_len += 1 + cfg.num_image_tokens_for_gen
                 h = out["last_hidden"][0:1, -1:]
