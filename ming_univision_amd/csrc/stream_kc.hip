@@ -121,6 +121,52 @@ __device__ __forceinline__ void mma_chunk(f32x4& acc, const char* wbuf, const ch
   }
 }
 
+// ---- half tiles (3 rows: w3's operand image takes 96 of the 160 KiB, the waves' weight tiles shrink from 8 to 4 KiB) -----------------------
+// A chunk still travels as 16 rows x 256 k in registers; it is parked and multiplied in two halves of 128 k: half h = slots [16 h, 16 h + 16)
+// of the rows (the XOR swizzle of wslot permutes within 16 slots, so a half keeps its own bank pattern), 256 bytes per row.
+__device__ __forceinline__ int wslot_half(int row, int slot16) { return row * WCH + ((slot16 ^ (row & 15)) << 4); }
+
+template <int WQ, int HF>
+__device__ __forceinline__ void park_half(const Chunk<WQ>& c, char* wbuf, int lane, int wf, const float* wscale, int n0, int Ntot) {
+  static_assert(WQ != 2, "NF4 tiles are transposed over the whole chunk: no half form");
+  const int fr = lane & 15, fq = lane >> 4, r8 = lane >> 3, c8 = lane & 7;
+  if constexpr (WQ == 1) {
+    if ((fr >> 3) == HF) {                          // lane fr holds k [16 fr, 16 fr + 16): slots 2 fr, 2 fr + 1
+      auto park8 = [&](auto i8) {
+        constexpr bool I8 = decltype(i8)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = i * 4 + fq, sw = (fr >> 2) & 1, f7 = fr & 7;
+          const float sc = I8 ? wscale[min(n0 + row, Ntot - 1)] : 1.0f;
+          const u32x4 a = w8x8_to_bf16<I8>(c.q[i].x, c.q[i].y, sc), b = w8x8_to_bf16<I8>(c.q[i].z, c.q[i].w, sc);
+          *reinterpret_cast<u32x4*>(wbuf + wslot_half(row, 2 * f7 + sw)) = sw ? b : a;
+          *reinterpret_cast<u32x4*>(wbuf + wslot_half(row, 2 * f7 + 1 - sw)) = sw ? a : b;
+        }
+      };
+      if (wf == MN_W_INT8) park8(std::true_type{}); else park8(std::false_type{});
+    }
+  } else {
+#pragma unroll
+    for (int i = 4 * HF; i < 4 * HF + 4; ++i) *reinterpret_cast<u32x4*>(wbuf + wslot_half((i & 1) * 8 + r8, ((i >> 1) & 1) * 8 + c8)) = c.q[i];
+  }
+}
+
+// the 4 MFMA steps of half HF of a parked chunk whose k starts at kc
+template <int HF>
+__device__ __forceinline__ void mma_half(f32x4& acc, const char* wbuf, const char* xs, int xstride, int M, int kc, int lane) {
+  const int fr = lane & 15, fq = lane >> 4;
+  const int ra = fr < M ? fr : 0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const bf16x8 w = *reinterpret_cast<const bf16x8*>(wbuf + wslot_half(fr, s * 4 + fq));
+    const int slot = (kc >> 3) + (4 * HF + s) * 4 + fq;
+    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xs + xoff(ra, slot, xstride));
+    const bf16x8 al = *reinterpret_cast<const bf16x8*>(xs + xoff(M + ra, slot, xstride));
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w, acc, 0, 0, 0);
+  }
+}
+
 // One wave's weight stream of a phase: rows [n0, n0 + 16) of W [Ntot][K], k from kbeg, nch chunks.
 struct WStream {
   const void* W; const float* wscale; int n0, Ntot, K, kbeg, nch, wf; bool live;
@@ -195,6 +241,15 @@ __device__ __forceinline__ void prefetch(const WStream& st, char* wbuf, Chunk<WQ
   for (int d = 0; d < RD; ++d)
     if (1 + d < st.nch) issue<WQ>(ring[d], st, 1 + d, lane);
   park<WQ>(c0, wbuf, lane, st.wf, st.wscale, st.n0, st.Ntot);
+}
+
+// Half-tile form (3 rows): nothing is parked before the wait — the ring takes chunks 0 .. RD - 1 and the body starts like a launch's
+template <int WQ, int RD>
+__device__ __forceinline__ void prefetch_ring(const WStream& st, Chunk<WQ> (&ring)[RD], int lane) {
+  if (!st.live) return;
+#pragma unroll
+  for (int d = 0; d < RD; ++d)
+    if (d < st.nch) issue<WQ>(ring[d], st, d, lane);
 }
 
 // The body of workgroup `vb` of w12' (PRE, the persistent form: chunk 0 is parked, the ring holds chunks 1 .. RD, and the data other
@@ -398,19 +453,21 @@ __device__ __forceinline__ WStream w3_stream(const W3Args& a, int vb, int wave, 
 }
 
 // The body of workgroup `vb` (one 16-column tile) of w3' (PRE: as in w12_body).
-template <int WQ, int RD, bool PRE>
+// HALF (3 rows): 4 KiB weight tiles, chunks parked in two halves; with PRE the ring already holds chunks 0 .. RD - 1 (prefetch_ring).
+// XN: 16-byte pieces of the operand per thread (2 M hid / 8 <= XN x 512).
+template <int WQ, int RD, bool PRE, int XN = 8, bool HALF = false>
 __device__ __forceinline__ void w3_body(const W3Args& a, char* lds, int vb, Chunk<WQ> (&ring)[RD], uint64_t* tr = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int M = a.M, K = a.hid, Ntot = a.w;
   const int xstride = K * 2 + 64;
+  constexpr int TILE = (HALF ? 8 : 16) * WCH * 2;   // bytes of a wave's weight tile
   char* xs = lds;
-  char* wbuf = lds + (size_t)2 * M * xstride + (size_t)wave * 16 * WCH * 2;
-  float* red = reinterpret_cast<float*>(lds + (size_t)2 * M * xstride + (size_t)KC_WAVES * 16 * WCH * 2);
+  char* wbuf = lds + (size_t)2 * M * xstride + (size_t)wave * TILE;
+  float* red = reinterpret_cast<float*>(lds + (size_t)2 * M * xstride + (size_t)KC_WAVES * TILE);
   const int n0 = vb * 16;
   const int Kw = K / KC_WAVES, kbeg = wave * Kw, nch = Kw / WCH;
   // ---- the operand (hi rows, lo rows: 2 M hid bf16, 16 bytes per thread and step) and the epilogue's operands go to registers FIRST:
   // loads retire in order, so they land before the (younger) weight chunks and the x image is in LDS while those are still in flight
-  constexpr int XN = 8;                             // 16-byte pieces per thread: 2 M hid / 8 <= 8 x 512 (host check)
   const int spr = K >> 3;                           // 16-byte slots per row
   u32x4 xr[XN];
 #pragma unroll
@@ -443,14 +500,23 @@ __device__ __forceinline__ void w3_body(const W3Args& a, char* lds, int vb, Chun
   __syncthreads();
   stamp(tr, 1);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (PRE) mma_chunk<WQ>(acc, wbuf, xs, xstride, M, kbeg, lane);
-  for (int c = PRE ? 1 : 0; c < nch; c += RD) {
+  constexpr bool PARKED = PRE && !HALF;            // chunk 0 sits in the tile, the ring holds chunks 1 ..
+  if constexpr (PARKED) mma_chunk<WQ>(acc, wbuf, xs, xstride, M, kbeg, lane);
+  for (int c = PARKED ? 1 : 0; c < nch; c += RD) {
 #pragma unroll
     for (int d = 0; d < RD; ++d) {
       if (c + d < nch) {
-        park<WQ>(ring[d], wbuf, lane, a.wf, a.wscale, n0, Ntot);
-        if (c + d + RD < nch) issue<WQ>(ring[d], a.W, a.wscale, n0, Ntot, K, kbeg + (c + d + RD) * WCH, lane);
-        mma_chunk<WQ>(acc, wbuf, xs, xstride, M, kbeg + (c + d) * WCH, lane);
+        if constexpr (HALF) {                      // (the ring slot is free once its second half is parked: re-issue in between)
+          park_half<WQ, 0>(ring[d], wbuf, lane, a.wf, a.wscale, n0, Ntot);
+          mma_half<0>(acc, wbuf, xs, xstride, M, kbeg + (c + d) * WCH, lane);
+          park_half<WQ, 1>(ring[d], wbuf, lane, a.wf, a.wscale, n0, Ntot);
+          if (c + d + RD < nch) issue<WQ>(ring[d], a.W, a.wscale, n0, Ntot, K, kbeg + (c + d + RD) * WCH, lane);
+          mma_half<1>(acc, wbuf, xs, xstride, M, kbeg + (c + d) * WCH, lane);
+        } else {
+          park<WQ>(ring[d], wbuf, lane, a.wf, a.wscale, n0, Ntot);
+          if (c + d + RD < nch) issue<WQ>(ring[d], a.W, a.wscale, n0, Ntot, K, kbeg + (c + d + RD) * WCH, lane);
+          mma_chunk<WQ>(acc, wbuf, xs, xstride, M, kbeg + (c + d) * WCH, lane);
+        }
       }
     }
   }
@@ -474,11 +540,11 @@ __device__ __forceinline__ void w3_body(const W3Args& a, char* lds, int vb, Chun
   }
 }
 
-template <int WQ, int RD>
+template <int WQ, int RD, int XN = 8, bool HALF = false>
 __global__ __launch_bounds__(KC_WAVES * 64) void rf_w3_kc_kernel(const W3Args a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   Chunk<WQ> ring[RD];
-  w3_body<WQ, RD, false>(a, lds, (int)blockIdx.x, ring);
+  w3_body<WQ, RD, false, XN, HALF>(a, lds, (int)blockIdx.x, ring);
 }
 
 // ---- the ResBlocks of one Euler step as ONE persistent launch ----------------------------------------------------------------------------
@@ -565,12 +631,13 @@ __device__ __forceinline__ void persist_boundary_phase(const PersistArgs& p, cha
 
 // Final-layer phase (workgroup t < T owns output column t of every row): v[m][t] = fin_b[t] + sum_k fin_w[t][k] *
 // (LayerNorm(h[m])[k] * (1 + scale[m][k]) + shift[m][k])   (no affine; diff_loss_rf_swiglu.py:288-292) in fp32.
+template <int MR>
 __device__ __forceinline__ void persist_final_phase(const PersistArgs& p, char* lds, const float* mod_s, int vb) {
   if (vb >= p.T) return;
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-  constexpr int NT = KC_WAVES * 64, PC = 1024 / NT, MR = 2;
-  float* red = reinterpret_cast<float*>(lds + p.lds_top) + 512;        // [8 waves][2 rows] + results
+  constexpr int NT = KC_WAVES * 64, PC = 1024 / NT;
+  float* red = reinterpret_cast<float*>(lds + p.lds_top) + 512;        // [8 waves][MR rows] (64 floats of scratch: MR <= 4)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, M = p.M, K = p.w, nq = K >> 2;
   const float* shift = mod_s + (int64_t)p.nblk * 3 * K;
   const float* scale = shift + K;
@@ -640,14 +707,20 @@ __device__ __forceinline__ void persist_final_phase(const PersistArgs& p, char* 
   }
   block_sum2(dot);
   if (tid < M) {
-    const float y = (tid == 0 ? dot[0] : dot[1]) + bf16_to_f32(p.fin_b[vb]);
+    float y = dot[0];
+#pragma unroll
+    for (int m = 1; m < MR; ++m) y = tid == m ? dot[m] : y;
+    y += bf16_to_f32(p.fin_b[vb]);
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), coh_rsrc(p.v, (uint32_t)M * p.T * 4), (tid * p.T + vb) * 4, 0, AUX_SC1);
   }
 }
 
-template <int WQ>
+// MR: rows the launch is compiled for — 2 (1 or 2 rows: text -> image) or 3 (3 CFG rows: editing; w3' then runs on half tiles, see w3_body)
+template <int WQ, int MR = 2>
 __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const PersistArgs p) {
   constexpr int RD3 = WQ == 1 ? 4 : 2;
+  constexpr bool HALF = MR > 2;
+  constexpr int XN3 = MR > 2 ? 12 : 8;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int vb = blockIdx.x, n12 = (p.hid + 31) / 32, n3 = (p.w + 15) / 16;
@@ -665,7 +738,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const 
     return W3Args{p.Y, p.M, p.w, p.hid, p.blk[b].W3, p.blk[b].s3, p.blk[b].b3, p.wf, base + (int64_t)b * 3 * p.w + 2 * p.w, p.ldmod, p.h};
   };
   char* wbuf12 = lds + (size_t)2 * p.M * (p.w * 2 + 64) + (size_t)wave * 16 * WCH * 2;
-  char* wbuf3 = lds + (size_t)2 * p.M * (p.hid * 2 + 64) + (size_t)wave * 16 * WCH * 2;
+  char* wbuf3 = lds + (size_t)2 * p.M * (p.hid * 2 + 64) + (size_t)wave * (HALF ? 8 : 16) * WCH * 2;
   const bool whole = p.steps > 0;                   // the whole sampler: steps x (boundary phase, blocks, final-layer phase)
   const int nsteps = whole ? p.steps : 1;
   W12Args a12 = args12(p.mod, 0);
@@ -690,11 +763,12 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const 
     const W3Args a3 = args3(mod_s, b);
     const WStream s3 = w3_stream(a3, vb, wave, vb < n3);
     stamp(tr, 0);
-    if (vb < n12) w12_body<WQ, 2, 1, KC_WAVES, true>(a12, lds, vb, r12, tr);
+    if (vb < n12) w12_body<WQ, MR, 1, KC_WAVES, true>(a12, lds, vb, r12, tr);
     stamp(tr, 3);
     gb.arrive();
     stamp(tr, 4);
-    prefetch<WQ, RD3>(s3, wbuf3, r3, lane);
+    if constexpr (HALF) prefetch_ring<WQ, RD3>(s3, r3, lane);
+    else prefetch<WQ, RD3>(s3, wbuf3, r3, lane);
     stamp(tr, 5);
     gb.wait();
     stamp(tr, 6);
@@ -706,7 +780,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const 
       a12 = args12(last ? mod_s + p.mod_step : mod_s, last ? 0 : b + 1);
       s12 = w12_stream<KC_WAVES>(a12, vb, wave, vb < n12);
     } else s12.live = false;
-    if (vb < n3) w3_body<WQ, RD3, true>(a3, lds, vb, r3, tr);
+    if (vb < n3) w3_body<WQ, RD3, true, XN3, HALF>(a3, lds, vb, r3, tr);
     stamp(tr, 3);
     if (more || whole) {
       gb.arrive();
@@ -719,7 +793,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void rf_blocks_persist_kernel(const 
     if (tr) tr += 8;
   }
   if (whole) {
-    persist_final_phase(p, lds, mod_s, vb);
+    persist_final_phase<MR>(p, lds, mod_s, vb);
     gb.arrive();
     gb.wait();
   }
@@ -740,7 +814,8 @@ int g_kc_fault_wg = -1; unsigned g_kc_fault_ms = 0;   // dev library: fault inje
 int g_kc_rd12 = 1, g_kc_rd3 = 0;     // weight chunks in flight per wave; rd3 = 0: by format (dev-library A/B knob: mn_rf_kc_tune)
 
 size_t w12_lds(int M, int w, int nw) { return (size_t)2 * M * (w * 2 + 64) + (size_t)nw * 16 * WCH * 2 + (nw * KC_MAX_M * 16 + 16) * sizeof(float); }
-size_t w3_lds(int M, int hid) { return (size_t)2 * M * (hid * 2 + 64) + (size_t)KC_WAVES * 16 * WCH * 2 + KC_WAVES * KC_MAX_M * 16 * sizeof(float); }
+// (3 rows: the operand image takes 96 KiB, the waves' weight tiles are half tiles — w3_body<.., HALF>)
+size_t w3_lds(int M, int hid) { return (size_t)2 * M * (hid * 2 + 64) + (size_t)KC_WAVES * (M > 2 ? 8 : 16) * WCH * 2 + KC_WAVES * KC_MAX_M * 16 * sizeof(float); }
 
 template <typename Kern>
 void opt_in(Kern k) {
@@ -759,9 +834,9 @@ extern "C" MN_DEV_API void mn_rf_kc_fault(int wg, unsigned wait_ms) { g_kc_fault
 // Can the ResBlock chain of this shape run as K-complete launches?  (whole chunks per wave, the x images + weight tiles within the
 // 160 KiB of LDS, the LayerNorm prologue's two float4 columns per thread)
 bool rf_kc_ok(int wfmt, int M, int w, int hid) {
-  if (M < 1 || M > 2 || w > 4096 || (w % (2 * WCH)) != 0 || (hid % (KC_WAVES * WCH)) != 0 || (hid % 32) != 0) return false;
-  if (wfmt == MN_W_NF4 && ((w % 64) != 0 || (hid % 64) != 0)) return false;
-  if ((int64_t)M * hid > 16384) return false;       // w3': the operand image is staged through 8 x 16 bytes per thread
+  if (M < 1 || M > 3 || w > 4096 || (w % (2 * WCH)) != 0 || (hid % (KC_WAVES * WCH)) != 0 || (hid % 32) != 0) return false;
+  if (wfmt == MN_W_NF4 && ((w % 64) != 0 || (hid % 64) != 0 || M > 2)) return false;      // (NF4 tiles have no half form: 3 rows keep the three-launch chain)
+  if ((int64_t)M * hid > (M > 2 ? 24576 : 16384)) return false;       // w3': the operand image is staged through 8 (3 rows: 12) x 16 bytes per thread
   return w12_lds(M, w, 8) <= 160 * 1024 && w3_lds(M, hid) <= 160 * 1024;
 }
 
@@ -833,8 +908,9 @@ int rf_blocks_persist(int wfmt, float* h, bf16_t* Y3, int M, int w, int hid, con
     std::lock_guard<std::mutex> lk(mu_attr);
     static size_t opted = 0;                         // (the kernel holds 256 bytes of static LDS: ask for what the launch needs, not for all 160 KiB)
     if (lds > opted) {
-      const void* ks[3] = {reinterpret_cast<const void*>(&rf_blocks_persist_kernel<0>), reinterpret_cast<const void*>(&rf_blocks_persist_kernel<1>),
-                           reinterpret_cast<const void*>(&rf_blocks_persist_kernel<2>)};
+      const void* ks[5] = {reinterpret_cast<const void*>(&rf_blocks_persist_kernel<0, 2>), reinterpret_cast<const void*>(&rf_blocks_persist_kernel<1, 2>),
+                           reinterpret_cast<const void*>(&rf_blocks_persist_kernel<2, 2>), reinterpret_cast<const void*>(&rf_blocks_persist_kernel<0, 3>),
+                           reinterpret_cast<const void*>(&rf_blocks_persist_kernel<1, 3>)};
       for (const void* k : ks)
         if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
           mn_set_error("rf_blocks_persist: cannot reserve %zu bytes of LDS", lds);
@@ -845,9 +921,11 @@ int rf_blocks_persist(int wfmt, float* h, bf16_t* Y3, int M, int w, int hid, con
   }
   { const int rc_o = mn_persist_order_before(st); if (rc_o != MN_OK) return rc_o; }
   const dim3 grid((unsigned)G), block(KC_WAVES * 64);
-  if (wfmt == MN_W_NF4) hipLaunchKernelGGL(rf_blocks_persist_kernel<2>, grid, block, lds, st, p);
-  else if (wfmt) hipLaunchKernelGGL(rf_blocks_persist_kernel<1>, grid, block, lds, st, p);
-  else hipLaunchKernelGGL(rf_blocks_persist_kernel<0>, grid, block, lds, st, p);
+  if (wfmt == MN_W_NF4) hipLaunchKernelGGL((rf_blocks_persist_kernel<2, 2>), grid, block, lds, st, p);
+  else if (M > 2 && wfmt) hipLaunchKernelGGL((rf_blocks_persist_kernel<1, 3>), grid, block, lds, st, p);
+  else if (M > 2) hipLaunchKernelGGL((rf_blocks_persist_kernel<0, 3>), grid, block, lds, st, p);
+  else if (wfmt) hipLaunchKernelGGL((rf_blocks_persist_kernel<1, 2>), grid, block, lds, st, p);
+  else hipLaunchKernelGGL((rf_blocks_persist_kernel<0, 2>), grid, block, lds, st, p);
   mn_persist_order_after(st);
   MN_CHECK_LAUNCH("rf_blocks_persist");
   return MN_OK;
@@ -897,7 +975,14 @@ int rf_w12_kc(int wfmt, const float* h, int M, int w, int hid, const bf16_t* ln_
 #define MN_OPT(WQ_) opt_in(&rf_w12_kc_kernel<WQ_, 2, 1, 8>); opt_in(&rf_w12_kc_kernel<WQ_, 2, 2, 8>); opt_in(&rf_w12_kc_kernel<WQ_, 2, 3, 8>);
     MN_OPT(0) MN_OPT(1) MN_OPT(2)
 #undef MN_OPT
+    opt_in(&rf_w12_kc_kernel<0, 3, 1, 8>); opt_in(&rf_w12_kc_kernel<1, 3, 1, 8>);
     opted = true;
+  }
+  if (M > 2) {                                      // 3 rows (editing): the MR = 3 instances, one chunk in flight
+    if (wfmt) hipLaunchKernelGGL((rf_w12_kc_kernel<1, 3, 1, 8>), grid, block, lds, mn_stream(stream), a);
+    else hipLaunchKernelGGL((rf_w12_kc_kernel<0, 3, 1, 8>), grid, block, lds, mn_stream(stream), a);
+    MN_CHECK_LAUNCH("rf_w12_kc");
+    return MN_OK;
   }
 #define MN_KC12(WQ_)                                                                                                       \
   do {                                                                                                                     \
@@ -922,7 +1007,14 @@ int rf_w3_kc(int wfmt, const bf16_t* Y3, int M, int w, int hid, const void* W3, 
     opt_in(&rf_w3_kc_kernel<0, 1>); opt_in(&rf_w3_kc_kernel<0, 2>); opt_in(&rf_w3_kc_kernel<0, 4>);
     opt_in(&rf_w3_kc_kernel<1, 1>); opt_in(&rf_w3_kc_kernel<1, 2>); opt_in(&rf_w3_kc_kernel<1, 4>);
     opt_in(&rf_w3_kc_kernel<2, 1>); opt_in(&rf_w3_kc_kernel<2, 2>); opt_in(&rf_w3_kc_kernel<2, 4>);
+    opt_in(&rf_w3_kc_kernel<0, 2, 12, true>); opt_in(&rf_w3_kc_kernel<1, 4, 12, true>);
     opted = true;
+  }
+  if (M > 2) {                                      // 3 rows: half tiles (w3_body<.., HALF>), chunks in flight by format
+    if (wfmt) hipLaunchKernelGGL((rf_w3_kc_kernel<1, 4, 12, true>), grid, block, lds, mn_stream(stream), a);
+    else hipLaunchKernelGGL((rf_w3_kc_kernel<0, 2, 12, true>), grid, block, lds, mn_stream(stream), a);
+    MN_CHECK_LAUNCH("rf_w3_kc");
+    return MN_OK;
   }
   // chunks in flight per wave, measured best per format (tools/exp/rf_kc_sweep.py): bf16 2 (16 KiB), e4m3 / int8 4 (16 KiB), NF4 2
   const int rd3 = g_kc_rd3 ? g_kc_rd3 : ((wfmt == MN_W_FP8_E4M3 || wfmt == MN_W_INT8) ? 4 : 2);

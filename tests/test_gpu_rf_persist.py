@@ -165,3 +165,45 @@ def test_a_late_resident_workgroup_poisons_the_result_and_raises_on_the_host():
         "print('FAULT_OK')\n" % root)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "FAULT_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+
+
+@pytest.mark.parametrize("weights", ["bf16", "fp8", "int8"])
+def test_three_rows_take_the_k_complete_launches_and_match_the_oracle(weights):
+    """Round 6: 3 rows — the editing shape, RectifiedFlowLoss.sample's 3-way CFG (diff_loss_rf_swiglu.py:143-150) — ran
+    the three-launch chain because w3's operand image + 8 KiB weight tiles per wave exceed the 160 KiB of LDS; with half tiles (4 KiB per
+    wave, chunks parked in two halves) the K-complete launches and the whole-sampler persistent launch take 3 rows too (bf16, e4m3;
+    int8 keeps its launches, NF4 the chain).  Against the oracle's sample() fed the mode's de-quantised weights, 1e-3; the persistent
+    launch (default) and the launch chain (MINGNATIVE_RF_PERSIST=0 would give it; here: inside a graph capture) agree to 1e-5."""
+    from oracle import rf_ref
+    from tests.util import rel_err
+    rf = _head(weights)
+    assert rf.stream_fmt == weights
+    osd = {k: v.float().cpu() for k, v in rf._sd.items()}
+    if weights != "bf16":
+        osd.update({k: v.float().cpu() for k, v in rf.dequantized_blocks().items()})
+    rsd = {k[len("diffloss."):]: v for k, v in osd.items() if k.startswith("diffloss.")}
+    g = torch.Generator().manual_seed(23)
+    h, n = torch.randn(3, LLM_HIDDEN, generator=g), torch.randn(1, 32, generator=g)
+    torch.set_num_threads(min(64, max(torch.get_num_threads(), 16)))
+    ref = rf_ref.sample(rf_ref.vis_head(h, osd), n, rsd, steps=16)[0]
+    hd, nd = h.cuda(), n.cuda()
+    got = rf.sample(hd, nd, n_images=1).clone()
+    rf.check_err()
+    e = rel_err(got, ref)
+    assert torch.equal(rf.sample(hd, nd, n_images=1), got)              # deterministic, barrier words reusable
+    # the launch form of the same bodies: a captured stream takes the two launches per ResBlock (no event calls inside a capture)
+    out = torch.empty(1, 32, device="cuda")
+    rf.sample(hd, nd, n_images=1, out=out)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        rf.sample(hd, nd, n_images=1, out=out)
+    out.zero_()
+    gr.replay()
+    torch.cuda.synchronize()
+    d = rel_err(out, got)
+    print(f"{weights} head, 3 rows: vs oracle {e:.2e}; launches vs the persistent launch {d:.2e}")
+    assert e < 1e-3 and d < 1e-5
+    # 2 images x 3 rows stays on the chain (6 rows) and gives the same latents for image 0
+    two = rf.sample(torch.cat([hd, hd]), torch.cat([nd, nd]), n_images=2)
+    assert rel_err(two[0], ref) < 1e-3 and rel_err(two[1], ref) < 1e-3
