@@ -126,29 +126,20 @@ __device__ __forceinline__ void mma_chunk(f32x4& acc, const char* wbuf, const ch
 // of the rows (the XOR swizzle of wslot permutes within 16 slots, so a half keeps its own bank pattern), 256 bytes per row.
 __device__ __forceinline__ int wslot_half(int row, int slot16) { return row * WCH + ((slot16 ^ (row & 15)) << 4); }
 
+// compiler-only ordering point for data one wave's lanes hand each other through LDS (no instruction is emitted)
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
 template <int WQ, int HF>
-__device__ __forceinline__ void park_half(const Chunk<WQ>& c, char* wbuf, int lane, int wf, const float* wscale, int n0, int Ntot) {
-  static_assert(WQ != 2, "NF4 tiles are transposed over the whole chunk: no half form");
-  const int fr = lane & 15, fq = lane >> 4, r8 = lane >> 3, c8 = lane & 7;
-  if constexpr (WQ == 1) {
-    if ((fr >> 3) == HF) {                          // lane fr holds k [16 fr, 16 fr + 16): slots 2 fr, 2 fr + 1
-      auto park8 = [&](auto i8) {
-        constexpr bool I8 = decltype(i8)::value;
+__device__ __forceinline__ void park_half(const Chunk<WQ>& c, char* wbuf, int lane) {
+  // bf16 only.  (An e4m3 / int8 form — the lanes of one half parking while the others idle — was built and measured: the conversions run
+  // twice at full cost under the exec mask, 3 rows 6.73 ms against the chain's 5.88; NF4 tiles are transposed over the whole chunk.)
+  static_assert(WQ == 0, "half tiles: bf16 weights");
+  const int r8 = lane >> 3, c8 = lane & 7;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = i * 4 + fq, sw = (fr >> 2) & 1, f7 = fr & 7;
-          const float sc = I8 ? wscale[min(n0 + row, Ntot - 1)] : 1.0f;
-          const u32x4 a = w8x8_to_bf16<I8>(c.q[i].x, c.q[i].y, sc), b = w8x8_to_bf16<I8>(c.q[i].z, c.q[i].w, sc);
-          *reinterpret_cast<u32x4*>(wbuf + wslot_half(row, 2 * f7 + sw)) = sw ? b : a;
-          *reinterpret_cast<u32x4*>(wbuf + wslot_half(row, 2 * f7 + 1 - sw)) = sw ? a : b;
-        }
-      };
-      if (wf == MN_W_INT8) park8(std::true_type{}); else park8(std::false_type{});
-    }
-  } else {
-#pragma unroll
-    for (int i = 4 * HF; i < 4 * HF + 4; ++i) *reinterpret_cast<u32x4*>(wbuf + wslot_half((i & 1) * 8 + r8, ((i >> 1) & 1) * 8 + c8)) = c.q[i];
-  }
+  for (int i = 4 * HF; i < 4 * HF + 4; ++i) *reinterpret_cast<u32x4*>(wbuf + wslot_half((i & 1) * 8 + r8, ((i >> 1) & 1) * 8 + c8)) = c.q[i];
 }
 
 // the 4 MFMA steps of half HF of a parked chunk whose k starts at kc
@@ -158,7 +149,9 @@ __device__ __forceinline__ void mma_half(f32x4& acc, const char* wbuf, const cha
   const int ra = fr < M ? fr : 0;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const bf16x8 w = *reinterpret_cast<const bf16x8*>(wbuf + wslot_half(fr, s * 4 + fq));
+    // (read with the type the tile was STORED with: park_half stores u32x4, and a bf16x8-typed load may be scheduled across those stores
+    // by type-based alias analysis)
+    const bf16x8 w = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wbuf + wslot_half(fr, s * 4 + fq)));
     const int slot = (kc >> 3) + (4 * HF + s) * 4 + fq;
     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xs + xoff(ra, slot, xstride));
     const bf16x8 al = *reinterpret_cast<const bf16x8*>(xs + xoff(M + ra, slot, xstride));
@@ -507,11 +500,19 @@ __device__ __forceinline__ void w3_body(const W3Args& a, char* lds, int vb, Chun
     for (int d = 0; d < RD; ++d) {
       if (c + d < nch) {
         if constexpr (HALF) {                      // (the ring slot is free once its second half is parked: re-issue in between)
-          park_half<WQ, 0>(ring[d], wbuf, lane, a.wf, a.wscale, n0, Ntot);
+          // The tile is re-used WITHIN the chunk and its lanes exchange data through it: the compiler sees one thread, whose own stores
+          // and loads it may prove disjoint — an e4m3 instance of this loop did move park_half<1>'s stores above mma_half<0>'s loads
+          // and multiplied the wrong half (tools/exp/kc_w3_probe.hip).  wave_fence(): no instruction, but no LDS access moves across it; the
+          // hardware keeps one wave's LDS operations in order.
+          park_half<WQ, 0>(ring[d], wbuf, lane);
+          wave_fence();
           mma_half<0>(acc, wbuf, xs, xstride, M, kbeg + (c + d) * WCH, lane);
-          park_half<WQ, 1>(ring[d], wbuf, lane, a.wf, a.wscale, n0, Ntot);
+          wave_fence();
+          park_half<WQ, 1>(ring[d], wbuf, lane);
+          wave_fence();
           if (c + d + RD < nch) issue<WQ>(ring[d], a.W, a.wscale, n0, Ntot, K, kbeg + (c + d + RD) * WCH, lane);
           mma_half<1>(acc, wbuf, xs, xstride, M, kbeg + (c + d) * WCH, lane);
+          wave_fence();
         } else {
           park<WQ>(ring[d], wbuf, lane, a.wf, a.wscale, n0, Ntot);
           if (c + d + RD < nch) issue<WQ>(ring[d], a.W, a.wscale, n0, Ntot, K, kbeg + (c + d + RD) * WCH, lane);
@@ -835,7 +836,8 @@ extern "C" MN_DEV_API void mn_rf_kc_fault(int wg, unsigned wait_ms) { g_kc_fault
 // 160 KiB of LDS, the LayerNorm prologue's two float4 columns per thread)
 bool rf_kc_ok(int wfmt, int M, int w, int hid) {
   if (M < 1 || M > 3 || w > 4096 || (w % (2 * WCH)) != 0 || (hid % (KC_WAVES * WCH)) != 0 || (hid % 32) != 0) return false;
-  if (wfmt == MN_W_NF4 && ((w % 64) != 0 || (hid % 64) != 0 || M > 2)) return false;      // (NF4 tiles have no half form: 3 rows keep the three-launch chain)
+  if (wfmt == MN_W_NF4 && ((w % 64) != 0 || (hid % 64) != 0)) return false;
+  if (M > 2 && wfmt != MN_W_BF16) return false;    // 3 rows: bf16 only — the byte formats keep the three-launch chain (faster than a masked half-tile park: park_half)
   if ((int64_t)M * hid > (M > 2 ? 24576 : 16384)) return false;       // w3': the operand image is staged through 8 (3 rows: 12) x 16 bytes per thread
   return w12_lds(M, w, 8) <= 160 * 1024 && w3_lds(M, hid) <= 160 * 1024;
 }
@@ -908,9 +910,8 @@ int rf_blocks_persist(int wfmt, float* h, bf16_t* Y3, int M, int w, int hid, con
     std::lock_guard<std::mutex> lk(mu_attr);
     static size_t opted = 0;                         // (the kernel holds 256 bytes of static LDS: ask for what the launch needs, not for all 160 KiB)
     if (lds > opted) {
-      const void* ks[5] = {reinterpret_cast<const void*>(&rf_blocks_persist_kernel<0, 2>), reinterpret_cast<const void*>(&rf_blocks_persist_kernel<1, 2>),
-                           reinterpret_cast<const void*>(&rf_blocks_persist_kernel<2, 2>), reinterpret_cast<const void*>(&rf_blocks_persist_kernel<0, 3>),
-                           reinterpret_cast<const void*>(&rf_blocks_persist_kernel<1, 3>)};
+      const void* ks[4] = {reinterpret_cast<const void*>(&rf_blocks_persist_kernel<0, 2>), reinterpret_cast<const void*>(&rf_blocks_persist_kernel<1, 2>),
+                           reinterpret_cast<const void*>(&rf_blocks_persist_kernel<2, 2>), reinterpret_cast<const void*>(&rf_blocks_persist_kernel<0, 3>)};
       for (const void* k : ks)
         if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
           mn_set_error("rf_blocks_persist: cannot reserve %zu bytes of LDS", lds);
@@ -922,7 +923,6 @@ int rf_blocks_persist(int wfmt, float* h, bf16_t* Y3, int M, int w, int hid, con
   { const int rc_o = mn_persist_order_before(st); if (rc_o != MN_OK) return rc_o; }
   const dim3 grid((unsigned)G), block(KC_WAVES * 64);
   if (wfmt == MN_W_NF4) hipLaunchKernelGGL((rf_blocks_persist_kernel<2, 2>), grid, block, lds, st, p);
-  else if (M > 2 && wfmt) hipLaunchKernelGGL((rf_blocks_persist_kernel<1, 3>), grid, block, lds, st, p);
   else if (M > 2) hipLaunchKernelGGL((rf_blocks_persist_kernel<0, 3>), grid, block, lds, st, p);
   else if (wfmt) hipLaunchKernelGGL((rf_blocks_persist_kernel<1, 2>), grid, block, lds, st, p);
   else hipLaunchKernelGGL((rf_blocks_persist_kernel<0, 2>), grid, block, lds, st, p);
@@ -975,12 +975,11 @@ int rf_w12_kc(int wfmt, const float* h, int M, int w, int hid, const bf16_t* ln_
 #define MN_OPT(WQ_) opt_in(&rf_w12_kc_kernel<WQ_, 2, 1, 8>); opt_in(&rf_w12_kc_kernel<WQ_, 2, 2, 8>); opt_in(&rf_w12_kc_kernel<WQ_, 2, 3, 8>);
     MN_OPT(0) MN_OPT(1) MN_OPT(2)
 #undef MN_OPT
-    opt_in(&rf_w12_kc_kernel<0, 3, 1, 8>); opt_in(&rf_w12_kc_kernel<1, 3, 1, 8>);
+    opt_in(&rf_w12_kc_kernel<0, 3, 1, 8>);
     opted = true;
   }
-  if (M > 2) {                                      // 3 rows (editing): the MR = 3 instances, one chunk in flight
-    if (wfmt) hipLaunchKernelGGL((rf_w12_kc_kernel<1, 3, 1, 8>), grid, block, lds, mn_stream(stream), a);
-    else hipLaunchKernelGGL((rf_w12_kc_kernel<0, 3, 1, 8>), grid, block, lds, mn_stream(stream), a);
+  if (M > 2) {                                      // 3 rows (editing; bf16): the MR = 3 instance, one chunk in flight
+    hipLaunchKernelGGL((rf_w12_kc_kernel<0, 3, 1, 8>), grid, block, lds, mn_stream(stream), a);
     MN_CHECK_LAUNCH("rf_w12_kc");
     return MN_OK;
   }
@@ -1007,12 +1006,11 @@ int rf_w3_kc(int wfmt, const bf16_t* Y3, int M, int w, int hid, const void* W3, 
     opt_in(&rf_w3_kc_kernel<0, 1>); opt_in(&rf_w3_kc_kernel<0, 2>); opt_in(&rf_w3_kc_kernel<0, 4>);
     opt_in(&rf_w3_kc_kernel<1, 1>); opt_in(&rf_w3_kc_kernel<1, 2>); opt_in(&rf_w3_kc_kernel<1, 4>);
     opt_in(&rf_w3_kc_kernel<2, 1>); opt_in(&rf_w3_kc_kernel<2, 2>); opt_in(&rf_w3_kc_kernel<2, 4>);
-    opt_in(&rf_w3_kc_kernel<0, 2, 12, true>); opt_in(&rf_w3_kc_kernel<1, 4, 12, true>);
+    opt_in(&rf_w3_kc_kernel<0, 2, 12, true>);
     opted = true;
   }
-  if (M > 2) {                                      // 3 rows: half tiles (w3_body<.., HALF>), chunks in flight by format
-    if (wfmt) hipLaunchKernelGGL((rf_w3_kc_kernel<1, 4, 12, true>), grid, block, lds, mn_stream(stream), a);
-    else hipLaunchKernelGGL((rf_w3_kc_kernel<0, 2, 12, true>), grid, block, lds, mn_stream(stream), a);
+  if (M > 2) {                                      // 3 rows (bf16): half tiles (w3_body<.., HALF>), two chunks in flight
+    hipLaunchKernelGGL((rf_w3_kc_kernel<0, 2, 12, true>), grid, block, lds, mn_stream(stream), a);
     MN_CHECK_LAUNCH("rf_w3_kc");
     return MN_OK;
   }

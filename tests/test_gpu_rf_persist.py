@@ -171,9 +171,10 @@ def test_a_late_resident_workgroup_poisons_the_result_and_raises_on_the_host():
 def test_three_rows_take_the_k_complete_launches_and_match_the_oracle(weights):
     """Round 6: 3 rows — the editing shape, RectifiedFlowLoss.sample's 3-way CFG (diff_loss_rf_swiglu.py:143-150) — ran
     the three-launch chain because w3's operand image + 8 KiB weight tiles per wave exceed the 160 KiB of LDS; with half tiles (4 KiB per
-    wave, chunks parked in two halves) the K-complete launches and the whole-sampler persistent launch take 3 rows too (bf16, e4m3;
-    int8 keeps its launches, NF4 the chain).  Against the oracle's sample() fed the mode's de-quantised weights, 1e-3; the persistent
-    launch (default) and the launch chain (MINGNATIVE_RF_PERSIST=0 would give it; here: inside a graph capture) agree to 1e-5."""
+    wave, chunks parked in two halves) the K-complete launches and the whole-sampler persistent launch take 3 rows too — bf16 heads:
+    the byte formats keep the chain at 3 rows (a masked half-tile park measured slower than it).  Every mode against the oracle's
+    sample() fed the mode's de-quantised weights, 1e-3; the persistent launch (default) and the launch form of the same bodies (what
+    MINGNATIVE_RF_PERSIST=0 gives; here: inside a graph capture) agree to 1e-5."""
     from oracle import rf_ref
     from tests.util import rel_err
     rf = _head(weights)
