@@ -209,6 +209,8 @@ SYMBOLS = {
     "mn_rf_workspace_bytes": (_sz, [C.POINTER(RfHead), _i]),
     "mn_persist_set_status_word": (_i, [_p]),
     "mn_llm_route_capture": (_i, [_p]),
+    "mn_gemm256_f8": (_i, [_p, _i64, _p, _p, _i64, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),
+    "mn_gemm256_f8_slices": (_i, [_i, _i]),
     "mn_rf_max_rows": (_i, [C.POINTER(RfHead)]),
     "mn_llm_max_rows": (_i, [C.POINTER(Llm)]),
     "mn_semdec_max_rows": (_i, [C.POINTER(SemDec)]),

@@ -172,6 +172,10 @@ typedef struct mn_g256 {
   const int32_t* tile_g; const int32_t* tile_m0; const int32_t* n_tiles; int max_mtiles;
   int group_m;                                           // set by the launcher: M-tiles per band of the tile order (0: tm fastest over all M-tiles)
   int thin;                                              // set by the launcher: tile lists skip the MFMAs / fragment reads of M-fragments without a live row
+  // fp8-MFMA regime (f8 != 0; labelled reduced arithmetic, never the default): A and W point to OCP e4m3 BYTES (lda / ldw / K count
+  // bytes = elements, K % 128 == 0), a_scale [M] / w_scale [N or 2N] are the operands' fp32 row scales (the accumulators are multiplied
+  // by a_scale[m] * w_scale[n] before bias / epilogue); no hi/lo rows, epilogues F32 (split-K allowed) and SWIGLU_BF16
+  int f8; const float* a_scale; const float* w_scale;
 } mn_g256;
 enum { MN_G256_F32 = 0, MN_G256_BF16 = 1, MN_G256_BF16_GELU = 2, MN_G256_F32_RESID = 3, MN_G256_SWIGLU_SPLIT = 4,
        MN_G256_F32_RESID_GATE = 5, MN_G256_SWIGLU_BF16 = 6 };

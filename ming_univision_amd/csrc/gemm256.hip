@@ -46,6 +46,13 @@
 //   * w_pair_rows != 0 — gate/up pairing (SwiGLU): W half 0 holds 128 gate rows, half 1 the matching up rows
 //     (w_pair_rows further down), so a lane holds silu-gate and up of the same hidden unit: the SwiGLU, its bias and
 //     the bf16 hi/lo split of the next GEMM's operand happen in the epilogue, a tile covers 128 hidden units.
+//
+// fp8-MFMA regime (template F8; BASELINE configs[4]'s "fp8 MFMA", round 6 — a LABELLED reduced-arithmetic leg with its own tolerance, never
+// the default): both operands are OCP e4m3 bytes with one fp32 scale per row, a K-tile is 128 k = the same 128 bytes per row, so staging,
+// swizzle, fragment reads and schedule are unchanged; the two bf16 MFMAs a (fragment, fragment) pair issued per K-tile (k 0..31 | 32..63)
+// become ONE v_mfma_scale_f32_16x16x128_f8f6f4 on the concatenated 32-byte fragments with unit block scales (E8M0 127) — the k order
+// inside the instruction is then {slot fq, slot 4 + fq} for BOTH operands, a permutation the dot product does not see.  Twice the flops
+// per K-tile at the same issue rate: the dense fp8 peak is 2 x the bf16 one (MI355X_MICROARCH.md), 4 x the hi/lo pair's.
 #include <type_traits>
 #include <utility>
 
@@ -55,6 +62,8 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -82,7 +91,7 @@ __device__ __forceinline__ void wait_vm() {
 
 // per-lane byte offsets (from A / W) of the global row behind LDS row L = 16*wave + 8*q + (lane >> 3) of half h, with
 // the k-slot swizzle (lane & 7) ^ f(L), f(row) = (row >> 1) & 7, folded in.  All offsets fit 32 bits (host check).
-template <bool HILO, bool PAIRED>
+template <bool HILO, bool PAIRED, bool F8 = false>
 __device__ __forceinline__ void g256_src_offsets(const G256& p, int wave, int lane, int m0, int n0, int row0, int Mg, int kbeg,
                                                  uint32_t (&srcA)[2][2], uint32_t (&srcW)[2][2]) {
   const int rin = lane >> 3;
@@ -99,8 +108,9 @@ __device__ __forceinline__ void g256_src_offsets(const G256& p, int wave, int la
       if (p.a_rows) gm = p.a_rows[gm];
       if (PAIRED) gn = min(n0 + L, p.N - 1) + (h ? (int)p.w_pair_rows : 0);
       else gn = min(n0 + (L >> 5) * 64 + h * 32 + (L & 31), p.N - 1);
-      srcA[h][q] = (uint32_t)(((int64_t)gm * p.lda + (HILO && h ? p.a_lo_off : 0) + kbeg) * 2 + ks);
-      srcW[h][q] = (uint32_t)(((int64_t)gn * p.ldw + kbeg) * 2 + ks);
+      constexpr int ES = F8 ? 1 : 2;                              // bytes per element
+      srcA[h][q] = (uint32_t)(((int64_t)gm * p.lda + (HILO && h ? p.a_lo_off : 0) + kbeg) * ES + ks);
+      srcW[h][q] = (uint32_t)(((int64_t)gn * p.ldw + kbeg) * ES + ks);
     }
 }
 
@@ -159,7 +169,7 @@ __device__ __forceinline__ void g256_emit(const G256& p, char* Cz, int m, int n,
 
 // Epilogue of one output tile of the 8-wave kernel.  A lane holds, per (i, j), output row 16 i + fr and the 4 CONSECUTIVE
 // columns 16 j + 4 fq .. +3.
-template <int EPI, bool HILO>
+template <int EPI, bool HILO, bool F8 = false>
 __device__ __forceinline__ void g256_epilogue(const G256& p, const f32x4 (&acc)[8][4], int wr, int wc, int fr, int fq, int m0,
                                               int n0, int row0, int Mg, int zslice) {
   constexpr bool hilo = HILO, paired = epi_paired(EPI);
@@ -177,13 +187,19 @@ __device__ __forceinline__ void g256_epilogue(const G256& p, const f32x4 (&acc)[
       if (hilo) v += acc[(i + 4) & 7][j];
       f32x4 u = {0.f, 0.f, 0.f, 0.f};
       if (paired) { u = acc[i][(j + 2) & 3]; if (hilo) u += acc[(i + 4) & 7][(j + 2) & 3]; }
+      if constexpr (F8) {                              // e4m3 operands: the row scales of both sides (before bias and epilogue)
+        const float sa = p.a_scale[row0 + ml];
+        v *= *reinterpret_cast<const f32x4*>(p.w_scale + n) * sa;
+        if (paired) u *= *reinterpret_cast<const f32x4*>(p.w_scale + p.w_pair_rows + n) * sa;
+      }
       g256_emit<EPI>(p, Cz, row0 + ml, n, v, u, zslice);
     }
   }
 }
 
-template <int EPI, bool HILO>
+template <int EPI, bool HILO, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
+  static_assert(!F8 || !HILO, "the fp8 regime is single-pass");
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -244,11 +260,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   }
   const int n0 = tn * cols_per_tile;
   const int kbeg = blockIdx.y * p.Kc, kend = min(p.K, kbeg + p.Kc);
-  const int nk = (kend - kbeg) / BK;
+  const int nk = (kend - kbeg) / (F8 ? 2 * BK : BK);        // (an fp8 K-tile is 128 k: the same 128 bytes per row)
 
   // ---- staging: wave w fills LDS rows [16w, 16w+16) of a half-tile with two instructions of 8 rows x 8 slots ----
   uint32_t srcA[2][2], srcW[2][2];
-  g256_src_offsets<hilo, paired>(p, wave, lane, m0, n0, row0, Mg, kbeg, srcA, srcW);
+  g256_src_offsets<hilo, paired, F8>(p, wave, lane, m0, n0, row0, Mg, kbeg, srcA, srcW);
   // Row tiles of a tile list (the expert GEMMs) are often mostly padding — 144 rows per expert = a full tile + a 16-row one —, and
   // a power-limited chip pays for the MFMAs and fragment reads of clamped rows in clock: M-fragments of this wave row without a live
   // row are skipped (wave-uniform count, one copy of the K loop per count so that no branch sits inside an MFMA cluster).  The last
@@ -256,7 +272,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   constexpr bool thin = HILO && (EPI == E_F32 || EPI == E_SWIGLU_SPLIT);
   const int live_f = (thin && p.thin) ? __builtin_amdgcn_readfirstlane(min(4, max(0, (Mg - m0 - wr * 64 + 15) >> 4))) : 4;
   const char* Ab = reinterpret_cast<const char*>(p.A);
-  const char* Wb = reinterpret_cast<const char*>(p.W) + (int64_t)grp * p.w_gstride * 2;
+  const char* Wb = reinterpret_cast<const char*>(p.W) + (int64_t)grp * p.w_gstride * (F8 ? 1 : 2);
   auto stage = [&](int op, int h, int kt, int buf) {   // op 0 = A, 1 = W; all arguments compile-time or wave-uniform
     char* dst = &lds[lds_off(buf, op, h) + wave * 2048];
     const uint32_t koff = (uint32_t)kt * (BK * 2);
@@ -294,6 +310,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   // quadrant (mh, nh): D[n][m] += W-frag (as A operand) x activation frag (as B operand)
   auto quad = [&](int mh, int nh, bf16x8 (&wf)[4], auto LVc) {
     constexpr int LV = decltype(LVc)::value;
+    if constexpr (F8) {                                 // one scaled MFMA per fragment pair: K = 128 e4m3, unit block scales
+#pragma unroll
+      for (int i = 0; i < LV; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const i32x8 wa = __builtin_shufflevector(__builtin_bit_cast(i32x4, wf[2 * j]), __builtin_bit_cast(i32x4, wf[2 * j + 1]), 0, 1, 2, 3, 4, 5, 6, 7);
+          const i32x8 xa = __builtin_shufflevector(__builtin_bit_cast(i32x4, af[2 * i]), __builtin_bit_cast(i32x4, af[2 * i + 1]), 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, acc[mh * 4 + i][nh * 2 + j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -360,7 +387,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
 
-  g256_epilogue<EPI, HILO>(p, acc, wr, wc, fr, fq, m0, n0, row0, Mg, blockIdx.y);
+  g256_epilogue<EPI, HILO, F8>(p, acc, wr, wc, fr, fq, m0, n0, row0, Mg, blockIdx.y);
 }
 
 
@@ -387,9 +414,19 @@ static int g256_launch(const G256& a, int epi, int ksplit, hipStream_t st) {
   p.group_m = a.tile_g ? g_g256_groupb : g_g256_groupm;
   p.thin = g_g256_thin;
   p.Kc = p.K;
-  if (ksplit > 1) p.Kc = (int)(mn_cdiv(mn_cdiv(p.K, ksplit), 2 * BK) * 2 * BK);   // even number of K-tiles per slice
+  const int kq = a.f8 ? 4 * BK : 2 * BK;             // an even number of K-tiles per slice (fp8: 128 k per K-tile)
+  if (ksplit > 1) p.Kc = (int)(mn_cdiv(mn_cdiv(p.K, ksplit), kq) * kq);
   const int nz = (int)mn_cdiv(p.K, p.Kc);
   dim3 grid(tiles, nz, (a.g_off && !a.tile_g) ? a.n_groups : 1);
+  if (a.f8) {                                          // the fp8-MFMA regime: plain rows, fp32 (split-K) or SwiGLU -> bf16 results
+    if (hilo || !a.a_scale || !a.w_scale || (a.K % (2 * BK)) != 0 || (epi != E_F32 && epi != E_SWIGLU_BF16)) {
+      mn_set_error("gemm256 (fp8): needs row scales, K %% 128 == 0, no hi/lo rows, epilogue F32 or SWIGLU_BF16");
+      return MN_EINVAL;
+    }
+    if (epi == E_F32) hipLaunchKernelGGL((gemm256_kernel<E_F32, false, true>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((gemm256_kernel<E_SWIGLU_BF16, false, true>), grid, dim3(512), 0, st, p);
+    return nz;
+  }
 #define G256_GO(E)                                                                          \
   do {                                                                                      \
     if (hilo) hipLaunchKernelGGL((gemm256_kernel<E, true>), grid, dim3(512), 0, st, p);     \
@@ -421,6 +458,11 @@ extern "C" int mn_gemm256_ex(const mn_g256* a, int epi, int ksplit, void* stream
 extern "C" int mn_gemm256_slices(int K, int ksplit) {
   if (ksplit <= 1) return 1;
   const int Kc = (int)(mn_cdiv(mn_cdiv(K, ksplit), 2 * BK) * 2 * BK);
+  return (int)mn_cdiv(K, Kc);
+}
+extern "C" int mn_gemm256_f8_slices(int K, int ksplit) {      // the fp8 regime: 128 k per K-tile
+  if (ksplit <= 1) return 1;
+  const int Kc = (int)(mn_cdiv(mn_cdiv(K, ksplit), 4 * BK) * 4 * BK);
   return (int)mn_cdiv(K, Kc);
 }
 
@@ -572,4 +614,27 @@ extern "C" int mn_gemm256_grouped_tiles(const uint16_t* A, int64_t lda, int64_t 
   if (rc < 0) return rc;
   MN_CHECK_LAUNCH("mn_gemm256_grouped_tiles");
   return MN_OK;
+}
+
+// ---- fp8-MFMA regime: the stand-alone entry (mingnative.h section 8) -------------------------------------------------------------
+// C = epilogue( (A8 . a_scale) (W8 . w_scale)^T + bias ): A8 e4m3 [M, K] with one fp32 scale per row, W8 e4m3 [N or 2N, K] likewise.
+//   swiglu == 0: C fp32 [M, N] (ldc); ksplit > 1: slice z writes its partial product to C + z * M * N (ldc must be N), bias in slice 0
+//   swiglu == 1: W8 holds 2N rows (gate rows, then up rows), C bf16 [M, N] = silu(gate) * up
+// Returns the number of split-K slices used (>= 1) or a negative error.
+extern "C" int mn_gemm256_f8(const uint8_t* A, int64_t lda, const float* a_scale, const uint8_t* W, int64_t ldw, const float* w_scale,
+                             const uint16_t* bias, void* C, int64_t ldc, int M, int N, int K, int swiglu, int ksplit, void* stream) {
+  MN_CHECK_ARG(A && W && C && a_scale && w_scale && ksplit >= 1 && (!swiglu || ksplit == 1), "mn_gemm256_f8: bad args");
+  MN_CHECK_ARG(M >= 1 && N >= 4 && (N % 4) == 0 && K >= 2 * BK && (K % (2 * BK)) == 0 && (lda % 16) == 0 && (ldw % 16) == 0 &&
+                   (((uintptr_t)A | (uintptr_t)W) & 15) == 0 && (int64_t)M * lda < ((int64_t)1 << 32) &&
+                   (int64_t)(swiglu ? 2 : 1) * N * ldw < ((int64_t)1 << 32) && (((uintptr_t)w_scale) & 15) == 0 &&
+                   g256_out_ok(C, ldc, 0, bias, !swiglu) && (ksplit == 1 || ldc == N),
+               "mn_gemm256_f8: unsupported shape M=%d N=%d K=%d (K %% 128 == 0, N %% 4 == 0, 16-byte rows and scales, < 4 GiB operands)", M, N, K);
+  G256 p{};
+  p.A = reinterpret_cast<const bf16_t*>(A); p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(W); p.ldw = ldw; p.bias = bias;
+  p.C = C; p.ldc = ldc; p.c_zstride = (int64_t)M * N; p.M = M; p.N = N; p.K = K; p.w_pair_rows = swiglu ? N : 0;
+  p.f8 = 1; p.a_scale = a_scale; p.w_scale = w_scale;
+  const int nz = g256_launch(p, swiglu ? E_SWIGLU_BF16 : E_F32, ksplit, mn_stream(stream));
+  if (nz < 0) return nz;
+  MN_CHECK_LAUNCH("mn_gemm256_f8");
+  return nz;
 }

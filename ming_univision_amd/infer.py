@@ -14,7 +14,7 @@ directory when a `tokenizer.json` is present, otherwise the byte-level stand-in 
            skip list, which replaces HF's default one) becomes bf16(NF4[code] * absmax) with one fp32 absmax per 64 weights.  The RF
            head's ResBlock / adaLN matrices and the decoder's experts — 95 % of the bytes a visual token streams — live in HBM as 4-bit
            codes and are decoded inside the weight-streaming kernels; the other Linears hold the same model's values as bf16;
-  "int8" — optimum-quanto's qint8 rule restated (oracle/int8_ref.py): every nn.Linear weight becomes bf16(s * q) with
+  "int8" — optimum-quanto's qint8 rule restated: every nn.Linear weight becomes bf16(s * q) with
            a bf16-valued scale s = amax / 127 per output row and q = clamp(round(W / s), -128, 127); experts, RF ResBlock and adaLN
            matrices are streamed as int8 bytes and decoded in the kernels, the other Linears hold the same values as bf16;
   "fp8"  — the same tensors as OCP e4m3 bytes + power-of-two row scales (no reference counterpart).

@@ -266,6 +266,30 @@ def gemm256_swiglu(a, w12, b12=None):
     return y
 
 
+def gemm256_f8(a8, a_scale, w8, w_scale, bias=None, swiglu=False, ksplit=1):
+    """The fp8-MFMA regime's GEMM (mingnative.h section 8; a labelled reduced-arithmetic regime): a8 uint8 [M, K] e4m3 bytes +
+    a_scale fp32 [M], w8 uint8 [N or 2N, K] + w_scale fp32 [N or 2N] (quant_rows(x, "fp8") of both operands) ->
+    fp32 [M, N] (swiglu=False; ksplit > 1: the sum of the split-K slabs) or bf16 [M, N] = silu(gate) * up (swiglu=True)."""
+    _req(a8, torch.uint8, "a8"); _req(w8, torch.uint8, "w8"); _req(a_scale, torch.float32, "a_scale"); _req(w_scale, torch.float32, "w_scale")
+    _req(bias, torch.bfloat16, "bias")
+    M, K = a8.shape
+    N = w8.shape[0] // (2 if swiglu else 1)
+    assert w8.shape[1] == K and a_scale.numel() == M and w_scale.numel() == w8.shape[0] and a8.is_contiguous() and w8.is_contiguous()
+    if swiglu:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a8.device)
+        nz = lib().mn_gemm256_f8(ptr(a8), K, ptr(a_scale), ptr(w8), K, ptr(w_scale), ptr(bias), ptr(out), N, M, N, K, 1, 1, current_stream())
+        if nz < 0:
+            check(nz, "mn_gemm256_f8")
+        return out
+    nzr = lib().mn_gemm256_f8_slices(K, ksplit)
+    out = torch.empty(nzr, M, N, dtype=torch.float32, device=a8.device)
+    nz = lib().mn_gemm256_f8(ptr(a8), K, ptr(a_scale), ptr(w8), K, ptr(w_scale), ptr(bias), ptr(out), N, M, N, K, 0, ksplit, current_stream())
+    if nz < 0:
+        check(nz, "mn_gemm256_f8")
+    assert nz == nzr
+    return out[0] if nz == 1 else out.sum(0)
+
+
 def gemm256_grouped(a2, a_rows, w, off, cnt, n_pos, m_max, swiglu):
     """Grouped (MoE) form: a2 bf16 [2, R, K] hi/lo pair; a_rows int32 [n_pos] or None; w bf16 [G, N or 2N, K];
     off / cnt int32 device arrays.  Returns fp32 [n_pos, N] or the bf16 hi/lo pair [2, n_pos, N] (swiglu)."""
