@@ -429,7 +429,14 @@ typedef struct mn_rf_head {
    * scales.  Used when all Euler steps' rows fit one streaming launch (steps * rows <= 64, i.e. <= 4 CFG rows at 16 steps: the
    * reference's call shape); ada_w must then hold the SAME values (the exact bf16 expansion) for the larger row counts. */
   const uint8_t* ada_q; const float* ada_scale;
+  /* (0.1.24) arithmetic regime of the WIDE route (> 64 rows in lock-step); 0 = fp32-class (bf16 hi/lo MFMA pairs, the parity regime).
+   * MN_ARITH_FP8_MFMA (section 8; needs wfmt == MN_W_FP8_E4M3 with ada_q): the ResBlock GEMMs w12 / w3 and the adaLN GEMM multiply
+   * e4m3 activations (quantised per row from the bf16 operand) by the e4m3 weight bytes on the scaled fp8 MFMA — no bf16 expansion of
+   * the weights, 2.2-2.6 x the hi/lo pair's rate per GEMM — a LABELLED reduced-arithmetic regime with its own stated tolerance
+   * (tests/test_gpu_fp8_mfma.py); every other Linear of the head, and every route up to 64 rows, is unchanged. */
+  int32_t arith;
 } mn_rf_head;
+enum { MN_ARITH_FP32_CLASS = 0, MN_ARITH_FP8_MFMA = 1 };
 
 /* hidden [rows, llm_hidden] fp32 (last hidden states of the LLM step), rows = n_images x R image-major with
  * R = 1 (no CFG), 2 ([cond, uncond]) or 3 ([cond, uncond, text_uncond]) rows per image; rows <= 64.

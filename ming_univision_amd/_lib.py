@@ -55,6 +55,7 @@ class RfHead(C.Structure):
         ("ln_g", PP), ("ln_b", PP), ("w12", PP), ("b12", PP), ("w3", PP), ("b3", PP),
         ("fin_w", C.c_void_p), ("fin_b", C.c_void_p),
         ("wfmt", C.c_int32), ("w12_scale", PP), ("w3_scale", PP), ("ada_q", C.c_void_p), ("ada_scale", C.c_void_p),
+        ("arith", C.c_int32),
     ]
 
 

@@ -85,7 +85,7 @@ extern "C" int mn_struct_layout(int which, size_t* offsets, int cap) {
 #define F(f) MN_OFF(mn_rf_head, f)
       F(w) F(depth) F(hidden) F(z_dim) F(target) F(steps) F(llm_hidden) F(vis_w) F(vis_b) F(vis_ln_g) F(vis_ln_b) F(cond_w) F(cond_b)
       F(in_w) F(in_b) F(temb) F(ada_w) F(ada_b) F(ln_g) F(ln_b) F(w12) F(b12) F(w3) F(b3) F(fin_w) F(fin_b) F(wfmt) F(w12_scale)
-      F(w3_scale) F(ada_q) F(ada_scale)
+      F(w3_scale) F(ada_q) F(ada_scale) F(arith)
 #undef F
   };
   static const size_t llm[] = {

@@ -36,6 +36,7 @@ struct RfWideWs {
   float* pbuf_stream3;   // tp.inl, <= 4 rows: w3's slabs when its prologue reads w12's (stream_fuse.h)
   bf16_t *hs, *zs, *y, *ya, *yb;
   bf16_t *wq12, *wq3;    // weight-only modes: the blocks' weights de-quantised once per call, [depth][2 hidden][w] / [depth][w][hidden]
+  float* f8s;            // fp8-MFMA regime: the activations' row scales — [steps * rows] adaLN operand, [rows] w12 operand, [rows] w3 operand
   int ks12, ks3, ksf;    // split-K requests of the w12 (1 = SwiGLU in the GEMM epilogue), w3 and final GEMMs
 };
 
@@ -97,6 +98,21 @@ static int rf_wide_ksplit(int rows, int N, int K) {
   return best;
 }
 
+// the fp8-MFMA regime of the wide route (mn_rf_head.arith; mingnative.h section 8): e4m3 weights present, widths in whole 128-k tiles
+static bool rf_f8_mfma(const mn_rf_head* h) {
+  return h->arith == MN_ARITH_FP8_MFMA && h->wfmt == MN_W_FP8_E4M3 && h->ada_q && h->ada_scale && h->w12_scale && h->w3_scale &&
+         (h->w % 128) == 0 && (h->hidden % 128) == 0;
+}
+extern "C" int mn_quant_fp8_rows(const uint16_t*, int64_t, uint8_t*, int64_t, float*, int64_t, int, void*);
+static mn_g256 g256_f8(const uint8_t* A, int64_t lda, const float* a_scale, const void* W, int64_t ldw, const float* w_scale, const bf16_t* bias,
+                       void* C, int64_t ldc, int M, int N, int K) {
+  mn_g256 a;
+  memset(&a, 0, sizeof(a));
+  a.A = reinterpret_cast<const bf16_t*>(A); a.lda = lda; a.W = reinterpret_cast<const bf16_t*>(W); a.ldw = ldw; a.bias = bias; a.C = C; a.ldc = ldc;
+  a.M = M; a.N = N; a.K = K; a.f8 = 1; a.a_scale = a_scale; a.w_scale = w_scale;
+  return a;
+}
+
 static size_t rf_wide_carve(const mn_rf_head* h, int rows, void* ws, size_t cap, RfWideWs* o) {
   Carver cv(ws, cap, ws == nullptr);
   const int64_t SR = (int64_t)h->steps * rows;
@@ -121,8 +137,10 @@ static size_t rf_wide_carve(const mn_rf_head* h, int rows, void* ws, size_t cap,
   o->y = cv.take<bf16_t>((size_t)2 * SR * h->w);
   o->ya = cv.take<bf16_t>((size_t)2 * rows * h->w);
   o->yb = cv.take<bf16_t>((size_t)2 * rows * h->hidden);
-  o->wq12 = cv.take<bf16_t>(h->wfmt ? (size_t)h->depth * 2 * h->hidden * h->w : 0);
-  o->wq3 = cv.take<bf16_t>(h->wfmt ? (size_t)h->depth * h->w * h->hidden : 0);
+  const bool f8 = rf_f8_mfma(h);                          // (the e4m3 bytes ARE the operands: no bf16 expansion of the blocks)
+  o->wq12 = cv.take<bf16_t>(h->wfmt && !f8 ? (size_t)h->depth * 2 * h->hidden * h->w : 0);
+  o->wq3 = cv.take<bf16_t>(h->wfmt && !f8 ? (size_t)h->depth * h->w * h->hidden : 0);
+  o->f8s = cv.take<float>(f8 ? (size_t)SR + 2 * (size_t)rows + 64 : 0);
   return cv.off;
 }
 
@@ -176,10 +194,23 @@ static int rf_sample_wide(const mn_rf_head* h, const float* hidden, int64_t ld_h
   hipLaunchKernelGGL(rf_init_x_kernel, dim3(mn_cdiv(rows * T, 256)), dim3(256), 0, st, noise, temperature, w.x, rows, T, rpi);
   // modulations of every Euler step: [steps * rows, w] x [w, depth*3w + 2w], adaLN weights read once per token
   hipLaunchKernelGGL(rf_build_y_kernel, dim3(mn_cdiv(SR * W, 256)), dim3(256), 0, st, h->temb, w.c, w.y, h->steps, rows, W);
-  a = g256_hilo(w.y, W, lo_at(LO_RF_ADA, SR * W), h->ada_w, W, h->ada_b, w.ada, A, (int)SR, A, W);
-  MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
+  const bool f8 = rf_f8_mfma(h);
+  // fp8-MFMA regime: every GEMM operand below is the bf16 hi part of what the hi/lo route multiplies, quantised per row to e4m3 (the lo
+  // rows of the pair — dead in this regime — hold the bytes); scales in w.f8s
+  float* s_ada = w.f8s;
+  float* s_a = w.f8s + SR;
+  float* s_b = s_a + rows;
+  if (f8) {
+    uint8_t* y8 = reinterpret_cast<uint8_t*>(w.y + SR * W);
+    MN_TRYZ(mn_quant_fp8_rows(w.y, W, y8, W, s_ada, SR, W, stream));
+    a = g256_f8(y8, W, s_ada, h->ada_q, W, h->ada_scale, h->ada_b, w.ada, A, (int)SR, A, W);
+    MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
+  } else {
+    a = g256_hilo(w.y, W, lo_at(LO_RF_ADA, SR * W), h->ada_w, W, h->ada_b, w.ada, A, (int)SR, A, W);
+    MN_TRYZ(mn_gemm256_ex(&a, MN_G256_F32, 1, stream));
+  }
 
-  if (h->wfmt) {          // weight-only mode: W' of every block, once per call
+  if (h->wfmt && !f8) {          // weight-only mode: W' of every block, once per call
     for (int b = 0; b < h->depth; ++b) {
       MN_TRYZ(wide_dequant_rows(h->wfmt, h->w12[b], h->w12_scale[b], w.wq12 + (int64_t)b * 2 * HID * W, (int64_t)2 * HID, W, stream));
       MN_TRYZ(wide_dequant_rows(h->wfmt, h->w3[b], h->w3_scale[b], w.wq3 + (int64_t)b * W * HID, (int64_t)W, HID, stream));
@@ -199,6 +230,31 @@ static int rf_sample_wide(const mn_rf_head* h, const float* hidden, int64_t ld_h
       const float* mod = ada + (int64_t)b * 3 * W;
       const bf16_t* w12b = h->wfmt ? w.wq12 + (int64_t)b * 2 * HID * W : h->w12[b];
       const bf16_t* w3b = h->wfmt ? w.wq3 + (int64_t)b * W * HID : h->w3[b];
+      if (f8) {
+        // w12: e4m3(ya) x e4m3(W12) with the SwiGLU in the epilogue -> bf16 [rows, HID]; w3: e4m3 of that x e4m3(W3), split-K slabs
+        uint8_t* ya8 = reinterpret_cast<uint8_t*>(w.ya + lo_a);
+        bf16_t* yb16 = w.yb;
+        uint8_t* yb8 = reinterpret_cast<uint8_t*>(w.yb + lo_b);
+        MN_TRYZ(mn_quant_fp8_rows(w.ya, W, ya8, W, s_a, rows, W, stream));
+        a = g256_f8(ya8, W, s_a, h->w12[b], W, h->w12_scale[b], h->b12[b], yb16, HID, rows, HID, W);
+        a.w_pair_rows = HID;
+        MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_BF16, 1, stream));
+        MN_TRYZ(mn_quant_fp8_rows(yb16, HID, yb8, HID, s_b, rows, HID, stream));
+        a = g256_f8(yb8, HID, s_b, h->w3[b], HID, h->w3_scale[b], nullptr, w.pbuf, W, rows, W, HID);
+        a.c_zstride = (int64_t)rows * W;
+        const int nz8 = mn_gemm256_ex(&a, MN_G256_F32, w.ks3, stream);
+        if (nz8 < 0) return nz8;
+        const bool last8 = b + 1 == h->depth;
+        const float* nmod8 = last8 ? ada + (int64_t)h->depth * 3 * W : ada + (int64_t)(b + 1) * 3 * W;
+        memset(&g, 0, sizeof(g));
+        g.h = w.hh; g.ldh = W; g.P = w.pbuf; g.nz = nz8; g.slab = (int64_t)rows * W; g.pbias = h->b3[b];
+        g.gate = mod + 2 * W; g.ldgate = A; g.h_out = w.hh; g.ldho = W;
+        g.norm = 2; g.ng = last8 ? nullptr : h->ln_g[b + 1]; g.nb = last8 ? nullptr : h->ln_b[b + 1]; g.eps = 1e-6f;
+        g.shift = nmod8; g.scale = nmod8 + W; g.ldmod = A;
+        g.Y = w.ya; g.ldy = W; g.y_lo_off = lo_a; g.M = rows; g.D = W;
+        wide_glue(g, st);
+        continue;
+      }
       if (w.ks12 > 1) {
         a = g256_hilo(w.ya, W, lo_at(LO_RF_W12, lo_a), w12b, W, nullptr, w.pbuf, 2 * HID, rows, 2 * HID, W);
         a.c_zstride = (int64_t)rows * 2 * HID;

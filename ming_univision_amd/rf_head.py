@@ -30,13 +30,18 @@ from .configuration import DEFAULT_VISHEAD_DIFFLOSS, swiglu_hidden
 
 
 class RectifiedFlowHead:
-    def __init__(self, sd, llm_hidden, vishead_diffloss_config=None, latent_dim=32, prefix="", weights="bf16"):
+    def __init__(self, sd, llm_hidden, vishead_diffloss_config=None, latent_dim=32, prefix="", weights="bf16", arith=None):
         """sd: {reference parameter name: bf16 CUDA tensor} holding `vis_head.*` and `diffloss.net.*`.
         weights: "bf16", or a weight-only mode ("fp8" / "int8" / "int4") = w12 / w3 / adaLN quantised here into streamed codes.  A head
         BUILT in a weight-only mode keeps no reference to the bf16 originals (the mode exists for its footprint: 2.4 GB of bf16 ResBlock
         matrices at the 16B-A3B shapes — they are freed as soon as the caller drops `sd`); only a bf16 head keeps them, for to_fp8()."""
         assert weights in _lib.WFMT, f"weights={weights!r}: 'bf16', 'fp8', 'int8' or 'int4'"
         self.weights = weights
+        # arith="fp8_mfma" (mingnative.h section 8; BASELINE configs[4]'s "fp8 MFMA"): a LABELLED reduced-arithmetic regime of the wide
+        # route (> 64 rows) — e4m3 activations x e4m3 weights on the scaled fp8 MFMA for w12 / w3 / adaLN — with its own stated tolerance;
+        # needs weights="fp8".  None: the fp32-class regime everywhere (the parity regime)
+        assert arith in (None, "fp8_mfma") and (arith is None or weights == "fp8"), "arith='fp8_mfma' needs weights='fp8'"
+        self.arith = arith
         cfg = {**DEFAULT_VISHEAD_DIFFLOSS, **(vishead_diffloss_config or {})}
         assert cfg["vis_head_arch"] == "linear2-norm"          # modeling_bailing_moe.py:1568
         assert cfg["gen_method"].startswith("flow_matching_swiglu-")
@@ -141,6 +146,7 @@ class RectifiedFlowHead:
         for k, arr in self._arrays.items():
             setattr(s, k, C.cast(arr, _lib.PP))
         s.wfmt = _lib.WFMT[weights]
+        s.arith = 1 if (getattr(self, "arith", None) == "fp8_mfma" and weights == "fp8") else 0
         if weights in _lib.W8:
             s.w12_scale = C.cast(self._scale_arrays["w12"], _lib.PP)
             s.w3_scale = C.cast(self._scale_arrays["w3"], _lib.PP)
@@ -148,12 +154,14 @@ class RectifiedFlowHead:
         self.struct = s
         self._ws = {}
 
-    def to_fp8(self, weights="fp8"):
+    def to_fp8(self, weights="fp8", arith=None):
         """A second head on the same HBM tensors in another weight mode — e4m3 (default), "int8" or "int4" — derived from the raw
-        bf16 tensors (this head stays usable)."""
+        bf16 tensors (this head stays usable).  arith="fp8_mfma": the labelled fp8-MFMA regime of the wide route (e4m3 weights only)."""
         import copy
         assert self.weights == "bf16" and weights in _lib.W8 and self._raw_t is not None
+        assert arith in (None, "fp8_mfma") and (arith is None or weights == "fp8")
         new = copy.copy(self)
+        new.arith = arith
         new._apply_mode(weights)
         return new
 

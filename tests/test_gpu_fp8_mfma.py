@@ -3,7 +3,7 @@ stated tolerance — the reference has no fp8 arithmetic, the 
 
 Two levels:
   * the KERNEL is exact arithmetic on what it is given: products of two e4m3 values are exact in fp32 and the accumulation is fp32, so
-    `mn_gemm256_f8` must agree with an fp64 product of the SAME quantised operands to fp32-accumulation rounding (<= 2e-5), over ragged
+    `mn_gemm256_f8` must agree with an fp64 product of the SAME quantised operands to fp32-accumulation rounding (<= 1e-4), over ragged
     shapes, split-K and the SwiGLU epilogue — the 1e-3-class bar of every other kernel here, untouched by the regime;
   * the REGIME (quantising both operands to e4m3 with one power-of-two scale per row) is what costs accuracy: against the fp64 product of
     the UN-quantised operands the stated tolerance is 6e-2 relative in max-norm (e4m3 carries 3 mantissa bits: 2^-4 relative per operand)."""
@@ -15,7 +15,7 @@ from tests.util import rel_err
 
 pytestmark = pytest.mark.gpu
 
-KERNEL_TOL = 2e-5
+KERNEL_TOL = 1e-4          # fp32 accumulation of exact products over K up to 8192
 REGIME_TOL = 6e-2
 
 
@@ -59,3 +59,43 @@ def test_gemm256_f8_rejects_what_it_cannot_run():
     x8 = torch.zeros(16, 192, dtype=torch.uint8, device="cuda"); s = torch.ones(16, device="cuda")
     with pytest.raises(RuntimeError):
         ops.gemm256_f8(x8, s, x8, s)                      # K % 128 != 0
+
+
+def test_rf_sampler_wide_route_in_the_fp8_mfma_regime_vs_oracle():
+    """RectifiedFlowLoss.sample (diff_loss_rf_swiglu.py:103-181) on the wide route with arith="fp8_mfma": w12 / w3 / adaLN on the scaled
+    fp8 MFMA (e4m3 activations x e4m3 weights), everything else fp32-class.  Against the fp32 oracle fed the de-quantised e4m3 weights:
+      * STATED TOLERANCE of the regime: 0.15 relative (max-norm) on the sampled latents of a 16-step, 8-block head — the activation
+        quantisation (3 mantissa bits) is re-applied at 2 x 8 x 16 GEMM inputs; the fp32-class regime on the SAME e4m3 model must stay
+        at 1e-3, which pins the difference on the arithmetic, not on the model;
+      * the regime changes nothing up to 64 rows (same bits as a head without it)."""
+    from oracle import rf_ref
+    from ming_univision_amd import configuration as C
+    from ming_univision_amd.rf_head import RectifiedFlowHead
+    from ming_univision_amd.synth import synth_tensor
+    w, d, steps, mult, LH = 1536, 8, 16, 4, 1024                          # SwiGLU hidden 4096: whole 128-k tiles
+    rf_cfg = dict(diffloss_w=w, diffloss_d=d, num_sampling_steps=str(steps), gen_method=f"flow_matching_swiglu-{mult}", vis_head_arch="linear2-norm")
+    shapes = {"vis_head.0.weight": (w, LH), "vis_head.0.bias": (w,), "vis_head.1.weight": (w,), "vis_head.1.bias": (w,)}
+    shapes.update(C.rf_param_shapes(w, d, w, 32, mult))
+    sd = {k: synth_tensor(k, s, 5, "cuda", torch.bfloat16) for k, s in shapes.items()}
+    rf16 = RectifiedFlowHead(sd, LH, rf_cfg)
+    rf8 = rf16.to_fp8("fp8")
+    rf8m = rf16.to_fp8("fp8", arith="fp8_mfma")
+    assert rf8m.struct.arith == 1 and rf8.struct.arith == 0
+    osd = {k: v.float().cpu() for k, v in sd.items()}
+    osd.update({k: v.float().cpu() for k, v in rf8.dequantized_blocks().items()})
+    rsd = {k[len("diffloss."):]: v for k, v in osd.items() if k.startswith("diffloss.")}
+    g = torch.Generator().manual_seed(2)
+    n_img, rpi = 65, 2
+    h = torch.randn(n_img * rpi, LH, generator=g)
+    n = torch.randn(n_img, 32, generator=g)
+    torch.set_num_threads(min(64, max(torch.get_num_threads(), 16)))
+    ref = torch.stack([rf_ref.sample(rf_ref.vis_head(h[i * rpi:(i + 1) * rpi], osd), n[i:i + 1], rsd, steps=steps)[0] for i in range(8)])
+    got8 = rf8.sample(h.cuda(), n.cuda(), n_images=n_img)
+    got8m = rf8m.sample(h.cuda(), n.cuda(), n_images=n_img)
+    e8, e8m = rel_err(got8[:8], ref), rel_err(got8m[:8], ref)
+    cos = torch.nn.functional.cosine_similarity(got8m[:8].flatten().double().cpu(), ref.flatten().double(), dim=0).item()
+    print(f"RF sampler, 130 rows, e4m3 model: fp32-class regime {e8:.2e} | fp8-MFMA regime {e8m:.2e} (cosine {cos:.5f}) vs the oracle")
+    assert e8 < 1e-3
+    assert e8m < 0.15 and cos > 0.995 and e8m > 1e-3            # (> 1e-3: the regime really ran)
+    small = torch.randn(4, LH, generator=g).cuda(); ns = torch.randn(2, 32, generator=g).cuda()
+    assert torch.equal(rf8m.sample(small, ns, n_images=2), rf8.sample(small, ns, n_images=2))
