@@ -602,17 +602,24 @@ class BailingMoeDecoder:
         uniforms u fp32 [M]): lm_head logits + mn_sample_logits.  hidden fp32 [M, H] -> int64 [M] on the device."""
         st = torch.empty(hidden.shape[0], dtype=torch.int32, device=hidden.device)
         ids = ops.sample_logits(self.logits(hidden.contiguous()), u, temperature, top_k, top_p, status=st)
-        # rows whose kept set was cut at the sampler's 2048 candidates (ops.SAMPLE_*), OR-ed on the device; read by
-        # `sampling_truncated()` at the caller's next host sync
-        flags = (st & 1).amax() | (st & 2).amax()
-        self.sample_flags = flags if getattr(self, "sample_flags", None) is None else self.sample_flags | flags
+        # rows whose kept set was cut at the sampler's 2048 candidates (ops.SAMPLE_*): the status words are only KEPT here — no kernel on
+        # the latency-critical decode loop (ADVICE r5) — and OR-ed at the caller's next host sync (`sampling_truncated()`)
+        pend = getattr(self, "_sample_status", None)
+        if pend is None:
+            pend = self._sample_status = []
+        pend.append(st)
+        if len(pend) >= 512:                       # bound the list on very long generations: one reduction per 512 tokens
+            self._sample_status = [torch.stack([(torch.cat(pend) & 1).amax(), (torch.cat(pend) & 2).amax()]).to(torch.int32)]
         return ids
 
     def sampling_truncated(self):
         """Host sync: ops.SAMPLE_* bits seen by `sample` since the last call (0 = every draw was HF's distribution exactly)."""
-        f = getattr(self, "sample_flags", None)
-        self.sample_flags = None
-        return 0 if f is None else int(f)
+        pend = getattr(self, "_sample_status", None)
+        self._sample_status = None
+        if not pend:
+            return 0
+        allst = torch.cat(pend)
+        return int((allst & 1).amax() | (allst & 2).amax())
 
     def embed(self, ids):
         """word_embeddings lookup -> fp32 rows (gather = memory plumbing)."""

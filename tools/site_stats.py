@@ -18,7 +18,20 @@ SITES = {
     ("E4", mt * (HID // 128), 1): "RF w12 (SwiGLU + split epilogue)",
     ("E0", cd(STEPS * rows, 128) * cd(A, 256), 1): "RF adaLN, all Euler steps",
     ("E4", cd(rows // 2, 128) * cd(2752, 128), 1): "semantic decoder w12 (per image)",
+    # the labelled fp8-MFMA regime (gemm256_kernel<.., false, true>: 256-row tiles, 128-k K-tiles)
+    ("F6", cd(rows, 256) * (HID // 128), 1): "fp8-MFMA: RF w12 (SwiGLU epilogue)",
+    ("F0", cd(STEPS * rows, 256) * cd(A, 256), 1): "fp8-MFMA: RF adaLN, all Euler steps",
 }
+for ks in range(2, 9):
+    SITES[("E0", mt * cd(W, 256), ks)] = "RF w3 (split-K slabs)"
+    SITES[("F0", cd(rows, 256) * cd(W, 256), ks)] = "fp8-MFMA: RF w3 (split-K slabs)"
+
+
+def site_of(name, gx, gy):
+    m = re.match(r"gemm256_kernel<(\d+), (true|false)(?:, (true|false))?>", name)
+    if not m:
+        return ""
+    return SITES.get((("F" if m.group(3) == "true" else "E") + m.group(1), gx, gy), "")
 
 
 def short(nm):
@@ -36,10 +49,7 @@ for r in csv.DictReader(open(path)):
 tot = sum(a[1] for a in acc.values())
 lines = []
 for (name, gx, gy, gz), (n, t, lo, hi) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
-    m = re.match(r"gemm256_kernel<(\d+), (true|false)>", name)
-    site = ""
-    if m:
-        site = SITES.get(("E" + m.group(1), gx, gy), "")
+    site = site_of(name, gx, gy)
     lines.append((name, gx, gy, gz, n, t / n, lo, hi, t / 1e3, 100 * t / tot, site))
 hdr = "kernel,workgroups_x,grid_y,grid_z,calls,avg_us,min_us,max_us,total_ms,percent,site"
 if out_path:
