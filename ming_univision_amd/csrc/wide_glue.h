@@ -28,6 +28,9 @@ struct WideGlue {
   // ---- outputs ----
   float* out; int64_t ldo;                             // fp32 result, or NULL
   bf16_t* Y; int64_t ldy; int64_t y_lo_off;            // bf16 hi rows at Y, lo rows y_lo_off elements further (0: plain bf16, no lo rows), or NULL
+  // fp8-MFMA regime (gemm256.hip F8): the row as OCP e4m3 bytes [M, D] at Y8 + one power-of-two scale per row — exactly what
+  // mn_quant_fp8_rows makes of the bf16 hi row (amax over the hi values, RNE), without the extra pass; or NULL
+  uint8_t* Y8; float* y8_scale;
   int M, D;
   // ---- tensor-parallel all-reduce, consumer side (tp.inl): before reading P (= this rank's inbox: nz = world slabs, one per
   // sender), row m waits until sender s's arrival flag wait_flags[s * wait_stride + m] reached wait_epoch.  The wait is bounded in
@@ -161,17 +164,36 @@ __global__ __launch_bounds__(1024) void wide_glue_kernel(const WideGlue p) {
       v = f4{o[0], o[1], o[2], o[3]};
     }
   }
-  if (!act) return;
+  if (!act && !p.Y8) return;                             // (Y8: every thread of the workgroup takes part in the row-amax reduction)
   if (p.scale) v = v * (1.0f + sc) + sh;
   if (p.act == 1) v = f4{gelu_erf_f(v.x), gelu_erf_f(v.y), gelu_erf_f(v.z), gelu_erf_f(v.w)};
-  if (p.out) *reinterpret_cast<f4*>(p.out + (int64_t)m * p.ldo + col) = v;
-  if (p.Y) {
-    uint32_t h0, l0, h1, l1;
-    split_pk_bf16(v.x, v.y, h0, l0);
-    split_pk_bf16(v.z, v.w, h1, l1);
+  if (act && p.out) *reinterpret_cast<f4*>(p.out + (int64_t)m * p.ldo + col) = v;
+  uint32_t h0 = 0, l0 = 0, h1 = 0, l1 = 0;
+  if (act) { split_pk_bf16(v.x, v.y, h0, l0); split_pk_bf16(v.z, v.w, h1, l1); }
+  if (act && p.Y) {
     bf16_t* yr = p.Y + (int64_t)m * p.ldy + col;
     *reinterpret_cast<u2*>(yr) = u2{h0, h1};
     if (p.y_lo_off) *reinterpret_cast<u2*>(yr + p.y_lo_off) = u2{l0, l1};
+  }
+  if (p.Y8) {                                            // uniform per launch
+    const float a0 = bf16lo_to_f32(h0), a1 = bf16hi_to_f32(h0), a2 = bf16lo_to_f32(h1), a3 = bf16hi_to_f32(h1);
+    const float amax = block_max(act ? fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fmaxf(fabsf(a2), fabsf(a3))) : 0.f, red);
+    // scale = 2^es with amax / 2^es in (224, 448]  (fp8_ops.hip pow2_scale_for: the weight format's rule)
+    const uint32_t ua = __float_as_uint(amax);
+    float sc8 = 1.0f;
+    if ((ua & 0x7fffffffu) != 0u) {
+      int es = (int)(ua >> 23) - 127 - 8 + ((ua & 0x7fffffu) > 0x600000u ? 1 : 0);
+      es = es < -126 ? -126 : (es > 127 ? 127 : es);
+      sc8 = __uint_as_float((uint32_t)(es + 127) << 23);
+    }
+    const float inv = 1.0f / sc8;                        // exact: a power of two
+    if (threadIdx.x == 0) p.y8_scale[m] = sc8;
+    if (act) {
+      int q = 0;
+      q = __builtin_amdgcn_cvt_pk_fp8_f32(a0 * inv, a1 * inv, q, false);
+      q = __builtin_amdgcn_cvt_pk_fp8_f32(a2 * inv, a3 * inv, q, true);
+      *reinterpret_cast<uint32_t*>(p.Y8 + (int64_t)m * D + col) = (uint32_t)q;
+    }
   }
 }
 

@@ -225,6 +225,7 @@ static int rf_sample_wide(const mn_rf_head* h, const float* hidden, int64_t ld_h
     g.xin = w.x; g.kin = T; g.win = h->in_w; g.bin = h->in_b; g.h_out = w.hh; g.ldho = W;
     g.norm = 2; g.ng = h->ln_g[0]; g.nb = h->ln_b[0]; g.eps = 1e-6f; g.shift = ada; g.scale = ada + W; g.ldmod = A;
     g.Y = w.ya; g.ldy = W; g.y_lo_off = lo_a; g.M = rows; g.D = W;
+    if (f8) { g.y_lo_off = 0; g.Y8 = reinterpret_cast<uint8_t*>(w.ya + lo_a); g.y8_scale = s_a; }
     wide_glue(g, st);
     for (int b = 0; b < h->depth; ++b) {
       const float* mod = ada + (int64_t)b * 3 * W;
@@ -235,7 +236,7 @@ static int rf_sample_wide(const mn_rf_head* h, const float* hidden, int64_t ld_h
         uint8_t* ya8 = reinterpret_cast<uint8_t*>(w.ya + lo_a);
         bf16_t* yb16 = w.yb;
         uint8_t* yb8 = reinterpret_cast<uint8_t*>(w.yb + lo_b);
-        MN_TRYZ(mn_quant_fp8_rows(w.ya, W, ya8, W, s_a, rows, W, stream));
+        // (ya8 / s_a: written by the glue launch that produced ya — wide_glue's Y8 output, the same bytes mn_quant_fp8_rows makes of ya's hi rows)
         a = g256_f8(ya8, W, s_a, h->w12[b], W, h->w12_scale[b], h->b12[b], yb16, HID, rows, HID, W);
         a.w_pair_rows = HID;
         MN_TRYZ(mn_gemm256_ex(&a, MN_G256_SWIGLU_BF16, 1, stream));
@@ -252,6 +253,7 @@ static int rf_sample_wide(const mn_rf_head* h, const float* hidden, int64_t ld_h
         g.norm = 2; g.ng = last8 ? nullptr : h->ln_g[b + 1]; g.nb = last8 ? nullptr : h->ln_b[b + 1]; g.eps = 1e-6f;
         g.shift = nmod8; g.scale = nmod8 + W; g.ldmod = A;
         g.Y = w.ya; g.ldy = W; g.y_lo_off = lo_a; g.M = rows; g.D = W;
+        if (!last8) { g.y_lo_off = 0; g.Y8 = ya8; g.y8_scale = s_a; }      // the next block multiplies e4m3: hi rows (unused, kept for inspection) + bytes; the last one feeds the hi/lo final layer
         wide_glue(g, st);
         continue;
       }
