@@ -481,6 +481,10 @@ typedef struct mn_llm {
    * runs the grouped expert kernels; mn_llm_max_rows returns 64). */
   int32_t wfmt;
   const float* const* w_gate_up_scale; const float* const* w_down_scale;
+  /* (0.1.24) arithmetic regime of the WIDE route, as mn_rf_head.arith: MN_ARITH_FP8_MFMA (needs wfmt == MN_W_FP8_E4M3) runs the grouped
+   * expert GEMMs (gate/up with the SwiGLU epilogue, down) on e4m3 activations x the e4m3 expert bytes (section 8) — no per-layer bf16
+   * expansion of the experts; attention, router and every route up to 64 rows unchanged.  Labelled reduced arithmetic, own tolerance. */
+  int32_t arith;
 } mn_llm;
 
 MN_API size_t mn_llm_workspace_bytes(const mn_llm* m, int rows, int64_t t_max);

@@ -72,6 +72,7 @@ class Llm(C.Structure):
         ("n_pos", C.c_int32),
         ("mrope_sec_t", C.c_int32), ("mrope_sec_h", C.c_int32),
         ("wfmt", C.c_int32), ("w_gate_up_scale", PP), ("w_down_scale", PP),
+        ("arith", C.c_int32),
     ]
 
 

@@ -92,12 +92,16 @@ class BailingMoeDecoder:
     """Weights + KV arena + C-ABI pointer table of the decoder stack."""
 
     def __init__(self, cfg: BailingMoeConfig, layers, final_norm, word_embeddings=None, lm_head=None,
-                 t_max=2048, n_seq=3, n_pos=None, weights="bf16"):
+                 t_max=2048, n_seq=3, n_pos=None, weights="bf16", arith=None, kv_cache=None):
         """layers: list of dicts with bf16 CUDA tensors: ln1, wqkv, wdense, ln2, gate, image_gate (or None),
         w_gate_up, w_down (see pack_experts).  Use `from_state_dict` / `synthetic` to build them.
         weights="fp8": w_gate_up / w_down are e4m3 bytes (uint8) with `w_gate_up_scale` / `w_down_scale` (quantize_layer_experts;
         bf16 experts are quantised here)."""
         assert weights in _lib.WFMT, f"weights={weights!r}: 'bf16', 'fp8', 'int8' or 'int4'"
+        # arith="fp8_mfma" (mingnative.h section 8): the LABELLED reduced-arithmetic regime of the wide route — the grouped expert GEMMs on
+        # e4m3 activations x the e4m3 expert bytes; needs weights="fp8".  None: fp32-class everywhere (the parity regime)
+        assert arith in (None, "fp8_mfma") and (arith is None or weights == "fp8"), "arith='fp8_mfma' needs weights='fp8'"
+        self.arith = arith
         self.weights = self.stream_fmt = weights         # the MODEL's mode / what the expert kernels read
         if weights == "int4" and (cfg.hidden_size % 64 or cfg.moe_intermediate_size % 64):
             # NF4 blocks (64 consecutive elements of the flattened matrix) would straddle rows: the experts keep the int4 model's VALUES
@@ -128,7 +132,11 @@ class BailingMoeDecoder:
         self.device = dev
         self.t_max, self.n_seq = t_max, n_seq
         L, nkv, hd = cfg.num_hidden_layers, cfg.num_key_value_heads, cfg.head_dim
-        self.kv_cache = torch.zeros(L, n_seq, 2, nkv, t_max, hd, dtype=torch.float32, device=dev)
+        if kv_cache is not None:                         # share another decoder's arena (same geometry): two weight modes, one conversation state
+            assert kv_cache.shape == (L, n_seq, 2, nkv, t_max, hd) and kv_cache.dtype == torch.float32
+            self.kv_cache = kv_cache
+        else:
+            self.kv_cache = torch.zeros(L, n_seq, 2, nkv, t_max, hd, dtype=torch.float32, device=dev)
         self.cos, self.sin = rope_tables(hd, cfg.rope_theta, n_pos or t_max, dev)
         self.n_shared = cfg.num_shared_experts or 0
         keys = ("ln1", "wqkv", "wdense", "ln2", "gate", "image_gate", "w_gate_up", "w_down")
@@ -140,6 +148,7 @@ class BailingMoeDecoder:
         for k in keys:
             setattr(s, k, C.cast(self._arrays[k], _lib.PP))
         s.wfmt = _lib.WFMT[self.stream_fmt]
+        s.arith = 1 if (arith == "fp8_mfma" and self.stream_fmt == "fp8") else 0
         if self.stream_fmt in _lib.W8:
             for k in ("w_gate_up_scale", "w_down_scale"):
                 self._arrays[k] = ptr_array([ly[k] for ly in layers])
@@ -221,15 +230,18 @@ class BailingMoeDecoder:
         """A second decoder on the SAME weights with its own KV arena / rotary tables (e.g. long-context understanding next to an
         image batch's arena)."""
         return BailingMoeDecoder(self.cfg, self.layers, self.final_norm, self.word_embeddings, self.lm_head, t_max=t_max, n_seq=n_seq,
-                                 n_pos=n_pos, weights=self.weights)
+                                 n_pos=n_pos, weights=self.weights, arith=self.arith)
 
-    def to_fp8(self, t_max=None, n_seq=None, weights="fp8"):
+    def to_fp8(self, t_max=None, n_seq=None, weights="fp8", arith=None, share_kv=False):
         """A second decoder whose experts are 8-bit copies of this one's — e4m3 (default) or int8 (weights="int8") — (attention /
-        router / vocabulary tensors shared; this bf16 decoder stays usable): + 0.5 bytes per expert parameter of HBM."""
+        router / vocabulary tensors shared; this bf16 decoder stays usable): + 0.5 bytes per expert parameter of HBM.
+        arith="fp8_mfma": the labelled fp8-MFMA regime of the wide route (e4m3 only).  share_kv: use THIS decoder's KV arena (same
+        t_max / n_seq) instead of allocating a second one."""
         assert self.weights == "bf16" and weights in _lib.W8
         layers = self._convert_linears([quantize_layer_experts(dict(ly), weights, self.n_shared) for ly in self.layers], weights)
         return BailingMoeDecoder(self.cfg, layers, self.final_norm, self.word_embeddings, self._convert_lm_head(self.lm_head, weights),
-                                 t_max=t_max or self.t_max, n_seq=n_seq or self.n_seq, weights=weights)
+                                 t_max=t_max or self.t_max, n_seq=n_seq or self.n_seq, weights=weights, arith=arith,
+                                 kv_cache=self.kv_cache if share_kv else None)
 
     def weight_bytes_active(self, distinct_experts_per_layer):
         """Weight bytes one decode step streams: attention + router (bf16) + the distinct routed and the shared experts

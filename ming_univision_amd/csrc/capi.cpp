@@ -92,7 +92,7 @@ extern "C" int mn_struct_layout(int which, size_t* offsets, int cap) {
 #define F(f) MN_OFF(mn_llm, f)
       F(hidden) F(n_layers) F(n_q) F(n_kv) F(head_dim) F(n_experts) F(top_k) F(n_shared_slots) F(moe_inter) F(norm_topk_prob) F(rms_eps)
       F(ln1) F(wqkv) F(wdense) F(ln2) F(gate) F(image_gate) F(w_gate_up) F(w_down) F(final_norm) F(cos_tab) F(sin_tab) F(n_pos)
-      F(mrope_sec_t) F(mrope_sec_h) F(wfmt) F(w_gate_up_scale) F(w_down_scale)
+      F(mrope_sec_t) F(mrope_sec_h) F(wfmt) F(w_gate_up_scale) F(w_down_scale) F(arith)
 #undef F
   };
   static const size_t semdec[] = {

@@ -175,7 +175,8 @@ typedef struct mn_g256 {
   // fp8-MFMA regime (f8 != 0; labelled reduced arithmetic, never the default): A and W point to OCP e4m3 BYTES (lda / ldw / K count
   // bytes = elements, K % 128 == 0), a_scale [M] / w_scale [N or 2N] are the operands' fp32 row scales (the accumulators are multiplied
   // by a_scale[m] * w_scale[n] before bias / epilogue); no hi/lo rows, epilogues F32 (split-K allowed) and SWIGLU_BF16
-  int f8; const float* a_scale; const float* w_scale;
+  // grouped form: group g's weight scales at w_scale + g * w_sstride; a_scale is indexed by the SOURCE row (through a_rows when given)
+  int f8; const float* a_scale; const float* w_scale; int64_t w_sstride;
 } mn_g256;
 enum { MN_G256_F32 = 0, MN_G256_BF16 = 1, MN_G256_BF16_GELU = 2, MN_G256_F32_RESID = 3, MN_G256_SWIGLU_SPLIT = 4,
        MN_G256_F32_RESID_GATE = 5, MN_G256_SWIGLU_BF16 = 6 };

@@ -171,7 +171,7 @@ __device__ __forceinline__ void g256_emit(const G256& p, char* Cz, int m, int n,
 // columns 16 j + 4 fq .. +3.
 template <int EPI, bool HILO, bool F8 = false>
 __device__ __forceinline__ void g256_epilogue(const G256& p, const f32x4 (&acc)[8][4], int wr, int wc, int fr, int fq, int m0,
-                                              int n0, int row0, int Mg, int zslice) {
+                                              int n0, int row0, int Mg, int zslice, int grp = 0) {
   constexpr bool hilo = HILO, paired = epi_paired(EPI);
   char* Cz = reinterpret_cast<char*>(p.C);
   if (EPI == E_F32) Cz += (int64_t)zslice * p.c_zstride * 4;
@@ -188,9 +188,10 @@ __device__ __forceinline__ void g256_epilogue(const G256& p, const f32x4 (&acc)[
       f32x4 u = {0.f, 0.f, 0.f, 0.f};
       if (paired) { u = acc[i][(j + 2) & 3]; if (hilo) u += acc[(i + 4) & 7][(j + 2) & 3]; }
       if constexpr (F8) {                              // e4m3 operands: the row scales of both sides (before bias and epilogue)
-        const float sa = p.a_scale[row0 + ml];
-        v *= *reinterpret_cast<const f32x4*>(p.w_scale + n) * sa;
-        if (paired) u *= *reinterpret_cast<const f32x4*>(p.w_scale + p.w_pair_rows + n) * sa;
+        const float sa = p.a_scale[p.a_rows ? p.a_rows[row0 + ml] : row0 + ml];      // (the operand row this output row was multiplied from)
+        const float* wsc = p.w_scale + (int64_t)grp * p.w_sstride;
+        v *= *reinterpret_cast<const f32x4*>(wsc + n) * sa;
+        if (paired) u *= *reinterpret_cast<const f32x4*>(wsc + p.w_pair_rows + n) * sa;
       }
       g256_emit<EPI>(p, Cz, row0 + ml, n, v, u, zslice);
     }
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const G256 p) {
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
 
-  g256_epilogue<EPI, HILO, F8>(p, acc, wr, wc, fr, fq, m0, n0, row0, Mg, blockIdx.y);
+  g256_epilogue<EPI, HILO, F8>(p, acc, wr, wc, fr, fq, m0, n0, row0, Mg, blockIdx.y, grp);
 }
 
 

@@ -49,6 +49,7 @@ struct LlmWideWs {
   float *h, *pp, *q, *yg, *tw;
   bf16_t *yh, *ya, *y2;
   bf16_t *wq_gu, *wq_dn;           // weight-only modes: ONE layer's expert weights de-quantised, [G][2 I][H] / [G][H][I] (wide_rf.inl)
+  uint8_t* yh8; float *s_h, *s_y2; // fp8-MFMA regime: the experts' e4m3 operand [rows][H] + its row scales, the down projection's row scales [P]
   int32_t *ti, *cnt, *off, *perm, *slot_of, *tile_g, *tile_m0, *n_tiles;
   int max_mtiles;
   void* attn_ws;
@@ -62,6 +63,12 @@ static bool llm_wide_ok(const mn_llm* m, int rows) {
   return fmt_ok && rows >= g_wide_min_llm && rows <= 2048 && wide_glue_ok(m->hidden) && (m->hidden % 64) == 0 && (ad % 64) == 0 && (m->moe_inter % 64) == 0 &&
          m->n_experts <= 64 && (m->n_experts % 4) == 0 && m->n_experts + m->n_shared_slots <= 128 && (int64_t)rows * n_slot <= 65536 &&
          (m->head_dim == 64 || m->head_dim == 128);
+}
+
+// the fp8-MFMA regime of the wide route (mn_llm.arith; mingnative.h section 8): the grouped expert GEMMs on e4m3 x e4m3
+static bool llm_f8_mfma(const mn_llm* m) {
+  return m->arith == MN_ARITH_FP8_MFMA && m->wfmt == MN_W_FP8_E4M3 && m->w_gate_up_scale && m->w_down_scale && (m->hidden % 128) == 0 &&
+         (m->moe_inter % 128) == 0;
 }
 
 static size_t llm_wide_carve(const mn_llm* m, int rows, int64_t t_max, void* ws, size_t cap, LlmWideWs* o) {
@@ -96,8 +103,12 @@ static size_t llm_wide_carve(const mn_llm* m, int rows, int64_t t_max, void* ws,
   o->n_tiles = cv.take<int32_t>(4);
   o->attn_ws_bytes = mn_attn_decode_workspace_bytes(rows, m->n_q, m->head_dim, t_max);
   o->attn_ws = cv.take<char>(o->attn_ws_bytes);
-  o->wq_gu = cv.take<bf16_t>(m->wfmt ? (size_t)G * 2 * m->moe_inter * H : 0);
-  o->wq_dn = cv.take<bf16_t>(m->wfmt ? (size_t)G * H * m->moe_inter : 0);
+  const bool f8 = llm_f8_mfma(m);                       // (the e4m3 bytes ARE the operands: no per-layer bf16 expansion)
+  o->wq_gu = cv.take<bf16_t>(m->wfmt && !f8 ? (size_t)G * 2 * m->moe_inter * H : 0);
+  o->wq_dn = cv.take<bf16_t>(m->wfmt && !f8 ? (size_t)G * H * m->moe_inter : 0);
+  o->yh8 = cv.take<uint8_t>(f8 ? (size_t)rows * H : 0);
+  o->s_h = cv.take<float>(f8 ? (size_t)rows + 64 : 0);
+  o->s_y2 = cv.take<float>(f8 ? P + 64 : 0);
   return cv.off;
 }
 
@@ -115,6 +126,7 @@ static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row
   const int64_t layer_kv = (int64_t)n_seq * 2 * nkv * t_max * hd;
   const float q_scale = 1.0f / sqrtf((float)hd);
   WideGlue g;
+  const bool f8 = llm_f8_mfma(m);
   for (int l = 0; l <= m->n_layers; ++l) {
     // glue: (stack input | previous layer's expert combine + residual) -> RMSNorm(ln1 | final norm)
     const bool fin = l == m->n_layers;
@@ -152,6 +164,7 @@ static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row
     memset(&g, 0, sizeof(g));
     g.h = w.h; g.ldh = H; g.P = w.pp; g.nz = nz; g.slab = (int64_t)M * H; g.h_out = w.h; g.ldho = H;
     g.norm = 1; g.ng = m->ln2[l]; g.eps = m->rms_eps; g.Y = w.yh; g.ldy = H; g.y_lo_off = (int64_t)M * H; g.M = M; g.D = H;
+    if (f8) { g.Y8 = w.yh8; g.y8_scale = w.s_h; }      // the experts' e4m3 operand beside the router's hi/lo one (routing stays fp32-class)
     wide_glue(g, st);
     // router: gate logits (split-K slabs) -> softmax / top-k -> expert sort  (:505-520, 608-616)
     a = g256_hilo(w.yh, H, lo_at(LO_LLM_GATE, (int64_t)M * H), m->gate[l], H, nullptr, w.pp, E, M, E, H);
@@ -170,8 +183,30 @@ static int llm_step_wide(const mn_llm* m, const float* x, int64_t ldx, int x_row
     hipLaunchKernelGGL(moe_topk_partials_kernel, dim3(mn_cdiv(M, 4)), dim3(256), 0, st, (const float*)w.pp, p_img, image_mask, nz,
                        (int64_t)M * E, M, E, m->top_k, m->norm_topk_prob, m->n_shared_slots, w.ti, w.tw);
     route_capture(l, w.ti, M, n_slot, st);
-    MN_TRY(mn_moe_sort_tiles(w.ti, M, n_slot, G, w.cnt, w.off, w.perm, w.slot_of, lo_at(LO_LLM_EXPERTS, 1) ? 128 : 256, w.tile_g, w.tile_m0,
+    MN_TRY(mn_moe_sort_tiles(w.ti, M, n_slot, G, w.cnt, w.off, w.perm, w.slot_of, (lo_at(LO_LLM_EXPERTS, 1) && !f8) ? 128 : 256, w.tile_g, w.tile_m0,
                              w.n_tiles, stream));
+    if (f8) {
+      // fp8-MFMA regime: gate/up = e4m3(RMSNorm'd row, gathered by perm) x e4m3 expert bytes, SwiGLU in the epilogue -> bf16 [P, I];
+      // down = e4m3 of that (one quantise pass over the sorted rows) x e4m3 bytes -> yg [P, H] fp32
+      mn_g256 a8;
+      memset(&a8, 0, sizeof(a8));
+      a8.A = reinterpret_cast<const bf16_t*>(w.yh8); a8.lda = H; a8.W = reinterpret_cast<const bf16_t*>(m->w_gate_up[l]); a8.ldw = H;
+      a8.C = w.y2; a8.ldc = I; a8.M = M; a8.N = I; a8.K = H; a8.w_pair_rows = I;
+      a8.f8 = 1; a8.a_scale = w.s_h; a8.w_scale = m->w_gate_up_scale[l]; a8.w_sstride = (int64_t)2 * I;
+      a8.g_off = w.off; a8.g_cnt = w.cnt; a8.w_gstride = (int64_t)2 * I * H; a8.a_rows = w.perm; a8.n_groups = G;
+      a8.tile_g = w.tile_g; a8.tile_m0 = w.tile_m0; a8.n_tiles = w.n_tiles; a8.max_mtiles = w.max_mtiles;
+      MN_TRYZ(mn_gemm256_ex(&a8, MN_G256_SWIGLU_BF16, 1, stream));
+      uint8_t* y28 = reinterpret_cast<uint8_t*>(w.y2 + P * I);
+      MN_TRYZ(mn_quant_fp8_rows(w.y2, I, y28, I, w.s_y2, P, I, stream));
+      memset(&a8, 0, sizeof(a8));
+      a8.A = reinterpret_cast<const bf16_t*>(y28); a8.lda = I; a8.W = reinterpret_cast<const bf16_t*>(m->w_down[l]); a8.ldw = I;
+      a8.C = w.yg; a8.ldc = H; a8.M = M; a8.N = H; a8.K = I;
+      a8.f8 = 1; a8.a_scale = w.s_y2; a8.w_scale = m->w_down_scale[l]; a8.w_sstride = H;
+      a8.g_off = w.off; a8.g_cnt = w.cnt; a8.w_gstride = (int64_t)H * I; a8.n_groups = G;
+      a8.tile_g = w.tile_g; a8.tile_m0 = w.tile_m0; a8.n_tiles = w.n_tiles; a8.max_mtiles = w.max_mtiles;
+      MN_TRYZ(mn_gemm256_ex(&a8, MN_G256_F32, 1, stream));
+      continue;
+    }
     // experts: grouped gate/up (rows gathered by perm, SwiGLU + split epilogue), grouped down -> yg [P, H]  (:617-628, 483-484)
     const bf16_t *wgu = m->w_gate_up[l], *wdn = m->w_down[l];
     if (m->wfmt) {          // weight-only mode: this layer's W' into the scratch (1.14 GB at the 16B-A3B shape; ~0.35 ms per layer and step)

@@ -99,3 +99,84 @@ def test_rf_sampler_wide_route_in_the_fp8_mfma_regime_vs_oracle():
     assert e8m < 0.15 and cos > 0.995 and e8m > 1e-3            # (> 1e-3: the regime really ran)
     small = torch.randn(4, LH, generator=g).cuda(); ns = torch.randn(2, 32, generator=g).cuda()
     assert torch.equal(rf8m.sample(small, ns, n_images=2), rf8.sample(small, ns, n_images=2))
+
+
+def test_decoder_step_wide_route_experts_in_the_fp8_mfma_regime_vs_oracle():
+    """BailingMoeModel.forward for one decode step (modeling_bailing_moe.py:1391-1540) at 130 rows on the wide route with arith="fp8_mfma":
+    the grouped expert GEMMs (moe_infer, :608-639: gate / up with SwiGLU, down) multiply e4m3 activations by the e4m3 expert bytes;
+    attention and the ROUTER stay fp32-class, so the expert CHOICE is the fp32-class one in layer 0 and the regime's error is arithmetic.
+    Full-width 2-layer 16B-A3B shapes against the oracle on the de-quantised experts, teacher-forced to the HIP path's routing.
+      * STATED TOLERANCE: 5e-2 relative (row max-norm, every row) on the hidden states after 2 layers — the MoE output is a small addend
+        of the residual stream at these weights; the fp32-class regime on the same e4m3 model: 1e-3;
+      * up to 64 rows the regime changes nothing (same bits)."""
+    import torch.nn.functional as F
+    from oracle import bailing_ref
+    from ming_univision_amd import configuration as C
+    from ming_univision_amd._lib import check, lib, ptr
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder
+    from tests.util import llm_sd, row_errs
+    d = C.BailingMoeConfig.ming_univision_16b_a3b().to_dict()
+    d.pop("model_type", None)
+    d.update(num_hidden_layers=2, vocab_size=1024, num_image_tokens_for_gen=3, image_start_token=1000, pad_token_id=0)
+    sd = llm_sd(d, dict(C.DEFAULT_VISHEAD_DIFFLOSS), 5)
+    cfg = C.BailingMoeConfig(**d)
+    ocfg = bailing_ref.LLMConfig(**{k: v for k, v in d.items() if k in bailing_ref.LLMConfig.__dataclass_fields__})
+    dsd = {k: v.to("cuda", torch.bfloat16).contiguous() for k, v in sd.items() if k.startswith("model.")}
+    M, T = 130, 12
+    dec16 = BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=T + 4, n_seq=M)
+    dec8 = dec16.to_fp8(share_kv=True)
+    dec8m = dec16.to_fp8(arith="fp8_mfma", share_kv=True)
+    assert dec8m.struct.arith == 1 and dec8.struct.arith == 0 and dec8m.kv_cache.data_ptr() == dec16.kv_cache.data_ptr()
+    sd8 = dict(sd)
+    sd8.update({k: v.float().cpu() for k, v in dec8.dequantized_state_dict().items()})
+    g = torch.Generator().manual_seed(9)
+    L, nkv, hd, H = 2, cfg.num_key_value_heads, cfg.head_dim, cfg.hidden_size
+    kv = torch.randn(L, M, 2, nkv, T + 4, hd, generator=g) * 0.5
+    x = torch.randn(M, H, generator=g) * 0.5
+    km = torch.ones(M, T + 4, dtype=torch.uint8)
+    slot = torch.full((M,), T, dtype=torch.int32).cuda()
+    seqs = torch.arange(M, dtype=torch.int32).cuda()
+    outs = {}
+    k_top = cfg.num_experts_per_tok
+    routes = {}
+    for name, dec in (("fp32_class", dec8), ("fp8_mfma", dec8m)):
+        dec.kv_cache.copy_(kv.cuda())
+        r = torch.full((L, M, k_top + dec.n_shared), -1, dtype=torch.int32, device="cuda")
+        check(lib().mn_llm_route_capture(ptr(r)), "mn_llm_route_capture")
+        try:
+            outs[name] = dec.step(x.cuda(), seqs, slot, slot, slot + 1, km.cuda()).clone()
+            torch.cuda.synchronize()
+        finally:
+            check(lib().mn_llm_route_capture(None), "mn_llm_route_capture")
+        routes[name] = r.cpu()[:, :, :k_top].long()
+    assert torch.equal(routes["fp32_class"][0], routes["fp8_mfma"][0])          # layer 0's router sees identical inputs in both regimes
+
+    def oracle(forced):
+        orig = bailing_ref.gate
+        calls = []
+
+        def gate_forced(x2d, w, c):
+            lg = F.linear(x2d, w).float()
+            sc = lg.softmax(dim=-1, dtype=torch.float32)
+            ti = forced[len(calls)]
+            calls.append(1)
+            tw = sc.gather(1, ti)
+            return ti, tw / tw.sum(-1, keepdim=True), lg
+        bailing_ref.gate = gate_forced
+        try:
+            kvs = [dict(k=kv[l, :, 0, :, :T].clone(), v=kv[l, :, 1, :, :T].clone()) for l in range(L)]
+            pos = torch.full((M, 1), T, dtype=torch.long)
+            return bailing_ref.model_forward(x.unsqueeze(1), sd8, ocfg, torch.ones(M, T + 1, dtype=torch.long), pos, kvs)[:, 0]
+        finally:
+            bailing_ref.gate = orig
+    e32 = row_errs(outs["fp32_class"], oracle(routes["fp32_class"]))
+    e8 = row_errs(outs["fp8_mfma"], oracle(routes["fp8_mfma"]))
+    print(f"decoder step, 130 rows, e4m3 experts, teacher-forced routing: fp32-class regime max {float(e32.max()):.2e} | fp8-MFMA regime median "
+          f"{float(e8.median()):.2e}, max {float(e8.max()):.2e} (hidden states after 2 layers, per-row max-norm)")
+    assert float(e32.max()) < 1e-3
+    assert 1e-4 < float(e8.max()) < 5e-2
+    xs = x[:6].cuda()
+    s6 = torch.full((6,), T, dtype=torch.int32).cuda()
+    a = dec8.step(xs, seqs[:6], s6, s6, s6 + 1, km[:6].cuda()).clone()
+    dec8.kv_cache.copy_(kv.cuda())
+    assert torch.equal(dec8m.step(xs, seqs[:6], s6, s6, s6 + 1, km[:6].cuda()), a)
