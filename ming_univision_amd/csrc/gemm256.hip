@@ -36,6 +36,9 @@
 //     A persistent tile loop whose LDS pipeline runs across output tiles (the next tile's first half-tiles issued during
 //     the last phases and the epilogue of the current one) measured within +-1.5 % of the plain grid (adaLN 4589 vs 4646 us,
 //     w12 at 1024 rows 177 vs 163 us): the dispatcher already starts the next workgroup's prologue while others compute.
+//     MFMA issue order inside a quadrant (round 6, a power A/B on this power-limited kernel): weight-fragment-major — the W operand
+//     stays for 4 consecutive MFMAs — measured 218.4 vs 215.8 us on RF w12 at 1536 rows and a LOWER clock at the same socket power
+//     (1 720 vs 1 775 MHz at 1.35 kW, profiles/r06_ab_mfma_order.txt): the activation-fragment-major order below stays.
 //   * The MFMA takes the W fragment as its A operand and the activation fragment as B, so a lane's 4 accumulator
 //     registers are 4 CONSECUTIVE output columns of one row: 16-byte fp32 / 8-byte bf16 stores.
 //

@@ -5,7 +5,7 @@ import subprocess
 
 from ming_univision_amd import _lib
 
-_DEV = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmingnative_dev.so")
+_DEV = os.environ.get("MINGNATIVE_DEV_LIB") or os.path.join(os.path.dirname(_lib.LIB_PATH), "libmingnative_dev.so")     # (A/B builds: another dev library)
 if not os.path.exists(_DEV):
     subprocess.run(["make", "-C", os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc"), "-j8", "dev"], check=True)
 assert _lib._lib is None, "tools.devlib must be imported before the library is loaded"
