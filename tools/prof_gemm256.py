@@ -1,5 +1,5 @@
 """One shape of the wide-row GEMM, a few launches, for rocprofv3 (--kernel-trace --stats, or --pmc passes).
-usage: prof_gemm256.py {w12|w3|ada|sq} [rows]"""
+usage: prof_gemm256.py {w12|w3|ada|sq|f8w12} [rows]      (f8w12: the fp8-MFMA regime's w12 launch, mingnative.h section 8)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,6 +18,13 @@ if which == "w12":
     ws = [(torch.randn(2 * hid, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev) for _ in range(6)]
     y = torch.empty(2, rows, hid, dtype=torch.bfloat16, device=dev)
     fn = lambda i: check(L.mn_gemm256_swiglu_split(ptr(a2), K, a2.stride(0), ptr(ws[i % 6]), K, None, ptr(y), hid, y.stride(0), rows, hid, K, current_stream()), "x")
+elif which == "f8w12":
+    from ming_univision_amd import ops
+    K, hid = 3072, 8192
+    x8, xs = ops.quant_rows(torch.randn(rows, K, generator=g).to(dev).to(torch.bfloat16), "fp8")
+    w8 = [ops.quant_rows((torch.randn(2 * hid, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev), "fp8") for _ in range(6)]
+    y = torch.empty(rows, hid, dtype=torch.bfloat16, device=dev)
+    fn = lambda i: L.mn_gemm256_f8(ptr(x8), K, ptr(xs), ptr(w8[i % 6][0]), K, ptr(w8[i % 6][1]), None, ptr(y), hid, rows, hid, K, 1, 1, current_stream())
 elif which == "w3":
     K, N = 8192, 3072
     a2 = split(torch.randn(rows, K, generator=g).to(dev))
