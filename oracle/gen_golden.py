@@ -15,6 +15,10 @@ Reference entry points exercised (paths relative to /root/reference):
   mingunivision/diff_loss_rf_swiglu.py   SimpleMLPAdaLN.forward, RectifiedFlowLoss.sample
   mingunivision/modeling_bailing_moe.py  BailingMoeModel.forward (eager attention),
                                    BailingMoeForCausalLM.generate_image, vis_head
+  mingunivision/modeling_bailingmm.py    MingUniVisionForConditionalGeneration.generate over three rounds, PAST_MODE KEEP and DROP
+                                   (round 6: gen_multiround -> multiround_tiny.npz; with BailingMoeForCausalLM.forward's `<image>`
+                                   branch and prepare_inputs_for_generation, driven by the installed transformers' greedy loop
+                                   through ref_shim.cache_position_452)
 """
 import json
 import os
