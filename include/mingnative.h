@@ -741,8 +741,8 @@ MN_API int mn_stream_mfma_grouped_w8(const uint16_t* Y, int y_rows, const uint8_
  * 8. fp8-MFMA regime (0.1.24) — BASELINE.json configs[4]'s "fp8 MFMA".  A LABELLED reduced-arithmetic regime with its own tolerance,
  *    never a default: the reference has no fp8 path, the parity target is the fp32 oracle at a stated looser bar.
  *    Both GEMM operands are OCP e4m3 bytes with one fp32 scale per row (weights: the "fp8" weight format of section 7; activations:
- *    mn_quant_fp8_rows of the bf16 operand the hi/lo route would multiply), products on v_mfma_scale_f32_16x16x128_f8f6f4 with unit
- *    block scales, fp32 accumulation — the 256 x 256-tile kernel of the wide route at twice the bf16 MFMA rate per pass, one pass
+ *    mn_quant_fp8_rows of the bf16 operand the hi/lo route would multiply), products on v_mfma_f32_16x16x128_f8f6f4 (no block
+ *    scales), fp32 accumulation — the 256 x 256-tile kernel of the wide route at twice the bf16 MFMA rate per pass, one pass
  *    instead of the hi/lo pair's two.
  *    C = epilogue((A8 . a_scale)(W8 . w_scale)^T + bias): swiglu == 0 -> C fp32 [M, N] (ksplit > 1: slice z at C + z * M * N, ldc == N,
  *    returns the slice count); swiglu == 1 -> W8 holds 2N rows (gate, up), C bf16 [M, N] = silu(gate) * up (swiglu_ffn.py:30-34,
