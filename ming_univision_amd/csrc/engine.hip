@@ -1015,14 +1015,14 @@ static bool moe_mfma_ok(const mn_llm* m, int rows) {
 // one wave per router row: 64 experts at most).  Measured end to end against the unfused sequence (same box, tokens/s):
 // 2 rows 78.5 vs 76.5, 8 rows 254 vs 247, 16 rows 451 vs 442, 32 rows 699 vs 698; at 64 rows the one-workgroup-per-row
 // glue kernels lose to the wider unfused ones (1084 vs 1122), so the chain stops at 32.
-static int g_chain_max_rows = 32, g_chain_router = 1;
+static int g_chain_max_rows = 32, g_chain_router = 1, g_chain_fuse_ln1 = 1;
 static int g_moe_gate_up = 1, g_moe_gate_up_rows = 1, g_moe_gate_up_chain_rows = 2, g_moe_gate_up_chain_all = 0;      // (chain: int8 / NF4 by default — bf16 / e4m3 keep the pair launches: 2.25 vs 2.64 ms, 1.71 vs 1.84)      // the one-launch router + gate/up of 1-row steps (dev-library A/B: mn_moe_tune_gate_up)
 bool moe_router_rows_ok(int M, int H, int E);
 int moe_router_rows(float* h, const float* P, int nz, const uint16_t* norm_w, float eps, const uint16_t* gate_w, int M, int H, int E, int top_k,
                     int norm_topk_prob, int n_shared_slots, float* x_norm, int32_t* topk_idx, float* topk_w, float* logits_ws, void* stream);
 #ifdef MN_DEV_HOOKS
 extern "C" MN_DEV_API void mn_moe_tune_gate_up(int on, int max_rows) { g_moe_gate_up = on; g_moe_gate_up_rows = max_rows & 0xff; g_moe_gate_up_chain_rows = (max_rows >> 8) & 0xff; g_moe_gate_up_chain_all = (max_rows >> 16) & 1; }
-extern "C" MN_DEV_API void mn_llm_tune_chain(int max_rows) { g_chain_max_rows = max_rows & 0xffff; g_chain_router = (max_rows >> 16) & 1 ? 0 : 1; }   // A/B hook (tools/): bit 16 = the one-launch router of the chain OFF
+extern "C" MN_DEV_API void mn_llm_tune_chain(int max_rows) { g_chain_max_rows = max_rows & 0xffff; g_chain_router = (max_rows >> 16) & 1 ? 0 : 1; g_chain_fuse_ln1 = (max_rows >> 17) & 1 ? 0 : 1; }   // A/B hook (tools/): bit 16 = the one-launch router of the chain OFF, bit 17 = RMSNorm(ln1) as its own glue launch
 #endif
 static bool llm_chain_ok(const mn_llm* m, int rows) {
   return rows >= 2 && rows <= g_chain_max_rows && (m->hidden % 8) == 0 && m->hidden <= 4096 && ((m->n_q * m->head_dim) % 8) == 0 &&
@@ -1212,7 +1212,8 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
   // append ride the attention launch
   const bool fuse_attn = (flags & MN_STEP_DISTINCT_SEQUENCES) && mn_attn_fused_ok(M, nq, nkv, hd, t_max);
   if (llm_chain_ok(m, M) && !(image_mask && m->image_gate)) {
-    // ---- chain path: 12 launches per layer (11 at 2 rows) instead of 18.  glue = llm_glue_kernel.
+    // ---- chain path: 12 launches per layer instead of 18 (2 rows: 6 — QKV with the RMSNorm prologue, attention with RoPE + KV append, dense,
+    // the one-launch router, the expert pairs' gate/up, the down projection into h).  glue = llm_glue_kernel.
     const int E = m->n_experts, S = m->n_shared_slots, G = E + S, ad = nq * hd, P = M * n_slot;
     // 2 rows (the CFG rows of one image): the experts run as router + gate/up in ONE launch and the wave-segmented down projection,
     // straight into h (moe_gate_up.hip, moe_down.hip) — int8 / NF4 (2.26 -> 2.05 ms, 2.48 -> 2.38 per step against their grouped streaming launches;
@@ -1224,17 +1225,20 @@ static int llm_step_impl(const mn_llm* m, const float* x, int64_t ldx, int x_row
     int nz2 = 0;                                                       // slabs of the previous layer's expert down-projection
     for (int l = 0; l < m->n_layers; ++l) {
       float* kv_l = kv_cache + (int64_t)l * layer_kv;
+      bool ln1_fused = false;
       // glue: (previous experts' combine + residual | stack input) -> RMSNorm(ln1) -> yh
       if (l == 0)
         hipLaunchKernelGGL(llm_glue_kernel, dim3(M), dim3(gt), 0, st, 0, x, ldx, x_row_div, (const float*)nullptr, 0, (int64_t)0,
                            (const int32_t*)nullptr, (const float*)nullptr, n_slot, w.h, M, H, m->ln1[l], m->rms_eps,
                            (float*)nullptr, w.yh);
-      else
+      else if (!(ln1_fused = !grouped && g_chain_fuse_ln1 && stream_rmsnorm_ok(M, qkv_dim, H)))
         hipLaunchKernelGGL(llm_glue_kernel, dim3(M), dim3(gt), 0, st, grouped ? 2 : 3, (const float*)nullptr, (int64_t)0, 1,
                            (const float*)w.moe.p2, nz2, (int64_t)P * H, (const int32_t*)w.moe.pair_pos, (const float*)w.tw,
                            n_slot, w.h, M, H, m->ln1[l], m->rms_eps, (float*)nullptr, w.yh);
-      // QKV launch -> partials; RoPE + KV append reduce them  (:743-789)
-      int nz = mn_stream_mfma(w.yh, m->wqkv[l], w.pp, M, qkv_dim, H, stream);
+      // QKV launch -> partials; RoPE + KV append reduce them  (:743-789).  With the experts already summed into h (2-4 rows) the
+      // launch normalises h itself (stream_mfma.hip FUSE_RMSNORM: the glue launch's arithmetic in every workgroup's staging pass)
+      int nz = ln1_fused ? stream_rmsnorm(m->wqkv[l], w.pp, M, qkv_dim, H, w.h, m->ln1[l], m->rms_eps, stream)
+                         : mn_stream_mfma(w.yh, m->wqkv[l], w.pp, M, qkv_dim, H, stream);
       if (nz < 0) return nz;
       if (fuse_attn) {
         MN_TRY(mn_attn_decode_fused(w.pp, qkv_dim, nz, (int64_t)M * qkv_dim, M, nq, nkv, hd, 1, m->cos_tab, m->sin_tab, row_seq, row_slot,

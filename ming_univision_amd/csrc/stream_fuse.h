@@ -3,12 +3,16 @@
 #pragma once
 #include "common.h"
 
-enum { FUSE_NONE = 0, FUSE_SWIGLU = 2 };
+enum { FUSE_NONE = 0, FUSE_SWIGLU = 2, FUSE_RMSNORM = 3 };
 
 // FUSE_SWIGLU: the launch builds its activation image itself, x[m, k] = silu(pb[k] + sum_z pP[z][m][k]) * (pb[K + k] + sum_z pP[z][m][K + k]),
 // from the slabs pP [pnz][M][2 * K] of the previous launch and its bias pb [2 * K] (may be NULL).
+// FUSE_RMSNORM: x[m, :] = RMSNorm(h[m, :]; norm_w, eps) (modeling_bailing_moe.py:131-136) from the fp32 residual stream h [M][K]: every
+// workgroup reads the M whole rows for the statistic (a few KiB of L2) and normalises its K-slice — the decoder chain's QKV launch
+// without the one-workgroup-per-row glue launch in front of it.
 struct StreamFuse {
   const float* pP; int pnz; const bf16_t* pb;
+  const float* h; const bf16_t* norm_w; float eps;
 };
 
 constexpr int FUSE_MAX_ROWS = 4;
@@ -17,6 +21,9 @@ constexpr int FUSE_MAX_ROWS = 4;
 bool stream_fused_ok(int wfmt, int M, int Ntot, int K, int prev_nz);
 // Launch: W = bf16 [Ntot][K], or e4m3 bytes + wscale (wfmt != 0).  P [nz][M][Ntot], nz = the plain launch's slice count.  Returns nz (< 0: error).
 int stream_fused(int wfmt, const void* W, const float* wscale, float* P, int M, int Ntot, int K, const StreamFuse& f, void* stream);
+// P [nz][M][Ntot] = RMSNorm(h; norm_w, eps) W^T in K slices (bf16 W): the glue launch's arithmetic (llm_glue_kernel; the statistic is summed in the same order), equal to 1.6e-6 of the hidden state over 28 layers.
+bool stream_rmsnorm_ok(int M, int Ntot, int K);
+int stream_rmsnorm(const bf16_t* W, float* P, int M, int Ntot, int K, const float* h, const bf16_t* norm_w, float eps, void* stream);
 
 // ---- K-complete launches of the RF ResBlock chain at <= 2 rows (stream_kc.hip): whole output tiles per workgroup, K split over its
 // waves — no split-K slabs, so the residual + LayerNorm glue launch between two blocks disappears (two launches per block).

@@ -137,8 +137,17 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
   const int kq = ks >> 2;                           // float4 elements per row of the slice; thread tid builds element (fm, fq4)
   const int fm = FUSE ? tid / kq : 0, fq4 = tid - fm * kq;
   const bool fon = FUSE && fm < M && fq4 * 4 < klen;
+  f4 hv = {0.f, 0.f, 0.f, 0.f}, rowv[FUSE == FUSE_RMSNORM ? FUSE_MAX_ROWS : 1];     // FUSE_RMSNORM: this thread's element, its 4 columns of every row
   if constexpr (FUSE == FUSE_NONE) {
     load_x();   // before the weights: loads retire in order, so the x image never waits behind a weight chunk
+  } else if constexpr (FUSE == FUSE_RMSNORM) {
+    if (fon) {
+      hv = *reinterpret_cast<const f4*>(f.h + (int64_t)fm * K + k0 + fq4 * 4);
+      bg = *reinterpret_cast<const u2v*>(f.norm_w + k0 + fq4 * 4);
+    }
+#pragma unroll
+    for (int r = 0; r < FUSE_MAX_ROWS; ++r)                 // blockDim.x * 4 == K (host check): the glue launch's column split
+      rowv[r] = r < M ? *reinterpret_cast<const f4*>(f.h + (int64_t)r * K + tid * 4) : f4{0.f, 0.f, 0.f, 0.f};
   } else {
 #pragma unroll
     for (int zz = 0; zz < NPZ; ++zz) pg[zz] = pu[zz] = f4{0.f, 0.f, 0.f, 0.f};
@@ -205,7 +214,31 @@ __global__ __launch_bounds__(MAXT) void stream_mfma_lds_kernel(const bf16_t* __r
   } else {
     // rows >= M and columns >= klen of the image are zero: clear it, then write what this launch computes
     for (int i = tid; i < 2 * XR * (srow >> 3); i += blockDim.x) *reinterpret_cast<u32x4*>(xs_raw + i * 8) = u32x4{0u, 0u, 0u, 0u};
+    float* scr = reinterpret_cast<float*>(reinterpret_cast<char*>(xs_raw) + (size_t)2 * XR * srow * sizeof(bf16_t));   // wave 0's weight tile: free until the K loop
+    if constexpr (FUSE == FUSE_RMSNORM) {                   // row statistics, summed as llm_glue_kernel's block_sum does: wave sums, then the waves in order
+#pragma unroll
+      for (int r = 0; r < FUSE_MAX_ROWS; ++r) {
+        const f4 v = rowv[r];
+        const float sw = wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+        if (lane == 0) scr[r * 16 + wave] = sw;
+      }
+    }
     __syncthreads();
+    if constexpr (FUSE == FUSE_RMSNORM) {
+      if (fon) {
+        float ss = 0.f;
+        for (int i = 0; i < nw; ++i) ss += scr[fm * 16 + i];
+        const float rstd = rsqrtf(ss / (float)K + f.eps);
+        const float o0 = hv.x * rstd * bf16lo_to_f32(bg.x), o1 = hv.y * rstd * bf16hi_to_f32(bg.x);
+        const float o2 = hv.z * rstd * bf16lo_to_f32(bg.y), o3 = hv.w * rstd * bf16hi_to_f32(bg.y);
+        uint32_t h0, l0, h1, l1;
+        split_pk_bf16(o0, o1, h0, l0);
+        split_pk_bf16(o2, o3, h1, l1);
+        const int off = xslot(fm, srow, fq4 >> 1) + (fq4 & 1) * 4;
+        *reinterpret_cast<u2v*>(xs_raw + off) = u2v{h0, h1};
+        *reinterpret_cast<u2v*>(xs_raw + XR * srow + off) = u2v{l0, l1};
+      }
+    } else
     if (fon) {
       f4 g = {bf16lo_to_f32(bg.x), bf16hi_to_f32(bg.x), bf16lo_to_f32(bg.y), bf16hi_to_f32(bg.y)};
       f4 u = {bf16lo_to_f32(bu.x), bf16hi_to_f32(bu.x), bf16lo_to_f32(bu.y), bf16hi_to_f32(bu.y)};
@@ -388,6 +421,28 @@ bool stream_fused_ok(int wfmt, int M, int Ntot, int K, int prev_nz) {
   if (M < 1 || M > FUSE_MAX_ROWS || (K % (wfmt == MN_W_NF4 ? 64 : (wfmt ? 16 : 8))) != 0 || prev_nz < 1 || prev_nz > FUSE_PNZ) return false;
   const StreamPlan pl = stream_plan(1, Ntot, K, mn_num_cus(), wq_of(wfmt));
   return (int64_t)M * (pl.ks / 4) <= (int64_t)pl.nw * 64;      // one float4 element of the x image per thread
+}
+
+// RMSNorm prologue (the decoder chain's QKV launch): the plain launch's plan; the statistic's column split needs blockDim * 4 == K
+bool stream_rmsnorm_ok(int M, int Ntot, int K) {
+  if (M < 1 || M > FUSE_MAX_ROWS || (K % 8) != 0) return false;
+  const StreamPlan pl = stream_plan(1, Ntot, K, mn_num_cus(), 0);
+  return pl.nw == 8 && pl.nw * 64 * 4 == K && (int64_t)M * (pl.ks / 4) <= (int64_t)pl.nw * 64 && pl.nw <= 16;
+}
+int stream_rmsnorm(const bf16_t* W, float* P, int M, int Ntot, int K, const float* h, const bf16_t* norm_w, float eps, void* stream) {
+  MN_CHECK_ARG(W && P && h && norm_w && stream_rmsnorm_ok(M, Ntot, K), "stream_rmsnorm: shape cannot run fused");
+  const StreamPlan pl = stream_plan(1, Ntot, K, mn_num_cus(), 0);
+  static bool opted = false;
+  if (!opted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mfma_lds_kernel<1, 1, 512, 0, FUSE_RMSNORM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP);
+    opted = true;
+  }
+  StreamFuse f{};
+  f.h = h; f.norm_w = norm_w; f.eps = eps;
+  hipLaunchKernelGGL((stream_mfma_lds_kernel<1, 1, 512, 0, FUSE_RMSNORM>), dim3(pl.gx, pl.nz, 1), dim3(pl.nw * 64), pl.lds, mn_stream(stream), (const bf16_t*)nullptr,
+                     (int64_t)0, (const void*)W, (const float*)nullptr, P, (int64_t)M * Ntot, M, Ntot, K, pl.ks, f, 0);
+  MN_CHECK_LAUNCH("stream_rmsnorm");
+  return pl.nz;
 }
 
 int stream_fused(int wfmt, const void* W, const float* wscale, float* P, int M, int Ntot, int K, const StreamFuse& f, void* stream) {
