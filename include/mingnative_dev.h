@@ -31,6 +31,7 @@ MN_DEV_API void mn_stream_kloop_tune(int nz, int depth, int nt);        /* strea
 MN_DEV_API void mn_stream_kloop_tune_small(int div);
 MN_DEV_API void mn_moe_router_tune(int max_rows);                       /* one-launch router up to this many rows */
 MN_DEV_API void mn_moe_tune_gate_up(int on, int max_rows);               /* engine.hip: router + expert gate/up of <= max_rows-row steps as one launch (moe_gate_up.hip) */
+MN_DEV_API void mn_moe_tune_min_rows(int rows);                         /* first row count of a decode step on the grouped expert route (bf16 / e4m3) */
 MN_DEV_API void mn_llm_tune_chain(int max_rows);                        /* fused decoder chain up to this many rows */
 MN_DEV_API void mn_gemm_tune(int glds);                                 /* batch_ops.hip: global_load_lds staging */
 MN_DEV_API void mn_gemm_route256(int on);                               /* mn_gemm_bf16 -> gemm256 for large problems */

@@ -997,15 +997,28 @@ static size_t moe_carve(Carver& cv, int rows, int H, int I, int G, int n_slot, M
   return cv.off - before;
 }
 
-// grouped-expert route from 3 rows (3 rows: 74.2 vs 70.6 tokens/s against the fp32-FMA pair kernels; 2 rows: 75.1 vs 76.8)
+// grouped-expert route from 5 rows (bf16) / 6 rows (e4m3).  (Rounds 3-5 switched at 3 rows — 74.2 vs 70.6 tokens/s against the fp32-FMA pair
+// kernels then.  Since then the pair route got the one-launch router, the wave-segmented down projection, the RMSNorm prologue of the QKV
+// launch and — round 6 — a launch plan that keeps the 24 / 32 / 40 pairs' workgroups in ONE round over the CUs (skinny_gemm.hip: the cap was
+// rounded up, 264 workgroups for 24 pairs).  Decoder step, 28 layers, grouped vs pairs: bf16 3 rows 3.05 vs 2.73 ms, 4 rows 3.42 vs 3.19,
+// 5 rows 3.64 vs 3.96; e4m3 3 rows 2.58 vs 1.92, 4 rows 2.79 vs 2.13, 5 rows 3.00 vs 2.58, 6 rows 3.17 vs 4.19 — tools/exp/moe_min_rows_ab.py,
+// profiles/r06_moe_min_rows_ab.txt.)
 static int g_moe_down = 1;            // the 1- / 2-row down projection on moe_down.hip (dev-library A/B switch: mn_moe_tune_down)
 #ifdef MN_DEV_HOOKS
 extern "C" MN_DEV_API void mn_moe_tune_down(int on) { g_moe_down = on; }
 #endif
-constexpr int MOE_MFMA_MIN_ROWS = 3;
+static int g_moe_min_rows_bf16 = 5, g_moe_min_rows_fp8 = 6;
+#ifdef MN_DEV_HOOKS
+extern "C" MN_DEV_API void mn_moe_tune_min_rows(int rows) {   // A/B hook: 0 = the shipped thresholds
+  g_moe_min_rows_bf16 = rows > 0 ? rows : 5;
+  g_moe_min_rows_fp8 = rows > 0 ? rows : 6;
+}
+#endif
 // NF4 / int8 experts run the grouped streaming launch from ONE row on: their products are rounded to bf16 per element (bitsandbytes' /
 // quanto's de-quantisation), which the fp32-FMA pair kernels of 1- / 2-row steps do not do
-static inline int moe_mfma_min_rows(const mn_llm* m) { return (m->wfmt == MN_W_NF4 || m->wfmt == MN_W_INT8) ? 1 : MOE_MFMA_MIN_ROWS; }
+static inline int moe_mfma_min_rows(const mn_llm* m) {
+  return (m->wfmt == MN_W_NF4 || m->wfmt == MN_W_INT8) ? 1 : (m->wfmt == MN_W_FP8_E4M3 ? g_moe_min_rows_fp8 : g_moe_min_rows_bf16);
+}
 static bool moe_mfma_ok(const mn_llm* m, int rows) {
   return rows >= moe_mfma_min_rows(m) && rows * (m->top_k + m->n_shared_slots) <= 1024 &&
          m->n_experts + m->n_shared_slots <= 256 && (m->hidden % 8) == 0 && (m->moe_inter % 8) == 0;   // % 4: vector glue

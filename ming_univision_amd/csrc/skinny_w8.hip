@@ -239,7 +239,7 @@ extern "C" int mn_skinny_w8_row(const mn_skinny_args* args, void* stream) {
   else if (a.N >= 16 * resident) R = 2;
   const int ngroups = (a.N + R - 1) / R;
   int64_t gx = mn_cdiv(ngroups, wpb);
-  const int64_t cap = mn_cdiv((int64_t)cus * bpc, ka.batch);
+  const int64_t cap = ((int64_t)cus * bpc) / ka.batch;       // one round over the CUs, rounded DOWN (skinny_gemm.hip)
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   const dim3 grid((unsigned)gx, (unsigned)ka.batch);
