@@ -997,20 +997,23 @@ static size_t moe_carve(Carver& cv, int rows, int H, int I, int G, int n_slot, M
   return cv.off - before;
 }
 
-// grouped-expert route from 5 rows (bf16) / 6 rows (e4m3).  (Rounds 3-5 switched at 3 rows — 74.2 vs 70.6 tokens/s against the fp32-FMA pair
-// kernels then.  Since then the pair route got the one-launch router, the wave-segmented down projection, the RMSNorm prologue of the QKV
-// launch and — round 6 — a launch plan that keeps the 24 / 32 / 40 pairs' workgroups in ONE round over the CUs (skinny_gemm.hip: the cap was
-// rounded up, 264 workgroups for 24 pairs).  Decoder step, 28 layers, grouped vs pairs: bf16 3 rows 3.05 vs 2.73 ms, 4 rows 3.42 vs 3.19,
-// 5 rows 3.64 vs 3.96; e4m3 3 rows 2.58 vs 1.92, 4 rows 2.79 vs 2.13, 5 rows 3.00 vs 2.58, 6 rows 3.17 vs 4.19 — tools/exp/moe_min_rows_ab.py,
-// profiles/r06_moe_min_rows_ab.txt.)
+// grouped-expert route from 3 rows (bf16) / 6 rows (e4m3).  Round 6 re-measured the switch after the pair route got the one-launch router, the
+// wave-segmented down projection, the RMSNorm prologue of the QKV launch and a launch plan that keeps the 24 / 32 / 40 pairs' workgroups in
+// ONE round over the CUs (skinny_gemm.hip: the cap was rounded up — 264 workgroups for 24 pairs).  On RANDOM rows the pairs win up to 4
+// (bf16) / 5 (e4m3) rows — decoder step, 28 layers, grouped vs pairs: bf16 3 rows 3.05 vs 2.73 ms, 4 rows 3.42 vs 3.19, 5 rows 3.64 vs 3.96;
+// e4m3 3 rows 2.58 vs 1.92, 4 rows 2.79 vs 2.13, 5 rows 3.00 vs 2.58, 6 rows 3.17 vs 4.19 (profiles/r06_moe_min_rows_ab.txt).  But the CFG
+// rows of ONE image select overlapping experts (10.0 distinct routed experts of 18 pairs per layer at 3 rows, 9.3 of 12 at 2:
+// tools/exp/cfg_row_expert_overlap.py), which the grouped route reads once: in REAL generation (tools/exp/edit_shape_ab.py,
+// profiles/r06_edit_shape_ab.txt) bf16 keeps the grouped route at 3 rows (98.3 vs 97.3 tokens/s; 4 rows: a tie), e4m3 takes the pairs
+// (3 rows 110.8 -> 113.0 and more, 2 images x 2 rows 196.8 -> 205.5).
 static int g_moe_down = 1;            // the 1- / 2-row down projection on moe_down.hip (dev-library A/B switch: mn_moe_tune_down)
 #ifdef MN_DEV_HOOKS
 extern "C" MN_DEV_API void mn_moe_tune_down(int on) { g_moe_down = on; }
 #endif
-static int g_moe_min_rows_bf16 = 5, g_moe_min_rows_fp8 = 6;
+static int g_moe_min_rows_bf16 = 3, g_moe_min_rows_fp8 = 6;
 #ifdef MN_DEV_HOOKS
 extern "C" MN_DEV_API void mn_moe_tune_min_rows(int rows) {   // A/B hook: 0 = the shipped thresholds
-  g_moe_min_rows_bf16 = rows > 0 ? rows : 5;
+  g_moe_min_rows_bf16 = rows > 0 ? rows : 3;
   g_moe_min_rows_fp8 = rows > 0 ? rows : 6;
 }
 #endif
