@@ -12,6 +12,7 @@ L = lib()
 L.mn_moe_tune_min_rows.argtypes = [ctypes.c_int]; L.mn_moe_tune_min_rows.restype = None
 dev = torch.device("cuda", 0)
 weights = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+ARMS = tuple(int(a) for a in sys.argv[2].split(",")) if len(sys.argv) > 2 else (3, 64)      # first row count on the grouped route, per arm
 args = argparse.Namespace(tiny=False, tokens=256, layers=None, prompt_len=40, images=2, cfg_rows=3, weights=weights)
 L.mn_moe_tune_min_rows(3)
 cfg, dec, rf, tok = bench.build_models(args, dev, 0)
@@ -21,11 +22,11 @@ noises = torch.randn(2, 257, 32, device=dev, generator=g)
 for images, rows in ((1, 3), (2, 2), (1, 2)):
     res = {}
     for rnd in range(3):
-        for arm in (3, 64):
+        for arm in ARMS:
             L.mn_moe_tune_min_rows(arm)
             bench.one_image(cfg, dec, rf, tok, prompt[:images], noises[:images], 1, rows); torch.cuda.synchronize()
             t0 = time.perf_counter()
             bench.one_image(cfg, dec, rf, tok, prompt[:images], noises[:images], 1, rows); torch.cuda.synchronize()
             res.setdefault(arm, []).append(256 * images / (time.perf_counter() - t0))
-    print(f"{weights} {images} image(s) x {rows} CFG rows = {images * rows} rows per step: grouped route from 3 rows {max(res[3]):.2f} tok/s ({', '.join('%.2f' % t for t in res[3])});  pair launches {max(res[64]):.2f} tok/s ({', '.join('%.2f' % t for t in res[64])})", flush=True)
+    print(f"{weights} {images} image(s) x {rows} CFG rows = {images * rows} rows per step: grouped route from {ARMS[0]} rows {max(res[ARMS[0]]):.2f} tok/s ({', '.join('%.2f' % t for t in res[ARMS[0]])});  grouped route from {ARMS[1]} rows {max(res[ARMS[1]]):.2f} tok/s ({', '.join('%.2f' % t for t in res[ARMS[1]])})", flush=True)
 L.mn_moe_tune_min_rows(0)
