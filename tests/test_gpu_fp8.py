@@ -114,9 +114,10 @@ def test_skinny_gemm_fp8_route_with_fused_prologue_and_epilogue():
         assert rel_err(y, ref) < 2e-5, (M, rel_err(y, ref))
 
 
-@pytest.mark.parametrize("M", [1, 2])
+@pytest.mark.parametrize("M", [1, 2, 3, 5])
 def test_expert_pair_kernels_on_fp8_weights_against_float64(M):
-    """The one-row fp8 kernel (skinny_w8.hip) on the expert launches of a 1- / 2-row step at the 16B-A3B shapes: (row, expert) pairs
+    """The one-row fp8 kernel (skinny_w8.hip) on the expert launches of a 1- / 2-row step — and of the 3..5-row steps that take the pair
+    launches in e4m3 since round 6 (24 / 40 pairs: their workgroups are planned into one round over the CUs) — at the 16B-A3B shapes: (row, expert) pairs
     with the SwiGLU epilogue, then the down projection as 8 K-segments (6 routed + 2 shared) with per-segment row scales, router
     weights and the residual — against the float64 formula on the dequantised weights."""
     from ming_univision_amd import ops

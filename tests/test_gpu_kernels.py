@@ -89,6 +89,30 @@ def test_skinny_prologues_and_resid(ops):
     assert rel(r, res.double() + gate.double() * lin(xd)) < 1e-5
 
 
+@pytest.mark.parametrize("M", [2, 3, 4, 7])
+def test_expert_pair_launches_at_full_shapes(ops, M):
+    """(row, expert) pair launches of a few-row decode step at the 16B-A3B expert shapes, bf16 weights: 16 / 24 / 32 / 56 pairs x the launch
+    plan that keeps all pairs' workgroups in one round over the CUs (skinny_gemm.hip: 24 pairs used to get 11 x 24 = 264 workgroups)
+    — SwiGLU epilogue, down projection as K-segments with router weights and residual — against float64."""
+    g = torch.Generator().manual_seed(60 + M)
+    E, S, I, H, top = 64, 2, 1408, 2048, 6
+    gu = (torch.randn(E + S, 2 * I, H, generator=g) * H ** -0.5).to(torch.bfloat16)
+    dn = (torch.randn(E + S, H, I, generator=g) * I ** -0.5).to(torch.bfloat16)
+    xn = torch.randn(M, H, generator=g)
+    res = torch.randn(M, H, generator=g)
+    idx = torch.stack([torch.cat((torch.randperm(E, generator=g)[:top], torch.tensor([E, E + 1]))) for _ in range(M)]).to(torch.int32)
+    w = torch.cat((torch.rand(M, top, generator=g), torch.ones(M, S)), 1)
+    out = ops.moe_experts(xn.cuda(), idx.cuda(), w.cuda(), gu.cuda(), dn.cuda(), res.cuda())
+    ref = res.double().clone()
+    for m in range(M):
+        for s_ in range(top + S):
+            e = int(idx[m, s_])
+            r = gu[e].double() @ xn[m].double()
+            hmid = F.silu(r[:I]) * r[I:]
+            ref[m] += float(w[m, s_]) * (dn[e].double() @ hmid.float().double())      # the kernel stores the SwiGLU output as fp32
+    assert rel(out, ref) < 1e-5, rel(out, ref)
+
+
 def test_router_and_experts(ops):
     M, H, E, k, I, S = 5, 256, 8, 3, 64, 2
     x = rnd(M, H, seed=20)
