@@ -321,9 +321,10 @@ extern "C" int mn_llm_step_tp(const mn_llm* m, const mn_llm_tp* tp, mn_tp_comm* 
   MN_CHECK_ARG(m && tp && comm && x && row_seq && row_slot && row_pos && row_len && kv_cache && hidden_out && workspace,
                "mn_llm_step_tp: null pointer");
   MN_CHECK_ARG(llm_tp_ok(m, tp, comm, M) && x_row_div >= 1, "mn_llm_step_tp: unsupported shard / communicator for M=%d rows", M);
-  MN_CHECK_ARG(m->wfmt == MN_W_BF16 || (mn_w8(m->wfmt) && M <= 64 && m->w_gate_up_scale && m->w_down_scale && (m->hidden % 16) == 0 &&
-                                        (m->moe_inter % 16) == 0 && (tp->shared_inter == 0 || (tp->ws_gate_up_scale && tp->ws_down_scale))),
-               "mn_llm_step_tp: fp8 experts need row scales, widths %% 16 == 0 and <= 64 rows (M = %d)", M);
+  MN_CHECK_ARG(m->wfmt == MN_W_BF16 || (mn_w8(m->wfmt) && M <= 64 && m->w_gate_up_scale && m->w_down_scale && (m->hidden % mn_wq_kmult(m->wfmt)) == 0 &&
+                                        (m->moe_inter % mn_wq_kmult(m->wfmt)) == 0 && (tp->shared_inter % mn_wq_kmult(m->wfmt)) == 0 &&
+                                        (tp->shared_inter == 0 || (tp->ws_gate_up_scale && tp->ws_down_scale))),
+               "mn_llm_step_tp: quantised experts need scale tables, widths %% 16 == 0 (NF4: %% 64) and <= 64 rows (M = %d)", M);
   // above two_shot_rows rows every all-reduce is two-shot: one more segment (the owners' reduce + all-gather) and one more epoch each
   const int gc = tp_two_shot_cols(comm, M, m->hidden), ars = gc ? 2 : 1;
   const int n_seg = 2 * ars * m->n_layers + 1;

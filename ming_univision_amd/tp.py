@@ -106,6 +106,49 @@ def shard_experts(w_gate_up, w_down, cfg, rank, world):
     return gu, dn, ws_gu, ws_dn
 
 
+def nf4_shared_units(cfg, rank, world):
+    """int4 (NF4) shards: this rank's units [u0, u0 + n) of the shared expert's S * I intermediate units.  NF4 quantises 64 consecutive
+    k of a row with one absmax, and the down projection is sliced along k: the 64-unit blocks are dealt out whole — the first ranks
+    take one more (16B-A3B, TP = 8: 44 blocks -> 6, 6, 6, 6, 5, 5, 5, 5) — so a shard holds the unsharded model's codes and absmax
+    values themselves (no re-quantisation: the sharded model IS the int4 model)."""
+    S, I = cfg.num_shared_experts or 0, cfg.moe_intermediate_size
+    assert (S * I) % 64 == 0 and I % 64 == 0
+    base, extra = divmod(S * I // 64, world)
+    b0 = rank * base + min(rank, extra)
+    return b0 * 64, (base + (1 if rank < extra else 0)) * 64
+
+
+def shard_experts_nf4(w_gate_up, w_down, gu_absmax, dn_absmax, cfg, rank, world):
+    """shard_experts + shard_expert_scales for NF4 experts: codes uint8 [E + S, 2I, H / 2] / [E + S, H, I / 2] (two per byte), absmax fp32
+    [E + S, 2I, H / 64] / [E + S, H, I / 64] -> the rank's routed experts and its block-aligned slice of the shared expert, padded to
+    `shared_pad` units with zero absmax (codes x 0 = 0).  Returns (gu, dn, ws_gu, ws_dn, gu_s, dn_s, ws_gu_s, ws_dn_s)."""
+    E, S, I = cfg.num_experts, cfg.num_shared_experts or 0, cfg.moe_intermediate_size
+    pl = shard_plan(cfg, world)
+    e0, ne = rank * pl["n_experts"], pl["n_experts"]
+    out = [w_gate_up[e0:e0 + ne].contiguous(), w_down[e0:e0 + ne].contiguous(), None, None,
+           gu_absmax[e0:e0 + ne].contiguous(), dn_absmax[e0:e0 + ne].contiguous(), None, None]
+    if not S:
+        return tuple(out)
+    u0, n = nf4_shared_units(cfg, rank, world)
+    pad = pl["shared_pad"]
+    assert n <= pad
+    dev = w_gate_up.device
+    for base, q, rows_per_unit in ((2, w_gate_up, None), (6, gu_absmax, None)):      # gate / up ROWS of the shared Linear: whole rows travel
+        sg = torch.cat([q[E + s, :I] for s in range(S)], 0)
+        su = torch.cat([q[E + s, I:] for s in range(S)], 0)
+        t = torch.zeros((2 * pad,) + tuple(sg.shape[1:]), dtype=q.dtype, device=dev)
+        t[:n], t[pad:pad + n] = sg[u0:u0 + n], su[u0:u0 + n]
+        out[base] = t
+    sd = torch.cat([w_down[E + s] for s in range(S)], 1)               # codes of the shared down_proj [H, S I / 2]
+    sa = torch.cat([dn_absmax[E + s] for s in range(S)], 1)            # its absmax [H, S I / 64]
+    ws_dn = torch.zeros(sd.shape[0], pad // 2, dtype=sd.dtype, device=dev)
+    ws_dn[:, :n // 2] = sd[:, u0 // 2:(u0 + n) // 2]
+    ws_da = torch.zeros(sa.shape[0], pad // 64, dtype=sa.dtype, device=dev)
+    ws_da[:, :n // 64] = sa[:, u0 // 64:(u0 + n) // 64]
+    out[3], out[7] = ws_dn, ws_da
+    return tuple(out)
+
+
 def shard_rf_block(w12, b12, w3, rank, world):
     """RF ResBlock MLP: w12 [2 hid, w] (gate rows, up rows) -> [2 hid / world, w]; b12 likewise; w3 [w, hid] -> [w, hid / world]."""
     hid = w12.shape[0] // 2
@@ -259,9 +302,8 @@ class TpDecoderShard:
         L = cfg.num_hidden_layers
         self.layers = getattr(self, "_shard_layers", None) or []
         self.weights = getattr(dec, "weights", "bf16")
-        if self.weights == "int4":
-            raise NotImplementedError("tensor parallel shards of an int4 (NF4) decoder: the shared expert's width is split into slices that "
-                                      "cut its 64-element absmax blocks; run int4 on one GPU (its point is the footprint) or shard bf16 / fp8 / int8")
+        if self.weights == "int4" and getattr(dec, "stream_fmt", "int4") != "int4":
+            raise NotImplementedError("tensor parallel shards of an int4 model whose widths are not multiples of 64 (its experts run as bf16 values)")
         for ly in (dec.layers or []):
             self.layers.append(self._shard_layer(ly, cfg, rank, world))
         hd = cfg.head_dim
@@ -302,6 +344,12 @@ class TpDecoderShard:
     def _shard_layer(ly, cfg, rank, world):
         """One layer of a full decoder (packed experts; bf16, or e4m3 bytes + row scales) -> this rank's tensors."""
         wqkv, wdense = shard_attention(ly["wqkv"], ly["wdense"], cfg, rank, world)
+        if ly["w_gate_up"].dtype == torch.uint8 and ly["w_gate_up_scale"].dim() == 3:      # NF4: codes + one absmax per 64 k
+            gu, dn, wsg, wsd, gs, ds, wsgs, wsds = shard_experts_nf4(ly["w_gate_up"], ly["w_down"], ly["w_gate_up_scale"], ly["w_down_scale"],
+                                                                    cfg, rank, world)
+            return dict(ln1=ly["ln1"], wqkv=wqkv, wdense=wdense, ln2=ly["ln2"], gate=ly["gate"], image_gate=ly.get("image_gate"),
+                        w_gate_up=gu, w_down=dn, ws_gate_up=wsg, ws_down=wsd, w_gate_up_scale=gs, w_down_scale=ds,
+                        ws_gate_up_scale=wsgs, ws_down_scale=wsds)
         gu, dn, wsg, wsd = shard_experts(ly["w_gate_up"], ly["w_down"], cfg, rank, world)
         out = dict(ln1=ly["ln1"], wqkv=wqkv, wdense=wdense, ln2=ly["ln2"], gate=ly["gate"], image_gate=ly.get("image_gate"),
                    w_gate_up=gu, w_down=dn, ws_gate_up=wsg, ws_down=wsd)
@@ -338,7 +386,6 @@ class TpDecoderShard:
                       gate=sd[p + ".mlp.gate.weight"], image_gate=sd.get(p + ".mlp.image_gate.weight") if cfg.multi_gate else None,
                       w_gate_up=gu, w_down=dn)
             if weights in _lib.W8:
-                assert weights != "int4", "int4 (NF4) shards are not built: see TpDecoderShard.__init__"
                 from .bailing_moe import quantize_layer_experts
                 quantize_layer_experts(ly, weights, cfg.num_shared_experts or 0)
             self._shard_layers.append(cls._shard_layer(ly, cfg, rank, world))
@@ -388,20 +435,28 @@ class TpRfShard:
         self.rf, self.rank, self.world = rf, rank, world
         assert rf.hidden % world == 0 and (rf.hidden // world) % 64 == 0, "RF SwiGLU width must split into multiples of 64"
         self.hidden = rf.hidden // world
+        self.weights = getattr(rf, "weights", "bf16")
+        nf4 = self.weights == "int4"
+        if nf4 and rf.lists["w12"][0].dtype != torch.uint8:
+            raise NotImplementedError("tensor parallel shards of an int4 RF head whose widths are not multiples of 64 (it runs as bf16 values)")
         w12, b12, w3 = [], [], []
         for b in range(rf.depth):
-            a, bb, c = shard_rf_block(rf.lists["w12"][b], rf.lists["b12"][b], rf.lists["w3"][b], rank, world)
+            if nf4:      # codes, two per byte: w12's rows travel whole; w3 is sliced along k in bytes (hidden / world is a multiple of 64: whole absmax blocks)
+                n, u0, hid = self.hidden, rank * self.hidden, rf.hidden
+                q12, bq = rf.lists["w12"][b], rf.lists["b12"][b]
+                a = torch.cat((q12[u0:u0 + n], q12[hid + u0:hid + u0 + n]), 0).contiguous()
+                bb = torch.cat((bq[u0:u0 + n], bq[hid + u0:hid + u0 + n]), 0).contiguous()
+                c = rf.lists["w3"][b][:, u0 // 2:(u0 + n) // 2].contiguous()
+            else:
+                a, bb, c = shard_rf_block(rf.lists["w12"][b], rf.lists["b12"][b], rf.lists["w3"][b], rank, world)
             w12.append(a); b12.append(bb); w3.append(c)
         self.lists = dict(rf.lists, w12=w12, b12=b12, w3=w3)
         self._arrays = {k: ptr_array(v) for k, v in self.lists.items()}
-        self.weights = getattr(rf, "weights", "bf16")
-        if self.weights == "int4":
-            raise NotImplementedError("tensor parallel shards of an int4 (NF4) RF head are not built (see TpDecoderShard)")
         if self.weights in _lib.W8:      # row scales: w12's rows are sliced like its weights, w3's columns share the full rows' scales
             hid, n = rf.hidden, rf.hidden // world
             u0 = rank * n
             self.scales = dict(w12=[torch.cat((sc[u0:u0 + n], sc[hid + u0:hid + u0 + n])).contiguous() for sc in rf.scales["w12"]],
-                               w3=rf.scales["w3"])
+                               w3=[sc[:, u0 // 64:(u0 + n) // 64].contiguous() for sc in rf.scales["w3"]] if nf4 else rf.scales["w3"])
             self._scale_arrays = {k: ptr_array(v) for k, v in self.scales.items()}
         s = RfHead()
         s.w, s.depth, s.hidden, s.z_dim, s.target, s.steps, s.llm_hidden = rf.w, rf.depth, self.hidden, rf.w, rf.target, rf.steps, rf.llm_hidden

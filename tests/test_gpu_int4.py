@@ -181,6 +181,22 @@ def test_int4_full_width_generate_image_vs_oracle_on_dequantised_weights(full, r
     assert max(errb) < TOL, errb
     full_b = sum(t.numel() * t.element_size() for ly in dec4.layers for k, t in ly.items() if torch.is_tensor(t) and k not in ("ln1", "ln2"))
     print("decoder-stack weight bytes per layer: int4 %.3f GB" % (full_b / 1e9 / cfg.num_hidden_layers))
+    # ---- TP = 8 + EP = 8 with NF4 shards, all on this GPU: the shared expert's 44 absmax blocks are dealt out whole (6, 6, 6, 6, 5, 5, 5, 5),
+    # so the shards hold the unsharded int4 model's own codes — the same oracle
+    from ming_univision_amd.bailing_moe import BailingMoeDecoder
+    from ming_univision_amd.tp import TpSimGroup, nf4_shared_units
+    assert [nf4_shared_units(cfg, r, 8)[1] for r in range(8)] == [384] * 4 + [320] * 4
+    assert sum(nf4_shared_units(cfg, r, 8)[1] for r in range(8)) == cfg.num_shared_experts * cfg.moe_intermediate_size
+    dec1 = BailingMoeDecoder.from_state_dict(cfg, dsd, t_max=32, n_seq=3, weights="int4")
+    grp = TpSimGroup(dec1, rf4, 8, rows_cap=16)
+    assert grp.shards[0].weights == "int4" and grp.rf_shards[0].weights == "int4" and grp.shards[0].struct.wfmt == 3
+    grp.prefill(dec1.embed(ids[0].cuda()), seq=0, past=0)
+    outt = generate_image(grp, grp.sampler(), tok, start, T, am, un, tu, noises.cuda(), decode_pixels=False)
+    grp.check_err()
+    errt = (rel_err(outt["latents"], ref4["latents"][:, 0]), rel_err(outt["sem"], ref4["sem"][0]), rel_err(outt["last_hidden"], ref4["last_hidden"][:, 0]))
+    print("int4 TP = 8 (simulated, %s) vs oracle: latents %.2e sem %.2e hidden %.2e; weight bytes per TP rank %.3f GB" % (
+        (rows_tag,) + errt + (grp.shards[0].weight_bytes() / 1e9,)))
+    assert max(errt) < TOL, errt
 
 
 def test_int4_text_steps_and_long_prompt(full):

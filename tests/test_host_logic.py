@@ -366,6 +366,39 @@ def test_tp_shard_plan_16b_a3b():
         shard_plan(cfg, 32)                                        # 16 q heads do not split 32 ways
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_tp_nf4_shards_are_pure_indexing(world):
+    """int4 (NF4) TP shards on CPU tensors: the shared expert's 64-unit absmax blocks are dealt out whole, so the ranks' slices —
+    codes (two per byte) and absmax values — tile the packed expert tensors exactly (nothing re-quantised, nothing lost), padding
+    carries zero absmax, and the routed experts are split by expert."""
+    from ming_univision_amd.tp import nf4_shared_units, shard_experts_nf4, shard_plan
+    cfg = C.BailingMoeConfig.ming_univision_16b_a3b()
+    E, S, I, H = 4 * world, cfg.num_shared_experts, cfg.moe_intermediate_size, 256          # (a narrow H: the split runs over units, not over H)
+    cfg.num_experts = E
+    g = torch.Generator().manual_seed(world)
+    gu = torch.randint(0, 256, (E + S, 2 * I, H // 2), generator=g, dtype=torch.uint8)
+    dn = torch.randint(0, 256, (E + S, H, I // 2), generator=g, dtype=torch.uint8)
+    gus = torch.rand(E + S, 2 * I, H // 64, generator=g) + 0.5
+    dns = torch.rand(E + S, H, I // 64, generator=g) + 0.5
+    pad = shard_plan(cfg, world)["shared_pad"]
+    units = [nf4_shared_units(cfg, r, world) for r in range(world)]
+    assert units[0][0] == 0 and all(units[r][0] + units[r][1] == units[r + 1][0] for r in range(world - 1))
+    assert units[-1][0] + units[-1][1] == S * I and all(n % 64 == 0 and u0 % 64 == 0 and n <= pad for u0, n in units)
+    if world == 8:
+        assert [n for _, n in units] == [384] * 4 + [320] * 4
+    sg_full = torch.cat([gu[E + s, :I] for s in range(S)], 0); su_full = torch.cat([gu[E + s, I:] for s in range(S)], 0)
+    sd_full = torch.cat([dn[E + s] for s in range(S)], 1); sa_full = torch.cat([dns[E + s] for s in range(S)], 1)
+    for r in range(world):
+        o = shard_experts_nf4(gu, dn, gus, dns, cfg, r, world)
+        u0, n = units[r]
+        ne = E // world
+        assert torch.equal(o[0], gu[r * ne:(r + 1) * ne]) and torch.equal(o[5], dns[r * ne:(r + 1) * ne])
+        assert o[2].shape == (2 * pad, H // 2) and o[6].shape == (2 * pad, H // 64) and o[3].shape == (H, pad // 2) and o[7].shape == (H, pad // 64)
+        assert torch.equal(o[2][:n], sg_full[u0:u0 + n]) and torch.equal(o[2][pad:pad + n], su_full[u0:u0 + n])
+        assert torch.equal(o[3][:, :n // 2], sd_full[:, u0 // 2:(u0 + n) // 2]) and torch.equal(o[7][:, :n // 64], sa_full[:, u0 // 64:(u0 + n) // 64])
+        assert float(o[6][n:pad].abs().sum()) == 0 and float(o[6][pad + n:].abs().sum()) == 0 and float(o[7][:, n // 64:].abs().sum()) == 0
+
+
 def test_tp_vocab_parallel_pick_rule():
     """The reduce of the ranks' (logit, id) pairs of a vocabulary-split lm_head: largest logit, lowest id among equals."""
     from ming_univision_amd.tp import pick_best
