@@ -450,6 +450,30 @@ def test_batched_generation_matches_single_image(B, groups, R):
     print("batch %d x %d rows: image 0 vs reference %.2e (bar %.0e); vs batch-1 runs: latents median %.1e max %.1e" % (
         B, R, e_ref, TOL, sorted(e_lat)[B // 2], max(e_lat)))
     assert e_ref < TOL      # image 0 is the reference's case
+    # ... and EVERY checked image of the batch against the ORACLE run on its own prompt, masks and noise (not only against the batch-1
+    # HIP run): all images for B <= 10, six spread over the batch otherwise — each under the 1e-3 bar (measured: latents <= 2.5e-4,
+    # hidden states <= 7.3e-4).
+    from oracle import bailing_ref, mingtok_ref
+    ocfg = bailing_ref.LLMConfig(**{k: v for k, v in g["llm_config"].items() if k in bailing_ref.LLMConfig.__dataclass_fields__})
+    tsd = {k: v.float().cpu() for k, v in tok.sd.items()}
+    lsd_c = {k: v.float().cpu() for k, v in lsd.items()}
+    emb = sd["model.word_embeddings.weight"]
+    o_lat, o_hid = [], []
+    for i in (range(B) if B <= 10 else sorted({0, 1, B // 3, B // 2, 2 * B // 3, B - 1})):
+        n = prompts[i].numel()
+        am, un, tu = (g["mask"], g["uncond"], g[tag + "_tuncond"]) if i == 0 else masks(n)
+        kvs = bailing_ref.new_kv(ocfg)
+        bailing_ref.model_forward(emb[prompts[i][None]], sd, ocfg, torch.ones(1, n, dtype=torch.long), None, kvs)
+        caches = mingtok_ref.semdec_new_cache(tsd)
+        ref = bailing_ref.generate_image(
+            emb[torch.tensor([[cfg.image_start_token]])], kvs, am, un, tu, sd, ocfg, noises[i],
+            latent_to_sem=lambda lat: mingtok_ref.mingtok_feature_decoder_step(lat, tsd, caches),
+            linear_proj=lambda x: bailing_ref.linear_proj(x, lsd_c), sem_to_pix=lambda x: None, steps=int(g["rf_config"]["num_sampling_steps"]))
+        o_lat.append(rel_err(out["latents"][i], ref["latents"][:, 0]))
+        o_hid.append(rel_err(out["last_hidden"][i * R:(i + 1) * R], ref["last_hidden"][:, 0]))
+    print("batch %d x %d rows vs the ORACLE, %d images: latents median %.1e max %.1e, hidden median %.1e max %.1e" % (
+        B, R, len(o_lat), sorted(o_lat)[len(o_lat) // 2], max(o_lat), sorted(o_hid)[len(o_hid) // 2], max(o_hid)))
+    assert max(o_lat) < TOL and max(o_hid) < TOL, (o_lat, o_hid)
 
 
 def test_prefill_mfma_vs_chunked_fp32_and_reference(llm):
